@@ -1,0 +1,150 @@
+"""Seeded synthetic RGB-D inputs for tests and bench (SURVEY.md §8(d) "Synthetic inputs").
+
+A tiny analytic ray-caster: a room (floor + two walls) and a few axis-aligned boxes, textured with a
+procedural multi-scale checker so that FAST corners exist at every pyramid level and so that two views
+of the same scene are photo-consistent (ORB matches and GICP have a true answer).  Harness code only —
+nothing here is part of the hot path.
+"""
+import numpy as np
+
+
+def intrinsics(width, height):
+    """fx=fy=607 for VGA, 910 for 720p (script/run_orbslam/RGBD-Inertial/config/g1_op_icp_lidar_indoor1.yaml:25-34)."""
+    f = 607.0 * width / 640.0
+    return f, f, (width - 1) / 2.0, (height - 1) / 2.0
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def random_motion(rng, trans=0.03, rot_deg=1.5):
+    """SE(3) T_world_cam of the second view: t ~ U(-3,3) cm, r ~ U(-1.5,1.5) deg per axis."""
+    T = np.eye(4)
+    T[:3, :3] = _rot(*(np.deg2rad(rot_deg) * rng.uniform(-1, 1, 3)))
+    T[:3, 3] = trans * rng.uniform(-1, 1, 3)
+    return T
+
+
+class Scene:
+    def __init__(self, seed):
+        rng = np.random.default_rng(seed)
+        self.seed = int(seed)
+        # planes: (normal, offset) with n.p = d ; camera looks along +z, y down
+        self.planes = [
+            (np.array([0.0, 1.0, 0.0]), 1.3 + 0.3 * rng.random()),   # floor (y = +h below the camera)
+            (np.array([0.0, 0.0, 1.0]), 4.0 + 1.8 * rng.random()),   # front wall
+            (np.array([1.0, 0.0, 0.0]), -(2.0 + 1.0 * rng.random())),  # left wall x = -a
+        ]
+        self.boxes = []
+        for _ in range(5):
+            c = np.array([rng.uniform(-1.5, 2.0), rng.uniform(0.2, 1.0), rng.uniform(1.5, 3.8)])
+            h = np.array([rng.uniform(0.15, 0.5), rng.uniform(0.15, 0.5), rng.uniform(0.15, 0.4)])
+            self.boxes.append((c - h, c + h))
+        nsurf = 3 + 6 * 5
+        self.freq = rng.uniform(2.5, 9.0, (nsurf, 3, 2)).astype(np.float32)
+        self.phase = rng.uniform(0, 6.28, (nsurf, 3, 2)).astype(np.float32)
+        self.amp = rng.uniform(15, 45, (nsurf, 3)).astype(np.float32)
+        self.base = rng.uniform(70, 180, nsurf).astype(np.float32)
+
+    def render(self, width, height, T_wc=None, noise_seed=0, depth_noise=0.002, invalid_frac=0.02):
+        """-> gray u8 [H,W], depth f32 [H,W] (metres, 0 = invalid)."""
+        fx, fy, cx, cy = intrinsics(width, height)
+        T = np.eye(4) if T_wc is None else T_wc
+        R, t = T[:3, :3].astype(np.float32), T[:3, 3].astype(np.float32)
+        u, v = np.meshgrid(np.arange(width, dtype=np.float32), np.arange(height, dtype=np.float32))
+        dc = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1).reshape(-1, 3)
+        d = dc @ R.T
+        o = t
+        n = d.shape[0]
+        best = np.full(n, np.inf, np.float32)
+        sid = np.zeros(n, np.int32)
+        uv = np.zeros((n, 2), np.float32)
+
+        def consider(tt, mask, s, ucoord, vcoord):
+            nonlocal best, sid, uv
+            m = mask & (tt > 0.05) & (tt < best)
+            best = np.where(m, tt, best)
+            sid = np.where(m, s, sid)
+            uv[m, 0] = ucoord[m]
+            uv[m, 1] = vcoord[m]
+
+        s = 0
+        for nrm, off in self.planes:
+            denom = d @ nrm.astype(np.float32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tt = (off - o @ nrm.astype(np.float32)) / denom
+            p = o + d * tt[:, None]
+            ax = [i for i in range(3) if abs(nrm[i]) < 0.5]
+            consider(tt, np.isfinite(tt), s, p[:, ax[0]], p[:, ax[1]])
+            s += 1
+        for lo, hi in self.boxes:
+            lo = lo.astype(np.float32)
+            hi = hi.astype(np.float32)
+            for axis in range(3):
+                for side, val in ((0, lo[axis]), (1, hi[axis])):
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        tt = (val - o[axis]) / d[:, axis]
+                    p = o + d * tt[:, None]
+                    oth = [i for i in range(3) if i != axis]
+                    inside = (np.isfinite(tt) & (p[:, oth[0]] >= lo[oth[0]]) & (p[:, oth[0]] <= hi[oth[0]])
+                              & (p[:, oth[1]] >= lo[oth[1]]) & (p[:, oth[1]] <= hi[oth[1]]))
+                    consider(tt, inside, s, p[:, oth[0]], p[:, oth[1]])
+                    s += 1
+        hit = np.isfinite(best)
+        f, ph, am = self.freq[sid], self.phase[sid], self.amp[sid]
+        val = self.base[sid].copy()
+        for k in range(3):
+            val += am[:, k] * np.sign(np.sin(f[:, k, 0] * (2.0 ** k) * uv[:, 0] + ph[:, k, 0])
+                                      * np.sin(f[:, k, 1] * (2.0 ** k) * uv[:, 1] + ph[:, k, 1]))
+        rng = np.random.default_rng((self.seed * 7919 + noise_seed) & 0x7FFFFFFF)
+        val = np.where(hit, val, 20.0) + rng.integers(-2, 3, n)
+        gray = np.clip(np.rint(val), 0, 255).astype(np.uint8).reshape(height, width)
+        z = (best * dc[:, 2]).astype(np.float32)  # depth along the optical axis (dc.z == 1)
+        z = z + rng.normal(0, depth_noise, n).astype(np.float32)
+        z = np.where(hit & (z > 0.3) & (z < 9.5), z, 0).astype(np.float32)
+        z[rng.random(n) < invalid_frac] = 0
+        return gray, z.reshape(height, width)
+
+
+def depth_to_cloud(depth, stride, width=None, height=None):
+    """Frame::ConvertDepthToPointCloud (reference src/Frame.cc:590-623): pixels on a stride grid with
+    0 < d < 10 -> (x, y, z, 1) float32 in the camera frame. Returns [N,4] float32."""
+    h, w = depth.shape
+    fx, fy, cx, cy = intrinsics(w, h)
+    vs, us = np.meshgrid(np.arange(0, h, stride), np.arange(0, w, stride), indexing="ij")
+    d = depth[vs, us]
+    m = (d > 0) & (d < 10)
+    d = d[m].astype(np.float32)
+    x = ((us[m].astype(np.float32) - np.float32(cx)) * d / np.float32(fx)).astype(np.float32)
+    y = ((vs[m].astype(np.float32) - np.float32(cy)) * d / np.float32(fy)).astype(np.float32)
+    return np.stack([x, y, d, np.ones_like(d)], -1).astype(np.float32)
+
+
+def frame_pair(seed, width=640, height=480, stride=4):
+    """-> dict(gray0, depth0, gray1, depth1, cloud0, cloud1, T_01) where T_01 maps frame-1 points into
+    frame 0 (= T_target_source for GICP with target = previous frame, source = current frame,
+    reference src/Tracking.cc:3375-3382)."""
+    sc = Scene(seed)
+    rng = np.random.default_rng(seed + 0x6F5)
+    T1 = random_motion(rng)
+    g0, d0 = sc.render(width, height, None, 0)
+    g1, d1 = sc.render(width, height, T1, 1)
+    return dict(gray0=g0, depth0=d0, gray1=g1, depth1=d1, cloud0=depth_to_cloud(d0, stride),
+                cloud1=depth_to_cloud(d1, stride), T_01=T1)
+
+
+def noise_image(seed, width, height):
+    """Unstructured test image: smooth background + rectangles + noise (lots of corners)."""
+    rng = np.random.default_rng(seed)
+    img = rng.uniform(60, 190) + 25 * np.sin(np.linspace(0, 6, width))[None, :] * np.cos(np.linspace(0, 4, height))[:, None]
+    for _ in range(max(40, width * height // 800)):
+        x0, y0 = rng.integers(0, width), rng.integers(0, height)
+        w, h = rng.integers(4, 60), rng.integers(4, 60)
+        img[y0:y0 + h, x0:x0 + w] += rng.uniform(30, 120) * rng.choice([-1, 1])
+    img += rng.integers(-2, 3, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -1,0 +1,320 @@
+"""ctypes binding of the CPU oracle (oracle/libgfs_oracle.so).
+
+TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module (see oracle/gfs_oracle.h).  PARITY UNPINNED.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"),
+     ("class_id", "<i4")]
+)
+
+
+class GicpCfg(C.Structure):
+    _fields_ = [
+        ("num_threads", C.c_int32),
+        ("downsampling_resolution", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("rotation_eps", C.c_double),
+        ("translation_eps", C.c_double),
+        ("max_iterations", C.c_int32),
+        ("num_neighbors", C.c_int32),
+    ]
+
+
+class GicpResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 16),
+        ("converged", C.c_int32),
+        ("iterations", C.c_uint64),
+        ("num_inliers", C.c_uint64),
+        ("H", C.c_double * 36),
+        ("b", C.c_double * 6),
+        ("error", C.c_double),
+        ("n_target_ds", C.c_int32),
+        ("n_source_ds", C.c_int32),
+        ("n_linearize", C.c_int32),
+        ("n_error_evals", C.c_int32),
+    ]
+
+
+class LbaProblem(C.Structure):
+    _fields_ = [
+        ("n_poses", C.c_int32),
+        ("n_points", C.c_int32),
+        ("n_edges", C.c_int32),
+        ("pose_q", C.c_void_p),
+        ("pose_t", C.c_void_p),
+        ("pose_fixed", C.c_void_p),
+        ("points", C.c_void_p),
+        ("edge_pose", C.c_void_p),
+        ("edge_point", C.c_void_p),
+        ("edge_obs", C.c_void_p),
+        ("edge_inv_sigma2", C.c_void_p),
+        ("edge_stereo", C.c_void_p),
+        ("fx", C.c_double),
+        ("fy", C.c_double),
+        ("cx", C.c_double),
+        ("cy", C.c_double),
+        ("bf", C.c_double),
+        ("huber_mono", C.c_double),
+        ("huber_stereo", C.c_double),
+        ("iterations", C.c_int32),
+    ]
+
+
+class LbaSolution(C.Structure):
+    _fields_ = [
+        ("pose_q", C.c_void_p),
+        ("pose_t", C.c_void_p),
+        ("points", C.c_void_p),
+        ("edge_chi2", C.c_void_p),
+        ("edge_depth_positive", C.c_void_p),
+        ("iterations_run", C.c_int32),
+        ("final_chi2", C.c_double),
+        ("final_lambda", C.c_double),
+    ]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE, "libgfs_oracle.so"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libgfs_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.gfso_orb_create.restype = C.c_void_p
+        L.gfso_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.gfso_orb_destroy.argtypes = [C.c_void_p]
+        L.gfso_orb_get_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.gfso_orb_extract.restype = C.c_int
+        L.gfso_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.gfso_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.gfso_orb_get_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gfso_orb_get_blurred.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gfso_orb_num_candidates.argtypes = [C.c_void_p, C.c_int]
+        L.gfso_orb_get_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gfso_orb_num_level_keypoints.argtypes = [C.c_void_p, C.c_int]
+        L.gfso_orb_get_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gfso_resize_area_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.gfso_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int]
+        L.gfso_fast_atan2.restype = C.c_float
+        L.gfso_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.gfso_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.gfso_distribute_octree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.gfso_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfso_bf_match_hamming.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(L, "gfso_gicp_align"):
+            L.gfso_gicp_default_cfg.argtypes = [C.POINTER(GicpCfg)]
+            L.gfso_gicp_align.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(GicpCfg),
+                                          C.POINTER(GicpResult)]
+            L.gfso_gicp_preprocess.restype = C.c_int
+            L.gfso_gicp_preprocess.argtypes = [C.c_void_p, C.c_int, C.POINTER(GicpCfg), C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+            L.gfso_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            L.gfso_eig3_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.gfso_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "gfso_lba_solve"):
+            L.gfso_lba_solve.restype = C.c_int
+            L.gfso_lba_solve.argtypes = [C.POINTER(LbaProblem), C.POINTER(LbaSolution)]
+            L.gfso_lba_linearize.restype = C.c_double
+            L.gfso_lba_linearize.argtypes = [C.POINTER(LbaProblem)] + [C.c_void_p] * 6
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbOracle:
+    """Mirror of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:46-118)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.h = self.L.gfso_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.gfso_orb_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        feats = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.gfso_orb_get_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(feats), _p(umax))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, feats=feats, umax=umax)
+
+    def extract(self, img, lapping=(0, 0), cap=None):
+        """-> (mono_index, keypoints[KP_DTYPE], descriptors[N,32] u8)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        rows, cols = img.shape
+        n = C.c_int(0)
+        r = self.L.gfso_orb_extract(self.h, _p(img), rows, cols, cols, lapping[0], lapping[1], None, None, 0,
+                                    C.byref(n))
+        if r < 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        N = n.value
+        kps = np.zeros(N, KP_DTYPE)
+        desc = np.zeros((N, 32), np.uint8)
+        r = self.L.gfso_orb_extract(self.h, _p(img), rows, cols, cols, lapping[0], lapping[1], _p(kps), _p(desc), N,
+                                    C.byref(n))
+        return r, kps, desc
+
+    def level_size(self, l):
+        r, c = C.c_int(), C.c_int()
+        self.L.gfso_orb_level_size(self.h, l, C.byref(r), C.byref(c))
+        return r.value, c.value
+
+    def level(self, l):
+        r, c = self.level_size(l)
+        a = np.zeros((r, c), np.uint8)
+        self.L.gfso_orb_get_level(self.h, l, _p(a))
+        return a
+
+    def blurred(self, l):
+        r, c = self.level_size(l)
+        a = np.zeros((r, c), np.uint8)
+        self.L.gfso_orb_get_blurred(self.h, l, _p(a))
+        return a
+
+    def candidates(self, l):
+        n = self.L.gfso_orb_num_candidates(self.h, l)
+        x, y, s = (np.zeros(n, np.int32) for _ in range(3))
+        if n:
+            self.L.gfso_orb_get_candidates(self.h, l, _p(x), _p(y), _p(s))
+        return x, y, s
+
+    def level_keypoints(self, l):
+        n = self.L.gfso_orb_num_level_keypoints(self.h, l)
+        k = np.zeros(n, KP_DTYPE)
+        if n:
+            self.L.gfso_orb_get_level_keypoints(self.h, l, _p(k))
+        return k
+
+
+def resize_area(src, drows, dcols):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((drows, dcols), np.uint8)
+    lib().gfso_resize_area_u8(_p(src), src.shape[0], src.shape[1], src.shape[1], _p(dst), drows, dcols, dcols)
+    return dst
+
+
+def fast9_16(img, threshold, nonmax=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    x, y, s = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().gfso_fast9_16(_p(img), img.shape[0], img.shape[1], img.shape[1], threshold, int(nonmax), _p(x), _p(y),
+                            _p(s), cap)
+    return x[:n], y[:n], s[:n]
+
+
+def fast_atan2(y, x):
+    return float(lib().gfso_fast_atan2(float(y), float(x)))
+
+
+def gaussian_blur7(img, variant=0):
+    img = np.ascontiguousarray(img, np.uint8)
+    dst = np.zeros_like(img)
+    lib().gfso_gaussian_blur7(_p(img), img.shape[0], img.shape[1], img.shape[1], _p(dst), img.shape[1], variant)
+    return dst
+
+
+def distribute_octree(x, y, resp, min_x, max_x, min_y, max_y, n_features):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    resp = np.ascontiguousarray(resp, np.float32)
+    out = np.zeros(max(len(x), 1), np.int32)
+    n = lib().gfso_distribute_octree(_p(x), _p(y), _p(resp), len(x), min_x, max_x, min_y, max_y, n_features, _p(out),
+                                     len(out))
+    return out[:n]
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().gfso_descriptor_distance(_p(a), _p(b)))
+
+
+def bf_match(q, t, nthreads=1):
+    """-> (train_idx[nq], dist[nq]) or empty arrays when the train set is empty."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    ti = np.zeros(len(q), np.int32)
+    di = np.zeros(len(q), np.int32)
+    n = lib().gfso_bf_match_hamming(_p(q), len(q), _p(t), len(t), _p(ti), _p(di), nthreads)
+    return ti[:n], di[:n]
+
+
+def gicp_default_cfg():
+    c = GicpCfg()
+    lib().gfso_gicp_default_cfg(C.byref(c))
+    return c
+
+
+def gicp_align(target, source, init_T=None, cfg=None):
+    target = np.ascontiguousarray(target, np.float32).reshape(-1, 4)
+    source = np.ascontiguousarray(source, np.float32).reshape(-1, 4)
+    T0 = np.eye(4) if init_T is None else np.asarray(init_T, np.float64)
+    T0c = np.ascontiguousarray(T0.T.reshape(-1))  # column-major
+    cfg = cfg or gicp_default_cfg()
+    res = GicpResult()
+    lib().gfso_gicp_align(_p(target), len(target), _p(source), len(source), _p(T0c), C.byref(cfg), C.byref(res))
+    return dict(
+        T=np.array(res.T).reshape(4, 4).T.copy(), converged=bool(res.converged), iterations=int(res.iterations),
+        num_inliers=int(res.num_inliers), H=np.array(res.H).reshape(6, 6).T.copy(), b=np.array(res.b),
+        error=float(res.error), n_target_ds=res.n_target_ds, n_source_ds=res.n_source_ds,
+        n_linearize=res.n_linearize, n_error_evals=res.n_error_evals)
+
+
+def gicp_preprocess(points, cfg=None):
+    points = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
+    cfg = cfg or gicp_default_cfg()
+    n = len(points)
+    pts = np.zeros((n, 4))
+    covs = np.zeros((n, 16))
+    nrm = np.zeros((n, 4))
+    m = lib().gfso_gicp_preprocess(_p(points), n, C.byref(cfg), _p(pts), _p(covs), _p(nrm))
+    return pts[:m], covs[:m].reshape(m, 4, 4).transpose(0, 2, 1).copy(), nrm[:m]
+
+
+def knn(points, queries, k):
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 4)
+    queries = np.ascontiguousarray(queries, np.float64).reshape(-1, 4)
+    idx = np.zeros((len(queries), k), np.int64)
+    sqd = np.zeros((len(queries), k))
+    lib().gfso_knn(_p(points), len(points), _p(queries), len(queries), k, _p(idx), _p(sqd))
+    return idx, sqd
+
+
+def eig3_direct(m):
+    m = np.ascontiguousarray(np.asarray(m, np.float64).T)
+    ev = np.zeros(3)
+    evec = np.zeros((3, 3))
+    lib().gfso_eig3_direct(_p(m), _p(ev), _p(evec))
+    return ev, evec.T.copy()
+
+
+def se3_exp(twist):
+    tw = np.ascontiguousarray(twist, np.float64)
+    T = np.zeros(16)
+    lib().gfso_se3_exp(_p(tw), _p(T))
+    return T.reshape(4, 4).T.copy()
