@@ -1,0 +1,405 @@
+"""Python mirror of the reference's four C++ seams on top of the C ABI (include/gfs_abi.h, libgfs_hip.so).
+
+The product is the shared library; this module is the thin host-side binding used by tests and bench.py.
+It mirrors the reference interfaces by name and argument meaning:
+    ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)(image, lapping) -> (monoIndex, keypoints, descriptors)
+        reference include/ORBextractor.h:53-64
+    ORBmatcher.DescriptorDistance(a, b) / ORBmatcher.match(d1, d2)     reference include/ORBmatcher.h:41, src/ORBmatcher.cc:755-756
+    RegistrationGICP.RegisterPointClouds(target, source, init_T)       reference include/RegistrationGICP.h:25-28
+    Optimizer.LocalBundleAdjustment(problem)                           reference include/Optimizer.h:62-65
+There is no CPU fallback here: if the library is missing, or no gfx950 device is present, calls raise GfsError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgfs_hip.so")
+_lib = None
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"),
+     ("class_id", "<i4")]
+)
+
+
+class GfsError(RuntimeError):
+    pass
+
+
+class OrbConfig(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_rows", C.c_int32),
+                ("max_cols", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32),
+                ("blur_taps_variant", C.c_int32)]
+
+
+class GicpConfig(C.Structure):
+    _fields_ = [("num_threads", C.c_int32), ("downsampling_resolution", C.c_double),
+                ("max_correspondence_distance", C.c_double), ("rotation_eps", C.c_double),
+                ("translation_eps", C.c_double), ("max_iterations", C.c_int32), ("num_neighbors", C.c_int32)]
+
+
+class GicpResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("converged", C.c_int32), ("iterations", C.c_uint64),
+                ("num_inliers", C.c_uint64), ("H", C.c_double * 36), ("b", C.c_double * 6), ("error", C.c_double),
+                ("n_target_ds", C.c_int32), ("n_source_ds", C.c_int32), ("n_linearize", C.c_int32),
+                ("n_error_evals", C.c_int32)]
+
+
+class LbaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("pose_q", C.c_void_p),
+                ("pose_t", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p), ("edge_pose", C.c_void_p),
+                ("edge_point", C.c_void_p), ("edge_obs", C.c_void_p), ("edge_inv_sigma2", C.c_void_p),
+                ("edge_stereo", C.c_void_p), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("bf", C.c_double), ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
+                ("iterations", C.c_int32)]
+
+
+class LbaSolution(C.Structure):
+    _fields_ = [("pose_q", C.c_void_p), ("pose_t", C.c_void_p), ("points", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("edge_depth_positive", C.c_void_p), ("iterations_run", C.c_int32), ("final_chi2", C.c_double),
+                ("final_lambda", C.c_double)]
+
+
+# every symbol include/gfs_abi.h declares (tests/test_abi.py checks the built library exports all of them)
+ABI_SYMBOLS = [
+    "gfs_abi_version", "gfs_last_error", "gfs_device_count",
+    "gfs_orb_default_config", "gfs_orb_create", "gfs_orb_destroy", "gfs_orb_get_tables", "gfs_orb_max_keypoints",
+    "gfs_orb_extract", "gfs_orb_extract_batch", "gfs_orb_extract_batch_device", "gfs_orb_device_results",
+    "gfs_orb_fetch", "gfs_orb_level_size", "gfs_orb_fetch_level", "gfs_orb_fetch_candidates", "gfs_orb_octree_host",
+    "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
+    "gfs_bf_match_hamming_batch_device",
+    "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
+    "gfs_gicp_fetch_preprocessed",
+    "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize",
+    "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
+    "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
+]
+
+
+def lib():
+    """Load libgfs_hip.so (built in-tree by __graft_entry__.build()). Raises GfsError if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise GfsError(f"{_LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(_LIB_PATH)
+        L.gfs_last_error.restype = C.c_char_p
+        vp, ip, i = C.c_void_p, C.POINTER(C.c_int), C.c_int
+        L.gfs_orb_default_config.argtypes = [C.POINTER(OrbConfig)]
+        L.gfs_orb_create.argtypes = [C.POINTER(OrbConfig), C.POINTER(vp)]
+        L.gfs_orb_destroy.argtypes = [vp]
+        L.gfs_orb_get_tables.argtypes = [vp] * 7
+        L.gfs_orb_max_keypoints.argtypes = [vp]
+        L.gfs_orb_extract.argtypes = [vp, vp, i, i, i, i, i, vp, vp, i, ip]
+        L.gfs_orb_extract_batch.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, i, vp, vp]
+        L.gfs_orb_extract_batch_device.argtypes = [vp, vp, i, i, i, i, i, vp]
+        L.gfs_orb_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip]
+        L.gfs_orb_fetch.argtypes = [vp, i, vp, vp, i, ip, ip]
+        L.gfs_orb_level_size.argtypes = [vp, i, ip, ip]
+        L.gfs_orb_fetch_level.argtypes = [vp, i, i, i, vp]
+        L.gfs_orb_fetch_candidates.argtypes = [vp, i, i, vp, vp, vp, i]
+        L.gfs_orb_octree_host.argtypes = [vp, vp, vp, i, i, i, i, i, i, vp, i]
+        L.gfs_hamming256.argtypes = [vp, vp]
+        L.gfs_matcher_create.argtypes = [i, i, i, i, C.POINTER(vp)]
+        L.gfs_matcher_destroy.argtypes = [vp]
+        L.gfs_bf_match_hamming.argtypes = [vp, vp, i, vp, i, vp, vp]
+        L.gfs_bf_match_hamming_batch_device.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp]
+        if hasattr(L, "gfs_gicp_create"):
+            L.gfs_gicp_default_config.argtypes = [C.POINTER(GicpConfig)]
+            L.gfs_gicp_create.argtypes = [i, i, i, C.POINTER(vp)]
+            L.gfs_gicp_destroy.argtypes = [vp]
+            L.gfs_gicp_align.argtypes = [vp, vp, i, vp, i, vp, C.POINTER(GicpConfig), C.POINTER(GicpResult)]
+            L.gfs_gicp_align_batch_device.argtypes = [vp, vp, vp, vp, vp, i, i, vp, C.POINTER(GicpConfig), vp, vp]
+            L.gfs_gicp_fetch_preprocessed.argtypes = [vp, i, i, vp, vp, i, ip]
+        if hasattr(L, "gfs_lba_create"):
+            L.gfs_lba_create.argtypes = [i, i, i, i, C.POINTER(vp)]
+            L.gfs_lba_destroy.argtypes = [vp]
+            L.gfs_lba_solve.argtypes = [vp, C.POINTER(LbaProblem), C.POINTER(LbaSolution), vp]
+            L.gfs_lba_linearize.argtypes = [vp, C.POINTER(LbaProblem), vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
+        L.gfs_timer_create.argtypes = [i, C.POINTER(vp)]
+        L.gfs_timer_destroy.argtypes = [vp]
+        L.gfs_timer_start.argtypes = [vp, vp]
+        L.gfs_timer_stop.argtypes = [vp, vp]
+        L.gfs_timer_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.gfs_profile_report.argtypes = [vp, vp, vp, i]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise GfsError(f"{what} failed ({rc}): {lib().gfs_last_error().decode()}")
+    return rc
+
+
+def device_count():
+    return lib().gfs_device_count()
+
+
+class ORBextractor:
+    """ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:46-118) backed by gfs_orb_*."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, max_rows=480,
+                 max_cols=640, max_batch=1, device=0, blur_taps_variant=0):
+        L = lib()
+        cfg = OrbConfig()
+        L.gfs_orb_default_config(C.byref(cfg))
+        cfg.nfeatures, cfg.scale_factor, cfg.nlevels = nfeatures, scaleFactor, nlevels
+        cfg.ini_th_fast, cfg.min_th_fast = iniThFAST, minThFAST
+        cfg.max_rows, cfg.max_cols, cfg.max_batch, cfg.device = max_rows, max_cols, max_batch, device
+        cfg.blur_taps_variant = blur_taps_variant
+        self.nlevels = nlevels
+        self.h = C.c_void_p()
+        _check(L.gfs_orb_create(C.byref(cfg), C.byref(self.h)), "gfs_orb_create")
+        self.cap = L.gfs_orb_max_keypoints(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gfs_orb_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def GetLevels(self):
+        return self.nlevels
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        feats = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        _check(lib().gfs_orb_get_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(feats), _p(umax)), "get_tables")
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, feats=feats, umax=umax)
+
+    def GetScaleFactors(self):
+        return self.tables()["scale"]
+
+    def GetInverseScaleFactors(self):
+        return self.tables()["inv_scale"]
+
+    def GetScaleSigmaSquares(self):
+        return self.tables()["sigma2"]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self.tables()["inv_sigma2"]
+
+    def __call__(self, image, vLappingArea=(0, 0)):
+        """operator(): -> (monoIndex or -1, keypoints[KP_DTYPE], descriptors [N,32] u8)"""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (src/ORBextractor.cc:1153)"
+        stride = image.strides[0]
+        assert image.strides[1] == 1
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        r = lib().gfs_orb_extract(self.h, C.c_void_p(image.ctypes.data), image.shape[0], image.shape[1], stride,
+                                  vLappingArea[0], vLappingArea[1], _p(kps), _p(desc), self.cap, C.byref(n))
+        if r < -1:
+            raise GfsError(f"gfs_orb_extract failed ({r + 100}): {lib().gfs_last_error().decode()}")
+        return r, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images, vLappingArea=(0, 0)):
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        B = len(imgs)
+        rows, cols = imgs[0].shape
+        ptrs = (C.c_void_p * B)(*[im.ctypes.data for im in imgs])
+        kps = np.zeros((B, self.cap), KP_DTYPE)
+        desc = np.zeros((B, self.cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        mono = np.zeros(B, np.int32)
+        _check(lib().gfs_orb_extract_batch(self.h, ptrs, B, rows, cols, cols, vLappingArea[0], vLappingArea[1], _p(kps),
+                                           _p(desc), self.cap, _p(n), _p(mono)), "gfs_orb_extract_batch")
+        return [(int(mono[b]), kps[b, :n[b]].copy(), desc[b, :n[b]].copy()) for b in range(B)]
+
+    def extract_batch_device(self, dev_ptr, B, rows, cols, vLappingArea=(0, 0), stream=None):
+        _check(lib().gfs_orb_extract_batch_device(self.h, C.c_void_p(dev_ptr), B, rows, cols, vLappingArea[0],
+                                                  vLappingArea[1], C.c_void_p(stream) if stream else None),
+               "gfs_orb_extract_batch_device")
+
+    def device_results(self):
+        k, d, c, m = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap = C.c_int()
+        _check(lib().gfs_orb_device_results(self.h, C.byref(k), C.byref(d), C.byref(c), C.byref(m), C.byref(cap)),
+               "gfs_orb_device_results")
+        return dict(kps=k.value, desc=d.value, counts=c.value, mono=m.value, cap=cap.value)
+
+    def fetch(self, b):
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n, mono = C.c_int(), C.c_int()
+        _check(lib().gfs_orb_fetch(self.h, b, _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono)), "gfs_orb_fetch")
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_size(self, l):
+        r, c = C.c_int(), C.c_int()
+        _check(lib().gfs_orb_level_size(self.h, l, C.byref(r), C.byref(c)), "gfs_orb_level_size")
+        return r.value, c.value
+
+    def level(self, l, b=0, blurred=False):
+        r, c = self.level_size(l)
+        a = np.zeros((r, c), np.uint8)
+        _check(lib().gfs_orb_fetch_level(self.h, b, l, int(blurred), _p(a)), "gfs_orb_fetch_level")
+        return a
+
+    def candidates(self, l, b=0):
+        n = _check(lib().gfs_orb_fetch_candidates(self.h, b, l, None, None, None, 0), "gfs_orb_fetch_candidates")
+        x, y, s = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        lib().gfs_orb_fetch_candidates(self.h, b, l, _p(x), _p(y), _p(s), n)
+        return x[:n], y[:n], s[:n]
+
+
+def octree_host(x, y, score, min_x, max_x, min_y, max_y, n_features):
+    """The library's host DistributeOctTree (no GPU needed)."""
+    x = np.ascontiguousarray(x, np.int32)
+    y = np.ascontiguousarray(y, np.int32)
+    score = np.ascontiguousarray(score, np.int32)
+    out = np.zeros(max(len(x), 1), np.int32)
+    n = lib().gfs_orb_octree_host(_p(x), _p(y), _p(score), len(x), min_x, max_x, min_y, max_y, n_features, _p(out),
+                                  len(out))
+    return out[:n]
+
+
+class ORBmatcher:
+    """The brute-force Hamming part of ORB_SLAM3::ORBmatcher (reference src/ORBmatcher.cc:744-778, 2536-2550)."""
+
+    def __init__(self, max_query=4096, max_train=4096, max_batch=1, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_matcher_create(device, max_query, max_train, max_batch, C.byref(self.h)), "gfs_matcher_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gfs_matcher_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return int(lib().gfs_hamming256(_p(a), _p(b)))
+
+    def match(self, query, train):
+        """cv::BFMatcher(NORM_HAMMING).match(query, train) -> (trainIdx[nq], distance[nq]); empty if no train rows."""
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        ti = np.zeros(len(q), np.int32)
+        di = np.zeros(len(q), np.int32)
+        n = _check(lib().gfs_bf_match_hamming(self.h, _p(q), len(q), _p(t), len(t), _p(ti), _p(di)),
+                   "gfs_bf_match_hamming")
+        return ti[:n], di[:n]
+
+    def match_batch_device(self, d_query, d_nq, d_train, d_nt, B, stride_rows, d_idx, d_dist, stream=None):
+        _check(lib().gfs_bf_match_hamming_batch_device(self.h, C.c_void_p(d_query), C.c_void_p(d_nq), C.c_void_p(d_train),
+                                                       C.c_void_p(d_nt), B, stride_rows, C.c_void_p(d_idx),
+                                                       C.c_void_p(d_dist), C.c_void_p(stream) if stream else None),
+               "gfs_bf_match_hamming_batch_device")
+
+
+def gicp_default_config():
+    c = GicpConfig()
+    lib().gfs_gicp_default_config(C.byref(c))
+    return c
+
+
+def _result_dict(res):
+    return dict(
+        T=np.array(res.T).reshape(4, 4).T.copy(), converged=bool(res.converged), iterations=int(res.iterations),
+        num_inliers=int(res.num_inliers), H=np.array(res.H).reshape(6, 6).T.copy(), b=np.array(res.b),
+        error=float(res.error), n_target_ds=res.n_target_ds, n_source_ds=res.n_source_ds,
+        n_linearize=res.n_linearize, n_error_evals=res.n_error_evals)
+
+
+class RegistrationGICP:
+    """RegistrationGICP (reference include/RegistrationGICP.h:19-31, src/RegistrationGICP.cc:5-20)."""
+
+    def __init__(self, max_points=40960, max_batch=1, device=0):
+        self.h = C.c_void_p()
+        self.max_points = max_points
+        _check(lib().gfs_gicp_create(device, max_points, max_batch, C.byref(self.h)), "gfs_gicp_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gfs_gicp_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def RegisterPointClouds(self, target_points, source_points, init_T_target_source=None, cfg=None):
+        t = np.ascontiguousarray(target_points, np.float32).reshape(-1, 4)
+        s = np.ascontiguousarray(source_points, np.float32).reshape(-1, 4)
+        T0 = np.eye(4) if init_T_target_source is None else np.asarray(init_T_target_source, np.float64)
+        T0c = np.ascontiguousarray(T0.T.reshape(-1))
+        cfg = cfg or gicp_default_config()
+        res = GicpResult()
+        _check(lib().gfs_gicp_align(self.h, _p(t), len(t), _p(s), len(s), _p(T0c), C.byref(cfg), C.byref(res)),
+               "gfs_gicp_align")
+        return _result_dict(res)
+
+    def align_batch_device(self, d_target, d_nt, d_source, d_ns, B, stride_pts, init_T=None, cfg=None, stream=None):
+        cfg = cfg or gicp_default_config()
+        out = (GicpResult * B)()
+        T0 = None
+        if init_T is not None:
+            T0 = np.ascontiguousarray(np.asarray(init_T, np.float64).transpose(0, 2, 1).reshape(B, 16))
+        _check(lib().gfs_gicp_align_batch_device(self.h, C.c_void_p(d_target), C.c_void_p(d_nt), C.c_void_p(d_source),
+                                                 C.c_void_p(d_ns), B, stride_pts, _p(T0), C.byref(cfg), out,
+                                                 C.c_void_p(stream) if stream else None), "gfs_gicp_align_batch_device")
+        return [_result_dict(r) for r in out]
+
+    def preprocessed(self, b, which, cap=None):
+        cap = cap or self.max_points
+        pts = np.zeros((cap, 4))
+        covs = np.zeros((cap, 9))
+        m = C.c_int()
+        _check(lib().gfs_gicp_fetch_preprocessed(self.h, b, which, _p(pts), _p(covs), cap, C.byref(m)),
+               "gfs_gicp_fetch_preprocessed")
+        return pts[:m.value], covs[:m.value].reshape(-1, 3, 3).transpose(0, 2, 1).copy()
+
+
+class Timer:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_timer_create(device, C.byref(self.h)), "gfs_timer_create")
+
+    def start(self, stream=None):
+        _check(lib().gfs_timer_start(self.h, C.c_void_p(stream) if stream else None), "gfs_timer_start")
+
+    def stop(self, stream=None):
+        _check(lib().gfs_timer_stop(self.h, C.c_void_p(stream) if stream else None), "gfs_timer_stop")
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        _check(lib().gfs_timer_elapsed_ms(self.h, C.byref(ms)), "gfs_timer_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().gfs_timer_destroy(self.h)
+            self.h = None
+
+
+def profile_enable(on=True):
+    lib().gfs_profile_enable(int(on))
+
+
+def profile_reset():
+    lib().gfs_profile_reset()
+
+
+def profile_report():
+    cap = 64
+    names = (C.c_char * 64 * cap)()
+    tot = np.zeros(cap)
+    cnt = np.zeros(cap, np.int64)
+    n = lib().gfs_profile_report(names, _p(tot), _p(cnt), cap)
+    return {names[i].value.decode(): (float(tot[i]), int(cnt[i])) for i in range(min(n, cap))}

@@ -1,0 +1,103 @@
+// Shared host-side infrastructure of libgfs_hip.so: error reporting, HIP checks, device buffers,
+// profiled kernel launches.  gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gfs_abi.h"
+
+namespace gfs {
+
+void set_error(const char* fmt, ...);
+bool device_ok(int device);  // true iff `device` exists and is a gfx950 part
+
+#define GFS_HIP(call)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (call);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      ::gfs::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return GFS_ERR_HIP;                                                                          \
+    }                                                                                              \
+  } while (0)
+
+#define GFS_REQUIRE(cond, code, ...)  \
+  do {                                \
+    if (!(cond)) {                    \
+      ::gfs::set_error(__VA_ARGS__);  \
+      return code;                    \
+    }                                 \
+  } while (0)
+
+// RAII device / pinned-host buffers (sized once at handle creation: nothing is allocated on the hot path).
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    free();
+    n = count;
+    if (count == 0) return GFS_OK;
+    GFS_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    return GFS_OK;
+  }
+  void free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { free(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+template <typename T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    free();
+    n = count;
+    if (count == 0) return GFS_OK;
+    GFS_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    return GFS_OK;
+  }
+  void free() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~PinBuf() { free(); }
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+};
+
+// ---- optional per-kernel timing (gfs_profile_*): HIP events recorded on the launch stream ----
+bool profile_on();
+void profile_begin(const char* name, hipStream_t s);
+void profile_end(hipStream_t s);
+
+#define GFS_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                        \
+  do {                                                                                   \
+    if (::gfs::profile_on()) ::gfs::profile_begin(name, stream);                         \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                 \
+    if (::gfs::profile_on()) ::gfs::profile_end(stream);                                 \
+    hipError_t _le = hipGetLastError();                                                  \
+    if (_le != hipSuccess) {                                                             \
+      ::gfs::set_error("launch %s failed: %s (%s:%d)", name, hipGetErrorString(_le), __FILE__, __LINE__); \
+      return GFS_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace gfs

@@ -1,0 +1,400 @@
+// Host-side tables and quadtree of the ORB extractor (see orb_host.hpp for the reference lines followed).
+#include "orb_host.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <utility>
+
+namespace gfs {
+
+namespace {
+inline int cv_round_f(float v) { return (int)std::lrintf(v); }  // cvRound: round-half-even
+inline int cv_round_d(double v) { return (int)std::lrint(v); }
+inline int cv_floor_d(double v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+inline int cv_ceil_d(double v) {
+  int i = (int)v;
+  return i + (i < v);
+}
+}  // namespace
+
+// ORBextractor::ORBextractor, src/ORBextractor.cc:421-479.  `scaleFactor` is a double member initialised from
+// the float argument (include/ORBextractor.h:109), hence the (double) products rounded back to float.
+void OrbParams::init(int nf, float sf, int nl, int ini, int mn, int bv) {
+  nfeatures = nf;
+  scale_factor = sf;
+  nlevels = nl;
+  ini_th = ini;
+  min_th = mn;
+  blur_variant = bv;
+  const double sfd = sf;
+  scale.assign(nl, 1.f);
+  sigma2.assign(nl, 1.f);
+  for (int i = 1; i < nl; i++) {
+    scale[i] = (float)(scale[i - 1] * sfd);
+    sigma2[i] = scale[i] * scale[i];
+  }
+  inv_scale.resize(nl);
+  inv_sigma2.resize(nl);
+  for (int i = 0; i < nl; i++) {
+    inv_scale[i] = 1.0f / scale[i];
+    inv_sigma2[i] = 1.0f / sigma2[i];
+  }
+  quota.assign(nl, 0);
+  float factor = (float)(1.0f / sfd);
+  float desired = nf * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; l++) {
+    quota[l] = cv_round_f(desired);
+    sum += quota[l];
+    desired *= factor;
+  }
+  quota[nl - 1] = std::max(nf - sum, 0);
+  int v, v0, vmax = cv_floor_d(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+  int vmin = cv_ceil_d(kHalfPatch * std::sqrt(2.f) / 2);
+  const double hp2 = kHalfPatch * kHalfPatch;
+  for (v = 0; v < 16; v++) umax[v] = 0;
+  for (v = 0; v <= vmax; ++v) umax[v] = cv_round_d(std::sqrt(hp2 - v * v));
+  for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+    while (umax[v0] == umax[v0 + 1]) ++v0;
+    umax[v] = v0;
+    ++v0;
+  }
+}
+
+// OpenCV computeResizeAreaTab (imgproc/src/resize.cpp) regrouped per destination index.
+static bool area_tab(int ssize, int dsize, std::vector<int>& start, std::vector<int>& cnt, std::vector<float>& alpha) {
+  const double scale = 1. / ((double)dsize / ssize);
+  for (int dx = 0; dx < dsize; dx++) {
+    double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    double cellWidth = std::min(scale, ssize - fsx1);
+    int sx1 = cv_ceil_d(fsx1), sx2 = cv_floor_d(fsx2);
+    sx2 = std::min(sx2, ssize - 1);
+    sx1 = std::min(sx1, sx2);
+    int s0 = -1, n = 0;
+    float a[kMaxAreaTaps + 4];
+    auto push = [&](int si, float al) {
+      if (n == 0) s0 = si;
+      if (n < kMaxAreaTaps + 4) a[n] = al;
+      n++;
+      return si == s0 + n - 1;
+    };
+    bool ok = true;
+    if (sx1 - fsx1 > 1e-3) ok &= push(sx1 - 1, (float)((sx1 - fsx1) / cellWidth));
+    for (int sx = sx1; sx < sx2; sx++) ok &= push(sx, float(1.0 / cellWidth));
+    if (fsx2 - sx2 > 1e-3) ok &= push(sx2, (float)(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth));
+    if (!ok || n == 0 || n > kMaxAreaTaps) return false;
+    start.push_back(s0);
+    cnt.push_back(n);
+    for (int k = 0; k < kMaxAreaTaps; k++) alpha.push_back(k < n ? a[k] : 0.f);
+  }
+  return true;
+}
+
+void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
+  rows = rows_;
+  cols = cols_;
+  levels.assign(p.nlevels, LevelDev{});
+  cells.clear();
+  blur_tiles.clear();
+  xt_start.clear();
+  yt_start.clear();
+  xt_n.clear();
+  yt_n.clear();
+  xt_alpha.clear();
+  yt_alpha.clear();
+  supported = true;
+  why = "";
+  size_t pyr = 0, blur = 0, slab = 0;
+  kp_cap = 0;
+  max_tile_w = max_tile_h = 0;
+  for (int l = 0; l < p.nlevels; l++) {
+    LevelDev& L = levels[l];
+    // ComputePyramid, src/ORBextractor.cc:1228-1231
+    L.cols = cv_round_f((float)cols * p.inv_scale[l]);
+    L.rows = cv_round_f((float)rows * p.inv_scale[l]);
+    L.pitch = (int)((L.cols + 63) / 64 * 64);
+    L.plane_off = (unsigned)pyr;
+    if (l > 0) pyr += (size_t)L.pitch * L.rows;
+    L.blur_off = (unsigned)blur;
+    blur += (size_t)L.pitch * L.rows;
+    L.scale = p.scale[l];
+    L.patch_size = (float)(int)(kPatchSize * p.scale[l]);
+    L.quota = p.quota[l];
+    if (l > 0) {
+      const LevelDev& S = levels[l - 1];
+      const double sx = 1. / ((double)L.cols / S.cols), sy = 1. / ((double)L.rows / S.rows);
+      const bool int_x = std::abs(sx - (int)std::lrint(sx)) < DBL_EPSILON, int_y = std::abs(sy - (int)std::lrint(sy)) < DBL_EPSILON;
+      if (sx < 1 || sy < 1 || (int_x && int_y)) {
+        supported = false;
+        why = "level ratio must be > 1 and non-integer (cv::resize INTER_AREA general path)";
+        return;
+      }
+      L.xtab_off = (int)xt_start.size();
+      L.ytab_off = (int)yt_start.size();
+      if (!area_tab(S.cols, L.cols, xt_start, xt_n, xt_alpha) || !area_tab(S.rows, L.rows, yt_start, yt_n, yt_alpha)) {
+        supported = false;
+        why = "INTER_AREA footprint wider than 4 source pixels (scale factor too large)";
+        return;
+      }
+    }
+    // cell grid, src/ORBextractor.cc:778-806
+    const int minBX = kEdgeThreshold - 3, minBY = minBX;
+    L.max_bx = L.cols - kEdgeThreshold + 3;
+    L.max_by = L.rows - kEdgeThreshold + 3;
+    const float W = 35;
+    const float width = (float)(L.max_bx - minBX), height = (float)(L.max_by - minBY);
+    const int nCols = (int)(width / W), nRows = (int)(height / W);
+    if (nCols < 1 || nRows < 1) {
+      supported = false;
+      why = "pyramid level smaller than one FAST cell (reference divides by zero here)";
+      return;
+    }
+    L.n_cell_cols = nCols;
+    L.n_cell_rows = nRows;
+    L.w_cell = (int)std::ceil(width / nCols);
+    L.h_cell = (int)std::ceil(height / nRows);
+    L.cell_base = (int)cells.size();
+    for (int i = 0; i < nRows; i++) {
+      const float iniY = (float)(minBY + i * L.h_cell);
+      float maxY = iniY + L.h_cell + 6;
+      if (iniY >= L.max_by - 3) continue;
+      if (maxY > L.max_by) maxY = (float)L.max_by;
+      for (int j = 0; j < nCols; j++) {
+        const float iniX = (float)(minBX + j * L.w_cell);
+        float maxX = iniX + L.w_cell + 6;
+        if (iniX >= L.max_bx - 6) continue;
+        if (maxX > L.max_bx) maxX = (float)L.max_bx;
+        CellDev c{};
+        c.level = (short)l;
+        c.x0 = (short)(int)iniX;
+        c.y0 = (short)(int)iniY;
+        c.w = (short)((int)maxX - (int)iniX);
+        c.h = (short)((int)maxY - (int)iniY);
+        const int dw = std::max(c.w - 6, 0), dh = std::max(c.h - 6, 0);
+        c.slab_off = (unsigned)slab;
+        c.slab_cap = (unsigned)(((dw + 1) / 2) * ((dh + 1) / 2));  // 3x3 strict-max NMS keeps <= 1 per 2x2 block
+        slab += c.slab_cap;
+        max_tile_w = std::max(max_tile_w, (int)c.w);
+        max_tile_h = std::max(max_tile_h, (int)c.h);
+        cells.push_back(c);
+      }
+    }
+    L.n_cells = (int)cells.size() - L.cell_base;
+    int nIni = (int)std::round(width / height);
+    if (nIni == 0) nIni = 1;
+    L.kp_cap = L.quota + 3 + 4 * nIni;
+    kp_cap += L.kp_cap;
+    for (int ty = 0; ty < (L.rows + 15) / 16; ty++)
+      for (int tx = 0; tx < (L.cols + 63) / 64; tx++) blur_tiles.push_back(BlurTileDev{(short)l, (short)tx, (short)ty, 0});
+  }
+  if (cols >= 4096 || rows >= 4096) {
+    supported = false;
+    why = "images must be smaller than 4096 x 4096 (12-bit packed candidate coordinates)";
+    return;
+  }
+  pyr_bytes = pyr;
+  blur_bytes = blur;
+  slab_entries = slab;
+  cand_cap = slab;
+}
+
+void ic_angle_offsets(const int umax[16], std::vector<int8_t>& du, std::vector<int8_t>& dv) {
+  du.clear();
+  dv.clear();
+  for (int u = -kHalfPatch; u <= kHalfPatch; ++u) {
+    du.push_back((int8_t)u);
+    dv.push_back(0);
+  }
+  for (int v = 1; v <= kHalfPatch; ++v) {
+    const int d = umax[v];
+    for (int u = -d; u <= d; ++u) {
+      du.push_back((int8_t)u);
+      dv.push_back((int8_t)v);
+      du.push_back((int8_t)u);
+      dv.push_back((int8_t)-v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DistributeOctTree — index-based equivalent of the std::list algorithm (src/ORBextractor.cc:567-768).
+// ------------------------------------------------------------------------------------------------
+void distribute_octree(const uint32_t* c, int n, int min_x, int max_x, int min_y, int max_y, int N,
+                       OctreeScratch& S, std::vector<int>& out) {
+  if (n <= 0) return;
+  int nIni = (int)std::round(static_cast<float>(max_x - min_x) / (max_y - min_y));  // :573
+  if (nIni == 0) nIni = 1;
+  const float hX = static_cast<float>(max_x - min_x) / nIni;
+  auto& nodes = S.nodes;
+  auto& perm = S.perm;
+  auto& tmp = S.tmp;
+  nodes.clear();
+  perm.resize(n);
+  tmp.resize(n);
+  int head = -1, tail = -1, size = 0;
+  auto push_back = [&](int idx) {
+    nodes[idx].prev = tail;
+    nodes[idx].next = -1;
+    if (tail >= 0)
+      nodes[tail].next = idx;
+    else
+      head = idx;
+    tail = idx;
+    size++;
+  };
+  auto push_front = [&](int idx) {
+    nodes[idx].prev = -1;
+    nodes[idx].next = head;
+    if (head >= 0)
+      nodes[head].prev = idx;
+    else
+      tail = idx;
+    head = idx;
+    size++;
+  };
+  auto erase = [&](int idx) {
+    const int p = nodes[idx].prev, q = nodes[idx].next;
+    if (p >= 0)
+      nodes[p].next = q;
+    else
+      head = q;
+    if (q >= 0)
+      nodes[q].prev = p;
+    else
+      tail = p;
+    size--;
+  };
+  // root nodes (:586-604): stable bucket of the candidates by (size_t)(pt.x / hX)
+  std::vector<int> rcount(nIni + 1, 0);
+  for (int i = 0; i < n; i++) {
+    int r = (int)((float)cand_x(c[i]) / hX);
+    r = std::min(std::max(r, 0), nIni - 1);
+    tmp[i] = r;
+    rcount[r + 1]++;
+  }
+  for (int r = 0; r < nIni; r++) rcount[r + 1] += rcount[r];
+  {
+    std::vector<int> pos(rcount.begin(), rcount.end() - 1);
+    for (int i = 0; i < n; i++) perm[pos[tmp[i]]++] = i;
+  }
+  for (int r = 0; r < nIni; r++) {
+    OctreeScratch::Node nd;
+    nd.x0 = (int)(hX * static_cast<float>(r));
+    nd.x1 = (int)(hX * static_cast<float>(r + 1));
+    nd.y0 = 0;
+    nd.y1 = max_y - min_y;
+    nd.kb = rcount[r];
+    nd.ke = rcount[r + 1];
+    nd.no_more = false;
+    nd.prev = nd.next = -1;
+    nodes.push_back(nd);
+    push_back((int)nodes.size() - 1);
+  }
+  for (int it = head; it >= 0;) {  // :606-616
+    const int nx = nodes[it].next, cnt = nodes[it].ke - nodes[it].kb;
+    if (cnt == 1)
+      nodes[it].no_more = true;
+    else if (cnt == 0)
+      erase(it);
+    it = nx;
+  }
+
+  std::vector<std::pair<int, int>> vsize, vprev;  // (size, node index)
+  // ExtractorNode::DivideNode (:502-550) + the four push_front blocks (:640-676 / :704-734)
+  auto split = [&](int it, int* n_to_expand) {
+    const OctreeScratch::Node P = nodes[it];
+    const int halfX = (int)std::ceil(static_cast<float>(P.x1 - P.x0) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(P.y1 - P.y0) / 2);
+    const int xm = P.x0 + halfX, ym = P.y0 + halfY;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int k = P.kb; k < P.ke; k++) {
+      const uint32_t v = c[perm[k]];
+      const int q = (cand_x(v) < xm ? 0 : 1) + (cand_y(v) < ym ? 0 : 2);
+      tmp[k] = q;
+      cnt[q]++;
+    }
+    int base[4] = {P.kb, P.kb + cnt[0], P.kb + cnt[0] + cnt[1], P.kb + cnt[0] + cnt[1] + cnt[2]};
+    {
+      int pos[4] = {base[0], base[1], base[2], base[3]};
+      // stable 4-way partition through a side buffer (reuse S.tmp upper half is not safe: use a local copy)
+      static thread_local std::vector<int> side;
+      side.assign(perm.begin() + P.kb, perm.begin() + P.ke);
+      for (int k = P.kb; k < P.ke; k++) perm[pos[tmp[k]]++] = side[k - P.kb];
+    }
+    const int bx0[4] = {P.x0, xm, P.x0, xm}, bx1[4] = {xm, P.x1, xm, P.x1};
+    const int by0[4] = {P.y0, P.y0, ym, ym}, by1[4] = {ym, ym, P.y1, P.y1};
+    for (int q = 0; q < 4; q++) {
+      if (cnt[q] == 0) continue;
+      OctreeScratch::Node ch;
+      ch.x0 = bx0[q];
+      ch.x1 = bx1[q];
+      ch.y0 = by0[q];
+      ch.y1 = by1[q];
+      ch.kb = base[q];
+      ch.ke = base[q] + cnt[q];
+      ch.no_more = cnt[q] == 1;
+      ch.prev = ch.next = -1;
+      nodes.push_back(ch);
+      const int idx = (int)nodes.size() - 1;
+      push_front(idx);
+      if (cnt[q] > 1) {
+        if (n_to_expand) (*n_to_expand)++;
+        vsize.push_back(std::make_pair(cnt[q], idx));
+      }
+    }
+  };
+  auto cmp = [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {  // compareNodes :552-565
+    if (a.first < b.first) return true;
+    if (a.first > b.first) return false;
+    return nodes[a.second].x0 < nodes[b.second].x0;
+  };
+
+  bool finish = false;
+  while (!finish) {
+    int prev_size = size, n_to_expand = 0;
+    vsize.clear();
+    for (int it = head; it >= 0;) {
+      if (nodes[it].no_more) {
+        it = nodes[it].next;
+        continue;
+      }
+      const int nx = nodes[it].next;
+      split(it, &n_to_expand);
+      erase(it);
+      it = nx;
+    }
+    if (size >= N || size == prev_size) {
+      finish = true;
+    } else if (size + n_to_expand * 3 > N) {
+      while (!finish) {
+        prev_size = size;
+        vprev = vsize;
+        vsize.clear();
+        std::sort(vprev.begin(), vprev.end(), cmp);
+        for (int j = (int)vprev.size() - 1; j >= 0; j--) {
+          split(vprev[j].second, nullptr);
+          erase(vprev[j].second);
+          if (size >= N) break;
+        }
+        if (size >= N || size == prev_size) finish = true;
+      }
+    }
+  }
+  for (int it = head; it >= 0; it = nodes[it].next) {  // :751-765
+    int best = perm[nodes[it].kb], best_r = cand_score(c[best]);
+    for (int k = nodes[it].kb + 1; k < nodes[it].ke; k++) {
+      const int r = cand_score(c[perm[k]]);
+      if (r > best_r) {
+        best = perm[k];
+        best_r = r;
+      }
+    }
+    out.push_back(best);
+  }
+}
+
+}  // namespace gfs

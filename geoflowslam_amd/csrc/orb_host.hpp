@@ -1,0 +1,94 @@
+// Host-side geometry / parameter tables of the ORB extractor and the (round-1) host quadtree distribution.
+// Everything here is derived from the reference constructor and control flow:
+//   src/ORBextractor.cc:421-479 (ctor tables), :770-806 (cell grid), :1227-1251 (level sizes),
+//   :502-768 (DistributeOctTree), and OpenCV's computeResizeAreaTab (imgproc/src/resize.cpp).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace gfs {
+
+constexpr int kPatchSize = 31;      // src/ORBextractor.cc:51
+constexpr int kHalfPatch = 15;      // :52
+constexpr int kEdgeThreshold = 19;  // :53
+constexpr int kMaxAreaTaps = 4;     // INTER_AREA taps per destination pixel we support (level ratio < 3)
+
+// Device-visible per-level geometry (POD, uploaded as an array).
+struct LevelDev {
+  int rows, cols, pitch;
+  unsigned plane_off;  // byte offset of this level inside one frame's pyramid buffer (level 0 unused)
+  unsigned blur_off;   // byte offset inside one frame's blurred-pyramid buffer
+  int xtab_off, ytab_off;  // first entry of this level's INTER_AREA tables (level >= 1)
+  int w_cell, h_cell, n_cell_cols, n_cell_rows, cell_base, n_cells;
+  int max_bx, max_by;  // maxBorderX / maxBorderY (level coords)
+  float scale;         // mvScaleFactor[level]
+  float patch_size;    // (float)(int)(PATCH_SIZE * mvScaleFactor[level])
+  int quota;           // mnFeaturesPerLevel[level]
+  int kp_cap;          // upper bound of keypoints this level can emit
+};
+
+// One FAST cell (src/ORBextractor.cc:788-806): the sub-image rowRange(y0,y1).colRange(x0,x1).
+struct CellDev {
+  short level, x0, y0, w, h;
+  short pad;
+  unsigned slab_off;  // first candidate slot of this cell in one frame's slab buffer
+  unsigned slab_cap;
+};
+
+struct BlurTileDev {
+  short level, tx, ty, pad;
+};
+
+struct OrbParams {
+  int nfeatures, nlevels, ini_th, min_th, blur_variant;
+  float scale_factor;
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> quota;
+  int umax[16];
+  void init(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int blur_variant);
+};
+
+struct OrbGeometry {
+  int rows = 0, cols = 0;
+  std::vector<LevelDev> levels;
+  std::vector<CellDev> cells;
+  std::vector<BlurTileDev> blur_tiles;
+  // INTER_AREA tables, concatenated over levels >= 1: entry i covers source indices
+  // [start[i], start[i] + n[i]) with weights alpha[4*i .. 4*i+n[i])
+  std::vector<int> xt_start, yt_start;
+  std::vector<int> xt_n, yt_n;
+  std::vector<float> xt_alpha, yt_alpha;
+  size_t pyr_bytes = 0, blur_bytes = 0;  // per frame
+  size_t slab_entries = 0;               // per frame
+  size_t cand_cap = 0;                   // dense candidate list capacity per frame (== slab_entries)
+  int kp_cap = 0;                        // keypoint capacity per frame
+  int max_tile_w = 0, max_tile_h = 0;    // FAST cell tile bounds (for the LDS allocation)
+  bool supported = true;
+  const char* why = "";
+  void build(const OrbParams& p, int rows, int cols);
+};
+
+// IC_Angle sampling offsets (src/ORBextractor.cc:71-95): 749 (du, dv) pairs of the circular patch.
+void ic_angle_offsets(const int umax[16], std::vector<int8_t>& du, std::vector<int8_t>& dv);
+
+// DistributeOctTree (src/ORBextractor.cc:567-768) on integer candidates (x, y relative to (16,16), response).
+// Array / index based: same node order, same libstdc++ std::sort tie behaviour, same first-max selection.
+// Appends the kept candidate indices, in std::list order, to `out`.
+struct OctreeScratch {
+  std::vector<int> perm, tmp;
+  struct Node {
+    int x0, x1, y0, y1;
+    int kb, ke;
+    int prev, next;
+    bool no_more;
+  };
+  std::vector<Node> nodes;
+};
+void distribute_octree(const uint32_t* packed, int n, int min_x, int max_x, int min_y, int max_y, int N,
+                       OctreeScratch& scratch, std::vector<int>& out);
+
+inline int cand_x(uint32_t c) { return (int)(c & 0xfff); }
+inline int cand_y(uint32_t c) { return (int)((c >> 12) & 0xfff); }
+inline int cand_score(uint32_t c) { return (int)(c >> 24); }
+
+}  // namespace gfs

@@ -1,0 +1,259 @@
+/* gfs_abi.h — C ABI of the MI355X-native GeoFlow-SLAM front-end hot path (libgfs_hip.so).
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: the seams are four
+ * ordinary C++ methods.  Each entry point below names the reference interface it replaces
+ * (file:line in HorizonRobotics/GeoFlowSlam).  Signatures are plain C: pointers, sizes, POD structs.
+ * No torch / OpenCV / Eigen types cross this boundary.  INTEGRATION.md shows the reference-side
+ * adaptor (what a maintainer adds to src/ORBextractor.cc etc. to call these).
+ *
+ * Conventions
+ *   - every function returns GFS_OK (0) or a negative gfs_status unless documented otherwise;
+ *     gfs_last_error() returns a thread-local human-readable message for the last failure.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point fails with
+ *     GFS_ERR_NO_DEVICE.
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device pointers on the
+ *     handle's device.  `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).
+ *   - matrices are column-major (Eigen default), quaternions are (x, y, z, w).
+ */
+#ifndef GFS_ABI_H_
+#define GFS_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFS_ABI_VERSION 1
+
+typedef enum {
+  GFS_OK = 0,
+  GFS_ERR_INVALID_ARG = -1,
+  GFS_ERR_NO_DEVICE = -2,   /* no gfx950 GPU / HIP runtime unusable */
+  GFS_ERR_HIP = -3,         /* a HIP call failed; see gfs_last_error() */
+  GFS_ERR_CAPACITY = -4,    /* caller buffer or handle capacity too small */
+  GFS_ERR_UNSUPPORTED = -5, /* configuration outside what the kernels implement */
+  GFS_ERR_STOPPED = -6      /* stop flag was raised (LBA) */
+} gfs_status;
+
+int gfs_abi_version(void);
+const char* gfs_last_error(void);
+/* number of usable gfx950 devices (0 if none / HIP unavailable) */
+int gfs_device_count(void);
+
+/* ============================================================================================
+ * 1. ORB extraction — replaces ORB_SLAM3::ORBextractor
+ *      ctor        include/ORBextractor.h:53-54, src/ORBextractor.cc:421-479
+ *      operator()  include/ORBextractor.h:61-64, src/ORBextractor.cc:1145-1225
+ *      getters     include/ORBextractor.h:66-80
+ *    called from Frame::ExtractORB (src/Frame.cc:768-777).
+ * ============================================================================================ */
+
+/* Field order and types of cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id): 28 bytes. */
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} gfs_keypoint;
+
+typedef struct gfs_orb gfs_orb; /* opaque; re-entrant: concurrent calls on one handle serialise internally (F9) */
+
+typedef struct {
+  int32_t nfeatures;   /* ORBextractor.nFeatures   (1000) */
+  float scale_factor;  /* ORBextractor.scaleFactor (1.2; must give non-integer level ratios) */
+  int32_t nlevels;     /* ORBextractor.nLevels     (8)   */
+  int32_t ini_th_fast; /* ORBextractor.iniThFAST   (20)  */
+  int32_t min_th_fast; /* ORBextractor.minThFAST   (7)   */
+  int32_t max_rows, max_cols; /* largest image the handle must accept */
+  int32_t max_batch;   /* largest batch for the *_batch entry points */
+  int32_t device;      /* HIP device ordinal */
+  int32_t blur_taps_variant; /* 0: OpenCV >= 4.5.1 {18,34,48,56,48,34,18}; 1: 4.0-4.5.0 {18,34,49,55,49,34,18} */
+} gfs_orb_config;
+
+void gfs_orb_default_config(gfs_orb_config* cfg);
+int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out);
+void gfs_orb_destroy(gfs_orb* h);
+
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (include/ORBextractor.h:66-80) plus the per-level feature quota and the umax table. Any pointer may be NULL. */
+int gfs_orb_get_tables(const gfs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                       int32_t* features_per_level, int32_t* umax16);
+/* upper bound of keypoints one image can produce (sum of quotas + 3 per level: the octree may overshoot). */
+int gfs_orb_max_keypoints(const gfs_orb* h);
+
+/* operator()(image, mask (ignored), keypoints, descriptors, vLappingArea): host image (CV_8UC1, `stride`
+ * bytes per row) -> kps[cap], desc[cap*32], *n = number of keypoints.
+ * RETURNS monoIndex (>= 0; == *n on the RGB-D path where lapping = {0,0}), -1 for an empty image
+ * (src/ORBextractor.cc:1150), or a gfs_status < -1 ... NOTE: to keep -1 unambiguous, errors are
+ * reported as (GFS_ERR_* - 100). */
+int gfs_orb_extract(gfs_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
+                    gfs_keypoint* kps, uint8_t* desc, int cap, int* n);
+
+/* Batched operator() over B independent host images of identical size: image b at imgs[b].
+ * kps: [B][cap], desc: [B][cap][32], n/mono_index: [B]. */
+int gfs_orb_extract_batch(gfs_orb* h, const uint8_t* const* imgs, int B, int rows, int cols, int stride, int lap0,
+                          int lap1, gfs_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
+
+/* Device-resident batch: dev_imgs is [B][rows][cols] dense u8 already in HBM.  Results stay in HBM in
+ * handle-owned buffers (see gfs_orb_device_results) until the next call on this handle. */
+int gfs_orb_extract_batch_device(gfs_orb* h, const void* dev_imgs, int B, int rows, int cols, int lap0, int lap1,
+                                 void* stream);
+/* Device result views of the last *_device call: kps [B][cap] gfs_keypoint, desc [B][cap][32] u8,
+ * counts [B] int32 (n), mono [B] int32. */
+int gfs_orb_device_results(gfs_orb* h, void** dev_kps, void** dev_desc, void** dev_counts, void** dev_mono, int* cap);
+/* Copy the last device results of image b to host buffers. */
+int gfs_orb_fetch(gfs_orb* h, int b, gfs_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
+
+/* Introspection used by the parity tests (mvImagePyramid is a public member of the reference class,
+ * include/ORBextractor.h:82): copies level `level` of image b of the last call (un-padded, rows*cols). */
+int gfs_orb_level_size(const gfs_orb* h, int level, int* rows, int* cols);
+int gfs_orb_fetch_level(gfs_orb* h, int b, int level, int blurred, uint8_t* dst);
+/* FAST candidates handed to the octree for (image b, level): x, y relative to (16,16), score. Returns count. */
+int gfs_orb_fetch_candidates(gfs_orb* h, int b, int level, int32_t* x, int32_t* y, int32_t* score, int cap);
+/* Host-logic test hook (no GPU needed): the library's DistributeOctTree (src/ORBextractor.cc:567-768) on caller
+ * candidates (integer x, y < 4096 relative to (min_x, min_y); score 0..255). Returns the number kept;
+ * out_idx[i] = input index of the i-th kept keypoint in the reference's std::list order. */
+int gfs_orb_octree_host(const int32_t* x, const int32_t* y, const int32_t* score, int n, int min_x, int max_x,
+                        int min_y, int max_y, int n_features, int32_t* out_idx, int cap);
+
+/* ============================================================================================
+ * 2. Brute-force Hamming matching — replaces
+ *      ORBmatcher::DescriptorDistance                       include/ORBmatcher.h:41, src/ORBmatcher.cc:2536-2550
+ *      cv::BFMatcher(NORM_HAMMING).match(d1, d2, matches)   src/ORBmatcher.cc:755-756, 805-806, 888-889
+ * ============================================================================================ */
+
+/* 256-bit Hamming distance of two 32-byte descriptors (pure host helper, bit-identical to DescriptorDistance). */
+int gfs_hamming256(const uint8_t* a, const uint8_t* b);
+
+typedef struct gfs_matcher gfs_matcher;
+int gfs_matcher_create(int device, int max_query, int max_train, int max_batch, gfs_matcher** out);
+void gfs_matcher_destroy(gfs_matcher* h);
+
+/* matcher.match(query, train): for every query row i the train row j of minimum Hamming distance, lowest j on
+ * ties -> train_idx[i], dist[i] (DMatch{queryIdx=i, trainIdx=train_idx[i], imgIdx=0, distance=(float)dist[i]}).
+ * Returns the number of matches written: nq, or 0 when the train set is empty (no matches, as OpenCV). */
+int gfs_bf_match_hamming(gfs_matcher* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                         int32_t* train_idx, int32_t* dist);
+
+/* Device-resident batch of B independent pairs.  dev_query/dev_train: [B][stride_rows][32] u8;
+ * dev_nq/dev_nt: [B] int32 row counts (device memory); outputs dev_train_idx/dev_dist: [B][stride_rows] int32
+ * (entries >= nq[b] untouched; train_idx = -1, dist = INT32_MAX when nt[b] == 0). */
+int gfs_bf_match_hamming_batch_device(gfs_matcher* h, const void* dev_query, const void* dev_nq, const void* dev_train,
+                                      const void* dev_nt, int B, int stride_rows, void* dev_train_idx, void* dev_dist,
+                                      void* stream);
+
+/* ============================================================================================
+ * 3. GICP registration — replaces RegistrationGICP::RegisterPointClouds
+ *      include/RegistrationGICP.h:25-28, src/RegistrationGICP.cc:5-20
+ *    (small_gicp::align<float,4> with GICPFactor + LevenbergMarquardtOptimizer,
+ *     Thirdparty/small_gicp/src/small_gicp/registration/registration_helper.cpp:57-122)
+ *    called from Tracking::PredictStateICP (src/Tracking.cc:3380-3382).
+ * ============================================================================================ */
+typedef struct {
+  int32_t num_threads;                /* kept for signature parity (src/RegistrationGICP.cc:10); ignored on GPU */
+  double downsampling_resolution;     /* 0.02 */
+  double max_correspondence_distance; /* 0.1  */
+  double rotation_eps;                /* 0.1 * pi / 180 */
+  double translation_eps;             /* 1e-3 */
+  int32_t max_iterations;             /* 20 */
+  int32_t num_neighbors;              /* 10 */
+} gfs_gicp_config;
+
+/* Field-for-field small_gicp::RegistrationResult (registration/registration_result.hpp:10-30). */
+typedef struct {
+  double T_target_source[16]; /* column-major 4x4 */
+  int32_t converged;
+  uint64_t iterations;
+  uint64_t num_inliers;
+  double H[36]; /* column-major 6x6 */
+  double b[6];
+  double error;
+  /* extra diagnostics */
+  int32_t n_target_downsampled, n_source_downsampled, n_linearize, n_error_evals;
+} gfs_gicp_result;
+
+typedef struct gfs_gicp gfs_gicp;
+void gfs_gicp_default_config(gfs_gicp_config* cfg);
+int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out);
+void gfs_gicp_destroy(gfs_gicp* h);
+
+/* RegisterPointClouds(target_points, source_points, init_T_target_source): clouds are arrays of
+ * Eigen::Vector4f (x, y, z, w; w ignored and forced to 1 like points/point_cloud.hpp:29). */
+int gfs_gicp_align(gfs_gicp* h, const float* target_xyzw, int nt, const float* source_xyzw, int ns,
+                   const double init_T_target_source[16], const gfs_gicp_config* cfg, gfs_gicp_result* out);
+
+/* Device-resident batch of B independent (target, source) pairs.  dev_target/dev_source: [B][stride_pts][4] f32,
+ * dev_nt/dev_ns: [B] int32 (device), init_T: host [B][16] (NULL = identity), out: host [B]. */
+int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void* dev_nt, const void* dev_source,
+                                const void* dev_ns, int B, int stride_pts, const double* init_T,
+                                const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream);
+
+/* Introspection for parity tests: preprocessing output (voxel means + covariances) of cloud `which`
+ * (0 = target, 1 = source) of pair b of the last call. pts: [m][4] f64, covs: [m][9] f64 (3x3 col-major). */
+int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, double* covs, int cap, int* m);
+
+/* ============================================================================================
+ * 4. Local bundle adjustment — replaces the numeric core of Optimizer::LocalBundleAdjustment
+ *      include/Optimizer.h:62-65, src/Optimizer.cc:1588-2040 (graph build 1662-1953, optimize(10) 1958-1959,
+ *      chi2 classification 1961-1999) with g2o BlockSolver<6,3> + Levenberg (Thirdparty/g2o).
+ *    The pointer-graph gather / write-back (src/Optimizer.cc:1592-1660, 2003-2039) stays in the C++ adaptor.
+ * ============================================================================================ */
+typedef struct {
+  int32_t n_poses, n_points, n_edges;
+  const double* pose_q;      /* [n_poses][4] unit quaternion (x,y,z,w) of Tcw */
+  const double* pose_t;      /* [n_poses][3] */
+  const uint8_t* pose_fixed; /* [n_poses] 1 = fixed (setFixed(true), src/Optimizer.cc:1697,1715) */
+  const double* points;      /* [n_points][3] world coordinates */
+  const int32_t* edge_pose;  /* [n_edges] */
+  const int32_t* edge_point; /* [n_edges] */
+  const double* edge_obs;    /* [n_edges][3] (u, v, u_right); u_right ignored for mono edges */
+  const double* edge_inv_sigma2; /* [n_edges] information = inv_sigma2 * I */
+  const uint8_t* edge_stereo;    /* [n_edges] 1 = EdgeStereoSE3ProjectXYZ, 0 = EdgeSE3ProjectXYZ */
+  double fx, fy, cx, cy, bf;
+  double huber_mono, huber_stereo; /* sqrt(5.991), sqrt(7.815) (src/Optimizer.cc:1728-1729) */
+  int32_t iterations;              /* 10 (src/Optimizer.cc:1959) */
+} gfs_lba_problem;
+
+typedef struct {
+  double* pose_q;               /* [n_poses][4] */
+  double* pose_t;               /* [n_poses][3] */
+  double* points;               /* [n_points][3] */
+  double* edge_chi2;            /* [n_edges] e->chi2() at the solution */
+  uint8_t* edge_depth_positive; /* [n_edges] e->isDepthPositive() */
+  int32_t iterations_run;
+  double final_chi2, final_lambda;
+} gfs_lba_solution;
+
+typedef struct gfs_lba gfs_lba;
+int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs_lba** out);
+void gfs_lba_destroy(gfs_lba* h);
+/* optimizer.optimize(iterations) with the stop flag polled like setForceStopFlag (src/Optimizer.cc:1679). */
+int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* s, volatile const int* stop);
+/* One BlockSolver::buildSystem (core/block_solver.hpp:502-558): Hpp [n_free][36] (col-major 6x6 diagonal blocks,
+ * free poses in ascending index order), Hll [n_points][9], Hpl per edge [n_edges][18] (6x3 col-major, zero for
+ * edges on fixed poses), bp [n_free][6], bl [n_points][3], edge_chi2 [n_edges]. Returns robust chi2 in *chi2. */
+int gfs_lba_linearize(gfs_lba* h, const gfs_lba_problem* p, double* Hpp, double* Hll, double* Hpl, double* bp,
+                      double* bl, double* edge_chi2, double* chi2);
+
+/* ============================================================================================
+ * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel
+ * with these rather than torch events, which only see torch's current stream).
+ * ============================================================================================ */
+typedef struct gfs_timer gfs_timer;
+int gfs_timer_create(int device, gfs_timer** out);
+void gfs_timer_destroy(gfs_timer* t);
+int gfs_timer_start(gfs_timer* t, void* stream);
+int gfs_timer_stop(gfs_timer* t, void* stream);
+/* blocks until the stop event completed; milliseconds between start and stop */
+int gfs_timer_elapsed_ms(gfs_timer* t, float* ms);
+
+/* Per-kernel accumulated device time (HIP events around each launch) — enable for profiling runs only. */
+int gfs_profile_enable(int on);
+/* Fills up to cap entries; returns number of distinct kernels. name buffers are 64 bytes each. */
+int gfs_profile_report(char (*names)[64], double* total_ms, int64_t* launches, int cap);
+int gfs_profile_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFS_ABI_H_ */

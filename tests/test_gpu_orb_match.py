@@ -1,0 +1,117 @@
+"""GPU parity tests (MI355X): the HIP path, called through the C ABI, must be BIT-EXACT against the CPU oracle
+for pyramid planes, FAST candidates, keypoints (x, y, size, angle, response, octave), 256-bit descriptors and
+brute-force match pairs.  Tolerance: none (integer / byte / index work and exactly-rounded float32)."""
+import numpy as np
+import pytest
+
+from geoflowslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_full(ext, orc, img, lap=(0, 0)):
+    m, k, d = ext(img, lap)
+    mo, ko, do = orc.extract(img, lap)
+    for l in range(ext.nlevels):
+        assert (ext.level(l) == orc.level(l)).all(), f"pyramid level {l} differs"
+    for l in range(ext.nlevels):
+        x, y, s = ext.candidates(l)
+        xo, yo, so = orc.candidates(l)
+        assert len(x) == len(xo), f"level {l}: {len(x)} candidates vs oracle {len(xo)}"
+        assert (x == xo).all() and (y == yo).all() and (s == so).all(), f"FAST candidates differ on level {l}"
+    for l in range(ext.nlevels):
+        if len(orc.level_keypoints(l)):
+            assert (ext.level(l, blurred=True) == orc.blurred(l)).all(), f"blurred level {l} differs"
+    assert m == mo and len(k) == len(ko)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert (k[f] == ko[f]).all(), f"keypoint field {f} differs"
+    assert (k["angle"].view(np.uint32) == ko["angle"].view(np.uint32)).all(), "angles differ (bitwise)"
+    assert (d == do).all(), "descriptors differ"
+    return m, k, d
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_orb_vga_noise_image(gpu_api, oracle, seed):
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=480, max_cols=640)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    _compare_full(ext, orc, synth.noise_image(seed, 640, 480))
+
+
+def test_orb_rendered_pair_and_match(gpu_api, oracle):
+    fp = synth.frame_pair(11)
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    _, k0, d0 = _compare_full(ext, orc, fp["gray0"])
+    _, k1, d1 = _compare_full(ext, orc, fp["gray1"])
+    mt = gpu_api.ORBmatcher()
+    ti, di = mt.match(d0, d1)
+    to, do = oracle.bf_match(d0, d1)
+    assert len(ti) == len(d0) and (ti == to).all() and (di == do).all()
+
+
+def test_orb_720p_2000(gpu_api, oracle):
+    ext = gpu_api.ORBextractor(2000, 1.2, 8, 20, 7, max_rows=720, max_cols=1280)
+    orc = oracle.OrbOracle(2000, 1.2, 8, 20, 7)
+    _compare_full(ext, orc, synth.noise_image(5, 1280, 720))
+
+
+def test_orb_other_params_and_strided_input(gpu_api, oracle):
+    # iniTh 25 / minTh 7 (the G1 yaml), 5 levels, odd size, non-continuous input (honour `stride`)
+    big = synth.noise_image(9, 700, 500)
+    view = big[7:7 + 411, 13:13 + 577]
+    assert not view.flags["C_CONTIGUOUS"]
+    ext = gpu_api.ORBextractor(600, 1.2, 5, 25, 7, max_rows=411, max_cols=577)
+    orc = oracle.OrbOracle(600, 1.2, 5, 25, 7)
+    m, k, d = ext(view)
+    mo, ko, do = orc.extract(np.ascontiguousarray(view))
+    assert m == mo and (k == ko).all() and (d == do).all()
+
+
+def test_orb_blur_variant_and_lapping(gpu_api, oracle):
+    img = synth.noise_image(21, 640, 480)
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7, blur_taps_variant=1)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7, blur_variant=1)
+    _compare_full(ext, orc, img, (0, 300))
+
+
+def test_orb_edge_cases(gpu_api, oracle):
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert ext(np.zeros((0, 0), np.uint8))[0] == -1  # empty image -> -1 (src/ORBextractor.cc:1150)
+    m, k, d = ext(np.full((480, 640), 90, np.uint8))  # flat image: nothing
+    assert m == 0 and len(k) == 0 and len(d) == 0
+    # low-contrast image: only the minThFAST fallback fires
+    img = (synth.noise_image(2, 640, 480).astype(np.int32) - 128) // 6 + 128
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    _compare_full(ext, orc, img.astype(np.uint8))
+
+
+def test_orb_batch_matches_single(gpu_api, oracle):
+    imgs = [synth.noise_image(30 + i, 640, 480) for i in range(5)]
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=5)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    res = ext.extract_batch(imgs)
+    for im, (m, k, d) in zip(imgs, res):
+        mo, ko, do = orc.extract(im)
+        assert m == mo and (k == ko).all() and (d == do).all()
+
+
+def test_bf_match_random_and_ties(gpu_api, oracle):
+    rng = np.random.default_rng(0)
+    mt = gpu_api.ORBmatcher(max_query=5000, max_train=5000)
+    for nq, nt in [(1, 1), (63, 65), (1000, 1000), (2000, 1999), (257, 4097), (5000, 3)]:
+        q = rng.integers(0, 256, (nq, 32)).astype(np.uint8)
+        t = rng.integers(0, 256, (nt, 32)).astype(np.uint8)
+        if nt > 10:
+            t[nt // 2] = t[3]  # duplicate train rows: lowest index must win
+            q[0] = t[3]
+        ti, di = mt.match(q, t)
+        to, do = oracle.bf_match(q, t)
+        assert (ti == to).all() and (di == do).all()
+        if nt > 10:
+            assert ti[0] == 3 and di[0] == 0
+    # empty train set -> no matches; empty query -> no matches
+    assert len(mt.match(rng.integers(0, 256, (5, 32)).astype(np.uint8), np.zeros((0, 32), np.uint8))[0]) == 0
+    assert len(mt.match(np.zeros((0, 32), np.uint8), rng.integers(0, 256, (5, 32)).astype(np.uint8))[0]) == 0
+    # all-equal distances: every query picks train 0
+    z = np.zeros((70, 32), np.uint8)
+    assert (mt.match(z, z)[0] == 0).all()

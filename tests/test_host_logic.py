@@ -1,0 +1,39 @@
+"""CPU tests of the product's host-side logic (no GPU): the index-based quadtree must reproduce the oracle's
+std::list restatement of DistributeOctTree (reference src/ORBextractor.cc:567-768) exactly, including order."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_octree_host_matches_oracle(api, oracle, seed):
+    rng = np.random.default_rng(seed)
+    w, h = [(608, 448), (501, 368), (1248, 688), (338, 246), (147, 102)][seed % 5]
+    n = int(rng.integers(1, 6000))
+    # clustered candidates like real FAST output, unique pixel positions
+    centers = rng.uniform(0, 1, (12, 2)) * [w, h]
+    pts = centers[rng.integers(0, 12, n)] + rng.normal(0, 25, (n, 2))
+    pts = np.unique(np.clip(np.rint(pts), [3, 3], [w - 4, h - 4]).astype(np.int32), axis=0)
+    order = np.lexsort((pts[:, 0], pts[:, 1]))
+    pts = pts[order]
+    score = rng.integers(7, 120, len(pts)).astype(np.int32)
+    quota = int(rng.choice([5, 60, 217, 434]))
+    got = api.octree_host(pts[:, 0], pts[:, 1], score, 16, 16 + w, 16, 16 + h, quota)
+    exp = oracle.distribute_octree(pts[:, 0], pts[:, 1], score, 16, 16 + w, 16, 16 + h, quota)
+    assert got.tolist() == exp.tolist()
+
+
+def test_octree_host_degenerate(api, oracle):
+    for x, y, s in [([5], [5], [9]), ([5, 5], [5, 5], [9, 9]), ([3, 600, 3, 600], [3, 3, 440, 440], [1, 2, 3, 4])]:
+        got = api.octree_host(x, y, s, 16, 624, 16, 464, 100)
+        exp = oracle.distribute_octree(x, y, s, 16, 624, 16, 464, 100)
+        assert got.tolist() == exp.tolist()
+    assert len(api.octree_host([], [], [], 16, 624, 16, 464, 100)) == 0
+
+
+def test_hamming256_host(api, oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = rng.integers(0, 256, 32).astype(np.uint8)
+        b = rng.integers(0, 256, 32).astype(np.uint8)
+        ref = int(np.unpackbits(a ^ b).sum())
+        assert api.ORBmatcher.DescriptorDistance(a, b) == ref == oracle.descriptor_distance(a, b)
