@@ -101,6 +101,9 @@ typedef struct {
 } gfso_gicp_result;
 
 void gfso_gicp_default_cfg(gfso_gicp_cfg*);
+/* on != 0: equal voxel keys are ordered by point index instead of by the reference's quick_sort_omp permutation
+ * (util/sort_omp.hpp:58-85). Only which points fall on either side of a 1024-block split changes. Default 0. */
+void gfso_gicp_set_stable_voxel_order(int on);
 /* RegistrationGICP::RegisterPointClouds, src/RegistrationGICP.cc:5-20 */
 void gfso_gicp_align(const float* target_xyzw, int nt, const float* source_xyzw, int ns, const double init_T[16],
                      const gfso_gicp_cfg* cfg, gfso_gicp_result* out);

@@ -264,6 +264,10 @@ def bf_match(q, t, nthreads=1):
     return ti[:n], di[:n]
 
 
+def gicp_set_stable_voxel_order(on):
+    lib().gfso_gicp_set_stable_voxel_order(int(on))
+
+
 def gicp_default_cfg():
     c = GicpCfg()
     lib().gfso_gicp_default_cfg(C.byref(c))
