@@ -1,0 +1,1175 @@
+// GICP registration for gfx950 (MI355X).  Replaces RegistrationGICP::RegisterPointClouds
+// (reference src/RegistrationGICP.cc:5-20 -> small_gicp::align<float,4>, registration_helper.cpp:57-122):
+//   voxel-grid downsampling (util/downsampling_omp.hpp:26-95)  -> k_voxel_keys, k_radix_sort, k_voxel_reduce
+//   exact k-NN (ann/kdtree.hpp) + covariances (util/normal_estimation.hpp:66-92) -> cell grid + k_knn_cov
+//   GICPFactor::linearize / error (factors/gicp_factor.hpp:35-89) + ParallelReductionOMP
+//   (registration/reduction_omp.hpp:21-69)                   -> k_gicp_linearize / k_gicp_error (+ fixed-order sums)
+//   LevenbergMarquardtOptimizer::optimize (registration/optimizer.hpp:83-147) -> device-side state machine
+//                                                              (k_gicp_solve / k_gicp_decide); the host only polls "all done".
+// Everything is double precision like the reference.  The KdTree is replaced by a uniform cell grid (cell edge =
+// max correspondence distance): nearest-neighbour results are exact, hence structure independent (ties aside).
+//
+// HBM layout: a batch holds 2B clouds (cloud c = 2*pair + {0: target, 1: source}), every per-cloud array has a
+// fixed stride of P entries.  Down-sampled points are stored sorted by (cell z, cell y, cell x) so that one cell
+// and its two x-neighbours form a contiguous run: a 27-cell probe is 9 binary searches + 9 linear runs.
+#include <algorithm>
+#include <memory>
+
+#include "gfs_common.hpp"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr u64 kInvalidKey = ~0ull;
+constexpr int kCoordBits = 21;
+constexpr int kCoordOffset = 1 << (kCoordBits - 1);
+constexpr int kCoordMask = (1 << kCoordBits) - 1;
+constexpr int kRed = 29;  // 21 (upper H) + 6 (b) + 1 (e) + 1 (inlier count)
+constexpr int kLinBlock = 256;
+
+struct PairState {
+  double T[12];     // R (col-major 9) | t (3): current estimate
+  double newT[12];  // trial estimate
+  double delta[6];
+  double H[21], b[6], e;  // last linearisation (upper triangle, (i,j) i<=j in row-major order)
+  double lambda;
+  int outer, inner;
+  int phase;  // 0 = linearise next, 1 = error evaluation next, 2 = done
+  int converged;
+  int iterations;  // RegistrationResult::iterations (index of the last outer iteration)
+  int inliers;
+  int n_lin, n_err;
+};
+
+struct GicpParams {
+  double inv_leaf, cell, inv_cell, max_dist_sq, rot_eps, trans_eps;
+  int max_iterations, k_neighbors;
+};
+
+__device__ __forceinline__ int fast_floor_d(double v) {  // util/fast_floor.hpp:12-15
+  const int n = (int)v;
+  return n - (v < (double)n ? 1 : 0);
+}
+__device__ __forceinline__ u64 pack_key(int cx, int cy, int cz) {
+  return (u64)(cx & kCoordMask) | ((u64)(cy & kCoordMask) << kCoordBits) | ((u64)(cz & kCoordMask) << (2 * kCoordBits));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_voxel_keys (util/downsampling_omp.hpp:39-55; points/point_cloud.hpp:26-31 widens float -> double, w := 1)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ tgt, const float4* __restrict__ src,
+                                                    const int* __restrict__ nt, const int* __restrict__ ns,
+                                                    int stride_pts, int P, double inv_leaf, u64* __restrict__ keys,
+                                                    unsigned* __restrict__ idx, int* __restrict__ counts) {
+  const int c = blockIdx.y, pair = c >> 1, which = c & 1;
+  const int n = min(which ? ns[pair] : nt[pair], P);
+  const float4* in = (which ? src : tgt) + (size_t)pair * stride_pts;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) counts[c] = n;
+  if (i >= n) return;
+  const float4 p = in[i];
+  const double x = (double)p.x * inv_leaf, y = (double)p.y * inv_leaf, z = (double)p.z * inv_leaf;
+  u64 key = kInvalidKey;
+  if (fabs(x) < 1.0e6 && fabs(y) < 1.0e6 && fabs(z) < 1.0e6) {  // also rejects NaN / inf
+    const int cx = fast_floor_d(x) + kCoordOffset, cy = fast_floor_d(y) + kCoordOffset, cz = fast_floor_d(z) + kCoordOffset;
+    if (cx >= 0 && cx <= kCoordMask && cy >= 0 && cy <= kCoordMask && cz >= 0 && cz <= kCoordMask) key = pack_key(cx, cy, cz);
+  }
+  keys[(size_t)c * P + i] = key;
+  idx[(size_t)c * P + i] = (unsigned)i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_radix_sort: one 1024-thread workgroup sorts one cloud's (key, value) pairs.  LSD radix, 8-bit digits,
+// stable (tiles scattered in order, wave-ballot ranking inside a tile), uniform digits skipped.  Ping-pongs
+// between buffers 0 and 1; which[c] says where the sorted data ended up.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u64* __restrict__ keys1,
+                                                     unsigned* __restrict__ val0, unsigned* __restrict__ val1,
+                                                     const int* __restrict__ counts, int P, int* __restrict__ which) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned bin_base[256];
+  __shared__ unsigned wave_hist[16][256];
+  __shared__ int s_uniform;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = counts[c];
+  u64* ka = keys0 + (size_t)c * P;
+  u64* kb = keys1 + (size_t)c * P;
+  unsigned* va = val0 + (size_t)c * P;
+  unsigned* vb = val1 + (size_t)c * P;
+  int flip = 0;
+  for (int pass = 0; pass < 8 && n > 0; pass++) {
+    const int shift = 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) s_uniform = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[(unsigned)(ka[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (tid < 256 && hist[tid] == (unsigned)n) s_uniform = 1;
+    __syncthreads();
+    if (s_uniform) continue;  // block-uniform
+    if (tid < 256) bin_base[tid] = hist[tid];
+    __syncthreads();
+    for (int ofs = 1; ofs < 256; ofs <<= 1) {  // inclusive scan
+      unsigned v = 0;
+      if (tid < 256 && tid >= ofs) v = bin_base[tid - ofs];
+      __syncthreads();
+      if (tid < 256) bin_base[tid] += v;
+      __syncthreads();
+    }
+    if (tid < 256) bin_base[tid] -= hist[tid];  // exclusive
+    __syncthreads();
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+      for (int k = tid; k < 16 * 256; k += 1024) (&wave_hist[0][0])[k] = 0;
+      __syncthreads();
+      const int i = t0 + tid;
+      const bool valid = i < n;
+      u64 key = 0;
+      unsigned val = 0, digit = 0;
+      if (valid) {
+        key = ka[i];
+        val = va[i];
+        digit = (unsigned)(key >> shift) & 255u;
+      }
+      u64 mask = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const bool b1 = (digit >> bit) & 1u;
+        const u64 bm = __ballot(b1);
+        mask &= b1 ? bm : ~bm;
+      }
+      const unsigned lane_rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+      if (valid && lane_rank == 0) wave_hist[wave][digit] = (unsigned)__popcll(mask);
+      __syncthreads();
+      if (tid < 256) {
+        unsigned acc = bin_base[tid];
+        for (int w = 0; w < 16; w++) {
+          const unsigned t = wave_hist[w][tid];
+          wave_hist[w][tid] = acc;
+          acc += t;
+        }
+        bin_base[tid] = acc;
+      }
+      __syncthreads();
+      if (valid) {
+        const unsigned pos = wave_hist[wave][digit] + lane_rank;
+        kb[pos] = key;
+        vb[pos] = val;
+      }
+      __syncthreads();
+    }
+    u64* tk = ka;
+    ka = kb;
+    kb = tk;
+    unsigned* tv = va;
+    va = vb;
+    vb = tv;
+    flip ^= 1;
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (tid == 0) which[c] = flip;
+}
+
+// block-wide exclusive scan of one int per thread (1024 threads); returns exclusive prefix, total in *total
+__device__ __forceinline__ int block_scan_1024(int v, int* s_wave /*16*/, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int ofs = 1; ofs < 64; ofs <<= 1) {
+    const int t = __shfl_up(incl, ofs, 64);
+    if (lane >= ofs) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < 16; w++) {
+    const int t = s_wave[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_voxel_reduce: per sorted run of equal voxel keys, cut additionally at every multiple of 1024 in the
+// sorted array (the reference's block-wise reduction, util/downsampling_omp.hpp:63-90), emit the mean
+// sum / sum.w.  Also emits the cell key of every mean.  One workgroup per cloud; output in sorted order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict__ tgt, const float4* __restrict__ src,
+                                                       int stride_pts, const u64* __restrict__ keys0,
+                                                       const u64* __restrict__ keys1, const unsigned* __restrict__ val0,
+                                                       const unsigned* __restrict__ val1, const int* __restrict__ which,
+                                                       const int* __restrict__ counts, int P, double inv_cell,
+                                                       double4* __restrict__ tmp_pts, u64* __restrict__ cell_keys,
+                                                       unsigned* __restrict__ cell_idx, int* __restrict__ m_counts) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int c = blockIdx.x, pair = c >> 1, tid = threadIdx.x;
+  const int n = counts[c];
+  const u64* keys = (which[c] ? keys1 : keys0) + (size_t)c * P;
+  const unsigned* idx = (which[c] ? val1 : val0) + (size_t)c * P;
+  const float4* in = ((c & 1) ? src : tgt) + (size_t)pair * stride_pts;
+  double4* out = tmp_pts + (size_t)c * P;
+  u64* ck = cell_keys + (size_t)c * P;
+  unsigned* ci = cell_idx + (size_t)c * P;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    const int i = t0 + tid;
+    u64 key = kInvalidKey;
+    if (i < n) key = keys[i];
+    const bool valid = key != kInvalidKey;
+    const bool start = valid && (i == 0 || (i & 1023) == 0 || keys[i - 1] != key);
+    int total;
+    const int pos = block_scan_1024(start ? 1 : 0, s_wave, &total) + s_carry;
+    if (start) {
+      double sx = 0, sy = 0, sz = 0, sw = 0;
+      int j = i;
+      do {
+        const float4 p = in[idx[j]];
+        sx += (double)p.x;
+        sy += (double)p.y;
+        sz += (double)p.z;
+        sw += 1.0;
+        j++;
+      } while (j < n && (j & 1023) != 0 && keys[j] == key);
+      const double mx = sx / sw, my = sy / sw, mz = sz / sw;
+      out[pos] = make_double4(mx, my, mz, sw / sw);
+      ck[pos] = pack_key(fast_floor_d(mx * inv_cell) + kCoordOffset, fast_floor_d(my * inv_cell) + kCoordOffset,
+                         fast_floor_d(mz * inv_cell) + kCoordOffset);
+      ci[pos] = (unsigned)pos;
+    }
+    __syncthreads();
+    if (tid == 0) s_carry += total;
+    __syncthreads();
+  }
+  if (tid == 0) m_counts[c] = s_carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cell_build: gather the means into cell-sorted order and build the table of occupied cells
+// (sorted unique cell keys + first point of each cell).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__ tmp_pts, const u64* __restrict__ ck0,
+                                                     const u64* __restrict__ ck1, const unsigned* __restrict__ ci0,
+                                                     const unsigned* __restrict__ ci1, const int* __restrict__ which,
+                                                     const int* __restrict__ m_counts, int P, double4* __restrict__ pts,
+                                                     u64* __restrict__ ucell, unsigned* __restrict__ ubegin,
+                                                     int* __restrict__ n_ucell, int* __restrict__ bbox) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  __shared__ int s_bb[6];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  if (tid < 3) s_bb[tid] = kCoordMask;
+  else if (tid < 6) s_bb[tid] = 0;
+  const int m = m_counts[c];
+  const u64* ck = (which[c] ? ck1 : ck0) + (size_t)c * P;
+  const unsigned* ci = (which[c] ? ci1 : ci0) + (size_t)c * P;
+  const double4* tp = tmp_pts + (size_t)c * P;
+  double4* out = pts + (size_t)c * P;
+  u64* uc = ucell + (size_t)c * (P + 1);
+  unsigned* ub = ubegin + (size_t)c * (P + 1);
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < m; t0 += 1024) {
+    const int i = t0 + tid;
+    bool start = false;
+    u64 key = 0;
+    if (i < m) {
+      key = ck[i];
+      out[i] = tp[ci[i]];
+      start = i == 0 || ck[i - 1] != key;
+    }
+    int total;
+    const int pos = block_scan_1024(start ? 1 : 0, s_wave, &total) + s_carry;
+    if (start) {
+      uc[pos] = key;
+      ub[pos] = (unsigned)i;
+      const int kx = (int)(key & kCoordMask), ky = (int)((key >> kCoordBits) & kCoordMask), kz = (int)((key >> (2 * kCoordBits)) & kCoordMask);
+      atomicMin(&s_bb[0], kx);
+      atomicMin(&s_bb[1], ky);
+      atomicMin(&s_bb[2], kz);
+      atomicMax(&s_bb[3], kx);
+      atomicMax(&s_bb[4], ky);
+      atomicMax(&s_bb[5], kz);
+    }
+    __syncthreads();
+    if (tid == 0) s_carry += total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    n_ucell[c] = s_carry;
+    ub[s_carry] = (unsigned)m;
+    uc[s_carry] = kInvalidKey;
+  }
+  if (tid < 6) bbox[6 * c + tid] = s_bb[tid];  // occupied-cell bounding box (x0,y0,z0,x1,y1,z1)
+}
+
+// ------------------------------------------------------------------------------------------------
+// cell-grid helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n, u64 key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Eigen 3.4 SelfAdjointEigenSolver<Matrix3d>::computeDirect (closed form) — same formulas as the oracle.
+// m: symmetric 3x3 as (xx, xy, xz, yy, yz, zz).  V column-major 3x3 (columns = eigenvectors, ascending).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double sqn3(const double* a) { return a[0] * a[0] + a[1] * a[1] + a[2] * a[2]; }
+
+__device__ void extract_kernel(const double* s /*9 col-major*/, double* res, double* rep) {
+  int i0 = 0;
+  double best = fabs(s[0]);
+  if (fabs(s[4]) > best) {
+    best = fabs(s[4]);
+    i0 = 1;
+  }
+  if (fabs(s[8]) > best) i0 = 2;
+  const int j1 = (i0 + 1) % 3, j2 = (i0 + 2) % 3;
+  rep[0] = s[3 * i0];
+  rep[1] = s[3 * i0 + 1];
+  rep[2] = s[3 * i0 + 2];
+  double c0[3], c1[3];
+  cross3(rep, s + 3 * j1, c0);
+  cross3(rep, s + 3 * j2, c1);
+  const double n0 = sqn3(c0), n1 = sqn3(c1);
+  if (n0 > n1) {
+    const double d = sqrt(n0);
+    res[0] = c0[0] / d;
+    res[1] = c0[1] / d;
+    res[2] = c0[2] / d;
+  } else {
+    const double d = sqrt(n1);
+    res[0] = c1[0] / d;
+    res[1] = c1[1] / d;
+    res[2] = c1[2] / d;
+  }
+}
+
+__device__ void eig3_direct(const double* cov6, double* V) {
+  const double shift = (cov6[0] + cov6[3] + cov6[5]) / 3.0;
+  double s[9] = {cov6[0] - shift, cov6[1], cov6[2], cov6[1], cov6[3] - shift, cov6[4], cov6[2], cov6[4], cov6[5] - shift};
+  double scale = 0;
+  for (int i = 0; i < 9; i++) scale = fmax(scale, fabs(s[i]));
+  if (scale > 0)
+    for (int i = 0; i < 9; i++) s[i] /= scale;
+  double ev[3];
+  {
+    const double s_inv3 = 1.0 / 3.0, s_sqrt3 = sqrt(3.0);
+    const double c0 = s[0] * s[4] * s[8] + 2.0 * s[1] * s[2] * s[5] - s[0] * s[5] * s[5] - s[4] * s[2] * s[2] - s[8] * s[1] * s[1];
+    const double c1 = s[0] * s[4] - s[1] * s[1] + s[0] * s[8] - s[2] * s[2] + s[4] * s[8] - s[5] * s[5];
+    const double c2 = s[0] + s[4] + s[8];
+    const double c2_over_3 = c2 * s_inv3;
+    double a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+    a_over_3 = fmax(a_over_3, 0.0);
+    const double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+    double q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    q = fmax(q, 0.0);
+    const double rho = sqrt(a_over_3);
+    const double theta = atan2(sqrt(q), half_b) * s_inv3;
+    const double cos_theta = cos(theta), sin_theta = sin(theta);
+    ev[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    ev[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    ev[2] = c2_over_3 + 2.0 * rho * cos_theta;
+  }
+  const double eps = 2.220446049250313e-16;
+  if ((ev[2] - ev[0]) <= eps) {
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+  double d0 = ev[2] - ev[1];
+  const double d1 = ev[1] - ev[0];
+  int k = 0, l = 2;
+  if (d0 > d1) {  // Eigen: swap(k, l); d0 = d1
+    k = 2;
+    l = 0;
+    d0 = d1;
+  }
+  double tmp[9], colk[3], coll[3];
+  for (int i = 0; i < 9; i++) tmp[i] = s[i];
+  tmp[0] -= ev[k];
+  tmp[4] -= ev[k];
+  tmp[8] -= ev[k];
+  extract_kernel(tmp, colk, coll);
+  if (d0 <= 2 * eps * d1) {
+    const double dot = colk[0] * coll[0] + colk[1] * coll[1] + colk[2] * coll[2];
+    for (int i = 0; i < 3; i++) coll[i] -= dot * coll[i];
+    const double nn = sqrt(sqn3(coll));
+    for (int i = 0; i < 3; i++) coll[i] /= nn;
+  } else {
+    for (int i = 0; i < 9; i++) tmp[i] = s[i];
+    tmp[0] -= ev[l];
+    tmp[4] -= ev[l];
+    tmp[8] -= ev[l];
+    double dummy[3];
+    extract_kernel(tmp, coll, dummy);
+  }
+  for (int i = 0; i < 3; i++) {
+    V[3 * k + i] = colk[i];
+    V[3 * l + i] = coll[i];
+  }
+  double c1v[3];
+  cross3(V + 6, V, c1v);
+  const double nn = sqrt(sqn3(c1v));
+  for (int i = 0; i < 3; i++) V[3 + i] = c1v[i] / nn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_knn_cov: one thread per down-sampled point: exact 10-NN in its own cloud (the query itself included,
+// util/normal_estimation.hpp:69) through ring-expanding cell probes, 3x3 covariance, closed-form
+// eigen-decomposition, cov := V diag(1e-3, 1, 1) V^T.  Stored as 6 doubles (xx, xy, xz, yy, yz, zz).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+struct TopK {
+  double d[K];
+  int id[K];
+  int found;
+  __device__ void init() {
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      d[i] = 1.79769313486231570e308;
+      id[i] = -1;
+    }
+    found = 0;
+  }
+  __device__ void push(int index, double dist) {  // ann/knn_result.hpp:80-101 (insert after equal distances)
+    if (dist >= d[K - 1]) return;
+    double cd = dist;
+    int ci = index;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      if (cd < d[i]) {
+        const double td = d[i];
+        const int ti = id[i];
+        d[i] = cd;
+        id[i] = ci;
+        cd = td;
+        ci = ti;
+      }
+    }
+    found = min(found + 1, K);
+  }
+};
+
+__global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts, const u64* __restrict__ ucell,
+                                                 const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
+                                                 const int* __restrict__ m_counts, const int* __restrict__ bbox,
+                                                 int P, GicpParams prm, double* __restrict__ cov6) {
+  const int c = blockIdx.y;
+  const int m = m_counts[c];
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= m) return;
+  const double4* p = pts + (size_t)c * P;
+  const u64* uc = ucell + (size_t)c * (P + 1);
+  const unsigned* ub = ubegin + (size_t)c * (P + 1);
+  const int nu = n_ucell[c];
+  const double4 q = p[i];
+  const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
+            cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
+  TopK<10> best;
+  const int kk = min(prm.k_neighbors, 10);
+  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
+            bz1 = bbox[6 * c + 5];
+  for (int r = 1;; r *= 2) {
+    best.init();
+    // rows outside the occupied-cell bounding box are empty: clamp the probe to it
+    for (int z = max(cz - r, bz0); z <= min(cz + r, bz1); z++)
+      for (int y = max(cy - r, by0); y <= min(cy + r, by1); y++) {
+        const u64 k0 = pack_key(max(cx - r, bx0), y, z), k1 = pack_key(min(cx + r, bx1), y, z);
+        int u = lower_bound_u64(uc, nu, k0);
+        if (u >= nu || uc[u] > k1) continue;
+        int u_end = u;
+        while (u_end < nu && uc[u_end] <= k1) u_end++;
+        const int j0 = (int)ub[u], j1 = (int)ub[u_end];
+        for (int j = j0; j < j1; j++) {
+          const double4 t = p[j];
+          const double ddx = t.x - q.x, ddy = t.y - q.y, ddz = t.z - q.z;
+          best.push(j, ddx * ddx + ddy * ddy + ddz * ddz);
+        }
+      }
+    const int want = min(kk, m);
+    const double reach = (double)r * prm.cell;
+    const double kth = kk == 10 ? best.d[9] : best.d[max(want - 1, 0)];
+    const bool covers_all = cx - r <= bx0 && cx + r >= bx1 && cy - r <= by0 && cy + r >= by1 && cz - r <= bz0 && cz + r >= bz1;
+    if ((best.found >= want && kth <= reach * reach) || covers_all || r > kCoordMask) break;
+  }
+  const int n = min(best.found, kk);
+  double* out = cov6 + ((size_t)c * P + i) * 6;
+  if (n < 5) {  // NormalCovarianceSetter::set_invalid: cov = diag(1,1,1,0)
+    out[0] = 1;
+    out[1] = 0;
+    out[2] = 0;
+    out[3] = 1;
+    out[4] = 0;
+    out[5] = 1;
+    return;
+  }
+  double sp[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    if (k < n) {
+      const double4 t = p[best.id[k]];
+      sp[0] += t.x;
+      sp[1] += t.y;
+      sp[2] += t.z;
+      sc[0] += t.x * t.x;
+      sc[1] += t.x * t.y;
+      sc[2] += t.x * t.z;
+      sc[3] += t.y * t.y;
+      sc[4] += t.y * t.z;
+      sc[5] += t.z * t.z;
+    }
+  }
+  const double dn = (double)n;
+  const double mean[3] = {sp[0] / dn, sp[1] / dn, sp[2] / dn};
+  // lower triangle of (sum_cross - mean * sum^T) / n  (Eigen's computeDirect reads the lower triangle)
+  double cv[6];
+  cv[0] = (sc[0] - mean[0] * sp[0]) / dn;
+  cv[1] = (sc[1] - mean[1] * sp[0]) / dn;  // (1,0)
+  cv[2] = (sc[2] - mean[2] * sp[0]) / dn;  // (2,0)
+  cv[3] = (sc[3] - mean[1] * sp[1]) / dn;
+  cv[4] = (sc[4] - mean[2] * sp[1]) / dn;  // (2,1)
+  cv[5] = (sc[5] - mean[2] * sp[2]) / dn;
+  double V[9];
+  eig3_direct(cv, V);
+  const double dv[3] = {1e-3, 1.0, 1.0};
+  int o = 0;
+  for (int r = 0; r < 3; r++)
+    for (int cc = r; cc < 3; cc++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += (V[3 * k + r] * dv[k]) * V[3 * k + cc];
+      out[o++] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LM state machine
+// ------------------------------------------------------------------------------------------------
+// Eigen::Matrix3d::inverse() (Inverse.h, size-3 cofactor form); A, M column-major.
+__device__ __forceinline__ void inv3(const double* A, double* M) {
+#define a_(i, j) A[(i) + 3 * (j)]
+#define cof_(i, j) (a_(((i) + 1) % 3, ((j) + 1) % 3) * a_(((i) + 2) % 3, ((j) + 2) % 3) - a_(((i) + 1) % 3, ((j) + 2) % 3) * a_(((i) + 2) % 3, ((j) + 1) % 3))
+  const double c00 = cof_(0, 0), c10 = cof_(1, 0), c20 = cof_(2, 0);
+  const double det = c00 * a_(0, 0) + c10 * a_(1, 0) + c20 * a_(2, 0);
+  const double id = 1.0 / det;
+  M[0] = c00 * id;
+  M[3] = c10 * id;
+  M[6] = c20 * id;
+  M[1] = cof_(0, 1) * id;
+  M[4] = cof_(1, 1) * id;
+  M[7] = cof_(2, 1) * id;
+  M[2] = cof_(0, 2) * id;
+  M[5] = cof_(1, 2) * id;
+  M[8] = cof_(2, 2) * id;
+#undef a_
+#undef cof_
+}
+
+// per-wave shuffle reduction, then the 4 waves of the block are folded in fixed order: deterministic sums
+template <int N>
+__device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __restrict__ dst, double* s_red /*[4][kRed]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double v = vals[k];
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_down(v, ofs, 64);
+    if (lane == 0) s_red[wave * kRed + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int k = threadIdx.x;
+    dst[k] = ((s_red[k] + s_red[kRed + k]) + s_red[2 * kRed + k]) + s_red[3 * kRed + k];
+  }
+}
+
+// GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
+// machine is in the "linearise" phase; per-block partial sums of H (upper), b, e and the inlier count.
+__global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* __restrict__ st,
+                                                              const double4* __restrict__ pts,
+                                                              const double* __restrict__ cov6, const u64* __restrict__ ucell,
+                                                              const unsigned* __restrict__ ubegin,
+                                                              const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
+                                                              int P, GicpParams prm, int* __restrict__ tgt_index,
+                                                              double* __restrict__ maha6, double* __restrict__ partial,
+                                                              int nblk) {
+  __shared__ double s_red[4 * kRed];
+  const int pair = blockIdx.y;
+  const PairState S = st[pair];
+  if (S.phase != 0) return;
+  const int ct = 2 * pair, cs = 2 * pair + 1;
+  const int ms = m_counts[cs];
+  const int i = blockIdx.x * kLinBlock + threadIdx.x;
+  double acc[kRed];
+#pragma unroll
+  for (int k = 0; k < kRed; k++) acc[k] = 0;
+  if (i < ms) {
+    const double4 p = pts[(size_t)cs * P + i];
+    const double* R = S.T;
+    const double* t = S.T + 9;
+    const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
+    const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
+    const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
+    // exact nearest neighbour within max_corr: 27-cell probe (cell edge = max_corr)
+    const double4* tp = pts + (size_t)ct * P;
+    const u64* uc = ucell + (size_t)ct * (P + 1);
+    const unsigned* ub = ubegin + (size_t)ct * (P + 1);
+    const int nu = n_ucell[ct];
+    const int cx = fast_floor_d(tx * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(ty * prm.inv_cell) + kCoordOffset,
+              cz = fast_floor_d(tz * prm.inv_cell) + kCoordOffset;
+    double best = 1.79769313486231570e308;
+    int bj = -1;
+    if (fabs(tx) < 2.0e4 && fabs(ty) < 2.0e4 && fabs(tz) < 2.0e4) {
+      for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+          const u64 k0 = pack_key(cx - 1, cy + dy, cz + dz), k1 = pack_key(cx + 1, cy + dy, cz + dz);
+          int u = lower_bound_u64(uc, nu, k0);
+          if (u >= nu || uc[u] > k1) continue;
+          int u_end = u;
+          while (u_end < nu && uc[u_end] <= k1) u_end++;
+          const int j0 = (int)ub[u], j1 = (int)ub[u_end];
+          for (int j = j0; j < j1; j++) {
+            const double4 q = tp[j];
+            const double dx = q.x - tx, dy2 = q.y - ty, dz2 = q.z - tz;
+            const double d = dx * dx + dy2 * dy2 + dz2 * dz2;
+            if (d < best) {
+              best = d;
+              bj = j;
+            }
+          }
+        }
+    }
+    int ti = -1;
+    if (bj >= 0 && !(best > prm.max_dist_sq)) {  // DistanceRejector: reject iff sq_dist > max_dist_sq
+      ti = bj;
+      const double* Cs = cov6 + ((size_t)cs * P + i) * 6;
+      const double* Ct = cov6 + ((size_t)ct * P + bj) * 6;
+      const double cs9[9] = {Cs[0], Cs[1], Cs[2], Cs[1], Cs[3], Cs[4], Cs[2], Cs[4], Cs[5]};
+      double RC[9];
+      for (int cc = 0; cc < 3; cc++)
+        for (int r = 0; r < 3; r++) RC[r + 3 * cc] = R[r] * cs9[3 * cc] + R[r + 3] * cs9[3 * cc + 1] + R[r + 6] * cs9[3 * cc + 2];
+      const double ct9[9] = {Ct[0], Ct[1], Ct[2], Ct[1], Ct[3], Ct[4], Ct[2], Ct[4], Ct[5]};
+      double A[9];
+      for (int cc = 0; cc < 3; cc++)
+        for (int r = 0; r < 3; r++) A[r + 3 * cc] = ct9[r + 3 * cc] + (RC[r] * R[cc] + RC[r + 3] * R[cc + 3] + RC[r + 6] * R[cc + 6]);
+      double M[9];
+      inv3(A, M);
+      double* mo = maha6 + ((size_t)pair * P + i) * 6;
+      mo[0] = M[0];
+      mo[1] = M[3];
+      mo[2] = M[6];
+      mo[3] = M[4];
+      mo[4] = M[7];
+      mo[5] = M[8];
+      const double4 q = tp[bj];
+      const double res[3] = {q.x - tx, q.y - ty, q.z - tz};
+      // J = [R * skew(p) | -R]
+      const double Sk[9] = {0, p.z, -p.y, -p.z, 0, p.x, p.y, -p.x, 0};
+      double J[18];
+      for (int cc = 0; cc < 3; cc++)
+        for (int r = 0; r < 3; r++) {
+          J[r + 3 * cc] = R[r] * Sk[3 * cc] + R[r + 3] * Sk[3 * cc + 1] + R[r + 6] * Sk[3 * cc + 2];
+          J[r + 3 * (cc + 3)] = -R[r + 3 * cc];
+        }
+      double MJ[18];
+      for (int cc = 0; cc < 6; cc++)
+        for (int r = 0; r < 3; r++) MJ[r + 3 * cc] = M[r] * J[3 * cc] + M[r + 3] * J[3 * cc + 1] + M[r + 6] * J[3 * cc + 2];
+      int o = 0;
+      for (int r = 0; r < 6; r++)
+        for (int cc = r; cc < 6; cc++) acc[o++] = J[3 * r] * MJ[3 * cc] + J[3 * r + 1] * MJ[3 * cc + 1] + J[3 * r + 2] * MJ[3 * cc + 2];
+      double Mr[3];
+      for (int r = 0; r < 3; r++) Mr[r] = M[r] * res[0] + M[r + 3] * res[1] + M[r + 6] * res[2];
+      for (int r = 0; r < 6; r++) acc[21 + r] = J[3 * r] * Mr[0] + J[3 * r + 1] * Mr[1] + J[3 * r + 2] * Mr[2];
+      acc[27] = 0.5 * (res[0] * Mr[0] + res[1] * Mr[1] + res[2] * Mr[2]);
+      acc[28] = 1.0;
+    }
+    tgt_index[(size_t)pair * P + i] = ti;
+  }
+  block_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + blockIdx.x) * kRed, s_red);
+}
+
+// GICPFactor::error (factors/gicp_factor.hpp:76-86) with the frozen correspondences / Mahalanobis matrices.
+__global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __restrict__ st, const double4* __restrict__ pts,
+                                                           const int* __restrict__ m_counts, int P,
+                                                           const int* __restrict__ tgt_index, const double* __restrict__ maha6,
+                                                           double* __restrict__ epartial, int nblk) {
+  __shared__ double s_red[4 * kRed];
+  const int pair = blockIdx.y;
+  const PairState& S = st[pair];
+  if (S.phase != 1) return;
+  const int ct = 2 * pair, cs = 2 * pair + 1;
+  const int ms = m_counts[cs];
+  const int i = blockIdx.x * kLinBlock + threadIdx.x;
+  double e[1] = {0.0};
+  if (i < ms) {
+    const int ti = tgt_index[(size_t)pair * P + i];
+    if (ti >= 0) {
+      const double4 p = pts[(size_t)cs * P + i];
+      const double* R = S.newT;
+      const double* t = S.newT + 9;
+      const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
+      const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
+      const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
+      const double4 q = pts[(size_t)ct * P + ti];
+      const double r0 = q.x - tx, r1 = q.y - ty, r2 = q.z - tz;
+      const double* M = maha6 + ((size_t)pair * P + i) * 6;
+      const double m0 = M[0] * r0 + M[1] * r1 + M[2] * r2, m1 = M[1] * r0 + M[3] * r1 + M[4] * r2,
+                   m2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
+      e[0] = 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
+    }
+  }
+  block_reduce_store<1>(e, epartial + (size_t)pair * nblk + blockIdx.x, s_red);
+}
+
+// (H + lambda I) delta = -b through a diagonally pivoted LDL^T (Eigen::LDLT), then new_T = T * se3_exp(delta)
+// (registration/optimizer.hpp:109-112, util/lie.hpp:54-103).
+__device__ void solve_and_propose(PairState& S) {
+  double A[36], rhs[6], x[6];
+  int o = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c = r; c < 6; c++) {
+      A[r + 6 * c] = S.H[o];
+      A[c + 6 * r] = S.H[o];
+      o++;
+    }
+  for (int k = 0; k < 6; k++) {
+    A[7 * k] += S.lambda;
+    rhs[k] = -S.b[k];
+  }
+  int perm[6] = {0, 1, 2, 3, 4, 5};
+  for (int k = 0; k < 6; k++) {
+    int p = k;
+    double best = fabs(A[7 * k]);
+    for (int i = k + 1; i < 6; i++)
+      if (fabs(A[7 * i]) > best) {
+        best = fabs(A[7 * i]);
+        p = i;
+      }
+    if (p != k) {
+      for (int j = 0; j < 6; j++) {
+        const double t = A[k + 6 * j];
+        A[k + 6 * j] = A[p + 6 * j];
+        A[p + 6 * j] = t;
+      }
+      for (int j = 0; j < 6; j++) {
+        const double t = A[j + 6 * k];
+        A[j + 6 * k] = A[j + 6 * p];
+        A[j + 6 * p] = t;
+      }
+      const int t = perm[k];
+      perm[k] = perm[p];
+      perm[p] = t;
+    }
+    const double d = A[7 * k];
+    if (d == 0) continue;
+    for (int i = k + 1; i < 6; i++) A[i + 6 * k] /= d;
+    for (int j = k + 1; j < 6; j++)
+      for (int i = j; i < 6; i++) {
+        A[i + 6 * j] -= A[i + 6 * k] * d * A[j + 6 * k];
+        A[j + 6 * i] = A[i + 6 * j];
+      }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) y[i] = rhs[perm[i]];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < i; j++) y[i] -= A[i + 6 * j] * y[j];
+  for (int i = 0; i < 6; i++) y[i] = A[7 * i] != 0 ? y[i] / A[7 * i] : 0;
+  for (int i = 5; i >= 0; i--)
+    for (int j = i + 1; j < 6; j++) y[i] -= A[j + 6 * i] * y[j];
+  for (int i = 0; i < 6; i++) x[perm[i]] = y[i];
+  for (int i = 0; i < 6; i++) S.delta[i] = x[i];
+  // se3_exp
+  const double* w = x;
+  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double theta = sqrt(theta_sq);
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double tq = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
+  } else {
+    const double ht = 0.5 * theta;
+    imag = sin(ht) / theta;
+    real = cos(ht);
+  }
+  const double qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+  double E[12];
+  {
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const double txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    E[0] = 1 - (tyy + tzz);
+    E[3] = txy - twz;
+    E[6] = txz + twy;
+    E[1] = txy + twz;
+    E[4] = 1 - (txx + tzz);
+    E[7] = tyz - twx;
+    E[2] = txz - twy;
+    E[5] = tyz + twx;
+    E[8] = 1 - (txx + tyy);
+  }
+  const double* v = x + 3;
+  if (theta < 1e-10) {
+    for (int i = 0; i < 3; i++) E[9 + i] = E[i] * v[0] + E[i + 3] * v[1] + E[i + 6] * v[2];
+  } else {
+    const double O[9] = {0, w[2], -w[1], -w[2], 0, w[0], w[1], -w[0], 0};
+    double O2[9];
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) O2[r + 3 * c] = O[r] * O[3 * c] + O[r + 3] * O[3 * c + 1] + O[r + 6] * O[3 * c + 2];
+    const double k1 = (1.0 - cos(theta)) / theta_sq, k2 = (theta - sin(theta)) / (theta_sq * theta);
+    double V[9];
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + k1 * O[i] + k2 * O2[i];
+    for (int i = 0; i < 3; i++) E[9 + i] = V[i] * v[0] + V[i + 3] * v[1] + V[i + 6] * v[2];
+  }
+  // newT = T * E
+  const double* R = S.T;
+  const double* t = S.T + 9;
+  for (int c = 0; c < 3; c++)
+    for (int i = 0; i < 3; i++) S.newT[i + 3 * c] = R[i] * E[3 * c] + R[i + 3] * E[3 * c + 1] + R[i + 6] * E[3 * c + 2];
+  for (int i = 0; i < 3; i++) S.newT[9 + i] = R[i] * E[9] + R[i + 3] * E[10] + R[i + 6] * E[11] + t[i];
+}
+
+// after a linearise pass: fold the per-block partial sums in block order, first damped solve
+__global__ __launch_bounds__(64) void k_gicp_solve(PairState* __restrict__ st, const double* __restrict__ partial,
+                                                   const int* __restrict__ m_counts, int nblk_max) {
+  __shared__ double s_sum[kRed];
+  const int pair = blockIdx.x;
+  PairState& S = st[pair];
+  if (S.phase != 0) return;
+  const int ms = m_counts[2 * pair + 1];
+  const int nblk = (ms + kLinBlock - 1) / kLinBlock;
+  if (threadIdx.x < kRed) {
+    double a = 0;
+    for (int k = 0; k < nblk; k++) a += partial[((size_t)pair * nblk_max + k) * kRed + threadIdx.x];
+    s_sum[threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 21; k++) S.H[k] = s_sum[k];
+    for (int k = 0; k < 6; k++) S.b[k] = s_sum[21 + k];
+    S.e = s_sum[27];
+    S.inliers = (int)(s_sum[28] + 0.5);
+    S.n_lin++;
+    S.inner = 0;
+    solve_and_propose(S);
+    S.phase = 1;
+  }
+}
+
+// after an error pass: accept / reject the trial (registration/optimizer.hpp:115-141)
+__global__ __launch_bounds__(64) void k_gicp_decide(PairState* __restrict__ st, const double* __restrict__ epartial,
+                                                    const int* __restrict__ m_counts, int nblk_max, GicpParams prm,
+                                                    int* __restrict__ n_done) {
+  const int pair = blockIdx.x;
+  PairState& S = st[pair];
+  if (S.phase != 1) return;
+  if (threadIdx.x != 0) return;
+  const int ms = m_counts[2 * pair + 1];
+  const int nblk = (ms + kLinBlock - 1) / kLinBlock;
+  double new_e = 0;
+  for (int k = 0; k < nblk; k++) new_e += epartial[(size_t)pair * nblk_max + k];
+  S.n_err++;
+  if (new_e <= S.e) {
+    const double dr = sqrt(S.delta[0] * S.delta[0] + S.delta[1] * S.delta[1] + S.delta[2] * S.delta[2]);
+    const double dt = sqrt(S.delta[3] * S.delta[3] + S.delta[4] * S.delta[4] + S.delta[5] * S.delta[5]);
+    S.converged = (dr <= prm.rot_eps && dt <= prm.trans_eps) ? 1 : 0;
+    for (int k = 0; k < 12; k++) S.T[k] = S.newT[k];
+    S.lambda /= 10.0;
+    S.iterations = S.outer;
+    S.outer++;
+    if (S.converged || S.outer >= prm.max_iterations) {
+      S.phase = 2;
+      atomicAdd(n_done, 1);
+    } else {
+      S.phase = 0;
+    }
+  } else {
+    S.lambda *= 10.0;
+    S.inner++;
+    if (S.inner >= 10) {  // max_inner_iterations: !success -> break
+      S.iterations = S.outer;
+      S.phase = 2;
+      atomicAdd(n_done, 1);
+    } else {
+      solve_and_propose(S);
+    }
+  }
+}
+
+__global__ void k_gicp_init(PairState* __restrict__ st, const double* __restrict__ init_T, int B, int max_iterations,
+                            int* __restrict__ n_done) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= B) return;
+  PairState& S = st[pair];
+  const double* T = init_T + 16 * (size_t)pair;
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) S.T[r + 3 * c] = T[r + 4 * c];
+  for (int r = 0; r < 3; r++) S.T[9 + r] = T[12 + r];
+  for (int k = 0; k < 12; k++) S.newT[k] = S.T[k];
+  for (int k = 0; k < 6; k++) S.delta[k] = 0;
+  for (int k = 0; k < 21; k++) S.H[k] = 0;
+  for (int k = 0; k < 6; k++) S.b[k] = 0;
+  S.e = 0;
+  S.lambda = 1e-3;  // init_lambda
+  S.outer = S.inner = 0;
+  S.converged = 0;
+  S.iterations = 0;
+  S.inliers = 0;
+  S.n_lin = S.n_err = 0;
+  S.phase = max_iterations > 0 ? 0 : 2;
+  if (max_iterations <= 0) atomicAdd(n_done, 1);
+}
+
+}  // namespace
+
+struct gfs_gicp {
+  int device, P, Bmax, nblk;
+  hipStream_t stream;
+  std::mutex mu;
+  gfs::DevBuf<float4> d_in_t, d_in_s;  // staging for the host-pointer entry
+  gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox;
+  gfs::DevBuf<u64> d_keys0, d_keys1, d_ck0, d_ck1, d_ucell;
+  gfs::DevBuf<unsigned> d_val0, d_val1, d_ci0, d_ci1, d_ubegin;
+  gfs::DevBuf<double4> d_tmp, d_pts;
+  gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
+  gfs::DevBuf<PairState> d_state;
+  gfs::PinBuf<PairState> h_state;
+  gfs::PinBuf<int> h_ndone, h_m;
+  gfs::PinBuf<double> h_initT;
+  int last_B = 0;
+};
+
+extern "C" {
+
+void gfs_gicp_default_config(gfs_gicp_config* c) {
+  if (!c) return;
+  c->num_threads = 4;                    // src/RegistrationGICP.cc:10
+  c->downsampling_resolution = 0.02;     // :11
+  c->max_correspondence_distance = 0.1;  // :12-13
+  c->rotation_eps = 0.1 * 3.14159265358979323846 / 180.0;
+  c->translation_eps = 1e-3;
+  c->max_iterations = 20;
+  c->num_neighbors = 10;  // registration_helper.cpp:60-61
+}
+
+int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
+  GFS_REQUIRE(out && max_points > 0 && max_batch > 0, GFS_ERR_INVALID_ARG, "gfs_gicp_create: invalid argument");
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  std::unique_ptr<gfs_gicp> h(new gfs_gicp);
+  h->device = device;
+  h->P = (int)gfs::align_up((size_t)max_points, 1024);
+  h->Bmax = max_batch;
+  h->nblk = gfs::div_up(h->P, kLinBlock);
+  GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t P = h->P, B = max_batch, C2 = 2 * B;
+  int rc = 0;
+#define A(x) if (!rc) rc = (x)
+  A(h->d_in_t.alloc(P));
+  A(h->d_in_s.alloc(P));
+  A(h->d_nt.alloc(B));
+  A(h->d_ns.alloc(B));
+  A(h->d_counts.alloc(C2));
+  A(h->d_which.alloc(C2));
+  A(h->d_which2.alloc(C2));
+  A(h->d_m.alloc(C2));
+  A(h->d_nucell.alloc(C2));
+  A(h->d_bbox.alloc(C2 * 6));
+  A(h->d_ndone.alloc(1));
+  A(h->d_keys0.alloc(C2 * P));
+  A(h->d_keys1.alloc(C2 * P));
+  A(h->d_val0.alloc(C2 * P));
+  A(h->d_val1.alloc(C2 * P));
+  A(h->d_ck0.alloc(C2 * P));
+  A(h->d_ck1.alloc(C2 * P));
+  A(h->d_ci0.alloc(C2 * P));
+  A(h->d_ci1.alloc(C2 * P));
+  A(h->d_ucell.alloc(C2 * (P + 1)));
+  A(h->d_ubegin.alloc(C2 * (P + 1)));
+  A(h->d_tmp.alloc(C2 * P));
+  A(h->d_pts.alloc(C2 * P));
+  A(h->d_cov6.alloc(C2 * P * 6));
+  A(h->d_maha6.alloc(B * P * 6));
+  A(h->d_tgt_index.alloc(B * P));
+  A(h->d_partial.alloc(B * h->nblk * kRed));
+  A(h->d_epartial.alloc(B * h->nblk));
+  A(h->d_initT.alloc(B * 16));
+  A(h->d_state.alloc(B));
+  A(h->h_state.alloc(B));
+  A(h->h_ndone.alloc(1));
+  A(h->h_m.alloc(C2));
+  A(h->h_initT.alloc(B * 16));
+#undef A
+  if (rc) return rc;
+  *out = h.release();
+  return GFS_OK;
+}
+
+void gfs_gicp_destroy(gfs_gicp* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void* dev_nt, const void* dev_source,
+                                const void* dev_ns, int B, int stride_pts, const double* init_T,
+                                const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream) {
+  GFS_REQUIRE(h && dev_target && dev_nt && dev_source && dev_ns && B > 0 && stride_pts > 0 && cfg && out,
+              GFS_ERR_INVALID_ARG, "gfs_gicp_align_batch_device: invalid argument");
+  GFS_REQUIRE(B <= h->Bmax, GFS_ERR_CAPACITY, "batch %d exceeds handle max_batch %d", B, h->Bmax);
+  GFS_REQUIRE(cfg->downsampling_resolution > 0 && cfg->max_correspondence_distance > 0 && cfg->num_neighbors >= 1 &&
+                  cfg->num_neighbors <= 10,
+              GFS_ERR_UNSUPPORTED, "gfs_gicp: need resolution > 0, max_corr > 0, 1 <= num_neighbors <= 10");
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const int P = h->P, C2 = 2 * B;
+  GicpParams prm;
+  prm.inv_leaf = 1.0 / cfg->downsampling_resolution;
+  prm.cell = cfg->max_correspondence_distance;
+  prm.inv_cell = 1.0 / prm.cell;
+  prm.max_dist_sq = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
+  prm.rot_eps = cfg->rotation_eps;
+  prm.trans_eps = cfg->translation_eps;
+  prm.max_iterations = cfg->max_iterations;
+  prm.k_neighbors = cfg->num_neighbors;
+  for (int b = 0; b < B; b++)
+    for (int k = 0; k < 16; k++) h->h_initT.p[16 * b + k] = init_T ? init_T[16 * b + k] : (k % 5 == 0 ? 1.0 : 0.0);
+  GFS_HIP(hipMemcpyAsync(h->d_initT.p, h->h_initT.p, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, sizeof(int), s));
+  const int npts = std::min(stride_pts, P);
+  // ---- preprocess_points x 2B (registration_helper.cpp:22-34)
+  GFS_LAUNCH("k_voxel_keys", k_voxel_keys, dim3(gfs::div_up(npts, 256), C2), dim3(256), 0, s, (const float4*)dev_target,
+             (const float4*)dev_source, (const int*)dev_nt, (const int*)dev_ns, stride_pts, P, prm.inv_leaf, h->d_keys0.p,
+             h->d_val0.p, h->d_counts.p);
+  GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
+             h->d_counts.p, P, h->d_which.p);
+  GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, (const float4*)dev_target,
+             (const float4*)dev_source, stride_pts, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p, h->d_which.p,
+             h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p, h->d_m.p);
+  GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p, h->d_ci1.p,
+             h->d_m.p, P, h->d_which2.p);
+  GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
+             h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p);
+  GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(gfs::div_up(npts, 128), C2), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
+             h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, P, prm, h->d_cov6.p);
+  // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
+  GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
+             prm.max_iterations, h->d_ndone.p);
+  const int nblk_run = gfs::div_up(npts, kLinBlock);
+  const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
+  for (int round = 0; round < max_rounds; round++) {
+    GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize, dim3(nblk_run, B), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
+               h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, P, prm, h->d_tgt_index.p, h->d_maha6.p,
+               h->d_partial.p, h->nblk);
+    GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(64), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk);
+    GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(nblk_run, B), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p, h->d_m.p, P,
+               h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk);
+    GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(64), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
+               h->d_ndone.p);
+    GFS_HIP(hipMemcpyAsync(h->h_ndone.p, h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipStreamSynchronize(s));
+    if (*h->h_ndone.p >= B) break;
+  }
+  GFS_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, (size_t)B * sizeof(PairState), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_m.p, h->d_m.p, (size_t)C2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int b = 0; b < B; b++) {
+    const PairState& S = h->h_state.p[b];
+    gfs_gicp_result& r = out[b];
+    memset(&r, 0, sizeof(r));
+    for (int c = 0; c < 3; c++)
+      for (int rr = 0; rr < 3; rr++) r.T_target_source[rr + 4 * c] = S.T[rr + 3 * c];
+    for (int rr = 0; rr < 3; rr++) r.T_target_source[12 + rr] = S.T[9 + rr];
+    r.T_target_source[15] = 1.0;
+    r.converged = S.converged;
+    r.iterations = (uint64_t)S.iterations;
+    r.num_inliers = (uint64_t)S.inliers;
+    int o = 0;
+    for (int rr = 0; rr < 6; rr++)
+      for (int c = rr; c < 6; c++) {
+        r.H[rr + 6 * c] = S.H[o];
+        r.H[c + 6 * rr] = S.H[o];
+        o++;
+      }
+    for (int k = 0; k < 6; k++) r.b[k] = S.b[k];
+    r.error = S.e;
+    r.n_target_downsampled = h->h_m.p[2 * b];
+    r.n_source_downsampled = h->h_m.p[2 * b + 1];
+    r.n_linearize = S.n_lin;
+    r.n_error_evals = S.n_err;
+  }
+  h->last_B = B;
+  return GFS_OK;
+}
+
+int gfs_gicp_align(gfs_gicp* h, const float* target_xyzw, int nt, const float* source_xyzw, int ns,
+                   const double init_T_target_source[16], const gfs_gicp_config* cfg, gfs_gicp_result* out) {
+  GFS_REQUIRE(h && target_xyzw && source_xyzw && nt >= 0 && ns >= 0 && cfg && out, GFS_ERR_INVALID_ARG,
+              "gfs_gicp_align: invalid argument");
+  GFS_REQUIRE(nt <= h->P && ns <= h->P, GFS_ERR_CAPACITY, "gfs_gicp_align: %d / %d points exceed capacity %d", nt, ns, h->P);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    GFS_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (nt) GFS_HIP(hipMemcpyAsync(h->d_in_t.p, target_xyzw, (size_t)nt * 16, hipMemcpyHostToDevice, s));
+    if (ns) GFS_HIP(hipMemcpyAsync(h->d_in_s.p, source_xyzw, (size_t)ns * 16, hipMemcpyHostToDevice, s));
+    GFS_HIP(hipMemcpyAsync(h->d_nt.p, &nt, sizeof(int), hipMemcpyHostToDevice, s));
+    GFS_HIP(hipMemcpyAsync(h->d_ns.p, &ns, sizeof(int), hipMemcpyHostToDevice, s));
+    GFS_HIP(hipStreamSynchronize(s));
+  }
+  return gfs_gicp_align_batch_device(h, h->d_in_t.p, h->d_nt.p, h->d_in_s.p, h->d_ns.p, 1, h->P, init_T_target_source, cfg,
+                                     out, nullptr);
+}
+
+int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, double* covs, int cap, int* m) {
+  GFS_REQUIRE(h && b >= 0 && b < h->last_B && (which == 0 || which == 1) && m, GFS_ERR_INVALID_ARG,
+              "gfs_gicp_fetch_preprocessed: invalid argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  GFS_HIP(hipDeviceSynchronize());
+  const int c = 2 * b + which;
+  int mm = 0;
+  GFS_HIP(hipMemcpy(&mm, h->d_m.p + c, sizeof(int), hipMemcpyDeviceToHost));
+  *m = mm;
+  GFS_REQUIRE(mm <= cap, GFS_ERR_CAPACITY, "gfs_gicp_fetch_preprocessed: %d points exceed capacity %d", mm, cap);
+  if (pts && mm) GFS_HIP(hipMemcpy(pts, h->d_pts.p + (size_t)c * h->P, (size_t)mm * 32, hipMemcpyDeviceToHost));
+  if (covs && mm) {
+    std::vector<double> c6((size_t)mm * 6);
+    GFS_HIP(hipMemcpy(c6.data(), h->d_cov6.p + (size_t)c * h->P * 6, (size_t)mm * 48, hipMemcpyDeviceToHost));
+    for (int i = 0; i < mm; i++) {
+      const double* s6 = &c6[(size_t)i * 6];
+      double* o = covs + (size_t)i * 9;
+      o[0] = s6[0];
+      o[1] = s6[1];
+      o[2] = s6[2];
+      o[3] = s6[1];
+      o[4] = s6[3];
+      o[5] = s6[4];
+      o[6] = s6[2];
+      o[7] = s6[4];
+      o[8] = s6[5];
+    }
+  }
+  return GFS_OK;
+}
+
+}  // extern "C"
