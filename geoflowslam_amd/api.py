@@ -403,3 +403,60 @@ def profile_report():
     cnt = np.zeros(cap, np.int64)
     n = lib().gfs_profile_report(names, _p(tot), _p(cnt), cap)
     return {names[i].value.decode(): (float(tot[i]), int(cnt[i])) for i in range(min(n, cap))}
+
+
+def _lba_problem(prob):
+    P = LbaProblem()
+    keep = {}
+    for name, dt in (("pose_q", np.float64), ("pose_t", np.float64), ("pose_fixed", np.uint8), ("points", np.float64),
+                     ("edge_pose", np.int32), ("edge_point", np.int32), ("edge_obs", np.float64),
+                     ("edge_inv_sigma2", np.float64), ("edge_stereo", np.uint8)):
+        keep[name] = np.ascontiguousarray(prob[name], dt)
+        setattr(P, name, keep[name].ctypes.data)
+    for name in ("n_poses", "n_points", "n_edges", "iterations"):
+        setattr(P, name, int(prob[name]))
+    for name in ("fx", "fy", "cx", "cy", "bf", "huber_mono", "huber_stereo"):
+        setattr(P, name, float(prob[name]))
+    return P, keep
+
+
+class Optimizer:
+    """The numeric core of ORB_SLAM3::Optimizer::LocalBundleAdjustment (reference include/Optimizer.h:62-65,
+    src/Optimizer.cc:1588-2040) on a flattened problem (see gfs_lba_problem in include/gfs_abi.h)."""
+
+    def __init__(self, max_poses=64, max_points=8192, max_edges=131072, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_lba_create(device, max_poses, max_points, max_edges, C.byref(self.h)), "gfs_lba_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gfs_lba_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def LocalBundleAdjustment(self, prob, stop_flag=None):
+        P, keep = _lba_problem(prob)
+        out = dict(pose_q=np.zeros((P.n_poses, 4)), pose_t=np.zeros((P.n_poses, 3)), points=np.zeros((P.n_points, 3)),
+                   edge_chi2=np.zeros(P.n_edges), edge_depth_positive=np.zeros(P.n_edges, np.uint8))
+        S = LbaSolution()
+        for k, v in out.items():
+            setattr(S, k, v.ctypes.data)
+        stop = stop_flag.ctypes.data_as(C.c_void_p) if stop_flag is not None else None
+        rc = lib().gfs_lba_solve(self.h, C.byref(P), C.byref(S), stop)
+        if rc == -6:  # GFS_ERR_STOPPED: the reference returns without touching the map (src/Optimizer.cc:1955-1956)
+            return None
+        _check(rc, "gfs_lba_solve")
+        out.update(iterations_run=S.iterations_run, final_chi2=S.final_chi2, final_lambda=S.final_lambda)
+        return out
+
+    def linearize(self, prob):
+        P, keep = _lba_problem(prob)
+        nf = int((np.asarray(prob["pose_fixed"]) == 0).sum())
+        Hpp = np.zeros((nf, 36)); Hll = np.zeros((P.n_points, 9)); Hpl = np.zeros((P.n_edges, 18))
+        bp = np.zeros((nf, 6)); bl = np.zeros((P.n_points, 3)); chi = np.zeros(P.n_edges)
+        tot = C.c_double()
+        _check(lib().gfs_lba_linearize(self.h, C.byref(P), _p(Hpp), _p(Hll), _p(Hpl), _p(bp), _p(bl), _p(chi),
+                                       C.byref(tot)), "gfs_lba_linearize")
+        return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
+                    Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=tot.value)

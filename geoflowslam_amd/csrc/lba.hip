@@ -1,0 +1,949 @@
+// Local bundle adjustment for gfx950 (MI355X): the numeric core of Optimizer::LocalBundleAdjustment
+// (reference src/Optimizer.cc:1588-2040): g2o BlockSolver_6_3 + OptimizationAlgorithmLevenberg on
+// VertexSE3Expmap / VertexSBAPointXYZ with EdgeSE3ProjectXYZ (mono) and EdgeStereoSE3ProjectXYZ (RGB-D) edges,
+// Huber kernels, Schur complement on the landmarks, 10 LM iterations with up to 10 lambda trials each.
+//
+// MI355X design: one window is far too small to feed 256 CUs (<= ~30 free poses, a few thousand landmarks), and
+// windows of one map cannot be sharded ("replicas only").  So ONE WORKGROUP (1024 threads, one CU)
+// runs the whole Levenberg-Marquardt loop of one window without any host round trip: every phase is a block-wide
+// parallel sweep separated by workgroup barriers, the reduced pose system (packed lower triangle, <= 180x180
+// doubles = 130 KB) lives in LDS for the Schur accumulation, the LDL^T factorisation and the triangular solves,
+// and all sums are taken in a fixed order (deterministic, unlike atomics).  Throughput scales by launching one
+// workgroup per window (grid = #windows).
+//
+// Edge order: edges are stably re-ordered landmark-major on the host so each landmark's observations are
+// contiguous (the reference builds them that way, src/Optimizer.cc:1816-1952); a second CSR lists each free
+// pose's edges; edge_of[free pose][landmark] gives O(1) co-visibility lookups for the Schur products.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <memory>
+#include <thread>
+
+#include "gfs_common.hpp"
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kMaxFree = 30;
+
+struct LbaDev {
+  // problem (edges landmark-major)
+  int n_poses, n_points, n_edges, n_free;
+  const double* pose_q0;  // [n_poses][4]
+  const double* pose_t0;  // [n_poses][3]
+  const int* free_index;  // [n_poses] -> free slot or -1
+  const int* free_pose;   // [n_free]  -> pose
+  const double* points0;  // [n_points][3]
+  const int* e_pose;
+  const int* e_point;
+  const double* e_obs;  // [n_edges][3]
+  const double* e_w;    // inv_sigma2
+  const unsigned char* e_stereo;
+  const int* pt_begin;     // [n_points+1]
+  const int* pose_begin;   // [n_free+1]
+  const int* pose_edges;   // edge ids (landmark-major numbering), ascending, per free pose
+  const int* edge_of;      // [n_free][n_points] edge id or -1
+  double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
+  int iterations;
+  // state / workspace
+  double* q;    // [n_poses][4] current
+  double* t;    // [n_poses][3]
+  double* X;    // [n_points][3]
+  double* q_try;
+  double* t_try;
+  double* X_try;
+  double* chi2;   // [n_edges] last computeActiveErrors
+  double* err;    // [n_edges][3]
+  double* Hpl;    // [n_edges][18] row-major (6 pose rows x 3 point cols)
+  double* Hll;    // [n_points][6] symmetric (xx,xy,xz,yy,yz,zz)
+  double* bl;     // [n_points][3]
+  double* Dinv;   // [n_points][6]
+  double* Hpp;    // [n_free][21] upper triangle row-major
+  double* bp;     // [n_free][6]
+  double* xl;     // [n_points][3]
+  double* xp;     // [n_free*6]
+  volatile int* stop;  // host-mapped force-stop flag
+  int* out_info;       // [0]=iterations_run [1]=failed flag
+  double* out_stats;   // [0]=final chi2 [1]=final lambda
+  int mode;            // 0 = full solve, 1 = linearise only
+};
+
+__device__ __forceinline__ void quat_rotate(const double* q, const double* v, double* o) {  // Eigen _transformVector
+  const double ux = 2 * (q[1] * v[2] - q[2] * v[1]), uy = 2 * (q[2] * v[0] - q[0] * v[2]), uz = 2 * (q[0] * v[1] - q[1] * v[0]);
+  o[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+  o[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+  o[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+}
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {  // row-major
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1 - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void normalize_rotation(double* q) {  // SE3Quat::normalizeRotation
+  if (q[3] < 0)
+    for (int i = 0; i < 4; i++) q[i] *= -1;
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; i++) q[i] /= n;
+}
+__device__ void R_to_quat(const double* m, double* q) {
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+    double qq[4];
+    qq[i] = 0.5 * t;
+    t = 0.5 / t;
+    qq[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+    qq[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    qq[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    for (int a = 0; a < 4; a++) q[a] = qq[a];
+  }
+}
+// VertexSE3Expmap::oplusImpl: estimate <- SE3Quat::exp(update) * estimate (types/se3quat.h:223-257, 101-107)
+__device__ void pose_oplus(const double* q_in, const double* t_in, const double* u, double* q_out, double* t_out) {
+  const double om[3] = {u[0], u[1], u[2]}, ups[3] = {u[3], u[4], u[5]};
+  const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+  double O2[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) O2[3 * r + c] = O[3 * r] * O[c] + O[3 * r + 1] * O[3 + c] + O[3 * r + 2] * O[6 + c];
+  double R[9], V[9];
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; i++) {
+      R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i];
+      V[i] = R[i];
+    }
+  } else {
+    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3.0);
+    for (int i = 0; i < 9; i++) {
+      R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+      V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i];
+    }
+  }
+  double eq[4], et[3];
+  R_to_quat(R, eq);
+  for (int r = 0; r < 3; r++) et[r] = V[3 * r] * ups[0] + V[3 * r + 1] * ups[1] + V[3 * r + 2] * ups[2];
+  normalize_rotation(eq);
+  double rt[3];
+  quat_rotate(eq, t_in, rt);
+  const double* a = eq;
+  const double* b = q_in;
+  double q[4];
+  q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  normalize_rotation(q);
+  for (int i = 0; i < 3; i++) t_out[i] = et[i] + rt[i];
+  for (int i = 0; i < 4; i++) q_out[i] = q[i];
+}
+
+__device__ __forceinline__ void huber(double e, double delta, double* rho0, double* rho1) {  // robust_kernel_impl.cpp:78-91
+  const double dsqr = delta * delta;
+  if (e <= dsqr) {
+    *rho0 = e;
+    *rho1 = 1.0;
+  } else {
+    const double sq = sqrt(e);
+    *rho0 = 2 * sq * delta - dsqr;
+    *rho1 = delta / sq;
+  }
+}
+
+// residual of one edge (computeError): types_six_dof_expmap.h:157-162 / .cpp:190-197 (float invz) and
+// include/OptimizableTypes.h:108-115 + src/CameraModels/Pinhole.cpp:35-41
+__device__ __forceinline__ void edge_residual(const LbaDev& D, int e, const double* q, const double* t, const double* X,
+                                              double* xc, double* r) {
+  const int pi = D.e_pose[e], li = D.e_point[e];
+  quat_rotate(q + 4 * pi, X + 3 * li, xc);
+  xc[0] += t[3 * pi];
+  xc[1] += t[3 * pi + 1];
+  xc[2] += t[3 * pi + 2];
+  const double* obs = D.e_obs + 3 * e;
+  if (D.e_stereo[e]) {
+    const float invz = (float)(1.0 / xc[2]);
+    const double u = xc[0] * (double)invz * D.fx + D.cx, v = xc[1] * (double)invz * D.fy + D.cy;
+    const float bf = (float)D.bf;
+    const double ur = u - (double)(bf * invz);
+    r[0] = obs[0] - u;
+    r[1] = obs[1] - v;
+    r[2] = obs[2] - ur;
+  } else {
+    r[0] = obs[0] - (D.fx * xc[0] / xc[2] + D.cx);
+    r[1] = obs[1] - (D.fy * xc[1] / xc[2] + D.cy);
+    r[2] = 0;
+  }
+}
+
+// linearizeOplus (types_six_dof_expmap.cpp:228-275; src/OptimizableTypes.cpp:134-154): Ji (3x3), Jj (3x6) row-major
+__device__ __forceinline__ void edge_jacobians(const LbaDev& D, int e, const double* q, const double* xc, double* Ji, double* Jj) {
+  double R[9];
+  quat_to_R(q + 4 * D.e_pose[e], R);
+  const double x = xc[0], y = xc[1], z = xc[2], fx = D.fx, fy = D.fy, bf = D.bf;
+  if (D.e_stereo[e]) {
+    const double z_2 = z * z;
+    for (int c = 0; c < 3; c++) {
+      Ji[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+      Ji[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+      Ji[6 + c] = Ji[c] - bf * R[6 + c] / z_2;
+    }
+    Jj[0] = x * y / z_2 * fx;
+    Jj[1] = -(1 + (x * x / z_2)) * fx;
+    Jj[2] = y / z * fx;
+    Jj[3] = -1. / z * fx;
+    Jj[4] = 0;
+    Jj[5] = x / z_2 * fx;
+    Jj[6] = (1 + y * y / z_2) * fy;
+    Jj[7] = -x * y / z_2 * fy;
+    Jj[8] = -x / z * fy;
+    Jj[9] = 0;
+    Jj[10] = -1. / z * fy;
+    Jj[11] = y / z_2 * fy;
+    Jj[12] = Jj[0] - bf * y / z_2;
+    Jj[13] = Jj[1] + bf * x / z_2;
+    Jj[14] = Jj[2];
+    Jj[15] = Jj[3];
+    Jj[16] = 0;
+    Jj[17] = Jj[5] - bf / z_2;
+  } else {
+    const double pj[6] = {-(fx / z), -0.0, -(-fx * x / (z * z)), -0.0, -(fy / z), -(-fy * y / (z * z))};
+    for (int r = 0; r < 2; r++)
+      for (int c = 0; c < 3; c++) Ji[r * 3 + c] = pj[r * 3] * R[c] + pj[r * 3 + 1] * R[3 + c] + pj[r * 3 + 2] * R[6 + c];
+    const double sd[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    for (int r = 0; r < 2; r++)
+      for (int c = 0; c < 6; c++) Jj[r * 6 + c] = pj[r * 3] * sd[c] + pj[r * 3 + 1] * sd[6 + c] + pj[r * 3 + 2] * sd[12 + c];
+    for (int c = 0; c < 3; c++) Ji[6 + c] = 0;
+    for (int c = 0; c < 6; c++) Jj[12 + c] = 0;
+  }
+}
+
+// deterministic block reductions (1024 threads): wave shuffle tree, then the 16 wave results in order
+__device__ double block_sum(double v, double* s16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_down(v, ofs, 64);
+  __syncthreads();
+  if (lane == 0) s16[wave] = v;
+  __syncthreads();
+  double r = 0;
+  for (int w = 0; w < 16; w++) r += s16[w];
+  return r;
+}
+__device__ double block_max(double v, double* s16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) v = fmax(v, __shfl_down(v, ofs, 64));
+  __syncthreads();
+  if (lane == 0) s16[wave] = v;
+  __syncthreads();
+  double r = 0;
+  for (int w = 0; w < 16; w++) r = fmax(r, s16[w]);
+  return r;
+}
+
+// SparseOptimizer::computeActiveErrors + activeRobustChi2 (core/sparse_optimizer.cpp:100-114)
+__device__ double compute_errors(const LbaDev& D, const double* q, const double* t, const double* X, double* s16) {
+  double local = 0;
+  for (int e = threadIdx.x; e < D.n_edges; e += kThreads) {
+    double xc[3], r[3];
+    edge_residual(D, e, q, t, X, xc, r);
+    const double c = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * D.e_w[e];
+    D.chi2[e] = c;
+    D.err[3 * e] = r[0];
+    D.err[3 * e + 1] = r[1];
+    D.err[3 * e + 2] = r[2];
+    double r0, r1;
+    huber(c, D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+    local += r0;
+  }
+  return block_sum(local, s16);
+}
+
+// BlockSolver::buildSystem + BaseBinaryEdge::constructQuadraticForm (block_solver.hpp:502-558, base_binary_edge.hpp:55-120)
+__device__ void build_system(const LbaDev& D, double* s16) {
+  // landmark sweep: Hll, bl and the per-edge pose-landmark blocks
+  for (int l = threadIdx.x; l < D.n_points; l += kThreads) {
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
+      double xc[3], r[3], Ji[9], Jj[18];
+      edge_residual(D, e, D.q, D.t, D.X, xc, r);
+      edge_jacobians(D, e, D.q, xc, Ji, Jj);
+      double r0, r1;
+      huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+      const double w = r1 * D.e_w[e];
+      double omr[3];
+      for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
+      int o = 0;
+      for (int a = 0; a < 3; a++) {
+        b[a] += Ji[a] * omr[0] + Ji[3 + a] * omr[1] + Ji[6 + a] * omr[2];
+        for (int c = a; c < 3; c++) H[o++] += Ji[a] * w * Ji[c] + Ji[3 + a] * w * Ji[3 + c] + Ji[6 + a] * w * Ji[6 + c];
+      }
+      if (D.free_index[D.e_pose[e]] >= 0) {
+        double* B = D.Hpl + 18 * (size_t)e;
+        for (int a = 0; a < 6; a++)
+          for (int c = 0; c < 3; c++) B[3 * a + c] = Jj[a] * w * Ji[c] + Jj[6 + a] * w * Ji[3 + c] + Jj[12 + a] * w * Ji[6 + c];
+      }
+    }
+    for (int k = 0; k < 6; k++) D.Hll[6 * (size_t)l + k] = H[k];
+    for (int k = 0; k < 3; k++) D.bl[3 * (size_t)l + k] = b[k];
+  }
+  // pose sweep: one wave per free pose, lanes over its edges, fixed-order shuffle reduction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int f = wave; f < D.n_free; f += 16) {
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] = 0;
+    for (int i = D.pose_begin[f] + lane; i < D.pose_begin[f + 1]; i += 64) {
+      const int e = D.pose_edges[i];
+      double xc[3], r[3], Ji[9], Jj[18];
+      edge_residual(D, e, D.q, D.t, D.X, xc, r);
+      edge_jacobians(D, e, D.q, xc, Ji, Jj);
+      double r0, r1;
+      huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+      const double w = r1 * D.e_w[e];
+      double omr[3];
+      for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
+      int o = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = a; c < 6; c++) acc[o++] += Jj[a] * w * Jj[c] + Jj[6 + a] * w * Jj[6 + c] + Jj[12 + a] * w * Jj[12 + c];
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * omr[0] + Jj[6 + a] * omr[1] + Jj[12 + a] * omr[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+      double v = acc[k];
+#pragma unroll
+      for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_down(v, ofs, 64);
+      if (lane == 0) {
+        if (k < 21)
+          D.Hpp[21 * f + k] = v;
+        else
+          D.bp[6 * f + (k - 21)] = v;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, i >= j
+
+__device__ __forceinline__ void inv3_sym(const double* h /*xx,xy,xz,yy,yz,zz*/, double lambda, double* o) {
+  const double a = h[0] + lambda, b = h[1], c = h[2], d = h[3] + lambda, e = h[4], f = h[5] + lambda;
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  const double id = 1.0 / det;
+  o[0] = c00 * id;
+  o[1] = c01 * id;
+  o[2] = c02 * id;
+  o[3] = (a * f - c * c) * id;
+  o[4] = (b * c - a * e) * id;
+  o[5] = (a * d - b * b) * id;
+}
+
+// BlockSolver::solve (block_solver.hpp:354-487): Schur complement in LDS, LDL^T, landmark back-substitution.
+// Returns false iff a zero / non-finite pivot appears (LinearSolverEigen reports failure).
+__device__ bool solve_schur(const LbaDev& D, double lambda, double* Hs, double* bs, double* s16, int* s_flag) {
+  const int n = 6 * D.n_free;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = threadIdx.x; l < D.n_points; l += kThreads) inv3_sym(D.Hll + 6 * (size_t)l, lambda, D.Dinv + 6 * (size_t)l);
+  for (int k = threadIdx.x; k < n * (n + 1) / 2; k += kThreads) Hs[k] = 0;
+  if (threadIdx.x == 0) *s_flag = 0;
+  __syncthreads();
+  // pose pairs (i1 >= i2), one wave per pair: Hs(i1,i2) = [i1==i2](Hpp + lambda I) - sum_l B_i1 Dinv_l B_i2^T
+  const int npairs = D.n_free * (D.n_free + 1) / 2;
+  for (int pr = wave; pr < npairs; pr += 16) {
+    int i1 = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+    while (i1 * (i1 + 1) / 2 > pr) i1--;
+    while ((i1 + 1) * (i1 + 2) / 2 <= pr) i1++;
+    const int i2 = pr - i1 * (i1 + 1) / 2;
+    double acc[36], accb[6];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) accb[k] = 0;
+    const int* eo = D.edge_of + (size_t)i2 * D.n_points;
+    for (int i = D.pose_begin[i1] + lane; i < D.pose_begin[i1 + 1]; i += 64) {
+      const int e1 = D.pose_edges[i];
+      const int l = D.e_point[e1];
+      const int e2 = eo[l];
+      if (e2 < 0) continue;
+      const double* Bi = D.Hpl + 18 * (size_t)e1;
+      const double* Bj = D.Hpl + 18 * (size_t)e2;
+      const double* Di = D.Dinv + 6 * (size_t)l;
+      const double d9[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
+      double BD[18];
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) BD[3 * a + c] = Bi[3 * a] * d9[c] + Bi[3 * a + 1] * d9[3 + c] + Bi[3 * a + 2] * d9[6 + c];
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[6 * a + c] += BD[3 * a] * Bj[3 * c] + BD[3 * a + 1] * Bj[3 * c + 1] + BD[3 * a + 2] * Bj[3 * c + 2];
+      if (i1 == i2) {
+        const double* bl = D.bl + 3 * (size_t)l;
+#pragma unroll
+        for (int a = 0; a < 6; a++) accb[a] += BD[3 * a] * bl[0] + BD[3 * a + 1] * bl[1] + BD[3 * a + 2] * bl[2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; k++) {
+      double v = acc[k];
+#pragma unroll
+      for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_down(v, ofs, 64);
+      if (lane == 0) {
+        const int a = k / 6, c = k % 6;
+        if (i1 != i2) {
+          Hs[tri(6 * i1 + a, 6 * i2 + c)] = -v;
+        } else if (a >= c) {
+          const int ua = c, uc = a;  // Hpp upper-triangle index of (c, a)
+          const double hpp = D.Hpp[21 * i1 + (ua * 6 - ua * (ua - 1) / 2 + (uc - ua))];
+          Hs[tri(6 * i1 + a, 6 * i1 + c)] = hpp + (a == c ? lambda : 0.0) - v;
+        }
+      }
+    }
+    if (i1 == i2) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        double v = accb[k];
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_down(v, ofs, 64);
+        if (lane == 0) bs[6 * i1 + k] = D.bp[6 * i1 + k] - v;
+      }
+    }
+  }
+  __syncthreads();
+  // LDL^T (right-looking) of the packed lower triangle; D on the diagonal, unit L below
+  for (int j = 0; j < n; j++) {
+    const double d = Hs[tri(j, j)];
+    if (threadIdx.x == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 1;
+    __syncthreads();
+    if (*s_flag) return false;
+    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) Hs[tri(i, j)] /= d;
+    __syncthreads();
+    const int m = n - j - 1;  // trailing size
+    for (int k = threadIdx.x; k < m * (m + 1) / 2; k += kThreads) {
+      int r = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
+      while (r * (r + 1) / 2 > k) r--;
+      while ((r + 1) * (r + 2) / 2 <= k) r++;
+      const int c = k - r * (r + 1) / 2;
+      const int ii = j + 1 + r, kk = j + 1 + c;
+      Hs[tri(ii, kk)] -= Hs[tri(ii, j)] * Hs[tri(kk, j)] * d;
+    }
+    __syncthreads();
+  }
+  // forward, diagonal, backward substitution on bs (in place)
+  for (int j = 0; j < n; j++) {
+    const double xj = bs[j];
+    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) bs[i] -= Hs[tri(i, j)] * xj;
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += kThreads) bs[i] /= Hs[tri(i, i)];
+  __syncthreads();
+  for (int j = n - 1; j >= 0; j--) {
+    const double xj = bs[j];
+    for (int i = threadIdx.x; i < j; i += kThreads) bs[i] -= Hs[tri(j, i)] * xj;
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += kThreads) D.xp[i] = bs[i];
+  // landmarks: xl = Dinv (bl - Hpl^T xp)
+  for (int l = threadIdx.x; l < D.n_points; l += kThreads) {
+    double cl[3] = {D.bl[3 * (size_t)l], D.bl[3 * (size_t)l + 1], D.bl[3 * (size_t)l + 2]};
+    for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
+      const int f = D.free_index[D.e_pose[e]];
+      if (f < 0) continue;
+      const double* B = D.Hpl + 18 * (size_t)e;
+      for (int c = 0; c < 3; c++)
+        for (int a = 0; a < 6; a++) cl[c] -= B[3 * a + c] * bs[6 * f + a];
+    }
+    const double* Di = D.Dinv + 6 * (size_t)l;
+    D.xl[3 * (size_t)l] = Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2];
+    D.xl[3 * (size_t)l + 1] = Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2];
+    D.xl[3 * (size_t)l + 2] = Di[2] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2];
+  }
+  __syncthreads();
+  return true;
+}
+
+// SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve
+// (core/sparse_optimizer.cpp:354-419, core/optimization_algorithm_levenberg.cpp:61-168)
+__global__ __launch_bounds__(kThreads) void k_lba(LbaDev D) {
+  extern __shared__ __align__(16) double lds[];
+  __shared__ double s16[16];
+  __shared__ int s_flag;
+  __shared__ double s_ctl[4];  // rho, accept flag
+  const int n = 6 * D.n_free;
+  double* Hs = lds;
+  double* bs = lds + (size_t)n * (n + 1) / 2;
+  // load the initial estimates (SE3Quat ctor normalises the quaternion, src/Optimizer.cc:1693-1694)
+  for (int i = threadIdx.x; i < D.n_poses; i += kThreads) {
+    double q[4] = {D.pose_q0[4 * i], D.pose_q0[4 * i + 1], D.pose_q0[4 * i + 2], D.pose_q0[4 * i + 3]};
+    normalize_rotation(q);
+    for (int k = 0; k < 4; k++) D.q[4 * i + k] = D.q_try[4 * i + k] = q[k];
+    for (int k = 0; k < 3; k++) D.t[3 * i + k] = D.t_try[3 * i + k] = D.pose_t0[3 * i + k];
+  }
+  for (int i = threadIdx.x; i < 3 * D.n_points; i += kThreads) D.X[i] = D.X_try[i] = D.points0[i];
+  __syncthreads();
+  const double tau = 1e-5, good_up = 2. / 3., good_lo = 1. / 3.;
+  double lambda = -1, ni = 2, last_chi = 0;
+  int n_bad = 0, iters = 0;
+  if (D.mode == 1 || D.iterations <= 0) {
+    const double chi = compute_errors(D, D.q, D.t, D.X, s16);
+    if (D.mode == 1) build_system(D, s16);
+    if (threadIdx.x == 0) {
+      D.out_info[0] = 0;
+      D.out_info[1] = 0;
+      D.out_stats[0] = chi;
+      D.out_stats[1] = 0;
+    }
+    return;
+  }
+  for (int iteration = 0; iteration < D.iterations; iteration++) {
+    if (threadIdx.x == 0) s_flag = *D.stop;  // SparseOptimizer::terminate(): one reader, block-uniform decision
+    __syncthreads();
+    const int stop_now = s_flag;
+    __syncthreads();
+    if (stop_now) break;
+    double current_chi = compute_errors(D, D.q, D.t, D.X, s16);
+    const double ini_chi = current_chi;
+    build_system(D, s16);
+    if (iteration == 0) {  // computeLambdaInit
+      double mx = 0;
+      for (int i = threadIdx.x; i < D.n_free * 6; i += kThreads) {
+        const int f = i / 6, a = i % 6;
+        mx = fmax(mx, fabs(D.Hpp[21 * f + (a * 6 - a * (a - 1) / 2)]));
+      }
+      for (int i = threadIdx.x; i < D.n_points * 3; i += kThreads) {
+        const int l = i / 3, a = i % 3;
+        mx = fmax(mx, fabs(D.Hll[6 * (size_t)l + (a == 0 ? 0 : a == 1 ? 3 : 5)]));
+      }
+      lambda = tau * block_max(mx, s16);
+      ni = 2;
+      n_bad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    bool stopped = false;
+    do {
+      const bool ok2 = n > 0 ? solve_schur(D, lambda, Hs, bs, s16, &s_flag) : true;
+      double temp_chi, scale = 0;
+      if (ok2) {
+        for (int f = threadIdx.x; f < D.n_free; f += kThreads) {
+          const int p = D.free_pose[f];
+          pose_oplus(D.q + 4 * p, D.t + 3 * p, D.xp + 6 * f, D.q_try + 4 * p, D.t_try + 3 * p);
+        }
+        for (int i = threadIdx.x; i < 3 * D.n_points; i += kThreads) D.X_try[i] = D.X[i] + D.xl[i];
+        __syncthreads();
+        temp_chi = compute_errors(D, D.q_try, D.t_try, D.X_try, s16);
+        double loc = 0;  // computeScale
+        for (int i = threadIdx.x; i < n; i += kThreads) {
+          const int f = i / 6, a = i % 6;
+          loc += D.xp[i] * (lambda * D.xp[i] + D.bp[6 * f + a]);
+        }
+        for (int i = threadIdx.x; i < 3 * D.n_points; i += kThreads) loc += D.xl[i] * (lambda * D.xl[i] + D.bl[i]);
+        scale = block_sum(loc, s16);
+      } else {
+        temp_chi = compute_errors(D, D.q, D.t, D.X, s16);
+        temp_chi = 1.79769313486231570e308;
+      }
+      rho = (current_chi - temp_chi) / (scale + 1e-3);
+      if (rho > 0 && isfinite(temp_chi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3.0);
+        alpha = fmin(alpha, good_up);
+        lambda *= fmax(good_lo, alpha);
+        ni = 2;
+        current_chi = temp_chi;
+        for (int f = threadIdx.x; f < D.n_free; f += kThreads) {  // discardTop: keep the trial
+          const int p = D.free_pose[f];
+          for (int k = 0; k < 4; k++) D.q[4 * p + k] = D.q_try[4 * p + k];
+          for (int k = 0; k < 3; k++) D.t[3 * p + k] = D.t_try[3 * p + k];
+        }
+        for (int i = threadIdx.x; i < 3 * D.n_points; i += kThreads) D.X[i] = D.X_try[i];
+      } else {
+        lambda *= ni;
+        ni *= 2;
+      }
+      if (threadIdx.x == 0) s_flag = *D.stop;
+      __syncthreads();
+      qmax++;
+      stopped = s_flag != 0;
+      __syncthreads();
+    } while (rho < 0 && qmax < 10 && !stopped);
+    iters++;
+    last_chi = current_chi;
+    if (qmax == 10 || rho == 0) break;
+    if ((ini_chi - current_chi) * 1e3 < ini_chi)
+      n_bad++;
+    else
+      n_bad = 0;
+    if (n_bad >= 3) break;
+  }
+  if (threadIdx.x == 0) {
+    D.out_info[0] = iters;
+    D.out_info[1] = 0;
+    D.out_stats[0] = last_chi;
+    D.out_stats[1] = lambda;
+  }
+}
+
+template <typename T>
+int upload(gfs::DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
+  if (h.empty()) return GFS_OK;
+  GFS_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return GFS_OK;
+}
+
+}  // namespace
+
+struct gfs_lba {
+  int device, max_poses, max_points, max_edges;
+  hipStream_t stream;
+  std::mutex mu;
+  int* h_stop = nullptr;  // host-mapped
+  gfs::DevBuf<double> d_q0, d_t0, d_X0, d_obs, d_w, d_q, d_t, d_X, d_qt, d_tt, d_Xt, d_chi2, d_err, d_Hpl, d_Hll, d_bl, d_Dinv,
+      d_Hpp, d_bp, d_xl, d_xp, d_stats;
+  gfs::DevBuf<int> d_free_index, d_free_pose, d_e_pose, d_e_point, d_pt_begin, d_pose_begin, d_pose_edges, d_edge_of, d_info;
+  gfs::DevBuf<unsigned char> d_stereo;
+};
+
+namespace {
+
+struct HostPrep {
+  std::vector<int> order;  // landmark-major position -> original edge
+  std::vector<int> free_index, free_pose, e_pose, e_point, pt_begin, pose_begin, pose_edges, edge_of;
+  std::vector<double> obs, w;
+  std::vector<unsigned char> stereo;
+  int n_free = 0;
+};
+
+int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
+  GFS_REQUIRE(p && p->n_poses >= 0 && p->n_points >= 0 && p->n_edges >= 0, GFS_ERR_INVALID_ARG, "gfs_lba: invalid problem");
+  GFS_REQUIRE(p->n_poses <= h->max_poses && p->n_points <= h->max_points && p->n_edges <= h->max_edges, GFS_ERR_CAPACITY,
+              "gfs_lba: problem (%d poses, %d points, %d edges) exceeds handle capacity (%d, %d, %d)", p->n_poses,
+              p->n_points, p->n_edges, h->max_poses, h->max_points, h->max_edges);
+  P.free_index.assign(p->n_poses, -1);
+  P.free_pose.clear();
+  for (int i = 0; i < p->n_poses; i++)
+    if (!p->pose_fixed[i]) {
+      P.free_index[i] = (int)P.free_pose.size();
+      P.free_pose.push_back(i);
+    }
+  P.n_free = (int)P.free_pose.size();
+  GFS_REQUIRE(P.n_free <= kMaxFree, GFS_ERR_UNSUPPORTED, "gfs_lba: %d free poses exceed the single-workgroup limit of %d",
+              P.n_free, kMaxFree);
+  const int E = p->n_edges, NP = p->n_points;
+  P.pt_begin.assign(NP + 1, 0);
+  for (int e = 0; e < E; e++) {
+    GFS_REQUIRE(p->edge_point[e] >= 0 && p->edge_point[e] < NP && p->edge_pose[e] >= 0 && p->edge_pose[e] < p->n_poses,
+                GFS_ERR_INVALID_ARG, "gfs_lba: edge %d references an unknown vertex", e);
+    P.pt_begin[p->edge_point[e] + 1]++;
+  }
+  for (int l = 0; l < NP; l++) P.pt_begin[l + 1] += P.pt_begin[l];
+  P.order.assign(E, 0);
+  {
+    std::vector<int> pos(P.pt_begin.begin(), P.pt_begin.end() - 1);
+    for (int e = 0; e < E; e++) P.order[pos[p->edge_point[e]]++] = e;  // stable
+  }
+  P.e_pose.resize(E);
+  P.e_point.resize(E);
+  P.obs.resize((size_t)E * 3);
+  P.w.resize(E);
+  P.stereo.resize(E);
+  P.pose_begin.assign(P.n_free + 1, 0);
+  P.edge_of.assign((size_t)P.n_free * NP, -1);
+  for (int k = 0; k < E; k++) {
+    const int e = P.order[k];
+    P.e_pose[k] = p->edge_pose[e];
+    P.e_point[k] = p->edge_point[e];
+    for (int c = 0; c < 3; c++) P.obs[3 * (size_t)k + c] = p->edge_obs[3 * (size_t)e + c];
+    P.w[k] = p->edge_inv_sigma2[e];
+    P.stereo[k] = p->edge_stereo[e] ? 1 : 0;
+    const int f = P.free_index[P.e_pose[k]];
+    if (f >= 0) {
+      P.pose_begin[f + 1]++;
+      GFS_REQUIRE(P.edge_of[(size_t)f * NP + P.e_point[k]] < 0, GFS_ERR_UNSUPPORTED,
+                  "gfs_lba: more than one edge between pose %d and point %d", P.e_pose[k], P.e_point[k]);
+      P.edge_of[(size_t)f * NP + P.e_point[k]] = k;
+    }
+  }
+  for (int f = 0; f < P.n_free; f++) P.pose_begin[f + 1] += P.pose_begin[f];
+  P.pose_edges.assign(P.pose_begin[P.n_free], 0);
+  {
+    std::vector<int> pos(P.pose_begin.begin(), P.pose_begin.end() - 1);
+    for (int k = 0; k < E; k++) {
+      const int f = P.free_index[P.e_pose[k]];
+      if (f >= 0) P.pose_edges[pos[f]++] = k;
+    }
+  }
+  return GFS_OK;
+}
+
+int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volatile const int* stop) {
+  hipStream_t s = h->stream;
+  const int E = p->n_edges, NP = p->n_points;
+  int rc;
+  if (p->n_poses) {
+    GFS_HIP(hipMemcpyAsync(h->d_q0.p, p->pose_q, (size_t)p->n_poses * 32, hipMemcpyHostToDevice, s));
+    GFS_HIP(hipMemcpyAsync(h->d_t0.p, p->pose_t, (size_t)p->n_poses * 24, hipMemcpyHostToDevice, s));
+  }
+  if (NP) GFS_HIP(hipMemcpyAsync(h->d_X0.p, p->points, (size_t)NP * 24, hipMemcpyHostToDevice, s));
+  if ((rc = upload(h->d_free_index, P.free_index, s)) || (rc = upload(h->d_free_pose, P.free_pose, s)) ||
+      (rc = upload(h->d_e_pose, P.e_pose, s)) || (rc = upload(h->d_e_point, P.e_point, s)) || (rc = upload(h->d_obs, P.obs, s)) ||
+      (rc = upload(h->d_w, P.w, s)) || (rc = upload(h->d_stereo, P.stereo, s)) || (rc = upload(h->d_pt_begin, P.pt_begin, s)) ||
+      (rc = upload(h->d_pose_begin, P.pose_begin, s)) || (rc = upload(h->d_pose_edges, P.pose_edges, s)) ||
+      (rc = upload(h->d_edge_of, P.edge_of, s)))
+    return rc;
+  if (E) GFS_HIP(hipMemsetAsync(h->d_Hpl.p, 0, (size_t)E * 18 * sizeof(double), s));
+  LbaDev D{};
+  D.n_poses = p->n_poses;
+  D.n_points = NP;
+  D.n_edges = E;
+  D.n_free = P.n_free;
+  D.pose_q0 = h->d_q0.p;
+  D.pose_t0 = h->d_t0.p;
+  D.free_index = h->d_free_index.p;
+  D.free_pose = h->d_free_pose.p;
+  D.points0 = h->d_X0.p;
+  D.e_pose = h->d_e_pose.p;
+  D.e_point = h->d_e_point.p;
+  D.e_obs = h->d_obs.p;
+  D.e_w = h->d_w.p;
+  D.e_stereo = h->d_stereo.p;
+  D.pt_begin = h->d_pt_begin.p;
+  D.pose_begin = h->d_pose_begin.p;
+  D.pose_edges = h->d_pose_edges.p;
+  D.edge_of = h->d_edge_of.p;
+  D.fx = p->fx;
+  D.fy = p->fy;
+  D.cx = p->cx;
+  D.cy = p->cy;
+  D.bf = p->bf;
+  D.huber_mono = p->huber_mono;
+  D.huber_stereo = p->huber_stereo;
+  D.iterations = p->iterations;
+  D.q = h->d_q.p;
+  D.t = h->d_t.p;
+  D.X = h->d_X.p;
+  D.q_try = h->d_qt.p;
+  D.t_try = h->d_tt.p;
+  D.X_try = h->d_Xt.p;
+  D.chi2 = h->d_chi2.p;
+  D.err = h->d_err.p;
+  D.Hpl = h->d_Hpl.p;
+  D.Hll = h->d_Hll.p;
+  D.bl = h->d_bl.p;
+  D.Dinv = h->d_Dinv.p;
+  D.Hpp = h->d_Hpp.p;
+  D.bp = h->d_bp.p;
+  D.xl = h->d_xl.p;
+  D.xp = h->d_xp.p;
+  int* d_stop = nullptr;
+  GFS_HIP(hipHostGetDevicePointer((void**)&d_stop, h->h_stop, 0));
+  *h->h_stop = 0;
+  D.stop = d_stop;
+  D.out_info = h->d_info.p;
+  D.out_stats = h->d_stats.p;
+  D.mode = mode;
+  const int n = 6 * P.n_free;
+  const size_t lds = ((size_t)n * (n + 1) / 2 + n + 8) * sizeof(double);
+  GFS_HIP(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GFS_LAUNCH("k_lba", k_lba, dim3(1), dim3(kThreads), lds, s, D);
+  // setForceStopFlag semantics (src/Optimizer.cc:1679): relay the caller's flag to the device-visible one
+  if (stop) {
+    while (hipStreamQuery(s) == hipErrorNotReady) {
+      if (*stop) *h->h_stop = 1;
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+  GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs_lba** out) {
+  GFS_REQUIRE(out && max_poses > 0 && max_points > 0 && max_edges > 0, GFS_ERR_INVALID_ARG, "gfs_lba_create: invalid argument");
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  std::unique_ptr<gfs_lba> h(new gfs_lba);
+  h->device = device;
+  h->max_poses = max_poses;
+  h->max_points = max_points;
+  h->max_edges = max_edges;
+  GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  GFS_HIP(hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped));
+  const size_t NP = max_points, E = max_edges, NQ = max_poses, F = kMaxFree;
+  int rc = 0;
+#define A(x) if (!rc) rc = (x)
+  A(h->d_q0.alloc(NQ * 4));
+  A(h->d_t0.alloc(NQ * 3));
+  A(h->d_X0.alloc(NP * 3));
+  A(h->d_obs.alloc(E * 3));
+  A(h->d_w.alloc(E));
+  A(h->d_q.alloc(NQ * 4));
+  A(h->d_t.alloc(NQ * 3));
+  A(h->d_X.alloc(NP * 3));
+  A(h->d_qt.alloc(NQ * 4));
+  A(h->d_tt.alloc(NQ * 3));
+  A(h->d_Xt.alloc(NP * 3));
+  A(h->d_chi2.alloc(E));
+  A(h->d_err.alloc(E * 3));
+  A(h->d_Hpl.alloc(E * 18));
+  A(h->d_Hll.alloc(NP * 6));
+  A(h->d_bl.alloc(NP * 3));
+  A(h->d_Dinv.alloc(NP * 6));
+  A(h->d_Hpp.alloc(F * 21));
+  A(h->d_bp.alloc(F * 6));
+  A(h->d_xl.alloc(NP * 3));
+  A(h->d_xp.alloc(F * 6));
+  A(h->d_stats.alloc(2));
+  A(h->d_free_index.alloc(NQ));
+  A(h->d_free_pose.alloc(F));
+  A(h->d_e_pose.alloc(E));
+  A(h->d_e_point.alloc(E));
+  A(h->d_pt_begin.alloc(NP + 1));
+  A(h->d_pose_begin.alloc(F + 1));
+  A(h->d_pose_edges.alloc(E));
+  A(h->d_edge_of.alloc(F * NP));
+  A(h->d_info.alloc(2));
+  A(h->d_stereo.alloc(E));
+#undef A
+  if (rc) return rc;
+  *out = h.release();
+  return GFS_OK;
+}
+
+void gfs_lba_destroy(gfs_lba* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamDestroy(h->stream);
+  if (h->h_stop) (void)hipHostFree(h->h_stop);
+  delete h;
+}
+
+int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, volatile const int* stop) {
+  GFS_REQUIRE(h && p && sol, GFS_ERR_INVALID_ARG, "gfs_lba_solve: NULL argument");
+  if (stop && *stop) {  // if (pbStopFlag) if (*pbStopFlag) return;  (src/Optimizer.cc:1955-1956)
+    gfs::set_error("gfs_lba_solve: stop flag raised before optimisation");
+    return GFS_ERR_STOPPED;
+  }
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  HostPrep P;
+  int rc = prepare(h, p, P);
+  if (rc) return rc;
+  rc = run(h, p, P, 0, stop);
+  if (rc) return rc;
+  hipStream_t s = h->stream;
+  const int E = p->n_edges, NP = p->n_points;
+  if (p->n_poses && sol->pose_q) GFS_HIP(hipMemcpyAsync(sol->pose_q, h->d_q.p, (size_t)p->n_poses * 32, hipMemcpyDeviceToHost, s));
+  if (p->n_poses && sol->pose_t) GFS_HIP(hipMemcpyAsync(sol->pose_t, h->d_t.p, (size_t)p->n_poses * 24, hipMemcpyDeviceToHost, s));
+  if (NP && sol->points) GFS_HIP(hipMemcpyAsync(sol->points, h->d_X.p, (size_t)NP * 24, hipMemcpyDeviceToHost, s));
+  std::vector<double> chi(E), q((size_t)p->n_poses * 4), t((size_t)p->n_poses * 3), X((size_t)NP * 3);
+  int info[2] = {0, 0};
+  double stats[2] = {0, 0};
+  if (E) GFS_HIP(hipMemcpyAsync(chi.data(), h->d_chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
+  if (p->n_poses) {
+    GFS_HIP(hipMemcpyAsync(q.data(), h->d_q.p, q.size() * 8, hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(t.data(), h->d_t.p, t.size() * 8, hipMemcpyDeviceToHost, s));
+  }
+  if (NP) GFS_HIP(hipMemcpyAsync(X.data(), h->d_X.p, X.size() * 8, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(info, h->d_info.p, sizeof(info), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(stats, h->d_stats.p, sizeof(stats), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < E; k++) {
+    const int e = P.order[k];
+    if (sol->edge_chi2) sol->edge_chi2[e] = chi[k];
+    if (sol->edge_depth_positive) {  // isDepthPositive() at the final estimates (host side, trivial)
+      const double* qq = &q[4 * (size_t)p->edge_pose[e]];
+      const double* v = &X[3 * (size_t)p->edge_point[e]];
+      const double ux = 2 * (qq[1] * v[2] - qq[2] * v[1]), uy = 2 * (qq[2] * v[0] - qq[0] * v[2]);
+      const double uz = 2 * (qq[0] * v[1] - qq[1] * v[0]);
+      const double z = v[2] + qq[3] * uz + (qq[0] * uy - qq[1] * ux) + t[3 * (size_t)p->edge_pose[e] + 2];
+      sol->edge_depth_positive[e] = z > 0.0;
+    }
+  }
+  sol->iterations_run = info[0];
+  sol->final_chi2 = stats[0];
+  sol->final_lambda = stats[1];
+  return GFS_OK;
+}
+
+int gfs_lba_linearize(gfs_lba* h, const gfs_lba_problem* p, double* Hpp, double* Hll, double* Hpl, double* bp, double* bl,
+                      double* edge_chi2, double* chi2) {
+  GFS_REQUIRE(h && p, GFS_ERR_INVALID_ARG, "gfs_lba_linearize: NULL argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  HostPrep P;
+  int rc = prepare(h, p, P);
+  if (rc) return rc;
+  rc = run(h, p, P, 1, nullptr);
+  if (rc) return rc;
+  const int E = p->n_edges, NP = p->n_points, F = P.n_free;
+  std::vector<double> hpp((size_t)F * 21), hll((size_t)NP * 6), hpl((size_t)E * 18), chi(E);
+  if (F) GFS_HIP(hipMemcpy(hpp.data(), h->d_Hpp.p, hpp.size() * 8, hipMemcpyDeviceToHost));
+  if (NP) GFS_HIP(hipMemcpy(hll.data(), h->d_Hll.p, hll.size() * 8, hipMemcpyDeviceToHost));
+  if (E) GFS_HIP(hipMemcpy(hpl.data(), h->d_Hpl.p, hpl.size() * 8, hipMemcpyDeviceToHost));
+  if (E) GFS_HIP(hipMemcpy(chi.data(), h->d_chi2.p, chi.size() * 8, hipMemcpyDeviceToHost));
+  if (bp && F) GFS_HIP(hipMemcpy(bp, h->d_bp.p, (size_t)F * 48, hipMemcpyDeviceToHost));
+  if (bl && NP) GFS_HIP(hipMemcpy(bl, h->d_bl.p, (size_t)NP * 24, hipMemcpyDeviceToHost));
+  double stats[2];
+  GFS_HIP(hipMemcpy(stats, h->d_stats.p, sizeof(stats), hipMemcpyDeviceToHost));
+  if (chi2) *chi2 = stats[0];
+  if (Hpp)
+    for (int f = 0; f < F; f++) {
+      int o = 0;
+      for (int a = 0; a < 6; a++)
+        for (int c = a; c < 6; c++) {
+          Hpp[36 * (size_t)f + a + 6 * c] = hpp[21 * (size_t)f + o];
+          Hpp[36 * (size_t)f + c + 6 * a] = hpp[21 * (size_t)f + o];
+          o++;
+        }
+    }
+  if (Hll)
+    for (int l = 0; l < NP; l++) {
+      const double* s6 = &hll[6 * (size_t)l];
+      double* o = Hll + 9 * (size_t)l;
+      o[0] = s6[0];
+      o[1] = o[3] = s6[1];
+      o[2] = o[6] = s6[2];
+      o[4] = s6[3];
+      o[5] = o[7] = s6[4];
+      o[8] = s6[5];
+    }
+  for (int k = 0; k < E; k++) {
+    const int e = P.order[k];
+    if (edge_chi2) edge_chi2[e] = chi[k];
+    if (Hpl)
+      for (int a = 0; a < 6; a++)
+        for (int c = 0; c < 3; c++) Hpl[18 * (size_t)e + a + 6 * c] = hpl[18 * (size_t)k + 3 * a + c];
+  }
+  return GFS_OK;
+}
+
+}  // extern "C"

@@ -148,3 +148,77 @@ def noise_image(seed, width, height):
         img[y0:y0 + h, x0:x0 + w] += rng.uniform(30, 120) * rng.choice([-1, 1])
     img += rng.integers(-2, 3, img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def _quat_from_R(R):
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(R).as_quat()  # x, y, z, w
+    return q if q[3] >= 0 else -q
+
+
+def lba_window(seed, n_free=20, n_fixed=5, n_points=3000, mono_frac=0.1, outlier_frac=0.03):
+    """Synthetic LocalBundleAdjustment window (BASELINE.json configs[4]): key-frames on a 2 m arc
+    looking at `n_points` points in a 6x4x3 m box; every point is observed by every key-frame whose frustum contains it;
+    RGB-D ("stereo", 3-D) edges, a fraction without depth (mono, 2-D); pixel noise sigma = sqrt(sigma2[octave]);
+    3 % gross outliers (20 px); key-frame poses perturbed by 1 cm / 0.3 deg, points by 2 cm.
+    Returns a dict of flat arrays matching gfs_lba_problem (include/gfs_abi.h) plus the ground truth."""
+    rng = np.random.default_rng(seed)
+    fx = fy = np.float64(np.float32(607.0))
+    cx, cy = np.float64(np.float32(319.5)), np.float64(np.float32(239.5))
+    bf = np.float64(np.float32(0.0745 * 607.0))
+    n_poses = n_free + n_fixed
+    pts = np.c_[rng.uniform(-3, 3, n_points), rng.uniform(-2, 2, n_points), rng.uniform(3.0, 6.0, n_points)]
+    Rs, ts = [], []
+    for i in range(n_poses):
+        a = (i / max(n_poses - 1, 1) - 0.5) * 0.8  # arc angle
+        c = np.array([2.0 * np.sin(a), 0.05 * rng.normal(), 2.0 - 2.0 * np.cos(a)])  # camera centre (world)
+        Rwc = _rot(0.02 * rng.normal(), -a + 0.02 * rng.normal(), 0.02 * rng.normal())
+        Rcw = Rwc.T
+        Rs.append(Rcw)
+        ts.append(-Rcw @ c)
+    sigma2 = np.float64(np.float32(1.2) ** (2 * np.arange(8))).astype(np.float64)
+    inv_sigma2 = np.float64(np.float32(1.0) / np.float32(1.2) ** (2 * np.arange(8)))
+    e_pose, e_point, e_obs, e_is2, e_stereo = [], [], [], [], []
+    for j in range(n_points):  # point-major edge order like the reference (src/Optimizer.cc:1816-1952)
+        for i in range(n_poses):
+            xc = Rs[i] @ pts[j] + ts[i]
+            if xc[2] < 0.3:
+                continue
+            u, v = fx * xc[0] / xc[2] + cx, fy * xc[1] / xc[2] + cy
+            if not (0 <= u < 640 and 0 <= v < 480):
+                continue
+            octv = int(rng.choice(8, p=np.array([217, 181, 151, 126, 105, 87, 73, 60]) / 1000.0))
+            s = np.sqrt(sigma2[octv])
+            noise = rng.normal(0, s, 3)
+            if rng.random() < outlier_frac:
+                noise[:2] += rng.choice([-1, 1], 2) * 20.0
+            stereo = rng.random() >= mono_frac
+            ur = u - bf / xc[2]
+            e_pose.append(i)
+            e_point.append(j)
+            e_obs.append([np.float32(u + noise[0]), np.float32(v + noise[1]), np.float32(ur + noise[2]) if stereo else -1.0])
+            e_is2.append(inv_sigma2[octv])
+            e_stereo.append(1 if stereo else 0)
+    fixed = np.zeros(n_poses, np.uint8)
+    fixed[n_free:] = 1
+    fixed[0] = 1 if n_fixed == 0 else fixed[0]
+    q_gt = np.array([_quat_from_R(R) for R in Rs])
+    t_gt = np.array(ts)
+    q0, t0 = q_gt.copy(), t_gt.copy()
+    for i in range(n_poses):
+        if fixed[i]:
+            continue
+        dR = _rot(*(np.deg2rad(0.3) * rng.normal(size=3)))
+        q0[i] = _quat_from_R(dR @ Rs[i])
+        t0[i] = dR @ ts[i] + 0.01 * rng.normal(size=3)
+    # the reference stores poses / points as float and widens them (src/Optimizer.cc:1692-1694, 1821)
+    q0 = q0.astype(np.float32).astype(np.float64)
+    t0 = t0.astype(np.float32).astype(np.float64)
+    p0 = (pts + 0.02 * rng.normal(size=pts.shape)).astype(np.float32).astype(np.float64)
+    return dict(n_poses=n_poses, n_points=n_points, n_edges=len(e_pose), pose_q=np.ascontiguousarray(q0),
+                pose_t=np.ascontiguousarray(t0), pose_fixed=fixed, points=np.ascontiguousarray(p0),
+                edge_pose=np.array(e_pose, np.int32), edge_point=np.array(e_point, np.int32),
+                edge_obs=np.array(e_obs, np.float64), edge_inv_sigma2=np.array(e_is2, np.float64),
+                edge_stereo=np.array(e_stereo, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
+                huber_mono=float(np.float32(np.sqrt(5.991))), huber_stereo=float(np.float32(np.sqrt(7.815))),
+                iterations=10, gt_q=q_gt, gt_t=t_gt, gt_points=pts)

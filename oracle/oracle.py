@@ -322,3 +322,42 @@ def se3_exp(twist):
     T = np.zeros(16)
     lib().gfso_se3_exp(_p(tw), _p(T))
     return T.reshape(4, 4).T.copy()
+
+
+def _lba_struct(cls, prob):
+    P = cls()
+    keep = {}
+    for name, dt in (("pose_q", np.float64), ("pose_t", np.float64), ("pose_fixed", np.uint8), ("points", np.float64),
+                     ("edge_pose", np.int32), ("edge_point", np.int32), ("edge_obs", np.float64),
+                     ("edge_inv_sigma2", np.float64), ("edge_stereo", np.uint8)):
+        keep[name] = np.ascontiguousarray(prob[name], dt)
+        setattr(P, name, keep[name].ctypes.data)
+    for name in ("n_poses", "n_points", "n_edges", "iterations"):
+        setattr(P, name, int(prob[name]))
+    for name in ("fx", "fy", "cx", "cy", "bf", "huber_mono", "huber_stereo"):
+        setattr(P, name, float(prob[name]))
+    return P, keep
+
+
+def lba_solve(prob):
+    """-> dict(pose_q, pose_t, points, edge_chi2, edge_depth_positive, iterations_run, final_chi2, final_lambda)"""
+    P, keep = _lba_struct(LbaProblem, prob)
+    out = dict(pose_q=np.zeros((P.n_poses, 4)), pose_t=np.zeros((P.n_poses, 3)), points=np.zeros((P.n_points, 3)),
+               edge_chi2=np.zeros(P.n_edges), edge_depth_positive=np.zeros(P.n_edges, np.uint8))
+    S = LbaSolution()
+    for k, v in out.items():
+        setattr(S, k, v.ctypes.data)
+    lib().gfso_lba_solve(C.byref(P), C.byref(S))
+    out.update(iterations_run=S.iterations_run, final_chi2=S.final_chi2, final_lambda=S.final_lambda)
+    return out
+
+
+def lba_linearize(prob):
+    """One buildSystem at the initial estimates -> dict(Hpp [nf,6,6], Hll [np,3,3], Hpl [ne,6,3], bp, bl, edge_chi2, chi2)"""
+    P, keep = _lba_struct(LbaProblem, prob)
+    nf = int((np.asarray(prob["pose_fixed"]) == 0).sum())
+    Hpp = np.zeros((nf, 36)); Hll = np.zeros((P.n_points, 9)); Hpl = np.zeros((P.n_edges, 18))
+    bp = np.zeros((nf, 6)); bl = np.zeros((P.n_points, 3)); chi = np.zeros(P.n_edges)
+    tot = lib().gfso_lba_linearize(C.byref(P), _p(Hpp), _p(Hll), _p(Hpl), _p(bp), _p(bl), _p(chi))
+    return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
+                Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=float(tot))
