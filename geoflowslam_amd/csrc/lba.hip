@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kThreads) void k_lba(LbaDev D) {
     int qmax = 0;
     bool stopped = false;
     do {
-      const bool ok2 = n > 0 ? solve_schur(D, lambda, Hs, bs, s16, &s_flag) : true;
+      const bool ok2 = solve_schur(D, lambda, Hs, bs, s16, &s_flag);
       double temp_chi, scale = 0;
       if (ok2) {
         for (int f = threadIdx.x; f < D.n_free; f += kThreads) {
