@@ -1,0 +1,191 @@
+// C++ host-side mirror of the reference's four seams on top of the C ABI (include/gfs_abi.h).
+//
+// The reference is C++17 (OpenCV / Eigen types in its signatures).  Neither library exists in this image, so
+// this header offers TWO layers:
+//   1. namespace gfs_host: the same classes with plain std:: containers (always compiled; used by the examples
+//      and by anything that does not want OpenCV / Eigen);
+//   2. namespace ORB_SLAM3 (guarded by GFS_WITH_OPENCV / GFS_WITH_EIGEN): drop-in classes with the reference's
+//      EXACT signatures —
+//        ORBextractor::operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&, cv::OutputArray,
+//                                 std::vector<int>&)                      include/ORBextractor.h:61-64
+//        ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)   include/ORBmatcher.h:41
+//        bf_match(d1, d2, std::vector<cv::DMatch>&)                       src/ORBmatcher.cc:755-756
+//        RegistrationGICP::RegisterPointClouds(...)                       include/RegistrationGICP.h:25-28
+//      INTEGRATION.md shows where they are swapped in.
+// Error behaviour follows the reference: operator() returns -1 on an empty image, asserts CV_8UC1; GICP never throws.
+// Anything the GPU library reports as an error is raised as std::runtime_error (there is no CPU fallback).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gfs_abi.h"
+
+namespace gfs_host {
+
+inline void check(int rc, const char* what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + ": " + gfs_last_error());
+}
+
+// ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:46-118)
+class ORBextractor {
+ public:
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int max_rows = 720,
+               int max_cols = 1280, int device = 0)
+      : nlevels_(nlevels) {
+    gfs_orb_config c;
+    gfs_orb_default_config(&c);
+    c.nfeatures = nfeatures;
+    c.scale_factor = scaleFactor;
+    c.nlevels = nlevels;
+    c.ini_th_fast = iniThFAST;
+    c.min_th_fast = minThFAST;
+    c.max_rows = max_rows;
+    c.max_cols = max_cols;
+    c.device = device;
+    check(gfs_orb_create(&c, &h_), "gfs_orb_create");
+    cap_ = gfs_orb_max_keypoints(h_);
+  }
+  ~ORBextractor() { gfs_orb_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // operator()(image, mask, keypoints, descriptors, vLappingArea): returns monoIndex, or -1 for an empty image
+  int operator()(const uint8_t* image, int rows, int cols, int stride, std::vector<gfs_keypoint>& keypoints,
+                 std::vector<uint8_t>& descriptors, const std::vector<int>& vLappingArea) {
+    keypoints.assign(cap_, gfs_keypoint{});
+    descriptors.assign((size_t)cap_ * 32, 0);
+    int n = 0;
+    const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+    const int r = gfs_orb_extract(h_, image, rows, cols, stride, lap0, lap1, keypoints.data(), descriptors.data(), cap_, &n);
+    if (r < -1) check(r + 100, "gfs_orb_extract");
+    keypoints.resize(n);
+    descriptors.resize((size_t)n * 32);
+    return r;
+  }
+  int GetLevels() const { return nlevels_; }
+  std::vector<float> GetScaleFactors() const { return table(0); }
+  std::vector<float> GetInverseScaleFactors() const { return table(1); }
+  std::vector<float> GetScaleSigmaSquares() const { return table(2); }
+  std::vector<float> GetInverseScaleSigmaSquares() const { return table(3); }
+  gfs_orb* handle() { return h_; }
+
+ private:
+  std::vector<float> table(int which) const {
+    std::vector<float> t[4];
+    for (auto& v : t) v.resize(nlevels_);
+    gfs_orb_get_tables(h_, t[0].data(), t[1].data(), t[2].data(), t[3].data(), nullptr, nullptr);
+    return t[which];
+  }
+  gfs_orb* h_ = nullptr;
+  int nlevels_, cap_ = 0;
+};
+
+struct DMatch {  // cv::DMatch
+  int queryIdx, trainIdx, imgIdx;
+  float distance;
+};
+
+// the brute-force part of ORB_SLAM3::ORBmatcher (reference src/ORBmatcher.cc:744-778, 2536-2550)
+class ORBmatcher {
+ public:
+  explicit ORBmatcher(int max_rows = 8192, int device = 0) { check(gfs_matcher_create(device, max_rows, max_rows, 1, &h_), "gfs_matcher_create"); }
+  ~ORBmatcher() { gfs_matcher_destroy(h_); }
+  static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return gfs_hamming256(a, b); }
+  // cv::BFMatcher(cv::NORM_HAMMING).match(query, train, matches)
+  void match(const uint8_t* query, int nq, const uint8_t* train, int nt, std::vector<DMatch>& matches) {
+    std::vector<int32_t> idx(nq > 0 ? nq : 1), dist(nq > 0 ? nq : 1);
+    const int n = gfs_bf_match_hamming(h_, query, nq, train, nt, idx.data(), dist.data());
+    check(n, "gfs_bf_match_hamming");
+    matches.resize(n);
+    for (int i = 0; i < n; i++) matches[i] = DMatch{i, idx[i], 0, (float)dist[i]};
+  }
+
+ private:
+  gfs_matcher* h_ = nullptr;
+};
+
+// RegistrationGICP (reference include/RegistrationGICP.h:19-31); result = small_gicp::RegistrationResult
+class RegistrationGICP {
+ public:
+  explicit RegistrationGICP(int max_points = 65536, int device = 0) { check(gfs_gicp_create(device, max_points, 1, &h_), "gfs_gicp_create"); }
+  ~RegistrationGICP() { gfs_gicp_destroy(h_); }
+  // target / source: arrays of (x, y, z, w) floats like std::vector<Eigen::Vector4f>; init: column-major 4x4
+  gfs_gicp_result RegisterPointClouds(const float* target_points, int nt, const float* source_points, int ns,
+                                      const double init_T_target_source[16]) {
+    gfs_gicp_config cfg;
+    gfs_gicp_default_config(&cfg);  // threads 4, voxel 0.02, max-corr 0.1, GICP (src/RegistrationGICP.cc:9-15)
+    gfs_gicp_result r;
+    check(gfs_gicp_align(h_, target_points, nt, source_points, ns, init_T_target_source, &cfg, &r), "gfs_gicp_align");
+    return r;
+  }
+
+ private:
+  gfs_gicp* h_ = nullptr;
+};
+
+// numeric core of Optimizer::LocalBundleAdjustment (reference include/Optimizer.h:62-65)
+class LocalBundleAdjuster {
+ public:
+  LocalBundleAdjuster(int max_poses = 64, int max_points = 16384, int max_edges = 262144, int device = 0) {
+    check(gfs_lba_create(device, max_poses, max_points, max_edges, &h_), "gfs_lba_create");
+  }
+  ~LocalBundleAdjuster() { gfs_lba_destroy(h_); }
+  // returns false when *pbStopFlag was already set (the reference returns early, src/Optimizer.cc:1955-1956)
+  bool solve(const gfs_lba_problem& p, gfs_lba_solution& s, const bool* pbStopFlag) {
+    volatile int stop = (pbStopFlag && *pbStopFlag) ? 1 : 0;
+    const int rc = gfs_lba_solve(h_, &p, &s, pbStopFlag ? &stop : nullptr);
+    if (rc == GFS_ERR_STOPPED) return false;
+    check(rc, "gfs_lba_solve");
+    return true;
+  }
+
+ private:
+  gfs_lba* h_ = nullptr;
+};
+
+}  // namespace gfs_host
+
+#if defined(GFS_WITH_OPENCV)
+#include <opencv2/core/core.hpp>
+#include <opencv2/features2d/features2d.hpp>
+#include <cassert>
+namespace ORB_SLAM3 {
+// Drop-in for the reference class (same name, same virtual operator()): see INTEGRATION.md §1.
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+      : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) {}
+  virtual ~ORBextractor() {}
+  virtual int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                         cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1);
+    std::vector<gfs_keypoint> k;
+    std::vector<uint8_t> d;
+    const int mono = impl_(image.data, image.rows, image.cols, (int)image.step, k, d, vLappingArea);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(gfs_keypoint), "cv::KeyPoint layout");
+    _keypoints.resize(k.size());
+    if (!k.empty()) memcpy((void*)_keypoints.data(), k.data(), k.size() * sizeof(gfs_keypoint));
+    if (k.empty())
+      _descriptors.release();
+    else {
+      _descriptors.create((int)k.size(), 32, CV_8U);
+      memcpy(_descriptors.getMat().data, d.data(), d.size());
+    }
+    return mono;
+  }
+  int GetLevels() { return impl_.GetLevels(); }
+  std::vector<float> GetScaleFactors() { return impl_.GetScaleFactors(); }
+  std::vector<float> GetInverseScaleFactors() { return impl_.GetInverseScaleFactors(); }
+  std::vector<float> GetScaleSigmaSquares() { return impl_.GetScaleSigmaSquares(); }
+  std::vector<float> GetInverseScaleSigmaSquares() { return impl_.GetInverseScaleSigmaSquares(); }
+
+ private:
+  gfs_host::ORBextractor impl_;
+};
+}  // namespace ORB_SLAM3
+#endif
