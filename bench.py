@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="run ORB+match and GICP back to back on one stream")
     ap.add_argument("--cpu-sample", type=int, default=32, help="frame pairs in the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -117,8 +118,10 @@ def main():
     mt = api.ORBmatcher(max_query=ext.cap, max_train=ext.cap, max_batch=B, device=local_rank)
     reg = api.RegistrationGICP(max_points=SP, max_batch=B, device=local_rank)
     stream = torch.cuda.Stream(device=dev)
-    sp = stream.cuda_stream
+    stream2 = torch.cuda.Stream(device=dev)
+    sp, sp2 = stream.cuda_stream, stream2.cuda_stream
     cap = ext.cap
+    pool = ThreadPoolExecutor(max_workers=2)
 
     # previous-frame features (the "keyframe" side of SearchWithGMS): computed once, kept in HBM
     ext.extract_batch_device(gray0.data_ptr(), B, H, W, (0, 0), sp)
@@ -135,12 +138,25 @@ def main():
     m_dist = torch.empty(B * cap, dtype=torch.int32, device=dev)
     last = {}
 
-    def step():
+    def orb_and_match():
         ext.extract_batch_device(gray1.data_ptr(), B, H, W, (0, 0), sp)
         mt.match_batch_device(prev_desc.data_ptr(), prev_cnt.data_ptr(), res["desc"], res["counts"], B, cap,
                               m_idx.data_ptr(), m_dist.data_ptr(), sp)
+
+    def gicp():
         last["gicp"] = reg.align_batch_device(d_c0.data_ptr(), d_n0.data_ptr(), d_c1.data_ptr(), d_n1.data_ptr(), B, SP,
-                                              None, None, sp)
+                                              None, None, sp2)
+
+    def step():
+        # ORB (+ its host quadtree) and GICP of the same batch are independent: two host threads, two HIP streams
+        # (ctypes releases the GIL), so the quadtree hides under the GICP kernels.
+        if args.serial:
+            orb_and_match()
+            gicp()
+        else:
+            f1, f2 = pool.submit(orb_and_match), pool.submit(gicp)
+            f1.result()
+            f2.result()
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,7 +223,23 @@ def main():
         from oracle import oracle as O
         O.lib()
         ncores = os.cpu_count() or 1
-        nsample = args.cpu_sample
+        orb0 = O.OrbOracle(NF, 1.2, NL, 20, 7)
+        prev_cpu = [orb0.extract(p["gray0"])[2] for p in pairs]
+        # (a) the reference's own threading: one frame at a time, ORB with OpenMP over the 8 levels
+        #     (src/ORBextractor.cc:775-777), GICP with 4 threads (src/RegistrationGICP.cc:10), match on all cores
+        orb0.set_threads(8)
+        O.gicp_set_threads(4)
+        nseq = max(8, min(args.cpu_sample, 64))
+        t1 = time.perf_counter()
+        for i in range(nseq):
+            p = pairs[i % nd]
+            _, _, d_cur = orb0.extract(p["gray1"])
+            O.bf_match(prev_cpu[i % nd], d_cur, nthreads=min(ncores, 16))
+            O.gicp_align(p["cloud0"], p["cloud1"])
+        dt_ref = time.perf_counter() - t1
+        orb0.set_threads(1)
+        O.gicp_set_threads(1)
+        # (b) all host cores: independent frame pairs on worker threads, each running the single-threaded oracle
         tl = threading.local()
 
         def one(i):
@@ -218,19 +250,16 @@ def main():
             O.bf_match(prev_cpu[i % nd], d_cur)
             O.gicp_align(p["cloud0"], p["cloud1"])
 
-        orb0 = O.OrbOracle(NF, 1.2, NL, 20, 7)
-        prev_cpu = [orb0.extract(p["gray0"])[2] for p in pairs]
-        t1 = time.perf_counter()
-        one(0)
-        single = time.perf_counter() - t1
+        nall = max(2 * ncores, 64)
         t1 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=ncores) as ex:
-            list(ex.map(one, range(nsample)))
-        dtc = time.perf_counter() - t1
-        cpu = dict(value=round(nsample / dtc, 3), unit="frames/s", cores=ncores, kind="port",
-                   sample=f"{nsample} VGA frame pairs (ORB 1000 feats + BF match 1000x1000 + GICP ~19k-pt clouds), "
-                          f"{ncores} worker threads each running the single-threaded CPU oracle on whole pairs",
-                   single_thread_frames_per_s=round(1.0 / single, 3),
+            list(ex.map(one, range(nall)))
+        dt_all = time.perf_counter() - t1
+        cpu = dict(value=round(nseq / dt_ref, 3), unit="frames/s", cores=8, kind="port",
+                   sample=f"{nseq} VGA frame pairs processed one at a time with the reference's threading: ORB 1000 feats "
+                          f"(OpenMP over 8 levels) + BF match 1000x1000 + GICP ~19k-pt clouds (4 threads, as hard-coded)",
+                   all_cores=dict(value=round(nall / dt_all, 3), cores=ncores,
+                                  sample=f"{nall} pairs on {ncores} worker threads, single-threaded oracle per pair"),
                    note="CPU restatement of the reference algorithm (reference not buildable here: OpenCV/Eigen/PCL absent)")
 
     if rank == 0:
@@ -250,6 +279,7 @@ def main():
         }
         if cpu:
             out["gpu_over_cpu"] = round(fps / cpu["value"], 2)
+            out["gpu_over_cpu_all_cores"] = round(fps / cpu["all_cores"]["value"], 2)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -39,6 +39,8 @@ typedef struct gfso_orb gfso_orb;
 gfso_orb* gfso_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
                           int blur_variant);
 void gfso_orb_destroy(gfso_orb*);
+/* OpenMP threads for timing runs (over levels / keypoints like the reference's ENABLE_OMP build); default 1 */
+void gfso_orb_set_threads(gfso_orb*, int n);
 /* ctor tables (src/ORBextractor.cc:421-479) */
 void gfso_orb_get_tables(const gfso_orb*, float* scale /*nlevels*/, float* inv_scale, float* sigma2,
                          float* inv_sigma2, int32_t* feats_per_level, int32_t* umax /*16*/);
@@ -104,6 +106,8 @@ void gfso_gicp_default_cfg(gfso_gicp_cfg*);
 /* on != 0: equal voxel keys are ordered by point index instead of by the reference's quick_sort_omp permutation
  * (util/sort_omp.hpp:58-85). Only which points fall on either side of a 1024-block split changes. Default 0. */
 void gfso_gicp_set_stable_voxel_order(int on);
+/* OpenMP threads for timing runs (the reference hard-codes 4, src/RegistrationGICP.cc:10); default 1 = deterministic */
+void gfso_gicp_set_threads(int n);
 /* RegistrationGICP::RegisterPointClouds, src/RegistrationGICP.cc:5-20 */
 void gfso_gicp_align(const float* target_xyzw, int nt, const float* source_xyzw, int ns, const double init_T[16],
                      const gfso_gicp_cfg* cfg, gfso_gicp_result* out);

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <omp.h>
+
 #include <vector>
 
 #include "gfs_oracle.h"
@@ -469,13 +471,14 @@ size_t knn(const KdTree& t, const V4& q, int k, size_t* idx, double* sqd) {
 }
 
 // ---- util/normal_estimation.hpp:13-92 (NormalCovarianceSetter) ----
-void estimate_normals_covariances(Cloud& cloud, const KdTree& tree, int num_neighbors) {
+void estimate_normals_covariances(Cloud& cloud, const KdTree& tree, int num_neighbors, int num_threads) {
   const size_t N = cloud.points.size();
   cloud.normals.assign(N, V4{0, 0, 0, 0});
   cloud.covs.assign(N, M3{});
-  std::vector<size_t> k_indices(num_neighbors);
-  std::vector<double> k_sq_dists(num_neighbors);
+#pragma omp parallel for num_threads(num_threads) if (num_threads > 1)  // util/normal_estimation_omp.hpp:21-26
   for (size_t pi = 0; pi < N; pi++) {
+    std::vector<size_t> k_indices(num_neighbors);
+    std::vector<double> k_sq_dists(num_neighbors);
     const size_t n = knn(tree, cloud.points[pi], num_neighbors, k_indices.data(), k_sq_dists.data());
     if (n < 5) {  // set_invalid: normal = 0, cov = diag(1,1,1,0)
       M3 c{};
@@ -520,12 +523,12 @@ void estimate_normals_covariances(Cloud& cloud, const KdTree& tree, int num_neig
 }
 
 // preprocess_points, registration_helper.cpp:22-34
-void preprocess(const float* xyzw, int n, const gfso_gicp_cfg& cfg, int stable_order, Cloud& out, KdTree& tree) {
+void preprocess(const float* xyzw, int n, const gfso_gicp_cfg& cfg, int stable_order, Cloud& out, KdTree& tree, int num_threads = 1) {
   std::vector<V4> pts(n);
   for (int i = 0; i < n; i++) pts[i] = {(double)xyzw[4 * i], (double)xyzw[4 * i + 1], (double)xyzw[4 * i + 2], 1.0};  // point_cloud.hpp:26-31
   voxelgrid_sampling(pts, cfg.downsampling_resolution, stable_order, out.points);
   tree.build(out.points);
-  estimate_normals_covariances(out, tree, cfg.num_neighbors);
+  estimate_normals_covariances(out, tree, cfg.num_neighbors, num_threads);
 }
 
 // ---- factors/gicp_factor.hpp:35-89 ----
@@ -623,15 +626,18 @@ void gfso_gicp_default_cfg(gfso_gicp_cfg* c) {
 }
 
 static int g_stable_order = 0;
+static int g_omp_threads = 1;  // 1 = deterministic; the reference hard-codes 4 (src/RegistrationGICP.cc:10) — used for timing
 void gfso_gicp_set_stable_voxel_order(int on) { g_stable_order = on; }
+void gfso_gicp_set_threads(int n) { g_omp_threads = n < 1 ? 1 : n; }
 
 void gfso_gicp_align(const float* target_xyzw, int nt, const float* source_xyzw, int ns, const double init_T[16],
                      const gfso_gicp_cfg* cfg, gfso_gicp_result* out) {
   // small_gicp::align<float,4>, registration_helper.cpp:57-69
   Cloud target, source;
   KdTree target_tree, source_tree;
-  preprocess(target_xyzw, nt, *cfg, g_stable_order, target, target_tree);
-  preprocess(source_xyzw, ns, *cfg, g_stable_order, source, source_tree);
+  const int NT = g_omp_threads;
+  preprocess(target_xyzw, nt, *cfg, g_stable_order, target, target_tree, NT);
+  preprocess(source_xyzw, ns, *cfg, g_stable_order, source, source_tree, NT);
   // Registration<GICPFactor, ParallelReductionOMP>::align, registration.hpp:33-43 +
   // LevenbergMarquardtOptimizer::optimize, optimizer.hpp:83-147
   const double max_dist_sq = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
@@ -650,12 +656,34 @@ void gfso_gicp_align(const float* target_xyzw, int nt, const float* source_xyzw,
     std::memset(H, 0, sizeof(H));
     std::memset(b, 0, sizeof(b));
     e = 0;
-    for (size_t s = 0; s < factors.size(); s++) {
-      double Hi[36], bi[6], ei;
-      if (!linearize(target, source, target_tree, T, s, max_dist_sq, factors[s], Hi, bi, &ei)) continue;
-      for (int k = 0; k < 36; k++) H[k] += Hi[k];
-      for (int k = 0; k < 6; k++) b[k] += bi[k];
-      e += ei;
+    if (NT == 1) {
+      for (size_t s = 0; s < factors.size(); s++) {
+        double Hi[36], bi[6], ei;
+        if (!linearize(target, source, target_tree, T, s, max_dist_sq, factors[s], Hi, bi, &ei)) continue;
+        for (int k = 0; k < 36; k++) H[k] += Hi[k];
+        for (int k = 0; k < 6; k++) b[k] += bi[k];
+        e += ei;
+      }
+    } else {  // per-thread sums folded thread 0..NT-1, reduction_omp.hpp:27-55
+      std::vector<std::array<double, 43>> part(NT);
+      for (auto& a : part) a.fill(0.0);
+#pragma omp parallel num_threads(NT)
+      {
+        const int tid = omp_get_thread_num();
+#pragma omp for schedule(guided, 8)
+        for (std::int64_t s = 0; s < (std::int64_t)factors.size(); s++) {
+          double Hi[36], bi[6], ei;
+          if (!linearize(target, source, target_tree, T, (size_t)s, max_dist_sq, factors[s], Hi, bi, &ei)) continue;
+          for (int k = 0; k < 36; k++) part[tid][k] += Hi[k];
+          for (int k = 0; k < 6; k++) part[tid][36 + k] += bi[k];
+          part[tid][42] += ei;
+        }
+      }
+      for (int t2 = 0; t2 < NT; t2++) {
+        for (int k = 0; k < 36; k++) H[k] += part[t2][k];
+        for (int k = 0; k < 6; k++) b[k] += part[t2][36 + k];
+        e += part[t2][42];
+      }
     }
     n_lin++;
     bool success = false;
@@ -666,7 +694,8 @@ void gfso_gicp_align(const float* target_xyzw, int nt, const float* source_xyzw,
       ldlt_solve6(A, rhs, delta);
       const Iso new_T = iso_mul(T, se3_exp(delta));
       double new_e = 0;
-      for (size_t s = 0; s < factors.size(); s++) new_e += factor_error(target, source, new_T, s, factors[s]);
+#pragma omp parallel for num_threads(NT) schedule(guided, 8) reduction(+ : new_e) if (NT > 1)  // reduction_omp.hpp:58-66
+      for (std::int64_t s = 0; s < (std::int64_t)factors.size(); s++) new_e += factor_error(target, source, new_T, (size_t)s, factors[s]);
       n_err++;
       if (new_e <= e) {
         const double dr = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);

@@ -155,6 +155,9 @@ class OrbOracle:
             self.L.gfso_orb_destroy(self.h)
             self.h = None
 
+    def set_threads(self, n):
+        self.L.gfso_orb_set_threads(C.c_void_p(self.h), int(n))
+
     def tables(self):
         n = self.nlevels
         sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
@@ -266,6 +269,10 @@ def bf_match(q, t, nthreads=1):
 
 def gicp_set_stable_voxel_order(on):
     lib().gfso_gicp_set_stable_voxel_order(int(on))
+
+
+def gicp_set_threads(n):
+    lib().gfso_gicp_set_threads(int(n))
 
 
 def gicp_default_cfg():

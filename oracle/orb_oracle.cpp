@@ -517,6 +517,7 @@ void computeOrbDescriptor(float angle_deg, float ptx, float pty, const uint8_t* 
 
 struct gfso_orb {
   int nfeatures, nlevels, iniThFAST, minThFAST, blur_variant;
+  int num_threads = 1;  // OpenMP over levels / keypoints like the reference's ENABLE_OMP build (src/ORBextractor.cc:775-777,1133-1137)
   double scaleFactor;  // include/ORBextractor.h:109 declares it double
   std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
   std::vector<int> mnFeaturesPerLevel, umax;
@@ -576,6 +577,7 @@ gfso_orb* gfso_orb_create(int nfeatures, float scale_factor, int nlevels, int in
 }
 
 void gfso_orb_destroy(gfso_orb* o) { delete o; }
+void gfso_orb_set_threads(gfso_orb* o, int n) { o->num_threads = n < 1 ? 1 : n; }
 
 void gfso_orb_get_tables(const gfso_orb* o, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
                          int32_t* feats, int32_t* umax) {
@@ -631,6 +633,7 @@ int gfso_orb_extract(gfso_orb* o, const uint8_t* img, int rows, int cols, int st
   o->cands.assign(nlevels, {});
   o->level_kps.assign(nlevels, {});
   const float W = 35;
+#pragma omp parallel for num_threads(o->num_threads) schedule(dynamic, 1) if (o->num_threads > 1)
   for (int level = 0; level < nlevels; ++level) {
     const Plane& P = o->pyr[level];
     const int minBorderX = EDGE_THRESHOLD - 3;
@@ -694,6 +697,9 @@ int gfso_orb_extract(gfso_orb* o, const uint8_t* img, int rows, int cols, int st
   o->blurred.assign(nlevels, {});
   int monoIndex = 0, stereoIndex = nkeypoints - 1;
   const bool emit = kps_out && desc_out && nkeypoints <= cap;
+  std::vector<std::vector<uint8_t>> level_desc(nlevels);
+  // blur + descriptors per level (independent of the packing order below, so they may run in parallel for timing)
+#pragma omp parallel for num_threads(o->num_threads) schedule(dynamic, 1) if (o->num_threads > 1)
   for (int level = 0; level < nlevels; ++level) {
     std::vector<gfso_keypoint>& keypoints = o->level_kps[level];
     if (keypoints.empty()) continue;
@@ -703,10 +709,15 @@ int gfso_orb_extract(gfso_orb* o, const uint8_t* img, int rows, int cols, int st
     for (int y = 0; y < P.rows; y++) std::memcpy(&clone[(size_t)y * P.cols], P.interior() + (size_t)y * P.stride, P.cols);
     o->blurred[level].resize(clone.size());
     gaussian_blur7(clone.data(), P.rows, P.cols, P.cols, o->blurred[level].data(), P.cols, o->blur_variant);
-    std::vector<uint8_t> desc(keypoints.size() * 32);
+    level_desc[level].resize(keypoints.size() * 32);
     for (size_t i = 0; i < keypoints.size(); i++)
       computeOrbDescriptor(keypoints[i].angle, keypoints[i].x, keypoints[i].y, o->blurred[level].data(), P.cols,
-                           &desc[i * 32]);
+                           &level_desc[level][i * 32]);
+  }
+  for (int level = 0; level < nlevels; ++level) {
+    std::vector<gfso_keypoint>& keypoints = o->level_kps[level];
+    if (keypoints.empty()) continue;
+    const std::vector<uint8_t>& desc = level_desc[level];
     float scale = o->mvScaleFactor[level];
     for (size_t i = 0; i < keypoints.size(); i++) {
       gfso_keypoint kp = keypoints[i];
