@@ -162,9 +162,9 @@ class ORBextractor:
         self.cap = L.gfs_orb_max_keypoints(self.h)
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().gfs_orb_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_orb_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -276,9 +276,9 @@ class ORBmatcher:
         _check(lib().gfs_matcher_create(device, max_query, max_train, max_batch, C.byref(self.h)), "gfs_matcher_create")
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().gfs_matcher_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_matcher_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -328,9 +328,9 @@ class RegistrationGICP:
         _check(lib().gfs_gicp_create(device, max_points, max_batch, C.byref(self.h)), "gfs_gicp_create")
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().gfs_gicp_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_gicp_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -383,9 +383,9 @@ class Timer:
         return ms.value
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().gfs_timer_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_timer_destroy(self.h)
+        self.h = None
 
 
 def profile_enable(on=True):
@@ -429,9 +429,9 @@ class Optimizer:
         _check(lib().gfs_lba_create(device, max_poses, max_points, max_edges, C.byref(self.h)), "gfs_lba_create")
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().gfs_lba_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_lba_destroy(self.h)
+        self.h = None
 
     __del__ = close
 

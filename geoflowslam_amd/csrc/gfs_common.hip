@@ -57,7 +57,7 @@ static hipEvent_t get_event() {
   return e;
 }
 
-void profile_begin(const char* name, hipStream_t s) {
+int profile_begin(const char* name, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.name = name;
@@ -65,11 +65,12 @@ void profile_begin(const char* name, hipStream_t s) {
   r.e1 = get_event();
   (void)hipEventRecord(r.e0, s);
   g_pending.push_back(r);
+  return (int)g_pending.size() - 1;
 }
 
-void profile_end(hipStream_t s) {
+void profile_end(int id, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_pending.empty()) (void)hipEventRecord(g_pending.back().e1, s);
+  if (id >= 0 && id < (int)g_pending.size()) (void)hipEventRecord(g_pending[id].e1, s);
 }
 
 static void profile_drain() {

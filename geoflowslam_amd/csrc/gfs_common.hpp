@@ -82,14 +82,14 @@ struct PinBuf {
 
 // ---- optional per-kernel timing (gfs_profile_*): HIP events recorded on the launch stream ----
 bool profile_on();
-void profile_begin(const char* name, hipStream_t s);
-void profile_end(hipStream_t s);
+int profile_begin(const char* name, hipStream_t s);  // returns a record id for profile_end (thread-safe)
+void profile_end(int id, hipStream_t s);
 
 #define GFS_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                        \
   do {                                                                                   \
-    if (::gfs::profile_on()) ::gfs::profile_begin(name, stream);                         \
+    const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin(name, stream) : -1;      \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                 \
-    if (::gfs::profile_on()) ::gfs::profile_end(stream);                                 \
+    if (_pid >= 0) ::gfs::profile_end(_pid, stream);                                     \
     hipError_t _le = hipGetLastError();                                                  \
     if (_le != hipSuccess) {                                                             \
       ::gfs::set_error("launch %s failed: %s (%s:%d)", name, hipGetErrorString(_le), __FILE__, __LINE__); \

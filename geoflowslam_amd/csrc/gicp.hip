@@ -14,6 +14,7 @@
 // and its two x-neighbours form a contiguous run: a 27-cell probe is 9 binary searches + 9 linear runs.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "gfs_common.hpp"
@@ -325,6 +326,93 @@ __device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense cell grid over the occupied-cell bounding box (+1 cell margin): G[lin(x,y,z)] = index of the first point
+// (in the cell-sorted array) whose cell key is >= that cell, G[ncell] = M.  Points are sorted by (z, y, x) and lin()
+// is the same lexicographic order, so the points of row (y, z) with x in [xlo, xhi] are exactly
+// [G[lin(xlo,y,z)], G[lin(xhi,y,z) + 1]) : a row lookup is two independent loads instead of two binary searches.
+// ginfo = {gx0, gy0, gz0, nx, ny, nz, ok}.  Clouds whose box exceeds kGridCap cells keep the binary-search path.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGridCap = 1 << 21;
+
+__global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
+                                                    const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
+                                                    const int* __restrict__ bbox, int P, unsigned* __restrict__ grid,
+                                                    int* __restrict__ ginfo) {
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nu = n_ucell[c], m = m_counts[c];
+  const u64* uc = ucell + (size_t)c * (P + 1);
+  const unsigned* ub = ubegin + (size_t)c * (P + 1);
+  unsigned* G = grid + (size_t)c * (kGridCap + 1);
+  const int gx0 = bbox[6 * c] - 1, gy0 = bbox[6 * c + 1] - 1, gz0 = bbox[6 * c + 2] - 1;
+  const long long nx = (long long)bbox[6 * c + 3] - gx0 + 2, ny = (long long)bbox[6 * c + 4] - gy0 + 2,
+                  nz = (long long)bbox[6 * c + 5] - gz0 + 2;
+  const bool ok = nu > 0 && nx > 0 && ny > 0 && nz > 0 && nx * ny * nz < (long long)kGridCap;
+  if (tid == 0) {
+    int* gi = ginfo + 8 * c;
+    gi[0] = gx0;
+    gi[1] = gy0;
+    gi[2] = gz0;
+    gi[3] = (int)nx;
+    gi[4] = (int)ny;
+    gi[5] = (int)nz;
+    gi[6] = ok ? 1 : 0;
+  }
+  if (!ok) return;
+  const int ncell = (int)(nx * ny * nz);
+  auto lin = [&](u64 key) {
+    const int x = (int)(key & kCoordMask), y = (int)((key >> kCoordBits) & kCoordMask), z = (int)(key >> (2 * kCoordBits));
+    return ((z - gz0) * (int)ny + (y - gy0)) * (int)nx + (x - gx0);
+  };
+  // every occupied cell fills the gap back to the previous occupied cell (lanes write contiguous entries)
+  const int per_wave = (nu + 15) / 16;
+  const int u_begin = wave * per_wave, u_end = min(u_begin + per_wave, nu);
+  for (int u = u_begin; u < u_end; u++) {
+    const int hi = lin(uc[u]), lo = u > 0 ? lin(uc[u - 1]) + 1 : 0;
+    const unsigned v = ub[u];
+    for (int k = lo + lane; k <= hi; k += 64) G[k] = v;
+  }
+  const int last = lin(uc[nu - 1]);
+  for (int k = last + 1 + tid; k <= ncell; k += 1024) G[k] = (unsigned)m;
+}
+
+// points of row (y, z) whose cell x lies in [xlo, xhi] -> [*j0, *j1)
+__device__ __forceinline__ void row_range(const int* __restrict__ gi, const unsigned* __restrict__ G, const u64* __restrict__ uc,
+                                          const unsigned* __restrict__ ub, int nu, int xlo, int xhi, int y, int z, int* j0,
+                                          int* j1) {
+  *j0 = 0;
+  *j1 = 0;
+  if (gi[6]) {
+    const int yy = y - gi[1], zz = z - gi[2];
+    if ((unsigned)yy >= (unsigned)gi[4] || (unsigned)zz >= (unsigned)gi[5]) return;
+    const int a = max(xlo - gi[0], 0), b = min(xhi - gi[0], gi[3] - 1);
+    if (a > b) return;
+    const size_t base = ((size_t)zz * gi[4] + yy) * gi[3];
+    *j0 = (int)G[base + a];
+    *j1 = (int)G[base + b + 1];
+  } else {
+    if (y < 0 || z < 0 || y > kCoordMask || z > kCoordMask) return;
+    const int u0 = lower_bound_u64(uc, nu, pack_key(max(xlo, 0), y, z));
+    const int u1 = lower_bound_u64(uc, nu, pack_key(min(xhi, kCoordMask), y, z) + 1);
+    *j0 = (int)ub[u0];
+    *j1 = (int)ub[u1];
+  }
+}
+
+// XCD-aware block -> (pair, which, chunk) map.  MI355X dispatches workgroup b to XCD b % 8 and every XCD has a private
+// 4 MiB L2: giving all chunks of one frame pair the same (b % 8) keeps that pair's ~1.5 MB of points / covariances /
+// grid resident in ONE L2 instead of being spread over (and evicted from) all eight.  Affects speed only.
+__device__ __forceinline__ bool xcd_pair_map(int nchunks, int npairs, int per_pair, int* pair, int* sub, int* chunk) {
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int span = per_pair * nchunks;
+  *pair = (slot / span) * 8 + xcd;
+  const int rem = slot % span;
+  *sub = rem / nchunks;
+  *chunk = rem % nchunks;
+  return *pair < npairs;
+}
+inline int xcd_grid(int nchunks, int npairs, int per_pair) { return ((npairs + 7) / 8) * 8 * per_pair * nchunks; }
+
+// ------------------------------------------------------------------------------------------------
 // Eigen 3.4 SelfAdjointEigenSolver<Matrix3d>::computeDirect (closed form) — same formulas as the oracle.
 // m: symmetric 3x3 as (xx, xy, xz, yy, yz, zz).  V column-major 3x3 (columns = eigenvectors, ascending).
 // ------------------------------------------------------------------------------------------------
@@ -467,16 +555,28 @@ struct TopK {
     }
     found = min(found + 1, K);
   }
+  __device__ double nth(int n) const {  // d[n] without dynamic register indexing (keeps the arrays out of scratch)
+    double v = d[K - 1];
+#pragma unroll
+    for (int i = 0; i < K; i++)
+      if (i == n) v = d[i];
+    return v;
+  }
 };
 
 __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts, const u64* __restrict__ ucell,
                                                  const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
                                                  const int* __restrict__ m_counts, const int* __restrict__ bbox,
-                                                 int P, GicpParams prm, double* __restrict__ cov6) {
-  const int c = blockIdx.y;
+                                                 const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
+                                                 int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
+  int pair, which, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
+  const int c = 2 * pair + which;
   const int m = m_counts[c];
-  const int i = blockIdx.x * 128 + threadIdx.x;
+  const int i = chunk * 128 + threadIdx.x;
   if (i >= m) return;
+  const unsigned* G = grid + (size_t)c * (kGridCap + 1);
+  const int* gi = ginfo + 8 * c;
   const double4* p = pts + (size_t)c * P;
   const u64* uc = ucell + (size_t)c * (P + 1);
   const unsigned* ub = ubegin + (size_t)c * (P + 1);
@@ -486,30 +586,60 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
             cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
   TopK<10> best;
   const int kk = min(prm.k_neighbors, 10);
+  const int want = min(kk, m);
   const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
             bz1 = bbox[6 * c + 5];
-  for (int r = 1;; r *= 2) {
+  // fast path: the 27-cell cube.  All 9 row ranges are fetched first (18 independent loads), the own row is scanned
+  // first so the k-th distance shrinks early, and candidates are loaded four at a time to keep loads in flight.
+  bool certified = false;
+  {
+    int j0s[9], j1s[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy + (t % 3) - 1, cz + t / 3 - 1, &j0s[t], &j1s[t]);
+    best.init();
+    constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+#pragma unroll
+    for (int tt = 0; tt < 9; tt++) {
+      const int t = order[tt];
+      const int jb = j0s[t], je = j1s[t];
+      for (int j = jb; j < je; j += 4) {
+        const double4 t0 = p[j], t1 = p[min(j + 1, je - 1)], t2 = p[min(j + 2, je - 1)], t3 = p[min(j + 3, je - 1)];
+        {
+          const double ddx = t0.x - q.x, ddy = t0.y - q.y, ddz = t0.z - q.z;
+          best.push(j, ddx * ddx + ddy * ddy + ddz * ddz);
+        }
+        if (j + 1 < je) {
+          const double ddx = t1.x - q.x, ddy = t1.y - q.y, ddz = t1.z - q.z;
+          best.push(j + 1, ddx * ddx + ddy * ddy + ddz * ddz);
+        }
+        if (j + 2 < je) {
+          const double ddx = t2.x - q.x, ddy = t2.y - q.y, ddz = t2.z - q.z;
+          best.push(j + 2, ddx * ddx + ddy * ddy + ddz * ddz);
+        }
+        if (j + 3 < je) {
+          const double ddx = t3.x - q.x, ddy = t3.y - q.y, ddz = t3.z - q.z;
+          best.push(j + 3, ddx * ddx + ddy * ddy + ddz * ddz);
+        }
+      }
+    }
+    certified = best.found >= want && best.nth(max(want - 1, 0)) <= prm.cell * prm.cell;
+  }
+  for (int r = 2; !certified; r *= 2) {  // rare: isolated points
     best.init();
     // rows outside the occupied-cell bounding box are empty: clamp the probe to it
     for (int z = max(cz - r, bz0); z <= min(cz + r, bz1); z++)
       for (int y = max(cy - r, by0); y <= min(cy + r, by1); y++) {
-        const u64 k0 = pack_key(max(cx - r, bx0), y, z), k1 = pack_key(min(cx + r, bx1), y, z);
-        int u = lower_bound_u64(uc, nu, k0);
-        if (u >= nu || uc[u] > k1) continue;
-        int u_end = u;
-        while (u_end < nu && uc[u_end] <= k1) u_end++;
-        const int j0 = (int)ub[u], j1 = (int)ub[u_end];
+        int j0, j1;
+        row_range(gi, G, uc, ub, nu, max(cx - r, bx0), min(cx + r, bx1), y, z, &j0, &j1);
         for (int j = j0; j < j1; j++) {
           const double4 t = p[j];
           const double ddx = t.x - q.x, ddy = t.y - q.y, ddz = t.z - q.z;
           best.push(j, ddx * ddx + ddy * ddy + ddz * ddz);
         }
       }
-    const int want = min(kk, m);
     const double reach = (double)r * prm.cell;
-    const double kth = kk == 10 ? best.d[9] : best.d[max(want - 1, 0)];
     const bool covers_all = cx - r <= bx0 && cx + r >= bx1 && cy - r <= by0 && cy + r >= by1 && cz - r <= bz0 && cz + r >= bz1;
-    if ((best.found >= want && kth <= reach * reach) || covers_all || r > kCoordMask) break;
+    if ((best.found >= want && best.nth(max(want - 1, 0)) <= reach * reach) || covers_all || r > kCoordMask) break;
   }
   const int n = min(best.found, kk);
   double* out = cov6 + ((size_t)c * P + i) * 6;
@@ -608,16 +738,21 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
                                                               const double* __restrict__ cov6, const u64* __restrict__ ucell,
                                                               const unsigned* __restrict__ ubegin,
                                                               const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
-                                                              int P, GicpParams prm, int* __restrict__ tgt_index,
-                                                              double* __restrict__ maha6, double* __restrict__ partial,
-                                                              int nblk) {
+                                                              const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
+                                                              int nchunks, int npairs, int P, GicpParams prm,
+                                                              int* __restrict__ tgt_index, double* __restrict__ maha6,
+                                                              double* __restrict__ partial, int nblk) {
   __shared__ double s_red[4 * kRed];
-  const int pair = blockIdx.y;
+  int pair, sub, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
   const PairState S = st[pair];
   if (S.phase != 0) return;
   const int ct = 2 * pair, cs = 2 * pair + 1;
   const int ms = m_counts[cs];
-  const int i = blockIdx.x * kLinBlock + threadIdx.x;
+  if (chunk * kLinBlock >= ms) return;
+  const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
+  const int* gi = ginfo + 8 * ct;
+  const int i = chunk * kLinBlock + threadIdx.x;
   double acc[kRed];
 #pragma unroll
   for (int k = 0; k < kRed; k++) acc[k] = 0;
@@ -639,17 +774,38 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
     if (fabs(tx) < 2.0e4 && fabs(ty) < 2.0e4 && fabs(tz) < 2.0e4) {
       // exact 1-NN by growing cubes of cells: after probing radius r every unvisited point is farther than r*cell,
       // so the search stops as soon as the best distance is certified (usually r = 1), or at nn_rings (>= max_corr).
-      for (int r = 1; r <= prm.nn_rings; r++) {
+      // r = 1 fast path: 9 row ranges fetched up-front, candidates loaded four at a time (loads kept in flight).
+      {
+        int j0s[9], j1s[9];
+#pragma unroll
+        for (int t9 = 0; t9 < 9; t9++)
+          row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy + (t9 % 3) - 1, cz + t9 / 3 - 1, &j0s[t9], &j1s[t9]);
+#pragma unroll
+        for (int t9 = 0; t9 < 9; t9++) {
+          const int jb = j0s[t9], je = j1s[t9];
+          for (int j = jb; j < je; j += 4) {
+            const int ja = min(j + 1, je - 1), jb2 = min(j + 2, je - 1), jc = min(j + 3, je - 1);
+            const double4 q0 = tp[j], q1 = tp[ja], q2 = tp[jb2], q3 = tp[jc];
+            const double d0 = (q0.x - tx) * (q0.x - tx) + (q0.y - ty) * (q0.y - ty) + (q0.z - tz) * (q0.z - tz);
+            const double d1 = (q1.x - tx) * (q1.x - tx) + (q1.y - ty) * (q1.y - ty) + (q1.z - tz) * (q1.z - tz);
+            const double d2 = (q2.x - tx) * (q2.x - tx) + (q2.y - ty) * (q2.y - ty) + (q2.z - tz) * (q2.z - tz);
+            const double d3 = (q3.x - tx) * (q3.x - tx) + (q3.y - ty) * (q3.y - ty) + (q3.z - tz) * (q3.z - tz);
+            // clamped duplicates of the last candidate cannot win the strict '<'
+            if (d0 < best) { best = d0; bj = j; }
+            if (d1 < best) { best = d1; bj = ja; }
+            if (d2 < best) { best = d2; bj = jb2; }
+            if (d3 < best) { best = d3; bj = jc; }
+          }
+        }
+      }
+      const bool done1 = (bj >= 0 && best <= prm.cell * prm.cell) || prm.nn_rings <= 1;
+      for (int r = 2; !done1 && r <= prm.nn_rings; r++) {
         best = 1.79769313486231570e308;
         bj = -1;
         for (int dz = -r; dz <= r; dz++)
           for (int dy = -r; dy <= r; dy++) {
-            const u64 k0 = pack_key(cx - r, cy + dy, cz + dz), k1 = pack_key(cx + r, cy + dy, cz + dz);
-            int u = lower_bound_u64(uc, nu, k0);
-            if (u >= nu || uc[u] > k1) continue;
-            int u_end = u;
-            while (u_end < nu && uc[u_end] <= k1) u_end++;
-            const int j0 = (int)ub[u], j1 = (int)ub[u_end];
+            int j0, j1;
+            row_range(gi, G, uc, ub, nu, cx - r, cx + r, cy + dy, cz + dz, &j0, &j1);
             for (int j = j0; j < j1; j++) {
               const double4 q = tp[j];
               const double dx = q.x - tx, dy2 = q.y - ty, dz2 = q.z - tz;
@@ -710,21 +866,23 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
     }
     tgt_index[(size_t)pair * P + i] = ti;
   }
-  block_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + blockIdx.x) * kRed, s_red);
+  block_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + chunk) * kRed, s_red);
 }
 
 // GICPFactor::error (factors/gicp_factor.hpp:76-86) with the frozen correspondences / Mahalanobis matrices.
 __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __restrict__ st, const double4* __restrict__ pts,
                                                            const int* __restrict__ m_counts, int P,
                                                            const int* __restrict__ tgt_index, const double* __restrict__ maha6,
-                                                           double* __restrict__ epartial, int nblk) {
+                                                           double* __restrict__ epartial, int nblk, int nchunks, int npairs) {
   __shared__ double s_red[4 * kRed];
-  const int pair = blockIdx.y;
+  int pair, sub, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
   const PairState& S = st[pair];
   if (S.phase != 1) return;
   const int ct = 2 * pair, cs = 2 * pair + 1;
   const int ms = m_counts[cs];
-  const int i = blockIdx.x * kLinBlock + threadIdx.x;
+  if (chunk * kLinBlock >= ms) return;
+  const int i = chunk * kLinBlock + threadIdx.x;
   double e[1] = {0.0};
   if (i < ms) {
     const int ti = tgt_index[(size_t)pair * P + i];
@@ -743,69 +901,69 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __res
       e[0] = 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
     }
   }
-  block_reduce_store<1>(e, epartial + (size_t)pair * nblk + blockIdx.x, s_red);
+  block_reduce_store<1>(e, epartial + (size_t)pair * nblk + chunk, s_red);
 }
 
-// (H + lambda I) delta = -b through a diagonally pivoted LDL^T (Eigen::LDLT), then new_T = T * se3_exp(delta)
-// (registration/optimizer.hpp:109-112, util/lie.hpp:54-103).
-__device__ void solve_and_propose(PairState& S) {
-  double A[36], rhs[6], x[6];
-  int o = 0;
-  for (int r = 0; r < 6; r++)
-    for (int c = r; c < 6; c++) {
-      A[r + 6 * c] = S.H[o];
-      A[c + 6 * r] = S.H[o];
-      o++;
-    }
-  for (int k = 0; k < 6; k++) {
-    A[7 * k] += S.lambda;
-    rhs[k] = -S.b[k];
-  }
-  int perm[6] = {0, 1, 2, 3, 4, 5};
-  for (int k = 0; k < 6; k++) {
-    int p = k;
-    double best = fabs(A[7 * k]);
-    for (int i = k + 1; i < 6; i++)
-      if (fabs(A[7 * i]) > best) {
-        best = fabs(A[7 * i]);
-        p = i;
-      }
-    if (p != k) {
-      for (int j = 0; j < 6; j++) {
-        const double t = A[k + 6 * j];
-        A[k + 6 * j] = A[p + 6 * j];
-        A[p + 6 * j] = t;
-      }
-      for (int j = 0; j < 6; j++) {
-        const double t = A[j + 6 * k];
-        A[j + 6 * k] = A[j + 6 * p];
-        A[j + 6 * p] = t;
-      }
-      const int t = perm[k];
-      perm[k] = perm[p];
-      perm[p] = t;
-    }
-    const double d = A[7 * k];
-    if (d == 0) continue;
-    for (int i = k + 1; i < 6; i++) A[i + 6 * k] /= d;
-    for (int j = k + 1; j < 6; j++)
-      for (int i = j; i < 6; i++) {
-        A[i + 6 * j] -= A[i + 6 * k] * d * A[j + 6 * k];
-        A[j + 6 * i] = A[i + 6 * j];
+// (H + lambda I) delta = -b, then new_T = T * se3_exp(delta) (registration/optimizer.hpp:109-112, util/lie.hpp:54-103).
+// H + lambda I is symmetric positive definite (lambda > 0), so an un-pivoted LDL^T is used: every loop has
+// compile-time bounds and everything stays in registers (Eigen's LDLT pivots; the solutions agree to rounding).
+__device__ void solve_and_propose(const double* H21, const double* b6, double lambda, const double* T12, double* delta6,
+                                  double* newT12) {
+  double A[6][6];
+  {
+    int o = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = r; c < 6; c++) {
+        A[r][c] = H21[o];
+        A[c][r] = H21[o];
+        o++;
       }
   }
-  double y[6];
-  for (int i = 0; i < 6; i++) y[i] = rhs[perm[i]];
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < i; j++) y[i] -= A[i + 6 * j] * y[j];
-  for (int i = 0; i < 6; i++) y[i] = A[7 * i] != 0 ? y[i] / A[7 * i] : 0;
-  for (int i = 5; i >= 0; i--)
-    for (int j = i + 1; j < 6; j++) y[i] -= A[j + 6 * i] * y[j];
-  for (int i = 0; i < 6; i++) x[perm[i]] = y[i];
-  for (int i = 0; i < 6; i++) S.delta[i] = x[i];
+#pragma unroll
+  for (int k = 0; k < 6; k++) A[k][k] += lambda;
+  double d[6], x[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = A[j][j];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < j) dj -= A[j][k] * A[j][k] * d[k];
+    d[j] = dj;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      if (i > j) {
+        double v = A[i][j];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          if (k < j) v -= A[i][k] * A[j][k] * d[k];
+        A[i][j] = dj != 0 ? v / dj : 0.0;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double v = -b6[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < i) v -= A[i][k] * x[k];
+    x[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = d[i] != 0 ? x[i] / d[i] : 0.0;
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double v = x[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k > i) v -= A[k][i] * x[k];
+    x[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) delta6[i] = x[i];
   // se3_exp
-  const double* w = x;
-  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double w0 = x[0], w1 = x[1], w2 = x[2];
+  const double theta_sq = w0 * w0 + w1 * w1 + w2 * w2;
   const double theta = sqrt(theta_sq);
   double imag, real;
   if (theta_sq < 1e-10) {
@@ -817,7 +975,7 @@ __device__ void solve_and_propose(PairState& S) {
     imag = sin(ht) / theta;
     real = cos(ht);
   }
-  const double qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+  const double qw = real, qx = imag * w0, qy = imag * w1, qz = imag * w2;
   double E[12];
   {
     const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
@@ -833,66 +991,100 @@ __device__ void solve_and_propose(PairState& S) {
     E[5] = tyz + twx;
     E[8] = 1 - (txx + tyy);
   }
-  const double* v = x + 3;
+  const double v0 = x[3], v1 = x[4], v2 = x[5];
   if (theta < 1e-10) {
-    for (int i = 0; i < 3; i++) E[9 + i] = E[i] * v[0] + E[i + 3] * v[1] + E[i + 6] * v[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) E[9 + i] = E[i] * v0 + E[i + 3] * v1 + E[i + 6] * v2;
   } else {
-    const double O[9] = {0, w[2], -w[1], -w[2], 0, w[0], w[1], -w[0], 0};
+    const double O[9] = {0, w2, -w1, -w2, 0, w0, w1, -w0, 0};
     double O2[9];
+#pragma unroll
     for (int c = 0; c < 3; c++)
+#pragma unroll
       for (int r = 0; r < 3; r++) O2[r + 3 * c] = O[r] * O[3 * c] + O[r + 3] * O[3 * c + 1] + O[r + 6] * O[3 * c + 2];
     const double k1 = (1.0 - cos(theta)) / theta_sq, k2 = (theta - sin(theta)) / (theta_sq * theta);
     double V[9];
+#pragma unroll
     for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + k1 * O[i] + k2 * O2[i];
-    for (int i = 0; i < 3; i++) E[9 + i] = V[i] * v[0] + V[i + 3] * v[1] + V[i + 6] * v[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) E[9 + i] = V[i] * v0 + V[i + 3] * v1 + V[i + 6] * v2;
   }
   // newT = T * E
-  const double* R = S.T;
-  const double* t = S.T + 9;
+#pragma unroll
   for (int c = 0; c < 3; c++)
-    for (int i = 0; i < 3; i++) S.newT[i + 3 * c] = R[i] * E[3 * c] + R[i + 3] * E[3 * c + 1] + R[i + 6] * E[3 * c + 2];
-  for (int i = 0; i < 3; i++) S.newT[9 + i] = R[i] * E[9] + R[i + 3] * E[10] + R[i + 6] * E[11] + t[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) newT12[i + 3 * c] = T12[i] * E[3 * c] + T12[i + 3] * E[3 * c + 1] + T12[i + 6] * E[3 * c + 2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) newT12[9 + i] = T12[i] * E[9] + T12[i + 3] * E[10] + T12[i + 6] * E[11] + T12[9 + i];
 }
 
-// after a linearise pass: fold the per-block partial sums in block order, first damped solve
-__global__ __launch_bounds__(64) void k_gicp_solve(PairState* __restrict__ st, const double* __restrict__ partial,
-                                                   const int* __restrict__ m_counts, int nblk_max) {
-  __shared__ double s_sum[kRed];
-  const int pair = blockIdx.x;
-  PairState& S = st[pair];
-  if (S.phase != 0) return;
-  const int ms = m_counts[2 * pair + 1];
-  const int nblk = (ms + kLinBlock - 1) / kLinBlock;
-  if (threadIdx.x < kRed) {
-    double a = 0;
-    for (int k = 0; k < nblk; k++) a += partial[((size_t)pair * nblk_max + k) * kRed + threadIdx.x];
-    s_sum[threadIdx.x] = a;
+// fixed-order sum of `n` per-block partial vectors of `stride` doubles: 8 strided sub-sums per component, then 8 -> 1
+template <int NCOMP>
+__device__ __forceinline__ void fold_partials(const double* __restrict__ part, int n, int stride, double* s_part /*[8][32]*/,
+                                              double* s_out /*[32]*/) {
+  const int comp = threadIdx.x & 31, sub = threadIdx.x >> 5;  // 256 threads = 32 components x 8 sub-sums
+  double a = 0;
+  if (comp < NCOMP)
+    for (int k = sub; k < n; k += 8) a += part[(size_t)k * stride + comp];
+  s_part[sub * 32 + comp] = a;
+  __syncthreads();
+  if (threadIdx.x < NCOMP) {
+    double v = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v += s_part[q * 32 + threadIdx.x];
+    s_out[threadIdx.x] = v;
   }
   __syncthreads();
+}
+
+// after a linearise pass: fold the per-block partial sums (fixed order), first damped solve
+__global__ __launch_bounds__(256) void k_gicp_solve(PairState* __restrict__ st, const double* __restrict__ partial,
+                                                    const int* __restrict__ m_counts, int nblk_max) {
+  __shared__ double s_part[8 * 32], s_sum[32];
+  const int pair = blockIdx.x;
+  if (st[pair].phase != 0) return;
+  const int ms = m_counts[2 * pair + 1];
+  const int nblk = (ms + kLinBlock - 1) / kLinBlock;
+  fold_partials<kRed>(partial + (size_t)pair * nblk_max * kRed, nblk, kRed, s_part, s_sum);
   if (threadIdx.x == 0) {
-    for (int k = 0; k < 21; k++) S.H[k] = s_sum[k];
-    for (int k = 0; k < 6; k++) S.b[k] = s_sum[21 + k];
+    PairState& S = st[pair];
+    double H[21], b[6], T[12], delta[6], newT[12];
+#pragma unroll
+    for (int k = 0; k < 21; k++) H[k] = s_sum[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) b[k] = s_sum[21 + k];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = S.T[k];
+    solve_and_propose(H, b, S.lambda, T, delta, newT);
+#pragma unroll
+    for (int k = 0; k < 21; k++) S.H[k] = H[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) S.b[k] = b[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) S.delta[k] = delta[k];
+#pragma unroll
+    for (int k = 0; k < 12; k++) S.newT[k] = newT[k];
     S.e = s_sum[27];
     S.inliers = (int)(s_sum[28] + 0.5);
     S.n_lin++;
     S.inner = 0;
-    solve_and_propose(S);
     S.phase = 1;
   }
 }
 
 // after an error pass: accept / reject the trial (registration/optimizer.hpp:115-141)
-__global__ __launch_bounds__(64) void k_gicp_decide(PairState* __restrict__ st, const double* __restrict__ epartial,
-                                                    const int* __restrict__ m_counts, int nblk_max, GicpParams prm,
-                                                    int* __restrict__ n_done) {
+__global__ __launch_bounds__(256) void k_gicp_decide(PairState* __restrict__ st, const double* __restrict__ epartial,
+                                                     const int* __restrict__ m_counts, int nblk_max, GicpParams prm,
+                                                     int* __restrict__ n_done) {
+  __shared__ double s_part[8 * 32], s_sum[32];
   const int pair = blockIdx.x;
-  PairState& S = st[pair];
-  if (S.phase != 1) return;
-  if (threadIdx.x != 0) return;
+  if (st[pair].phase != 1) return;
   const int ms = m_counts[2 * pair + 1];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
-  double new_e = 0;
-  for (int k = 0; k < nblk; k++) new_e += epartial[(size_t)pair * nblk_max + k];
+  fold_partials<1>(epartial + (size_t)pair * nblk_max, nblk, 1, s_part, s_sum);
+  if (threadIdx.x != 0) return;
+  PairState& S = st[pair];
+  const double new_e = s_sum[0];
   S.n_err++;
   if (new_e <= S.e) {
     const double dr = sqrt(S.delta[0] * S.delta[0] + S.delta[1] * S.delta[1] + S.delta[2] * S.delta[2]);
@@ -916,7 +1108,18 @@ __global__ __launch_bounds__(64) void k_gicp_decide(PairState* __restrict__ st, 
       S.phase = 2;
       atomicAdd(n_done, 1);
     } else {
-      solve_and_propose(S);
+      double H[21], b[6], T[12], delta[6], newT[12];
+#pragma unroll
+      for (int k = 0; k < 21; k++) H[k] = S.H[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) b[k] = S.b[k];
+#pragma unroll
+      for (int k = 0; k < 12; k++) T[k] = S.T[k];
+      solve_and_propose(H, b, S.lambda, T, delta, newT);
+#pragma unroll
+      for (int k = 0; k < 6; k++) S.delta[k] = delta[k];
+#pragma unroll
+      for (int k = 0; k < 12; k++) S.newT[k] = newT[k];
     }
   }
 }
@@ -952,9 +1155,9 @@ struct gfs_gicp {
   hipStream_t stream;
   std::mutex mu;
   gfs::DevBuf<float4> d_in_t, d_in_s;  // staging for the host-pointer entry
-  gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox;
+  gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox, d_ginfo;
   gfs::DevBuf<u64> d_keys0, d_keys1, d_ck0, d_ck1, d_ucell;
-  gfs::DevBuf<unsigned> d_val0, d_val1, d_ci0, d_ci1, d_ubegin;
+  gfs::DevBuf<unsigned> d_val0, d_val1, d_ci0, d_ci1, d_ubegin, d_grid;
   gfs::DevBuf<double4> d_tmp, d_pts;
   gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
   gfs::DevBuf<PairState> d_state;
@@ -1000,6 +1203,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_m.alloc(C2));
   A(h->d_nucell.alloc(C2));
   A(h->d_bbox.alloc(C2 * 6));
+  A(h->d_ginfo.alloc(C2 * 8));
+  A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
   A(h->d_ndone.alloc(1));
   A(h->d_keys0.alloc(C2 * P));
   A(h->d_keys1.alloc(C2 * P));
@@ -1057,6 +1262,7 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
   // spacing) every 10-NN probe.  Measured on MI355X (profiles/r01a vs a 0.04 m cell): the per-row lookups, not
   // the candidate scans, dominate, so fewer / larger cells win until the probes are LDS-tiled.
   prm.cell = cfg->max_correspondence_distance;
+  if (const char* e = getenv("GFS_GICP_CELL")) prm.cell = atof(e);  // experiment knob (results are exact for any cell size)
   prm.inv_cell = 1.0 / prm.cell;
   prm.nn_rings = (int)std::ceil(cfg->max_correspondence_distance / prm.cell - 1e-12);
   if (prm.nn_rings < 1) prm.nn_rings = 1;
@@ -1083,21 +1289,25 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
              h->d_m.p, P, h->d_which2.p);
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
              h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p);
-  GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(gfs::div_up(npts, 128), C2), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
-             h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, P, prm, h->d_cov6.p);
+  GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(C2), dim3(1024), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
+             h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p);
+  const int knn_chunks = gfs::div_up(npts, 128);
+  GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(xcd_grid(knn_chunks, B, 2)), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
+             h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, knn_chunks, B, P, prm,
+             h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
   GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
              prm.max_iterations, h->d_ndone.p);
   const int nblk_run = gfs::div_up(npts, kLinBlock);
   const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
   for (int round = 0; round < max_rounds; round++) {
-    GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize, dim3(nblk_run, B), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
-               h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, P, prm, h->d_tgt_index.p, h->d_maha6.p,
-               h->d_partial.p, h->nblk);
-    GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(64), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk);
-    GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(nblk_run, B), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p, h->d_m.p, P,
-               h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk);
-    GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(64), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
+    GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
+               h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
+               nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
+    GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk);
+    GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
+               h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B);
+    GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
                h->d_ndone.p);
     GFS_HIP(hipMemcpyAsync(h->h_ndone.p, h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
     GFS_HIP(hipStreamSynchronize(s));
