@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run ORB+match and GICP back to back on one stream")
+    ap.add_argument("--lanes", type=int, default=2, help="independent slices of the batch processed concurrently per GPU")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
+    ap.add_argument("--all-ranks-device0", action="store_true", help="dry-run aid: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="frame pairs in the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -84,7 +87,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.all_ranks_device0:
+            local_rank = 0
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -114,49 +122,69 @@ def main():
         n0[b], n1[b] = len(a), len(bb)
     d_c0, d_c1, d_n0, d_n1 = to_dev(c0), to_dev(c1), to_dev(n0), to_dev(n1)
 
-    ext = api.ORBextractor(NF, 1.2, NL, 20, 7, max_rows=H, max_cols=W, max_batch=B, device=local_rank)
-    mt = api.ORBmatcher(max_query=ext.cap, max_train=ext.cap, max_batch=B, device=local_rank)
-    reg = api.RegistrationGICP(max_points=SP, max_batch=B, device=local_rank)
-    stream = torch.cuda.Stream(device=dev)
-    stream2 = torch.cuda.Stream(device=dev)
-    sp, sp2 = stream.cuda_stream, stream2.cuda_stream
-    cap = ext.cap
-    pool = ThreadPoolExecutor(max_workers=2)
-
-    # previous-frame features (the "keyframe" side of SearchWithGMS): computed once, kept in HBM
-    ext.extract_batch_device(gray0.data_ptr(), B, H, W, (0, 0), sp)
-    res = ext.device_results()
-    stream.synchronize()
     import ctypes as C
-    prev_desc = torch.empty(B * cap * 32, dtype=torch.uint8, device=dev)
-    prev_cnt = torch.empty(B, dtype=torch.int32, device=dev)
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    assert hip.hipMemcpy(prev_desc.data_ptr(), res["desc"], B * cap * 32, 3) == 0
-    assert hip.hipMemcpy(prev_cnt.data_ptr(), res["counts"], B * 4, 3) == 0
-    m_idx = torch.empty(B * cap, dtype=torch.int32, device=dev)
-    m_dist = torch.empty(B * cap, dtype=torch.int32, device=dev)
+    from geoflowslam_amd.shard import shard_range
+
+    class Lane:
+        """One independent slice of the batch with its own handles, HIP streams and host threads.  Several lanes in
+        flight keep the GPU busy while another lane's host work (quadtree, LM convergence polling) runs."""
+
+        def __init__(self, b0, b1):
+            self.b0, self.n = b0, b1 - b0
+            n = self.n
+            self.ext = api.ORBextractor(NF, 1.2, NL, 20, 7, max_rows=H, max_cols=W, max_batch=n, device=local_rank)
+            self.cap = self.ext.cap
+            self.mt = api.ORBmatcher(max_query=self.cap, max_train=self.cap, max_batch=n, device=local_rank)
+            self.reg = api.RegistrationGICP(max_points=SP, max_batch=n, device=local_rank)
+            self.s1 = torch.cuda.Stream(device=dev)
+            self.s2 = torch.cuda.Stream(device=dev)
+            self.g0, self.g1 = gray0[b0:b1], gray1[b0:b1]
+            self.c0, self.c1, self.n0, self.n1 = d_c0[b0:b1], d_c1[b0:b1], d_n0[b0:b1], d_n1[b0:b1]
+            # previous-frame features (the "keyframe" side of SearchWithGMS): computed once, kept in HBM
+            self.ext.extract_batch_device(self.g0.data_ptr(), n, H, W, (0, 0), self.s1.cuda_stream)
+            self.res = self.ext.device_results()
+            self.s1.synchronize()
+            self.prev_desc = torch.empty(n * self.cap * 32, dtype=torch.uint8, device=dev)
+            self.prev_cnt = torch.empty(n, dtype=torch.int32, device=dev)
+            assert hip.hipMemcpy(self.prev_desc.data_ptr(), self.res["desc"], n * self.cap * 32, 3) == 0
+            assert hip.hipMemcpy(self.prev_cnt.data_ptr(), self.res["counts"], n * 4, 3) == 0
+            self.m_idx = torch.empty(n * self.cap, dtype=torch.int32, device=dev)
+            self.m_dist = torch.empty(n * self.cap, dtype=torch.int32, device=dev)
+            self.gicp_out = None
+
+        def orb_and_match(self):
+            sp = self.s1.cuda_stream
+            self.ext.extract_batch_device(self.g1.data_ptr(), self.n, H, W, (0, 0), sp)
+            self.mt.match_batch_device(self.prev_desc.data_ptr(), self.prev_cnt.data_ptr(), self.res["desc"], self.res["counts"],
+                                       self.n, self.cap, self.m_idx.data_ptr(), self.m_dist.data_ptr(), sp)
+
+        def gicp(self):
+            self.gicp_out = self.reg.align_batch_device(self.c0.data_ptr(), self.n0.data_ptr(), self.c1.data_ptr(),
+                                                        self.n1.data_ptr(), self.n, SP, None, None, self.s2.cuda_stream, raw=True)
+
+    nlanes = max(1, min(args.lanes, B))
+    lanes = [Lane(*shard_range(B, l, nlanes)) for l in range(nlanes)]
+    pool = ThreadPoolExecutor(max_workers=2 * nlanes)
     last = {}
-
-    def orb_and_match():
-        ext.extract_batch_device(gray1.data_ptr(), B, H, W, (0, 0), sp)
-        mt.match_batch_device(prev_desc.data_ptr(), prev_cnt.data_ptr(), res["desc"], res["counts"], B, cap,
-                              m_idx.data_ptr(), m_dist.data_ptr(), sp)
-
-    def gicp():
-        last["gicp"] = reg.align_batch_device(d_c0.data_ptr(), d_n0.data_ptr(), d_c1.data_ptr(), d_n1.data_ptr(), B, SP,
-                                              None, None, sp2)
+    ext = lanes[0].ext
 
     def step():
-        # ORB (+ its host quadtree) and GICP of the same batch are independent: two host threads, two HIP streams
-        # (ctypes releases the GIL), so the quadtree hides under the GICP kernels.
+        # ORB (+ its host quadtree) and GICP of a slice are independent, and so are the slices: every lane runs its two
+        # halves on two host threads / two HIP streams (ctypes releases the GIL); no data-path synchronisation between lanes.
         if args.serial:
-            orb_and_match()
-            gicp()
+            for ln in lanes:
+                ln.orb_and_match()
+                ln.gicp()
         else:
-            f1, f2 = pool.submit(orb_and_match), pool.submit(gicp)
-            f1.result()
-            f2.result()
+            futs = [pool.submit(f) for ln in lanes for f in (ln.orb_and_match, ln.gicp)]
+            for f in futs:
+                f.result()
+
+    def gicp_results():
+        return [dict(n_linearize=r.n_linearize, n_error_evals=r.n_error_evals, n_source_ds=r.n_source_ds,
+                     n_target_ds=r.n_target_ds, converged=bool(r.converged)) for ln in lanes for r in ln.gicp_out]
 
     def barrier():
         torch.cuda.synchronize()
@@ -173,7 +201,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fps = world * B * args.steps / dt
@@ -190,9 +218,8 @@ def main():
         torch.cuda.synchronize()
         kern = api.profile_report()
         api.profile_enable(False)
-        g = last["gicp"]
-        counts = torch.empty(B, dtype=torch.int32)
-        assert hip.hipMemcpy(counts.data_ptr(), res["counts"], B * 4, 2) == 0
+        g = gicp_results()
+        counts = torch.cat([ln.prev_cnt.cpu() for ln in lanes])
         lin_pts = sum(r["n_linearize"] * r["n_source_ds"] for r in g)
         err_pts = sum(r["n_error_evals"] * r["n_source_ds"] for r in g)
         nl_lin = max(1, kern.get("k_gicp_linearize", (0, 1))[1] // nprof)
@@ -200,7 +227,7 @@ def main():
         lv = [ext.level_size(l) for l in range(NL)]
         P = sum(r * c for r, c in lv)
         ctx = dict(B=B, P0=W * H, P=P, p_last=lv[-1][0] * lv[-1][1], nlevels_m1=NL - 1, K=float(counts.float().mean()),
-                   cands=float(np.mean([sum(len(ext.candidates(l, b)[0]) for l in range(NL)) for b in range(min(B, 4))])),
+                   cands=float(np.mean([sum(len(ext.candidates(l, b)[0]) for l in range(NL)) for b in range(min(lanes[0].n, 4))])),
                    lin_points_per_launch=lin_pts / nl_lin, err_points_per_launch=err_pts / nl_err,
                    ds_points=sum(r["n_source_ds"] + r["n_target_ds"] for r in g), in_points=int(n0.sum() + n1.sum()),
                    sort_points_per_launch=(int(n0.sum() + n1.sum()) + sum(r["n_source_ds"] + r["n_target_ds"] for r in g)) / 2)
@@ -263,7 +290,7 @@ def main():
                    note="CPU restatement of the reference algorithm (reference not buildable here: OpenCV/Eigen/PCL absent)")
 
     if rank == 0:
-        g = last["gicp"]
+        g = gicp_results()
         out = {
             "metric": "front-end frames/sec (ORB+match+GICP) on 640x480 RGBD",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -271,7 +298,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32 (ORB, match) + f64 (GICP)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 640x480 RGBD frame pair, ORB extract (1000 feats, 8 levels) "
                                    "+ BF Hamming match + GICP on ~19k-pt clouds (stride-4 depth grid)",
-                       "batch_pairs_per_gpu": B, "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
+                       "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
                        "gicp_mean_outer_iterations": round(float(np.mean([r["n_linearize"] for r in g])), 2),
                        "gicp_mean_error_evals": round(float(np.mean([r["n_error_evals"] for r in g])), 2),
                        "gicp_converged_frac": round(float(np.mean([r["converged"] for r in g])), 3)},

@@ -345,7 +345,9 @@ class RegistrationGICP:
                "gfs_gicp_align")
         return _result_dict(res)
 
-    def align_batch_device(self, d_target, d_nt, d_source, d_ns, B, stride_pts, init_T=None, cfg=None, stream=None):
+    def align_batch_device(self, d_target, d_nt, d_source, d_ns, B, stride_pts, init_T=None, cfg=None, stream=None,
+                           raw=False):
+        """raw=True returns the ctypes array of gfs_gicp_result (no per-pair Python conversion on the hot path)."""
         cfg = cfg or gicp_default_config()
         out = (GicpResult * B)()
         T0 = None
@@ -354,6 +356,8 @@ class RegistrationGICP:
         _check(lib().gfs_gicp_align_batch_device(self.h, C.c_void_p(d_target), C.c_void_p(d_nt), C.c_void_p(d_source),
                                                  C.c_void_p(d_ns), B, stride_pts, _p(T0), C.byref(cfg), out,
                                                  C.c_void_p(stream) if stream else None), "gfs_gicp_align_batch_device")
+        if raw:
+            return out
         return [_result_dict(r) for r in out]
 
     def preprocessed(self, b, which, cap=None):

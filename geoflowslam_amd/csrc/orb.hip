@@ -15,6 +15,8 @@
 //   kpin [B][kp_cap] -> kps [B][kp_cap] gfs_keypoint + desc [B][kp_cap][32]
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <thread>
 
@@ -493,27 +495,74 @@ const int8_t kPattern[256 * 4] = {
 };
 const int kBlurTaps[2][4] = {{18, 34, 48, 56}, {18, 34, 49, 55}};
 
-// tiny parallel-for over host threads (quadtree tasks)
-template <typename F>
-void parallel_for(int n, int nthreads, F f) {
-  if (n <= 0) return;
-  nthreads = std::max(1, std::min(nthreads, n));
-  if (nthreads == 1) {
-    for (int i = 0; i < n; i++) f(i, 0);
-    return;
+// persistent host worker pool for the quadtree tasks (threads are created once per handle, not per call)
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n) : n_(std::max(1, n)) {
+    for (int t = 1; t < n_; t++) th_.emplace_back([this, t]() { loop(t); });
   }
-  std::atomic<int> next(0);
-  std::vector<std::thread> th;
-  for (int t = 0; t < nthreads; t++)
-    th.emplace_back([&, t]() {
-      for (;;) {
-        const int i = next.fetch_add(1);
-        if (i >= n) break;
-        f(i, t);
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+      gen_++;
+    }
+    cv_.notify_all();
+    for (auto& x : th_) x.join();
+  }
+  int size() const { return n_; }
+  // runs f(i, worker) for i in [0, n); the calling thread participates as worker 0
+  void run(int n, const std::function<void(int, int)>& f) {
+    if (n <= 0) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &f;
+      total_ = n;
+      next_.store(0);
+      pending_ = n_ - 1;
+      gen_++;
+    }
+    cv_.notify_all();
+    work(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this]() { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work(int t) {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= total_) break;
+      (*fn_)(i, t);
+    }
+  }
+  void loop(int t) {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
       }
-    });
-  for (auto& x : th) x.join();
-}
+      work(t);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  int n_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int, int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int total_ = 0, pending_ = 0;
+  unsigned long gen_ = 0;
+  bool quit_ = false;
+};
 
 }  // namespace
 
@@ -528,6 +577,7 @@ struct gfs_orb {
   hipEvent_t ev_copy = nullptr;
   std::mutex mu;
   int host_threads = 1;
+  std::unique_ptr<WorkerPool> pool;
   // device
   gfs::DevBuf<uint8_t> d_stage, d_pyr, d_blur;
   gfs::DevBuf<LevelDev> d_levels;
@@ -617,7 +667,7 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   const int ntask = B * nl;
   if ((int)h->kept.size() < ntask) h->kept.resize(ntask);
   if ((int)h->scratch.size() < h->host_threads) h->scratch.resize(h->host_threads);
-  parallel_for(ntask, h->host_threads, [&](int t, int tid) {
+  h->pool->run(ntask, [&](int t, int tid) {
     const int b = t / nl, l = t % nl;
     const int* off = h->h_cand_off.p + (size_t)b * (nl + 1);
     const LevelDev& L = G.levels[l];
@@ -754,7 +804,9 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   GFS_HIP(hipMemcpy(h->d_ic_dv.p, dv.data(), dv.size(), hipMemcpyHostToDevice));
   GFS_HIP(hipMemcpy(h->d_pattern.p, kPattern, 1024, hipMemcpyHostToDevice));
   GFS_HIP(hipMemset(h->d_kp_count.p, 0, B * sizeof(int)));
-  h->host_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  h->host_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("GFS_ORB_HOST_THREADS")) h->host_threads = std::max(1, atoi(e));
+  h->pool.reset(new WorkerPool(h->host_threads));
   *out = h.release();
   return GFS_OK;
 }
