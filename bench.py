@@ -26,37 +26,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
-# SURVEY.md §8(d) algorithmic bytes per unit of work for each kernel
-def algorithmic_bytes(kernel, ctx):
+# SURVEY.md §8(d) algorithmic bytes of each kernel for ONE STEP (whole batch); bench divides by launches per step
+def algorithmic_bytes_per_step(kernel, ctx):
     P0, P, K = ctx["P0"], ctx["P"], ctx["K"]  # level-0 pixels, pyramid pixels, keypoints per frame
     B = ctx["B"]
-    if kernel == "k_fast_cells":      # P read + 12 B x candidates (here 4 B packed)  -> per frame
-        return B * (P + 4 * ctx["cands"])
-    if kernel == "k_pyr_area":        # whole chain per frame: P0 read + (P - P0) write + re-read of levels 0..L-2
-        return B * (P0 + (P - P0) + (P - ctx["p_last"])) / ctx["nlevels_m1"]  # per launch (one level)
-    if kernel == "k_blur7":
-        return B * 2 * P
-    if kernel == "k_orient_brief":    # K x (31x31 + 37x37) read + 60 B out
-        return B * K * (31 * 31 + 37 * 37 + 60)
-    if kernel == "k_bf_hamming":
-        return B * (32 * 2 * K + 8 * K)
-    if kernel == "k_gicp_linearize":  # 320 B per source point per linearisation
-        return 320.0 * ctx["lin_points_per_launch"]
-    if kernel == "k_gicp_error":
-        return 136.0 * ctx["err_points_per_launch"]
-    if kernel == "k_knn_cov":         # kNN gather 10 x 32 B + 160 B write, per down-sampled point, both clouds
-        return (10 * 32 + 160) * ctx["ds_points"]
-    if kernel == "k_radix_sort":      # 2 x (key + idx) per pass-free sort, N points
-        return 2 * 12 * ctx["sort_points_per_launch"]
-    if kernel == "k_voxel_reduce":
-        return (16 + 12) * ctx["in_points"] + 32 * ctx["ds_points"]
-    if kernel == "k_voxel_keys":
-        return (16 + 12) * ctx["in_points"]
-    if kernel == "k_cell_build":
-        return (32 + 12 + 32) * ctx["ds_points"]
-    if kernel == "k_cand_pack":
-        return B * 8 * ctx["cands"]
-    return None
+    table = {
+        "k_fast_cells": B * (P + 4 * ctx["cands"]),                 # P read + 4 B per packed candidate
+        "k_pyr_area": B * (P0 + (P - P0) + (P - ctx["p_last"])),    # P0 read + levels written + levels re-read
+        "k_blur7": B * 2 * P,
+        "k_orient_brief": B * K * (31 * 31 + 37 * 37 + 60),         # K x (31x31 + 37x37) read + 60 B out
+        "k_bf_hamming": B * (32 * 2 * K + 8 * K),
+        "k_gicp_linearize": 320.0 * ctx["lin_points"],              # 320 B per source point per linearisation
+        "k_gicp_error": 136.0 * ctx["err_points"],
+        "k_knn_cov": (10 * 32 + 160) * ctx["ds_points"],            # 10-NN gather + covariance write, both clouds
+        "k_radix_sort": 2 * 12 * (ctx["in_points"] + ctx["ds_points"]),
+        "k_voxel_reduce": (16 + 12) * ctx["in_points"] + 32 * ctx["ds_points"],
+        "k_voxel_keys": (16 + 12) * ctx["in_points"],
+        "k_cell_build": (32 + 12 + 32) * ctx["ds_points"],
+        "k_grid_fill": 12 * ctx["ds_points"],
+        "k_cand_pack": B * 8 * ctx["cands"],
+    }
+    return table.get(kernel)
 
 
 def gen_pairs(n_distinct, seed0, width, height, stride):
@@ -222,24 +212,33 @@ def main():
         counts = torch.cat([ln.prev_cnt.cpu() for ln in lanes])
         lin_pts = sum(r["n_linearize"] * r["n_source_ds"] for r in g)
         err_pts = sum(r["n_error_evals"] * r["n_source_ds"] for r in g)
-        nl_lin = max(1, kern.get("k_gicp_linearize", (0, 1))[1] // nprof)
-        nl_err = max(1, kern.get("k_gicp_error", (0, 1))[1] // nprof)
         lv = [ext.level_size(l) for l in range(NL)]
         P = sum(r * c for r, c in lv)
-        ctx = dict(B=B, P0=W * H, P=P, p_last=lv[-1][0] * lv[-1][1], nlevels_m1=NL - 1, K=float(counts.float().mean()),
+        ctx = dict(B=B, P0=W * H, P=P, p_last=lv[-1][0] * lv[-1][1], K=float(counts.float().mean()),
                    cands=float(np.mean([sum(len(ext.candidates(l, b)[0]) for l in range(NL)) for b in range(min(lanes[0].n, 4))])),
-                   lin_points_per_launch=lin_pts / nl_lin, err_points_per_launch=err_pts / nl_err,
-                   ds_points=sum(r["n_source_ds"] + r["n_target_ds"] for r in g), in_points=int(n0.sum() + n1.sum()),
-                   sort_points_per_launch=(int(n0.sum() + n1.sum()) + sum(r["n_source_ds"] + r["n_target_ds"] for r in g)) / 2)
+                   lin_points=lin_pts, err_points=err_pts, ds_points=sum(r["n_source_ds"] + r["n_target_ds"] for r in g),
+                   in_points=int(n0.sum() + n1.sum()))
         tot = sum(v[0] for v in kern.values())
         name = max(kern, key=lambda k: kern[k][0])
         ms, launches = kern[name]
         avg_s = ms / launches / 1e3
-        ab = algorithmic_bytes(name, ctx)
+        lps = launches / nprof
+        ab_step = algorithmic_bytes_per_step(name, ctx)
+        ab = ab_step / lps if ab_step else None
         ach = ab / avg_s / 1e9 if ab else None
+        traffic = None
+        traffic_note = None
+        pmc = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_serial_b64.json")
+        if os.path.exists(pmc) and B == 64:
+            t = json.load(open(pmc)).get(name)
+            if t:  # HBM-side bytes per STEP measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)
+                traffic = int((t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
+                traffic_note = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, B=64, 1 lane, serial), KB*1024, "
+                                "per step / launches per step; FETCH_SIZE left uncorrected (gather pattern uncalibrated, "
+                                "MI355X_MICROARCH.md §HBM)")
         roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 2) if ach else None, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5) if ach else None, traffic=None,
-                        avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=launches / nprof,
+                        frac=round(ach / HBM_PEAK_GBS, 5) if ach else None, traffic=traffic, traffic_note=traffic_note,
+                        avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=lps,
                         algorithmic_bytes_per_launch=int(ab) if ab else None,
                         share_of_gpu_kernel_time=round(ms / tot, 3),
                         kernels_ms_per_step={k: round(v[0] / nprof, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])})
