@@ -74,6 +74,8 @@ ABI_SYMBOLS = [
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
     "gfs_gicp_fetch_preprocessed",
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize",
+    "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
+    "gfs_stereo_from_rgbd_batch_device",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
 ]
@@ -120,6 +122,14 @@ def lib():
             L.gfs_lba_destroy.argtypes = [vp]
             L.gfs_lba_solve.argtypes = [vp, C.POINTER(LbaProblem), C.POINTER(LbaSolution), vp]
             L.gfs_lba_linearize.argtypes = [vp, C.POINTER(LbaProblem), vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
+        if hasattr(L, "gfs_frame_create"):
+            f = C.c_float
+            L.gfs_frame_create.argtypes = [i, i, i, i, C.POINTER(vp)]
+            L.gfs_frame_destroy.argtypes = [vp]
+            L.gfs_depth_to_cloud.argtypes = [vp, vp, i, i, i, i, f, f, f, f, vp, i, ip]
+            L.gfs_depth_to_cloud_batch_device.argtypes = [vp, vp, i, i, i, i, f, f, f, f, vp, i, vp, vp]
+            L.gfs_stereo_from_rgbd.argtypes = [vp, vp, vp, i, vp, i, i, i, f, vp, vp]
+            L.gfs_stereo_from_rgbd_batch_device.argtypes = [vp, vp, vp, vp, i, i, vp, i, i, f, vp, vp, vp]
         L.gfs_timer_create.argtypes = [i, C.POINTER(vp)]
         L.gfs_timer_destroy.argtypes = [vp]
         L.gfs_timer_start.argtypes = [vp, vp]
@@ -464,3 +474,46 @@ class Optimizer:
                                        C.byref(tot)), "gfs_lba_linearize")
         return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
                     Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=tot.value)
+
+
+class Frame:
+    """The two Frame members next to the hot path (reference src/Frame.cc:590-623 and 1314-1332)."""
+
+    def __init__(self, max_rows=720, max_cols=1280, max_keypoints=8192, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_frame_create(device, max_rows, max_cols, max_keypoints, C.byref(self.h)), "gfs_frame_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_frame_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def ConvertDepthToPointCloud(self, depth, downSample, fx, fy, cx, cy):
+        depth = np.asarray(depth, np.float32)
+        if depth.size == 0:
+            return np.zeros((0, 4), np.float32)
+        rows, cols = depth.shape
+        stride = depth.strides[0] // 4
+        out = np.zeros((rows * cols, 4), np.float32)
+        n = C.c_int()
+        _check(lib().gfs_depth_to_cloud(self.h, C.c_void_p(depth.ctypes.data), rows, cols, stride, downSample, fx, fy, cx, cy,
+                                        _p(out), len(out), C.byref(n)), "gfs_depth_to_cloud")
+        return out[:n.value].copy()
+
+    def ComputeStereoFromRGBD(self, kps, depth, bf, kps_un_x=None):
+        depth = np.ascontiguousarray(depth, np.float32)
+        kps = np.ascontiguousarray(kps)
+        n = len(kps)
+        ur = np.zeros(max(n, 1), np.float32)
+        vd = np.zeros(max(n, 1), np.float32)
+        unx = np.ascontiguousarray(kps_un_x, np.float32) if kps_un_x is not None else None
+        _check(lib().gfs_stereo_from_rgbd(self.h, _p(kps), _p(unx), n, _p(depth), depth.shape[0], depth.shape[1], depth.shape[1],
+                                          bf, _p(ur), _p(vd)), "gfs_stereo_from_rgbd")
+        return ur[:n], vd[:n]
+
+    def depth_to_cloud_batch_device(self, d_depth, B, rows, cols, ds, fx, fy, cx, cy, d_out, stride_pts, d_counts, stream=None):
+        _check(lib().gfs_depth_to_cloud_batch_device(self.h, C.c_void_p(d_depth), B, rows, cols, ds, fx, fy, cx, cy,
+                                                     C.c_void_p(d_out), stride_pts, C.c_void_p(d_counts),
+                                                     C.c_void_p(stream) if stream else None), "gfs_depth_to_cloud_batch_device")

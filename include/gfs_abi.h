@@ -236,6 +236,32 @@ int gfs_lba_linearize(gfs_lba* h, const gfs_lba_problem* p, double* Hpp, double*
                       double* bl, double* edge_chi2, double* chi2);
 
 /* ============================================================================================
+ * 5. Frame helpers next to the hot path — keep GICP input and RGB-D "stereo" coordinates on device
+ *      Frame::ConvertDepthToPointCloud(downSample, ...)   src/Frame.cc:590-623
+ *      Frame::ComputeStereoFromRGBD(imDepth)              src/Frame.cc:1314-1332
+ * ============================================================================================ */
+typedef struct gfs_frame gfs_frame;
+int gfs_frame_create(int device, int max_rows, int max_cols, int max_keypoints, gfs_frame** out);
+void gfs_frame_destroy(gfs_frame* h);
+/* depth: CV_32F metres, `stride_elems` floats per row.  Emits (x, y, z, 1) for every pixel of the `downsample` grid with
+ * 0 < depth < 10 in raster order (the reference's push_back order): x = (u - cx) * depth / fx, y = (v - cy) * depth / fy.
+ * An empty depth image yields *n = 0 (the reference logs an error and returns). */
+int gfs_depth_to_cloud(gfs_frame* h, const float* depth, int rows, int cols, int stride_elems, int downsample, float fx,
+                       float fy, float cx, float cy, float* out_xyzw, int cap, int* n);
+/* dev_depth [B][rows][cols] f32 -> dev_out_xyzw [B][stride_pts][4] f32 + dev_counts [B] int32: exactly the cloud layout
+ * gfs_gicp_align_batch_device consumes. */
+int gfs_depth_to_cloud_batch_device(gfs_frame* h, const void* dev_depth, int B, int rows, int cols, int downsample, float fx,
+                                    float fy, float cx, float cy, void* dev_out_xyzw, int stride_pts, void* dev_counts,
+                                    void* stream);
+/* mvDepth[i] = d = imDepth.at<float>(kp.pt.y, kp.pt.x) (float -> int truncation), mvuRight[i] = kpUn.pt.x - bf / d when
+ * d > 0, else both -1.  kps_un_x may be NULL (no distortion: mvKeysUn == mvKeys). */
+int gfs_stereo_from_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x, int n, const float* depth, int rows,
+                         int cols, int stride_elems, float bf, float* u_right, float* depth_out);
+int gfs_stereo_from_rgbd_batch_device(gfs_frame* h, const void* dev_kps, const void* dev_kps_un_x, const void* dev_counts,
+                                      int B, int kp_stride, const void* dev_depth, int rows, int cols, float bf,
+                                      void* dev_u_right, void* dev_depth_out, void* stream);
+
+/* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel
  * with these rather than torch events, which only see torch's current stream).
  * ============================================================================================ */

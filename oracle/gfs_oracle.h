@@ -120,6 +120,12 @@ void gfso_knn(const double* pts, int n, const double* queries, int nq, int k, in
 void gfso_eig3_direct(const double* m, double* evals, double* evecs);
 void gfso_se3_exp(const double* twist6, double* T16);
 
+/* ---------------- Frame helpers (src/Frame.cc:590-623, 1314-1332) ---------------- */
+int gfso_depth_to_cloud(const float* depth, int rows, int cols, int stride_elems, int downsample, float fx, float fy, float cx,
+                        float cy, float* out_xyzw, int cap);
+void gfso_stereo_from_rgbd(const gfso_keypoint* kps, const float* kps_un_x, int n, const float* depth, int stride_elems,
+                           float bf, float* u_right, float* depth_out);
+
 /* ---------------- Optimizer::LocalBundleAdjustment (src/Optimizer.cc:1588-2040 + Thirdparty/g2o) -------- */
 typedef struct {
   int32_t n_poses, n_points, n_edges;

@@ -368,3 +368,27 @@ def lba_linearize(prob):
     tot = lib().gfso_lba_linearize(C.byref(P), _p(Hpp), _p(Hll), _p(Hpl), _p(bp), _p(bl), _p(chi))
     return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
                 Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=float(tot))
+
+
+def depth_to_cloud(depth, downsample, fx, fy, cx, cy):
+    depth = np.ascontiguousarray(depth, np.float32)
+    rows, cols = depth.shape if depth.ndim == 2 else (0, 0)
+    out = np.zeros((max(rows * cols, 1), 4), np.float32)
+    L = lib()
+    L.gfso_depth_to_cloud.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_void_p, C.c_int]
+    n = L.gfso_depth_to_cloud(_p(depth), rows, cols, cols, downsample, fx, fy, cx, cy, _p(out), len(out))
+    return out[:n].copy()
+
+
+def stereo_from_rgbd(kps, depth, bf, kps_un_x=None):
+    depth = np.ascontiguousarray(depth, np.float32)
+    kps = np.ascontiguousarray(kps)
+    n = len(kps)
+    ur = np.zeros(max(n, 1), np.float32)
+    vd = np.zeros(max(n, 1), np.float32)
+    L = lib()
+    L.gfso_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    unx = np.ascontiguousarray(kps_un_x, np.float32) if kps_un_x is not None else None
+    L.gfso_stereo_from_rgbd(_p(kps), _p(unx) if unx is not None else None, n, _p(depth), depth.shape[1], bf, _p(ur), _p(vd))
+    return ur[:n], vd[:n]
