@@ -69,6 +69,7 @@ ABI_SYMBOLS = [
     "gfs_orb_default_config", "gfs_orb_create", "gfs_orb_destroy", "gfs_orb_get_tables", "gfs_orb_max_keypoints",
     "gfs_orb_extract", "gfs_orb_extract_batch", "gfs_orb_extract_batch_device", "gfs_orb_device_results",
     "gfs_orb_fetch", "gfs_orb_level_size", "gfs_orb_fetch_level", "gfs_orb_fetch_candidates", "gfs_orb_octree_host",
+    "gfs_orb_octree_device", "gfs_test_sort_replica", "gfs_test_heap_sort_replica",
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
@@ -105,6 +106,7 @@ def lib():
         L.gfs_orb_fetch_level.argtypes = [vp, i, i, i, vp]
         L.gfs_orb_fetch_candidates.argtypes = [vp, i, i, vp, vp, vp, i]
         L.gfs_orb_octree_host.argtypes = [vp, vp, vp, i, i, i, i, i, i, vp, i]
+        L.gfs_orb_octree_device.argtypes = [i, vp, vp, vp, i, i, i, i, i, i, vp, vp, vp, i]
         L.gfs_hamming256.argtypes = [vp, vp]
         L.gfs_matcher_create.argtypes = [i, i, i, i, C.POINTER(vp)]
         L.gfs_matcher_destroy.argtypes = [vp]
@@ -276,6 +278,18 @@ def octree_host(x, y, score, min_x, max_x, min_y, max_y, n_features):
     n = lib().gfs_orb_octree_host(_p(x), _p(y), _p(score), len(x), min_x, max_x, min_y, max_y, n_features, _p(out),
                                   len(out))
     return out[:n]
+
+
+def octree_device(x, y, score, min_x, max_x, min_y, max_y, n_features, device=0):
+    """The library's device DistributeOctTree (k_octree) -> kept (x, y, score) arrays in list order."""
+    x = np.ascontiguousarray(x, np.int32)
+    y = np.ascontiguousarray(y, np.int32)
+    score = np.ascontiguousarray(score, np.int32)
+    cap = n_features + 64
+    ox, oy, os_ = (np.zeros(cap, np.int32) for _ in range(3))
+    n = _check(lib().gfs_orb_octree_device(device, _p(x), _p(y), _p(score), len(x), min_x, max_x, min_y, max_y, n_features,
+                                           _p(ox), _p(oy), _p(os_), cap), "gfs_orb_octree_device")
+    return ox[:n], oy[:n], os_[:n]
 
 
 class ORBmatcher:

@@ -15,6 +15,7 @@
 //   kpin [B][kp_cap] -> kps [B][kp_cap] gfs_keypoint + desc [B][kp_cap][32]
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -22,6 +23,7 @@
 
 #include "gfs_common.hpp"
 #include "orb_host.hpp"
+#include "std_sort_replica.hpp"
 
 using gfs::BlurTileDev;
 using gfs::CellDev;
@@ -287,6 +289,483 @@ __global__ __launch_bounds__(256) void k_cand_pack(const LevelDev* __restrict__ 
     }
   }
   if (tid == 0) cand_off[(size_t)b * (nlevels + 1) + nlevels] = s_base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_octree: ORBextractor::DistributeOctTree (reference src/ORBextractor.cc:567-768) on the device, one workgroup
+// per (frame, level).  The std::list is represented by an array in list order; a node is a box plus a contiguous
+// range of a key permutation (children always partition their parent's range in place, stably).
+//   * "Loop A" (every multi-key node is split in one pass, :621-683) is one block-wide sweep: every key computes its
+//     quadrant, a block scan of packed per-quadrant counters gives its stable rank, per-node scans give the new list
+//     positions (children of later nodes come first, children n4..n1, single-key nodes keep their relative order
+//     behind them: the push_front / erase semantics of the reference).
+//   * "Loop B" (split the largest nodes first until the quota is reached, :689-744) sorts the (size, UL.x) pairs with
+//     a replica of libstdc++'s std::sort on one lane (tie order matters), evaluates all candidate splits in parallel,
+//     finds the break index with a scan and applies the prefix.
+//   * finally the first maximum-response key of every node is emitted in list order (:751-765).
+// Keys stay in global memory (L2-resident permutation ping-pong), the node arrays live in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int kOctThreads = 256;
+constexpr int kOctMaxNodes = 768;
+
+struct ONode {
+  short x0, x1, y0, y1;
+  int kb, ke;
+};
+struct OVs {  // vSizeAndPointerToNode entry
+  int size;
+  short x0, node;
+};
+struct U128 {
+  unsigned long long lo, hi;  // four 32-bit per-quadrant counters
+};
+__device__ __forceinline__ U128 u128_add(U128 a, U128 b) { return U128{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ unsigned u128_field(U128 a, int q) {
+  const unsigned long long w = q < 2 ? a.lo : a.hi;
+  return (unsigned)((q & 1) ? (w >> 32) : (w & 0xffffffffull));
+}
+__device__ __forceinline__ U128 u128_one(int q) {
+  U128 r{0, 0};
+  const unsigned long long v = (q & 1) ? (1ull << 32) : 1ull;
+  if (q < 2)
+    r.lo = v;
+  else
+    r.hi = v;
+  return r;
+}
+
+// exclusive block scan (256 threads) of one U128 per thread; *total = sum over the block
+__device__ U128 oct_scan_u128(U128 v, U128* s_w /*[4]*/, U128* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  U128 incl = v;
+#pragma unroll
+  for (int ofs = 1; ofs < 64; ofs <<= 1) {
+    const unsigned long long lo = __shfl_up(incl.lo, ofs, 64), hi = __shfl_up(incl.hi, ofs, 64);
+    if (lane >= ofs) {
+      incl.lo += lo;
+      incl.hi += hi;
+    }
+  }
+  __syncthreads();
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  U128 base{0, 0}, tot{0, 0};
+  for (int w = 0; w < 4; w++) {
+    if (w < wave) base = u128_add(base, s_w[w]);
+    tot = u128_add(tot, s_w[w]);
+  }
+  *total = tot;
+  return U128{base.lo + incl.lo - v.lo, base.hi + incl.hi - v.hi};
+}
+// exclusive block scan of one packed u64 (three 20-bit fields) per thread
+__device__ unsigned long long oct_scan_u64(unsigned long long v, unsigned long long* s_w /*[4]*/, unsigned long long* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int ofs = 1; ofs < 64; ofs <<= 1) {
+    const unsigned long long t = __shfl_up(incl, ofs, 64);
+    if (lane >= ofs) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+  for (int w = 0; w < 4; w++) {
+    if (w < wave) base += s_w[w];
+    tot += s_w[w];
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+__device__ __forceinline__ int oct_quadrant(const ONode& nd, uint32_t key) {  // ExtractorNode::DivideNode :502-550
+  const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+  const int x = (int)(key & 0xfff), y = (int)((key >> 12) & 0xfff);
+  return (x < nd.x0 + halfX ? 0 : 1) + (y < nd.y0 + halfY ? 0 : 2);
+}
+__device__ __forceinline__ ONode oct_child(const ONode& nd, int q) {
+  const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+  const int xm = nd.x0 + halfX, ym = nd.y0 + halfY;
+  ONode c;
+  c.x0 = (short)((q & 1) ? xm : nd.x0);
+  c.x1 = (short)((q & 1) ? nd.x1 : xm);
+  c.y0 = (short)((q & 2) ? ym : nd.y0);
+  c.y1 = (short)((q & 2) ? nd.y1 : ym);
+  c.kb = c.ke = 0;
+  return c;
+}
+
+__global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restrict__ levels, int nlevels,
+                                                        const uint32_t* __restrict__ cand, const int* __restrict__ cand_off,
+                                                        size_t cand_frame, uint32_t* __restrict__ perm0,
+                                                        uint32_t* __restrict__ perm1, unsigned short* __restrict__ seg0,
+                                                        unsigned short* __restrict__ seg1, const int* __restrict__ kept_off,
+                                                        int kp_cap, uint32_t* __restrict__ kept, int* __restrict__ kept_cnt) {
+  __shared__ ONode s_nodes[2][kOctMaxNodes];
+  __shared__ U128 s_start[kOctMaxNodes], s_end[kOctMaxNodes];
+  __shared__ unsigned short s_newidx[kOctMaxNodes][4];
+  __shared__ unsigned long long s_npre[kOctMaxNodes];  // per node: exclusive prefix of (children | multi << 20 | single << 40)
+  __shared__ OVs s_vs[2][kOctMaxNodes];
+  __shared__ unsigned char s_proc[kOctMaxNodes];
+  __shared__ U128 s_w128[4];
+  __shared__ unsigned long long s_w64[4];
+  __shared__ int s_ctl[8];
+  const int tid = threadIdx.x;
+  const int l = blockIdx.x % nlevels, b = blockIdx.x / nlevels;
+  const int* off = cand_off + (size_t)b * (nlevels + 1);
+  const int n = off[l + 1] - off[l];
+  const uint32_t* c = cand + (size_t)b * cand_frame + off[l];
+  uint32_t* perm[2] = {perm0 + (size_t)b * cand_frame + off[l], perm1 + (size_t)b * cand_frame + off[l]};
+  unsigned short* seg[2] = {seg0 + (size_t)b * cand_frame + off[l], seg1 + (size_t)b * cand_frame + off[l]};
+  if (n <= 0) {
+    if (tid == 0) kept_cnt[(size_t)b * nlevels + l] = 0;
+    return;
+  }
+  const LevelDev L = levels[l];
+  const int N = L.quota;
+  const int width = L.max_bx - 16, height = L.max_by - 16;
+  int nIni = (int)roundf((float)width / (float)height);  // :573
+  if (nIni == 0) nIni = 1;
+  const float hX = (float)width / (float)nIni;
+  const int chunk = (n + kOctThreads - 1) / kOctThreads;
+  const int p0 = min(tid * chunk, n), p1 = min(p0 + chunk, n);
+  for (int p = p0; p < p1; p++) {
+    perm[0][p] = (uint32_t)p;
+    seg[0][p] = 0;
+  }
+  if (tid == 0) {
+    ONode root;
+    root.x0 = 0;
+    root.x1 = (short)width;
+    root.y0 = 0;
+    root.y1 = (short)height;
+    root.kb = 0;
+    root.ke = n;
+    s_nodes[0][0] = root;
+  }
+  __syncthreads();
+  int cur = 0, pc = 0, nn = 1;  // node-buffer index, permutation-buffer index, number of nodes in the list
+  int nvs = 0, vcur = 0;
+
+  // One split sweep over the whole list.  init = true: the virtual root is cut into the nIni initial nodes
+  // (push_back order, :586-604); otherwise every node with > 1 keys is divided (push_front order).
+  auto sweep = [&](bool init) {
+    const ONode* nodes = s_nodes[cur];
+    ONode* nxt = s_nodes[cur ^ 1];
+    const uint32_t* pa = perm[pc];
+    const unsigned short* sa = seg[pc];
+    // 1. per-key quadrant counters, exclusive block scan
+    U128 local{0, 0};
+    for (int p = p0; p < p1; p++) {
+      const ONode nd = nodes[sa[p]];
+      if (!init && nd.ke - nd.kb <= 1) continue;
+      const uint32_t key = c[pa[p]];
+      const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
+      local = u128_add(local, u128_one(q));
+    }
+    U128 total;
+    const U128 base = oct_scan_u128(local, s_w128, &total);
+    U128 run = base;
+    for (int p = p0; p < p1; p++) {
+      const int ni = sa[p];
+      const ONode nd = nodes[ni];
+      if (p == nd.kb) s_start[ni] = run;
+      if (init || nd.ke - nd.kb > 1) {
+        const uint32_t key = c[pa[p]];
+        const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
+        run = u128_add(run, u128_one(q));
+      }
+      if (p + 1 == nd.ke) s_end[ni] = run;
+    }
+    __syncthreads();
+    // 2. per-node child counts -> packed (children, multi, single) and its exclusive scan over the list
+    const int nchunk = (nn + kOctThreads - 1) / kOctThreads;
+    const int i0 = min(tid * nchunk, nn), i1 = min(i0 + nchunk, nn);
+    unsigned long long lsum = 0;
+    for (int i = i0; i < i1; i++) {
+      const ONode nd = nodes[i];
+      unsigned long long v;
+      if (init || nd.ke - nd.kb > 1) {
+        int cc = 0, mm = 0;
+        for (int q = 0; q < 4; q++) {
+          const unsigned cq = u128_field(s_end[i], q) - u128_field(s_start[i], q);
+          cc += cq > 0;
+          mm += cq > 1;
+        }
+        v = (unsigned long long)cc | ((unsigned long long)mm << 20);
+      } else {
+        v = 1ull << 40;
+      }
+      s_npre[i] = v;
+      lsum += v;
+    }
+    unsigned long long ntot;
+    unsigned long long nbase = oct_scan_u64(lsum, s_w64, &ntot);
+    const int T = (int)(ntot & 0xfffff), Mtot = (int)((ntot >> 20) & 0xfffff), Z = (int)(ntot >> 40);
+    // 3. new nodes, new index table, vSizeAndPointerToNode in creation order
+    for (int i = i0; i < i1; i++) {
+      const unsigned long long v = s_npre[i];
+      const int A = (int)(nbase & 0xfffff), Mx = (int)((nbase >> 20) & 0xfffff), Zx = (int)(nbase >> 40);
+      nbase += v;
+      const ONode nd = nodes[i];
+      if (init || nd.ke - nd.kb > 1) {
+        const int ci = (int)(v & 0xfffff);
+        unsigned cnt[4];
+        for (int q = 0; q < 4; q++) cnt[q] = u128_field(s_end[i], q) - u128_field(s_start[i], q);
+        int kb = nd.kb, before = 0, mrank = 0;
+        for (int q = 0; q < 4; q++) {
+          if (cnt[q] == 0) {
+            s_newidx[i][q] = 0;
+            continue;
+          }
+          // init: push_back order (ascending); else children of later nodes first, n4..n1 inside a node
+          const int pos = init ? (A + before) : (T - A - ci + (ci - 1 - before));
+          ONode ch;
+          if (init) {
+            ch.x0 = (short)(int)(hX * (float)q);
+            ch.x1 = (short)(int)(hX * (float)(q + 1));
+            ch.y0 = 0;
+            ch.y1 = (short)height;
+          } else {
+            ch = oct_child(nd, q);
+          }
+          ch.kb = kb;
+          ch.ke = kb + (int)cnt[q];
+          nxt[pos] = ch;
+          s_newidx[i][q] = (unsigned short)pos;
+          if (cnt[q] > 1) {
+            s_vs[vcur][Mx + mrank] = OVs{(int)cnt[q], ch.x0, (short)pos};
+            mrank++;
+          }
+          kb += (int)cnt[q];
+          before++;
+        }
+      } else {
+        nxt[T + Zx] = nd;
+        s_newidx[i][0] = (unsigned short)(T + Zx);
+      }
+    }
+    __syncthreads();
+    // 4. stable scatter of the keys into their child ranges
+    uint32_t* pb = perm[pc ^ 1];
+    unsigned short* sb = seg[pc ^ 1];
+    run = base;
+    for (int p = p0; p < p1; p++) {
+      const int ni = sa[p];
+      const ONode nd = nodes[ni];
+      if (init || nd.ke - nd.kb > 1) {
+        const uint32_t key = c[pa[p]];
+        const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
+        unsigned ofs = 0;
+        for (int qq = 0; qq < q; qq++) ofs += u128_field(s_end[ni], qq) - u128_field(s_start[ni], qq);
+        const int dst = nd.kb + (int)ofs + (int)(u128_field(run, q) - u128_field(s_start[ni], q));
+        pb[dst] = pa[p];
+        sb[dst] = s_newidx[ni][q];
+        run = u128_add(run, u128_one(q));
+      } else {
+        pb[p] = pa[p];
+        sb[p] = s_newidx[ni][0];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+    pc ^= 1;
+    nn = T + Z;
+    nvs = Mtot;
+  };
+
+  sweep(true);
+  bool finish = false;
+  while (!finish) {
+    const int prev = nn;
+    vcur ^= 1;  // vSizeAndPointerToNode.clear(): entries are rebuilt by the sweep into the other buffer
+    sweep(false);
+    if (nn >= N || nn == prev) {
+      finish = true;
+    } else if (nn + nvs * 3 > N) {
+      while (!finish) {  // :690-744
+        const int prev2 = nn;
+        OVs* vs = s_vs[vcur];
+        const int V = nvs;
+        ONode* nodes = s_nodes[cur];
+        if (tid == 0)
+          gfs::replica_std_sort(vs, vs + V, [](const OVs& a, const OVs& e) {  // compareNodes :552-565
+            if (a.size < e.size) return true;
+            if (a.size > e.size) return false;
+            return a.x0 < e.x0;
+          });
+        for (int i = tid; i < nn; i += kOctThreads) s_proc[i] = 0;
+        __syncthreads();
+        // candidate splits of every entry; processing order k = 0.. is j = V-1-k (from the back)
+        const int vchunk = (V + kOctThreads - 1) / kOctThreads;
+        const int k0 = min(tid * vchunk, V), k1 = min(k0 + vchunk, V);
+        unsigned long long lsum = 0;
+        for (int k = k0; k < k1; k++) {
+          const int j = V - 1 - k;
+          const ONode nd = nodes[vs[j].node];
+          int cnt[4] = {0, 0, 0, 0};
+          for (int p = nd.kb; p < nd.ke; p++) cnt[oct_quadrant(nd, c[perm[pc][p]])]++;
+          int cc = 0, mm = 0;
+          for (int q = 0; q < 4; q++) {
+            cc += cnt[q] > 0;
+            mm += cnt[q] > 1;
+          }
+          s_npre[k] = (unsigned long long)cc | ((unsigned long long)mm << 20);
+          lsum += s_npre[k];
+        }
+        unsigned long long vtot;
+        unsigned long long vbase = oct_scan_u64(lsum, s_w64, &vtot);
+        // break index t: the reference stops right after the split that makes lNodes.size() >= N
+        if (tid == 0) s_ctl[0] = V;
+        __syncthreads();
+        {
+          unsigned long long run = vbase;
+          for (int k = k0; k < k1; k++) {
+            run += s_npre[k];
+            const int size_after = nn + (int)(run & 0xfffff) - (k + 1);
+            if (size_after >= N) atomicMin(&s_ctl[0], k + 1);
+          }
+        }
+        __syncthreads();
+        const int t = s_ctl[0];
+        // totals over the processed prefix
+        unsigned long long lsum2 = 0;
+        for (int k = k0; k < k1; k++)
+          if (k < t) lsum2 += s_npre[k];
+        unsigned long long ptot;
+        unsigned long long pbase = oct_scan_u64(lsum2, s_w64, &ptot);
+        const int T = (int)(ptot & 0xfffff), Mtot = (int)((ptot >> 20) & 0xfffff);
+        ONode* nxt = s_nodes[cur ^ 1];
+        OVs* vnew = s_vs[vcur ^ 1];
+        for (int k = k0; k < k1; k++) {
+          if (k >= t) break;
+          const int j = V - 1 - k;
+          const int ni = vs[j].node;
+          const ONode nd = nodes[ni];
+          s_proc[ni] = 1;
+          const unsigned long long v = s_npre[k];
+          const int A = (int)(pbase & 0xfffff), Mx = (int)((pbase >> 20) & 0xfffff);
+          pbase += v;
+          const int ci = (int)(v & 0xfffff);
+          // stable 4-way partition of this node's keys (through the other permutation buffer, then back)
+          int cnt[4] = {0, 0, 0, 0};
+          uint32_t* pa = perm[pc];  // partitioned through the other buffer and copied back: pc does not flip here
+          uint32_t* pb = perm[pc ^ 1];
+          for (int p = nd.kb; p < nd.ke; p++) cnt[oct_quadrant(nd, c[pa[p]])]++;
+          int pos[4] = {nd.kb, nd.kb + cnt[0], nd.kb + cnt[0] + cnt[1], nd.kb + cnt[0] + cnt[1] + cnt[2]};
+          for (int p = nd.kb; p < nd.ke; p++) pb[pos[oct_quadrant(nd, c[pa[p]])]++] = pa[p];
+          for (int p = nd.kb; p < nd.ke; p++) pa[p] = pb[p];
+          int kb = nd.kb, before = 0, mrank = 0;
+          for (int q = 0; q < 4; q++) {
+            if (cnt[q] == 0) continue;
+            const int posn = T - A - ci + (ci - 1 - before);
+            ONode ch = oct_child(nd, q);
+            ch.kb = kb;
+            ch.ke = kb + cnt[q];
+            nxt[posn] = ch;
+            if (cnt[q] > 1) {
+              vnew[Mx + mrank] = OVs{cnt[q], ch.x0, (short)posn};
+              mrank++;
+            }
+            kb += cnt[q];
+            before++;
+          }
+        }
+        __syncthreads();
+        // surviving nodes keep their relative order behind the new children
+        const int nchunk = (nn + kOctThreads - 1) / kOctThreads;
+        const int i0 = min(tid * nchunk, nn), i1 = min(i0 + nchunk, nn);
+        unsigned long long ls = 0;
+        for (int i = i0; i < i1; i++) ls += s_proc[i] ? 0 : 1;
+        unsigned long long stot;
+        unsigned long long sbase = oct_scan_u64(ls, s_w64, &stot);
+        for (int i = i0; i < i1; i++) {
+          if (s_proc[i]) continue;
+          nxt[T + (int)sbase] = nodes[i];
+          sbase++;
+        }
+        __syncthreads();
+        cur ^= 1;
+        vcur ^= 1;
+        nn = T + (int)stot;
+        nvs = Mtot;
+        if (nn >= N || nn == prev2) finish = true;
+      }
+    }
+  }
+  // retain the best point of each node, first maximum wins (:751-765)
+  const ONode* nodes = s_nodes[cur];
+  uint32_t* out = kept + (size_t)b * kp_cap + kept_off[l];
+  for (int i = tid; i < nn; i += kOctThreads) {
+    const ONode nd = nodes[i];
+    uint32_t best = c[perm[pc][nd.kb]];
+    for (int p = nd.kb + 1; p < nd.ke; p++) {
+      const uint32_t k2 = c[perm[pc][p]];
+      if ((k2 >> 24) > (best >> 24)) best = k2;
+    }
+    out[i] = best;
+  }
+  if (tid == 0) kept_cnt[(size_t)b * nlevels + l] = nn;
+}
+
+// k_kp_finalize: per frame, level-major concatenation of the kept keypoints and the monoIndex / stereoIndex slot
+// assignment of operator() (reference src/ORBextractor.cc:1176-1221).
+__global__ __launch_bounds__(256) void k_kp_finalize(const LevelDev* __restrict__ levels, int nlevels,
+                                                     const uint32_t* __restrict__ kept, const int* __restrict__ kept_cnt,
+                                                     const int* __restrict__ kept_off, int kp_cap, int lap0, int lap1,
+                                                     KpIn* __restrict__ kpin, int* __restrict__ kp_count,
+                                                     int* __restrict__ mono_out) {
+  __shared__ unsigned long long s_w64[4];
+  __shared__ int s_base[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t* kp = kept + (size_t)b * kp_cap;
+  const int* cnt = kept_cnt + (size_t)b * nlevels;
+  int total = 0;
+  for (int l = 0; l < nlevels; l++) total += cnt[l];
+  KpIn* out = kpin + (size_t)b * kp_cap;
+  if (tid == 0) {
+    s_base[0] = 0;
+    s_base[1] = 0;
+  }
+  __syncthreads();
+  int rec = 0;  // running record index (level-major, list order)
+  for (int l = 0; l < nlevels; l++) {
+    const float scale = levels[l].scale;
+    const int nl_ = cnt[l];
+    for (int i0 = 0; i0 < nl_; i0 += 256) {
+      const int i = i0 + tid;
+      const bool valid = i < nl_;
+      KpIn k;
+      bool stereo = false;
+      if (valid) {
+        const uint32_t v = kp[kept_off[l] + i];
+        k.x = (float)((int)(v & 0xfff) + 16);
+        k.y = (float)((int)((v >> 12) & 0xfff) + 16);
+        k.level = l;
+        k.response = (float)(v >> 24);
+        const float sx = l ? __fmul_rn(k.x, scale) : k.x;
+        stereo = sx >= (float)lap0 && sx <= (float)lap1;
+      }
+      unsigned long long tot;
+      const unsigned long long pre = oct_scan_u64(valid ? (stereo ? (1ull << 32) : 1ull) : 0ull, s_w64, &tot);
+      if (valid) {
+        const int mono_rank = s_base[0] + (int)(pre & 0xffffffffull), st_rank = s_base[1] + (int)(pre >> 32);
+        k.slot = stereo ? (total - 1 - st_rank) : mono_rank;
+        out[rec + i] = k;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        s_base[0] += (int)(tot & 0xffffffffull);
+        s_base[1] += (int)(tot >> 32);
+      }
+      __syncthreads();
+    }
+    rec += nl_;
+  }
+  if (tid == 0) {
+    kp_count[b] = total;
+    mono_out[b] = s_base[0];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,7 +1064,12 @@ struct gfs_orb {
   gfs::DevBuf<BlurTileDev> d_tiles;
   gfs::DevBuf<int> d_xt_start, d_xt_n, d_yt_start, d_yt_n, d_cell_cnt, d_cand_off, d_kp_count, d_mono;
   gfs::DevBuf<float> d_xt_alpha, d_yt_alpha;
-  gfs::DevBuf<uint32_t> d_slab, d_cand;
+  gfs::DevBuf<uint32_t> d_slab, d_cand, d_perm0, d_perm1, d_kept;
+  gfs::DevBuf<unsigned short> d_seg0, d_seg1;
+  gfs::DevBuf<int> d_kept_cnt, d_kept_off;
+  bool device_octree = true;   // DistributeOctTree on the GPU (k_octree); false = host quadtree (GFS_ORB_OCTREE=host)
+  bool octree_supported = true;
+  bool host_counts_valid = false, host_cands_valid = false;
   gfs::DevBuf<KpIn> d_kpin;
   gfs::DevBuf<gfs_keypoint> d_kps;
   gfs::DevBuf<uint8_t> d_desc;
@@ -624,7 +1108,22 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
   GFS_HIP(hipMemcpyAsync(h->d_yt_start.p, G.yt_start.data(), G.yt_start.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_yt_n.p, G.yt_n.data(), G.yt_n.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_yt_alpha.p, G.yt_alpha.data(), G.yt_alpha.size() * 4, hipMemcpyHostToDevice, s));
+  std::vector<int> kept_off(G.levels.size());
+  bool oct_ok = true;
+  {
+    int o = 0;
+    for (size_t l = 0; l < G.levels.size(); l++) {
+      kept_off[l] = o;
+      o += G.levels[l].kp_cap;
+      const LevelDev& L = G.levels[l];
+      int nIni = (int)std::round((float)(L.max_bx - 16) / (float)(L.max_by - 16));
+      if (nIni == 0) nIni = 1;
+      if (nIni > 4 || L.quota + 4 * nIni + 8 > kOctMaxNodes) oct_ok = false;  // outside what k_octree holds in LDS
+    }
+  }
+  GFS_HIP(hipMemcpyAsync(h->d_kept_off.p, kept_off.data(), kept_off.size() * sizeof(int), hipMemcpyHostToDevice, s));
   GFS_HIP(hipStreamSynchronize(s));
+  h->octree_supported = oct_ok;
   h->G = std::move(G);
   h->geom_rows = rows;
   h->geom_cols = cols;
@@ -650,6 +1149,25 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
              h->d_pyr.p, cap_pyr, h->P.ini_th, h->P.min_th, n_cells, cap_slab, h->d_slab.p, h->d_cell_cnt.p);
   GFS_LAUNCH("k_cand_pack", k_cand_pack, dim3(B), dim3(256), 0, s, h->d_levels.p, h->d_cells.p, nl, n_cells, cap_slab,
              h->d_slab.p, h->d_cell_cnt.p, cap_slab, h->d_cand.p, h->d_cand_off.p);
+  const int* tp = kBlurTaps[h->P.blur_variant ? 1 : 0];
+  if (h->device_octree && h->octree_supported) {
+    // 3-6 (device): quadtree, slot assignment, blur, orientation + descriptors — no host round trip at all
+    GFS_LAUNCH("k_octree", k_octree, dim3(B * nl), dim3(kOctThreads), 0, s, h->d_levels.p, nl, h->d_cand.p, h->d_cand_off.p,
+               cap_slab, h->d_perm0.p, h->d_perm1.p, h->d_seg0.p, h->d_seg1.p, h->d_kept_off.p, h->cap_kp, h->d_kept.p,
+               h->d_kept_cnt.p);
+    GFS_LAUNCH("k_kp_finalize", k_kp_finalize, dim3(B), dim3(256), 0, s, h->d_levels.p, nl, h->d_kept.p, h->d_kept_cnt.p,
+               h->d_kept_off.p, h->cap_kp, lap0, lap1, h->d_kpin.p, h->d_kp_count.p, h->d_mono.p);
+    GFS_LAUNCH("k_blur7", k_blur7, dim3((unsigned)G.blur_tiles.size(), B), dim3(256), 0, s, h->d_levels.p, h->d_tiles.p, l0,
+               h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, tp[0], tp[1], tp[2], tp[3]);
+    GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(h->cap_kp, 4), B), dim3(256), 0, s, h->d_levels.p, l0,
+               h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_ic_du.p,
+               h->d_ic_dv.p, h->ic_n, h->d_pattern.p, h->d_kps.p, h->d_desc.p);
+    h->last_B = B;
+    h->last_l0 = l0;
+    h->host_counts_valid = false;
+    h->host_cands_valid = false;
+    return GFS_OK;
+  }
   GFS_HIP(hipMemcpyAsync(h->h_cand_off.p, h->d_cand_off.p, (size_t)B * (nl + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
   int max_total = 0;
@@ -659,7 +1177,6 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                              hipMemcpyDeviceToHost, s));
   GFS_HIP(hipEventRecord(h->ev_copy, s));
   // 3. blur of every level runs on the GPU while the host distributes keypoints
-  const int* tp = kBlurTaps[h->P.blur_variant ? 1 : 0];
   GFS_LAUNCH("k_blur7", k_blur7, dim3((unsigned)G.blur_tiles.size(), B), dim3(256), 0, s, h->d_levels.p, h->d_tiles.p, l0,
              h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, tp[0], tp[1], tp[2], tp[3]);
   GFS_HIP(hipEventSynchronize(h->ev_copy));
@@ -718,6 +1235,24 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   }
   h->last_B = B;
   h->last_l0 = l0;
+  h->host_counts_valid = true;
+  h->host_cands_valid = true;
+  return GFS_OK;
+}
+
+// bring the per-frame counts (and, for the introspection calls, the candidate lists) of the last call to the host
+int sync_host_view(gfs_orb* h, bool want_candidates) {
+  if (h->host_counts_valid && (!want_candidates || h->host_cands_valid)) return GFS_OK;
+  const int B = h->last_B, nl = h->P.nlevels;
+  GFS_HIP(hipDeviceSynchronize());
+  GFS_HIP(hipMemcpy(h->h_kp_count.p, h->d_kp_count.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+  GFS_HIP(hipMemcpy(h->h_mono.p, h->d_mono.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+  h->host_counts_valid = true;
+  if (want_candidates) {
+    GFS_HIP(hipMemcpy(h->h_cand_off.p, h->d_cand_off.p, (size_t)B * (nl + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    GFS_HIP(hipMemcpy(h->h_cand.p, h->d_cand.p, (size_t)B * h->cap_slab * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    h->host_cands_valid = true;
+  }
   return GFS_OK;
 }
 
@@ -785,6 +1320,13 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   A(h->d_slab.alloc(B * h->cap_slab));
   A(h->d_cand.alloc(B * h->cap_slab));
   A(h->d_kpin.alloc(B * h->cap_kp));
+  A(h->d_perm0.alloc(B * h->cap_slab));
+  A(h->d_perm1.alloc(B * h->cap_slab));
+  A(h->d_seg0.alloc(B * h->cap_slab));
+  A(h->d_seg1.alloc(B * h->cap_slab));
+  A(h->d_kept.alloc(B * h->cap_kp));
+  A(h->d_kept_cnt.alloc(B * nl));
+  A(h->d_kept_off.alloc(nl));
   A(h->d_kps.alloc(B * h->cap_kp));
   A(h->d_desc.alloc(B * h->cap_kp * 32));
   A(h->h_cand_off.alloc(B * (nl + 1)));
@@ -807,6 +1349,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   h->host_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (const char* e = getenv("GFS_ORB_HOST_THREADS")) h->host_threads = std::max(1, atoi(e));
   h->pool.reset(new WorkerPool(h->host_threads));
+  if (const char* e = getenv("GFS_ORB_OCTREE")) h->device_octree = strcmp(e, "host") != 0;
   *out = h.release();
   return GFS_OK;
 }
@@ -867,6 +1410,7 @@ int gfs_orb_extract_batch(gfs_orb* h, const uint8_t* const* imgs, int B, int row
   rc = run_batch(h, l0, B, rows, cols, lap0, lap1, s);
   if (rc) return rc;
   GFS_HIP(hipStreamSynchronize(s));
+  if ((rc = sync_host_view(h, false))) return rc;
   for (int b = 0; b < B; b++) {
     const int nb = h->h_kp_count.p[b];
     n[b] = nb;
@@ -913,6 +1457,10 @@ int gfs_orb_fetch(gfs_orb* h, int b, gfs_keypoint* kps, uint8_t* desc, int cap, 
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->cfg.device));
   GFS_HIP(hipDeviceSynchronize());
+  {
+    const int rc0 = sync_host_view(h, false);
+    if (rc0) return rc0;
+  }
   const int nb = h->h_kp_count.p[b];
   if (n) *n = nb;
   if (mono_index) *mono_index = h->h_mono.p[b];
@@ -957,6 +1505,11 @@ int gfs_orb_fetch_candidates(gfs_orb* h, int b, int level, int32_t* x, int32_t* 
   GFS_REQUIRE(h && b >= 0 && b < h->last_B && level >= 0 && level < h->P.nlevels, GFS_ERR_INVALID_ARG,
               "gfs_orb_fetch_candidates: invalid argument");
   std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->cfg.device));
+  {
+    const int rc0 = sync_host_view(h, true);
+    if (rc0) return rc0;
+  }
   const int nl = h->P.nlevels;
   const int* off = h->h_cand_off.p + (size_t)b * (nl + 1);
   const int cnt = off[level + 1] - off[level];
@@ -965,6 +1518,52 @@ int gfs_orb_fetch_candidates(gfs_orb* h, int b, int level, int32_t* x, int32_t* 
     if (x) x[i] = gfs::cand_x(c[i]);
     if (y) y[i] = gfs::cand_y(c[i]);
     if (score) score[i] = gfs::cand_score(c[i]);
+  }
+  return cnt;
+}
+
+// GPU test hook: the device DistributeOctTree (k_octree) on caller candidates; out = kept candidates as packed values
+// (x | y << 12 | score << 24) in list order.  Returns the number kept or a negative gfs_status.
+int gfs_orb_octree_device(int device, const int32_t* x, const int32_t* y, const int32_t* score, int n, int min_x, int max_x,
+                          int min_y, int max_y, int n_features, int32_t* out_x, int32_t* out_y, int32_t* out_score, int cap) {
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  GFS_REQUIRE(min_x == 16 && min_y == 16 && n >= 0, GFS_ERR_INVALID_ARG, "gfs_orb_octree_device: min border must be 16");
+  LevelDev L{};
+  L.max_bx = max_x;
+  L.max_by = max_y;
+  L.quota = n_features;
+  int nIni = (int)std::round((float)(max_x - 16) / (float)(max_y - 16));
+  if (nIni == 0) nIni = 1;
+  GFS_REQUIRE(nIni <= 4 && n_features + 4 * nIni + 8 <= kOctMaxNodes, GFS_ERR_UNSUPPORTED, "outside k_octree limits");
+  const int kcap = n_features + 3 + 4 * nIni + 8;
+  std::vector<uint32_t> c(std::max(n, 1));
+  for (int i = 0; i < n; i++) c[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 12) | ((uint32_t)score[i] << 24);
+  gfs::DevBuf<LevelDev> dL;
+  gfs::DevBuf<uint32_t> dc, p0, p1, dk;
+  gfs::DevBuf<unsigned short> s0, s1;
+  gfs::DevBuf<int> doff, dko, dcnt;
+  int rc = 0;
+  if ((rc = dL.alloc(1)) || (rc = dc.alloc(c.size())) || (rc = p0.alloc(c.size())) || (rc = p1.alloc(c.size())) ||
+      (rc = s0.alloc(c.size())) || (rc = s1.alloc(c.size())) || (rc = dk.alloc(kcap)) || (rc = doff.alloc(2)) ||
+      (rc = dko.alloc(1)) || (rc = dcnt.alloc(1)))
+    return rc;
+  const int off[2] = {0, n}, ko = 0;
+  GFS_HIP(hipMemcpy(dL.p, &L, sizeof(L), hipMemcpyHostToDevice));
+  GFS_HIP(hipMemcpy(dc.p, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+  GFS_HIP(hipMemcpy(doff.p, off, sizeof(off), hipMemcpyHostToDevice));
+  GFS_HIP(hipMemcpy(dko.p, &ko, sizeof(ko), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_octree, dim3(1), dim3(kOctThreads), 0, 0, dL.p, 1, dc.p, doff.p, c.size(), p0.p, p1.p, s0.p, s1.p, dko.p, kcap,
+                     dk.p, dcnt.p);
+  GFS_HIP(hipDeviceSynchronize());
+  int cnt = 0;
+  GFS_HIP(hipMemcpy(&cnt, dcnt.p, sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> k(std::max(cnt, 1));
+  if (cnt) GFS_HIP(hipMemcpy(k.data(), dk.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < cnt && i < cap; i++) {
+    out_x[i] = gfs::cand_x(k[i]);
+    out_y[i] = gfs::cand_y(k[i]);
+    out_score[i] = gfs::cand_score(k[i]);
   }
   return cnt;
 }

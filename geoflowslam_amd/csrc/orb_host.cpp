@@ -398,3 +398,42 @@ void distribute_octree(const uint32_t* c, int n, int min_x, int max_x, int min_y
 }
 
 }  // namespace gfs
+
+// ---- test hook: the std::sort replica used by the device quadtree, run on the host against caller data ----
+#include "std_sort_replica.hpp"
+extern "C" int gfs_test_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n) {
+  struct E {
+    int s, x, p;
+  };
+  std::vector<E> v(n);
+  for (int i = 0; i < n; i++) v[i] = E{size_key[i], x_key[i], payload[i]};
+  gfs::replica_std_sort(v.data(), v.data() + n, [](const E& a, const E& b) {
+    if (a.s < b.s) return true;
+    if (a.s > b.s) return false;
+    return a.x < b.x;
+  });
+  for (int i = 0; i < n; i++) {
+    size_key[i] = v[i].s;
+    x_key[i] = v[i].x;
+    payload[i] = v[i].p;
+  }
+  return n;
+}
+extern "C" int gfs_test_heap_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n) {
+  struct E {
+    int s, x, p;
+  };
+  std::vector<E> v(n);
+  for (int i = 0; i < n; i++) v[i] = E{size_key[i], x_key[i], payload[i]};
+  gfs::replica_heap_sort(v.data(), v.data() + n, [](const E& a, const E& b) {
+    if (a.s < b.s) return true;
+    if (a.s > b.s) return false;
+    return a.x < b.x;
+  });
+  for (int i = 0; i < n; i++) {
+    size_key[i] = v[i].s;
+    x_key[i] = v[i].x;
+    payload[i] = v[i].p;
+  }
+  return n;
+}

@@ -115,6 +115,13 @@ int gfs_orb_fetch_candidates(gfs_orb* h, int b, int level, int32_t* x, int32_t* 
  * out_idx[i] = input index of the i-th kept keypoint in the reference's std::list order. */
 int gfs_orb_octree_host(const int32_t* x, const int32_t* y, const int32_t* score, int n, int min_x, int max_x,
                         int min_y, int max_y, int n_features, int32_t* out_idx, int cap);
+/* GPU test hook: the device DistributeOctTree kernel on caller candidates (min_x = min_y = 16). Writes the kept
+ * candidates (x, y, score) in list order; returns their number. */
+int gfs_orb_octree_device(int device, const int32_t* x, const int32_t* y, const int32_t* score, int n, int min_x, int max_x,
+                          int min_y, int max_y, int n_features, int32_t* out_x, int32_t* out_y, int32_t* out_score, int cap);
+/* Host test hooks for the libstdc++ std::sort replica used by the device quadtree (sorts (size, x) pairs in place). */
+int gfs_test_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
+int gfs_test_heap_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
 
 /* ============================================================================================
  * 2. Brute-force Hamming matching — replaces

@@ -800,3 +800,41 @@ int gfso_distribute_octree(const float* x, const float* y, const float* response
 }
 
 }  // extern "C"
+
+// std::sort with the compareNodes ordering on caller data (reference for the product's sort replica test)
+extern "C" int gfso_std_sort_pairs(int32_t* size_key, int32_t* x_key, int32_t* payload, int n) {
+  struct E {
+    int s, x, p;
+  };
+  std::vector<E> v(n);
+  for (int i = 0; i < n; i++) v[i] = E{size_key[i], x_key[i], payload[i]};
+  std::sort(v.begin(), v.end(), [](const E& a, const E& b) {
+    if (a.s < b.s) return true;
+    if (a.s > b.s) return false;
+    return a.x < b.x;
+  });
+  for (int i = 0; i < n; i++) {
+    size_key[i] = v[i].s;
+    x_key[i] = v[i].x;
+    payload[i] = v[i].p;
+  }
+  return n;
+}
+extern "C" int gfso_std_partial_sort_pairs(int32_t* size_key, int32_t* x_key, int32_t* payload, int n) {
+  struct E {
+    int s, x, p;
+  };
+  std::vector<E> v(n);
+  for (int i = 0; i < n; i++) v[i] = E{size_key[i], x_key[i], payload[i]};
+  std::partial_sort(v.begin(), v.end(), v.end(), [](const E& a, const E& b) {  // introsort's depth-limit fallback
+    if (a.s < b.s) return true;
+    if (a.s > b.s) return false;
+    return a.x < b.x;
+  });
+  for (int i = 0; i < n; i++) {
+    size_key[i] = v[i].s;
+    x_key[i] = v[i].x;
+    payload[i] = v[i].p;
+  }
+  return n;
+}

@@ -115,3 +115,30 @@ def test_bf_match_random_and_ties(gpu_api, oracle):
     # all-equal distances: every query picks train 0
     z = np.zeros((70, 32), np.uint8)
     assert (mt.match(z, z)[0] == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_octree_matches_oracle(gpu_api, oracle, seed):
+    """k_octree (device DistributeOctTree) against the oracle's std::list restatement: same keypoints, same order."""
+    rng = np.random.default_rng(100 + seed)
+    for trial in range(25):
+        w, h = [(608, 448), (501, 368), (1248, 688), (338, 246), (147, 102)][trial % 5]
+        n = int(rng.integers(1, [12, 300, 3000, 9000][trial % 4]))
+        centers = rng.uniform(0, 1, (10, 2)) * [w, h]
+        pts = centers[rng.integers(0, 10, n)] + rng.normal(0, 20, (n, 2))
+        pts = np.unique(np.clip(np.rint(pts), [3, 3], [w - 4, h - 4]).astype(np.int32), axis=0)
+        pts = pts[np.lexsort((pts[:, 0], pts[:, 1]))]
+        score = rng.integers(7, 25, len(pts)).astype(np.int32)  # narrow range: many response ties
+        quota = int(rng.choice([5, 60, 217, 434]))
+        exp = oracle.distribute_octree(pts[:, 0], pts[:, 1], score, 16, 16 + w, 16, 16 + h, quota)
+        ox, oy, os_ = gpu_api.octree_device(pts[:, 0], pts[:, 1], score, 16, 16 + w, 16, 16 + h, quota)
+        assert len(ox) == len(exp)
+        assert (ox == pts[exp, 0]).all() and (oy == pts[exp, 1]).all() and (os_ == score[exp]).all()
+
+
+def test_host_octree_path_still_matches(gpu_api, oracle, monkeypatch):
+    """GFS_ORB_OCTREE=host selects the round-1 host quadtree (kept as the fallback for geometries k_octree rejects)."""
+    monkeypatch.setenv("GFS_ORB_OCTREE", "host")
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    _compare_full(ext, orc, synth.noise_image(3, 640, 480))

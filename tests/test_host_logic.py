@@ -37,3 +37,35 @@ def test_hamming256_host(api, oracle):
         b = rng.integers(0, 256, 32).astype(np.uint8)
         ref = int(np.unpackbits(a ^ b).sum())
         assert api.ORBmatcher.DescriptorDistance(a, b) == ref == oracle.descriptor_distance(a, b)
+
+
+def _sort_pair(fn_prod, fn_oracle, s, x):
+    import ctypes as C
+    n = len(s)
+    p = np.arange(n, dtype=np.int32)
+    a = [s.astype(np.int32).copy(), x.astype(np.int32).copy(), p.copy()]
+    b = [s.astype(np.int32).copy(), x.astype(np.int32).copy(), p.copy()]
+    fn_prod(*[v.ctypes.data_as(C.c_void_p) for v in a], n)
+    fn_oracle(*[v.ctypes.data_as(C.c_void_p) for v in b], n)
+    return all((u == v).all() for u, v in zip(a, b))
+
+
+def test_std_sort_replica_matches_libstdcxx(api, oracle):
+    """The device quadtree re-implements libstdc++'s std::sort (introsort + final insertion sort + heap fallback)
+    because the reference's tie order depends on it (src/ORBextractor.cc:552-565, 697-698).  Same permutation as
+    std::sort / std::partial_sort on tie-heavy inputs."""
+    P, O = api.lib(), oracle.lib()
+    rng = np.random.default_rng(0)
+    for trial in range(600):
+        n = int(rng.integers(0, 700))
+        mode = trial % 4
+        if mode == 0:
+            s, x = rng.integers(2, 6, n), rng.integers(0, 8, n) * 10
+        elif mode == 1:
+            s, x = rng.integers(2, 200, n), rng.integers(0, 600, n)
+        elif mode == 2:
+            s, x = np.full(n, 3), np.full(n, 7)
+        else:
+            s, x = np.sort(rng.integers(2, 30, n))[::-1].copy(), rng.integers(0, 3, n)
+        assert _sort_pair(P.gfs_test_sort_replica, O.gfso_std_sort_pairs, s, x)
+        assert _sort_pair(P.gfs_test_heap_sort_replica, O.gfso_std_partial_sort_pairs, s, x)
