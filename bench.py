@@ -163,10 +163,12 @@ def main():
     def step():
         # ORB (+ its host quadtree) and GICP of a slice are independent, and so are the slices: every lane runs its two
         # halves on two host threads / two HIP streams (ctypes releases the GIL); no data-path synchronisation between lanes.
-        if args.serial:
+        if args.serial:  # strictly one module at a time (clean per-kernel timings for profiling)
             for ln in lanes:
                 ln.orb_and_match()
+                torch.cuda.synchronize()
                 ln.gicp()
+                torch.cuda.synchronize()
         else:
             futs = [pool.submit(f) for ln in lanes for f in (ln.orb_and_match, ln.gicp)]
             for f in futs:

@@ -88,11 +88,13 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ t
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u64* __restrict__ keys1,
                                                      unsigned* __restrict__ val0, unsigned* __restrict__ val1,
-                                                     const int* __restrict__ counts, int P, int* __restrict__ which) {
+                                                     const int* __restrict__ counts, int P, int* __restrict__ which,
+                                                     int* __restrict__ kinfo) {
   __shared__ unsigned hist[256];
   __shared__ unsigned bin_base[256];
   __shared__ unsigned wave_hist[16][256];
   __shared__ int s_uniform;
+  __shared__ int s_mn[3], s_mx[3];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = counts[c];
   u64* ka = keys0 + (size_t)c * P;
@@ -100,7 +102,62 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   unsigned* va = val0 + (size_t)c * P;
   unsigned* vb = val1 + (size_t)c * P;
   int flip = 0;
+  // Key compaction: the keys pack three 21-bit cell coordinates (x | y << 21 | z << 42) but one cloud spans only a
+  // few hundred cells per axis.  Re-basing every field to the cloud's minimum and packing the fields tightly is order
+  // preserving and cuts the 8 radix passes to ceil((bx + by + bz) / 8) (typically 4).  kinfo = {xmin, ymin, zmin, bx, by}
+  // lets later kernels decode; equality and the invalid key (all ones) are preserved.
+  if (tid < 3) {
+    s_mn[tid] = 0x7fffffff;
+    s_mx[tid] = -1;
+  }
+  __syncthreads();
+  {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+    for (int i = tid; i < n; i += 1024) {
+      const u64 k = ka[i];
+      if (k == kInvalidKey) continue;
+      const int f[3] = {(int)(k & kCoordMask), (int)((k >> kCoordBits) & kCoordMask), (int)(k >> (2 * kCoordBits))};
+      for (int a = 0; a < 3; a++) {
+        mn[a] = min(mn[a], f[a]);
+        mx[a] = max(mx[a], f[a]);
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      if (mx[a] >= 0) {
+        atomicMin(&s_mn[a], mn[a]);
+        atomicMax(&s_mx[a], mx[a]);
+      }
+    }
+  }
+  __syncthreads();
+  const bool any_valid = s_mx[0] >= 0;
+  const int mnx = any_valid ? s_mn[0] : 0, mny = any_valid ? s_mn[1] : 0, mnz = any_valid ? s_mn[2] : 0;
+  auto nbits = [](int range) {
+    int b = 1;
+    while ((1 << b) <= range) b++;
+    return b;
+  };
+  const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
+            bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
+  for (int i = tid; i < n; i += 1024) {
+    const u64 k = ka[i];
+    if (k == kInvalidKey) continue;
+    const u64 x = (k & kCoordMask) - mnx, y = ((k >> kCoordBits) & kCoordMask) - mny, z = (k >> (2 * kCoordBits)) - mnz;
+    ka[i] = x | (y << bx) | (z << (bx + by));
+  }
+  if (tid == 0) {
+    int* ki = kinfo + 8 * c;
+    ki[0] = mnx;
+    ki[1] = mny;
+    ki[2] = mnz;
+    ki[3] = bx;
+    ki[4] = by;
+  }
+  __syncthreads();
+  // invalid keys (all ones) must still sort last: run one more pass over the top bits only if any key is invalid
+  const int npass = (bx + by + bz + 7) / 8;
   for (int pass = 0; pass < 8 && n > 0; pass++) {
+    if (pass >= npass && pass < 7) continue;  // digits above the packed width are zero for valid keys (pass 7 places invalid keys)
     const int shift = 8 * pass;
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) s_uniform = 0;
@@ -260,7 +317,8 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
                                                      const unsigned* __restrict__ ci1, const int* __restrict__ which,
                                                      const int* __restrict__ m_counts, int P, double4* __restrict__ pts,
                                                      u64* __restrict__ ucell, unsigned* __restrict__ ubegin,
-                                                     int* __restrict__ n_ucell, int* __restrict__ bbox) {
+                                                     int* __restrict__ n_ucell, int* __restrict__ bbox,
+                                                     const int* __restrict__ kinfo) {
   __shared__ int s_wave[16];
   __shared__ int s_carry;
   __shared__ int s_bb[6];
@@ -288,9 +346,13 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
     int total;
     const int pos = block_scan_1024(start ? 1 : 0, s_wave, &total) + s_carry;
     if (start) {
-      uc[pos] = key;
+      // the sort compacted the keys (k_radix_sort): decode back to the packed 3 x 21-bit cell key
+      const int* ki = kinfo + 8 * c;
+      const int kbx = ki[3], kby = ki[4];
+      const int kx = (int)(key & ((1ull << kbx) - 1)) + ki[0], ky = (int)((key >> kbx) & ((1ull << kby) - 1)) + ki[1],
+                kz = (int)(key >> (kbx + kby)) + ki[2];
+      uc[pos] = pack_key(kx, ky, kz);
       ub[pos] = (unsigned)i;
-      const int kx = (int)(key & kCoordMask), ky = (int)((key >> kCoordBits) & kCoordMask), kz = (int)((key >> (2 * kCoordBits)) & kCoordMask);
       atomicMin(&s_bb[0], kx);
       atomicMin(&s_bb[1], ky);
       atomicMin(&s_bb[2], kz);
@@ -1155,7 +1217,7 @@ struct gfs_gicp {
   hipStream_t stream;
   std::mutex mu;
   gfs::DevBuf<float4> d_in_t, d_in_s;  // staging for the host-pointer entry
-  gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox, d_ginfo;
+  gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox, d_ginfo, d_kinfo1, d_kinfo2;
   gfs::DevBuf<u64> d_keys0, d_keys1, d_ck0, d_ck1, d_ucell;
   gfs::DevBuf<unsigned> d_val0, d_val1, d_ci0, d_ci1, d_ubegin, d_grid;
   gfs::DevBuf<double4> d_tmp, d_pts;
@@ -1204,6 +1266,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_nucell.alloc(C2));
   A(h->d_bbox.alloc(C2 * 6));
   A(h->d_ginfo.alloc(C2 * 8));
+  A(h->d_kinfo1.alloc(C2 * 8));
+  A(h->d_kinfo2.alloc(C2 * 8));
   A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
   A(h->d_ndone.alloc(1));
   A(h->d_keys0.alloc(C2 * P));
@@ -1281,14 +1345,14 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
              (const float4*)dev_source, (const int*)dev_nt, (const int*)dev_ns, stride_pts, P, prm.inv_leaf, h->d_keys0.p,
              h->d_val0.p, h->d_counts.p);
   GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
-             h->d_counts.p, P, h->d_which.p);
+             h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p);
   GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, (const float4*)dev_target,
              (const float4*)dev_source, stride_pts, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p, h->d_which.p,
              h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p, h->d_m.p);
   GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p, h->d_ci1.p,
-             h->d_m.p, P, h->d_which2.p);
+             h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p);
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
-             h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p);
+             h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p);
   GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(C2), dim3(1024), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
              h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p);
   const int knn_chunks = gfs::div_up(npts, 128);

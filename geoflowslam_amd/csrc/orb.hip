@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256) void k_kp_finalize(const LevelDev* __restrict_
 // ------------------------------------------------------------------------------------------------
 // k_blur7: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) fixed-point path on the un-padded level
 // (reference src/ORBextractor.cc:1188-1189; OpenCV smooth.simd.hpp): Q8.8 taps, u16 horizontal sums,
-// u32 vertical sums, (v + 32768) >> 16.  64x16 output tile per workgroup, raw + horizontal pass in LDS.
+// u32 vertical sums, (v + 32768) >> 16.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int n) {
   if (p < 0) p = -p;
@@ -779,42 +779,87 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
+// 64 x 32 output tile per workgroup; the (32+6) x 72-byte source tile (4-byte left pad keeps rows word aligned) is
+// fetched with 32-bit loads, the horizontal pass produces 4 pixels per thread from three LDS words, the vertical pass
+// 4 pixels per thread from seven 8-byte LDS reads and stores one 32-bit word.
+constexpr int kBlurTW = 64, kBlurTH = 32;
 __global__ __launch_bounds__(256) void k_blur7(const LevelDev* __restrict__ levels,
                                                const BlurTileDev* __restrict__ tiles, Lvl0 l0,
                                                const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                uint8_t* __restrict__ blur, size_t blur_frame, int t0, int t1, int t2,
                                                int t3) {
-  __shared__ uint8_t raw[22][72];
-  __shared__ uint16_t hb[22][64];
+  __shared__ __align__(16) uint32_t raw[kBlurTH + 6][18];        // 72 bytes per row: [x0-4, x0+68)
+  __shared__ __align__(16) uint16_t hb[kBlurTH + 6][kBlurTW];
   const BlurTileDev T = tiles[blockIdx.x];
   const int b = blockIdx.y;
   const LevelDev L = levels[T.level];
   int sp;
   const uint8_t* src = level_ptr(L, T.level, b, l0, pyr, pyr_frame, &sp);
-  const int x0 = T.tx * 64, y0 = T.ty * 16;
+  const int x0 = T.tx * kBlurTW, y0 = T.ty * kBlurTH;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 22 * 70; i += 256) {
-    const int r = i / 70, c = i - r * 70;
-    const int sy = reflect101(y0 + r - 3, L.rows), sx = reflect101(x0 + c - 3, L.cols);
-    raw[r][c] = src[(size_t)sy * sp + sx];
+  const bool word_ok = ((sp & 3) == 0) && ((reinterpret_cast<size_t>(src) & 3) == 0);
+  for (int i = tid; i < (kBlurTH + 6) * 18; i += 256) {
+    const int r = i / 18, w = i - r * 18;
+    const int sy = reflect101(y0 + r - 3, L.rows);
+    const int xb = x0 - 4 + 4 * w;  // first source column of this word
+    uint32_t v;
+    if (word_ok && xb >= 0 && xb + 3 < L.cols) {
+      v = *reinterpret_cast<const uint32_t*>(src + (size_t)sy * sp + xb);
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int sx = reflect101(xb + k, L.cols);
+        const int sxc = min(max(sx, 0), L.cols - 1);  // columns far right of the image are never used
+        v |= (uint32_t)src[(size_t)sy * sp + sxc] << (8 * k);
+      }
+    }
+    raw[r][w] = v;
   }
   __syncthreads();
-  for (int i = tid; i < 22 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const unsigned v = t0 * (raw[r][c] + raw[r][c + 6]) + t1 * (raw[r][c + 1] + raw[r][c + 5]) +
-                       t2 * (raw[r][c + 2] + raw[r][c + 4]) + t3 * raw[r][c + 3];
-    hb[r][c] = (uint16_t)min(v, 0xffffu);
+  for (int i = tid; i < (kBlurTH + 6) * (kBlurTW / 4); i += 256) {
+    const int r = i >> 4, g = i & 15;  // outputs 4g..4g+3 need source bytes 4g+1 .. 4g+10 of the padded row
+    const uint32_t w0 = raw[r][g], w1 = raw[r][g + 1], w2 = raw[r][g + 2];
+    unsigned by[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      by[k] = (w0 >> (8 * k)) & 0xff;
+      by[4 + k] = (w1 >> (8 * k)) & 0xff;
+      by[8 + k] = (w2 >> (8 * k)) & 0xff;
+    }
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned v = t0 * (by[k + 1] + by[k + 7]) + t1 * (by[k + 2] + by[k + 6]) + t2 * (by[k + 3] + by[k + 5]) + t3 * by[k + 4];
+      o[k] = min(v, 0xffffu);
+    }
+    *reinterpret_cast<uint2*>(&hb[r][4 * g]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
   }
   __syncthreads();
   uint8_t* dst = blur + (size_t)b * blur_frame + L.blur_off;
-  for (int i = tid; i < 16 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const int y = y0 + r, x = x0 + c;
+  for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
+    const int r = i >> 4, g = i & 15;
+    const int y = y0 + r, x = x0 + 4 * g;
     if (y >= L.rows || x >= L.cols) continue;
-    const unsigned v = t0 * ((unsigned)hb[r][c] + hb[r + 6][c]) + t1 * ((unsigned)hb[r + 1][c] + hb[r + 5][c]) +
-                       t2 * ((unsigned)hb[r + 2][c] + hb[r + 4][c]) + t3 * (unsigned)hb[r + 3][c];
-    const unsigned o = (v + 32768u) >> 16;
-    dst[(size_t)y * L.pitch + x] = (uint8_t)min(o, 255u);
+    unsigned acc[4] = {0, 0, 0, 0};
+    const int taps[7] = {t0, t1, t2, t3, t2, t1, t0};
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const uint2 h = *reinterpret_cast<const uint2*>(&hb[r + j][4 * g]);
+      acc[0] += taps[j] * (h.x & 0xffff);
+      acc[1] += taps[j] * (h.x >> 16);
+      acc[2] += taps[j] * (h.y & 0xffff);
+      acc[3] += taps[j] * (h.y >> 16);
+    }
+    uint32_t pk = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) pk |= min((acc[k] + 32768u) >> 16, 255u) << (8 * k);
+    uint8_t* d = dst + (size_t)y * L.pitch + x;
+    if (x + 3 < L.cols) {
+      *reinterpret_cast<uint32_t*>(d) = pk;  // pitch and blur_off are multiples of 64: aligned
+    } else {
+      for (int k = 0; k < 4 && x + k < L.cols; k++) d[k] = (uint8_t)(pk >> (8 * k));
+    }
   }
 }
 

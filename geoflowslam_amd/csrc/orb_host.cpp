@@ -188,7 +188,7 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
     if (nIni == 0) nIni = 1;
     L.kp_cap = L.quota + 3 + 4 * nIni;
     kp_cap += L.kp_cap;
-    for (int ty = 0; ty < (L.rows + 15) / 16; ty++)
+    for (int ty = 0; ty < (L.rows + 31) / 32; ty++)  // 64 x 32 tiles (k_blur7)
       for (int tx = 0; tx < (L.cols + 63) / 64; tx++) blur_tiles.push_back(BlurTileDev{(short)l, (short)tx, (short)ty, 0});
   }
   if (cols >= 4096 || rows >= 4096) {
