@@ -106,9 +106,8 @@ __device__ __forceinline__ unsigned has9(unsigned m) {  // any run of >= 9 set b
   return r & 0xffffu;
 }
 
-__device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, int p, int th_low) {
+__device__ __forceinline__ void ring_diffs(const uint8_t* __restrict__ c, int p, int* d) {
   const int v = c[0];
-  int d[16];
   d[0] = v - c[3 * p];
   d[1] = v - c[3 * p + 1];
   d[2] = v - c[2 * p + 2];
@@ -125,13 +124,25 @@ __device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, int p, i
   d[13] = v - c[p - 3];
   d[14] = v - c[2 * p - 2];
   d[15] = v - c[3 * p - 1];
+}
+
+// cheap test: is the pixel a FAST-9/16 corner at threshold th_low (9 contiguous ring pixels all darker or all brighter)?
+__device__ __forceinline__ bool arc_is_corner(const uint8_t* __restrict__ c, int p, int th_low) {
+  int d[16];
+  ring_diffs(c, p, d);
   unsigned md = 0, mb = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     md |= (unsigned)(d[k] > th_low) << k;
     mb |= (unsigned)(d[k] < -th_low) << k;
   }
-  if ((has9(md) | has9(mb)) == 0) return 0;
+  return (has9(md) | has9(mb)) != 0;
+}
+
+// exact arc score S (max over the 16 arcs of 9 of min(v - ring) and of min(ring - v)): only evaluated for corners
+__device__ __forceinline__ int arc_score_full(const uint8_t* __restrict__ c, int p) {
+  int d[16];
+  ring_diffs(c, p, d);
   // sliding min / max over 9 cyclic neighbours by doubling
   int lo[16], hi[16];
 #pragma unroll
@@ -176,6 +187,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
   }
   uint8_t* tile = smem;             // [h][w]
   uint8_t* sc = smem + (size_t)w * h;  // [h][w] arc score - 1 (0 = not a corner at the low threshold)
+  unsigned short* clist = reinterpret_cast<unsigned short*>(smem + (((size_t)2 * w * h + 3) & ~(size_t)3));  // corner offsets
+  __shared__ int s_ncorner;
   int sp;
   const uint8_t* src = level_ptr(L, C.level, b, l0, pyr, pyr_frame, &sp);
   src += (size_t)C.y0 * sp + C.x0;
@@ -184,15 +197,25 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
     tile[i] = src[(size_t)y * sp + x];
     sc[i] = 0;
   }
-  if (tid == 0) s_count = 0;
+  if (tid == 0) {
+    s_count = 0;
+    s_ncorner = 0;
+  }
   __syncthreads();
   const int th_hi = min(max(ini_th, 0), 255), th_lo = min(max(min_th, 0), 255);
   const int th_low = min(th_hi, th_lo);
+  // phase 1: cheap 9-arc test on every pixel; corners (a few %) are compacted into a list ...
   for (int i = tid; i < dw * dh; i += 256) {
     const int yy = i / dw, xx = i - yy * dw;
     const int o = (yy + 3) * w + xx + 3;
-    const int S = arc_score(tile + o, w, th_low);
-    sc[o] = (uint8_t)(S > th_low ? S - 1 : 0);
+    if (arc_is_corner(tile + o, w, th_low)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
+  }
+  __syncthreads();
+  // ... phase 2: the expensive exact score runs on dense lanes over the corner list only
+  const int ncorner = s_ncorner;
+  for (int k = tid; k < ncorner; k += 256) {
+    const int o = clist[k];
+    sc[o] = (uint8_t)(arc_score_full(tile + o, w) - 1);  // corner at th_low => S > th_low >= 0
   }
   __syncthreads();
   // each thread owns a contiguous raster chunk of the detection area so the emission order is raster
@@ -1189,7 +1212,7 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p, h->d_yt_start.p, h->d_yt_n.p, h->d_yt_alpha.p);
   }
   // 2. FAST cells of all levels, all frames in one launch
-  const size_t lds = 2 * (size_t)G.max_tile_w * G.max_tile_h;
+  const size_t lds = 4 * (size_t)G.max_tile_w * G.max_tile_h + 8;  // tile + score map + corner list (u16)
   GFS_LAUNCH("k_fast_cells", k_fast_cells, dim3(n_cells, B), dim3(256), lds, s, h->d_levels.p, h->d_cells.p, l0,
              h->d_pyr.p, cap_pyr, h->P.ini_th, h->P.min_th, n_cells, cap_slab, h->d_slab.p, h->d_cell_cnt.p);
   GFS_LAUNCH("k_cand_pack", k_cand_pack, dim3(B), dim3(256), 0, s, h->d_levels.p, h->d_cells.p, nl, n_cells, cap_slab,
@@ -1333,7 +1356,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   G.build(h->P, cfg->max_rows, cfg->max_cols);
   GFS_REQUIRE(G.supported, GFS_ERR_UNSUPPORTED, "ORB geometry for max size %dx%d unsupported: %s", cfg->max_cols,
               cfg->max_rows, G.why);
-  GFS_REQUIRE(2 * (size_t)G.max_tile_w * G.max_tile_h <= 60000, GFS_ERR_UNSUPPORTED, "FAST cell tile too large for LDS");
+  GFS_REQUIRE(4 * (size_t)G.max_tile_w * G.max_tile_h + 8 <= 60000, GFS_ERR_UNSUPPORTED, "FAST cell tile too large for LDS");
   const size_t B = cfg->max_batch;
   h->cap_pyr = G.pyr_bytes + 4096;
   h->cap_blur = G.blur_bytes + 4096;
