@@ -399,7 +399,7 @@ constexpr int kGridCap = 1 << 21;
 __global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
                                                     const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
                                                     const int* __restrict__ bbox, int P, unsigned* __restrict__ grid,
-                                                    int* __restrict__ ginfo) {
+                                                    int* __restrict__ ginfo, int* __restrict__ far2_count) {
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nu = n_ucell[c], m = m_counts[c];
   const u64* uc = ucell + (size_t)c * (P + 1);
@@ -418,6 +418,8 @@ __global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucel
     gi[4] = (int)ny;
     gi[5] = (int)nz;
     gi[6] = ok ? 1 : 0;
+    gi[7] = 0;  // k_knn_cov's deferred-query counter
+    far2_count[c] = 0;
   }
   if (!ok) return;
   const int ncell = (int)(nx * ny * nz);
@@ -626,85 +628,9 @@ struct TopK {
   }
 };
 
-__global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts, const u64* __restrict__ ucell,
-                                                 const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
-                                                 const int* __restrict__ m_counts, const int* __restrict__ bbox,
-                                                 const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
-                                                 int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
-  int pair, which, chunk;
-  if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
-  const int c = 2 * pair + which;
-  const int m = m_counts[c];
-  const int i = chunk * 128 + threadIdx.x;
-  if (i >= m) return;
-  const unsigned* G = grid + (size_t)c * (kGridCap + 1);
-  const int* gi = ginfo + 8 * c;
-  const double4* p = pts + (size_t)c * P;
-  const u64* uc = ucell + (size_t)c * (P + 1);
-  const unsigned* ub = ubegin + (size_t)c * (P + 1);
-  const int nu = n_ucell[c];
-  const double4 q = p[i];
-  const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
-            cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
-  TopK<10> best;
-  const int kk = min(prm.k_neighbors, 10);
-  const int want = min(kk, m);
-  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
-            bz1 = bbox[6 * c + 5];
-  // fast path: the 27-cell cube.  All 9 row ranges are fetched first (18 independent loads), the own row is scanned
-  // first so the k-th distance shrinks early, and candidates are loaded four at a time to keep loads in flight.
-  bool certified = false;
-  {
-    int j0s[9], j1s[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy + (t % 3) - 1, cz + t / 3 - 1, &j0s[t], &j1s[t]);
-    best.init();
-    constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
-#pragma unroll
-    for (int tt = 0; tt < 9; tt++) {
-      const int t = order[tt];
-      const int jb = j0s[t], je = j1s[t];
-      for (int j = jb; j < je; j += 4) {
-        const double4 t0 = p[j], t1 = p[min(j + 1, je - 1)], t2 = p[min(j + 2, je - 1)], t3 = p[min(j + 3, je - 1)];
-        {
-          const double ddx = t0.x - q.x, ddy = t0.y - q.y, ddz = t0.z - q.z;
-          best.push(j, ddx * ddx + ddy * ddy + ddz * ddz);
-        }
-        if (j + 1 < je) {
-          const double ddx = t1.x - q.x, ddy = t1.y - q.y, ddz = t1.z - q.z;
-          best.push(j + 1, ddx * ddx + ddy * ddy + ddz * ddz);
-        }
-        if (j + 2 < je) {
-          const double ddx = t2.x - q.x, ddy = t2.y - q.y, ddz = t2.z - q.z;
-          best.push(j + 2, ddx * ddx + ddy * ddy + ddz * ddz);
-        }
-        if (j + 3 < je) {
-          const double ddx = t3.x - q.x, ddy = t3.y - q.y, ddz = t3.z - q.z;
-          best.push(j + 3, ddx * ddx + ddy * ddy + ddz * ddz);
-        }
-      }
-    }
-    certified = best.found >= want && best.nth(max(want - 1, 0)) <= prm.cell * prm.cell;
-  }
-  for (int r = 2; !certified; r *= 2) {  // rare: isolated points
-    best.init();
-    // rows outside the occupied-cell bounding box are empty: clamp the probe to it
-    for (int z = max(cz - r, bz0); z <= min(cz + r, bz1); z++)
-      for (int y = max(cy - r, by0); y <= min(cy + r, by1); y++) {
-        int j0, j1;
-        row_range(gi, G, uc, ub, nu, max(cx - r, bx0), min(cx + r, bx1), y, z, &j0, &j1);
-        for (int j = j0; j < j1; j++) {
-          const double4 t = p[j];
-          const double ddx = t.x - q.x, ddy = t.y - q.y, ddz = t.z - q.z;
-          best.push(j, ddx * ddx + ddy * ddy + ddz * ddz);
-        }
-      }
-    const double reach = (double)r * prm.cell;
-    const bool covers_all = cx - r <= bx0 && cx + r >= bx1 && cy - r <= by0 && cy + r >= by1 && cz - r <= bz0 && cz + r >= bz1;
-    if ((best.found >= want && best.nth(max(want - 1, 0)) <= reach * reach) || covers_all || r > kCoordMask) break;
-  }
+// covariance of the k nearest neighbours, regularised: cov := V diag(1e-3, 1, 1) V^T  (util/normal_estimation.hpp:66-92)
+__device__ __forceinline__ void knn_write_cov(const TopK<10>& best, int kk, const double4* __restrict__ p, double* __restrict__ out) {
   const int n = min(best.found, kk);
-  double* out = cov6 + ((size_t)c * P + i) * 6;
   if (n < 5) {  // NormalCovarianceSetter::set_invalid: cov = diag(1,1,1,0)
     out[0] = 1;
     out[1] = 0;
@@ -750,6 +676,251 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
       for (int k = 0; k < 3; k++) acc += (V[3 * k + r] * dv[k]) * V[3 * k + cc];
       out[o++] = acc;
     }
+}
+
+constexpr int kKnnList = 12;  // capacity of a lane's pending-candidate list
+
+__global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts, const u64* __restrict__ ucell,
+                                                 const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
+                                                 const int* __restrict__ m_counts, const int* __restrict__ bbox,
+                                                 const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
+                                                 int* __restrict__ ginfo_rw, unsigned* __restrict__ hard_list,
+                                                 int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
+  __shared__ double s_list_d[kKnnList * 128];    // lane-private pending candidates (column layout): distance^2 ...
+  __shared__ unsigned s_list_j[kKnnList * 128];  // ... and index
+  int pair, which, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
+  const int c = 2 * pair + which;
+  const int m = m_counts[c];
+  const int i = chunk * 128 + threadIdx.x;
+  if (i >= m) return;
+  const unsigned* G = grid + (size_t)c * (kGridCap + 1);
+  const int* gi = ginfo + 8 * c;
+  const double4* p = pts + (size_t)c * P;
+  const u64* uc = ucell + (size_t)c * (P + 1);
+  const unsigned* ub = ubegin + (size_t)c * (P + 1);
+  const int nu = n_ucell[c];
+  const double4 q = p[i];
+  const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
+            cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
+  TopK<10> best;
+  const int kk = min(prm.k_neighbors, 10);
+  const int want = min(kk, m);
+  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
+            bz1 = bbox[6 * c + 5];
+  // Fast path: the 27-cell cube.  All 9 row ranges are fetched first (18 independent loads), the own row is scanned
+  // first so the k-th distance shrinks early, and candidates are loaded four at a time to keep loads in flight.
+  // A sorted insertion per candidate would run for the whole wave whenever ANY of its 64 lanes inserts (in practice:
+  // almost always), so candidates that beat the lane's current k-th distance are only appended to a lane-private
+  // LDS list (a few instructions) and the wave inserts the lists together when one of them fills up: dense lanes, and
+  // ~4 short bursts instead of one insertion per candidate.  Result identical to inserting every candidate in visiting
+  // order: the bound is never smaller than the final k-th distance and lists keep the visiting order.
+  bool certified = false;
+  {
+    int j0s[9], j1s[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy + (t % 3) - 1, cz + t / 3 - 1, &j0s[t], &j1s[t]);
+    best.init();
+    unsigned* lj = s_list_j + threadIdx.x;  // column layout [slot][lane]
+    double* ld = s_list_d + threadIdx.x;
+    int cnt = 0;
+    double dk = best.d[9];
+#define KNN_FLUSH_()                                         \
+  {                                                          \
+    for (int k_ = 0; __any(k_ < cnt); k_++)                  \
+      if (k_ < cnt) best.push((int)lj[k_ * 128], ld[k_ * 128]); \
+    cnt = 0;                                                 \
+    dk = best.d[9];                                          \
+  }
+#define KNN_APPEND_(t_, jj_)                                                      \
+  {                                                                               \
+    const double ddx_ = t_.x - q.x, ddy_ = t_.y - q.y, ddz_ = t_.z - q.z;         \
+    const double d2_ = ddx_ * ddx_ + ddy_ * ddy_ + ddz_ * ddz_;                   \
+    if (d2_ < dk) {                                                               \
+      lj[cnt * 128] = (unsigned)(jj_);                                            \
+      ld[cnt * 128] = d2_;                                                        \
+      cnt++;                                                                      \
+    }                                                                             \
+  }
+    constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+#pragma unroll
+    for (int tt = 0; tt < 9; tt++) {
+      const int t = order[tt];
+      const int jb = j0s[t], je = j1s[t];
+      for (int j = jb; j < je; j += 4) {
+        const double4 t0 = p[j], t1 = p[min(j + 1, je - 1)], t2 = p[min(j + 2, je - 1)], t3 = p[min(j + 3, je - 1)];
+        if (__any(cnt > kKnnList - 4)) KNN_FLUSH_()
+        KNN_APPEND_(t0, j)
+        if (j + 1 < je) KNN_APPEND_(t1, j + 1)
+        if (j + 2 < je) KNN_APPEND_(t2, j + 2)
+        if (j + 3 < je) KNN_APPEND_(t3, j + 3)
+      }
+    }
+    KNN_FLUSH_()
+#undef KNN_APPEND_
+#undef KNN_FLUSH_
+    certified = best.found >= want && best.nth(max(want - 1, 0)) <= prm.cell * prm.cell;
+  }
+  if (!certified) {  // isolated point (a few %): deferred to k_knn_cov_far so that one slow lane does not stall its wave
+    hard_list[(size_t)c * P + atomicAdd(&ginfo_rw[8 * c + 7], 1)] = (unsigned)i;
+    return;
+  }
+  knn_write_cov(best, kk, p, cov6 + ((size_t)c * P + i) * 6);
+}
+
+// k_knn_cov_far<LANES, R0, DEFER>: the queries whose k-th neighbour is farther than one cell (sparse regions, a few %
+// of the points).  A group of LANES lanes per deferred query, 256 / LANES queries per workgroup and round.  Search,
+// group-wide: the cells (small probes) or rows (big probes) of the ring-r cube are spread over the group's lanes (a
+// lone thread would walk them as one long dependent chain; a whole wave per query leaves the chip latency-bound on the
+// per-query fixed costs), every lane keeps the top-k of its share, and the k global winners are extracted by k
+// group-wide arg-min rounds over the lanes' list heads (ties: lower point index).  The probe grows until the k-th
+// distance is certified (<= r cells) or it covers the whole cloud.  The covariance / eigen step (scalar per query)
+// then runs for the workgroup's queries side by side.
+// Two passes: <16, 2, true> takes k_knn_cov's list (front of hard_list, counter ginfo[7]) with one r = 2 probe and
+// defers the really isolated points (~1 % of the list, but thousands of candidates each) to <64, 4, false>
+// (back of hard_list, counter far2_count) so that they do not hold up the other queries of their workgroup.
+__device__ __forceinline__ void knn_scan_run(const double4* __restrict__ p, const double4& q, int j0, int j1, TopK<10>& loc) {
+  for (int j = j0; j < j1; j += 4) {  // four loads in flight
+    const double4 t0 = p[j], t1 = p[min(j + 1, j1 - 1)], t2 = p[min(j + 2, j1 - 1)], t3 = p[min(j + 3, j1 - 1)];
+    {
+      const double ddx = t0.x - q.x, ddy = t0.y - q.y, ddz = t0.z - q.z;
+      loc.push(j, ddx * ddx + ddy * ddy + ddz * ddz);
+    }
+    if (j + 1 < j1) {
+      const double ddx = t1.x - q.x, ddy = t1.y - q.y, ddz = t1.z - q.z;
+      loc.push(j + 1, ddx * ddx + ddy * ddy + ddz * ddz);
+    }
+    if (j + 2 < j1) {
+      const double ddx = t2.x - q.x, ddy = t2.y - q.y, ddz = t2.z - q.z;
+      loc.push(j + 2, ddx * ddx + ddy * ddy + ddz * ddz);
+    }
+    if (j + 3 < j1) {
+      const double ddx = t3.x - q.x, ddy = t3.y - q.y, ddz = t3.z - q.z;
+      loc.push(j + 3, ddx * ddx + ddy * ddy + ddz * ddz);
+    }
+  }
+}
+
+template <int LANES, int R0, bool DEFER>
+__global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__ pts, const u64* __restrict__ ucell,
+                                                     const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
+                                                     const int* __restrict__ m_counts, const int* __restrict__ bbox,
+                                                     const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
+                                                     unsigned* __restrict__ hard_list, int* __restrict__ far2_count,
+                                                     int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
+  constexpr int kQueries = 256 / LANES;
+  __shared__ int s_ids[kQueries][10];
+  __shared__ int s_found[kQueries];
+  __shared__ int s_query[kQueries];
+  int pair, which, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
+  const int c = 2 * pair + which;
+  const int m = m_counts[c];
+  const unsigned* G = grid + (size_t)c * (kGridCap + 1);
+  const int* gi = ginfo + 8 * c;
+  const double4* p = pts + (size_t)c * P;
+  const u64* uc = ucell + (size_t)c * (P + 1);
+  const unsigned* ub = ubegin + (size_t)c * (P + 1);
+  unsigned* list = hard_list + (size_t)c * P;
+  const int nu = n_ucell[c];
+  const int nhard = DEFER ? gi[7] : far2_count[c];
+  const int kk = min(prm.k_neighbors, 10);
+  const int want = min(kk, m);
+  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
+            bz1 = bbox[6 * c + 5];
+  const int gl = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+  for (int base = chunk * kQueries; base < nhard; base += nchunks * kQueries) {  // uniform per workgroup
+    const int h = base + grp;
+    if (gl == 0) s_query[grp] = -1;
+    if (h < nhard) {
+      const int i = (int)(DEFER ? list[h] : list[P - 1 - h]);
+      const double4 q = p[i];
+      const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
+                cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
+      TopK<10> best;  // merged result, identical in all lanes of the group
+      bool done = false;
+      for (int r = R0;;) {
+        TopK<10> loc;
+        loc.init();
+        // cells outside the occupied-cell bounding box are empty: clamp the probe to it
+        const int x0 = max(cx - r, bx0), x1 = min(cx + r, bx1), y0 = max(cy - r, by0), y1 = min(cy + r, by1),
+                  z0 = max(cz - r, bz0), z1 = min(cz + r, bz1);
+        const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        const int upr = nx * nrows <= 128 ? nx : 1;  // work units per row: single cells for the r = 2 probe, whole rows otherwise
+        const int nunits = nrows * upr;
+        for (int t = gl; t < nunits; t += 2 * LANES) {  // two units per trip: both lookups are in flight together
+          const int ta = t, tb = min(t + LANES, nunits - 1);
+          const int rowa = ta / upr, xa = ta - rowa * upr, rowb = tb / upr, xb = tb - rowb * upr;
+          int ja0, ja1, jb0, jb1;
+          row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xa, upr == 1 ? x1 : x0 + xa, y0 + rowa % ny, z0 + rowa / ny, &ja0, &ja1);
+          row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xb, upr == 1 ? x1 : x0 + xb, y0 + rowb % ny, z0 + rowb / ny, &jb0, &jb1);
+          if (t + LANES >= nunits) jb1 = jb0;
+          knn_scan_run(p, q, ja0, ja1, loc);
+          knn_scan_run(p, q, jb0, jb1, loc);
+        }
+        best.init();
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          const double hd = loc.d[0];
+          const int hj = loc.id[0];
+          double bd = hd;
+          int bj = hj;
+#pragma unroll
+          for (int ofs = LANES / 2; ofs > 0; ofs >>= 1) {
+            const double od = __shfl_xor(bd, ofs, LANES);
+            const int oj = __shfl_xor(bj, ofs, LANES);
+            if (od < bd || (od == bd && (unsigned)oj < (unsigned)bj)) {
+              bd = od;
+              bj = oj;
+            }
+          }
+          if (bj >= 0) {
+            best.d[k] = bd;
+            best.id[k] = bj;
+            best.found = k + 1;
+          }
+          if (hj == bj && bj >= 0) {  // the owning lane pops its head
+#pragma unroll
+            for (int e = 0; e < 9; e++) {
+              loc.d[e] = loc.d[e + 1];
+              loc.id[e] = loc.id[e + 1];
+            }
+            loc.d[9] = 1.79769313486231570e308;
+            loc.id[9] = -1;
+          }
+        }
+        const double reach = (double)r * prm.cell;
+        const bool covers_all = cx - r <= bx0 && cx + r >= bx1 && cy - r <= by0 && cy + r >= by1 && cz - r <= bz0 && cz + r >= bz1;
+        const double kth = best.nth(max(want - 1, 0));
+        if ((best.found >= want && kth <= reach * reach) || covers_all || r > kCoordMask) {
+          done = true;
+          break;
+        }
+        if (DEFER) break;
+        // k candidates are known: the true k nearest lie within sqrt(kth), so the next probe is the last one
+        r = best.found >= want ? min(2 * r, (int)ceil(sqrt(kth) * prm.inv_cell)) : 2 * r;
+      }
+      if (gl == 0) {
+        if (done) {
+#pragma unroll
+          for (int k = 0; k < 10; k++) s_ids[grp][k] = best.id[k];
+          s_found[grp] = best.found;
+          s_query[grp] = i;
+        } else {
+          list[P - 1 - atomicAdd(&far2_count[c], 1)] = (unsigned)i;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kQueries && s_query[threadIdx.x] >= 0) {
+      TopK<10> res;
+      res.found = s_found[threadIdx.x];
+#pragma unroll
+      for (int k = 0; k < 10; k++) res.id[k] = s_ids[threadIdx.x][k];
+      knn_write_cov(res, kk, p, cov6 + ((size_t)c * P + s_query[threadIdx.x]) * 6);
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1217,6 +1388,8 @@ struct gfs_gicp {
   hipStream_t stream;
   std::mutex mu;
   gfs::DevBuf<float4> d_in_t, d_in_s;  // staging for the host-pointer entry
+  gfs::DevBuf<unsigned> d_hard;  // per cloud: indices of the points k_knn_cov deferred to k_knn_cov_far
+  gfs::DevBuf<int> d_far2;  // per cloud: number of points deferred a second time (stored from the back of d_hard)
   gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox, d_ginfo, d_kinfo1, d_kinfo2;
   gfs::DevBuf<u64> d_keys0, d_keys1, d_ck0, d_ck1, d_ucell;
   gfs::DevBuf<unsigned> d_val0, d_val1, d_ci0, d_ci1, d_ubegin, d_grid;
@@ -1266,6 +1439,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_nucell.alloc(C2));
   A(h->d_bbox.alloc(C2 * 6));
   A(h->d_ginfo.alloc(C2 * 8));
+  A(h->d_hard.alloc((size_t)C2 * P));
+  A(h->d_far2.alloc(C2));
   A(h->d_kinfo1.alloc(C2 * 8));
   A(h->d_kinfo2.alloc(C2 * 8));
   A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
@@ -1354,11 +1529,18 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
              h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p);
   GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(C2), dim3(1024), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
-             h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p);
+             h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p, h->d_far2.p);
   const int knn_chunks = gfs::div_up(npts, 128);
   GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(xcd_grid(knn_chunks, B, 2)), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
-             h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, knn_chunks, B, P, prm,
-             h->d_cov6.p);
+             h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_ginfo.p, h->d_hard.p,
+             knn_chunks, B, P, prm, h->d_cov6.p);
+  const int far_chunks = std::max(1, std::min(32, knn_chunks));  // grid-stride over the deferred lists
+  GFS_LAUNCH("k_knn_cov_far", (k_knn_cov_far<16, 2, true>), dim3(xcd_grid(far_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
+             h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
+             h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
+  GFS_LAUNCH("k_knn_cov_far2", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(far_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
+             h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
+             h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
   GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
              prm.max_iterations, h->d_ndone.p);
