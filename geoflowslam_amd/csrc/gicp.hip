@@ -462,6 +462,55 @@ __device__ __forceinline__ void row_range(const int* __restrict__ gi, const unsi
   }
 }
 
+// boundaries (point indices) of the three cells cx-1, cx, cx+1 of row (y, z): cell k is [e[k], e[k+1]); cells outside
+// the grid collapse to empty ranges
+__device__ __forceinline__ void row_cells3(const int* __restrict__ gi, const unsigned* __restrict__ G, const u64* __restrict__ uc,
+                                           const unsigned* __restrict__ ub, int nu, int cx, int y, int z, int* e) {
+  e[0] = e[1] = e[2] = e[3] = 0;
+  if (gi[6]) {
+    const int yy = y - gi[1], zz = z - gi[2];
+    if ((unsigned)yy >= (unsigned)gi[4] || (unsigned)zz >= (unsigned)gi[5]) return;
+    const size_t base = ((size_t)zz * gi[4] + yy) * gi[3];
+    const int a = cx - 1 - gi[0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) e[k] = (int)G[base + min(max(a + k, 0), gi[3])];
+  } else {
+    if (y < 0 || z < 0 || y > kCoordMask || z > kCoordMask) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int x = cx - 1 + k;
+      const u64 key = x < 0 ? pack_key(0, y, z) : x > kCoordMask ? pack_key(kCoordMask, y, z) + 1 : pack_key(x, y, z);
+      e[k] = (int)ub[lower_bound_u64(uc, nu, key)];
+    }
+  }
+}
+
+// 1-NN scan over up to four candidate runs (begin, length) concatenated into one lane-private sequence: every lane
+// walks only ITS surviving cells, four loads in flight, so a wave iterates max-over-lanes(sum of lengths) / 4 times.
+__device__ __forceinline__ void nn_scan_runs4(const double4* __restrict__ tp, double tx, double ty, double tz, int b0, int l0,
+                                              int b1, int l1, int b2, int l2, int b3, int l3, double& best, int& bj) {
+  const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
+  const int o0 = b0, o1 = b1 - c1, o2 = b2 - c2, o3 = b3 - c3;
+  for (int v = 0; v < total; v += 4) {
+    int j[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int vv = min(v + u, total - 1);
+      j[u] = vv + (vv < c1 ? o0 : vv < c2 ? o1 : vv < c3 ? o2 : o3);
+    }
+    const double4 q0 = tp[j[0]], q1 = tp[j[1]], q2 = tp[j[2]], q3 = tp[j[3]];
+    const double d0 = (q0.x - tx) * (q0.x - tx) + (q0.y - ty) * (q0.y - ty) + (q0.z - tz) * (q0.z - tz);
+    const double d1 = (q1.x - tx) * (q1.x - tx) + (q1.y - ty) * (q1.y - ty) + (q1.z - tz) * (q1.z - tz);
+    const double d2 = (q2.x - tx) * (q2.x - tx) + (q2.y - ty) * (q2.y - ty) + (q2.z - tz) * (q2.z - tz);
+    const double d3 = (q3.x - tx) * (q3.x - tx) + (q3.y - ty) * (q3.y - ty) + (q3.z - tz) * (q3.z - tz);
+    // clamped duplicates of the last candidate cannot win the strict '<'
+    if (d0 < best) { best = d0; bj = j[0]; }
+    if (d1 < best) { best = d1; bj = j[1]; }
+    if (d2 < best) { best = d2; bj = j[2]; }
+    if (d3 < best) { best = d3; bj = j[3]; }
+  }
+}
+
 // XCD-aware block -> (pair, which, chunk) map.  MI355X dispatches workgroup b to XCD b % 8 and every XCD has a private
 // 4 MiB L2: giving all chunks of one frame pair the same (b % 8) keeps that pair's ~1.5 MB of points / covariances /
 // grid resident in ONE L2 instead of being spread over (and evicted from) all eight.  Affects speed only.
@@ -678,107 +727,7 @@ __device__ __forceinline__ void knn_write_cov(const TopK<10>& best, int kk, cons
     }
 }
 
-constexpr int kKnnList = 12;  // capacity of a lane's pending-candidate list
-
-__global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts, const u64* __restrict__ ucell,
-                                                 const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
-                                                 const int* __restrict__ m_counts, const int* __restrict__ bbox,
-                                                 const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
-                                                 int* __restrict__ ginfo_rw, unsigned* __restrict__ hard_list,
-                                                 int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
-  __shared__ double s_list_d[kKnnList * 128];    // lane-private pending candidates (column layout): distance^2 ...
-  __shared__ unsigned s_list_j[kKnnList * 128];  // ... and index
-  int pair, which, chunk;
-  if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
-  const int c = 2 * pair + which;
-  const int m = m_counts[c];
-  const int i = chunk * 128 + threadIdx.x;
-  if (i >= m) return;
-  const unsigned* G = grid + (size_t)c * (kGridCap + 1);
-  const int* gi = ginfo + 8 * c;
-  const double4* p = pts + (size_t)c * P;
-  const u64* uc = ucell + (size_t)c * (P + 1);
-  const unsigned* ub = ubegin + (size_t)c * (P + 1);
-  const int nu = n_ucell[c];
-  const double4 q = p[i];
-  const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
-            cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
-  TopK<10> best;
-  const int kk = min(prm.k_neighbors, 10);
-  const int want = min(kk, m);
-  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
-            bz1 = bbox[6 * c + 5];
-  // Fast path: the 27-cell cube.  All 9 row ranges are fetched first (18 independent loads), the own row is scanned
-  // first so the k-th distance shrinks early, and candidates are loaded four at a time to keep loads in flight.
-  // A sorted insertion per candidate would run for the whole wave whenever ANY of its 64 lanes inserts (in practice:
-  // almost always), so candidates that beat the lane's current k-th distance are only appended to a lane-private
-  // LDS list (a few instructions) and the wave inserts the lists together when one of them fills up: dense lanes, and
-  // ~4 short bursts instead of one insertion per candidate.  Result identical to inserting every candidate in visiting
-  // order: the bound is never smaller than the final k-th distance and lists keep the visiting order.
-  bool certified = false;
-  {
-    int j0s[9], j1s[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy + (t % 3) - 1, cz + t / 3 - 1, &j0s[t], &j1s[t]);
-    best.init();
-    unsigned* lj = s_list_j + threadIdx.x;  // column layout [slot][lane]
-    double* ld = s_list_d + threadIdx.x;
-    int cnt = 0;
-    double dk = best.d[9];
-#define KNN_FLUSH_()                                         \
-  {                                                          \
-    for (int k_ = 0; __any(k_ < cnt); k_++)                  \
-      if (k_ < cnt) best.push((int)lj[k_ * 128], ld[k_ * 128]); \
-    cnt = 0;                                                 \
-    dk = best.d[9];                                          \
-  }
-#define KNN_APPEND_(t_, jj_)                                                      \
-  {                                                                               \
-    const double ddx_ = t_.x - q.x, ddy_ = t_.y - q.y, ddz_ = t_.z - q.z;         \
-    const double d2_ = ddx_ * ddx_ + ddy_ * ddy_ + ddz_ * ddz_;                   \
-    if (d2_ < dk) {                                                               \
-      lj[cnt * 128] = (unsigned)(jj_);                                            \
-      ld[cnt * 128] = d2_;                                                        \
-      cnt++;                                                                      \
-    }                                                                             \
-  }
-    constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
-#pragma unroll
-    for (int tt = 0; tt < 9; tt++) {
-      const int t = order[tt];
-      const int jb = j0s[t], je = j1s[t];
-      for (int j = jb; j < je; j += 4) {
-        const double4 t0 = p[j], t1 = p[min(j + 1, je - 1)], t2 = p[min(j + 2, je - 1)], t3 = p[min(j + 3, je - 1)];
-        if (__any(cnt > kKnnList - 4)) KNN_FLUSH_()
-        KNN_APPEND_(t0, j)
-        if (j + 1 < je) KNN_APPEND_(t1, j + 1)
-        if (j + 2 < je) KNN_APPEND_(t2, j + 2)
-        if (j + 3 < je) KNN_APPEND_(t3, j + 3)
-      }
-    }
-    KNN_FLUSH_()
-#undef KNN_APPEND_
-#undef KNN_FLUSH_
-    certified = best.found >= want && best.nth(max(want - 1, 0)) <= prm.cell * prm.cell;
-  }
-  if (!certified) {  // isolated point (a few %): deferred to k_knn_cov_far so that one slow lane does not stall its wave
-    hard_list[(size_t)c * P + atomicAdd(&ginfo_rw[8 * c + 7], 1)] = (unsigned)i;
-    return;
-  }
-  knn_write_cov(best, kk, p, cov6 + ((size_t)c * P + i) * 6);
-}
-
-// k_knn_cov_far<LANES, R0, DEFER>: the queries whose k-th neighbour is farther than one cell (sparse regions, a few %
-// of the points).  A group of LANES lanes per deferred query, 256 / LANES queries per workgroup and round.  Search,
-// group-wide: the cells (small probes) or rows (big probes) of the ring-r cube are spread over the group's lanes (a
-// lone thread would walk them as one long dependent chain; a whole wave per query leaves the chip latency-bound on the
-// per-query fixed costs), every lane keeps the top-k of its share, and the k global winners are extracted by k
-// group-wide arg-min rounds over the lanes' list heads (ties: lower point index).  The probe grows until the k-th
-// distance is certified (<= r cells) or it covers the whole cloud.  The covariance / eigen step (scalar per query)
-// then runs for the workgroup's queries side by side.
-// Two passes: <16, 2, true> takes k_knn_cov's list (front of hard_list, counter ginfo[7]) with one r = 2 probe and
-// defers the really isolated points (~1 % of the list, but thousands of candidates each) to <64, 4, false>
-// (back of hard_list, counter far2_count) so that they do not hold up the other queries of their workgroup.
+// scans the run [j0, j1) of candidate points, four loads in flight
 __device__ __forceinline__ void knn_scan_run(const double4* __restrict__ p, const double4& q, int j0, int j1, TopK<10>& loc) {
   for (int j = j0; j < j1; j += 4) {  // four loads in flight
     const double4 t0 = p[j], t1 = p[min(j + 1, j1 - 1)], t2 = p[min(j + 2, j1 - 1)], t3 = p[min(j + 3, j1 - 1)];
@@ -801,6 +750,65 @@ __device__ __forceinline__ void knn_scan_run(const double4* __restrict__ p, cons
   }
 }
 
+__global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts, const u64* __restrict__ ucell,
+                                                 const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
+                                                 const int* __restrict__ m_counts, const int* __restrict__ bbox,
+                                                 const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
+                                                 int* __restrict__ ginfo_rw, unsigned* __restrict__ hard_list,
+                                                 int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
+  int pair, which, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
+  const int c = 2 * pair + which;
+  const int m = m_counts[c];
+  const int i = chunk * 128 + threadIdx.x;
+  if (i >= m) return;
+  const unsigned* G = grid + (size_t)c * (kGridCap + 1);
+  const int* gi = ginfo + 8 * c;
+  const double4* p = pts + (size_t)c * P;
+  const u64* uc = ucell + (size_t)c * (P + 1);
+  const unsigned* ub = ubegin + (size_t)c * (P + 1);
+  const int nu = n_ucell[c];
+  const double4 q = p[i];
+  const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
+            cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
+  TopK<10> best;
+  const int kk = min(prm.k_neighbors, 10);
+  const int want = min(kk, m);
+  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
+            bz1 = bbox[6 * c + 5];
+  // The 27-cell cube: all 9 row ranges are fetched first (18 independent loads), the own row is scanned first so the
+  // k-th distance shrinks early, candidates are loaded four at a time.
+  bool certified = false;
+  {
+    int j0s[9], j1s[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy + (t % 3) - 1, cz + t / 3 - 1, &j0s[t], &j1s[t]);
+    best.init();
+    constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+#pragma unroll
+    for (int tt = 0; tt < 9; tt++) knn_scan_run(p, q, j0s[order[tt]], j1s[order[tt]], best);
+    certified = best.found >= want && best.nth(max(want - 1, 0)) <= prm.cell * prm.cell;
+  }
+  // Isolated point (k-th neighbour beyond one cell, ~2 % of a depth-camera cloud): it needs a (much) bigger probe.  Done
+  // here it would stall the other 63 lanes of its wave (and ~70 % of the waves hold such a lane), so it is deferred.
+  if (!certified) {
+    hard_list[(size_t)c * P + atomicAdd(&ginfo_rw[8 * c + 7], 1)] = (unsigned)i;
+    return;
+  }
+  knn_write_cov(best, kk, p, cov6 + ((size_t)c * P + i) * 6);
+}
+
+// k_knn_cov_far<LANES, R0, DEFER>: the queries whose k-th neighbour is farther than one cell (sparse regions, a few %
+// of the points).  A group of LANES lanes per deferred query, 256 / LANES queries per workgroup and round.  Search,
+// group-wide: the cells (small probes) or rows (big probes) of the ring-r cube are spread over the group's lanes (a
+// lone thread would walk them as one long dependent chain; a whole wave per query leaves the chip latency-bound on the
+// per-query fixed costs), every lane keeps the top-k of its share, and the k global winners are extracted by k
+// group-wide arg-min rounds over the lanes' list heads (ties: lower point index).  The probe grows until the k-th
+// distance is certified (<= r cells) or it covers the whole cloud.  The covariance / eigen step (scalar per query)
+// then runs for the workgroup's queries side by side.
+// Two passes: <16, 2, true> takes k_knn_cov's list (front of hard_list, counter ginfo[7]) with one r = 2 probe and
+// defers the really isolated points (~1 % of the list, but thousands of candidates each) to <64, 4, false>
+// (back of hard_list, counter far2_count) so that they do not hold up the other queries of their workgroup.
 template <int LANES, int R0, bool DEFER>
 __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__ pts, const u64* __restrict__ ucell,
                                                      const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
@@ -1005,6 +1013,67 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
     double best = 1.79769313486231570e308;
     int bj = -1;
     if (fabs(tx) < 2.0e4 && fabs(ty) < 2.0e4 && fabs(tz) < 2.0e4) {
+      if (prm.nn_rings <= 1) {
+        // Exact 1-NN inside the 27-cell cube (cell edge >= max correspondence distance), branch-and-bound per lane:
+        // a cell is skipped when its box is farther than the bound B = min(max_dist^2, best so far).  The bound starts
+        // from the correspondence of the previous linearisation (re-evaluated under the new pose) when there is one,
+        // so most lanes visit their own cell and little else; each lane walks only its surviving cells (nn_scan_runs4).
+        double B = prm.max_dist_sq;
+        if (S.n_lin > 0) {
+          const int pj = tgt_index[(size_t)pair * P + i];
+          if (pj >= 0) {
+            const double4 q = tp[pj];
+            best = (q.x - tx) * (q.x - tx) + (q.y - ty) * (q.y - ty) + (q.z - tz) * (q.z - tz);
+            bj = pj;
+            B = fmin(B, best);
+          }
+        }
+        // lower bounds of the distance to the neighbouring cells along each axis (a hair conservative: 1e-9 cells)
+        const double ux = tx * prm.inv_cell - (double)(cx - kCoordOffset), uy = ty * prm.inv_cell - (double)(cy - kCoordOffset),
+                     uz = tz * prm.inv_cell - (double)(cz - kCoordOffset);
+        const double lx0 = fmax(ux - 1e-9, 0.0) * prm.cell, lx2 = fmax(1.0 - ux - 1e-9, 0.0) * prm.cell;
+        const double ly[3] = {fmax(uy - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uy - 1e-9, 0.0) * prm.cell};
+        const double lz[3] = {fmax(uz - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uz - 1e-9, 0.0) * prm.cell};
+        {  // own row first
+          int e[4];
+          row_cells3(gi, G, uc, ub, nu, cx, cy, cz, e);
+          const int b0 = lx0 * lx0 <= B ? e[0] : e[1], e0 = lx2 * lx2 <= B ? e[3] : e[2];
+          nn_scan_runs4(tp, tx, ty, tz, b0, e0 - b0, 0, 0, 0, 0, 0, 0, best, bj);
+          B = fmin(B, best);
+        }
+        int rb[8], rl[8], rank[8], nkept = 0;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) {
+          const int t9 = t8 < 4 ? t8 : t8 + 1, dy = t9 % 3, dz = t9 / 3;
+          const double row2 = ly[dy] * ly[dy] + lz[dz] * lz[dz];
+          rb[t8] = 0;
+          rl[t8] = 0;
+          if (row2 <= B) {
+            int e[4];
+            row_cells3(gi, G, uc, ub, nu, cx, cy + dy - 1, cz + dz - 1, e);
+            const int b0 = row2 + lx0 * lx0 <= B ? e[0] : e[1], e0 = row2 + lx2 * lx2 <= B ? e[3] : e[2];
+            rb[t8] = b0;
+            rl[t8] = e0 - b0;
+          }
+          rank[t8] = nkept;
+          nkept += rl[t8] > 0 ? 1 : 0;
+        }
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+          if (round == 1 && !__any(nkept > 4)) break;
+          int sb[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int t8 = 0; t8 < 8; t8++)
+#pragma unroll
+            for (int sl_i = 0; sl_i < 4; sl_i++)
+              if (rl[t8] > 0 && rank[t8] == 4 * round + sl_i) {
+                sb[sl_i] = rb[t8];
+                sl[sl_i] = rl[t8];
+              }
+          nn_scan_runs4(tp, tx, ty, tz, sb[0], sl[0], sb[1], sl[1], sb[2], sl[2], sb[3], sl[3], best, bj);
+        }
+      } else {
+      // (cell edge < max correspondence distance: experiment knob GFS_GICP_CELL)
       // exact 1-NN by growing cubes of cells: after probing radius r every unvisited point is farther than r*cell,
       // so the search stops as soon as the best distance is certified (usually r = 1), or at nn_rings (>= max_corr).
       // r = 1 fast path: 9 row ranges fetched up-front, candidates loaded four at a time (loads kept in flight).
@@ -1051,6 +1120,7 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
           }
         const double reach = (double)r * prm.cell;
         if (bj >= 0 && best <= reach * reach) break;
+      }
       }
     }
     int ti = -1;
