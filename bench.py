@@ -160,19 +160,21 @@ def main():
     last = {}
     ext = lanes[0].ext
 
-    def step():
-        # ORB (+ its host quadtree) and GICP of a slice are independent, and so are the slices: every lane runs its two
-        # halves on two host threads / two HIP streams (ctypes releases the GIL); no data-path synchronisation between lanes.
-        if args.serial:  # strictly one module at a time (clean per-kernel timings for profiling)
-            for ln in lanes:
-                ln.orb_and_match()
-                torch.cuda.synchronize()
-                ln.gicp()
-                torch.cuda.synchronize()
-        else:
-            futs = [pool.submit(f) for ln in lanes for f in (ln.orb_and_match, ln.gicp)]
-            for f in futs:
-                f.result()
+    def step_serial():  # strictly one module at a time: clean per-kernel timings (profiling pass, --serial)
+        for ln in lanes:
+            ln.orb_and_match()
+            torch.cuda.synchronize()
+            ln.gicp()
+            torch.cuda.synchronize()
+
+    def step_overlapped():
+        # ORB and GICP of a slice are independent, and so are the slices: every lane runs its two halves on two host
+        # threads / two HIP streams (ctypes releases the GIL); no data-path synchronisation between lanes.
+        futs = [pool.submit(f) for ln in lanes for f in (ln.orb_and_match, ln.gicp)]
+        for f in futs:
+            f.result()
+
+    step = step_serial if args.serial else step_overlapped
 
     def gicp_results():
         return [dict(n_linearize=r.n_linearize, n_error_evals=r.n_error_evals, n_source_ds=r.n_source_ds,
@@ -198,7 +200,8 @@ def main():
         dt = float(t.item())
     fps = world * B * args.steps / dt
 
-    # ---- dominant-kernel roofline: per-kernel HIP-event timing on the launch stream (extra, untimed steps)
+    # ---- dominant-kernel roofline: per-kernel HIP-event timing on the launch stream (extra, untimed steps, run one
+    #      module at a time so that a kernel's events do not include waiting for kernels of other streams)
     roofline = None
     kern = {}
     if rank == 0:
@@ -206,7 +209,7 @@ def main():
         api.profile_enable(True)
         nprof = 2
         for _ in range(nprof):
-            step()
+            step_serial()
         torch.cuda.synchronize()
         kern = api.profile_report()
         api.profile_enable(False)

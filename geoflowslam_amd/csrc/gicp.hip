@@ -1468,6 +1468,7 @@ struct gfs_gicp {
   gfs::DevBuf<PairState> d_state;
   gfs::PinBuf<PairState> h_state;
   gfs::PinBuf<int> h_ndone, h_m;
+  hipEvent_t ev_round[2] = {nullptr, nullptr};  // completion of the two LM rounds in flight
   gfs::PinBuf<double> h_initT;
   int last_B = 0;
 };
@@ -1535,7 +1536,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_initT.alloc(B * 16));
   A(h->d_state.alloc(B));
   A(h->h_state.alloc(B));
-  A(h->h_ndone.alloc(1));
+  A(h->h_ndone.alloc(2));
+  for (int k = 0; k < 2; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_round[k], hipEventDisableTiming));
   A(h->h_m.alloc(C2));
   A(h->h_initT.alloc(B * 16));
 #undef A
@@ -1549,6 +1551,8 @@ void gfs_gicp_destroy(gfs_gicp* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamDestroy(h->stream);
+  for (int k = 0; k < 2; k++)
+    if (h->ev_round[k]) (void)hipEventDestroy(h->ev_round[k]);
   delete h;
 }
 
@@ -1625,9 +1629,14 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
                h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B);
     GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
                h->d_ndone.p);
-    GFS_HIP(hipMemcpyAsync(h->h_ndone.p, h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    GFS_HIP(hipStreamSynchronize(s));
-    if (*h->h_ndone.p >= B) break;
+    // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
+    // speculative round after convergence finds every pair in phase 2 and its blocks exit at once.
+    GFS_HIP(hipMemcpyAsync(h->h_ndone.p + (round & 1), h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipEventRecord(h->ev_round[round & 1], s));
+    if (round >= 1) {
+      GFS_HIP(hipEventSynchronize(h->ev_round[(round - 1) & 1]));
+      if (h->h_ndone.p[(round - 1) & 1] >= B) break;
+    }
   }
   GFS_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, (size_t)B * sizeof(PairState), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_m.p, h->d_m.p, (size_t)C2 * sizeof(int), hipMemcpyDeviceToHost, s));
