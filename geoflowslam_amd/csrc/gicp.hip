@@ -651,20 +651,28 @@ struct TopK {
     }
     found = 0;
   }
-  __device__ void push(int index, double dist) {  // ann/knn_result.hpp:80-101 (insert after equal distances)
+  // ann/knn_result.hpp:80-101 (sorted insertion, after equal distances), walked from the BACK of the list: a candidate
+  // that passes the k-th-distance test usually lands in the last few slots, and once every lane of the wave has placed
+  // its element the remaining stages run with an empty EXEC mask (skipped).
+  __device__ void push(int index, double dist) {
     if (dist >= d[K - 1]) return;
-    double cd = dist;
-    int ci = index;
+    bool active = true;
 #pragma unroll
-    for (int i = 0; i < K; i++) {
-      if (cd < d[i]) {
-        const double td = d[i];
-        const int ti = id[i];
-        d[i] = cd;
-        id[i] = ci;
-        cd = td;
-        ci = ti;
+    for (int i = K - 1; i >= 1; i--) {
+      if (active) {
+        if (dist < d[i - 1]) {
+          d[i] = d[i - 1];
+          id[i] = id[i - 1];
+        } else {
+          d[i] = dist;
+          id[i] = index;
+          active = false;
+        }
       }
+    }
+    if (active) {
+      d[0] = dist;
+      id[0] = index;
     }
     found = min(found + 1, K);
   }
