@@ -127,15 +127,22 @@ __device__ __forceinline__ void ring_diffs(const uint8_t* __restrict__ c, int p,
 }
 
 // cheap test: is the pixel a FAST-9/16 corner at threshold th_low (9 contiguous ring pixels all darker or all brighter)?
+// One subtraction + one funnel shift per ring pixel and polarity: the sign bit of (ring - (v - t)) resp. ((v + t) - ring)
+// is shifted into a 16-bit mask (ring order reversed, which the cyclic run test does not care about).
 __device__ __forceinline__ bool arc_is_corner(const uint8_t* __restrict__ c, int p, int th_low) {
-  int d[16];
-  ring_diffs(c, p, d);
+  const int v = c[0], lo = v - th_low, hi = v + th_low;
+  const uint8_t *rm3 = c - 3 * p, *rm2 = c - 2 * p, *rm1 = c - p, *rp1 = c + p, *rp2 = c + 2 * p, *rp3 = c + 3 * p;
   unsigned md = 0, mb = 0;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    md |= (unsigned)(d[k] > th_low) << k;
-    mb |= (unsigned)(d[k] < -th_low) << k;
+#define GFS_RING_(px)                                                     \
+  {                                                                       \
+    const int cv_ = (px);                                                 \
+    md = __builtin_amdgcn_alignbit(md, (unsigned)(cv_ - lo), 31);         \
+    mb = __builtin_amdgcn_alignbit(mb, (unsigned)(hi - cv_), 31);         \
   }
+  GFS_RING_(rp3[0]) GFS_RING_(rp3[1]) GFS_RING_(rp2[2]) GFS_RING_(rp1[3]) GFS_RING_(c[3]) GFS_RING_(rm1[3]) GFS_RING_(rm2[2])
+  GFS_RING_(rm3[1]) GFS_RING_(rm3[0]) GFS_RING_(rm3[-1]) GFS_RING_(rm2[-2]) GFS_RING_(rm1[-3]) GFS_RING_(c[-3])
+  GFS_RING_(rp1[-3]) GFS_RING_(rp2[-2]) GFS_RING_(rp3[-1])
+#undef GFS_RING_
   return (has9(md) | has9(mb)) != 0;
 }
 
@@ -174,7 +181,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
                                                     uint32_t* __restrict__ slab, int* __restrict__ cell_cnt) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ int s_count;
-  __shared__ int s_scan[256];
   const int cell_id = blockIdx.x, b = blockIdx.y;
   const CellDev C = cells[cell_id];
   const LevelDev L = levels[C.level];
@@ -192,10 +198,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
   int sp;
   const uint8_t* src = level_ptr(L, C.level, b, l0, pyr, pyr_frame, &sp);
   src += (size_t)C.y0 * sp + C.x0;
-  for (int i = tid; i < w * h; i += 256) {
-    const int y = i / w, x = i - y * w;
-    tile[i] = src[(size_t)y * sp + x];
-    sc[i] = 0;
+  {
+    const int sy = 256 / w, sx = 256 - sy * w;  // raster step of 256 pixels
+    int x = tid % w;
+    size_t g = (size_t)(tid / w) * sp + x;
+    for (int i = tid; i < w * h; i += 256) {
+      tile[i] = src[g];
+      sc[i] = 0;
+      x += sx;
+      g += (size_t)sy * sp + sx;
+      if (x >= w) {
+        x -= w;
+        g += sp - w;
+      }
+    }
   }
   if (tid == 0) {
     s_count = 0;
@@ -205,10 +221,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
   const int th_hi = min(max(ini_th, 0), 255), th_lo = min(max(min_th, 0), 255);
   const int th_low = min(th_hi, th_lo);
   // phase 1: cheap 9-arc test on every pixel; corners (a few %) are compacted into a list ...
-  for (int i = tid; i < dw * dh; i += 256) {
-    const int yy = i / dw, xx = i - yy * dw;
-    const int o = (yy + 3) * w + xx + 3;
-    if (arc_is_corner(tile + o, w, th_low)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
+  {
+    const int sy = 256 / dw, sx = 256 - sy * dw;  // raster step of 256 pixels
+    int xx = tid % dw, o = (tid / dw + 3) * w + xx + 3;
+    for (int i = tid; i < dw * dh; i += 256) {
+      if (arc_is_corner(tile + o, w, th_low)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
+      xx += sx;
+      o += sy * w + sx;
+      if (xx >= dw) {
+        xx -= dw;
+        o += w - dw;
+      }
+    }
   }
   __syncthreads();
   // ... phase 2: the expensive exact score runs on dense lanes over the corner list only
@@ -218,56 +242,40 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
     sc[o] = (uint8_t)(arc_score_full(tile + o, w) - 1);  // corner at th_low => S > th_low >= 0
   }
   __syncthreads();
-  // each thread owns a contiguous raster chunk of the detection area so the emission order is raster
-  const int total = dw * dh;
-  const int chunk = (total + 255) / 256;
-  const int i0 = min(tid * chunk, total), i1 = min(i0 + chunk, total);
+  // phase 3: 3x3 non-maximum suppression (scores below the threshold count as 0 outside the corner set, and the cell
+  // border is outside the detection area: nonmaxSuppression of cv::FAST on the cell image) over the corner list only.
+  // Survivors are collected unordered; the tile is no longer needed and is reused for their offsets (at most one
+  // survivor per 2x2 block -> w*h/4 entries of 2 bytes).
+  unsigned short* klist = reinterpret_cast<unsigned short*>(tile);
   int T = max(th_hi, 1);
-  int mine = 0;
+  int nk = 0;
   for (int pass = 0; pass < 2; pass++) {
-    mine = 0;
-    for (int i = i0; i < i1; i++) {
-      const int yy = i / dw, xx = i - yy * dw;
-      const int o = (yy + 3) * w + xx + 3;
+    for (int k = tid; k < ncorner; k += 256) {
+      const int o = clist[k];
       const int s = sc[o];
       if (s < T) continue;
 #define NB(off) ((int)sc[o + (off)] >= T ? (int)sc[o + (off)] : 0)
       const bool keep = s > NB(-1) && s > NB(1) && s > NB(-w - 1) && s > NB(-w) && s > NB(-w + 1) && s > NB(w - 1) &&
                         s > NB(w) && s > NB(w + 1);
 #undef NB
-      mine += keep ? 1 : 0;
+      if (keep) klist[atomicAdd(&s_count, 1)] = (unsigned short)o;
     }
-    if (mine) atomicAdd(&s_count, mine);
     __syncthreads();
-    const int cnt = s_count;
-    __syncthreads();
-    if (cnt > 0 || pass == 1) break;
+    nk = s_count;
+    if (nk > 0 || pass == 1) break;
     T = max(th_lo, 1);  // vKeysCell.empty() -> retry with minThFAST (src/ORBextractor.cc:825-827)
   }
-  // exclusive scan of per-thread counts
-  s_scan[tid] = mine;
-  __syncthreads();
-  for (int ofs = 1; ofs < 256; ofs <<= 1) {
-    const int v = tid >= ofs ? s_scan[tid - ofs] : 0;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
-  }
-  int pos = s_scan[tid] - mine;
+  // phase 4: raster order = ascending tile offset; every survivor finds its rank among the (few) survivors
   uint32_t* out = slab + (size_t)b * slab_frame + C.slab_off;
   const int offx = C.x0 - 16, offy = C.y0 - 16;  // + j*wCell, + i*hCell (src/ORBextractor.cc:847-848)
-  for (int i = i0; i < i1 && mine > 0; i++) {
-    const int yy = i / dw, xx = i - yy * dw;
-    const int o = (yy + 3) * w + xx + 3;
-    const int s = sc[o];
-    if (s < T) continue;
-#define NB(off) ((int)sc[o + (off)] >= T ? (int)sc[o + (off)] : 0)
-    const bool keep = s > NB(-1) && s > NB(1) && s > NB(-w - 1) && s > NB(-w) && s > NB(-w + 1) && s > NB(w - 1) &&
-                      s > NB(w) && s > NB(w + 1);
-#undef NB
-    if (keep) out[pos++] = (uint32_t)(xx + 3 + offx) | ((uint32_t)(yy + 3 + offy) << 12) | ((uint32_t)s << 24);
+  for (int k = tid; k < nk; k += 256) {
+    const int o = klist[k];
+    int r = 0;
+    for (int j = 0; j < nk; j++) r += klist[j] < o ? 1 : 0;
+    const int y = o / w, x = o - y * w;
+    out[r] = (uint32_t)(x + offx) | ((uint32_t)(y + offy) << 12) | ((uint32_t)sc[o] << 24);
   }
-  if (tid == 255) cell_cnt[(size_t)b * n_cells + cell_id] = s_scan[255];
+  if (tid == 0) cell_cnt[(size_t)b * n_cells + cell_id] = nk;
 }
 
 // ------------------------------------------------------------------------------------------------
