@@ -233,12 +233,13 @@ def main():
         ach = ab / avg_s / 1e9 if ab else None
         traffic = None
         traffic_note = None
-        pmc = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_serial_b64.json")
-        if os.path.exists(pmc) and B == 64:
-            t = json.load(open(pmc)).get(name)
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_serial_b64.json")))  # newest round last
+        if pmcs and B == 64:
+            t = json.load(open(pmcs[-1])).get(name)
             if t:  # HBM-side bytes per STEP measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)
                 traffic = int((t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
-                traffic_note = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, B=64, 1 lane, serial), KB*1024, "
+                traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, B=64, 1 lane, serial), KB*1024, "
                                 "per step / launches per step; FETCH_SIZE left uncorrected (gather pattern uncalibrated, "
                                 "MI355X_MICROARCH.md §HBM)")
         roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 2) if ach else None, peak=HBM_PEAK_GBS, unit="GB/s",

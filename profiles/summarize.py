@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 CSVs written by profiles/collect.sh into the small summaries kept under profiles/:
+   <tag>_kernel_stats.csv / <tag>_kernel_stats_serial.csv (copies of rocprofv3's kernel_stats.csv),
+   <tag>_pmc_traffic_serial_b64.json (FETCH_SIZE / WRITE_SIZE in KB per launch and per bench step),
+   <tag>_pmc_sq.json (SQ / TCP counters per launch).
+Usage: summarize.py <gpurun_out dir> <tag> [steps-in-the-pmc-runs (default 3 = 2 timed + 1 warm-up)]"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+nsteps = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0 + 2.0  # warm-up + timed + the 2 profiling steps of bench.py
+
+
+def kname(full):
+    m = re.search(r"(k_[a-z0-9_]+)", full)
+    if not m:
+        return None
+    k = m.group(1)
+    t = re.search(r"k_knn_cov_far<(\d+)", full)
+    if t:
+        k = "k_knn_cov_far" if t.group(1) == "16" else "k_knn_cov_far2"
+    return k
+
+
+def counters(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            if k:
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                n[k].add(r["Dispatch_Id"])
+    return acc, n
+
+
+for suffix in ("stats", "stats_serial"):
+    for f in glob.glob(os.path.join(out, f"{tag}_{suffix}", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(out, f"{tag}_kernel_{suffix}.csv"))
+
+traffic = {}
+for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    acc, n = counters(os.path.join(out, f"{tag}_pmc_{c}"))
+    for k, v in acc.items():
+        t = traffic.setdefault(k, {})
+        launches = len(n[k])
+        t[f"{key}_kb_per_launch"] = round(v[c] / launches, 1)
+        t["launches_per_step"] = round(launches / nsteps, 2)
+        t[f"{key}_kb_per_step"] = round(v[c] / nsteps, 1)
+json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_traffic_serial_b64.json"), "w"), indent=1)
+
+sq = {}
+for d in ("pmc_sq", "pmc_sq2"):
+    acc, n = counters(os.path.join(out, f"{tag}_{d}"))
+    for k, v in acc.items():
+        sq.setdefault(k, {}).update({a: round(b / len(n[k])) for a, b in v.items()})
+        sq[k]["launches"] = len(n[k])
+json.dump(sq, open(os.path.join(out, f"{tag}_pmc_sq.json"), "w"), indent=1)
+print("summaries written:", sorted(os.path.basename(p) for p in glob.glob(os.path.join(out, f"{tag}_*.json")) + glob.glob(os.path.join(out, f"{tag}_kernel_*.csv"))))
