@@ -56,6 +56,8 @@ def gen_pairs(n_distinct, seed0, width, height, stride):
 
 
 def main():
+    # The lanes drive 2 HIP streams each; with the default of 4 hardware queues they would share queues and serialise.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)

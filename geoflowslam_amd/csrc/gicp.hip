@@ -82,17 +82,20 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ t
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_radix_sort: one 1024-thread workgroup sorts one cloud's (key, value) pairs.  LSD radix, 8-bit digits,
-// stable (tiles scattered in order, wave-ballot ranking inside a tile), uniform digits skipped.  Ping-pongs
-// between buffers 0 and 1; which[c] says where the sorted data ended up.
+// k_radix_sort: one 1024-thread workgroup sorts one cloud's (key, value) pairs.  LSD radix, 9-bit digits,
+// stable (4096-element tiles scattered in order; every wave ranks its 4 x 64 consecutive elements by wave ballots and
+// a running per-wave digit count), uniform digits skipped.  Ping-pongs between buffers 0 and 1; which[c] says where
+// the sorted data ended up.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u64* __restrict__ keys1,
                                                      unsigned* __restrict__ val0, unsigned* __restrict__ val1,
                                                      const int* __restrict__ counts, int P, int* __restrict__ which,
                                                      int* __restrict__ kinfo) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned bin_base[256];
-  __shared__ unsigned wave_hist[16][256];
+  constexpr int kDB = 9, kNB = 1 << kDB;  // digit bits, bins
+  constexpr int kEl = 4;                  // elements per thread and tile
+  __shared__ unsigned hist[kNB];
+  __shared__ unsigned bin_base[kNB];
+  __shared__ unsigned wave_hist[16][kNB];
   __shared__ int s_uniform;
   __shared__ int s_mn[3], s_mx[3];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,53 +157,64 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
     ki[4] = by;
   }
   __syncthreads();
-  // invalid keys (all ones) must still sort last: run one more pass over the top bits only if any key is invalid
-  const int npass = (bx + by + bz + 7) / 8;
-  for (int pass = 0; pass < 8 && n > 0; pass++) {
-    if (pass >= npass && pass < 7) continue;  // digits above the packed width are zero for valid keys (pass 7 places invalid keys)
-    const int shift = 8 * pass;
-    if (tid < 256) hist[tid] = 0;
+  // valid keys have bx + by + bz bits; invalid keys (all ones) must still sort last: one more pass over a digit above
+  // the packed width places them (skipped as uniform when there is no invalid key)
+  const int npass = (bx + by + bz + kDB - 1) / kDB;  // <= 7
+  for (int pass = 0; pass <= npass && n > 0; pass++) {
+    const int shift = kDB * pass;
+    for (int k = tid; k < kNB; k += 1024) hist[k] = 0;
     if (tid == 0) s_uniform = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[(unsigned)(ka[i] >> shift) & 255u], 1u);
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[(unsigned)(ka[i] >> shift) & (kNB - 1)], 1u);
     __syncthreads();
-    if (tid < 256 && hist[tid] == (unsigned)n) s_uniform = 1;
+    if (tid < kNB && hist[tid] == (unsigned)n) s_uniform = 1;
     __syncthreads();
     if (s_uniform) continue;  // block-uniform
-    if (tid < 256) bin_base[tid] = hist[tid];
+    if (tid < kNB) bin_base[tid] = hist[tid];
     __syncthreads();
-    for (int ofs = 1; ofs < 256; ofs <<= 1) {  // inclusive scan
+    for (int ofs = 1; ofs < kNB; ofs <<= 1) {  // inclusive scan
       unsigned v = 0;
-      if (tid < 256 && tid >= ofs) v = bin_base[tid - ofs];
+      if (tid < kNB && tid >= ofs) v = bin_base[tid - ofs];
       __syncthreads();
-      if (tid < 256) bin_base[tid] += v;
+      if (tid < kNB) bin_base[tid] += v;
       __syncthreads();
     }
-    if (tid < 256) bin_base[tid] -= hist[tid];  // exclusive
+    if (tid < kNB) bin_base[tid] -= hist[tid];  // exclusive
     __syncthreads();
-    for (int t0 = 0; t0 < n; t0 += 1024) {
-      for (int k = tid; k < 16 * 256; k += 1024) (&wave_hist[0][0])[k] = 0;
+    for (int t0 = 0; t0 < n; t0 += 1024 * kEl) {
+      for (int k = tid; k < 16 * kNB; k += 1024) (&wave_hist[0][0])[k] = 0;
       __syncthreads();
-      const int i = t0 + tid;
-      const bool valid = i < n;
-      u64 key = 0;
-      unsigned val = 0, digit = 0;
-      if (valid) {
-        key = ka[i];
-        val = va[i];
-        digit = (unsigned)(key >> shift) & 255u;
-      }
-      u64 mask = __ballot(valid);
+      u64 key[kEl];
+      unsigned val[kEl], digit[kEl], rank[kEl];
+      bool valid[kEl];
 #pragma unroll
-      for (int bit = 0; bit < 8; bit++) {
-        const bool b1 = (digit >> bit) & 1u;
-        const u64 bm = __ballot(b1);
-        mask &= b1 ? bm : ~bm;
+      for (int e = 0; e < kEl; e++) {  // wave w owns elements [t0 + 256 w, t0 + 256 (w + 1)) in index order
+        const int i = t0 + wave * (64 * kEl) + e * 64 + lane;
+        valid[e] = i < n;
+        key[e] = 0;
+        val[e] = 0;
+        if (valid[e]) {
+          key[e] = ka[i];
+          val[e] = va[i];
+        }
+        digit[e] = (unsigned)(key[e] >> shift) & (kNB - 1);
       }
-      const unsigned lane_rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-      if (valid && lane_rank == 0) wave_hist[wave][digit] = (unsigned)__popcll(mask);
+#pragma unroll
+      for (int e = 0; e < kEl; e++) {
+        u64 mask = __ballot(valid[e]);
+#pragma unroll
+        for (int bit = 0; bit < kDB; bit++) {
+          const bool b1 = (digit[e] >> bit) & 1u;
+          const u64 bm = __ballot(b1);
+          mask &= b1 ? bm : ~bm;
+        }
+        const unsigned lane_rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned before = valid[e] ? wave_hist[wave][digit[e]] : 0u;  // same digit, earlier 64-element groups of this wave
+        rank[e] = before + lane_rank;
+        if (valid[e] && lane_rank == 0) wave_hist[wave][digit[e]] = before + (unsigned)__popcll(mask);
+      }
       __syncthreads();
-      if (tid < 256) {
+      if (tid < kNB) {
         unsigned acc = bin_base[tid];
         for (int w = 0; w < 16; w++) {
           const unsigned t = wave_hist[w][tid];
@@ -210,10 +224,13 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
         bin_base[tid] = acc;
       }
       __syncthreads();
-      if (valid) {
-        const unsigned pos = wave_hist[wave][digit] + lane_rank;
-        kb[pos] = key;
-        vb[pos] = val;
+#pragma unroll
+      for (int e = 0; e < kEl; e++) {
+        if (valid[e]) {
+          const unsigned pos = wave_hist[wave][digit[e]] + rank[e];
+          kb[pos] = key[e];
+          vb[pos] = val[e];
+        }
       }
       __syncthreads();
     }
@@ -320,7 +337,6 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
                                                      int* __restrict__ n_ucell, int* __restrict__ bbox,
                                                      const int* __restrict__ kinfo) {
   __shared__ int s_wave[16];
-  __shared__ int s_carry;
   __shared__ int s_bb[6];
   const int c = blockIdx.x, tid = threadIdx.x;
   if (tid < 3) s_bb[tid] = kCoordMask;
@@ -332,42 +348,46 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
   double4* out = pts + (size_t)c * P;
   u64* uc = ucell + (size_t)c * (P + 1);
   unsigned* ub = ubegin + (size_t)c * (P + 1);
-  if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int t0 = 0; t0 < m; t0 += 1024) {
-    const int i = t0 + tid;
-    bool start = false;
-    u64 key = 0;
-    if (i < m) {
-      key = ck[i];
-      out[i] = tp[ci[i]];
-      start = i == 0 || ck[i - 1] != key;
+  for (int i = tid; i < m; i += 1024) out[i] = tp[ci[i]];  // independent gathers, all in flight
+  // every thread owns a contiguous chunk of the sorted keys: one block scan numbers the cell starts
+  const int chunk = (m + 1023) / 1024;
+  const int i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
+  int cnt = 0;
+  for (int i = i0; i < i1; i++) cnt += (i == 0 || ck[i - 1] != ck[i]) ? 1 : 0;
+  int total;
+  int pos = block_scan_1024(cnt, s_wave, &total);
+  if (cnt > 0) {
+    // the sort compacted the keys (k_radix_sort): decode back to the packed 3 x 21-bit cell key
+    const int* ki = kinfo + 8 * c;
+    const int kbx = ki[3], kby = ki[4];
+    int mn[3] = {kCoordMask, kCoordMask, kCoordMask}, mx[3] = {0, 0, 0};
+    for (int i = i0; i < i1; i++) {
+      const u64 key = ck[i];
+      if (i == 0 || ck[i - 1] != key) {
+        const int kx = (int)(key & ((1ull << kbx) - 1)) + ki[0], ky = (int)((key >> kbx) & ((1ull << kby) - 1)) + ki[1],
+                  kz = (int)(key >> (kbx + kby)) + ki[2];
+        uc[pos] = pack_key(kx, ky, kz);
+        ub[pos] = (unsigned)i;
+        pos++;
+        mn[0] = min(mn[0], kx);
+        mn[1] = min(mn[1], ky);
+        mn[2] = min(mn[2], kz);
+        mx[0] = max(mx[0], kx);
+        mx[1] = max(mx[1], ky);
+        mx[2] = max(mx[2], kz);
+      }
     }
-    int total;
-    const int pos = block_scan_1024(start ? 1 : 0, s_wave, &total) + s_carry;
-    if (start) {
-      // the sort compacted the keys (k_radix_sort): decode back to the packed 3 x 21-bit cell key
-      const int* ki = kinfo + 8 * c;
-      const int kbx = ki[3], kby = ki[4];
-      const int kx = (int)(key & ((1ull << kbx) - 1)) + ki[0], ky = (int)((key >> kbx) & ((1ull << kby) - 1)) + ki[1],
-                kz = (int)(key >> (kbx + kby)) + ki[2];
-      uc[pos] = pack_key(kx, ky, kz);
-      ub[pos] = (unsigned)i;
-      atomicMin(&s_bb[0], kx);
-      atomicMin(&s_bb[1], ky);
-      atomicMin(&s_bb[2], kz);
-      atomicMax(&s_bb[3], kx);
-      atomicMax(&s_bb[4], ky);
-      atomicMax(&s_bb[5], kz);
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&s_bb[a], mn[a]);
+      atomicMax(&s_bb[3 + a], mx[a]);
     }
-    __syncthreads();
-    if (tid == 0) s_carry += total;
-    __syncthreads();
   }
+  __syncthreads();
   if (tid == 0) {
-    n_ucell[c] = s_carry;
-    ub[s_carry] = (unsigned)m;
-    uc[s_carry] = kInvalidKey;
+    n_ucell[c] = total;
+    ub[total] = (unsigned)m;
+    uc[total] = kInvalidKey;
   }
   if (tid < 6) bbox[6 * c + tid] = s_bb[tid];  // occupied-cell bounding box (x0,y0,z0,x1,y1,z1)
 }
@@ -395,12 +415,13 @@ __device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n,
 // ginfo = {gx0, gy0, gz0, nx, ny, nz, ok}.  Clouds whose box exceeds kGridCap cells keep the binary-search path.
 // ------------------------------------------------------------------------------------------------
 constexpr int kGridCap = 1 << 21;
+constexpr int kGridFillParts = 16;  // workgroups per cloud in k_grid_fill
 
 __global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
                                                     const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
                                                     const int* __restrict__ bbox, int P, unsigned* __restrict__ grid,
                                                     int* __restrict__ ginfo, int* __restrict__ far2_count) {
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nu = n_ucell[c], m = m_counts[c];
   const u64* uc = ucell + (size_t)c * (P + 1);
   const unsigned* ub = ubegin + (size_t)c * (P + 1);
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucel
   const long long nx = (long long)bbox[6 * c + 3] - gx0 + 2, ny = (long long)bbox[6 * c + 4] - gy0 + 2,
                   nz = (long long)bbox[6 * c + 5] - gz0 + 2;
   const bool ok = nu > 0 && nx > 0 && ny > 0 && nz > 0 && nx * ny * nz < (long long)kGridCap;
-  if (tid == 0) {
+  if (tid == 0 && part == 0) {
     int* gi = ginfo + 8 * c;
     gi[0] = gx0;
     gi[1] = gy0;
@@ -427,16 +448,18 @@ __global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucel
     const int x = (int)(key & kCoordMask), y = (int)((key >> kCoordBits) & kCoordMask), z = (int)(key >> (2 * kCoordBits));
     return ((z - gz0) * (int)ny + (y - gy0)) * (int)nx + (x - gx0);
   };
-  // every occupied cell fills the gap back to the previous occupied cell (lanes write contiguous entries)
-  const int per_wave = (nu + 15) / 16;
-  const int u_begin = wave * per_wave, u_end = min(u_begin + per_wave, nu);
+  // every occupied cell fills the gap back to the previous occupied cell (lanes write contiguous entries); the cells
+  // are dealt to kGridFillParts x 16 waves
+  const int nwaves = 16 * kGridFillParts;
+  const int per_wave = (nu + nwaves - 1) / nwaves;
+  const int u_begin = (part * 16 + wave) * per_wave, u_end = min(u_begin + per_wave, nu);
   for (int u = u_begin; u < u_end; u++) {
     const int hi = lin(uc[u]), lo = u > 0 ? lin(uc[u - 1]) + 1 : 0;
     const unsigned v = ub[u];
     for (int k = lo + lane; k <= hi; k += 64) G[k] = v;
   }
   const int last = lin(uc[nu - 1]);
-  for (int k = last + 1 + tid; k <= ncell; k += 1024) G[k] = (unsigned)m;
+  for (int k = last + 1 + part * 1024 + tid; k <= ncell; k += 1024 * kGridFillParts) G[k] = (unsigned)m;
 }
 
 // points of row (y, z) whose cell x lies in [xlo, xhi] -> [*j0, *j1)
@@ -1610,7 +1633,7 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
              h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p);
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
              h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p);
-  GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(C2), dim3(1024), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
+  GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(kGridFillParts, C2), dim3(1024), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
              h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p, h->d_far2.p);
   const int knn_chunks = gfs::div_up(npts, 128);
   GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(xcd_grid(knn_chunks, B, 2)), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
