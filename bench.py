@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run ORB+match and GICP back to back on one stream")
@@ -236,9 +236,10 @@ def main():
         traffic = None
         traffic_note = None
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_serial_b64.json")))  # newest round last
-        if pmcs and B == 64:
-            t = json.load(open(pmcs[-1])).get(name)
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_serial.json")))  # newest round last
+        pmc_all = json.load(open(pmcs[-1])) if pmcs else {}
+        if pmc_all.get("_batch_pairs") == B:
+            t = pmc_all.get(name)
             if t:  # HBM-side bytes per STEP measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)
                 traffic = int((t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
                 traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, B=64, 1 lane, serial), KB*1024, "

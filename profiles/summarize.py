@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 CSVs written by profiles/collect.sh into the small summaries kept under profiles/:
    <tag>_kernel_stats.csv / <tag>_kernel_stats_serial.csv (copies of rocprofv3's kernel_stats.csv),
-   <tag>_pmc_traffic_serial_b64.json (FETCH_SIZE / WRITE_SIZE in KB per launch and per bench step),
+   <tag>_pmc_traffic_serial.json (FETCH_SIZE / WRITE_SIZE in KB per launch and per bench step),
    <tag>_pmc_sq.json (SQ / TCP counters per launch).
 Usage: summarize.py <gpurun_out dir> <tag> [steps-in-the-pmc-runs (default 3 = 2 timed + 1 warm-up)]"""
 import collections
@@ -44,7 +44,7 @@ for suffix in ("stats", "stats_serial"):
     for f in glob.glob(os.path.join(out, f"{tag}_{suffix}", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(out, f"{tag}_kernel_{suffix}.csv"))
 
-traffic = {}
+traffic = {"_batch_pairs": int(os.environ.get("GFS_BENCH_BATCH", "128"))}
 for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     acc, n = counters(os.path.join(out, f"{tag}_pmc_{c}"))
     for k, v in acc.items():
@@ -53,7 +53,7 @@ for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         t[f"{key}_kb_per_launch"] = round(v[c] / launches, 1)
         t["launches_per_step"] = round(launches / nsteps, 2)
         t[f"{key}_kb_per_step"] = round(v[c] / nsteps, 1)
-json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_traffic_serial_b64.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_traffic_serial.json"), "w"), indent=1)
 
 sq = {}
 for d in ("pmc_sq", "pmc_sq2"):
