@@ -63,6 +63,45 @@ class LbaSolution(C.Structure):
                 ("final_lambda", C.c_double)]
 
 
+class PoseProblem(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("n_obs", C.c_int32), ("xw", C.c_void_p), ("obs", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double), ("n_rounds", C.c_int32), ("its", C.c_int32)]
+
+
+class PoseSolution(C.Structure):
+    _fields_ = [("outlier", C.c_void_p), ("chi2", C.c_void_p), ("q", C.c_double * 4), ("t", C.c_double * 3),
+                ("avg_reproj_error", C.c_float), ("n_inliers", C.c_int32), ("rounds_run", C.c_int32),
+                ("iterations_run", C.c_int32)]
+
+
+def pose_structs(prob):
+    """ctypes views of one PoseOptimization problem dict (shared with oracle/oracle.py: same struct layout)."""
+    P, S = PoseProblem(), PoseSolution()
+    n = int(prob["n_obs"]) if "n_obs" in prob else len(prob["xw"])
+    keep = dict(xw=np.ascontiguousarray(prob["xw"], np.float64).reshape(-1, 3), obs=np.ascontiguousarray(prob["obs"], np.float64).reshape(-1, 3),
+                inv_sigma2=np.ascontiguousarray(prob["inv_sigma2"], np.float32), stereo=np.ascontiguousarray(prob["stereo"], np.uint8),
+                outlier=np.zeros(max(n, 1), np.uint8), chi2=np.zeros(max(n, 1), np.float64))
+    P.q[:] = [float(v) for v in prob["q"]]
+    P.t[:] = [float(v) for v in prob["t"]]
+    P.n_obs = n
+    for name in ("xw", "obs", "inv_sigma2", "stereo"):
+        setattr(P, name, keep[name].ctypes.data)
+    for name in ("fx", "fy", "cx", "cy", "bf"):
+        setattr(P, name, float(prob[name]))
+    P.n_rounds = int(prob.get("n_rounds", 4))
+    P.its = int(prob.get("its", 10))
+    S.outlier = keep["outlier"].ctypes.data
+    S.chi2 = keep["chi2"].ctypes.data
+    return P, S, keep, n
+
+
+def pose_result(S, keep, n):
+    return dict(outlier=keep["outlier"][:n].astype(bool), chi2=keep["chi2"][:n].copy(), q=np.array(S.q[:]), t=np.array(S.t[:]),
+                avg_reproj_error=float(S.avg_reproj_error), n_inliers=int(S.n_inliers), rounds_run=int(S.rounds_run),
+                iterations_run=int(S.iterations_run))
+
+
 # every symbol include/gfs_abi.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
     "gfs_abi_version", "gfs_last_error", "gfs_device_count",
@@ -77,6 +116,7 @@ ABI_SYMBOLS = [
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
+    "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
 ]
@@ -488,6 +528,37 @@ class Optimizer:
                                        C.byref(tot)), "gfs_lba_linearize")
         return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
                     Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=tot.value)
+
+
+class PoseOptimizer:
+    """ORB_SLAM3::Optimizer::PoseOptimization (reference include/Optimizer.h, src/Optimizer.cc:763-1098), conventional-SLAM
+    branch, on flattened frames (gfs_pose_problem in include/gfs_abi.h).  A batch of frames is one kernel launch."""
+
+    def __init__(self, max_obs=4096, max_batch=64, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_pose_create(device, max_obs, max_batch, C.byref(self.h)), "gfs_pose_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_pose_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def PoseOptimization(self, frames):
+        """frames: one problem dict or a list of them -> result dict(s) (outlier, chi2, q, t, avg_reproj_error, n_inliers)."""
+        single = isinstance(frames, dict)
+        probs = [frames] if single else list(frames)
+        B = len(probs)
+        PP, SS = (PoseProblem * B)(), (PoseSolution * B)()
+        keeps = []
+        for f, prob in enumerate(probs):
+            P, S, keep, n = pose_structs(prob)
+            PP[f], SS[f] = P, S
+            keeps.append((keep, n))
+        _check(lib().gfs_pose_optimize(self.h, PP, B, SS), "gfs_pose_optimize")
+        res = [pose_result(SS[f], *keeps[f]) for f in range(B)]
+        return res[0] if single else res
 
 
 class Frame:

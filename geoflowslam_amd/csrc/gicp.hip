@@ -805,8 +805,6 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
   TopK<10> best;
   const int kk = min(prm.k_neighbors, 10);
   const int want = min(kk, m);
-  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
-            bz1 = bbox[6 * c + 5];
   // The 27-cell cube: all 9 row ranges are fetched first (18 independent loads), the own row is scanned first so the
   // k-th distance shrinks early, candidates are loaded four at a time.
   bool certified = false;

@@ -222,3 +222,42 @@ def lba_window(seed, n_free=20, n_fixed=5, n_points=3000, mono_frac=0.1, outlier
                 edge_stereo=np.array(e_stereo, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
                 huber_mono=float(np.float32(np.sqrt(5.991))), huber_stereo=float(np.float32(np.sqrt(7.815))),
                 iterations=10, gt_q=q_gt, gt_t=t_gt, gt_points=pts)
+
+
+def pose_frame(seed, n_obs=300, mono_frac=0.15, outlier_frac=0.1, rot_deg=1.0, trans=0.03, outlier_px=25.0, noise_scale=1.0):
+    """Synthetic Optimizer::PoseOptimization problem (reference src/Optimizer.cc:763-1098): one frame looking at `n_obs`
+    map points in a 6x4x3 m box, RGB-D ("stereo", 3-D) observations with a fraction without depth (mono, 2-D), pixel noise
+    sigma = sqrt(sigma2[octave]), `outlier_frac` gross outliers, initial pose off by ~rot_deg / ~trans metres.
+    Returns the flat arrays of gfs_pose_problem (include/gfs_abi.h) plus the ground truth pose (q_gt, t_gt)."""
+    rng = np.random.default_rng(seed)
+    fx = fy = np.float64(np.float32(607.0))
+    cx, cy = np.float64(np.float32(319.5)), np.float64(np.float32(239.5))
+    bf = np.float64(np.float32(0.0745 * 607.0))
+    Rcw = _rot(0.05 * rng.normal(), 0.2 * rng.normal(), 0.05 * rng.normal())
+    tcw = np.array([0.3 * rng.normal(), 0.1 * rng.normal(), 0.2 * rng.normal()])
+    sigma2 = np.float64(np.float32(1.2) ** (2 * np.arange(8)))
+    inv_sigma2 = (np.float32(1.0) / np.float32(1.2) ** (2 * np.arange(8))).astype(np.float32)
+    xw, obs, w, st, is_out = [], [], [], [], []
+    while len(xw) < n_obs:
+        xc = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(1.0, 6.0)])
+        u, v = fx * xc[0] / xc[2] + cx, fy * xc[1] / xc[2] + cy
+        if not (0 <= u < 640 and 0 <= v < 480):
+            continue
+        octv = int(rng.choice(8, p=np.array([217, 181, 151, 126, 105, 87, 73, 60]) / 1000.0))
+        noise = noise_scale * rng.normal(0, np.sqrt(sigma2[octv]), 3)
+        out = rng.random() < outlier_frac
+        if out:
+            noise[:2] += rng.choice([-1, 1], 2) * outlier_px
+        stereo = rng.random() >= mono_frac
+        ur = u - bf / xc[2]
+        xw.append((Rcw.T @ (xc - tcw)).astype(np.float32).astype(np.float64))  # MapPoint world positions are floats
+        obs.append([np.float32(u + noise[0]), np.float32(v + noise[1]), np.float32(ur + noise[2]) if stereo else -1.0])
+        w.append(inv_sigma2[octv])
+        st.append(1 if stereo else 0)
+        is_out.append(out)
+    dR = _rot(*(np.deg2rad(rot_deg) * rng.normal(size=3)))
+    q0 = _quat_from_R(dR @ Rcw).astype(np.float32).astype(np.float64)  # Sophus::SE3f pose widened to double
+    t0 = (dR @ tcw + trans * rng.normal(size=3)).astype(np.float32).astype(np.float64)
+    return dict(q=q0, t=t0, n_obs=n_obs, xw=np.array(xw), obs=np.array(obs, np.float64), inv_sigma2=np.array(w, np.float32),
+                stereo=np.array(st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, n_rounds=4, its=10,
+                q_gt=_quat_from_R(Rcw), t_gt=tcw, is_outlier=np.array(is_out))

@@ -269,6 +269,41 @@ int gfs_stereo_from_rgbd_batch_device(gfs_frame* h, const void* dev_kps, const v
                                       void* dev_u_right, void* dev_depth_out, void* stream);
 
 /* ============================================================================================
+ * 6. Optimizer::PoseOptimization — motion-only bundle adjustment of a frame
+ *      int Optimizer::PoseOptimization(Frame*, bool, bool, int)      src/Optimizer.cc:763-1098
+ *    conventional-SLAM branch (pFrame->mpCamera2 == nullptr): EdgeSE3ProjectXYZOnlyPose (src/OptimizableTypes.cpp:49-63) and
+ *    g2o::EdgeStereoSE3ProjectXYZOnlyPose (Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:339-404), Huber kernels,
+ *    4 rounds x optimize(10) with BlockSolver_6_3 + LinearSolverDense + OptimizationAlgorithmLevenberg.
+ *    The two-camera rigid-body branch (:883-951, EdgeSE3ProjectXYZOnlyPoseToBody) is not implemented.
+ * ============================================================================================ */
+typedef struct {
+  double q[4], t[3];          /* Tcw = pFrame->GetPose(): unit quaternion (x, y, z, w) and translation cast to double (:784-786) */
+  int32_t n_obs;              /* key-points that have a MapPoint, in key-point index order (= edge creation order) */
+  const double* xw;           /* [n_obs][3] pMP->GetWorldPos().cast<double>() */
+  const double* obs;          /* [n_obs][3] kpUn.pt.x, kpUn.pt.y, mvuRight[i] (third value ignored for mono edges) */
+  const float* inv_sigma2;    /* [n_obs] mvInvLevelSigma2[kpUn.octave] */
+  const uint8_t* stereo;      /* [n_obs] mvuRight[i] >= 0 */
+  double fx, fy, cx, cy, bf;  /* pFrame->fx ... mbf (floats widened to double, :865-869) */
+  int32_t n_rounds;           /* 4 */
+  int32_t its;                /* 10 (its[] = {10, 10, 10, 10}) */
+} gfs_pose_problem;
+
+typedef struct {
+  uint8_t* outlier;       /* [n_obs] pFrame->mvbOutlier after the last round */
+  double* chi2;           /* [n_obs] e->chi2() as read by the last classification */
+  double q[4], t[3];      /* vSE3_recov->estimate(): the reference computes it and then drops it (SetPose is commented out, :1078-1097) */
+  float avg_reproj_error; /* value of the last SetFrame2FrameReprojError / SetFrame2MapReprojError call */
+  int32_t n_inliers;      /* return value: nInitialCorrespondences - nBad (0 when there are fewer than 3 correspondences) */
+  int32_t rounds_run, iterations_run;
+} gfs_pose_solution;
+
+typedef struct gfs_pose gfs_pose;
+int gfs_pose_create(int device, int max_obs, int max_batch, gfs_pose** out);
+void gfs_pose_destroy(gfs_pose* h);
+/* B independent frames (host pointers), one workgroup per frame. */
+int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_pose_solution* solutions);
+
+/* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel
  * with these rather than torch events, which only see torch's current stream).
  * ============================================================================================ */

@@ -160,6 +160,30 @@ int gfso_lba_solve(const gfso_lba_problem*, gfso_lba_solution*);
 double gfso_lba_linearize(const gfso_lba_problem*, double* Hpp, double* Hll, double* Hpl, double* bp, double* bl,
                           double* edge_chi2);
 
+/* ---- Optimizer::PoseOptimization (src/Optimizer.cc:763-1098): motion-only BA of one frame ---- */
+typedef struct {
+  double q[4], t[3];          /* Tcw as handed to g2o::SE3Quat (x,y,z,w | translation), doubles cast from the Sophus floats */
+  int32_t n_obs;              /* key-points with a MapPoint, in key-point index order */
+  const double* xw;           /* n_obs*3: pMP->GetWorldPos().cast<double>() */
+  const double* obs;          /* n_obs*3: kpUn.pt.x, kpUn.pt.y, mvuRight (any value when mono) */
+  const float* inv_sigma2;    /* n_obs: mvInvLevelSigma2[kpUn.octave] */
+  const uint8_t* stereo;      /* n_obs: mvuRight[i] >= 0 */
+  double fx, fy, cx, cy, bf;  /* floats of the Frame widened to double */
+  int32_t n_rounds;           /* 4; its[] = 10 each */
+  int32_t its;                /* 10 */
+} gfso_pose_problem;
+
+typedef struct {
+  uint8_t* outlier;     /* n_obs: pFrame->mvbOutlier */
+  double* chi2;         /* n_obs: e->chi2() read by the last classification */
+  double q[4], t[3];    /* vSE3_recov->estimate() (the reference computes it but never writes it back: SURVEY F12) */
+  float avg_reproj_error; /* value handed to SetFrame2FrameReprojError / SetFrame2MapReprojError by the last round */
+  int32_t n_inliers;    /* return value: nInitialCorrespondences - nBad */
+  int32_t rounds_run, iterations_run; /* LM iterations summed over the rounds */
+} gfso_pose_solution;
+
+int gfso_pose_optimization(const gfso_pose_problem*, gfso_pose_solution*);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,6 +370,47 @@ def lba_linearize(prob):
                 Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=float(tot))
 
 
+class PoseProblem(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("n_obs", C.c_int32), ("xw", C.c_void_p), ("obs", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double), ("n_rounds", C.c_int32), ("its", C.c_int32)]
+
+
+class PoseSolution(C.Structure):
+    _fields_ = [("outlier", C.c_void_p), ("chi2", C.c_void_p), ("q", C.c_double * 4), ("t", C.c_double * 3),
+                ("avg_reproj_error", C.c_float), ("n_inliers", C.c_int32), ("rounds_run", C.c_int32),
+                ("iterations_run", C.c_int32)]
+
+
+def pose_optimization(prob):
+    """Optimizer::PoseOptimization restatement (oracle/pose_oracle.cpp) on one frame dict:
+    q, t, xw [n,3], obs [n,3], inv_sigma2 [n], stereo [n], fx, fy, cx, cy, bf (+ n_rounds = 4, its = 10)."""
+    P, S = PoseProblem(), PoseSolution()
+    xw = np.ascontiguousarray(prob["xw"], np.float64).reshape(-1, 3)
+    obs = np.ascontiguousarray(prob["obs"], np.float64).reshape(-1, 3)
+    w = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+    st = np.ascontiguousarray(prob["stereo"], np.uint8)
+    n = len(xw)
+    outlier = np.zeros(max(n, 1), np.uint8)
+    chi2 = np.zeros(max(n, 1), np.float64)
+    P.q[:] = [float(v) for v in prob["q"]]
+    P.t[:] = [float(v) for v in prob["t"]]
+    P.n_obs = n
+    P.xw, P.obs, P.inv_sigma2, P.stereo = xw.ctypes.data, obs.ctypes.data, w.ctypes.data, st.ctypes.data
+    for name in ("fx", "fy", "cx", "cy", "bf"):
+        setattr(P, name, float(prob[name]))
+    P.n_rounds = int(prob.get("n_rounds", 4))
+    P.its = int(prob.get("its", 10))
+    S.outlier, S.chi2 = outlier.ctypes.data, chi2.ctypes.data
+    L = lib()
+    L.gfso_pose_optimization.restype = C.c_int
+    L.gfso_pose_optimization.argtypes = [C.POINTER(PoseProblem), C.POINTER(PoseSolution)]
+    L.gfso_pose_optimization(C.byref(P), C.byref(S))
+    return dict(outlier=outlier[:n].astype(bool), chi2=chi2[:n].copy(), q=np.array(S.q[:]), t=np.array(S.t[:]),
+                avg_reproj_error=float(S.avg_reproj_error), n_inliers=int(S.n_inliers), rounds_run=int(S.rounds_run),
+                iterations_run=int(S.iterations_run))
+
+
 def depth_to_cloud(depth, downsample, fx, fy, cx, cy):
     depth = np.ascontiguousarray(depth, np.float32)
     rows, cols = depth.shape if depth.ndim == 2 else (0, 0)

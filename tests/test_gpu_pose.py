@@ -1,0 +1,72 @@
+"""GPU parity tests for Optimizer::PoseOptimization (MI355X, k_pose_opt through gfs_pose_optimize): identical outlier flags,
+inlier counts, round and LM iteration counts; pose within 1e-5 relative Frobenius of the CPU oracle (BASELINE.json north_star
+tolerance for the BA poses); chi2 within 1e-6 relative.  Edge cases as in the reference: < 3 correspondences, < 10 edges,
+everything an outlier, mono-only and stereo-only frames, ragged batches."""
+import numpy as np
+import pytest
+
+from geoflowslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _same(r, ro):
+    assert np.array_equal(r["outlier"], ro["outlier"])
+    assert r["n_inliers"] == ro["n_inliers"] and r["rounds_run"] == ro["rounds_run"]
+    assert r["iterations_run"] == ro["iterations_run"]
+    assert _rel(r["q"], ro["q"]) < 1e-5 and _rel(r["t"], ro["t"]) < 1e-5
+    if len(ro["chi2"]):
+        assert _rel(r["chi2"], ro["chi2"]) < 1e-6
+    if np.isfinite(ro["avg_reproj_error"]):
+        assert abs(r["avg_reproj_error"] - ro["avg_reproj_error"]) <= 1e-5 * max(abs(ro["avg_reproj_error"]), 1e-30)
+    else:
+        assert not np.isfinite(r["avg_reproj_error"])
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=11, n_obs=300), dict(seed=12, n_obs=1000, outlier_frac=0.2),
+                                 dict(seed=13, n_obs=120, mono_frac=1.0), dict(seed=14, n_obs=150, mono_frac=0.0),
+                                 dict(seed=15, n_obs=40, rot_deg=3.0, trans=0.1)])
+def test_single_frame_matches_oracle(gpu_api, oracle, cfg):
+    p = synth.pose_frame(**cfg)
+    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=4)
+    _same(po.PoseOptimization(p), oracle.pose_optimization(p))
+
+
+def test_ragged_batch_matches_oracle(gpu_api, oracle):
+    frames = [synth.pose_frame(100 + i, n_obs=n) for i, n in enumerate([300, 2, 8, 0, 777, 64, 10, 9])]
+    frames[3] = dict(frames[3], xw=np.zeros((0, 3)), obs=np.zeros((0, 3)), inv_sigma2=np.zeros(0, np.float32),
+                     stereo=np.zeros(0, np.uint8), n_obs=0)
+    po = gpu_api.PoseOptimizer(max_obs=1024, max_batch=8)
+    res = po.PoseOptimization(frames)
+    for p, r in zip(frames, res):
+        _same(r, oracle.pose_optimization(p))
+    assert res[1]["n_inliers"] == 0 and res[1]["rounds_run"] == 0  # < 3 correspondences
+    assert res[2]["rounds_run"] == 1 and res[7]["rounds_run"] == 1  # < 10 edges: one round
+    assert res[6]["rounds_run"] == 4
+
+
+def test_all_outliers_and_capacity_errors(gpu_api, oracle):
+    p = synth.pose_frame(9, n_obs=50, outlier_frac=1.0, outlier_px=200.0)
+    po = gpu_api.PoseOptimizer(max_obs=64, max_batch=2)
+    r = po.PoseOptimization(p)
+    _same(r, oracle.pose_optimization(p))
+    assert r["outlier"].all() and r["n_inliers"] == 0
+    with pytest.raises(gpu_api.GfsError):
+        po.PoseOptimization(synth.pose_frame(1, n_obs=65))
+    with pytest.raises(gpu_api.GfsError):
+        po.PoseOptimization([p, p, p])
+
+
+def test_quirks_survive_on_the_gpu(gpu_api, oracle):
+    """Rounds restart from the frame pose; nGood accumulates over the rounds (see tests/test_pose_oracle.py)."""
+    po = gpu_api.PoseOptimizer(max_obs=512, max_batch=2)
+    p = synth.pose_frame(7, n_obs=200, outlier_frac=0.0, noise_scale=0.01, rot_deg=0.05, trans=0.002)
+    a, b = po.PoseOptimization([dict(p, its=1, n_rounds=1), dict(p, its=1, n_rounds=3)])
+    assert np.array_equal(a["q"], b["q"]) and np.array_equal(a["t"], b["t"])
+    p2 = synth.pose_frame(8, n_obs=120, outlier_frac=0.0)
+    one, four = po.PoseOptimization([dict(p2, n_rounds=1), p2])
+    assert four["avg_reproj_error"] < 0.5 * one["avg_reproj_error"]
