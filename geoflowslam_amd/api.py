@@ -102,6 +102,43 @@ def pose_result(S, keep, n):
                 iterations_run=int(S.iterations_run))
 
 
+class SbpProblem(C.Structure):
+    _fields_ = [("n_last", C.c_int32), ("last_xw", C.c_void_p), ("last_desc", C.c_void_p), ("last_octave", C.c_void_p),
+                ("last_angle", C.c_void_p), ("last_mp_has_obs", C.c_void_p), ("n_cur", C.c_int32), ("cur_kps_un", C.c_void_p),
+                ("cur_u_right", C.c_void_p), ("cur_desc", C.c_void_p), ("cur_has_mp_obs", C.c_void_p),
+                ("Tcw_q", C.c_float * 4), ("Tcw_t", C.c_float * 3), ("Tlw_q", C.c_float * 4), ("Tlw_t", C.c_float * 3),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("b", C.c_float),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float), ("scale_factors", C.c_void_p), ("n_levels", C.c_int32),
+                ("th", C.c_float), ("mono", C.c_int32), ("check_orientation", C.c_int32)]
+
+
+def sbp_struct(prob):
+    """ctypes view of one SearchByProjection problem dict (keys as in gfs_sbp_problem; cur_kps_un = KP_DTYPE array)."""
+    P = SbpProblem()
+    keep = dict(last_xw=np.ascontiguousarray(prob["last_xw"], np.float32).reshape(-1, 3),
+                last_desc=np.ascontiguousarray(prob["last_desc"], np.uint8).reshape(-1, 32),
+                last_octave=np.ascontiguousarray(prob["last_octave"], np.int32),
+                last_angle=np.ascontiguousarray(prob["last_angle"], np.float32),
+                last_mp_has_obs=np.ascontiguousarray(prob["last_mp_has_obs"], np.uint8),
+                cur_kps_un=np.ascontiguousarray(prob["cur_kps_un"], KP_DTYPE),
+                cur_u_right=np.ascontiguousarray(prob["cur_u_right"], np.float32),
+                cur_desc=np.ascontiguousarray(prob["cur_desc"], np.uint8).reshape(-1, 32),
+                cur_has_mp_obs=np.ascontiguousarray(prob["cur_has_mp_obs"], np.uint8),
+                scale_factors=np.ascontiguousarray(prob["scale_factors"], np.float32))
+    P.n_last, P.n_cur = len(keep["last_xw"]), len(keep["cur_kps_un"])
+    for name, a in keep.items():
+        setattr(P, name, a.ctypes.data)
+    for name in ("Tcw_q", "Tcw_t", "Tlw_q", "Tlw_t"):
+        getattr(P, name)[:] = [float(np.float32(v)) for v in prob[name]]
+    for name in ("fx", "fy", "cx", "cy", "bf", "b", "min_x", "max_x", "min_y", "max_y", "grid_w_inv", "grid_h_inv", "th"):
+        setattr(P, name, float(np.float32(prob[name])))
+    P.n_levels = len(keep["scale_factors"])
+    P.mono = int(prob.get("mono", 0))
+    P.check_orientation = int(prob.get("check_orientation", 1))
+    return P, keep
+
+
 # every symbol include/gfs_abi.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
     "gfs_abi_version", "gfs_last_error", "gfs_device_count",
@@ -117,6 +154,7 @@ ABI_SYMBOLS = [
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
     "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
+    "gfs_sbp_create", "gfs_sbp_destroy", "gfs_search_by_projection",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
 ]
@@ -528,6 +566,41 @@ class Optimizer:
                                        C.byref(tot)), "gfs_lba_linearize")
         return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
                     Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=tot.value)
+
+
+class ProjectionMatcher:
+    """ORB_SLAM3::ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference include/ORBmatcher.h,
+    src/ORBmatcher.cc:1853-2063) on flattened single-camera frame pairs (gfs_sbp_problem in include/gfs_abi.h)."""
+
+    def __init__(self, max_last=2048, max_cur=2048, max_batch=64, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_sbp_create(device, max_last, max_cur, max_batch, C.byref(self.h)), "gfs_sbp_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_sbp_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def SearchByProjection(self, pairs):
+        """pairs: one problem dict or a list -> (cur_match int32 [n_cur], nmatches) per pair."""
+        single = isinstance(pairs, dict)
+        probs = [pairs] if single else list(pairs)
+        B = len(probs)
+        PP = (SbpProblem * B)()
+        keeps, outs = [], []
+        ptrs = (C.c_void_p * B)()
+        for f, prob in enumerate(probs):
+            P, keep = sbp_struct(prob)
+            PP[f] = P
+            keeps.append(keep)
+            outs.append(np.full(max(P.n_cur, 1), -9, np.int32))
+            ptrs[f] = outs[f].ctypes.data
+        nm = np.zeros(B, np.int32)
+        _check(lib().gfs_search_by_projection(self.h, PP, B, ptrs, _p(nm)), "gfs_search_by_projection")
+        res = [(outs[f][:PP[f].n_cur].copy(), int(nm[f])) for f in range(B)]
+        return res[0] if single else res
 
 
 class PoseOptimizer:

@@ -1,0 +1,511 @@
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (reference
+// src/ORBmatcher.cc:1853-2063) on MI355X, single-camera frames (Nleft == -1), a batch of frame pairs per launch.
+//
+// One 256-thread workgroup per frame pair:
+//   0. Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:734-761, 1073-1084): the 64 x 48 grid of the current frame as
+//      a CSR table in LDS (cells keep ascending key-point order, like the reference's push_back);
+//   A. in parallel over the last frame's map points: projection with Sophus::SE3f float arithmetic
+//      (Thirdparty/Sophus/sophus/so3.hpp:358-367), Frame::GetFeaturesInArea (src/Frame.cc:1007-1071) and the Hamming
+//      distances (ORBmatcher::DescriptorDistance :2536-2550) of the window's candidates, kept in visiting order;
+//   B. the reference loop is order dependent (a key-point taken by an earlier map point with observations is skipped by
+//      the later ones, :1914-1915), so the assignment itself runs in map-point order on one wave: the lanes check one
+//      candidate each, a wave-wide arg-min (first minimum wins, as `dist < bestDist` does) picks the match;
+//   C. rotation histogram + ComputeThreeMaxima (:2500-2532) and the final NULL-ing of inconsistent matches.
+// Results are bit-exact integer work; the float decisions (image bounds, window membership, level ranges, histogram bins)
+// use the reference's float expressions (the library is built with -ffp-contract=off).
+#include <memory>
+#include <mutex>
+
+#include "gfs_common.hpp"
+
+namespace {
+
+constexpr int kGridCols = 64, kGridRows = 48, kCells = kGridCols * kGridRows;
+constexpr int kHisto = 30, kThHigh = 100;
+constexpr int kSbpThreads = 256;
+constexpr int kSbpMaxCur = 4096;   // key-points of the current frame (LDS tables)
+constexpr int kSbpMaxLast = 8192;  // map points of the last frame
+constexpr int kCand = 64;          // candidates kept per map point (more: the assignment pass re-enumerates them)
+
+struct SbpPair {
+  int n_last, n_cur, n_levels, mono, check_orientation;
+  float Tcw_q[4], Tcw_t[3], Tlw_q[4], Tlw_t[3];
+  float fx, fy, cx, cy, bf, b, min_x, max_x, min_y, max_y, grid_w_inv, grid_h_inv, th;
+  float scale[16];
+};
+
+struct SbpView {
+  const float* last_xw;
+  const uint8_t* last_desc;
+  const int* last_octave;
+  const float* last_angle;
+  const uint8_t* last_has_obs;
+  const gfs_keypoint* cur_kp;
+  const float* cur_ur;
+  const uint8_t* cur_desc;
+  const uint8_t* cur_has_obs;
+};
+
+// SO3f * p (so3.hpp:358-367): uv = q.vec x p; uv += uv; p + w * uv + q.vec x uv
+__device__ __forceinline__ void so3_act(const float* q, const float* p, float* o) {
+  float uv[3] = {q[1] * p[2] - q[2] * p[1], q[2] * p[0] - q[0] * p[2], q[0] * p[1] - q[1] * p[0]};
+  for (int k = 0; k < 3; k++) uv[k] += uv[k];
+  const float c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+  for (int k = 0; k < 3; k++) o[k] = (p[k] + q[3] * uv[k]) + c[k];
+}
+
+__device__ __forceinline__ int hamming256(const uint8_t* a, const uint8_t* b) {
+  const uint4* pa = reinterpret_cast<const uint4*>(a);
+  const uint4* pb = reinterpret_cast<const uint4*>(b);
+  const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+         __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+struct Proj {
+  float u, v, radius, invzc;
+  int minLevel, maxLevel, x0, x1, y0, y1;
+  bool ok;
+};
+
+// projection of map point l + the cell range of its search window (everything before the candidate loop of :1878-1911)
+__device__ __forceinline__ Proj sbp_project(const SbpPair& P, const SbpView& V, int l, bool bForward, bool bBackward) {
+  Proj R;
+  R.ok = false;
+  float x3Dc[3];
+  so3_act(P.Tcw_q, V.last_xw + 3 * l, x3Dc);
+  for (int k = 0; k < 3; k++) x3Dc[k] += P.Tcw_t[k];
+  R.invzc = (float)(1.0 / (double)x3Dc[2]);
+  if (R.invzc < 0) return R;
+  R.u = P.fx * x3Dc[0] / x3Dc[2] + P.cx;
+  R.v = P.fy * x3Dc[1] / x3Dc[2] + P.cy;
+  if (R.u < P.min_x || R.u > P.max_x) return R;
+  if (R.v < P.min_y || R.v > P.max_y) return R;
+  const int oct = V.last_octave[l];
+  R.radius = P.th * P.scale[oct];
+  if (bForward) {
+    R.minLevel = oct;
+    R.maxLevel = -1;
+  } else if (bBackward) {
+    R.minLevel = 0;
+    R.maxLevel = oct;
+  } else {
+    R.minLevel = oct - 1;
+    R.maxLevel = oct + 1;
+  }
+  R.x0 = max(0, (int)floorf((R.u - P.min_x - R.radius) * P.grid_w_inv));
+  if (R.x0 >= kGridCols) return R;
+  R.x1 = min(kGridCols - 1, (int)ceilf((R.u - P.min_x + R.radius) * P.grid_w_inv));
+  if (R.x1 < 0) return R;
+  R.y0 = max(0, (int)floorf((R.v - P.min_y - R.radius) * P.grid_h_inv));
+  if (R.y0 >= kGridRows) return R;
+  R.y1 = min(kGridRows - 1, (int)ceilf((R.v - P.min_y + R.radius) * P.grid_h_inv));
+  if (R.y1 < 0) return R;
+  R.ok = true;
+  return R;
+}
+
+// GetFeaturesInArea + the static filters of the candidate loop, in the reference's visiting order (ix, iy, cell order).
+// f(i2, dist) is called for every candidate that survives them; returns whether vIndices2 was non-empty.
+template <class F>
+__device__ __forceinline__ bool sbp_candidates(const SbpPair& P, const SbpView& V, const Proj& R, int l,
+                                               const unsigned short* s_start, const unsigned short* s_items, F&& f) {
+  const bool bCheckLevels = (R.minLevel > 0) || (R.maxLevel >= 0);
+  bool any = false;
+  for (int ix = R.x0; ix <= R.x1; ix++)
+    for (int iy = R.y0; iy <= R.y1; iy++) {
+      const int cell = ix * kGridRows + iy;
+      for (int k = s_start[cell]; k < s_start[cell + 1]; k++) {
+        const int i2 = s_items[k];
+        const gfs_keypoint kp = V.cur_kp[i2];
+        if (bCheckLevels) {
+          if (kp.octave < R.minLevel) continue;
+          if (R.maxLevel >= 0 && kp.octave > R.maxLevel) continue;
+        }
+        const float distx = kp.x - R.u, disty = kp.y - R.v;
+        if (!(fabsf(distx) < R.radius && fabsf(disty) < R.radius)) continue;
+        any = true;
+        if (V.cur_has_obs[i2]) continue;  // a map point with observations was there on entry: never replaced
+        const float ur2 = V.cur_ur[i2];
+        if (ur2 > 0) {
+          const float ur = R.u - P.bf * R.invzc;
+          const float er = fabsf(ur - ur2);
+          if (er > R.radius) continue;
+        }
+        f(i2, hamming256(V.last_desc + 32 * (size_t)l, V.cur_desc + 32 * (size_t)i2));
+      }
+    }
+  return any;
+}
+
+__global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__ pairs, const float* __restrict__ last_xw,
+                                                     const uint8_t* __restrict__ last_desc, const int* __restrict__ last_octave,
+                                                     const float* __restrict__ last_angle, const uint8_t* __restrict__ last_has_obs,
+                                                     const gfs_keypoint* __restrict__ cur_kp, const float* __restrict__ cur_ur,
+                                                     const uint8_t* __restrict__ cur_desc, const uint8_t* __restrict__ cur_has_obs,
+                                                     int SL, int SC, unsigned* __restrict__ cand, int* __restrict__ cand_cnt,
+                                                     int* __restrict__ lsel, int* __restrict__ cur_match, int* __restrict__ nmatches) {
+  __shared__ unsigned short s_cell[kSbpMaxCur];
+  __shared__ unsigned short s_start[kCells + 1];
+  __shared__ unsigned short s_items[kSbpMaxCur];
+  __shared__ short s_state[kSbpMaxCur];  // -1 untouched, -2 reset to NULL, >= 0 map point of last entry l
+  __shared__ int s_cnt[kCells];
+  __shared__ int s_scan[kSbpThreads];
+  __shared__ int s_hist[kHisto];
+  __shared__ int s_ctl[4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const SbpPair P = pairs[f];
+  const SbpView V{last_xw + (size_t)f * SL * 3, last_desc + (size_t)f * SL * 32, last_octave + (size_t)f * SL,
+                  last_angle + (size_t)f * SL, last_has_obs + (size_t)f * SL, cur_kp + (size_t)f * SC,
+                  cur_ur + (size_t)f * SC, cur_desc + (size_t)f * SC * 32, cur_has_obs + (size_t)f * SC};
+  unsigned* cnd = cand + (size_t)f * SL * kCand;
+  int* ccnt = cand_cnt + (size_t)f * SL;
+  int* sel = lsel + (size_t)f * SL;
+  const int N = P.n_cur, NL = P.n_last;
+  // ---- 0. grid
+  for (int c = tid; c < kCells; c += kSbpThreads) s_cnt[c] = 0;
+  if (tid < kHisto) s_hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < N; i += kSbpThreads) {
+    const gfs_keypoint kp = V.cur_kp[i];
+    const int px = (int)roundf((kp.x - P.min_x) * P.grid_w_inv), py = (int)roundf((kp.y - P.min_y) * P.grid_h_inv);
+    const bool in = px >= 0 && px < kGridCols && py >= 0 && py < kGridRows;
+    s_cell[i] = in ? (unsigned short)(px * kGridRows + py) : (unsigned short)0xffff;
+    s_state[i] = -1;
+    if (in) atomicAdd(&s_cnt[px * kGridRows + py], 1);
+  }
+  __syncthreads();
+  {
+    constexpr int per = kCells / kSbpThreads;  // 12
+    int local = 0;
+    for (int k = 0; k < per; k++) local += s_cnt[tid * per + k];
+    s_scan[tid] = local;
+    __syncthreads();
+    for (int ofs = 1; ofs < kSbpThreads; ofs <<= 1) {
+      const int v = tid >= ofs ? s_scan[tid - ofs] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    int run = s_scan[tid] - local;
+    for (int k = 0; k < per; k++) {
+      s_start[tid * per + k] = (unsigned short)run;
+      run += s_cnt[tid * per + k];
+    }
+    if (tid == kSbpThreads - 1) s_start[kCells] = (unsigned short)run;
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += kSbpThreads) {  // position inside the cell = number of earlier key-points of that cell
+    const unsigned short c = s_cell[i];
+    if (c == 0xffff) continue;
+    int r = 0;
+    for (int j = 0; j < i; j++) r += s_cell[j] == c ? 1 : 0;
+    s_items[s_start[c] + r] = (unsigned short)i;
+  }
+  // twc = Tcw.inverse().translation(); tlc = Tlw * twc  (se3.hpp:208-211; the SO3 constructor re-normalises the conjugate)
+  float qi[4] = {-P.Tcw_q[0], -P.Tcw_q[1], -P.Tcw_q[2], P.Tcw_q[3]};
+  {
+    const float nrm = sqrtf((qi[0] * qi[0] + qi[2] * qi[2]) + (qi[1] * qi[1] + qi[3] * qi[3]));
+    for (int k = 0; k < 4; k++) qi[k] /= nrm;
+  }
+  const float mt[3] = {P.Tcw_t[0] * -1.0f, P.Tcw_t[1] * -1.0f, P.Tcw_t[2] * -1.0f};
+  float twc[3], tlc[3];
+  so3_act(qi, mt, twc);
+  so3_act(P.Tlw_q, twc, tlc);
+  for (int k = 0; k < 3; k++) tlc[k] += P.Tlw_t[k];
+  const bool bForward = tlc[2] > P.b && !P.mono, bBackward = -tlc[2] > P.b && !P.mono;
+  __syncthreads();
+  // ---- A. candidates of every map point (parallel)
+  for (int l = tid; l < NL; l += kSbpThreads) {
+    const Proj R = sbp_project(P, V, l, bForward, bBackward);
+    int n = 0;
+    bool any = false;
+    if (R.ok)
+      any = sbp_candidates(P, V, R, l, s_start, s_items, [&](int i2, int dist) {
+        if (n < kCand) cnd[(size_t)l * kCand + n] = (unsigned)i2 | ((unsigned)dist << 16);
+        n++;
+      });
+    ccnt[l] = any ? n : -1;  // -1: vIndices2.empty() -> continue
+  }
+  __syncthreads();
+  // ---- B. assignment in map-point order (one wave)
+  if (tid < 64) {
+    int nm = 0;
+    for (int l = 0; l < NL; l++) {
+      const int n = ccnt[l];
+      sel[l] = -1;
+      if (n < 0) continue;
+      unsigned key = 0xffffffffu;  // dist << 16 | visiting order: the first minimum wins
+      unsigned idx = 0;
+      if (n <= kCand) {
+        if (lane < n) {
+          const unsigned e = cnd[(size_t)l * kCand + lane];
+          const int i2 = (int)(e & 0xffffu);
+          const int st = s_state[i2];
+          if (!(st >= 0 && V.last_has_obs[st])) {  // mvpMapPoints[i2] && Observations() > 0 -> skip (:1914-1915)
+            key = ((e >> 16) << 16) | (unsigned)lane;
+            idx = (unsigned)i2;
+          }
+        }
+      } else if (lane == 0) {  // more candidates than the list holds: enumerate them again (rare)
+        const Proj R = sbp_project(P, V, l, bForward, bBackward);
+        int order = 0;
+        int bestDist = 256;
+        sbp_candidates(P, V, R, l, s_start, s_items, [&](int i2, int dist) {
+          const int st = s_state[i2];
+          if (!(st >= 0 && V.last_has_obs[st]) && dist < bestDist) {
+            bestDist = dist;
+            idx = (unsigned)i2;
+            key = ((unsigned)dist << 16) | (unsigned)min(order, 0xffff);
+          }
+          order++;
+        });
+      }
+#pragma unroll
+      for (int ofs = 32; ofs > 0; ofs >>= 1) {
+        const unsigned ok = __shfl_xor(key, ofs, 64), oi = __shfl_xor(idx, ofs, 64);
+        if (ok < key) {
+          key = ok;
+          idx = oi;
+        }
+      }
+      const int bestDist = key == 0xffffffffu ? 256 : (int)(key >> 16);
+      if (bestDist <= kThHigh) {
+        const int best = (int)idx;
+        nm++;
+        if (lane == 0) {
+          s_state[best] = (short)l;
+          int bin = -1;
+          if (P.check_orientation) {
+            float rot = V.last_angle[l] - V.cur_kp[best].angle;
+            if (rot < 0.0) rot += 360.0f;
+            bin = (int)roundf(rot * (1.0f / kHisto));
+            if (bin == kHisto) bin = 0;
+            s_hist[bin]++;
+          }
+          sel[l] = best | (bin << 16);
+        }
+      }
+    }
+    if (lane == 0) s_ctl[0] = nm;
+  }
+  __syncthreads();
+  // ---- C. rotation consistency
+  if (P.check_orientation) {
+    if (tid == 0) {  // ComputeThreeMaxima
+      int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+      for (int i = 0; i < kHisto; i++) {
+        const int s = s_hist[i];
+        if (s > max1) {
+          max3 = max2;
+          max2 = max1;
+          max1 = s;
+          ind3 = ind2;
+          ind2 = ind1;
+          ind1 = i;
+        } else if (s > max2) {
+          max3 = max2;
+          max2 = s;
+          ind3 = ind2;
+          ind2 = i;
+        } else if (s > max3) {
+          max3 = s;
+          ind3 = i;
+        }
+      }
+      if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+      } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+      }
+      int nm = s_ctl[0];
+      for (int i = 0; i < kHisto; i++)
+        if (i != ind1 && i != ind2 && i != ind3) nm -= s_hist[i];
+      s_ctl[0] = nm;
+      s_ctl[1] = ind1;
+      s_ctl[2] = ind2;
+      s_ctl[3] = ind3;
+    }
+    __syncthreads();
+    const int ind1 = s_ctl[1], ind2 = s_ctl[2], ind3 = s_ctl[3];
+    for (int l = tid; l < NL; l += kSbpThreads) {
+      const int e = sel[l];
+      if (e < 0) continue;
+      const int bin = e >> 16, i2 = e & 0xffff;
+      if (bin != ind1 && bin != ind2 && bin != ind3) s_state[i2] = -2;  // CurrentFrame.mvpMapPoints[i2] = NULL
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < N; i += kSbpThreads) cur_match[(size_t)f * SC + i] = s_state[i];
+  if (tid == 0) nmatches[f] = s_ctl[0];
+}
+
+}  // namespace
+
+struct gfs_sbp {
+  int device, max_last, max_cur, max_batch;
+  hipStream_t stream;
+  std::mutex mu;
+  gfs::DevBuf<SbpPair> d_pairs;
+  gfs::DevBuf<float> d_last_xw, d_last_angle, d_cur_ur;
+  gfs::DevBuf<uint8_t> d_last_desc, d_last_has_obs, d_cur_desc, d_cur_has_obs;
+  gfs::DevBuf<int> d_last_octave, d_cand_cnt, d_lsel, d_cur_match, d_nmatches;
+  gfs::DevBuf<gfs_keypoint> d_cur_kp;
+  gfs::DevBuf<unsigned> d_cand;
+  gfs::PinBuf<SbpPair> h_pairs;
+  gfs::PinBuf<float> h_last_xw, h_last_angle, h_cur_ur;
+  gfs::PinBuf<uint8_t> h_last_desc, h_last_has_obs, h_cur_desc, h_cur_has_obs;
+  gfs::PinBuf<int> h_last_octave, h_cur_match, h_nmatches;
+  gfs::PinBuf<gfs_keypoint> h_cur_kp;
+};
+
+extern "C" {
+
+int gfs_sbp_create(int device, int max_last, int max_cur, int max_batch, gfs_sbp** out) {
+  GFS_REQUIRE(out && max_last > 0 && max_cur > 0 && max_batch > 0, GFS_ERR_INVALID_ARG, "gfs_sbp_create: invalid argument");
+  GFS_REQUIRE(max_cur <= kSbpMaxCur && max_last <= kSbpMaxLast, GFS_ERR_UNSUPPORTED,
+              "gfs_sbp_create: at most %d current key-points and %d map points per frame", kSbpMaxCur, kSbpMaxLast);
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  std::unique_ptr<gfs_sbp> h(new gfs_sbp);
+  h->device = device;
+  h->max_last = max_last;
+  h->max_cur = max_cur;
+  h->max_batch = max_batch;
+  GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t L = (size_t)max_last * max_batch, Cn = (size_t)max_cur * max_batch, B = max_batch;
+  int rc = 0;
+#define A(x) if (!rc) rc = (x)
+  A(h->d_pairs.alloc(B));
+  A(h->d_last_xw.alloc(L * 3));
+  A(h->d_last_desc.alloc(L * 32));
+  A(h->d_last_octave.alloc(L));
+  A(h->d_last_angle.alloc(L));
+  A(h->d_last_has_obs.alloc(L));
+  A(h->d_cur_kp.alloc(Cn));
+  A(h->d_cur_ur.alloc(Cn));
+  A(h->d_cur_desc.alloc(Cn * 32));
+  A(h->d_cur_has_obs.alloc(Cn));
+  A(h->d_cand.alloc(L * kCand));
+  A(h->d_cand_cnt.alloc(L));
+  A(h->d_lsel.alloc(L));
+  A(h->d_cur_match.alloc(Cn));
+  A(h->d_nmatches.alloc(B));
+  A(h->h_pairs.alloc(B));
+  A(h->h_last_xw.alloc(L * 3));
+  A(h->h_last_desc.alloc(L * 32));
+  A(h->h_last_octave.alloc(L));
+  A(h->h_last_angle.alloc(L));
+  A(h->h_last_has_obs.alloc(L));
+  A(h->h_cur_kp.alloc(Cn));
+  A(h->h_cur_ur.alloc(Cn));
+  A(h->h_cur_desc.alloc(Cn * 32));
+  A(h->h_cur_has_obs.alloc(Cn));
+  A(h->h_cur_match.alloc(Cn));
+  A(h->h_nmatches.alloc(B));
+#undef A
+  if (rc) {
+    (void)hipStreamDestroy(h->stream);
+    return rc;
+  }
+  *out = h.release();
+  return GFS_OK;
+}
+
+void gfs_sbp_destroy(gfs_sbp* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B, int32_t* const* cur_match, int32_t* nmatches) {
+  GFS_REQUIRE(h && problems && cur_match && nmatches && B > 0, GFS_ERR_INVALID_ARG, "gfs_search_by_projection: invalid argument");
+  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_search_by_projection: batch %d exceeds capacity %d", B, h->max_batch);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  const int SL = h->max_last, SC = h->max_cur;
+  for (int f = 0; f < B; f++) {
+    const gfs_sbp_problem& p = problems[f];
+    GFS_REQUIRE(p.n_last >= 0 && p.n_last <= SL && p.n_cur >= 0 && p.n_cur <= SC, GFS_ERR_CAPACITY,
+                "gfs_search_by_projection: pair %d has %d map points / %d key-points (capacity %d / %d)", f, p.n_last, p.n_cur, SL, SC);
+    GFS_REQUIRE(p.n_levels > 0 && p.n_levels <= 16 && p.scale_factors, GFS_ERR_INVALID_ARG,
+                "gfs_search_by_projection: pair %d needs 1..16 scale factors", f);
+    GFS_REQUIRE(p.n_cur == 0 || cur_match[f], GFS_ERR_INVALID_ARG, "gfs_search_by_projection: cur_match[%d] is NULL", f);
+    GFS_REQUIRE(p.n_last == 0 || (p.last_xw && p.last_desc && p.last_octave && p.last_angle && p.last_mp_has_obs), GFS_ERR_INVALID_ARG,
+                "gfs_search_by_projection: pair %d has NULL last-frame arrays", f);
+    GFS_REQUIRE(p.n_cur == 0 || (p.cur_kps_un && p.cur_u_right && p.cur_desc && p.cur_has_mp_obs), GFS_ERR_INVALID_ARG,
+                "gfs_search_by_projection: pair %d has NULL current-frame arrays", f);
+    for (int l = 0; l < p.n_last; l++)
+      GFS_REQUIRE(p.last_octave[l] >= 0 && p.last_octave[l] < p.n_levels, GFS_ERR_INVALID_ARG,
+                  "gfs_search_by_projection: pair %d map point %d has octave %d outside [0, %d)", f, l, p.last_octave[l], p.n_levels);
+    SbpPair& S = h->h_pairs.p[f];
+    S.n_last = p.n_last;
+    S.n_cur = p.n_cur;
+    S.n_levels = p.n_levels;
+    S.mono = p.mono;
+    S.check_orientation = p.check_orientation;
+    for (int k = 0; k < 4; k++) {
+      S.Tcw_q[k] = p.Tcw_q[k];
+      S.Tlw_q[k] = p.Tlw_q[k];
+    }
+    for (int k = 0; k < 3; k++) {
+      S.Tcw_t[k] = p.Tcw_t[k];
+      S.Tlw_t[k] = p.Tlw_t[k];
+    }
+    S.fx = p.fx;
+    S.fy = p.fy;
+    S.cx = p.cx;
+    S.cy = p.cy;
+    S.bf = p.bf;
+    S.b = p.b;
+    S.min_x = p.min_x;
+    S.max_x = p.max_x;
+    S.min_y = p.min_y;
+    S.max_y = p.max_y;
+    S.grid_w_inv = p.grid_w_inv;
+    S.grid_h_inv = p.grid_h_inv;
+    S.th = p.th;
+    for (int k = 0; k < 16; k++) S.scale[k] = k < p.n_levels ? p.scale_factors[k] : 0.f;
+    if (p.n_last > 0) {
+      memcpy(h->h_last_xw.p + (size_t)f * SL * 3, p.last_xw, (size_t)p.n_last * 12);
+      memcpy(h->h_last_desc.p + (size_t)f * SL * 32, p.last_desc, (size_t)p.n_last * 32);
+      memcpy(h->h_last_octave.p + (size_t)f * SL, p.last_octave, (size_t)p.n_last * 4);
+      memcpy(h->h_last_angle.p + (size_t)f * SL, p.last_angle, (size_t)p.n_last * 4);
+      memcpy(h->h_last_has_obs.p + (size_t)f * SL, p.last_mp_has_obs, (size_t)p.n_last);
+    }
+    if (p.n_cur > 0) {
+      memcpy(h->h_cur_kp.p + (size_t)f * SC, p.cur_kps_un, (size_t)p.n_cur * sizeof(gfs_keypoint));
+      memcpy(h->h_cur_ur.p + (size_t)f * SC, p.cur_u_right, (size_t)p.n_cur * 4);
+      memcpy(h->h_cur_desc.p + (size_t)f * SC * 32, p.cur_desc, (size_t)p.n_cur * 32);
+      memcpy(h->h_cur_has_obs.p + (size_t)f * SC, p.cur_has_mp_obs, (size_t)p.n_cur);
+    }
+  }
+  hipStream_t s = h->stream;
+  const size_t L = (size_t)SL * B, Cn = (size_t)SC * B;
+  GFS_HIP(hipMemcpyAsync(h->d_pairs.p, h->h_pairs.p, B * sizeof(SbpPair), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_xw.p, h->h_last_xw.p, L * 12, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_desc.p, h->h_last_desc.p, L * 32, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_octave.p, h->h_last_octave.p, L * 4, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_angle.p, h->h_last_angle.p, L * 4, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_has_obs.p, h->h_last_has_obs.p, L, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_kp.p, h->h_cur_kp.p, Cn * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_ur.p, h->h_cur_ur.p, Cn * 4, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_desc.p, h->h_cur_desc.p, Cn * 32, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_has_obs.p, h->h_cur_has_obs.p, Cn, hipMemcpyHostToDevice, s));
+  GFS_LAUNCH("k_sbp", k_sbp, dim3(B), dim3(kSbpThreads), 0, s, h->d_pairs.p, h->d_last_xw.p, h->d_last_desc.p, h->d_last_octave.p,
+             h->d_last_angle.p, h->d_last_has_obs.p, h->d_cur_kp.p, h->d_cur_ur.p, h->d_cur_desc.p, h->d_cur_has_obs.p, SL, SC,
+             h->d_cand.p, h->d_cand_cnt.p, h->d_lsel.p, h->d_cur_match.p, h->d_nmatches.p);
+  GFS_HIP(hipMemcpyAsync(h->h_cur_match.p, h->d_cur_match.p, Cn * 4, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_nmatches.p, h->d_nmatches.p, B * 4, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int f = 0; f < B; f++) {
+    if (problems[f].n_cur > 0) memcpy(cur_match[f], h->h_cur_match.p + (size_t)f * SC, (size_t)problems[f].n_cur * 4);
+    nmatches[f] = h->h_nmatches.p[f];
+  }
+  return GFS_OK;
+}
+
+}  // extern "C"

@@ -261,3 +261,92 @@ def pose_frame(seed, n_obs=300, mono_frac=0.15, outlier_frac=0.1, rot_deg=1.0, t
     return dict(q=q0, t=t0, n_obs=n_obs, xw=np.array(xw), obs=np.array(obs, np.float64), inv_sigma2=np.array(w, np.float32),
                 stereo=np.array(st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, n_rounds=4, its=10,
                 q_gt=_quat_from_R(Rcw), t_gt=tcw, is_outlier=np.array(is_out))
+
+
+def sbp_pair(seed, n_points=900, n_extra_cur=250, motion=0.04, rot_deg=0.8, th=7.0, mono=False, desc_flip_bits=18,
+             dup_frac=0.0, zero_obs_frac=0.0, preassigned_frac=0.0, n_levels=8, check_orientation=True):
+    """Synthetic input of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference
+    src/ORBmatcher.cc:1853-2063), flattened as gfs_sbp_problem (include/gfs_abi.h).
+
+    `n_points` map points seen by the last frame; the current frame (pose = last pose composed with a small motion) sees
+    most of them again (key-point = projection + sub-pixel noise, octave within +-1, descriptor = map-point descriptor with
+    `desc_flip_bits` random bit flips, angle = last angle + small rotation) plus `n_extra_cur` unrelated key-points.
+    dup_frac: fraction of map points duplicated (two map points competing for the same key-point -> the order-dependent
+    skip of :1914-1915); zero_obs_frac: map points with Observations() == 0 (their assignment may be overwritten);
+    preassigned_frac: current key-points that already hold a map point with observations."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    fx = fy = f32(607.0)
+    cx, cy = f32(319.5), f32(239.5)
+    bf = f32(0.0745 * 607.0)
+    b = f32(0.0745)
+    W, H = 640, 480
+    min_x, max_x, min_y, max_y = f32(0), f32(W), f32(0), f32(H)
+    scale = np.cumprod(np.r_[1.0, np.full(n_levels - 1, 1.2)]).astype(np.float32)
+    Rlw = _rot(0.03 * rng.normal(), 0.2 * rng.normal(), 0.03 * rng.normal())
+    tlw = np.array([0.2 * rng.normal(), 0.05 * rng.normal(), 0.1 * rng.normal()])
+    dR = _rot(*(np.deg2rad(rot_deg) * rng.normal(size=3)))
+    Rcw, tcw = dR @ Rlw, dR @ tlw + motion * rng.normal(size=3) + np.array([0, 0, -motion])
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                         ("octave", "<i4"), ("class_id", "<i4")])
+    last_xw, last_desc, last_oct, last_ang, last_obs = [], [], [], [], []
+    cur = []  # (x, y, octave, angle, u_right, desc)
+    roll = np.deg2rad(rot_deg) * rng.normal()
+    while len(last_xw) < n_points:
+        xl = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(1.0, 7.0)])  # in the last camera
+        ul, vl = fx * xl[0] / xl[2] + cx, fy * xl[1] / xl[2] + cy
+        if not (0 <= ul < W and 0 <= vl < H):
+            continue
+        xw = (Rlw.T @ (xl - tlw)).astype(np.float32)
+        octv = int(rng.choice(n_levels, p=np.array([217, 181, 151, 126, 105, 87, 73, 60][:n_levels]) / sum([217, 181, 151, 126, 105, 87, 73, 60][:n_levels])))
+        ang = f32(rng.uniform(0, 360))
+        desc = rng.integers(0, 256, 32, dtype=np.uint8)
+        reps = 2 if rng.random() < dup_frac else 1
+        for _ in range(reps):
+            last_xw.append(xw + (0 if _ == 0 else rng.normal(0, 0.002, 3).astype(np.float32)))
+            d = desc.copy()
+            if _ > 0:
+                flip = rng.choice(256, 6, replace=False)
+                np.bitwise_xor.at(d, flip // 8, (1 << (flip % 8)).astype(np.uint8))
+            last_desc.append(d)
+            last_oct.append(octv)
+            last_ang.append(ang)
+            last_obs.append(0 if rng.random() < zero_obs_frac else 1)
+        xc = Rcw @ xw.astype(np.float64) + tcw
+        if xc[2] <= 0.2:
+            continue
+        uc, vc = fx * xc[0] / xc[2] + cx, fy * xc[1] / xc[2] + cy
+        if not (0 <= uc < W and 0 <= vc < H) or rng.random() < 0.15:
+            continue
+        d = desc.copy()
+        flip = rng.choice(256, int(rng.integers(0, desc_flip_bits + 1)), replace=False)
+        np.bitwise_xor.at(d, flip // 8, (1 << (flip % 8)).astype(np.uint8))
+        o2 = int(np.clip(octv + rng.integers(-1, 2), 0, n_levels - 1))
+        a2 = f32((ang + np.rad2deg(roll) + rng.normal(0, 3.0)) % 360.0)
+        if rng.random() < 0.06:
+            a2 = f32(rng.uniform(0, 360))  # inconsistent rotation -> removed by the histogram check
+        x2, y2 = f32(uc + rng.normal(0, 0.7)), f32(vc + rng.normal(0, 0.7))
+        ur = f32(x2 - bf / xc[2] + rng.normal(0, 0.5)) if (not mono and rng.random() < 0.85) else f32(-1)
+        cur.append((x2, y2, o2, a2, ur, d))
+    for _ in range(n_extra_cur):
+        cur.append((f32(rng.uniform(0, W)), f32(rng.uniform(0, H)), int(rng.integers(0, n_levels)), f32(rng.uniform(0, 360)),
+                    f32(rng.uniform(1, W)) if rng.random() < 0.5 else f32(-1), rng.integers(0, 256, 32, dtype=np.uint8)))
+    order = rng.permutation(len(cur))
+    cur = [cur[i] for i in order]
+    kps = np.zeros(len(cur), kp_dtype)
+    kps["x"] = [c[0] for c in cur]
+    kps["y"] = [c[1] for c in cur]
+    kps["octave"] = [c[2] for c in cur]
+    kps["angle"] = [c[3] for c in cur]
+    kps["size"] = 31.0
+    kps["class_id"] = -1
+    return dict(last_xw=np.array(last_xw, np.float32)[:n_points], last_desc=np.array(last_desc, np.uint8)[:n_points],
+                last_octave=np.array(last_oct, np.int32)[:n_points], last_angle=np.array(last_ang, np.float32)[:n_points],
+                last_mp_has_obs=np.array(last_obs, np.uint8)[:n_points], cur_kps_un=kps,
+                cur_u_right=np.array([c[4] for c in cur], np.float32), cur_desc=np.array([c[5] for c in cur], np.uint8).reshape(-1, 32),
+                cur_has_mp_obs=(rng.random(len(cur)) < preassigned_frac).astype(np.uint8),
+                Tcw_q=_quat_from_R(Rcw).astype(np.float32), Tcw_t=tcw.astype(np.float32),
+                Tlw_q=_quat_from_R(Rlw).astype(np.float32), Tlw_t=tlw.astype(np.float32),
+                fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, b=b, min_x=min_x, max_x=max_x, min_y=min_y, max_y=max_y,
+                grid_w_inv=f32(64) / (max_x - min_x), grid_h_inv=f32(48) / (max_y - min_y), scale_factors=scale,
+                th=f32(th), mono=int(mono), check_orientation=int(check_orientation))

@@ -304,6 +304,50 @@ void gfs_pose_destroy(gfs_pose* h);
 int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_pose_solution* solutions);
 
 /* ============================================================================================
+ * 7. ORBmatcher::SearchByProjection, frame to frame — the windowed matcher of TrackWithMotionModel
+ *      int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th, bool bMono)
+ *                                                                             src/ORBmatcher.cc:1853-2063
+ *    with Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea (src/Frame.cc:734-761, 1073-1084, 1007-1071),
+ *    ORBmatcher::DescriptorDistance (:2536-2550, TH_HIGH = 100) and ComputeThreeMaxima (:2500-2532, HISTO_LENGTH = 30).
+ *    Single-camera frames only (Nleft == -1); the two-camera branch (:1951-2035) is not implemented.
+ * ============================================================================================ */
+typedef struct {
+  /* LastFrame: the key-points i with mvpMapPoints[i] != NULL && !mvbOutlier[i], in index order (the loop of :1872-1875) */
+  int32_t n_last;
+  const float* last_xw;           /* [n_last][3] pMP->GetWorldPos() */
+  const uint8_t* last_desc;       /* [n_last][32] pMP->GetDescriptor() */
+  const int32_t* last_octave;     /* [n_last] LastFrame.mvKeys[i].octave */
+  const float* last_angle;        /* [n_last] LastFrame.mvKeysUn[i].angle */
+  const uint8_t* last_mp_has_obs; /* [n_last] pMP->Observations() > 0 */
+  /* CurrentFrame */
+  int32_t n_cur;
+  const gfs_keypoint* cur_kps_un; /* [n_cur] mvKeysUn (cv::KeyPoint layout) */
+  const float* cur_u_right;       /* [n_cur] mvuRight */
+  const uint8_t* cur_desc;        /* [n_cur][32] mDescriptors */
+  const uint8_t* cur_has_mp_obs;  /* [n_cur] mvpMapPoints[i] != NULL && ->Observations() > 0 on entry */
+  float Tcw_q[4], Tcw_t[3];       /* CurrentFrame.GetPose(): Sophus::SE3f unit quaternion (x, y, z, w), translation */
+  float Tlw_q[4], Tlw_t[3];       /* LastFrame.GetPose() */
+  float fx, fy, cx, cy;           /* CurrentFrame.mpCamera (Pinhole) */
+  float bf, b;                    /* CurrentFrame.mbf, mb */
+  float min_x, max_x, min_y, max_y; /* Frame::mnMinX ... mnMaxY */
+  float grid_w_inv, grid_h_inv;   /* Frame::mfGridElementWidthInv / HeightInv (64 x 48 grid) */
+  const float* scale_factors;     /* CurrentFrame.mvScaleFactors */
+  int32_t n_levels;               /* <= 16 */
+  float th;                       /* window size factor (15 mono, 7 stereo in Tracking::TrackWithMotionModel) */
+  int32_t mono;                   /* bMono */
+  int32_t check_orientation;      /* ORBmatcher::mbCheckOrientation */
+} gfs_sbp_problem;
+
+typedef struct gfs_sbp gfs_sbp;
+/* max_last <= 8192 map points, max_cur <= 4096 key-points per frame */
+int gfs_sbp_create(int device, int max_last, int max_cur, int max_batch, gfs_sbp** out);
+void gfs_sbp_destroy(gfs_sbp* h);
+/* B independent frame pairs (host pointers).  cur_match[f][i] (n_cur entries): >= 0 = CurrentFrame.mvpMapPoints[i] now holds
+ * the map point of last-list entry cur_match[f][i]; -1 = left as it was; -2 = reset to NULL by the rotation-consistency
+ * check.  nmatches[f] = the function's return value (it counts overwritten assignments twice, like the reference). */
+int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B, int32_t* const* cur_match, int32_t* nmatches);
+
+/* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel
  * with these rather than torch events, which only see torch's current stream).
  * ============================================================================================ */

@@ -184,6 +184,33 @@ typedef struct {
 
 int gfso_pose_optimization(const gfso_pose_problem*, gfso_pose_solution*);
 
+/* ---- ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (src/ORBmatcher.cc:1853-2063), Nleft == -1 ---- */
+typedef struct {
+  int32_t n_last;               /* LastFrame key-points with a MapPoint that are not outliers, in index order */
+  const float* last_xw;         /* n_last*3 pMP->GetWorldPos() */
+  const uint8_t* last_desc;     /* n_last*32 pMP->GetDescriptor() */
+  const int32_t* last_octave;   /* LastFrame.mvKeys[i].octave */
+  const float* last_angle;      /* LastFrame.mvKeysUn[i].angle */
+  const uint8_t* last_mp_has_obs; /* pMP->Observations() > 0 */
+  int32_t n_cur;
+  const float* cur_xy;          /* n_cur*2 CurrentFrame.mvKeysUn[i].pt */
+  const int32_t* cur_octave;
+  const float* cur_angle;
+  const float* cur_u_right;     /* mvuRight */
+  const uint8_t* cur_desc;      /* n_cur*32 mDescriptors */
+  const uint8_t* cur_has_mp_obs; /* mvpMapPoints[i] != NULL && Observations() > 0 on entry */
+  float Tcw_q[4], Tcw_t[3], Tlw_q[4], Tlw_t[3]; /* Sophus::SE3f unit quaternions (x,y,z,w) + translations */
+  float fx, fy, cx, cy, bf, b;
+  float min_x, max_x, min_y, max_y, grid_w_inv, grid_h_inv;
+  const float* scale_factors;   /* mvScaleFactors */
+  int32_t n_levels;
+  float th;
+  int32_t mono, check_orientation;
+} gfso_sbp_problem;
+/* cur_match[n_cur]: >= 0 CurrentFrame.mvpMapPoints[i] := map point of that last-list entry; -1 left as it was;
+ * -2 reset to NULL by the rotation-consistency check.  Returns nmatches. */
+int gfso_search_by_projection(const gfso_sbp_problem*, int32_t* cur_match);
+
 #ifdef __cplusplus
 }
 #endif

@@ -411,6 +411,52 @@ def pose_optimization(prob):
                 iterations_run=int(S.iterations_run))
 
 
+class SbpProblem(C.Structure):
+    _fields_ = [("n_last", C.c_int32), ("last_xw", C.c_void_p), ("last_desc", C.c_void_p), ("last_octave", C.c_void_p),
+                ("last_angle", C.c_void_p), ("last_mp_has_obs", C.c_void_p), ("n_cur", C.c_int32), ("cur_xy", C.c_void_p),
+                ("cur_octave", C.c_void_p), ("cur_angle", C.c_void_p), ("cur_u_right", C.c_void_p), ("cur_desc", C.c_void_p),
+                ("cur_has_mp_obs", C.c_void_p), ("Tcw_q", C.c_float * 4), ("Tcw_t", C.c_float * 3), ("Tlw_q", C.c_float * 4),
+                ("Tlw_t", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("bf", C.c_float), ("b", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int32), ("th", C.c_float), ("mono", C.c_int32), ("check_orientation", C.c_int32)]
+
+
+def search_by_projection(prob):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) restatement (oracle/sbp_oracle.cpp).
+    prob: the keys of gfs_sbp_problem; cur_kps_un is a structured array with x, y, angle, octave fields.
+    Returns (cur_match int32 [n_cur], nmatches)."""
+    P = SbpProblem()
+    kps = prob["cur_kps_un"]
+    keep = dict(last_xw=np.ascontiguousarray(prob["last_xw"], np.float32).reshape(-1, 3),
+                last_desc=np.ascontiguousarray(prob["last_desc"], np.uint8).reshape(-1, 32),
+                last_octave=np.ascontiguousarray(prob["last_octave"], np.int32),
+                last_angle=np.ascontiguousarray(prob["last_angle"], np.float32),
+                last_mp_has_obs=np.ascontiguousarray(prob["last_mp_has_obs"], np.uint8),
+                cur_xy=np.ascontiguousarray(np.stack([kps["x"], kps["y"]], 1) if len(kps) else np.zeros((0, 2)), np.float32),
+                cur_octave=np.ascontiguousarray(kps["octave"], np.int32), cur_angle=np.ascontiguousarray(kps["angle"], np.float32),
+                cur_u_right=np.ascontiguousarray(prob["cur_u_right"], np.float32),
+                cur_desc=np.ascontiguousarray(prob["cur_desc"], np.uint8).reshape(-1, 32),
+                cur_has_mp_obs=np.ascontiguousarray(prob["cur_has_mp_obs"], np.uint8),
+                scale_factors=np.ascontiguousarray(prob["scale_factors"], np.float32))
+    P.n_last, P.n_cur = len(keep["last_xw"]), len(keep["cur_xy"])
+    for name, a in keep.items():
+        setattr(P, name, a.ctypes.data)
+    for name in ("Tcw_q", "Tcw_t", "Tlw_q", "Tlw_t"):
+        getattr(P, name)[:] = [float(np.float32(v)) for v in prob[name]]
+    for name in ("fx", "fy", "cx", "cy", "bf", "b", "min_x", "max_x", "min_y", "max_y", "grid_w_inv", "grid_h_inv", "th"):
+        setattr(P, name, float(np.float32(prob[name])))
+    P.n_levels = len(keep["scale_factors"])
+    P.mono = int(prob.get("mono", 0))
+    P.check_orientation = int(prob.get("check_orientation", 1))
+    out = np.full(max(P.n_cur, 1), -9, np.int32)
+    L = lib()
+    L.gfso_search_by_projection.restype = C.c_int
+    L.gfso_search_by_projection.argtypes = [C.POINTER(SbpProblem), C.c_void_p]
+    n = L.gfso_search_by_projection(C.byref(P), out.ctypes.data)
+    return out[:P.n_cur].copy(), int(n)
+
+
 def depth_to_cloud(depth, downsample, fx, fy, cx, cy):
     depth = np.ascontiguousarray(depth, np.float32)
     rows, cols = depth.shape if depth.ndim == 2 else (0, 0)
