@@ -145,6 +145,41 @@ class LocalBundleAdjuster {
   gfs_lba* h_ = nullptr;
 };
 
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on flattened frames (reference src/ORBmatcher.cc:1853-2063;
+// see INTEGRATION.md §6 for the flattening of Frame / MapPoint)
+class ProjectionMatcher {
+ public:
+  ProjectionMatcher(int max_last = 8192, int max_cur = 4096, int device = 0) { check(gfs_sbp_create(device, max_last, max_cur, 1, &h_), "gfs_sbp_create"); }
+  ~ProjectionMatcher() { gfs_sbp_destroy(h_); }
+  // cur_match: p.n_cur entries (>= 0 new map point = last-list entry, -1 untouched, -2 reset to NULL); returns nmatches
+  int SearchByProjection(const gfs_sbp_problem& p, std::vector<int32_t>& cur_match) {
+    cur_match.assign((size_t)std::max(p.n_cur, 1), -1);
+    int32_t* ptr = cur_match.data();
+    int32_t n = 0;
+    check(gfs_search_by_projection(h_, &p, 1, &ptr, &n), "gfs_search_by_projection");
+    cur_match.resize((size_t)p.n_cur);
+    return n;
+  }
+
+ private:
+  gfs_sbp* h_ = nullptr;
+};
+
+// Optimizer::PoseOptimization on a flattened frame (reference src/Optimizer.cc:763-1098)
+class PoseOptimizer {
+ public:
+  PoseOptimizer(int max_obs = 8192, int device = 0) { check(gfs_pose_create(device, max_obs, 1, &h_), "gfs_pose_create"); }
+  ~PoseOptimizer() { gfs_pose_destroy(h_); }
+  // returns nInitialCorrespondences - nBad; s.outlier / s.chi2 must point to p.n_obs entries
+  int PoseOptimization(const gfs_pose_problem& p, gfs_pose_solution& s) {
+    check(gfs_pose_optimize(h_, &p, 1, &s), "gfs_pose_optimize");
+    return s.n_inliers;
+  }
+
+ private:
+  gfs_pose* h_ = nullptr;
+};
+
 }  // namespace gfs_host
 
 #if defined(GFS_WITH_OPENCV)
