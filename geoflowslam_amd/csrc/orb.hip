@@ -60,18 +60,10 @@ __device__ __forceinline__ const uint8_t* level_ptr(const LevelDev& L, int level
 // saturate_cast<uchar>(cvRound(sum)).  One thread per destination pixel; <= 4x4 source taps.
 // Reference call: src/ORBextractor.cc:1240-1241.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_area(const LevelDev* __restrict__ levels, int level, Lvl0 l0,
-                                                  uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                  const int* __restrict__ xt_start, const int* __restrict__ xt_n,
-                                                  const float* __restrict__ xt_alpha, const int* __restrict__ yt_start,
-                                                  const int* __restrict__ yt_n, const float* __restrict__ yt_alpha) {
-  const LevelDev L = levels[level];
-  const LevelDev S = levels[level - 1];
-  const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
-  if (dx >= L.cols || dy >= L.rows) return;
-  int sp;
-  const uint8_t* src = level_ptr(S, level - 1, b, l0, pyr, pyr_frame, &sp);
-  const int xi = L.xtab_off + dx, yi = L.ytab_off + dy;
+__device__ __forceinline__ uint8_t area_pixel(const uint8_t* __restrict__ src, int sp, int xi, int yi,
+                                              const int* __restrict__ xt_start, const int* __restrict__ xt_n,
+                                              const float* __restrict__ xt_alpha, const int* __restrict__ yt_start,
+                                              const int* __restrict__ yt_n, const float* __restrict__ yt_alpha) {
   const int sx0 = xt_start[xi], nx = xt_n[xi], sy0 = yt_start[yi], ny = yt_n[yi];
   const float4 ax = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)xi);
   const float4 ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)yi);
@@ -85,8 +77,83 @@ __global__ __launch_bounds__(256) void k_pyr_area(const LevelDev* __restrict__ l
     sum = (j == 0) ? t : __fadd_rn(sum, t);
   }
   int r = __float2int_rn(sum);  // cvRound: round-half-even
-  r = min(max(r, 0), 255);
-  pyr[(size_t)b * pyr_frame + L.plane_off + (size_t)dy * L.pitch + dx] = (uint8_t)r;
+  return (uint8_t)min(max(r, 0), 255);
+}
+
+// One launch for the whole chain: workgroup (k, b) produces, level after level, a horizontal strip of every level of
+// frame b (OrbGeometry::strip_rows: its share of the level plus the halo rows its own higher levels read), so a level
+// only ever reads rows the same workgroup produced.  Neighbouring strips recompute a few identical halo rows instead of
+// synchronising.  The strips live in LDS (two ping-pong buffers: level 0 strip staged with word loads, every level is
+// computed LDS -> LDS and streamed out to HBM once): the 16 byte taps per pixel are LDS reads, not 16 global byte loads
+// (the per-level kernel was bound by the texture-address rate of those loads: 0.32 ms / 64 VGA frames, this one 0.1x ms).
+// LDS = false: same schedule through HBM (a level re-reads the rows its own workgroup wrote: workgroup-scope fence +
+// barrier; an agent-scope fence would write back the XCD's L2 at every level, measured 4x slower) for images whose
+// strips do not fit the LDS.
+constexpr int kPyrThreads = 1024;
+template <bool LDS>
+__global__ __launch_bounds__(kPyrThreads) void k_pyr_area(const LevelDev* __restrict__ levels, int nlevels, Lvl0 l0,
+                                                          uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                          const int* __restrict__ strip_rows, unsigned lds_a,
+                                                          const int* __restrict__ xt_start, const int* __restrict__ xt_n,
+                                                          const float* __restrict__ xt_alpha, const int* __restrict__ yt_start,
+                                                          const int* __restrict__ yt_n, const float* __restrict__ yt_alpha) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int* rng = strip_rows + 2 * k * nlevels;
+  if (LDS) {  // stage the level-0 rows level 1 reads
+    const LevelDev S0 = levels[0];
+    int sp;
+    const uint8_t* src = level_ptr(S0, 0, b, l0, pyr, pyr_frame, &sp);
+    const int s0 = rng[0], s1 = rng[1], cols = S0.cols;
+    if (((cols | sp) & 3) == 0 && ((uintptr_t)src & 3) == 0) {
+      const int wpr = cols >> 2, total = (s1 - s0) * wpr;
+      for (int i = tid; i < total; i += kPyrThreads) {
+        const int y = i / wpr, x = i - y * wpr;
+        reinterpret_cast<uint32_t*>(smem)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(s0 + y) * sp + 4 * x);
+      }
+    } else {
+      const int total = (s1 - s0) * cols;
+      for (int i = tid; i < total; i += kPyrThreads) {
+        const int y = i / cols, x = i - y * cols;
+        smem[i] = src[(size_t)(s0 + y) * sp + x];
+      }
+    }
+    __syncthreads();
+  }
+  for (int level = 1; level < nlevels; level++) {
+    const LevelDev L = levels[level];
+    const LevelDev S = levels[level - 1];
+    const int r0 = rng[2 * level], r1 = rng[2 * level + 1];
+    int sp;
+    const uint8_t* src;
+    uint8_t* keep = nullptr;  // LDS copy of the rows produced here (the next level's source)
+    if (LDS) {
+      // source rows [rng[2 (level-1)], ...) of level-1 sit in the buffer of that level's parity, pitch = its column count
+      const uint8_t* sbuf = smem + ((level - 1) & 1 ? lds_a : 0u);
+      sp = S.cols;
+      src = sbuf - (size_t)rng[2 * (level - 1)] * sp;
+      if (level + 1 < nlevels) keep = smem + (level & 1 ? lds_a : 0u);
+    } else {
+      src = level_ptr(S, level - 1, b, l0, pyr, pyr_frame, &sp);
+    }
+    uint8_t* dst = pyr + (size_t)b * pyr_frame + L.plane_off;
+    const int total = (r1 - r0) * L.cols;
+    const int sy = kPyrThreads / L.cols, sx = kPyrThreads - sy * L.cols;  // raster step of one workgroup stride
+    int dx = tid % L.cols, dy = r0 + tid / L.cols;
+    for (int i = tid; i < total; i += kPyrThreads) {
+      const uint8_t v = area_pixel(src, sp, L.xtab_off + dx, L.ytab_off + dy, xt_start, xt_n, xt_alpha, yt_start, yt_n, yt_alpha);
+      dst[(size_t)dy * L.pitch + dx] = v;
+      if (LDS && keep) keep[i] = v;  // i == (dy - r0) * cols + dx
+      dx += sx;
+      dy += sy;
+      if (dx >= L.cols) {
+        dx -= L.cols;
+        dy++;
+      }
+    }
+    if (!LDS) __threadfence_block();
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,7 +1205,7 @@ struct gfs_orb {
   gfs::DevBuf<LevelDev> d_levels;
   gfs::DevBuf<CellDev> d_cells;
   gfs::DevBuf<BlurTileDev> d_tiles;
-  gfs::DevBuf<int> d_xt_start, d_xt_n, d_yt_start, d_yt_n, d_cell_cnt, d_cand_off, d_kp_count, d_mono;
+  gfs::DevBuf<int> d_strip_rows, d_xt_start, d_xt_n, d_yt_start, d_yt_n, d_cell_cnt, d_cand_off, d_kp_count, d_mono;
   gfs::DevBuf<float> d_xt_alpha, d_yt_alpha;
   gfs::DevBuf<uint32_t> d_slab, d_cand, d_perm0, d_perm1, d_kept;
   gfs::DevBuf<unsigned short> d_seg0, d_seg1;
@@ -1178,6 +1245,7 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
   GFS_HIP(hipMemcpyAsync(h->d_levels.p, G.levels.data(), G.levels.size() * sizeof(LevelDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_cells.p, G.cells.data(), G.cells.size() * sizeof(CellDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_tiles.p, G.blur_tiles.data(), G.blur_tiles.size() * sizeof(BlurTileDev), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_strip_rows.p, G.strip_rows.data(), G.strip_rows.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_xt_start.p, G.xt_start.data(), G.xt_start.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_xt_n.p, G.xt_n.data(), G.xt_n.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_xt_alpha.p, G.xt_alpha.data(), G.xt_alpha.size() * 4, hipMemcpyHostToDevice, s));
@@ -1212,12 +1280,15 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   const int nl = h->P.nlevels;
   const int n_cells = (int)G.cells.size();
   const size_t cap_pyr = h->cap_pyr, cap_blur = h->cap_blur, cap_slab = h->cap_slab;
-  // 1. pyramid chain (level l depends on l-1)
-  for (int l = 1; l < nl; l++) {
-    const LevelDev& L = G.levels[l];
-    dim3 grid(gfs::div_up(L.cols, 64), gfs::div_up(L.rows, 4), B);
-    GFS_LAUNCH("k_pyr_area", k_pyr_area, grid, dim3(64, 4), 0, s, h->d_levels.p, l, l0, h->d_pyr.p, cap_pyr,
-               h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p, h->d_yt_start.p, h->d_yt_n.p, h->d_yt_alpha.p);
+  // 1. pyramid chain (level l depends on l-1): one launch, row strips with recomputed halos
+  if (G.pyr_lds_a + G.pyr_lds_b > 0) {
+    GFS_LAUNCH("k_pyr_area", (k_pyr_area<true>), dim3(G.pyr_strips, B), dim3(kPyrThreads), G.pyr_lds_a + G.pyr_lds_b, s, h->d_levels.p,
+               nl, l0, h->d_pyr.p, cap_pyr, h->d_strip_rows.p, (unsigned)G.pyr_lds_a, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p,
+               h->d_yt_start.p, h->d_yt_n.p, h->d_yt_alpha.p);
+  } else {
+    GFS_LAUNCH("k_pyr_area", (k_pyr_area<false>), dim3(G.pyr_strips, B), dim3(kPyrThreads), 0, s, h->d_levels.p, nl, l0, h->d_pyr.p,
+               cap_pyr, h->d_strip_rows.p, 0u, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p, h->d_yt_start.p, h->d_yt_n.p,
+               h->d_yt_alpha.p);
   }
   // 2. FAST cells of all levels, all frames in one launch
   const size_t lds = 4 * (size_t)G.max_tile_w * G.max_tile_h + 8;  // tile + score map + corner list (u16)
@@ -1383,6 +1454,8 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   A(h->d_levels.alloc(nl));
   A(h->d_cells.alloc(h->cap_cells));
   A(h->d_tiles.alloc(G.blur_tiles.size() + 64));
+  A(h->d_strip_rows.alloc((size_t)2 * gfs::OrbGeometry::kPyrMaxStrips * 16));
+  GFS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_area<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   A(h->d_xt_start.alloc(tab_x));
   A(h->d_xt_n.alloc(tab_x));
   A(h->d_xt_alpha.alloc(tab_x * 4));

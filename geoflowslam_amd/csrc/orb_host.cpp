@@ -200,6 +200,56 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
   blur_bytes = blur;
   slab_entries = slab;
   cand_cap = slab;
+  // Row strips of the fused pyramid kernel.  Strip k owns rows [k R_l / S, (k+1) R_l / S) of every level; to produce them
+  // without any inter-workgroup dependency it also computes, at every lower level, the rows its higher levels read
+  // (INTER_AREA footprints from the y tables).  Neighbouring strips recompute a few identical halo rows.  S is the smallest
+  // candidate whose level-0 and level-1 strips (the two LDS ping-pong buffers) fit the CU's LDS.
+  pyr_strips = 0;
+  pyr_lds_a = pyr_lds_b = 0;
+  const int nl = p.nlevels;
+  if (nl >= 2) {
+    const int cand[] = {8, 12, 16, 24, 32, 48, 64};
+    for (int S : cand) {
+      std::vector<int> tab((size_t)2 * S * nl, 0);
+      size_t la = 0, lb = 0;
+      for (int k = 0; k < S; k++) {
+        int a = 0, b = 0;
+        for (int l = nl - 1; l >= 0; l--) {
+          const int R = levels[l].rows;
+          int oa = l >= 1 ? (int)((long long)k * R / S) : 0, ob = l >= 1 ? (int)((long long)(k + 1) * R / S) : 0;
+          if (l < nl - 1 && b > a) {  // footprint of the rows held at level l + 1
+            const LevelDev& U = levels[l + 1];
+            const int fa = yt_start[U.ytab_off + a], fb = yt_start[U.ytab_off + b - 1] + yt_n[U.ytab_off + b - 1];
+            if (ob > oa) {
+              oa = std::min(oa, fa);
+              ob = std::max(ob, fb);
+            } else {
+              oa = fa;
+              ob = fb;
+            }
+          }
+          a = oa;
+          b = ob;
+          tab[2 * ((size_t)k * nl + l)] = a;
+          tab[2 * ((size_t)k * nl + l) + 1] = b;
+          const size_t bytes = (size_t)(b - a) * levels[l].cols;
+          if (l % 2 == 0) la = std::max(la, bytes);
+          else lb = std::max(lb, bytes);
+        }
+      }
+      la = (la + 15) / 16 * 16;
+      lb = (lb + 15) / 16 * 16;
+      if (la + lb <= 150 * 1024 || S == 64) {
+        strip_rows = tab;
+        pyr_strips = S;
+        if (la + lb <= 150 * 1024) {
+          pyr_lds_a = la;
+          pyr_lds_b = lb;
+        }
+        break;
+      }
+    }
+  }
 }
 
 void ic_angle_offsets(const int umax[16], std::vector<int8_t>& du, std::vector<int8_t>& dv) {

@@ -58,6 +58,13 @@ struct OrbGeometry {
   std::vector<int> xt_start, yt_start;
   std::vector<int> xt_n, yt_n;
   std::vector<float> xt_alpha, yt_alpha;
+  // fused pyramid kernel: rows [strip_rows[2*(k*nlevels+l)], strip_rows[2*(k*nlevels+l)+1]) of level l held by strip k: for
+  // l >= 1 the rows it computes (its own share of the level plus the halo its higher levels read), for l = 0 the source rows
+  // level 1 reads.  pyr_lds_a / pyr_lds_b: bytes of the two LDS ping-pong buffers (even / odd levels); 0 = does not fit.
+  std::vector<int> strip_rows;
+  int pyr_strips = 0;
+  size_t pyr_lds_a = 0, pyr_lds_b = 0;
+  static constexpr int kPyrMaxStrips = 64;
   size_t pyr_bytes = 0, blur_bytes = 0;  // per frame
   size_t slab_entries = 0;               // per frame
   size_t cand_cap = 0;                   // dense candidate list capacity per frame (== slab_entries)
