@@ -786,7 +786,8 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
                                                  const int* __restrict__ m_counts, const int* __restrict__ bbox,
                                                  const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
                                                  int* __restrict__ ginfo_rw, unsigned* __restrict__ hard_list,
-                                                 int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
+                                                 double* __restrict__ hard_d, int nchunks, int npairs, int P, GicpParams prm,
+                                                 double* __restrict__ cov6) {
   int pair, which, chunk;
   if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
   const int c = 2 * pair + which;
@@ -821,7 +822,10 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
   // Isolated point (k-th neighbour beyond one cell, ~2 % of a depth-camera cloud): it needs a (much) bigger probe.  Done
   // here it would stall the other 63 lanes of its wave (and ~70 % of the waves hold such a lane), so it is deferred.
   if (!certified) {
-    hard_list[(size_t)c * P + atomicAdd(&ginfo_rw[8 * c + 7], 1)] = (unsigned)i;
+    const int slot = atomicAdd(&ginfo_rw[8 * c + 7], 1);
+    hard_list[(size_t)c * P + slot] = (unsigned)i;
+    // k candidates already known: the true k nearest lie within this distance (bounds the follow-up probe)
+    hard_d[(size_t)c * P + slot] = best.found >= want ? best.nth(max(want - 1, 0)) : 1.79769313486231570e308;
     return;
   }
   knn_write_cov(best, kk, p, cov6 + ((size_t)c * P + i) * 6);
@@ -843,8 +847,9 @@ __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__
                                                      const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
                                                      const int* __restrict__ m_counts, const int* __restrict__ bbox,
                                                      const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
-                                                     unsigned* __restrict__ hard_list, int* __restrict__ far2_count,
-                                                     int nchunks, int npairs, int P, GicpParams prm, double* __restrict__ cov6) {
+                                                     unsigned* __restrict__ hard_list, double* __restrict__ hard_d,
+                                                     int* __restrict__ far2_count, int nchunks, int npairs, int P, GicpParams prm,
+                                                     double* __restrict__ cov6) {
   constexpr int kQueries = 256 / LANES;
   __shared__ int s_ids[kQueries][10];
   __shared__ int s_found[kQueries];
@@ -859,6 +864,7 @@ __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__
   const u64* uc = ucell + (size_t)c * (P + 1);
   const unsigned* ub = ubegin + (size_t)c * (P + 1);
   unsigned* list = hard_list + (size_t)c * P;
+  double* list_d = hard_d + (size_t)c * P;
   const int nu = n_ucell[c];
   const int nhard = DEFER ? gi[7] : far2_count[c];
   const int kk = min(prm.k_neighbors, 10);
@@ -871,12 +877,26 @@ __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__
     if (gl == 0) s_query[grp] = -1;
     if (h < nhard) {
       const int i = (int)(DEFER ? list[h] : list[P - 1 - h]);
+      // squared distance within which the k nearest are known to lie (k_knn_cov found k candidates), or "infinite"
+      const double Dk = DEFER ? list_d[h] : list_d[P - 1 - h];
+      const bool bounded = Dk < 1.0e300;
       const double4 q = p[i];
       const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
                 cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
+      // lower bound of the distance from q to the cells d steps away along one axis (a hair conservative)
+      const double ux = q.x * prm.inv_cell - (double)(cx - kCoordOffset), uy = q.y * prm.inv_cell - (double)(cy - kCoordOffset),
+                   uz = q.z * prm.inv_cell - (double)(cz - kCoordOffset);
+      auto axis_lb = [&](int d, double u) {
+        const double v = d == 0 ? 0.0 : d > 0 ? (double)d - u : u - (double)(d + 1);
+        return fmax(v - 1e-9, 0.0) * prm.cell;
+      };
       TopK<10> best;  // merged result, identical in all lanes of the group
       bool done = false;
-      for (int r = R0;;) {
+      double Dnext = Dk;  // bound handed to the next pass
+      // bounded: one probe of ceil(sqrt(Dk) / cell) rings is final, and cells (rows) farther than sqrt(Dk) are skipped
+      int r = bounded ? max((int)ceil(sqrt(Dk) * prm.inv_cell), 2) : R0;
+      if (DEFER && r > 2) r = -1;  // beyond this pass: hand over at once
+      for (; r > 0;) {
         TopK<10> loc;
         loc.init();
         // cells outside the occupied-cell bounding box are empty: clamp the probe to it
@@ -888,10 +908,17 @@ __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__
         for (int t = gl; t < nunits; t += 2 * LANES) {  // two units per trip: both lookups are in flight together
           const int ta = t, tb = min(t + LANES, nunits - 1);
           const int rowa = ta / upr, xa = ta - rowa * upr, rowb = tb / upr, xb = tb - rowb * upr;
-          int ja0, ja1, jb0, jb1;
-          row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xa, upr == 1 ? x1 : x0 + xa, y0 + rowa % ny, z0 + rowa / ny, &ja0, &ja1);
-          row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xb, upr == 1 ? x1 : x0 + xb, y0 + rowb % ny, z0 + rowb / ny, &jb0, &jb1);
-          if (t + LANES >= nunits) jb1 = jb0;
+          const int ya = y0 + rowa % ny, za = z0 + rowa / ny, yb = y0 + rowb % ny, zb = z0 + rowb / ny;
+          bool usea = true, useb = t + LANES < nunits;
+          if (bounded) {
+            const double la = axis_lb(ya - cy, uy), lza = axis_lb(za - cz, uz), lxa = upr == 1 ? 0.0 : axis_lb(x0 + xa - cx, ux);
+            const double lb = axis_lb(yb - cy, uy), lzb = axis_lb(zb - cz, uz), lxb = upr == 1 ? 0.0 : axis_lb(x0 + xb - cx, ux);
+            usea = la * la + lza * lza + lxa * lxa <= Dk;
+            useb = useb && lb * lb + lzb * lzb + lxb * lxb <= Dk;
+          }
+          int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0;
+          if (usea) row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xa, upr == 1 ? x1 : x0 + xa, ya, za, &ja0, &ja1);
+          if (useb) row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xb, upr == 1 ? x1 : x0 + xb, yb, zb, &jb0, &jb1);
           knn_scan_run(p, q, ja0, ja1, loc);
           knn_scan_run(p, q, jb0, jb1, loc);
         }
@@ -933,6 +960,7 @@ __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__
           done = true;
           break;
         }
+        if (best.found >= want) Dnext = fmin(Dnext, kth);
         if (DEFER) break;
         // k candidates are known: the true k nearest lie within sqrt(kth), so the next probe is the last one
         r = best.found >= want ? min(2 * r, (int)ceil(sqrt(kth) * prm.inv_cell)) : 2 * r;
@@ -944,7 +972,9 @@ __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__
           s_found[grp] = best.found;
           s_query[grp] = i;
         } else {
-          list[P - 1 - atomicAdd(&far2_count[c], 1)] = (unsigned)i;
+          const int slot = atomicAdd(&far2_count[c], 1);
+          list[P - 1 - slot] = (unsigned)i;
+          list_d[P - 1 - slot] = Dnext;
         }
       }
     }
@@ -1488,6 +1518,7 @@ struct gfs_gicp {
   std::mutex mu;
   gfs::DevBuf<float4> d_in_t, d_in_s;  // staging for the host-pointer entry
   gfs::DevBuf<unsigned> d_hard;  // per cloud: indices of the points k_knn_cov deferred to k_knn_cov_far
+  gfs::DevBuf<double> d_hard_d;  // ... and the squared distance bounding their k nearest (same slots)
   gfs::DevBuf<int> d_far2;  // per cloud: number of points deferred a second time (stored from the back of d_hard)
   gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox, d_ginfo, d_kinfo1, d_kinfo2;
   gfs::DevBuf<u64> d_keys0, d_keys1, d_ck0, d_ck1, d_ucell;
@@ -1540,6 +1571,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_bbox.alloc(C2 * 6));
   A(h->d_ginfo.alloc(C2 * 8));
   A(h->d_hard.alloc((size_t)C2 * P));
+  A(h->d_hard_d.alloc((size_t)C2 * P));
   A(h->d_far2.alloc(C2));
   A(h->d_kinfo1.alloc(C2 * 8));
   A(h->d_kinfo2.alloc(C2 * 8));
@@ -1636,14 +1668,14 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
   const int knn_chunks = gfs::div_up(npts, 128);
   GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(xcd_grid(knn_chunks, B, 2)), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
              h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_ginfo.p, h->d_hard.p,
-             knn_chunks, B, P, prm, h->d_cov6.p);
+             h->d_hard_d.p, knn_chunks, B, P, prm, h->d_cov6.p);
   const int far_chunks = std::max(1, std::min(32, knn_chunks));  // grid-stride over the deferred lists
   GFS_LAUNCH("k_knn_cov_far", (k_knn_cov_far<16, 2, true>), dim3(xcd_grid(far_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
              h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
-             h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
+             h->d_hard_d.p, h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
   GFS_LAUNCH("k_knn_cov_far2", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(far_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
              h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
-             h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
+             h->d_hard_d.p, h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
   GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
              prm.max_iterations, h->d_ndone.p);
