@@ -113,6 +113,35 @@ class SbpProblem(C.Structure):
                 ("th", C.c_float), ("mono", C.c_int32), ("check_orientation", C.c_int32)]
 
 
+class SbpMapProblem(C.Structure):
+    _fields_ = [("n_mp", C.c_int32), ("mp_proj", C.c_void_p), ("mp_level", C.c_void_p), ("mp_view_cos", C.c_void_p),
+                ("mp_desc", C.c_void_p), ("mp_has_obs", C.c_void_p), ("n_cur", C.c_int32), ("cur_kps_un", C.c_void_p),
+                ("cur_u_right", C.c_void_p), ("cur_desc", C.c_void_p), ("cur_has_mp_obs", C.c_void_p), ("min_x", C.c_float),
+                ("min_y", C.c_float), ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int32), ("th", C.c_float), ("nn_ratio", C.c_float)]
+
+
+def sbp_map_struct(prob):
+    P = SbpMapProblem()
+    keep = dict(mp_proj=np.ascontiguousarray(prob["mp_proj"], np.float32).reshape(-1, 3),
+                mp_level=np.ascontiguousarray(prob["mp_level"], np.int32),
+                mp_view_cos=np.ascontiguousarray(prob["mp_view_cos"], np.float32),
+                mp_desc=np.ascontiguousarray(prob["mp_desc"], np.uint8).reshape(-1, 32),
+                mp_has_obs=np.ascontiguousarray(prob["mp_has_obs"], np.uint8),
+                cur_kps_un=np.ascontiguousarray(prob["cur_kps_un"], KP_DTYPE),
+                cur_u_right=np.ascontiguousarray(prob["cur_u_right"], np.float32),
+                cur_desc=np.ascontiguousarray(prob["cur_desc"], np.uint8).reshape(-1, 32),
+                cur_has_mp_obs=np.ascontiguousarray(prob["cur_has_mp_obs"], np.uint8),
+                scale_factors=np.ascontiguousarray(prob["scale_factors"], np.float32))
+    P.n_mp, P.n_cur = len(keep["mp_proj"]), len(keep["cur_kps_un"])
+    for name, a in keep.items():
+        setattr(P, name, a.ctypes.data)
+    for name in ("min_x", "min_y", "grid_w_inv", "grid_h_inv", "th", "nn_ratio"):
+        setattr(P, name, float(np.float32(prob[name])))
+    P.n_levels = len(keep["scale_factors"])
+    return P, keep
+
+
 def sbp_struct(prob):
     """ctypes view of one SearchByProjection problem dict (keys as in gfs_sbp_problem; cur_kps_un = KP_DTYPE array)."""
     P = SbpProblem()
@@ -154,7 +183,7 @@ ABI_SYMBOLS = [
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
     "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
-    "gfs_sbp_create", "gfs_sbp_destroy", "gfs_search_by_projection",
+    "gfs_sbp_create", "gfs_sbp_destroy", "gfs_search_by_projection", "gfs_search_by_projection_map",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
 ]
@@ -599,6 +628,27 @@ class ProjectionMatcher:
             ptrs[f] = outs[f].ctypes.data
         nm = np.zeros(B, np.int32)
         _check(lib().gfs_search_by_projection(self.h, PP, B, ptrs, _p(nm)), "gfs_search_by_projection")
+        res = [(outs[f][:PP[f].n_cur].copy(), int(nm[f])) for f in range(B)]
+        return res[0] if single else res
+
+
+    def SearchByProjectionMap(self, frames):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:43-206):
+        one problem dict (keys of gfs_sbp_map_problem) or a list -> (cur_match int32 [n_cur], nmatches) per frame."""
+        single = isinstance(frames, dict)
+        probs = [frames] if single else list(frames)
+        B = len(probs)
+        PP = (SbpMapProblem * B)()
+        keeps, outs = [], []
+        ptrs = (C.c_void_p * B)()
+        for f, prob in enumerate(probs):
+            P, keep = sbp_map_struct(prob)
+            PP[f] = P
+            keeps.append(keep)
+            outs.append(np.full(max(P.n_cur, 1), -9, np.int32))
+            ptrs[f] = outs[f].ctypes.data
+        nm = np.zeros(B, np.int32)
+        _check(lib().gfs_search_by_projection_map(self.h, PP, B, ptrs, _p(nm)), "gfs_search_by_projection_map")
         res = [(outs[f][:PP[f].n_cur].copy(), int(nm[f])) for f in range(B)]
         return res[0] if single else res
 

@@ -395,7 +395,6 @@ __global__ __launch_bounds__(kThreads) void k_lba(LbaDev D) {
   extern __shared__ __align__(16) double lds[];
   __shared__ double s16[16];
   __shared__ int s_flag;
-  __shared__ double s_ctl[4];  // rho, accept flag
   const int n = 6 * D.n_free;
   double* Hs = lds;
   double* bs = lds + (size_t)n * (n + 1) / 2;

@@ -11,6 +11,9 @@
 //      the later ones, :1914-1915), so the assignment itself runs in map-point order on one wave: the lanes check one
 //      candidate each, a wave-wide arg-min (first minimum wins, as `dist < bestDist` does) picks the match;
 //   C. rotation histogram + ComputeThreeMaxima (:2500-2532) and the final NULL-ing of inconsistent matches.
+// Mode 1 is ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th, ...) (:43-206): the projections come
+// with the map points (Frame::isInFrustum), the window depends on the viewing angle, and phase B keeps best and second best
+// (two arg-min rounds) for the ratio test; no rotation histogram.
 // Results are bit-exact integer work; the float decisions (image bounds, window membership, level ranges, histogram bins)
 // use the reference's float expressions (the library is built with -ffp-contract=off).
 #include <memory>
@@ -29,6 +32,8 @@ constexpr int kCand = 64;          // candidates kept per map point (more: the a
 
 struct SbpPair {
   int n_last, n_cur, n_levels, mono, check_orientation;
+  int mode;  // 0 = frame to frame (:1853-2063), 1 = map points with Frame::isInFrustum projections (:43-206)
+  float nn_ratio;
   float Tcw_q[4], Tcw_t[3], Tlw_q[4], Tlw_t[3];
   float fx, fy, cx, cy, bf, b, min_x, max_x, min_y, max_y, grid_w_inv, grid_h_inv, th;
   float scale[16];
@@ -63,7 +68,7 @@ __device__ __forceinline__ int hamming256(const uint8_t* a, const uint8_t* b) {
 }
 
 struct Proj {
-  float u, v, radius, invzc;
+  float u, v, radius, ur, ur_gate;  // window centre / half size, predicted right-image x and its tolerance
   int minLevel, maxLevel, x0, x1, y0, y1;
   bool ok;
 };
@@ -72,26 +77,41 @@ struct Proj {
 __device__ __forceinline__ Proj sbp_project(const SbpPair& P, const SbpView& V, int l, bool bForward, bool bBackward) {
   Proj R;
   R.ok = false;
-  float x3Dc[3];
-  so3_act(P.Tcw_q, V.last_xw + 3 * l, x3Dc);
-  for (int k = 0; k < 3; k++) x3Dc[k] += P.Tcw_t[k];
-  R.invzc = (float)(1.0 / (double)x3Dc[2]);
-  if (R.invzc < 0) return R;
-  R.u = P.fx * x3Dc[0] / x3Dc[2] + P.cx;
-  R.v = P.fy * x3Dc[1] / x3Dc[2] + P.cy;
-  if (R.u < P.min_x || R.u > P.max_x) return R;
-  if (R.v < P.min_y || R.v > P.max_y) return R;
-  const int oct = V.last_octave[l];
-  R.radius = P.th * P.scale[oct];
-  if (bForward) {
-    R.minLevel = oct;
-    R.maxLevel = -1;
-  } else if (bBackward) {
-    R.minLevel = 0;
-    R.maxLevel = oct;
+  if (P.mode == 1) {  // the projection was done by Frame::isInFrustum: (mTrackProjX, mTrackProjY, mTrackProjXR), level, viewCos
+    R.u = V.last_xw[3 * l];
+    R.v = V.last_xw[3 * l + 1];
+    R.ur = V.last_xw[3 * l + 2];
+    const int level = V.last_octave[l];
+    float r = (double)V.last_angle[l] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:250-255)
+    if ((double)P.th != 1.0) r *= P.th;
+    R.radius = r * P.scale[level];
+    R.ur_gate = R.radius;
+    R.minLevel = level - 1;
+    R.maxLevel = level;
   } else {
-    R.minLevel = oct - 1;
-    R.maxLevel = oct + 1;
+    float x3Dc[3];
+    so3_act(P.Tcw_q, V.last_xw + 3 * l, x3Dc);
+    for (int k = 0; k < 3; k++) x3Dc[k] += P.Tcw_t[k];
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    if (invzc < 0) return R;
+    R.u = P.fx * x3Dc[0] / x3Dc[2] + P.cx;
+    R.v = P.fy * x3Dc[1] / x3Dc[2] + P.cy;
+    if (R.u < P.min_x || R.u > P.max_x) return R;
+    if (R.v < P.min_y || R.v > P.max_y) return R;
+    const int oct = V.last_octave[l];
+    R.radius = P.th * P.scale[oct];
+    R.ur = R.u - P.bf * invzc;
+    R.ur_gate = R.radius;
+    if (bForward) {
+      R.minLevel = oct;
+      R.maxLevel = -1;
+    } else if (bBackward) {
+      R.minLevel = 0;
+      R.maxLevel = oct;
+    } else {
+      R.minLevel = oct - 1;
+      R.maxLevel = oct + 1;
+    }
   }
   R.x0 = max(0, (int)floorf((R.u - P.min_x - R.radius) * P.grid_w_inv));
   if (R.x0 >= kGridCols) return R;
@@ -128,9 +148,8 @@ __device__ __forceinline__ bool sbp_candidates(const SbpPair& P, const SbpView& 
         if (V.cur_has_obs[i2]) continue;  // a map point with observations was there on entry: never replaced
         const float ur2 = V.cur_ur[i2];
         if (ur2 > 0) {
-          const float ur = R.u - P.bf * R.invzc;
-          const float er = fabsf(ur - ur2);
-          if (er > R.radius) continue;
+          const float er = fabsf(R.ur - ur2);
+          if (er > R.ur_gate) continue;
         }
         f(i2, hamming256(V.last_desc + 32 * (size_t)l, V.cur_desc + 32 * (size_t)i2));
       }
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
       if (n < 0) continue;
       unsigned key = 0xffffffffu;  // dist << 16 | visiting order: the first minimum wins
       unsigned idx = 0;
+      unsigned key2 = 0xffffffffu, idx2 = 0;  // second best (mode 1, re-enumeration path)
       if (n <= kCand) {
         if (lane < n) {
           const unsigned e = cnd[(size_t)l * kCand + lane];
@@ -251,16 +271,28 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
         const Proj R = sbp_project(P, V, l, bForward, bBackward);
         int order = 0;
         int bestDist = 256;
+        int bestDist2 = 256;
         sbp_candidates(P, V, R, l, s_start, s_items, [&](int i2, int dist) {
           const int st = s_state[i2];
-          if (!(st >= 0 && V.last_has_obs[st]) && dist < bestDist) {
-            bestDist = dist;
-            idx = (unsigned)i2;
-            key = ((unsigned)dist << 16) | (unsigned)min(order, 0xffff);
+          if (!(st >= 0 && V.last_has_obs[st])) {
+            const unsigned kk = ((unsigned)dist << 16) | (unsigned)min(order, 0xffff);
+            if (dist < bestDist) {
+              bestDist2 = bestDist;
+              key2 = key;
+              idx2 = idx;
+              bestDist = dist;
+              idx = (unsigned)i2;
+              key = kk;
+            } else if (dist < bestDist2) {
+              bestDist2 = dist;
+              key2 = kk;
+              idx2 = (unsigned)i2;
+            }
           }
           order++;
         });
       }
+      const unsigned mykey = key, myidx = idx;
 #pragma unroll
       for (int ofs = 32; ofs > 0; ofs >>= 1) {
         const unsigned ok = __shfl_xor(key, ofs, 64), oi = __shfl_xor(idx, ofs, 64);
@@ -270,6 +302,30 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
         }
       }
       const int bestDist = key == 0xffffffffu ? 256 : (int)(key >> 16);
+      if (P.mode == 1) {
+        // second best = the smallest (distance, visiting order) among the others: what the sequential best / second-best
+        // bookkeeping of :96-113 ends with.  (The re-enumeration path has filled key2 / idx2 on lane 0.)
+        unsigned k2 = (n <= kCand) ? (mykey == key ? 0xffffffffu : mykey) : key2, i2b = (n <= kCand) ? myidx : idx2;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+          const unsigned ok = __shfl_xor(k2, ofs, 64), oi = __shfl_xor(i2b, ofs, 64);
+          if (ok < k2) {
+            k2 = ok;
+            i2b = oi;
+          }
+        }
+        if (bestDist <= kThHigh) {
+          const int best = (int)idx;
+          const int bestDist2 = k2 == 0xffffffffu ? 256 : (int)(k2 >> 16);
+          const int bestLevel = V.cur_kp[best].octave, bestLevel2 = k2 == 0xffffffffu ? -1 : V.cur_kp[i2b].octave;
+          const bool reject = bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2;
+          if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= P.nn_ratio * (float)bestDist2)) {
+            nm++;
+            if (lane == 0) s_state[best] = (short)l;
+          }
+        }
+        continue;
+      }
       if (bestDist <= kThHigh) {
         const int best = (int)idx;
         nm++;
@@ -291,7 +347,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
   }
   __syncthreads();
   // ---- C. rotation consistency
-  if (P.check_orientation) {
+  if (P.mode == 0 && P.check_orientation) {
     if (tid == 0) {  // ComputeThreeMaxima
       int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
       for (int i = 0; i < kHisto; i++) {
@@ -359,6 +415,30 @@ struct gfs_sbp {
   gfs::PinBuf<int> h_last_octave, h_cur_match, h_nmatches;
   gfs::PinBuf<gfs_keypoint> h_cur_kp;
 };
+
+// uploads the staged batch, runs k_sbp, downloads cur_match / nmatches into the pinned buffers
+static int sbp_run(gfs_sbp* h, int B) {
+  const int SL = h->max_last, SC = h->max_cur;
+  hipStream_t s = h->stream;
+  const size_t L = (size_t)SL * B, Cn = (size_t)SC * B;
+  GFS_HIP(hipMemcpyAsync(h->d_pairs.p, h->h_pairs.p, B * sizeof(SbpPair), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_xw.p, h->h_last_xw.p, L * 12, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_desc.p, h->h_last_desc.p, L * 32, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_octave.p, h->h_last_octave.p, L * 4, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_angle.p, h->h_last_angle.p, L * 4, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_last_has_obs.p, h->h_last_has_obs.p, L, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_kp.p, h->h_cur_kp.p, Cn * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_ur.p, h->h_cur_ur.p, Cn * 4, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_desc.p, h->h_cur_desc.p, Cn * 32, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_cur_has_obs.p, h->h_cur_has_obs.p, Cn, hipMemcpyHostToDevice, s));
+  GFS_LAUNCH("k_sbp", k_sbp, dim3(B), dim3(kSbpThreads), 0, s, h->d_pairs.p, h->d_last_xw.p, h->d_last_desc.p, h->d_last_octave.p,
+             h->d_last_angle.p, h->d_last_has_obs.p, h->d_cur_kp.p, h->d_cur_ur.p, h->d_cur_desc.p, h->d_cur_has_obs.p, SL, SC,
+             h->d_cand.p, h->d_cand_cnt.p, h->d_lsel.p, h->d_cur_match.p, h->d_nmatches.p);
+  GFS_HIP(hipMemcpyAsync(h->h_cur_match.p, h->d_cur_match.p, Cn * 4, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_nmatches.p, h->d_nmatches.p, B * 4, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
 
 extern "C" {
 
@@ -447,6 +527,8 @@ int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B,
     S.n_levels = p.n_levels;
     S.mono = p.mono;
     S.check_orientation = p.check_orientation;
+    S.mode = 0;
+    S.nn_ratio = 0.f;
     for (int k = 0; k < 4; k++) {
       S.Tcw_q[k] = p.Tcw_q[k];
       S.Tlw_q[k] = p.Tlw_q[k];
@@ -483,24 +565,64 @@ int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B,
       memcpy(h->h_cur_has_obs.p + (size_t)f * SC, p.cur_has_mp_obs, (size_t)p.n_cur);
     }
   }
-  hipStream_t s = h->stream;
-  const size_t L = (size_t)SL * B, Cn = (size_t)SC * B;
-  GFS_HIP(hipMemcpyAsync(h->d_pairs.p, h->h_pairs.p, B * sizeof(SbpPair), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_xw.p, h->h_last_xw.p, L * 12, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_desc.p, h->h_last_desc.p, L * 32, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_octave.p, h->h_last_octave.p, L * 4, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_angle.p, h->h_last_angle.p, L * 4, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_has_obs.p, h->h_last_has_obs.p, L, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_kp.p, h->h_cur_kp.p, Cn * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_ur.p, h->h_cur_ur.p, Cn * 4, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_desc.p, h->h_cur_desc.p, Cn * 32, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_has_obs.p, h->h_cur_has_obs.p, Cn, hipMemcpyHostToDevice, s));
-  GFS_LAUNCH("k_sbp", k_sbp, dim3(B), dim3(kSbpThreads), 0, s, h->d_pairs.p, h->d_last_xw.p, h->d_last_desc.p, h->d_last_octave.p,
-             h->d_last_angle.p, h->d_last_has_obs.p, h->d_cur_kp.p, h->d_cur_ur.p, h->d_cur_desc.p, h->d_cur_has_obs.p, SL, SC,
-             h->d_cand.p, h->d_cand_cnt.p, h->d_lsel.p, h->d_cur_match.p, h->d_nmatches.p);
-  GFS_HIP(hipMemcpyAsync(h->h_cur_match.p, h->d_cur_match.p, Cn * 4, hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(h->h_nmatches.p, h->d_nmatches.p, B * 4, hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipStreamSynchronize(s));
+  const int rc = sbp_run(h, B);
+  if (rc != GFS_OK) return rc;
+  for (int f = 0; f < B; f++) {
+    if (problems[f].n_cur > 0) memcpy(cur_match[f], h->h_cur_match.p + (size_t)f * SC, (size_t)problems[f].n_cur * 4);
+    nmatches[f] = h->h_nmatches.p[f];
+  }
+  return GFS_OK;
+}
+
+int gfs_search_by_projection_map(gfs_sbp* h, const gfs_sbp_map_problem* problems, int B, int32_t* const* cur_match, int32_t* nmatches) {
+  GFS_REQUIRE(h && problems && cur_match && nmatches && B > 0, GFS_ERR_INVALID_ARG, "gfs_search_by_projection_map: invalid argument");
+  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_search_by_projection_map: batch %d exceeds capacity %d", B, h->max_batch);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  const int SL = h->max_last, SC = h->max_cur;
+  for (int f = 0; f < B; f++) {
+    const gfs_sbp_map_problem& p = problems[f];
+    GFS_REQUIRE(p.n_mp >= 0 && p.n_mp <= SL && p.n_cur >= 0 && p.n_cur <= SC, GFS_ERR_CAPACITY,
+                "gfs_search_by_projection_map: frame %d has %d map points / %d key-points (capacity %d / %d)", f, p.n_mp, p.n_cur, SL, SC);
+    GFS_REQUIRE(p.n_levels > 0 && p.n_levels <= 16 && p.scale_factors, GFS_ERR_INVALID_ARG,
+                "gfs_search_by_projection_map: frame %d needs 1..16 scale factors", f);
+    GFS_REQUIRE(p.n_cur == 0 || cur_match[f], GFS_ERR_INVALID_ARG, "gfs_search_by_projection_map: cur_match[%d] is NULL", f);
+    GFS_REQUIRE(p.n_mp == 0 || (p.mp_proj && p.mp_desc && p.mp_level && p.mp_view_cos && p.mp_has_obs), GFS_ERR_INVALID_ARG,
+                "gfs_search_by_projection_map: frame %d has NULL map-point arrays", f);
+    GFS_REQUIRE(p.n_cur == 0 || (p.cur_kps_un && p.cur_u_right && p.cur_desc && p.cur_has_mp_obs), GFS_ERR_INVALID_ARG,
+                "gfs_search_by_projection_map: frame %d has NULL key-point arrays", f);
+    for (int l = 0; l < p.n_mp; l++)
+      GFS_REQUIRE(p.mp_level[l] >= 0 && p.mp_level[l] < p.n_levels, GFS_ERR_INVALID_ARG,
+                  "gfs_search_by_projection_map: frame %d map point %d has level %d outside [0, %d)", f, l, p.mp_level[l], p.n_levels);
+    SbpPair& S = h->h_pairs.p[f];
+    memset(&S, 0, sizeof(S));
+    S.n_last = p.n_mp;
+    S.n_cur = p.n_cur;
+    S.n_levels = p.n_levels;
+    S.mode = 1;
+    S.nn_ratio = p.nn_ratio;
+    S.min_x = p.min_x;
+    S.min_y = p.min_y;
+    S.grid_w_inv = p.grid_w_inv;
+    S.grid_h_inv = p.grid_h_inv;
+    S.th = p.th;
+    for (int k = 0; k < 16; k++) S.scale[k] = k < p.n_levels ? p.scale_factors[k] : 0.f;
+    if (p.n_mp > 0) {
+      memcpy(h->h_last_xw.p + (size_t)f * SL * 3, p.mp_proj, (size_t)p.n_mp * 12);
+      memcpy(h->h_last_desc.p + (size_t)f * SL * 32, p.mp_desc, (size_t)p.n_mp * 32);
+      memcpy(h->h_last_octave.p + (size_t)f * SL, p.mp_level, (size_t)p.n_mp * 4);
+      memcpy(h->h_last_angle.p + (size_t)f * SL, p.mp_view_cos, (size_t)p.n_mp * 4);
+      memcpy(h->h_last_has_obs.p + (size_t)f * SL, p.mp_has_obs, (size_t)p.n_mp);
+    }
+    if (p.n_cur > 0) {
+      memcpy(h->h_cur_kp.p + (size_t)f * SC, p.cur_kps_un, (size_t)p.n_cur * sizeof(gfs_keypoint));
+      memcpy(h->h_cur_ur.p + (size_t)f * SC, p.cur_u_right, (size_t)p.n_cur * 4);
+      memcpy(h->h_cur_desc.p + (size_t)f * SC * 32, p.cur_desc, (size_t)p.n_cur * 32);
+      memcpy(h->h_cur_has_obs.p + (size_t)f * SC, p.cur_has_mp_obs, (size_t)p.n_cur);
+    }
+  }
+  const int rc = sbp_run(h, B);
+  if (rc != GFS_OK) return rc;
   for (int f = 0; f < B; f++) {
     if (problems[f].n_cur > 0) memcpy(cur_match[f], h->h_cur_match.p + (size_t)f * SC, (size_t)problems[f].n_cur * 4);
     nmatches[f] = h->h_nmatches.p[f];

@@ -350,3 +350,31 @@ def sbp_pair(seed, n_points=900, n_extra_cur=250, motion=0.04, rot_deg=0.8, th=7
                 fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, b=b, min_x=min_x, max_x=max_x, min_y=min_y, max_y=max_y,
                 grid_w_inv=f32(64) / (max_x - min_x), grid_h_inv=f32(48) / (max_y - min_y), scale_factors=scale,
                 th=f32(th), mono=int(mono), check_orientation=int(check_orientation))
+
+
+def sbp_map_frame(seed, th=1.0, nn_ratio=0.8, **kw):
+    """Synthetic input of ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) (reference src/ORBmatcher.cc:43-206) as
+    gfs_sbp_map_problem: the scene of sbp_pair with the projections Frame::isInFrustum would leave on the map points
+    (mTrackProjX / Y / XR, predicted level, viewing cosine), in double like the float pipeline's inputs rounded to float."""
+    p = sbp_pair(seed, **kw)
+    rng = np.random.default_rng(seed + 7919)
+    R = _rot_from_quat(p["Tcw_q"].astype(np.float64))
+    xc = p["last_xw"].astype(np.float64) @ R.T + p["Tcw_t"].astype(np.float64)
+    keep = (xc[:, 2] > 0.2)
+    u = p["fx"] * xc[:, 0] / xc[:, 2] + p["cx"]
+    v = p["fy"] * xc[:, 1] / xc[:, 2] + p["cy"]
+    keep &= (u >= 0) & (u < 640) & (v >= 0) & (v < 480)
+    ur = u - p["bf"] / xc[:, 2]
+    view_cos = np.where(rng.random(len(u)) < 0.5, 0.9995, rng.uniform(0.5, 0.998, len(u))).astype(np.float32)
+    return dict(mp_proj=np.stack([u, v, ur], 1)[keep].astype(np.float32), mp_level=p["last_octave"][keep],
+                mp_view_cos=view_cos[keep], mp_desc=p["last_desc"][keep], mp_has_obs=p["last_mp_has_obs"][keep],
+                cur_kps_un=p["cur_kps_un"], cur_u_right=p["cur_u_right"], cur_desc=p["cur_desc"], cur_has_mp_obs=p["cur_has_mp_obs"],
+                min_x=p["min_x"], min_y=p["min_y"], grid_w_inv=p["grid_w_inv"], grid_h_inv=p["grid_h_inv"],
+                scale_factors=p["scale_factors"], th=np.float32(th), nn_ratio=np.float32(nn_ratio))
+
+
+def _rot_from_quat(q):
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])

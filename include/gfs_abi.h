@@ -347,6 +347,33 @@ void gfs_sbp_destroy(gfs_sbp* h);
  * check.  nmatches[f] = the function's return value (it counts overwritten assignments twice, like the reference). */
 int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B, int32_t* const* cur_match, int32_t* nmatches);
 
+/*      int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, float th, bool bFarPoints,
+ *                                         float thFarPoints)                    src/ORBmatcher.cc:43-206
+ *    (TrackLocalMap / relocalisation): the caller lists the map points that pass the filters of :53-58 (mbTrackInView, not
+ *    beyond thFarPoints, !isBad()) with the projection Frame::isInFrustum left on them; the window depends on the viewing
+ *    angle (RadiusByViewingCos :250-255), best / second-best ratio test (mfNNratio) when both sit on the same pyramid level. */
+typedef struct {
+  int32_t n_mp;
+  const float* mp_proj;          /* [n_mp][3] pMP->mTrackProjX, mTrackProjY, mTrackProjXR */
+  const int32_t* mp_level;       /* [n_mp] mnTrackScaleLevel */
+  const float* mp_view_cos;      /* [n_mp] mTrackViewCos */
+  const uint8_t* mp_desc;        /* [n_mp][32] GetDescriptor() */
+  const uint8_t* mp_has_obs;     /* [n_mp] Observations() > 0 */
+  int32_t n_cur;
+  const gfs_keypoint* cur_kps_un; /* F.mvKeysUn */
+  const float* cur_u_right;      /* F.mvuRight */
+  const uint8_t* cur_desc;       /* F.mDescriptors */
+  const uint8_t* cur_has_mp_obs; /* F.mvpMapPoints[i] != NULL && ->Observations() > 0 on entry */
+  float min_x, min_y, grid_w_inv, grid_h_inv;
+  const float* scale_factors;    /* F.mvScaleFactors */
+  int32_t n_levels;
+  float th;                      /* window factor (1, 3, 5 ... in Tracking::SearchLocalPoints) */
+  float nn_ratio;                /* ORBmatcher::mfNNratio */
+} gfs_sbp_map_problem;
+/* cur_match[f][i]: >= 0 = F.mvpMapPoints[i] := map point of list entry cur_match[f][i]; -1 = left as it was. */
+int gfs_search_by_projection_map(gfs_sbp* h, const gfs_sbp_map_problem* problems, int B, int32_t* const* cur_match,
+                                 int32_t* nmatches);
+
 /* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel
  * with these rather than torch events, which only see torch's current stream).

@@ -211,6 +211,29 @@ typedef struct {
  * -2 reset to NULL by the rotation-consistency check.  Returns nmatches. */
 int gfso_search_by_projection(const gfso_sbp_problem*, int32_t* cur_match);
 
+/* ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:43-206),
+ *      Nleft == -1: the map points that pass the filters of :53-58, with the projection Frame::isInFrustum left on them ---- */
+typedef struct {
+  int32_t n_mp;
+  const float* mp_proj;        /* n_mp*3 mTrackProjX, mTrackProjY, mTrackProjXR */
+  const int32_t* mp_level;     /* mnTrackScaleLevel */
+  const float* mp_view_cos;    /* mTrackViewCos */
+  const uint8_t* mp_desc;      /* n_mp*32 */
+  const uint8_t* mp_has_obs;   /* Observations() > 0 */
+  int32_t n_cur;
+  const float* cur_xy;
+  const int32_t* cur_octave;
+  const float* cur_u_right;
+  const uint8_t* cur_desc;
+  const uint8_t* cur_has_mp_obs;
+  float min_x, min_y, grid_w_inv, grid_h_inv;
+  const float* scale_factors;
+  int32_t n_levels;
+  float th, nn_ratio;
+} gfso_sbp_map_problem;
+/* cur_match[n_cur]: >= 0 F.mvpMapPoints[i] := that list entry, -1 untouched.  Returns nmatches. */
+int gfso_search_by_projection_map(const gfso_sbp_map_problem*, int32_t* cur_match);
+
 #ifdef __cplusplus
 }
 #endif

@@ -457,6 +457,43 @@ def search_by_projection(prob):
     return out[:P.n_cur].copy(), int(n)
 
 
+class SbpMapProblem(C.Structure):
+    _fields_ = [("n_mp", C.c_int32), ("mp_proj", C.c_void_p), ("mp_level", C.c_void_p), ("mp_view_cos", C.c_void_p),
+                ("mp_desc", C.c_void_p), ("mp_has_obs", C.c_void_p), ("n_cur", C.c_int32), ("cur_xy", C.c_void_p),
+                ("cur_octave", C.c_void_p), ("cur_u_right", C.c_void_p), ("cur_desc", C.c_void_p), ("cur_has_mp_obs", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float),
+                ("scale_factors", C.c_void_p), ("n_levels", C.c_int32), ("th", C.c_float), ("nn_ratio", C.c_float)]
+
+
+def search_by_projection_map(prob):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) restatement (oracle/sbp_oracle.cpp) -> (cur_match, nmatches)."""
+    P = SbpMapProblem()
+    kps = prob["cur_kps_un"]
+    keep = dict(mp_proj=np.ascontiguousarray(prob["mp_proj"], np.float32).reshape(-1, 3),
+                mp_level=np.ascontiguousarray(prob["mp_level"], np.int32),
+                mp_view_cos=np.ascontiguousarray(prob["mp_view_cos"], np.float32),
+                mp_desc=np.ascontiguousarray(prob["mp_desc"], np.uint8).reshape(-1, 32),
+                mp_has_obs=np.ascontiguousarray(prob["mp_has_obs"], np.uint8),
+                cur_xy=np.ascontiguousarray(np.stack([kps["x"], kps["y"]], 1) if len(kps) else np.zeros((0, 2)), np.float32),
+                cur_octave=np.ascontiguousarray(kps["octave"], np.int32),
+                cur_u_right=np.ascontiguousarray(prob["cur_u_right"], np.float32),
+                cur_desc=np.ascontiguousarray(prob["cur_desc"], np.uint8).reshape(-1, 32),
+                cur_has_mp_obs=np.ascontiguousarray(prob["cur_has_mp_obs"], np.uint8),
+                scale_factors=np.ascontiguousarray(prob["scale_factors"], np.float32))
+    P.n_mp, P.n_cur = len(keep["mp_proj"]), len(keep["cur_xy"])
+    for name, a in keep.items():
+        setattr(P, name, a.ctypes.data)
+    for name in ("min_x", "min_y", "grid_w_inv", "grid_h_inv", "th", "nn_ratio"):
+        setattr(P, name, float(np.float32(prob[name])))
+    P.n_levels = len(keep["scale_factors"])
+    out = np.full(max(P.n_cur, 1), -9, np.int32)
+    L = lib()
+    L.gfso_search_by_projection_map.restype = C.c_int
+    L.gfso_search_by_projection_map.argtypes = [C.POINTER(SbpMapProblem), C.c_void_p]
+    n = L.gfso_search_by_projection_map(C.byref(P), out.ctypes.data)
+    return out[:P.n_cur].copy(), int(n)
+
+
 def depth_to_cloud(depth, downsample, fx, fy, cx, cy):
     depth = np.ascontiguousarray(depth, np.float32)
     rows, cols = depth.shape if depth.ndim == 2 else (0, 0)

@@ -174,3 +174,77 @@ extern "C" int gfso_search_by_projection(const gfso_sbp_problem* p, int32_t* cur
   }
   return nmatches;
 }
+
+// ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+// (reference src/ORBmatcher.cc:43-206), single-camera frames: best / second-best Hamming match inside a window whose size
+// depends on the viewing angle (RadiusByViewingCos :250-255), ratio test when both are on the same pyramid level.
+extern "C" int gfso_search_by_projection_map(const gfso_sbp_map_problem* p, int32_t* cur_match) {
+  const int N = p->n_cur;
+  for (int i = 0; i < N; i++) cur_match[i] = -1;
+  std::vector<std::vector<int>> grid(kGridCols * kGridRows);
+  for (int i = 0; i < N; i++) {
+    const int px = (int)std::round((p->cur_xy[2 * i] - p->min_x) * p->grid_w_inv);
+    const int py = (int)std::round((p->cur_xy[2 * i + 1] - p->min_y) * p->grid_h_inv);
+    if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
+    grid[px * kGridRows + py].push_back(i);
+  }
+  const bool bFactor = (double)p->th != 1.0;
+  int nmatches = 0;
+  for (int l = 0; l < p->n_mp; l++) {
+    const int level = p->mp_level[l];
+    float r = (double)p->mp_view_cos[l] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos
+    if (bFactor) r *= p->th;
+    const float x = p->mp_proj[3 * l], y = p->mp_proj[3 * l + 1], xr = p->mp_proj[3 * l + 2];
+    const float radius = r * p->scale_factors[level];
+    const int minLevel = level - 1, maxLevel = level;
+    const int nMinCellX = std::max(0, (int)std::floor((x - p->min_x - radius) * p->grid_w_inv));
+    if (nMinCellX >= kGridCols) continue;
+    const int nMaxCellX = std::min(kGridCols - 1, (int)std::ceil((x - p->min_x + radius) * p->grid_w_inv));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)std::floor((y - p->min_y - radius) * p->grid_h_inv));
+    if (nMinCellY >= kGridRows) continue;
+    const int nMaxCellY = std::min(kGridRows - 1, (int)std::ceil((y - p->min_y + radius) * p->grid_h_inv));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    bool any = false;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+        for (int idx : grid[ix * kGridRows + iy]) {
+          if (bCheckLevels) {
+            if (p->cur_octave[idx] < minLevel) continue;
+            if (maxLevel >= 0 && p->cur_octave[idx] > maxLevel) continue;
+          }
+          const float distx = p->cur_xy[2 * idx] - x, disty = p->cur_xy[2 * idx + 1] - y;
+          if (!(std::fabs(distx) < radius && std::fabs(disty) < radius)) continue;
+          any = true;
+          const bool blocked = p->cur_has_mp_obs[idx] ? (cur_match[idx] == -1 ? true : p->mp_has_obs[cur_match[idx]] != 0)
+                                                      : (cur_match[idx] >= 0 && p->mp_has_obs[cur_match[idx]] != 0);
+          if (blocked) continue;
+          if (p->cur_u_right[idx] > 0) {
+            const float er = std::fabs(xr - p->cur_u_right[idx]);
+            if (er > r * p->scale_factors[level]) continue;
+          }
+          const int dist = popcnt256(p->mp_desc + 32 * l, p->cur_desc + 32 * idx);
+          if (dist < bestDist) {
+            bestDist2 = bestDist;
+            bestDist = dist;
+            bestLevel2 = bestLevel;
+            bestLevel = p->cur_octave[idx];
+            bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = p->cur_octave[idx];
+            bestDist2 = dist;
+          }
+        }
+    if (!any) continue;
+    if (bestDist <= kThHigh) {
+      if (bestLevel == bestLevel2 && bestDist > p->nn_ratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= p->nn_ratio * bestDist2) {
+        cur_match[bestIdx] = l;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}

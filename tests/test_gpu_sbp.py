@@ -71,3 +71,37 @@ def test_capacity_and_argument_errors(gpu_api):
     bad["last_octave"][0] = 99
     with pytest.raises(gpu_api.GfsError):
         pm.SearchByProjection(bad)
+
+
+MAP_CASES = [dict(seed=1), dict(seed=2, th=3.0, dup_frac=0.3, zero_obs_frac=0.3, preassigned_frac=0.1),
+             dict(seed=3, th=5.0, nn_ratio=0.6, desc_flip_bits=80), dict(seed=4, n_points=1900, n_extra_cur=400, th=3.0),
+             dict(seed=5, th=1.0, nn_ratio=1.0, zero_obs_frac=1.0, dup_frac=0.5)]
+
+
+@pytest.mark.parametrize("cfg", MAP_CASES)
+def test_map_variant_matches_oracle(gpu_api, oracle, cfg):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) (src/ORBmatcher.cc:43-206): bit-exact assignments and count."""
+    p = synth.sbp_map_frame(**cfg)
+    pm = gpu_api.ProjectionMatcher(max_last=2048, max_cur=2560, max_batch=2)
+    m, n = pm.SearchByProjectionMap(p)
+    mo, no = oracle.search_by_projection_map(p)
+    assert n == no and np.array_equal(m, mo)
+
+
+def test_map_variant_batch_and_dense_window(gpu_api, oracle):
+    frames = [synth.sbp_map_frame(40 + i, n_points=n, n_extra_cur=e, th=t) for i, (n, e, t) in enumerate([(300, 50, 1.0), (5, 0, 3.0), (700, 200, 5.0)])]
+    # a dense cluster (> 64 candidates in one window) exercises the re-enumeration path with its second-best bookkeeping
+    p = synth.sbp_map_frame(50, n_points=60, n_extra_cur=0, th=5.0)
+    rng = np.random.default_rng(1)
+    k = p["cur_kps_un"]
+    extra = np.zeros(200, k.dtype)
+    extra["x"] = p["mp_proj"][0, 0] + rng.uniform(-8, 8, 200).astype(np.float32)
+    extra["y"] = p["mp_proj"][0, 1] + rng.uniform(-8, 8, 200).astype(np.float32)
+    extra["octave"] = p["mp_level"][0]
+    frames.append(dict(p, cur_kps_un=np.concatenate([k, extra]), cur_u_right=np.concatenate([p["cur_u_right"], np.full(200, -1, np.float32)]),
+                       cur_desc=np.concatenate([p["cur_desc"], rng.integers(0, 256, (200, 32), dtype=np.uint8)]),
+                       cur_has_mp_obs=np.concatenate([p["cur_has_mp_obs"], np.zeros(200, np.uint8)])))
+    pm = gpu_api.ProjectionMatcher(max_last=1024, max_cur=1536, max_batch=4)
+    for q, (m, n) in zip(frames, pm.SearchByProjectionMap(frames)):
+        mo, no = oracle.search_by_projection_map(q)
+        assert n == no and np.array_equal(m, mo)

@@ -159,3 +159,87 @@ def test_empty_inputs():
               cur_has_mp_obs=np.zeros(0, np.uint8))
     m, n = O.search_by_projection(e2)
     assert n == 0 and len(m) == 0
+
+
+def _bruteforce_map(p):
+    """Python transcription of ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) (src/ORBmatcher.cc:43-206)."""
+    f32 = np.float32
+    kps = p["cur_kps_un"]
+    N = len(kps)
+    gw, gh = f32(p["grid_w_inv"]), f32(p["grid_h_inv"])
+    cell = []
+    for i in range(N):
+        fxv, fyv = float((kps["x"][i] - p["min_x"]) * gw), float((kps["y"][i] - p["min_y"]) * gh)
+        px, py = int(np.floor(abs(fxv) + 0.5) * np.sign(fxv)), int(np.floor(abs(fyv) + 0.5) * np.sign(fyv))
+        cell.append((px, py) if (0 <= px < 64 and 0 <= py < 48) else None)
+    state = np.full(N, -1, np.int64)
+    nm = 0
+    for l in range(len(p["mp_proj"])):
+        level = int(p["mp_level"][l])
+        r = f32(2.5) if float(p["mp_view_cos"][l]) > 0.998 else f32(4.0)
+        if float(p["th"]) != 1.0:
+            r = f32(r * p["th"])
+        x, y, xr = (f32(t) for t in p["mp_proj"][l])
+        rad = f32(r * p["scale_factors"][level])
+        x0 = max(0, int(np.floor(f32(f32(f32(x - p["min_x"]) - rad) * gw))))
+        x1 = min(63, int(np.ceil(f32(f32(f32(x - p["min_x"]) + rad) * gw))))
+        y0 = max(0, int(np.floor(f32(f32(f32(y - p["min_y"]) - rad) * gh))))
+        y1 = min(47, int(np.ceil(f32(f32(f32(y - p["min_y"]) + rad) * gh))))
+        if x0 >= 64 or x1 < 0 or y0 >= 48 or y1 < 0:
+            continue
+        cands = []
+        for i2 in range(N):
+            c = cell[i2]
+            if c is None or not (x0 <= c[0] <= x1 and y0 <= c[1] <= y1):
+                continue
+            if kps["octave"][i2] < level - 1 or kps["octave"][i2] > level:
+                continue
+            if not (abs(f32(kps["x"][i2] - x)) < rad and abs(f32(kps["y"][i2] - y)) < rad):
+                continue
+            cands.append((c[0], c[1], i2))
+        if not cands:
+            continue
+        cands.sort()
+        bd, bl, bd2, bl2, bi = 256, -1, 256, -1, -1
+        for _, _, i2 in cands:
+            if bool(p["cur_has_mp_obs"][i2]) or (state[i2] >= 0 and p["mp_has_obs"][state[i2]]):
+                continue
+            if p["cur_u_right"][i2] > 0 and abs(f32(xr - p["cur_u_right"][i2])) > rad:
+                continue
+            d = _popcnt(p["mp_desc"][l], p["cur_desc"][i2])
+            if d < bd:
+                bd2, bd, bl2, bl, bi = bd, d, bl, int(kps["octave"][i2]), i2
+            elif d < bd2:
+                bl2, bd2 = int(kps["octave"][i2]), d
+        if bd <= 100:
+            if bl == bl2 and f32(bd) > f32(p["nn_ratio"] * f32(bd2)):
+                continue
+            state[bi] = l
+            nm += 1
+    return state.astype(np.int32), nm
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=1, n_points=300, n_extra_cur=80),
+                                 dict(seed=2, n_points=250, n_extra_cur=60, th=3.0, dup_frac=0.3, zero_obs_frac=0.3, preassigned_frac=0.1),
+                                 dict(seed=3, n_points=250, n_extra_cur=60, th=5.0, nn_ratio=0.6, desc_flip_bits=80)])
+def test_map_variant_matches_python_transcription(cfg):
+    p = synth.sbp_map_frame(**cfg)
+    m, n = O.search_by_projection_map(p)
+    mb, nb = _bruteforce_map(p)
+    assert n == nb and np.array_equal(m, mb)
+
+
+def test_map_variant_ratio_test_rejects_ambiguous_matches():
+    """A twin key-point (same level, almost the same descriptor) next to every key-point makes best and second best
+    comparable: with a strict mfNNratio the match is dropped (bestDist > mfNNratio * bestDist2), with ratio 1 it is kept."""
+    p = synth.sbp_map_frame(4, n_points=200, n_extra_cur=0, th=5.0)
+    k = p["cur_kps_un"]
+    twin = k.copy()
+    twin["x"] += np.float32(0.5)
+    d2 = p["cur_desc"].copy()
+    d2[:, 0] ^= 1  # one bit away from the original
+    q = dict(p, cur_kps_un=np.concatenate([k, twin]), cur_u_right=np.concatenate([p["cur_u_right"]] * 2),
+             cur_desc=np.concatenate([p["cur_desc"], d2]), cur_has_mp_obs=np.concatenate([p["cur_has_mp_obs"]] * 2))
+    _, n_loose = O.search_by_projection_map(dict(q, nn_ratio=np.float32(1.0)))
+    _, n_tight = O.search_by_projection_map(dict(q, nn_ratio=np.float32(0.3)))
+    assert n_loose > 50 and n_tight < n_loose // 4
