@@ -28,6 +28,15 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kMaxFree = 30;
 
+// LM bookkeeping of the multi-kernel path, resident in HBM (the scalar logic of OptimizationAlgorithmLevenberg::solve)
+struct LbaState {
+  double lambda, ni, current_chi, ini_chi, temp_chi, rho, last_chi;
+  int cur;                       // which of the two estimate buffers holds the accepted state
+  int qmax, n_bad, iters;
+  int solve_ok;                  // LinearSolver succeeded in the current trial
+  int again, terminate;          // outputs of k_lba_decide for the host loop
+};
+
 struct LbaDev {
   // problem (edges landmark-major)
   int n_poses, n_points, n_edges, n_free;
@@ -68,6 +77,13 @@ struct LbaDev {
   int* out_info;       // [0]=iterations_run [1]=failed flag
   double* out_stats;   // [0]=final chi2 [1]=final lambda
   int mode;            // 0 = full solve, 1 = linearise only
+  // multi-kernel path (one launch per phase, all CUs): LM state, per-block partial sums, the reduced system in HBM
+  struct LbaState* S;
+  double* part_chi;    // [n_err_blocks] robust chi2 partial sums of the last k_lba_errors
+  double* part_scale;  // [n_upd_blocks] computeScale partial sums of the last k_lba_update
+  double* Hs;          // packed lower triangle of the Schur complement (6 n_free)^2 / 2
+  double* bs;          // [6 n_free]
+  int n_err_blocks, n_upd_blocks;
 };
 
 using namespace gfs_se3;
@@ -509,12 +525,409 @@ __global__ __launch_bounds__(kThreads) void k_lba(LbaDev D) {
   }
 }
 
-template <typename T>
-int upload(gfs::DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
-  if (h.empty()) return GFS_OK;
-  GFS_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
-  return GFS_OK;
+// ================================================================================================
+// Multi-kernel path: the same algorithm, one launch per phase so that every phase uses the whole chip instead of one
+// CU (the single-workgroup kernel above is latency-bound: 61 ms for the C5 window).  The scalar LM logic lives in
+// LbaState (HBM) and runs in k_lba_begin / k_lba_decide; the host only enqueues the phases and reads two flags per trial.
+// The two estimate buffers (q/t/X and q_try/t_try/X_try) swap roles when a step is accepted (S->cur).
+// ================================================================================================
+constexpr int kMk = 256;  // threads per workgroup of the wide kernels
+
+__device__ __forceinline__ double* sel(double* a, double* b, int which) { return which ? b : a; }
+
+// deterministic 256-thread block sum: wave shuffle tree, then the four waves in order; result in every thread
+__device__ double block_sum256(double v, double* s4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_down(v, ofs, 64);
+  __syncthreads();
+  if (lane == 0) s4[wave] = v;
+  __syncthreads();
+  return ((s4[0] + s4[1]) + s4[2]) + s4[3];
 }
+
+__global__ __launch_bounds__(kMk) void k_lba_init(LbaDev D) {
+  const int g = blockIdx.x * kMk + threadIdx.x, G = gridDim.x * kMk;
+  for (int i = g; i < D.n_poses; i += G) {
+    double q[4] = {D.pose_q0[4 * i], D.pose_q0[4 * i + 1], D.pose_q0[4 * i + 2], D.pose_q0[4 * i + 3]};
+    normalize_rotation(q);
+    for (int k = 0; k < 4; k++) D.q[4 * i + k] = D.q_try[4 * i + k] = q[k];
+    for (int k = 0; k < 3; k++) D.t[3 * i + k] = D.t_try[3 * i + k] = D.pose_t0[3 * i + k];
+  }
+  for (int i = g; i < 3 * D.n_points; i += G) D.X[i] = D.X_try[i] = D.points0[i];
+  if (g == 0) {
+    LbaState& S = *D.S;
+    S.lambda = -1;
+    S.ni = 2;
+    S.current_chi = S.ini_chi = S.temp_chi = S.rho = S.last_chi = 0;
+    S.cur = 0;
+    S.qmax = S.n_bad = S.iters = 0;
+    S.solve_ok = 1;
+    S.again = S.terminate = 0;
+  }
+}
+
+// computeActiveErrors on the accepted (trial = 0) or the trial estimate (trial = 1; falls back to the accepted one when the
+// linear solve failed, like the reference which restores the estimate before recomputing the errors)
+__global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial) {
+  __shared__ double s4[4];
+  const LbaState& S = *D.S;
+  const int which = (trial && S.solve_ok) ? (S.cur ^ 1) : S.cur;
+  const double *q = sel(D.q, D.q_try, which), *t = sel(D.t, D.t_try, which), *X = sel(D.X, D.X_try, which);
+  double local = 0;
+  const int e = blockIdx.x * kMk + threadIdx.x;
+  if (e < D.n_edges) {
+    double xc[3], r[3];
+    edge_residual(D, e, q, t, X, xc, r);
+    const double c = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * D.e_w[e];
+    D.chi2[e] = c;
+    D.err[3 * e] = r[0];
+    D.err[3 * e + 1] = r[1];
+    D.err[3 * e + 2] = r[2];
+    double r0, r1;
+    huber(c, D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+    local = r0;
+  }
+  const double tot = block_sum256(local, s4);
+  if (threadIdx.x == 0) D.part_chi[blockIdx.x] = tot;
+}
+
+// buildSystem, landmark side: Hll, bl and the per-edge pose-landmark blocks (one thread per landmark)
+__global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) {
+  const LbaState& S = *D.S;
+  const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
+  const int l = blockIdx.x * 128 + threadIdx.x;
+  if (l >= D.n_points) return;
+  double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
+    double xc[3], r[3], Ji[9], Jj[18];
+    edge_residual(D, e, q, t, X, xc, r);
+    edge_jacobians(D, e, q, xc, Ji, Jj);
+    double r0, r1;
+    huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+    const double w = r1 * D.e_w[e];
+    double omr[3];
+    for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
+    int o = 0;
+    for (int a = 0; a < 3; a++) {
+      b[a] += Ji[a] * omr[0] + Ji[3 + a] * omr[1] + Ji[6 + a] * omr[2];
+      for (int c = a; c < 3; c++) H[o++] += Ji[a] * w * Ji[c] + Ji[3 + a] * w * Ji[3 + c] + Ji[6 + a] * w * Ji[6 + c];
+    }
+    if (D.free_index[D.e_pose[e]] >= 0) {
+      double* B = D.Hpl + 18 * (size_t)e;
+      for (int a = 0; a < 6; a++)
+        for (int c = 0; c < 3; c++) B[3 * a + c] = Jj[a] * w * Ji[c] + Jj[6 + a] * w * Ji[3 + c] + Jj[12 + a] * w * Ji[6 + c];
+    }
+  }
+  for (int k = 0; k < 6; k++) D.Hll[6 * (size_t)l + k] = H[k];
+  for (int k = 0; k < 3; k++) D.bl[3 * (size_t)l + k] = b[k];
+}
+
+// buildSystem, pose side: one workgroup per free pose, threads over its edges, fixed-order reduction
+__global__ __launch_bounds__(kMk) void k_lba_build_poses(LbaDev D) {
+  __shared__ double s4[4];
+  const LbaState& S = *D.S;
+  const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
+  const int f = blockIdx.x;
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = 0;
+  for (int i = D.pose_begin[f] + threadIdx.x; i < D.pose_begin[f + 1]; i += kMk) {
+    const int e = D.pose_edges[i];
+    double xc[3], r[3], Ji[9], Jj[18];
+    edge_residual(D, e, q, t, X, xc, r);
+    edge_jacobians(D, e, q, xc, Ji, Jj);
+    double r0, r1;
+    huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+    const double w = r1 * D.e_w[e];
+    double omr[3];
+    for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = a; c < 6; c++) acc[o++] += Jj[a] * w * Jj[c] + Jj[6 + a] * w * Jj[6 + c] + Jj[12 + a] * w * Jj[12 + c];
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * omr[0] + Jj[6 + a] * omr[1] + Jj[12 + a] * omr[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 27; k++) {
+    const double v = block_sum256(acc[k], s4);
+    if (threadIdx.x == 0) {
+      if (k < 21)
+        D.Hpp[21 * f + k] = v;
+      else
+        D.bp[6 * f + (k - 21)] = v;
+    }
+  }
+}
+
+// start of an LM iteration: currentChi, and at iteration 0 computeLambdaInit (tau * max |diag H|)
+__global__ __launch_bounds__(kThreads) void k_lba_begin(LbaDev D, int iteration) {
+  __shared__ double s16[16];
+  LbaState& S = *D.S;
+  double chi = 0;
+  if (threadIdx.x == 0)
+    for (int b = 0; b < D.n_err_blocks; b++) chi += D.part_chi[b];
+  if (iteration == 0) {
+    double mx = 0;
+    for (int i = threadIdx.x; i < D.n_free * 6; i += kThreads) {
+      const int f = i / 6, a = i % 6;
+      mx = fmax(mx, fabs(D.Hpp[21 * f + (a * 6 - a * (a - 1) / 2)]));
+    }
+    for (int i = threadIdx.x; i < D.n_points * 3; i += kThreads) {
+      const int l = i / 3, a = i % 3;
+      mx = fmax(mx, fabs(D.Hll[6 * (size_t)l + (a == 0 ? 0 : a == 1 ? 3 : 5)]));
+    }
+    mx = block_max(mx, s16);
+    if (threadIdx.x == 0) {
+      S.lambda = 1e-5 * mx;
+      S.ni = 2;
+      S.n_bad = 0;
+    }
+  }
+  if (threadIdx.x == 0) {
+    S.current_chi = S.ini_chi = chi;
+    S.rho = 0;
+    S.qmax = 0;
+    S.again = 0;
+  }
+}
+
+__global__ __launch_bounds__(kMk) void k_lba_dinv(LbaDev D) {
+  const int l = blockIdx.x * kMk + threadIdx.x;
+  if (l < D.n_points) inv3_sym(D.Hll + 6 * (size_t)l, D.S->lambda, D.Dinv + 6 * (size_t)l);
+}
+
+// Schur complement, one workgroup per pose pair (i1 >= i2): Hs(i1,i2) = [i1==i2](Hpp + lambda I) - sum_l B_i1 Dinv_l B_i2^T
+__global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) {
+  __shared__ double s4[4];
+  const double lambda = D.S->lambda;
+  const int pr = blockIdx.x;
+  int i1 = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+  while (i1 * (i1 + 1) / 2 > pr) i1--;
+  while ((i1 + 1) * (i1 + 2) / 2 <= pr) i1++;
+  const int i2 = pr - i1 * (i1 + 1) / 2;
+  double acc[36], accb[6];
+#pragma unroll
+  for (int k = 0; k < 36; k++) acc[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) accb[k] = 0;
+  const int* eo = D.edge_of + (size_t)i2 * D.n_points;
+  for (int i = D.pose_begin[i1] + threadIdx.x; i < D.pose_begin[i1 + 1]; i += kMk) {
+    const int e1 = D.pose_edges[i];
+    const int l = D.e_point[e1];
+    const int e2 = eo[l];
+    if (e2 < 0) continue;
+    const double* Bi = D.Hpl + 18 * (size_t)e1;
+    const double* Bj = D.Hpl + 18 * (size_t)e2;
+    const double* Di = D.Dinv + 6 * (size_t)l;
+    const double d9[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
+    double BD[18];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) BD[3 * a + c] = Bi[3 * a] * d9[c] + Bi[3 * a + 1] * d9[3 + c] + Bi[3 * a + 2] * d9[6 + c];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) acc[6 * a + c] += BD[3 * a] * Bj[3 * c] + BD[3 * a + 1] * Bj[3 * c + 1] + BD[3 * a + 2] * Bj[3 * c + 2];
+    if (i1 == i2) {
+      const double* bl = D.bl + 3 * (size_t)l;
+#pragma unroll
+      for (int a = 0; a < 6; a++) accb[a] += BD[3 * a] * bl[0] + BD[3 * a + 1] * bl[1] + BD[3 * a + 2] * bl[2];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 36; k++) {
+    const double v = block_sum256(acc[k], s4);
+    if (threadIdx.x == 0) {
+      const int a = k / 6, c = k % 6;
+      if (i1 != i2) {
+        D.Hs[tri(6 * i1 + a, 6 * i2 + c)] = -v;
+      } else if (a >= c) {
+        const int ua = c, uc = a;  // Hpp upper-triangle index of (c, a)
+        const double hpp = D.Hpp[21 * i1 + (ua * 6 - ua * (ua - 1) / 2 + (uc - ua))];
+        D.Hs[tri(6 * i1 + a, 6 * i1 + c)] = hpp + (a == c ? lambda : 0.0) - v;
+      }
+    }
+  }
+  if (i1 == i2) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double v = block_sum256(accb[k], s4);
+      if (threadIdx.x == 0) D.bs[6 * i1 + k] = D.bp[6 * i1 + k] - v;
+    }
+  }
+}
+
+// LDL^T + triangular solves of the reduced pose system in LDS (single workgroup: n <= 180)
+__global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
+  extern __shared__ __align__(16) double lds[];
+  __shared__ int s_flag;
+  const int n = 6 * D.n_free;
+  double* Hs = lds;
+  double* bs = lds + (size_t)n * (n + 1) / 2;
+  for (int k = threadIdx.x; k < n * (n + 1) / 2; k += kThreads) Hs[k] = D.Hs[k];
+  for (int k = threadIdx.x; k < n; k += kThreads) bs[k] = D.bs[k];
+  if (threadIdx.x == 0) s_flag = 0;
+  __syncthreads();
+  bool ok = true;
+  for (int j = 0; j < n && ok; j++) {
+    const double d = Hs[tri(j, j)];
+    if (threadIdx.x == 0 && (d == 0.0 || !isfinite(d))) s_flag = 1;
+    __syncthreads();
+    if (s_flag) {
+      ok = false;
+      break;
+    }
+    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) Hs[tri(i, j)] /= d;
+    __syncthreads();
+    const int m = n - j - 1;
+    for (int k = threadIdx.x; k < m * (m + 1) / 2; k += kThreads) {
+      int r = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
+      while (r * (r + 1) / 2 > k) r--;
+      while ((r + 1) * (r + 2) / 2 <= k) r++;
+      const int c = k - r * (r + 1) / 2;
+      const int ii = j + 1 + r, kk = j + 1 + c;
+      Hs[tri(ii, kk)] -= Hs[tri(ii, j)] * Hs[tri(kk, j)] * d;
+    }
+    __syncthreads();
+  }
+  if (ok) {
+    for (int j = 0; j < n; j++) {
+      const double xj = bs[j];
+      for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) bs[i] -= Hs[tri(i, j)] * xj;
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += kThreads) bs[i] /= Hs[tri(i, i)];
+    __syncthreads();
+    for (int j = n - 1; j >= 0; j--) {
+      const double xj = bs[j];
+      for (int i = threadIdx.x; i < j; i += kThreads) bs[i] -= Hs[tri(j, i)] * xj;
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += kThreads) D.xp[i] = bs[i];
+  }
+  if (threadIdx.x == 0) D.S->solve_ok = ok ? 1 : 0;
+}
+
+// landmark back-substitution, update of the trial estimate, computeScale partial sums
+__global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D) {
+  __shared__ double s4[4];
+  const LbaState& S = *D.S;
+  double loc = 0;
+  if (S.solve_ok) {
+    const int cur = S.cur;
+    const double *q = sel(D.q, D.q_try, cur), *t = sel(D.t, D.t_try, cur), *X = sel(D.X, D.X_try, cur);
+    double *qn = sel(D.q, D.q_try, cur ^ 1), *tn = sel(D.t, D.t_try, cur ^ 1), *Xn = sel(D.X, D.X_try, cur ^ 1);
+    const double lambda = S.lambda;
+    const int l = blockIdx.x * kMk + threadIdx.x;
+    if (l < D.n_points) {
+      double cl[3] = {D.bl[3 * (size_t)l], D.bl[3 * (size_t)l + 1], D.bl[3 * (size_t)l + 2]};
+      for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
+        const int f = D.free_index[D.e_pose[e]];
+        if (f < 0) continue;
+        const double* B = D.Hpl + 18 * (size_t)e;
+        for (int c = 0; c < 3; c++)
+          for (int a = 0; a < 6; a++) cl[c] -= B[3 * a + c] * D.xp[6 * f + a];
+      }
+      const double* Di = D.Dinv + 6 * (size_t)l;
+      const double xl[3] = {Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2], Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2],
+                            Di[2] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2]};
+      for (int c = 0; c < 3; c++) {
+        D.xl[3 * (size_t)l + c] = xl[c];
+        Xn[3 * (size_t)l + c] = X[3 * (size_t)l + c] + xl[c];
+        loc += xl[c] * (lambda * xl[c] + D.bl[3 * (size_t)l + c]);
+      }
+    }
+    if (blockIdx.x == 0) {
+      for (int f = threadIdx.x; f < D.n_free; f += kMk) {
+        const int p = D.free_pose[f];
+        pose_oplus(q + 4 * p, t + 3 * p, D.xp + 6 * f, qn + 4 * p, tn + 3 * p);
+        for (int a = 0; a < 6; a++) loc += D.xp[6 * f + a] * (lambda * D.xp[6 * f + a] + D.bp[6 * f + a]);
+      }
+    }
+  }
+  const double tot = block_sum256(loc, s4);
+  if (threadIdx.x == 0) D.part_scale[blockIdx.x] = tot;
+}
+
+// end of an LM trial (and, when the trial loop ends, of the iteration): rho test, lambda update, termination tests
+__global__ void k_lba_decide(LbaDev D, int force_end, int* __restrict__ host_flags) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  LbaState& S = *D.S;
+  if (!force_end) {
+    double temp_chi = 0, scale = 0;
+    for (int b = 0; b < D.n_err_blocks; b++) temp_chi += D.part_chi[b];
+    for (int b = 0; b < D.n_upd_blocks; b++) scale += D.part_scale[b];
+    if (!S.solve_ok) {
+      temp_chi = 1.79769313486231570e308;
+      scale = 0;
+    }
+    S.temp_chi = temp_chi;
+    S.rho = (S.current_chi - temp_chi) / (scale + 1e-3);
+    if (S.rho > 0 && isfinite(temp_chi)) {
+      double alpha = 1. - pow((2 * S.rho - 1), 3.0);
+      alpha = fmin(alpha, 2. / 3.);
+      S.lambda *= fmax(1. / 3., alpha);
+      S.ni = 2;
+      S.current_chi = temp_chi;
+      S.cur ^= 1;  // discardTop: the trial becomes the estimate
+    } else {
+      S.lambda *= S.ni;
+      S.ni *= 2;
+    }
+    S.qmax++;
+    S.again = (S.rho < 0 && S.qmax < 10) ? 1 : 0;
+  } else {
+    S.again = 0;  // the stop flag ended the trial loop
+  }
+  S.terminate = 0;
+  if (!S.again) {
+    S.iters++;
+    S.last_chi = S.current_chi;
+    if (S.qmax == 10 || S.rho == 0) {
+      S.terminate = 1;
+    } else {
+      if ((S.ini_chi - S.current_chi) * 1e3 < S.ini_chi)
+        S.n_bad++;
+      else
+        S.n_bad = 0;
+      if (S.n_bad >= 3) S.terminate = 1;
+    }
+  }
+  host_flags[0] = S.again;
+  host_flags[1] = S.terminate;
+  host_flags[2] = S.cur;
+  host_flags[3] = S.iters;
+}
+
+__global__ void k_lba_finish(LbaDev D) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const LbaState& S = *D.S;
+  D.out_info[0] = S.iters;
+  D.out_info[1] = S.cur;
+  D.out_stats[0] = D.mode == 1 ? S.current_chi : S.last_chi;
+  D.out_stats[1] = D.mode == 1 ? 0.0 : S.lambda;
+}
+
+// host -> device through the pinned arena (bump allocation; the arena outlives the asynchronous copies of one call)
+struct Stager {
+  unsigned char* base;
+  size_t cap, used = 0;
+  hipStream_t s;
+  template <typename T>
+  int put(T* dev, const T* host, size_t count) {
+    if (count == 0) return GFS_OK;
+    const size_t bytes = count * sizeof(T), at = (used + 63) & ~(size_t)63;
+    GFS_REQUIRE(at + bytes <= cap, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
+    memcpy(base + at, host, bytes);
+    used = at + bytes;
+    GFS_HIP(hipMemcpyAsync(dev, base + at, bytes, hipMemcpyHostToDevice, s));
+    return GFS_OK;
+  }
+};
 
 }  // namespace
 
@@ -523,6 +936,11 @@ struct gfs_lba {
   hipStream_t stream;
   std::mutex mu;
   int* h_stop = nullptr;  // host-mapped
+  int* h_flags = nullptr;  // host-mapped: {again, terminate, cur, iters} written by k_lba_decide
+  int final_cur = 0;       // estimate buffer holding the result of the last solve
+  gfs::DevBuf<LbaState> d_state;
+  gfs::PinBuf<unsigned char> h_stage;  // pinned staging arena for the problem upload (pageable copies cost ~2 ms each)
+  gfs::DevBuf<double> d_part_chi, d_part_scale, d_Hs, d_bs;
   gfs::DevBuf<double> d_q0, d_t0, d_X0, d_obs, d_w, d_q, d_t, d_X, d_qt, d_tt, d_Xt, d_chi2, d_err, d_Hpl, d_Hll, d_bl, d_Dinv,
       d_Hpp, d_bp, d_xl, d_xp, d_stats;
   gfs::DevBuf<int> d_free_index, d_free_pose, d_e_pose, d_e_point, d_pt_begin, d_pose_begin, d_pose_edges, d_edge_of, d_info;
@@ -605,16 +1023,16 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   hipStream_t s = h->stream;
   const int E = p->n_edges, NP = p->n_points;
   int rc;
-  if (p->n_poses) {
-    GFS_HIP(hipMemcpyAsync(h->d_q0.p, p->pose_q, (size_t)p->n_poses * 32, hipMemcpyHostToDevice, s));
-    GFS_HIP(hipMemcpyAsync(h->d_t0.p, p->pose_t, (size_t)p->n_poses * 24, hipMemcpyHostToDevice, s));
-  }
-  if (NP) GFS_HIP(hipMemcpyAsync(h->d_X0.p, p->points, (size_t)NP * 24, hipMemcpyHostToDevice, s));
-  if ((rc = upload(h->d_free_index, P.free_index, s)) || (rc = upload(h->d_free_pose, P.free_pose, s)) ||
-      (rc = upload(h->d_e_pose, P.e_pose, s)) || (rc = upload(h->d_e_point, P.e_point, s)) || (rc = upload(h->d_obs, P.obs, s)) ||
-      (rc = upload(h->d_w, P.w, s)) || (rc = upload(h->d_stereo, P.stereo, s)) || (rc = upload(h->d_pt_begin, P.pt_begin, s)) ||
-      (rc = upload(h->d_pose_begin, P.pose_begin, s)) || (rc = upload(h->d_pose_edges, P.pose_edges, s)) ||
-      (rc = upload(h->d_edge_of, P.edge_of, s)))
+  Stager st{h->h_stage.p, h->h_stage.n, 0, s};
+  if ((rc = st.put(h->d_q0.p, p->pose_q, (size_t)p->n_poses * 4)) || (rc = st.put(h->d_t0.p, p->pose_t, (size_t)p->n_poses * 3)) ||
+      (rc = st.put(h->d_X0.p, p->points, (size_t)NP * 3)) || (rc = st.put(h->d_free_index.p, P.free_index.data(), P.free_index.size())) ||
+      (rc = st.put(h->d_free_pose.p, P.free_pose.data(), P.free_pose.size())) || (rc = st.put(h->d_e_pose.p, P.e_pose.data(), P.e_pose.size())) ||
+      (rc = st.put(h->d_e_point.p, P.e_point.data(), P.e_point.size())) || (rc = st.put(h->d_obs.p, P.obs.data(), P.obs.size())) ||
+      (rc = st.put(h->d_w.p, P.w.data(), P.w.size())) || (rc = st.put(h->d_stereo.p, P.stereo.data(), P.stereo.size())) ||
+      (rc = st.put(h->d_pt_begin.p, P.pt_begin.data(), P.pt_begin.size())) ||
+      (rc = st.put(h->d_pose_begin.p, P.pose_begin.data(), P.pose_begin.size())) ||
+      (rc = st.put(h->d_pose_edges.p, P.pose_edges.data(), P.pose_edges.size())) ||
+      (rc = st.put(h->d_edge_of.p, P.edge_of.data(), P.edge_of.size())))
     return rc;
   if (E) GFS_HIP(hipMemsetAsync(h->d_Hpl.p, 0, (size_t)E * 18 * sizeof(double), s));
   LbaDev D{};
@@ -669,16 +1087,87 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   D.mode = mode;
   const int n = 6 * P.n_free;
   const size_t lds = ((size_t)n * (n + 1) / 2 + n + 8) * sizeof(double);
-  GFS_HIP(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  GFS_LAUNCH("k_lba", k_lba, dim3(1), dim3(kThreads), lds, s, D);
-  // setForceStopFlag semantics (src/Optimizer.cc:1679): relay the caller's flag to the device-visible one
-  if (stop) {
-    while (hipStreamQuery(s) == hipErrorNotReady) {
-      if (*stop) *h->h_stop = 1;
-      std::this_thread::sleep_for(std::chrono::microseconds(50));
+  static const bool single_wg = getenv("GFS_LBA_SINGLE_WG") != nullptr;  // the round-1a kernel: whole solve in one workgroup
+  h->final_cur = 0;
+  if (single_wg) {
+    GFS_HIP(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GFS_LAUNCH("k_lba", k_lba, dim3(1), dim3(kThreads), lds, s, D);
+    // setForceStopFlag semantics (src/Optimizer.cc:1679): relay the caller's flag to the device-visible one
+    if (stop) {
+      while (hipStreamQuery(s) == hipErrorNotReady) {
+        if (*stop) *h->h_stop = 1;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
     }
+    GFS_HIP(hipStreamSynchronize(s));
+    return GFS_OK;
   }
+  // ---- multi-kernel path: one launch per phase, the host walks the LM control flow from two flags per trial
+  static const bool timing = getenv("GFS_LBA_TIMING") != nullptr;
+  if (timing) GFS_HIP(hipStreamSynchronize(s));
+  const auto Ta = std::chrono::steady_clock::now();
+  D.S = h->d_state.p;
+  D.part_chi = h->d_part_chi.p;
+  D.part_scale = h->d_part_scale.p;
+  D.Hs = h->d_Hs.p;
+  D.bs = h->d_bs.p;
+  D.n_err_blocks = gfs::div_up(std::max(E, 1), kMk);
+  D.n_upd_blocks = gfs::div_up(std::max(NP, 1), kMk);
+  int* d_flags = nullptr;
+  GFS_HIP(hipHostGetDevicePointer((void**)&d_flags, h->h_flags, 0));
+  GFS_HIP(hipFuncSetAttribute((const void*)k_lba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 128)), g_upd(D.n_upd_blocks);
+  GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
+  const bool lin_only = mode == 1 || p->iterations <= 0;
+  if (lin_only) {
+    GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
+    if (mode == 1) {
+      GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(128), 0, s, D);
+      if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kMk), 0, s, D);
+    }
+    GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, 1);
+    LbaDev Df = D;
+    Df.mode = 1;
+    GFS_LAUNCH("k_lba_finish", k_lba_finish, dim3(1), dim3(64), 0, s, Df);
+    GFS_HIP(hipStreamSynchronize(s));
+    return GFS_OK;
+  }
+  const int npairs = P.n_free * (P.n_free + 1) / 2;
+  for (int iteration = 0; iteration < p->iterations; iteration++) {
+    if (stop && *stop) break;  // SparseOptimizer::terminate() at the top of the iteration
+    GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
+    GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(128), 0, s, D);
+    if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kMk), 0, s, D);
+    GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, iteration);
+    bool terminate = false;
+    for (;;) {
+      GFS_LAUNCH("k_lba_dinv", k_lba_dinv, g_upd, dim3(kMk), 0, s, D);
+      if (npairs > 0) GFS_LAUNCH("k_lba_schur", k_lba_schur, dim3(npairs), dim3(kMk), 0, s, D);
+      GFS_LAUNCH("k_lba_solve", k_lba_solve, dim3(1), dim3(kThreads), lds, s, D);
+      GFS_LAUNCH("k_lba_update", k_lba_update, g_upd, dim3(kMk), 0, s, D);
+      GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 1);
+      GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 0, d_flags);
+      GFS_HIP(hipStreamSynchronize(s));
+      const bool again = h->h_flags[0] != 0;
+      terminate = h->h_flags[1] != 0;
+      if (!again) break;
+      if (stop && *stop) {  // the stop flag ends the trial loop: close the iteration's bookkeeping on the device
+        GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 1, d_flags);
+        GFS_HIP(hipStreamSynchronize(s));
+        terminate = h->h_flags[1] != 0;
+        break;
+      }
+    }
+    if (terminate) break;
+  }
+  GFS_LAUNCH("k_lba_finish", k_lba_finish, dim3(1), dim3(64), 0, s, D);
   GFS_HIP(hipStreamSynchronize(s));
+  if (timing) fprintf(stderr, "  run: LM loop %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - Ta).count());
+  {
+    int info[2] = {0, 0};
+    GFS_HIP(hipMemcpy(info, h->d_info.p, sizeof(info), hipMemcpyDeviceToHost));
+    h->final_cur = info[1];
+  }
   return GFS_OK;
 }
 
@@ -697,6 +1186,7 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   h->max_edges = max_edges;
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   GFS_HIP(hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped));
+  GFS_HIP(hipHostMalloc((void**)&h->h_flags, 4 * sizeof(int), hipHostMallocMapped));
   const size_t NP = max_points, E = max_edges, NQ = max_poses, F = kMaxFree;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
@@ -732,6 +1222,12 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   A(h->d_edge_of.alloc(F * NP));
   A(h->d_info.alloc(2));
   A(h->d_stereo.alloc(E));
+  A(h->d_state.alloc(1));
+  A(h->h_stage.alloc(NQ * (32 + 24 + 4) + NP * (24 + 4) + E * (4 + 4 + 24 + 8 + 1 + 4) + F * (4 + 4 + NP * 4) + 4096));
+  A(h->d_part_chi.alloc(E / kMk + 2));
+  A(h->d_part_scale.alloc(NP / kMk + 2));
+  A(h->d_Hs.alloc((size_t)(6 * F) * (6 * F + 1) / 2 + 8));
+  A(h->d_bs.alloc(6 * F + 8));
 #undef A
   if (rc) return rc;
   *out = h.release();
@@ -744,6 +1240,7 @@ void gfs_lba_destroy(gfs_lba* h) {
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamDestroy(h->stream);
   if (h->h_stop) (void)hipHostFree(h->h_stop);
+  if (h->h_flags) (void)hipHostFree(h->h_flags);
   delete h;
 }
 
@@ -755,28 +1252,50 @@ int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, v
   }
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
+  static const bool timing = getenv("GFS_LBA_TIMING") != nullptr;
+  const auto T0 = std::chrono::steady_clock::now();
   HostPrep P;
   int rc = prepare(h, p, P);
   if (rc) return rc;
+  const auto T1 = std::chrono::steady_clock::now();
   rc = run(h, p, P, 0, stop);
   if (rc) return rc;
+  const auto T2 = std::chrono::steady_clock::now();
+  if (timing)
+    fprintf(stderr, "gfs_lba_solve: prepare %.2f ms, upload + solve %.2f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(),
+            std::chrono::duration<double, std::milli>(T2 - T1).count());
   hipStream_t s = h->stream;
   const int E = p->n_edges, NP = p->n_points;
-  if (p->n_poses && sol->pose_q) GFS_HIP(hipMemcpyAsync(sol->pose_q, h->d_q.p, (size_t)p->n_poses * 32, hipMemcpyDeviceToHost, s));
-  if (p->n_poses && sol->pose_t) GFS_HIP(hipMemcpyAsync(sol->pose_t, h->d_t.p, (size_t)p->n_poses * 24, hipMemcpyDeviceToHost, s));
-  if (NP && sol->points) GFS_HIP(hipMemcpyAsync(sol->points, h->d_X.p, (size_t)NP * 24, hipMemcpyDeviceToHost, s));
-  std::vector<double> chi(E), q((size_t)p->n_poses * 4), t((size_t)p->n_poses * 3), X((size_t)NP * 3);
-  int info[2] = {0, 0};
-  double stats[2] = {0, 0};
-  if (E) GFS_HIP(hipMemcpyAsync(chi.data(), h->d_chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
+  const double* rq = h->final_cur ? h->d_qt.p : h->d_q.p;  // the accepted estimate (the two buffers swap roles)
+  const double* rt = h->final_cur ? h->d_tt.p : h->d_t.p;
+  const double* rX = h->final_cur ? h->d_Xt.p : h->d_X.p;
+  // results come back through the pinned arena too (the uploads of this call have completed)
+  unsigned char* base = h->h_stage.p;
+  size_t at = 0;
+  auto take = [&](size_t bytes) {
+    unsigned char* r = base + at;
+    at = (at + bytes + 63) & ~(size_t)63;
+    return r;
+  };
+  double* chi = (double*)take((size_t)E * 8);
+  double* q = (double*)take((size_t)p->n_poses * 32);
+  double* t = (double*)take((size_t)p->n_poses * 24);
+  double* X = (double*)take((size_t)NP * 24);
+  int* info = (int*)take(2 * sizeof(int));
+  double* stats = (double*)take(2 * sizeof(double));
+  GFS_REQUIRE(at <= h->h_stage.n, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
+  if (E) GFS_HIP(hipMemcpyAsync(chi, h->d_chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
   if (p->n_poses) {
-    GFS_HIP(hipMemcpyAsync(q.data(), h->d_q.p, q.size() * 8, hipMemcpyDeviceToHost, s));
-    GFS_HIP(hipMemcpyAsync(t.data(), h->d_t.p, t.size() * 8, hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(q, rq, (size_t)p->n_poses * 32, hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(t, rt, (size_t)p->n_poses * 24, hipMemcpyDeviceToHost, s));
   }
-  if (NP) GFS_HIP(hipMemcpyAsync(X.data(), h->d_X.p, X.size() * 8, hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(info, h->d_info.p, sizeof(info), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(stats, h->d_stats.p, sizeof(stats), hipMemcpyDeviceToHost, s));
+  if (NP) GFS_HIP(hipMemcpyAsync(X, rX, (size_t)NP * 24, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(info, h->d_info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(stats, h->d_stats.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
+  if (p->n_poses && sol->pose_q) memcpy(sol->pose_q, q, (size_t)p->n_poses * 32);
+  if (p->n_poses && sol->pose_t) memcpy(sol->pose_t, t, (size_t)p->n_poses * 24);
+  if (NP && sol->points) memcpy(sol->points, X, (size_t)NP * 24);
   for (int k = 0; k < E; k++) {
     const int e = P.order[k];
     if (sol->edge_chi2) sol->edge_chi2[e] = chi[k];
