@@ -772,39 +772,78 @@ __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
   for (int k = threadIdx.x; k < n; k += kThreads) bs[k] = D.bs[k];
   if (threadIdx.x == 0) s_flag = 0;
   __syncthreads();
+  // LDL^T by 6-wide block columns (n = 6 n_free): every entry sees the same subtraction sequence as in the column-by-column
+  // form, but a block step costs 3 barriers instead of 18:
+  //   (a) the 6x6 diagonal block is factored by one lane, (b) every row below solves its 6 entries against it (rows are
+  //   independent), (c) the trailing triangle takes the rank-6 update.
   bool ok = true;
-  for (int j = 0; j < n && ok; j++) {
-    const double d = Hs[tri(j, j)];
-    if (threadIdx.x == 0 && (d == 0.0 || !isfinite(d))) s_flag = 1;
+  for (int jb = 0; jb < n && ok; jb += 6) {
+    if (threadIdx.x == 0) {
+      for (int c = 0; c < 6; c++) {
+        const int j = jb + c;
+        const double d = Hs[tri(j, j)];
+        if (d == 0.0 || !isfinite(d)) {
+          s_flag = 1;
+          break;
+        }
+        for (int i = j + 1; i < jb + 6; i++) Hs[tri(i, j)] /= d;
+        for (int k = j + 1; k < jb + 6; k++)
+          for (int i = k; i < jb + 6; i++) Hs[tri(i, k)] -= Hs[tri(i, j)] * Hs[tri(k, j)] * d;
+      }
+    }
     __syncthreads();
     if (s_flag) {
       ok = false;
       break;
     }
-    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) Hs[tri(i, j)] /= d;
+    for (int i = jb + 6 + threadIdx.x; i < n; i += kThreads) {  // (b) panel rows
+      for (int c = 0; c < 6; c++) {
+        double v = Hs[tri(i, jb + c)];
+        for (int c2 = 0; c2 < c; c2++) v -= Hs[tri(i, jb + c2)] * Hs[tri(jb + c, jb + c2)] * Hs[tri(jb + c2, jb + c2)];
+        Hs[tri(i, jb + c)] = v / Hs[tri(jb + c, jb + c)];
+      }
+    }
     __syncthreads();
-    const int m = n - j - 1;
+    const int m = n - jb - 6;  // (c) trailing size
     for (int k = threadIdx.x; k < m * (m + 1) / 2; k += kThreads) {
       int r = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
       while (r * (r + 1) / 2 > k) r--;
       while ((r + 1) * (r + 2) / 2 <= k) r++;
       const int c = k - r * (r + 1) / 2;
-      const int ii = j + 1 + r, kk = j + 1 + c;
-      Hs[tri(ii, kk)] -= Hs[tri(ii, j)] * Hs[tri(kk, j)] * d;
+      const int ii = jb + 6 + r, kk = jb + 6 + c;
+      double v = Hs[tri(ii, kk)];
+      for (int c2 = 0; c2 < 6; c2++) v -= Hs[tri(ii, jb + c2)] * Hs[tri(kk, jb + c2)] * Hs[tri(jb + c2, jb + c2)];
+      Hs[tri(ii, kk)] = v;
     }
     __syncthreads();
   }
   if (ok) {
-    for (int j = 0; j < n; j++) {
-      const double xj = bs[j];
-      for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) bs[i] -= Hs[tri(i, j)] * xj;
+    // forward substitution (unit lower), block by block: the 6 unknowns of a block on one lane, then all rows below
+    for (int jb = 0; jb < n; jb += 6) {
+      if (threadIdx.x == 0)
+        for (int c = 0; c < 6; c++)
+          for (int c2 = 0; c2 < c; c2++) bs[jb + c] -= Hs[tri(jb + c, jb + c2)] * bs[jb + c2];
+      __syncthreads();
+      for (int i = jb + 6 + threadIdx.x; i < n; i += kThreads) {
+        double v = bs[i];
+        for (int c = 0; c < 6; c++) v -= Hs[tri(i, jb + c)] * bs[jb + c];
+        bs[i] = v;
+      }
       __syncthreads();
     }
     for (int i = threadIdx.x; i < n; i += kThreads) bs[i] /= Hs[tri(i, i)];
     __syncthreads();
-    for (int j = n - 1; j >= 0; j--) {
-      const double xj = bs[j];
-      for (int i = threadIdx.x; i < j; i += kThreads) bs[i] -= Hs[tri(j, i)] * xj;
+    // backward substitution with L^T, from the last block up
+    for (int jb = n - 6; jb >= 0; jb -= 6) {
+      if (threadIdx.x == 0)
+        for (int c = 5; c >= 0; c--)
+          for (int c2 = 5; c2 > c; c2--) bs[jb + c] -= Hs[tri(jb + c2, jb + c)] * bs[jb + c2];
+      __syncthreads();
+      for (int i = threadIdx.x; i < jb; i += kThreads) {
+        double v = bs[i];
+        for (int c = 5; c >= 0; c--) v -= Hs[tri(jb + c, i)] * bs[jb + c];
+        bs[i] = v;
+      }
       __syncthreads();
     }
     for (int i = threadIdx.x; i < n; i += kThreads) D.xp[i] = bs[i];
