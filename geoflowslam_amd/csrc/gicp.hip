@@ -1673,9 +1673,10 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
   GFS_LAUNCH("k_knn_cov_far", (k_knn_cov_far<16, 2, true>), dim3(xcd_grid(far_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
              h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
              h->d_hard_d.p, h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
-  GFS_LAUNCH("k_knn_cov_far2", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(far_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
+  const int far2_chunks = std::max(1, std::min(4, knn_chunks));  // a handful of queries per cloud: few workgroups, grid-stride
+  GFS_LAUNCH("k_knn_cov_far2", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(far2_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
              h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
-             h->d_hard_d.p, h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
+             h->d_hard_d.p, h->d_far2.p, far2_chunks, B, P, prm, h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
   GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
              prm.max_iterations, h->d_ndone.p);
