@@ -111,4 +111,4 @@ def test_gicp_pose_equals_the_stable_order_oracle(gpu_api, oracle, seed):
     assert r["iterations"] == ro["iterations"] and r["num_inliers"] == ro["num_inliers"] and r["converged"] == ro["converged"]
     # 1e-7: an exact distance tie at a 10th neighbour (seed 2 has one) may pick the other point; otherwise ~1e-16
     assert np.linalg.norm(r["T"] - ro["T"]) <= 1e-7 * np.linalg.norm(ro["T"])
-    assert abs(r["error"] - ro["error"]) <= 1e-6 * abs(ro["error"])
+    assert abs(r["error"] - ro["error"]) <= 1e-5 * abs(ro["error"])
