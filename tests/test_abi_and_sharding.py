@@ -35,6 +35,9 @@ def test_no_cpu_fallback_without_gpu(api):
         api.RegistrationGICP()
     with pytest.raises(api.GfsError):
         api.Optimizer()
+    for cls in (api.Frame, api.ProjectionMatcher, api.PoseOptimizer):
+        with pytest.raises(api.GfsError):
+            cls()
 
 
 def test_product_does_not_reference_the_oracle():
