@@ -60,8 +60,8 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,7 +131,7 @@ def main():
             self.mt = api.ORBmatcher(max_query=self.cap, max_train=self.cap, max_batch=n, device=local_rank)
             self.reg = api.RegistrationGICP(max_points=SP, max_batch=n, device=local_rank)
             self.s1 = torch.cuda.Stream(device=dev)
-            self.s2 = torch.cuda.Stream(device=dev)
+            self.s2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GFS_BENCH_GICP_PRIO", "0")))
             self.g0, self.g1 = gray0[b0:b1], gray1[b0:b1]
             self.c0, self.c1, self.n0, self.n1 = d_c0[b0:b1], d_c1[b0:b1], d_n0[b0:b1], d_n1[b0:b1]
             # previous-frame features (the "keyframe" side of SearchWithGMS): computed once, kept in HBM
