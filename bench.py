@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""bench.py — front-end frames/sec (ORB + BF match + GICP) on synthetic 640x480 RGB-D, BASELINE.json config C2.
+"""bench.py — front-end frames/sec (ORB + BF match + GMS + GICP) on synthetic 640x480 RGB-D, BASELINE.json config C2.
 
 One "step" = one pass of the hot path over one batch of B independent frame pairs already resident in HBM:
     ORB extract (1000 feats, 8 levels) of the B current frames
- -> brute-force Hamming match of the B previous-frame descriptor sets against them
+ -> brute-force Hamming match of the B previous-frame descriptor sets against them + GMS filter (SearchWithGMS)
  -> GICP (voxel 0.02, max-corr 0.1, LM <= 20x10) of the B (previous, current) cloud pairs, both clouds preprocessed.
 `value` = frames/s = N * B * steps / max-over-ranks wall time.  Multi-GPU: one process per GPU, batches are
 independent (no RCCL collective on the data path); torch.distributed is used only for the barrier / max reduction.
@@ -36,6 +36,7 @@ def algorithmic_bytes_per_step(kernel, ctx):
         "k_blur7": B * 2 * P,
         "k_orient_brief": B * K * (31 * 31 + 37 * 37 + 60),         # K x (31x31 + 37x37) read + 60 B out
         "k_bf_hamming": B * (32 * 2 * K + 8 * K),
+        "k_gms": B * (2 * 28 * K + 5 * K),                          # both key-point sets + match indices in, mask out
         "k_gicp_linearize": 320.0 * ctx["lin_points"],              # 320 B per source point per linearisation
         "k_gicp_error": 136.0 * ctx["err_points"],
         "k_knn_cov": (10 * 32 + 160) * ctx["ds_points"],            # 10-NN gather + covariance write, both clouds
@@ -129,6 +130,7 @@ def main():
             self.ext = api.ORBextractor(NF, 1.2, NL, 20, 7, max_rows=H, max_cols=W, max_batch=n, device=local_rank)
             self.cap = self.ext.cap
             self.mt = api.ORBmatcher(max_query=self.cap, max_train=self.cap, max_batch=n, device=local_rank)
+            self.gms = api.GmsMatcher(max_keypoints=self.cap, max_batch=n, device=local_rank)
             self.reg = api.RegistrationGICP(max_points=SP, max_batch=n, device=local_rank)
             self.s1 = torch.cuda.Stream(device=dev)
             self.s2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GFS_BENCH_GICP_PRIO", "0")))
@@ -140,10 +142,14 @@ def main():
             self.s1.synchronize()
             self.prev_desc = torch.empty(n * self.cap * 32, dtype=torch.uint8, device=dev)
             self.prev_cnt = torch.empty(n, dtype=torch.int32, device=dev)
+            self.prev_kps = torch.empty(n * self.cap * 28, dtype=torch.uint8, device=dev)  # cv::KeyPoint layout
+            assert hip.hipMemcpy(self.prev_kps.data_ptr(), self.res["kps"], n * self.cap * 28, 3) == 0
             assert hip.hipMemcpy(self.prev_desc.data_ptr(), self.res["desc"], n * self.cap * 32, 3) == 0
             assert hip.hipMemcpy(self.prev_cnt.data_ptr(), self.res["counts"], n * 4, 3) == 0
             self.m_idx = torch.empty(n * self.cap, dtype=torch.int32, device=dev)
             self.m_dist = torch.empty(n * self.cap, dtype=torch.int32, device=dev)
+            self.m_mask = torch.empty(n * self.cap, dtype=torch.uint8, device=dev)
+            self.m_inl = torch.empty(n, dtype=torch.int32, device=dev)
             self.gicp_out = None
 
         def orb_and_match(self):
@@ -151,6 +157,10 @@ def main():
             self.ext.extract_batch_device(self.g1.data_ptr(), self.n, H, W, (0, 0), sp)
             self.mt.match_batch_device(self.prev_desc.data_ptr(), self.prev_cnt.data_ptr(), self.res["desc"], self.res["counts"],
                                        self.n, self.cap, self.m_idx.data_ptr(), self.m_dist.data_ptr(), sp)
+            # ... followed by the GMS filter like every BFMatcher::match of the reference (SearchWithGMS, src/ORBmatcher.cc:744-778)
+            self.gms.inlier_mask_batch_device(self.prev_kps.data_ptr(), self.prev_cnt.data_ptr(), self.res["kps"], self.res["counts"],
+                                              self.n, self.cap, self.m_idx.data_ptr(), W, H, self.m_mask.data_ptr(),
+                                              self.m_inl.data_ptr(), sp)
 
         def gicp(self):
             self.gicp_out = self.reg.align_batch_device(self.c0.data_ptr(), self.n0.data_ptr(), self.c1.data_ptr(),
@@ -259,7 +269,9 @@ def main():
         O.lib()
         ncores = os.cpu_count() or 1
         orb0 = O.OrbOracle(NF, 1.2, NL, 20, 7)
-        prev_cpu = [orb0.extract(p["gray0"])[2] for p in pairs]
+        prev_full = [orb0.extract(p["gray0"]) for p in pairs]
+        prev_cpu = [r[2] for r in prev_full]
+        prev_kps_cpu = [r[1] for r in prev_full]
         # (a) the reference's own threading: one frame at a time, ORB with OpenMP over the 8 levels
         #     (src/ORBextractor.cc:775-777), GICP with 4 threads (src/RegistrationGICP.cc:10), match on all cores
         orb0.set_threads(8)
@@ -268,8 +280,9 @@ def main():
         t1 = time.perf_counter()
         for i in range(nseq):
             p = pairs[i % nd]
-            _, _, d_cur = orb0.extract(p["gray1"])
-            O.bf_match(prev_cpu[i % nd], d_cur, nthreads=min(ncores, 16))
+            _, k_cur, d_cur = orb0.extract(p["gray1"])
+            ti_cpu, _ = O.bf_match(prev_cpu[i % nd], d_cur, nthreads=min(ncores, 16))
+            O.gms_inlier_mask(prev_kps_cpu[i % nd], (W, H), k_cur, (W, H), np.arange(len(ti_cpu), dtype=np.int32), ti_cpu)
             O.gicp_align(p["cloud0"], p["cloud1"])
         dt_ref = time.perf_counter() - t1
         orb0.set_threads(1)
@@ -281,8 +294,9 @@ def main():
             p = pairs[i % nd]
             if not hasattr(tl, "orb"):
                 tl.orb = O.OrbOracle(NF, 1.2, NL, 20, 7)
-            _, _, d_cur = tl.orb.extract(p["gray1"])
-            O.bf_match(prev_cpu[i % nd], d_cur)
+            _, k_cur, d_cur = tl.orb.extract(p["gray1"])
+            ti_cpu, _ = O.bf_match(prev_cpu[i % nd], d_cur)
+            O.gms_inlier_mask(prev_kps_cpu[i % nd], (W, H), k_cur, (W, H), np.arange(len(ti_cpu), dtype=np.int32), ti_cpu)
             O.gicp_align(p["cloud0"], p["cloud1"])
 
         nall = max(2 * ncores, 64)
@@ -292,7 +306,7 @@ def main():
         dt_all = time.perf_counter() - t1
         cpu = dict(value=round(nseq / dt_ref, 3), unit="frames/s", cores=8, kind="port",
                    sample=f"{nseq} VGA frame pairs processed one at a time with the reference's threading: ORB 1000 feats "
-                          f"(OpenMP over 8 levels) + BF match 1000x1000 + GICP ~19k-pt clouds (4 threads, as hard-coded)",
+                          f"(OpenMP over 8 levels) + BF match 1000x1000 + GMS + GICP ~19k-pt clouds (4 threads, as hard-coded)",
                    all_cores=dict(value=round(nall / dt_all, 3), cores=ncores,
                                   sample=f"{nall} pairs on {ncores} worker threads, single-threaded oracle per pair"),
                    note="CPU restatement of the reference algorithm (reference not buildable here: OpenCV/Eigen/PCL absent)")
@@ -305,7 +319,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 (ORB, match) + f64 (GICP)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 640x480 RGBD frame pair, ORB extract (1000 feats, 8 levels) "
-                                   "+ BF Hamming match + GICP on ~19k-pt clouds (stride-4 depth grid)",
+                                   "+ BF Hamming match + GMS filter + GICP on ~19k-pt clouds (stride-4 depth grid)",
                        "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
                        "gicp_mean_outer_iterations": round(float(np.mean([r["n_linearize"] for r in g])), 2),
                        "gicp_mean_error_evals": round(float(np.mean([r["n_error_evals"] for r in g])), 2),

@@ -102,6 +102,12 @@ def pose_result(S, keep, n):
                 iterations_run=int(S.iterations_run))
 
 
+class GmsProblem(C.Structure):
+    _fields_ = [("n1", C.c_int32), ("n2", C.c_int32), ("kp1", C.c_void_p), ("kp2", C.c_void_p), ("width1", C.c_int32),
+                ("height1", C.c_int32), ("width2", C.c_int32), ("height2", C.c_int32), ("n_matches", C.c_int32),
+                ("query_idx", C.c_void_p), ("train_idx", C.c_void_p)]
+
+
 class SbpProblem(C.Structure):
     _fields_ = [("n_last", C.c_int32), ("last_xw", C.c_void_p), ("last_desc", C.c_void_p), ("last_octave", C.c_void_p),
                 ("last_angle", C.c_void_p), ("last_mp_has_obs", C.c_void_p), ("n_cur", C.c_int32), ("cur_kps_un", C.c_void_p),
@@ -183,6 +189,7 @@ ABI_SYMBOLS = [
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
     "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
+    "gfs_gms_create", "gfs_gms_destroy", "gfs_gms_inlier_mask", "gfs_gms_inlier_mask_batch_device",
     "gfs_sbp_create", "gfs_sbp_destroy", "gfs_search_by_projection", "gfs_search_by_projection_map",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
@@ -595,6 +602,43 @@ class Optimizer:
                                        C.byref(tot)), "gfs_lba_linearize")
         return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
                     Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=tot.value)
+
+
+class GmsMatcher:
+    """gms_matcher(kp1, size1, kp2, size2, matches).GetInlierMask(mask, false, false) (reference
+    Thirdparty/GMS/include/gms_matcher.h; call sites src/ORBmatcher.cc:761-762, 812-813, 893-894)."""
+
+    def __init__(self, max_keypoints=4096, max_batch=64, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_gms_create(device, max_keypoints, max_batch, C.byref(self.h)), "gfs_gms_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_gms_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def GetInlierMask(self, kp1, size1, kp2, size2, query_idx, train_idx):
+        """size = (width, height) like cv::Size -> (mask bool [n_matches], n_inliers)"""
+        kp1 = np.ascontiguousarray(kp1, KP_DTYPE)
+        kp2 = np.ascontiguousarray(kp2, KP_DTYPE)
+        q = np.ascontiguousarray(query_idx, np.int32)
+        t = np.ascontiguousarray(train_idx, np.int32)
+        P = GmsProblem(len(kp1), len(kp2), kp1.ctypes.data, kp2.ctypes.data, int(size1[0]), int(size1[1]), int(size2[0]),
+                       int(size2[1]), len(q), q.ctypes.data, t.ctypes.data)
+        mask = np.zeros(max(len(q), 1), np.uint8)
+        ptrs = (C.c_void_p * 1)(mask.ctypes.data)
+        n = np.zeros(1, np.int32)
+        _check(lib().gfs_gms_inlier_mask(self.h, C.byref(P), 1, ptrs, _p(n)), "gfs_gms_inlier_mask")
+        return mask[:len(q)].astype(bool), int(n[0])
+
+    def inlier_mask_batch_device(self, d_kps1, d_n1, d_kps2, d_n2, B, kp_stride, d_train_idx, width, height, d_mask, d_counts,
+                                 stream=None):
+        _check(lib().gfs_gms_inlier_mask_batch_device(self.h, C.c_void_p(d_kps1), C.c_void_p(d_n1), C.c_void_p(d_kps2),
+                                                      C.c_void_p(d_n2), B, kp_stride, C.c_void_p(d_train_idx), width, height,
+                                                      C.c_void_p(d_mask), C.c_void_p(d_counts),
+                                                      C.c_void_p(stream) if stream else None), "gfs_gms_inlier_mask_batch_device")
 
 
 class ProjectionMatcher:

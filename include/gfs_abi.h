@@ -375,6 +375,34 @@ int gfs_search_by_projection_map(gfs_sbp* h, const gfs_sbp_map_problem* problems
                                  int32_t* nmatches);
 
 /* ============================================================================================
+ * 8. GMS filter of the brute-force matches (the second half of ORBmatcher::SearchWithGMS / SearchForInitializationWithGMS)
+ *      gms_matcher gms(kp1, frameSize, kp2, frameSize, matches_all); nmatches = gms.GetInlierMask(vbInliers, false, false);
+ *                                                                     src/ORBmatcher.cc:761-762, 812-813, 893-894
+ *      Thirdparty/GMS/include/gms_matcher.h:43-60 (constructor), 289-301 (GetInlierMask), 356-455 (run, no scale / rotation)
+ * ============================================================================================ */
+typedef struct {
+  int32_t n1, n2;
+  const gfs_keypoint* kp1;   /* [n1] vkp1 (cv::KeyPoint layout; only pt is used) */
+  const gfs_keypoint* kp2;   /* [n2] vkp2 */
+  int32_t width1, height1, width2, height2; /* size1, size2 */
+  int32_t n_matches;
+  const int32_t* query_idx;  /* [n_matches] vDMatches[i].queryIdx */
+  const int32_t* train_idx;  /* [n_matches] vDMatches[i].trainIdx */
+} gfs_gms_problem;
+
+typedef struct gfs_gms gfs_gms;
+int gfs_gms_create(int device, int max_keypoints /* <= 8192 */, int max_batch, gfs_gms** out);
+void gfs_gms_destroy(gfs_gms* h);
+/* B pairs (host pointers): inlier[f][i] = vbInliers[i] (0 / 1), n_inliers[f] = the return value. */
+int gfs_gms_inlier_mask(gfs_gms* h, const gfs_gms_problem* problems, int B, uint8_t* const* inlier, int32_t* n_inliers);
+/* Device-resident chain ORB -> BF match -> GMS: dev_kps1 / dev_kps2 [B][kp_stride] gfs_keypoint and dev_n1 / dev_n2 [B] as
+ * returned by gfs_orb_device_results, dev_train_idx [B][kp_stride] as written by gfs_bf_match_hamming_batch_device (match i
+ * of pair b = (i, dev_train_idx[b][i]), i < n1[b]; no matches when n2[b] == 0).  dev_mask [B][kp_stride] u8, dev_counts [B]. */
+int gfs_gms_inlier_mask_batch_device(gfs_gms* h, const void* dev_kps1, const void* dev_n1, const void* dev_kps2, const void* dev_n2,
+                                     int B, int kp_stride, const void* dev_train_idx, int width, int height, void* dev_mask,
+                                     void* dev_counts, void* stream);
+
+/* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel
  * with these rather than torch events, which only see torch's current stream).
  * ============================================================================================ */

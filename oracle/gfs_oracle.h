@@ -234,6 +234,11 @@ typedef struct {
 /* cur_match[n_cur]: >= 0 F.mvpMapPoints[i] := that list entry, -1 untouched.  Returns nmatches. */
 int gfso_search_by_projection_map(const gfso_sbp_map_problem*, int32_t* cur_match);
 
+/* ---- gms_matcher(vkp1, size1, vkp2, size2, vDMatches).GetInlierMask(mask, false, false)
+ *      (Thirdparty/GMS/include/gms_matcher.h:43-60, 289-301, 356-466; call sites src/ORBmatcher.cc:761-762, 812-813, 893-894) ---- */
+int gfso_gms_inlier_mask(const float* kp1_xy, int n1, int width1, int height1, const float* kp2_xy, int n2, int width2,
+                         int height2, const int32_t* query_idx, const int32_t* train_idx, int n_matches, uint8_t* inlier);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,6 +494,23 @@ def search_by_projection_map(prob):
     return out[:P.n_cur].copy(), int(n)
 
 
+def gms_inlier_mask(kp1, size1, kp2, size2, query_idx, train_idx):
+    """gms_matcher(...).GetInlierMask(mask, false, false) restatement (oracle/gms_oracle.cpp); size = (width, height).
+    kp1 / kp2: structured key-point arrays with x, y fields.  Returns (mask bool [n_matches], n_inliers)."""
+    xy1 = np.ascontiguousarray(np.stack([kp1["x"], kp1["y"]], 1) if len(kp1) else np.zeros((0, 2)), np.float32)
+    xy2 = np.ascontiguousarray(np.stack([kp2["x"], kp2["y"]], 1) if len(kp2) else np.zeros((0, 2)), np.float32)
+    q = np.ascontiguousarray(query_idx, np.int32)
+    t = np.ascontiguousarray(train_idx, np.int32)
+    mask = np.zeros(max(len(q), 1), np.uint8)
+    L = lib()
+    L.gfso_gms_inlier_mask.restype = C.c_int
+    L.gfso_gms_inlier_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p]
+    n = L.gfso_gms_inlier_mask(xy1.ctypes.data, len(xy1), int(size1[0]), int(size1[1]), xy2.ctypes.data, len(xy2), int(size2[0]),
+                               int(size2[1]), q.ctypes.data, t.ctypes.data, len(q), mask.ctypes.data)
+    return mask[:len(q)].astype(bool), int(n)
+
+
 def depth_to_cloud(depth, downsample, fx, fy, cx, cy):
     depth = np.ascontiguousarray(depth, np.float32)
     rows, cols = depth.shape if depth.ndim == 2 else (0, 0)
