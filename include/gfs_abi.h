@@ -1,7 +1,7 @@
 /* gfs_abi.h — C ABI of the MI355X-native GeoFlow-SLAM front-end hot path (libgfs_hip.so).
  *
  * This is the drop-in boundary.  The reference has no FFI layer: the seams are four
- * ordinary C++ methods.  Each entry point below names the reference interface it replaces
+ * ordinary C++ methods (sections 1-4), followed by the neighbouring rows of SURVEY.md §8(f) (sections 5-8).  Each entry point below names the reference interface it replaces
  * (file:line in HorizonRobotics/GeoFlowSlam).  Signatures are plain C: pointers, sizes, POD structs.
  * No torch / OpenCV / Eigen types cross this boundary.  INTEGRATION.md shows the reference-side
  * adaptor (what a maintainer adds to src/ORBextractor.cc etc. to call these).
