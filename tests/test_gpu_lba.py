@@ -66,3 +66,28 @@ def test_edge_cases(gpu_api, oracle):
     # stop flag present but not raised: normal result
     rn = opt.LocalBundleAdjustment(w, stop_flag=np.zeros(1, np.int32))
     assert _rel(rn["points"], r["points"]) == 0
+
+
+def test_stop_flag_raised_while_solving(gpu_api, oracle):
+    """setForceStopFlag semantics (src/Optimizer.cc:1679): raising the flag during optimize() ends it at the next check
+    (top of an iteration / end of an LM trial); the estimate is then a state some earlier iteration reached."""
+    import threading
+    import time
+    w = synth.lba_window(0, n_free=20, n_fixed=5, n_points=3000)
+    opt = gpu_api.Optimizer()
+    full = opt.LocalBundleAdjustment(w)
+    flag = np.zeros(1, np.int32)
+
+    def raiser():
+        time.sleep(0.0015)
+        flag[0] = 1
+
+    t = threading.Thread(target=raiser)
+    t.start()
+    r = opt.LocalBundleAdjustment(w, stop_flag=flag)
+    t.join()
+    assert r is not None and 0 <= r["iterations_run"] <= full["iterations_run"]
+    assert np.isfinite(r["points"]).all() and np.isfinite(r["pose_t"]).all()
+    if r["iterations_run"] < full["iterations_run"]:  # stopped early: the cost is not above the starting cost
+        chi0 = oracle.lba_linearize(w)["chi2"]
+        assert r["final_chi2"] <= chi0 * (1 + 1e-12)
