@@ -15,6 +15,7 @@
 // Error behaviour follows the reference: operator() returns -1 on an empty image, asserts CV_8UC1; GICP never throws.
 // Anything the GPU library reports as an error is raised as std::runtime_error (there is no CPU fallback).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -143,6 +144,29 @@ class LocalBundleAdjuster {
 
  private:
   gfs_lba* h_ = nullptr;
+};
+
+// gms_matcher(kp1, size1, kp2, size2, matches).GetInlierMask(mask, false, false) (reference Thirdparty/GMS/include/gms_matcher.h;
+// the filter SearchWithGMS applies to the brute-force matches, src/ORBmatcher.cc:761-762)
+class GmsMatcher {
+ public:
+  explicit GmsMatcher(int max_keypoints = 8192, int device = 0) { check(gfs_gms_create(device, max_keypoints, 1, &h_), "gfs_gms_create"); }
+  ~GmsMatcher() { gfs_gms_destroy(h_); }
+  // matches[i] = (queryIdx, trainIdx); returns the number of inliers, mask[i] = vbInliers[i]
+  int GetInlierMask(const gfs_keypoint* kp1, int n1, int w1, int h1, const gfs_keypoint* kp2, int n2, int w2, int h2,
+                    const std::vector<int32_t>& query_idx, const std::vector<int32_t>& train_idx, std::vector<uint8_t>& mask) {
+    const int n = (int)query_idx.size();
+    mask.assign((size_t)std::max(n, 1), 0);
+    gfs_gms_problem p{n1, n2, kp1, kp2, w1, h1, w2, h2, n, query_idx.data(), train_idx.data()};
+    uint8_t* mp = mask.data();
+    int32_t nin = 0;
+    check(gfs_gms_inlier_mask(h_, &p, 1, &mp, &nin), "gfs_gms_inlier_mask");
+    mask.resize((size_t)n);
+    return nin;
+  }
+
+ private:
+  gfs_gms* h_ = nullptr;
 };
 
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on flattened frames (reference src/ORBmatcher.cc:1853-2063;
