@@ -1281,7 +1281,8 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   const int n_cells = (int)G.cells.size();
   const size_t cap_pyr = h->cap_pyr, cap_blur = h->cap_blur, cap_slab = h->cap_slab;
   // 1. pyramid chain (level l depends on l-1): one launch, row strips with recomputed halos
-  if (G.pyr_lds_a + G.pyr_lds_b > 0) {
+  static const bool pyr_in_hbm = getenv("GFS_ORB_PYR_HBM") != nullptr;  // test knob: take the large-image path on any image
+  if (G.pyr_lds_a + G.pyr_lds_b > 0 && !pyr_in_hbm) {
     GFS_LAUNCH("k_pyr_area", (k_pyr_area<true>), dim3(G.pyr_strips, B), dim3(kPyrThreads), G.pyr_lds_a + G.pyr_lds_b, s, h->d_levels.p,
                nl, l0, h->d_pyr.p, cap_pyr, h->d_strip_rows.p, (unsigned)G.pyr_lds_a, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p,
                h->d_yt_start.p, h->d_yt_n.p, h->d_yt_alpha.p);
