@@ -1014,20 +1014,37 @@ __device__ __forceinline__ void inv3(const double* A, double* M) {
 }
 
 // per-wave shuffle reduction, then the 4 waves of the block are folded in fixed order: deterministic sums
+// Wave-wide sums of up to 32 values per lane by recursive halving: at level s the lanes of a pair (lane ^ 2^s) split the
+// remaining values between them (one keeps the even, the other the odd ones, each adds what its partner sends), so the work
+// per level halves: 16 + 8 + 4 + 2 + 1 exchanges instead of 32 x 6 for one shuffle tree per value.  After five levels lane l
+// of each half-wave holds the half-wave total of value (l & 31); one more exchange joins the two halves.  The
+// summation order is fixed (deterministic), just a different tree.
 template <int N>
 __device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __restrict__ dst, double* s_red /*[4][kRed]*/) {
+  static_assert(N <= 32, "at most 32 values");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[32];
 #pragma unroll
-  for (int k = 0; k < N; k++) {
-    double v = vals[k];
+  for (int k = 0; k < 32; k++) v[k] = k < N ? vals[k] : 0.0;
 #pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_down(v, ofs, 64);
-    if (lane == 0) s_red[wave * kRed + k] = v;
+  for (int s = 0; s < 5; s++) {
+    const bool odd = (lane >> s) & 1;
+    const int half = 16 >> s;
+#pragma unroll
+    for (int j = 0; j < half; j++) {
+      const double keep = odd ? v[2 * j + 1] : v[2 * j];
+      const double send = odd ? v[2 * j] : v[2 * j + 1];
+      v[j] = keep + __shfl_xor(send, 1 << s, 64);
+    }
   }
+  const double tot = v[0] + __shfl_xor(v[0], 32, 64);
+  // value index held by this lane: bit s of the lane chose bit s of the index at level s
+  const int k = lane & 31;
+  if (lane < 32 && k < N) s_red[wave * kRed + k] = tot;
   __syncthreads();
   if (threadIdx.x < N) {
-    const int k = threadIdx.x;
-    dst[k] = ((s_red[k] + s_red[kRed + k]) + s_red[2 * kRed + k]) + s_red[3 * kRed + k];
+    const int kk = threadIdx.x;
+    dst[kk] = ((s_red[kk] + s_red[kRed + kk]) + s_red[2 * kRed + kk]) + s_red[3 * kRed + kk];
   }
 }
 
