@@ -18,6 +18,7 @@
 #include <memory>
 
 #include "gfs_common.hpp"
+#include "wave_reduce.hpp"
 
 namespace {
 
@@ -1014,38 +1015,11 @@ __device__ __forceinline__ void inv3(const double* A, double* M) {
 }
 
 // per-wave shuffle reduction, then the 4 waves of the block are folded in fixed order: deterministic sums
-// Wave-wide sums of up to 32 values per lane by recursive halving: at level s the lanes of a pair (lane ^ 2^s) split the
-// remaining values between them (one keeps the even, the other the odd ones, each adds what its partner sends), so the work
-// per level halves: 16 + 8 + 4 + 2 + 1 exchanges instead of 32 x 6 for one shuffle tree per value.  After five levels lane l
-// of each half-wave holds the half-wave total of value (l & 31); one more exchange joins the two halves.  The
-// summation order is fixed (deterministic), just a different tree.
+// per-block partial sums: wave totals by recursive halving (wave_reduce.hpp), then the 4 waves of the block in fixed order
 template <int N>
-__device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __restrict__ dst, double* s_red /*[4][kRed]*/) {
-  static_assert(N <= 32, "at most 32 values");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double v[32];
-#pragma unroll
-  for (int k = 0; k < 32; k++) v[k] = k < N ? vals[k] : 0.0;
-#pragma unroll
-  for (int s = 0; s < 5; s++) {
-    const bool odd = (lane >> s) & 1;
-    const int half = 16 >> s;
-#pragma unroll
-    for (int j = 0; j < half; j++) {
-      const double keep = odd ? v[2 * j + 1] : v[2 * j];
-      const double send = odd ? v[2 * j] : v[2 * j + 1];
-      v[j] = keep + __shfl_xor(send, 1 << s, 64);
-    }
-  }
-  const double tot = v[0] + __shfl_xor(v[0], 32, 64);
-  // value index held by this lane: bit s of the lane chose bit s of the index at level s
-  const int k = lane & 31;
-  if (lane < 32 && k < N) s_red[wave * kRed + k] = tot;
-  __syncthreads();
-  if (threadIdx.x < N) {
-    const int kk = threadIdx.x;
-    dst[kk] = ((s_red[kk] + s_red[kRed + kk]) + s_red[2 * kRed + kk]) + s_red[3 * kRed + kk];
-  }
+__device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __restrict__ dst, double* s_red /*[4][32]*/) {
+  const double r = gfs_red::block_sum_many<N, kLinBlock / 64>(vals, s_red);
+  if (threadIdx.x < N) dst[threadIdx.x] = r;
 }
 
 // GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
@@ -1059,7 +1033,7 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
                                                               int nchunks, int npairs, int P, GicpParams prm,
                                                               int* __restrict__ tgt_index, double* __restrict__ maha6,
                                                               double* __restrict__ partial, int nblk) {
-  __shared__ double s_red[4 * kRed];
+  __shared__ double s_red[4 * 32];
   int pair, sub, chunk;
   if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
   const PairState S = st[pair];
@@ -1253,7 +1227,7 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __res
                                                            const int* __restrict__ m_counts, int P,
                                                            const int* __restrict__ tgt_index, const double* __restrict__ maha6,
                                                            double* __restrict__ epartial, int nblk, int nchunks, int npairs) {
-  __shared__ double s_red[4 * kRed];
+  __shared__ double s_red[4 * 32];
   int pair, sub, chunk;
   if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
   const PairState& S = st[pair];

@@ -22,6 +22,7 @@
 
 #include "g2o_se3_dev.hpp"
 #include "gfs_common.hpp"
+#include "wave_reduce.hpp"
 
 namespace {
 
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) {
 
 // buildSystem, pose side: one workgroup per free pose, threads over its edges, fixed-order reduction
 __global__ __launch_bounds__(kMk) void k_lba_build_poses(LbaDev D) {
-  __shared__ double s4[4];
+  __shared__ double s_buf[(kMk / 64) * 32];
   const LbaState& S = *D.S;
   const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
   const int f = blockIdx.x;
@@ -650,16 +651,11 @@ __global__ __launch_bounds__(kMk) void k_lba_build_poses(LbaDev D) {
 #pragma unroll
     for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * omr[0] + Jj[6 + a] * omr[1] + Jj[12 + a] * omr[2];
   }
-#pragma unroll
-  for (int k = 0; k < 27; k++) {
-    const double v = block_sum256(acc[k], s4);
-    if (threadIdx.x == 0) {
-      if (k < 21)
-        D.Hpp[21 * f + k] = v;
-      else
-        D.bp[6 * f + (k - 21)] = v;
-    }
-  }
+  const double v = gfs_red::block_sum_many<27, kMk / 64>(acc, s_buf);
+  if (threadIdx.x < 21)
+    D.Hpp[21 * f + threadIdx.x] = v;
+  else if (threadIdx.x < 27)
+    D.bp[6 * f + (threadIdx.x - 21)] = v;
 }
 
 // start of an LM iteration: currentChi, and at iteration 0 computeLambdaInit (tau * max |diag H|)
@@ -701,7 +697,7 @@ __global__ __launch_bounds__(kMk) void k_lba_dinv(LbaDev D) {
 
 // Schur complement, one workgroup per pose pair (i1 >= i2): Hs(i1,i2) = [i1==i2](Hpp + lambda I) - sum_l B_i1 Dinv_l B_i2^T
 __global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) {
-  __shared__ double s4[4];
+  __shared__ double s_buf[(kMk / 64) * 32];
   const double lambda = D.S->lambda;
   const int pr = blockIdx.x;
   int i1 = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
@@ -738,27 +734,31 @@ __global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) {
       for (int a = 0; a < 6; a++) accb[a] += BD[3 * a] * bl[0] + BD[3 * a + 1] * bl[1] + BD[3 * a + 2] * bl[2];
     }
   }
+  // 36 + 6 sums over the workgroup: two many-value reductions (32, then the remaining 4 + 6)
+  double head[32], tail[10];
 #pragma unroll
-  for (int k = 0; k < 36; k++) {
-    const double v = block_sum256(acc[k], s4);
-    if (threadIdx.x == 0) {
-      const int a = k / 6, c = k % 6;
-      if (i1 != i2) {
-        D.Hs[tri(6 * i1 + a, 6 * i2 + c)] = -v;
-      } else if (a >= c) {
-        const int ua = c, uc = a;  // Hpp upper-triangle index of (c, a)
-        const double hpp = D.Hpp[21 * i1 + (ua * 6 - ua * (ua - 1) / 2 + (uc - ua))];
-        D.Hs[tri(6 * i1 + a, 6 * i1 + c)] = hpp + (a == c ? lambda : 0.0) - v;
-      }
-    }
-  }
-  if (i1 == i2) {
+  for (int k = 0; k < 32; k++) head[k] = acc[k];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const double v = block_sum256(accb[k], s4);
-      if (threadIdx.x == 0) D.bs[6 * i1 + k] = D.bp[6 * i1 + k] - v;
+  for (int k = 0; k < 4; k++) tail[k] = acc[32 + k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) tail[4 + k] = accb[k];
+  const double v0 = gfs_red::block_sum_many<32, kMk / 64>(head, s_buf);
+  const double v1 = gfs_red::block_sum_many<10, kMk / 64>(tail, s_buf);
+  const int tk = threadIdx.x;
+  // threads 0..31 own acc[0..31] (v0); threads 0..3 own acc[32..35] and threads 4..9 own accb[0..5] (v1)
+  auto store_h = [&](int k, double val) {
+    const int a = k / 6, c = k % 6;
+    if (i1 != i2) {
+      D.Hs[tri(6 * i1 + a, 6 * i2 + c)] = -val;
+    } else if (a >= c) {
+      const int ua = c, uc = a;  // Hpp upper-triangle index of (c, a)
+      const double hpp = D.Hpp[21 * i1 + (ua * 6 - ua * (ua - 1) / 2 + (uc - ua))];
+      D.Hs[tri(6 * i1 + a, 6 * i1 + c)] = hpp + (a == c ? lambda : 0.0) - val;
     }
-  }
+  };
+  if (tk < 32) store_h(tk, v0);
+  if (tk < 4) store_h(32 + tk, v1);
+  if (i1 == i2 && tk >= 4 && tk < 10) D.bs[6 * i1 + (tk - 4)] = D.bp[6 * i1 + (tk - 4)] - v1;
 }
 
 // LDL^T + triangular solves of the reduced pose system in LDS (single workgroup: n <= 180)

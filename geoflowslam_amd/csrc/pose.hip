@@ -15,6 +15,7 @@
 
 #include "g2o_se3_dev.hpp"
 #include "gfs_common.hpp"
+#include "wave_reduce.hpp"
 
 using namespace gfs_se3;
 
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
                                                            double* __restrict__ err_all, uint8_t* __restrict__ level_all,
                                                            PoseOut* __restrict__ outs) {
   __shared__ double s4[4];
+  __shared__ double s_many[(kPoseThreads / 64) * 32];
   __shared__ double s_T[7], s_Tb[7];  // current estimate, backup (push / pop)
   __shared__ double s_sys[kSys];
   __shared__ double s_x[6];
@@ -308,11 +310,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
             }
           }
         }
-#pragma unroll
-        for (int k = 0; k < kSys; k++) {
-          const double v = block_sum256(acc[k], s4);
-          if (tid == 0) s_sys[k] = v;
-        }
+        const double v = gfs_red::block_sum_many<kSys, kPoseThreads / 64>(acc, s_many);
+        if (tid < kSys) s_sys[tid] = v;
         __syncthreads();
       }
       if (tid == 0 && iteration == 0) {  // computeLambdaInit: tau * max |diag(H)|
