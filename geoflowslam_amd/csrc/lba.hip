@@ -593,35 +593,48 @@ __global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial) {
   if (threadIdx.x == 0) D.part_chi[blockIdx.x] = tot;
 }
 
-// buildSystem, landmark side: Hll, bl and the per-edge pose-landmark blocks (one thread per landmark)
+// buildSystem, landmark side: Hll, bl and the per-edge pose-landmark blocks.  16 lanes per landmark (its edges over the
+// lanes, the 9 sums folded by xor-shuffles inside the group in a fixed order), 8 landmarks per 128-thread workgroup.
 __global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) {
   const LbaState& S = *D.S;
   const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
-  const int l = blockIdx.x * 128 + threadIdx.x;
-  if (l >= D.n_points) return;
-  double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-  for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
-    double xc[3], r[3], Ji[9], Jj[18];
-    edge_residual(D, e, q, t, X, xc, r);
-    edge_jacobians(D, e, q, xc, Ji, Jj);
-    double r0, r1;
-    huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
-    const double w = r1 * D.e_w[e];
-    double omr[3];
-    for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
-    int o = 0;
-    for (int a = 0; a < 3; a++) {
-      b[a] += Ji[a] * omr[0] + Ji[3 + a] * omr[1] + Ji[6 + a] * omr[2];
-      for (int c = a; c < 3; c++) H[o++] += Ji[a] * w * Ji[c] + Ji[3 + a] * w * Ji[3 + c] + Ji[6 + a] * w * Ji[6 + c];
-    }
-    if (D.free_index[D.e_pose[e]] >= 0) {
-      double* B = D.Hpl + 18 * (size_t)e;
-      for (int a = 0; a < 6; a++)
-        for (int c = 0; c < 3; c++) B[3 * a + c] = Jj[a] * w * Ji[c] + Jj[6 + a] * w * Ji[3 + c] + Jj[12 + a] * w * Ji[6 + c];
+  const int gl = threadIdx.x & 15;
+  const int l = blockIdx.x * 8 + (threadIdx.x >> 4);
+  const bool live = l < D.n_points;  // (whole 16-lane groups are live or not: the shuffles below stay inside a group)
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx,xy,xz,yy,yz,zz), b
+  if (live) {
+    for (int e = D.pt_begin[l] + gl; e < D.pt_begin[l + 1]; e += 16) {
+      double xc[3], r[3], Ji[9], Jj[18];
+      edge_residual(D, e, q, t, X, xc, r);
+      edge_jacobians(D, e, q, xc, Ji, Jj);
+      double r0, r1;
+      huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+      const double w = r1 * D.e_w[e];
+      double omr[3];
+      for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
+      int o = 0;
+      for (int a = 0; a < 3; a++) {
+        acc[6 + a] += Ji[a] * omr[0] + Ji[3 + a] * omr[1] + Ji[6 + a] * omr[2];
+        for (int c = a; c < 3; c++) acc[o++] += Ji[a] * w * Ji[c] + Ji[3 + a] * w * Ji[3 + c] + Ji[6 + a] * w * Ji[6 + c];
+      }
+      if (D.free_index[D.e_pose[e]] >= 0) {
+        double* B = D.Hpl + 18 * (size_t)e;
+        for (int a = 0; a < 6; a++)
+          for (int c = 0; c < 3; c++) B[3 * a + c] = Jj[a] * w * Ji[c] + Jj[6 + a] * w * Ji[3 + c] + Jj[12 + a] * w * Ji[6 + c];
+      }
     }
   }
-  for (int k = 0; k < 6; k++) D.Hll[6 * (size_t)l + k] = H[k];
-  for (int k = 0; k < 3; k++) D.bl[3 * (size_t)l + k] = b[k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    double v = acc[k];
+#pragma unroll
+    for (int ofs = 8; ofs > 0; ofs >>= 1) v += __shfl_xor(v, ofs, 16);
+    acc[k] = v;
+  }
+  if (live && gl == 0) {
+    for (int k = 0; k < 6; k++) D.Hll[6 * (size_t)l + k] = acc[k];
+    for (int k = 0; k < 3; k++) D.bl[3 * (size_t)l + k] = acc[6 + k];
+  }
 }
 
 // buildSystem, pose side: one workgroup per free pose, threads over its edges, fixed-order reduction
@@ -778,18 +791,31 @@ __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
   //   independent), (c) the trailing triangle takes the rank-6 update.
   bool ok = true;
   for (int jb = 0; jb < n && ok; jb += 6) {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {  // the 21 entries are pulled into registers first: one LDS latency instead of ~100 dependent ones
+      double a[6][6];
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k <= i; k++) a[i][k] = Hs[tri(jb + i, jb + k)];
+      bool bad = false;
+#pragma unroll
       for (int c = 0; c < 6; c++) {
-        const int j = jb + c;
-        const double d = Hs[tri(j, j)];
-        if (d == 0.0 || !isfinite(d)) {
-          s_flag = 1;
-          break;
+        const double d = a[c][c];
+        if (d == 0.0 || !isfinite(d)) bad = true;
+        if (!bad) {
+#pragma unroll
+          for (int i = c + 1; i < 6; i++) a[i][c] /= d;
+#pragma unroll
+          for (int k = c + 1; k < 6; k++)
+#pragma unroll
+            for (int i = k; i < 6; i++) a[i][k] -= a[i][c] * a[k][c] * d;
         }
-        for (int i = j + 1; i < jb + 6; i++) Hs[tri(i, j)] /= d;
-        for (int k = j + 1; k < jb + 6; k++)
-          for (int i = k; i < jb + 6; i++) Hs[tri(i, k)] -= Hs[tri(i, j)] * Hs[tri(k, j)] * d;
       }
+      if (bad) s_flag = 1;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k <= i; k++) Hs[tri(jb + i, jb + k)] = a[i][k];
     }
     __syncthreads();
     if (s_flag) {
@@ -820,9 +846,21 @@ __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
   if (ok) {
     // forward substitution (unit lower), block by block: the 6 unknowns of a block on one lane, then all rows below
     for (int jb = 0; jb < n; jb += 6) {
-      if (threadIdx.x == 0)
+      if (threadIdx.x == 0) {
+        double y[6], l[6][6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          y[c] = bs[jb + c];
+#pragma unroll
+          for (int c2 = 0; c2 < c; c2++) l[c][c2] = Hs[tri(jb + c, jb + c2)];
+        }
+#pragma unroll
         for (int c = 0; c < 6; c++)
-          for (int c2 = 0; c2 < c; c2++) bs[jb + c] -= Hs[tri(jb + c, jb + c2)] * bs[jb + c2];
+#pragma unroll
+          for (int c2 = 0; c2 < c; c2++) y[c] -= l[c][c2] * y[c2];
+#pragma unroll
+        for (int c = 0; c < 6; c++) bs[jb + c] = y[c];
+      }
       __syncthreads();
       for (int i = jb + 6 + threadIdx.x; i < n; i += kThreads) {
         double v = bs[i];
@@ -835,9 +873,21 @@ __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
     __syncthreads();
     // backward substitution with L^T, from the last block up
     for (int jb = n - 6; jb >= 0; jb -= 6) {
-      if (threadIdx.x == 0)
+      if (threadIdx.x == 0) {
+        double y[6], l[6][6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          y[c] = bs[jb + c];
+#pragma unroll
+          for (int c2 = c + 1; c2 < 6; c2++) l[c2][c] = Hs[tri(jb + c2, jb + c)];
+        }
+#pragma unroll
         for (int c = 5; c >= 0; c--)
-          for (int c2 = 5; c2 > c; c2--) bs[jb + c] -= Hs[tri(jb + c2, jb + c)] * bs[jb + c2];
+#pragma unroll
+          for (int c2 = 5; c2 > c; c2--) y[c] -= l[c2][c] * y[c2];
+#pragma unroll
+        for (int c = 0; c < 6; c++) bs[jb + c] = y[c];
+      }
       __syncthreads();
       for (int i = threadIdx.x; i < jb; i += kThreads) {
         double v = bs[i];
@@ -1155,7 +1205,7 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   int* d_flags = nullptr;
   GFS_HIP(hipHostGetDevicePointer((void**)&d_flags, h->h_flags, 0));
   GFS_HIP(hipFuncSetAttribute((const void*)k_lba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 128)), g_upd(D.n_upd_blocks);
+  const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 8)), g_upd(D.n_upd_blocks);
   GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
   const bool lin_only = mode == 1 || p->iterations <= 0;
   if (lin_only) {
