@@ -191,6 +191,9 @@ ABI_SYMBOLS = [
     "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
     "gfs_gms_create", "gfs_gms_destroy", "gfs_gms_inlier_mask", "gfs_gms_inlier_mask_batch_device",
     "gfs_sbp_create", "gfs_sbp_destroy", "gfs_search_by_projection", "gfs_search_by_projection_map",
+    "gfs_klt_create", "gfs_klt_destroy", "gfs_klt_layout", "gfs_klt_pyramid_create", "gfs_klt_pyramid_destroy",
+    "gfs_klt_build_pyramid", "gfs_klt_build_pyramid_device", "gfs_klt_pyramid_download", "gfs_klt_track", "gfs_klt_fb_track",
+    "gfs_klt_fb_track_device",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
 ]
@@ -246,6 +249,19 @@ def lib():
             L.gfs_depth_to_cloud_batch_device.argtypes = [vp, vp, i, i, i, i, f, f, f, f, vp, i, vp, vp]
             L.gfs_stereo_from_rgbd.argtypes = [vp, vp, vp, i, vp, i, i, i, f, vp, vp]
             L.gfs_stereo_from_rgbd_batch_device.argtypes = [vp, vp, vp, vp, i, i, vp, i, i, f, vp, vp, vp]
+        if hasattr(L, "gfs_klt_create"):
+            f, d = C.c_float, C.c_double
+            L.gfs_klt_create.argtypes = [i, i, i, i, i, i, i, C.POINTER(vp)]
+            L.gfs_klt_destroy.argtypes = [vp]
+            L.gfs_klt_layout.argtypes = [vp, vp, vp, vp]
+            L.gfs_klt_pyramid_create.argtypes = [vp, C.POINTER(vp)]
+            L.gfs_klt_pyramid_destroy.argtypes = [vp]
+            L.gfs_klt_build_pyramid.argtypes = [vp, vp, vp, i, i]
+            L.gfs_klt_build_pyramid_device.argtypes = [vp, vp, vp, i, i, vp]
+            L.gfs_klt_pyramid_download.argtypes = [vp, vp, i, vp, vp]
+            L.gfs_klt_track.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, i, d, i, d]
+            L.gfs_klt_fb_track.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, f]
+            L.gfs_klt_fb_track_device.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, vp, i, f, f, vp]
         L.gfs_timer_create.argtypes = [i, C.POINTER(vp)]
         L.gfs_timer_destroy.argtypes = [vp]
         L.gfs_timer_start.argtypes = [vp, vp]
@@ -639,6 +655,122 @@ class GmsMatcher:
                                                       C.c_void_p(d_n2), B, kp_stride, C.c_void_p(d_train_idx), width, height,
                                                       C.c_void_p(d_mask), C.c_void_p(d_counts),
                                                       C.c_void_p(stream) if stream else None), "gfs_gms_inlier_mask_batch_device")
+
+
+KLT_USE_INITIAL_FLOW, KLT_GET_MIN_EIGENVALS = 4, 8
+
+
+class KltPyramid:
+    """The optical-flow pyramids (cv::buildOpticalFlowPyramid output, images + derivatives) of a batch of frames, resident in HBM."""
+
+    def __init__(self, tracker):
+        self.tracker = tracker
+        self.h = C.c_void_p()
+        _check(lib().gfs_klt_pyramid_create(tracker.h, C.byref(self.h)), "gfs_klt_pyramid_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None and getattr(self.tracker, "h", None):
+            _lib.gfs_klt_pyramid_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def download(self, f=0):
+        """-> (img u8 [total], deriv i16 [total, 2]) of frame f in the layout of KltTracker.layout()."""
+        total = int(self.tracker.layout()[2][-1])
+        img = np.zeros(total, np.uint8)
+        der = np.zeros((total, 2), np.int16)
+        _check(lib().gfs_klt_pyramid_download(self.tracker.h, self.h, f, _p(img), _p(der)), "gfs_klt_pyramid_download")
+        return img, der
+
+
+class KltTracker:
+    """The optical-flow front end of the reference: cv::buildOpticalFlowPyramid (src/Frame.cc:373), cv::calcOpticalFlowPyrLK and
+    ORBmatcher::fbKltTracking (src/ORBmatcher.cc:2186-2297).  win = LKWindowSize, max_level = 3 as in Frame.cc:371."""
+
+    def __init__(self, width, height, win, max_level=3, max_batch=1, max_points=4096, device=0):
+        self.width, self.height, self.win = width, height, win
+        self.h = C.c_void_p()
+        _check(lib().gfs_klt_create(device, width, height, win, max_level, max_batch, max_points, C.byref(self.h)), "gfs_klt_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_klt_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def layout(self):
+        lw, lh, off = np.zeros(8, np.int32), np.zeros(8, np.int32), np.zeros(9, np.int64)
+        n = lib().gfs_klt_layout(self.h, _p(lw), _p(lh), _p(off))
+        if n <= 0:
+            raise GfsError("gfs_klt_layout failed")
+        return lw[:n].copy(), lh[:n].copy(), off[:n + 1].copy()
+
+    def buildOpticalFlowPyramid(self, images, pyramid=None):
+        """images: one [H, W] u8 array or a list of them -> KltPyramid (reused when given)."""
+        if isinstance(images, np.ndarray) and images.ndim == 2:
+            images = [images]
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            if im.shape != (self.height, self.width):
+                raise GfsError(f"image shape {im.shape} != {(self.height, self.width)}")
+        pyr = pyramid if pyramid is not None else KltPyramid(self)
+        ptrs = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+        _check(lib().gfs_klt_build_pyramid(self.h, pyr.h, ptrs, self.width, len(imgs)), "gfs_klt_build_pyramid")
+        return pyr
+
+    def build_pyramid_device(self, d_images, stride, B, pyramid, stream=None):
+        _check(lib().gfs_klt_build_pyramid_device(self.h, pyramid.h, C.c_void_p(d_images), stride, B,
+                                                  C.c_void_p(stream) if stream else None), "gfs_klt_build_pyramid_device")
+
+    @staticmethod
+    def _lists(pts):
+        if isinstance(pts, np.ndarray):
+            pts = [pts]
+        return [np.ascontiguousarray(p, np.float32).reshape(-1, 2) for p in pts]
+
+    def calcOpticalFlowPyrLK(self, prev, nxt, prev_pts, next_pts=None, max_level=3, max_iter=30, eps=0.01, flags=0, min_eig_thr=1e-4):
+        """Batched cv::calcOpticalFlowPyrLK: prev_pts = [n, 2] array or one per pair -> list of (next_pts, status, err) (a single
+        tuple when a single array was given)."""
+        single = isinstance(prev_pts, np.ndarray)
+        P = self._lists(prev_pts)
+        B = len(P)
+        N = [np.zeros((max(len(p), 1), 2), np.float32) for p in P]
+        if next_pts is not None:
+            for dst, src in zip(N, self._lists(next_pts)):
+                dst[:len(src)] = src
+        S = [np.zeros(max(len(p), 1), np.uint8) for p in P]
+        E = [np.zeros(max(len(p), 1), np.float32) for p in P]
+        n = np.array([len(p) for p in P], np.int32)
+        arr = lambda L: (C.c_void_p * B)(*[a.ctypes.data for a in L])
+        _check(lib().gfs_klt_track(self.h, prev.h, nxt.h, B, _p(n), arr(P), arr(N), arr(S), arr(E), max_level, max_iter, float(eps),
+                                   flags, float(min_eig_thr)), "gfs_klt_track")
+        out = [(N[b][:n[b]].copy(), S[b][:n[b]].copy(), E[b][:n[b]].copy()) for b in range(B)]
+        return out[0] if single else out
+
+    def fbKltTracking(self, prev, cur, nbpyrlvl, ferr, fmax_fbklt_dist, kps, priors):
+        """Batched ORBmatcher::fbKltTracking -> list of (priors_out, kpstatus bool, n_good) (a single tuple for a single array)."""
+        single = isinstance(kps, np.ndarray)
+        K = self._lists(kps)
+        B = len(K)
+        Pr = [np.zeros((max(len(k), 1), 2), np.float32) for k in K]
+        for dst, src in zip(Pr, self._lists(priors)):
+            dst[:len(src)] = src
+        S = [np.zeros(max(len(k), 1), np.uint8) for k in K]
+        n = np.array([len(k) for k in K], np.int32)
+        good = np.zeros(B, np.int32)
+        arr = lambda L: (C.c_void_p * B)(*[a.ctypes.data for a in L])
+        _check(lib().gfs_klt_fb_track(self.h, prev.h, cur.h, B, _p(n), arr(K), arr(Pr), arr(S), _p(good), nbpyrlvl, ferr,
+                                      fmax_fbklt_dist), "gfs_klt_fb_track")
+        out = [(Pr[b][:n[b]].copy(), S[b][:n[b]].astype(bool), int(good[b])) for b in range(B)]
+        return out[0] if single else out
+
+    def fb_track_device(self, prev, cur, B, pt_stride, d_n, d_kps, d_priors, d_kpstatus, d_n_good, nbpyrlvl=3, ferr=15.0,
+                        fmax_fbklt_dist=0.5, stream=None):
+        _check(lib().gfs_klt_fb_track_device(self.h, prev.h, cur.h, B, pt_stride, C.c_void_p(d_n), C.c_void_p(d_kps),
+                                             C.c_void_p(d_priors), C.c_void_p(d_kpstatus), C.c_void_p(d_n_good), nbpyrlvl, ferr,
+                                             fmax_fbklt_dist, C.c_void_p(stream) if stream else None), "gfs_klt_fb_track_device")
 
 
 class ProjectionMatcher:

@@ -1,0 +1,726 @@
+// Optical-flow front end on MI355X: cv::buildOpticalFlowPyramid (reference call sites src/Frame.cc:373, 505, 1415),
+// cv::calcOpticalFlowPyrLK on such pyramids and ORBmatcher::fbKltTracking (src/ORBmatcher.cc:2186-2297, identical in
+// src/Tracking.cc:3262-3366) — SURVEY.md §8(f) rank 4.  OpenCV's algorithm (video/src/lkpyramid.cpp, imgproc/src/pyramids.cpp,
+// 4.5.4 semantics) is restated in oracle/klt_oracle.cpp; this file computes the same values bit for bit.
+//
+// Pyramid: one buffer per batch, a frame = the concatenation of its padded levels (bytes) + the same layout of short2
+// derivatives.  5 launches per batch (level 0 + border, one pyrDown per level, one Scharr pass over all levels); every thread
+// produces one padded pixel, borders included, so there is no separate border pass and no intra-launch dependency.
+//
+// Tracker: ONE WAVE PER POINT, no workgroup barriers.  The win x win window is cut into runs of 4 pixels in a row; lane l
+// owns runs l, l + 64, ...  A run needs 2 x (dword + byte) unaligned loads from the image (bilinear taps of 4 pixels) instead of
+// 16 byte loads.  The template patch (I << 5, Ix, Iy as int16, 24 B per run) is private to the owning lane and parked in LDS
+// ([round][lane] layout, conflict-free b64 accesses).  All sums (A11, A12, A22, b1, b2, L1 residual) are integer sums: int32
+// per run, int64 per lane, butterfly-reduced over the wave and rounded to float once — independent of the summation order,
+// which is what makes the result reproducible and equal to the oracle.  The scalar 2x2 algebra runs redundantly in all lanes.
+// fbKltTracking's forward pass, gates, backward pass and forward-backward distance run back to back in the same wave.
+#include <memory>
+#include <mutex>
+
+#include "gfs_common.hpp"
+
+namespace {
+
+using gfs::DevBuf;
+using gfs::PinBuf;
+
+constexpr int kKltWavesPerBlock = 4;
+constexpr int kKltThreads = 64 * kKltWavesPerBlock;
+constexpr int kKltSlack = 256;  // bytes after the last level: masked tail pixels of a run may be loaded from there
+
+struct KltGeom {
+  int n_levels, win, runs, ntasks, rounds, inv_runs;
+  int width, height;
+  int lw[GFS_KLT_MAX_LEVELS], lh[GFS_KLT_MAX_LEVELS];
+  long long off[GFS_KLT_MAX_LEVELS + 1];
+  long long frame_stride;  // pixels between consecutive frames of a pyramid batch (images: bytes, derivatives: short2)
+};
+
+struct KltParams {
+  int max_level, max_iter, flags;
+  double eps2, min_eig_thr;
+};
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pyramid kernels
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_klt_level0(KltGeom G, const uint8_t* __restrict__ src, int stride, long long src_frame,
+                                                     uint8_t* __restrict__ pyr) {
+  const int pw = G.lw[0] + 2 * G.win, ph = G.lh[0] + 2 * G.win;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= pw * ph) return;
+  const int y = i / pw, x = i - y * pw;
+  const int sx = reflect101(x - G.win, G.lw[0]), sy = reflect101(y - G.win, G.lh[0]);
+  pyr[(long long)blockIdx.y * G.frame_stride + i] = src[(long long)blockIdx.y * src_frame + (long long)sy * stride + sx];
+}
+
+// Level l >= 1: pyrDown of level l - 1 (5x5 binomial, (s + 128) >> 8) for every padded pixel.  The taps reach at most two
+// pixels outside level l - 1, where its own reflect-101 border holds exactly what pyrDown's border rule would fetch.
+__global__ void __launch_bounds__(256) k_klt_pyrdown(KltGeom G, int level, uint8_t* __restrict__ pyr) {
+  const int cw = G.lw[level], ch = G.lh[level], pw = cw + 2 * G.win, ph = ch + 2 * G.win;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= pw * ph) return;
+  const int y = i / pw, x = i - y * pw;
+  const int ix = reflect101(x - G.win, cw), iy = reflect101(y - G.win, ch);
+  const int ppw = G.lw[level - 1] + 2 * G.win;
+  uint8_t* frame = pyr + (long long)blockIdx.y * G.frame_stride;
+  const uint8_t* p = frame + G.off[level - 1] + (long long)(2 * iy - 2 + G.win) * ppw + (2 * ix - 2 + G.win);
+  int s = 0;
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const uint8_t* row = p + (long long)r * ppw;
+    const int hs = row[0] + row[4] + 4 * (row[1] + row[3]) + 6 * row[2];
+    s += (r == 0 || r == 4) ? hs : (r == 2 ? 6 * hs : 4 * hs);
+  }
+  frame[G.off[level] + i] = (uint8_t)((s + 128) >> 8);
+}
+
+// calcSharrDeriv on every level at once: thread = one padded pixel of one level (zero outside the level itself).  Inside, the
+// 3x3 stencil reads the padded image, whose reflect-101 border equals calcSharrDeriv's own border rule.
+__global__ void __launch_bounds__(256) k_klt_scharr(KltGeom G, const uint8_t* __restrict__ pyr, short2* __restrict__ deriv) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= G.off[G.n_levels]) return;
+  int level = 0;
+  while (level + 1 < G.n_levels && i >= G.off[level + 1]) level++;
+  const int cw = G.lw[level], ch = G.lh[level], pw = cw + 2 * G.win;
+  const int rel = (int)(i - G.off[level]);
+  const int y = rel / pw, x = rel - y * pw;
+  short2 d = make_short2(0, 0);
+  if (x >= G.win && x < G.win + cw && y >= G.win && y < G.win + ch) {
+    const uint8_t* p = pyr + (long long)blockIdx.y * G.frame_stride + i;
+    const int a0 = p[-pw - 1], a1 = p[-pw], a2 = p[-pw + 1];
+    const int b0 = p[-1], b2 = p[1];
+    const int c0 = p[pw - 1], c1 = p[pw], c2 = p[pw + 1];
+    const int t0m = (a0 + c0) * 3 + b0 * 10, t0p = (a2 + c2) * 3 + b2 * 10;
+    const int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
+    d.x = (short)(t0p - t0m);
+    d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+  }
+  deriv[(long long)blockIdx.y * G.frame_stride + i] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tracker
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned load_u32(const uint8_t* p) {  // unaligned dword load (gfx950 runs in unaligned-access mode)
+  unsigned v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+__device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+  w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+  w01 = __float2int_rn(a * (1.f - b) * 16384.f);
+  w10 = __float2int_rn((1.f - a) * b * 16384.f);
+  w11 = 16384 - w00 - w01 - w10;
+}
+// Five bytes of two image rows -> four bilinear samples << 5 (CV_DESCALE(..., W_BITS1 - 5)).
+__device__ __forceinline__ void blend4(const uint8_t* r0, int pitch, int w00, int w01, int w10, int w11, int (&out)[4]) {
+  const unsigned a = load_u32(r0), b = load_u32(r0 + pitch);
+  const int a4 = r0[4], b4 = r0[pitch + 4];
+  int pa[5], pb[5];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    pa[i] = (a >> (8 * i)) & 0xff;
+    pb[i] = (b >> (8 * i)) & 0xff;
+  }
+  pa[4] = a4;
+  pb[4] = b4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int v = __mul24(pa[i], w00) + __mul24(pa[i + 1], w01) + __mul24(pb[i], w10) + __mul24(pb[i + 1], w11);
+    out[i] = (v + 256) >> 9;
+  }
+}
+__device__ __forceinline__ void unpack4(uint2 v, int (&o)[4]) {
+  o[0] = (short)(v.x & 0xffff);
+  o[1] = (int)v.x >> 16;
+  o[2] = (short)(v.y & 0xffff);
+  o[3] = (int)v.y >> 16;
+}
+__device__ __forceinline__ uint2 pack4(const int (&o)[4]) {
+  return make_uint2((unsigned)(o[0] & 0xffff) | ((unsigned)o[1] << 16), (unsigned)(o[2] & 0xffff) | ((unsigned)o[3] << 16));
+}
+
+// LKTrackerInvoker::operator() over the levels max_level .. 0 for one point, executed by one wave.
+// lds: this wave's 3 * rounds * 64 uint2.  All arguments and results are wave-uniform.
+__device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint8_t* __restrict__ Ipyr,
+                                const short2* __restrict__ dIpyr, const uint8_t* __restrict__ Jpyr, float2 prev, float2& next,
+                                int& status, float& err, uint2* lds, int lane) {
+  const int win = G.win;
+  const float half = (win - 1) * 0.5f;
+  uint2* sI = lds;
+  uint2* sIx = lds + G.rounds * 64;
+  uint2* sIy = lds + 2 * G.rounds * 64;
+  for (int level = P.max_level; level >= 0; level--) {
+    const int w = G.lw[level], h = G.lh[level], pitch = w + 2 * win;
+    const long long org = G.off[level] + (long long)win * pitch + win;
+    const float sc = 1.f / (float)(1 << level);
+    float px = prev.x * sc, py = prev.y * sc;
+    float nx, ny;
+    if (level == P.max_level) {
+      if (P.flags & GFS_KLT_USE_INITIAL_FLOW) {
+        nx = next.x * sc;
+        ny = next.y * sc;
+      } else {
+        nx = px;
+        ny = py;
+      }
+    } else {
+      nx = next.x * 2.f;
+      ny = next.y * 2.f;
+    }
+    next = make_float2(nx, ny);
+    px -= half;
+    py -= half;
+    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    if (ipx < -win || ipx >= w || ipy < -win || ipy >= h) {
+      if (level == 0) {
+        status = 0;
+        err = 0.f;
+      }
+      continue;
+    }
+    int w00, w01, w10, w11;
+    bilinear_weights(px - ipx, py - ipy, w00, w01, w10, w11);
+
+    // --- template patch + gradient matrix ---
+    const uint8_t* Ib = Ipyr + org + (long long)ipy * pitch + ipx;
+    const short2* dIb = dIpyr + org + (long long)ipy * pitch + ipx;
+    long long a11 = 0, a12 = 0, a22 = 0;
+    for (int r = 0; r < G.rounds; r++) {
+      const int t = r * 64 + lane;
+      int I4[4] = {0, 0, 0, 0}, X4[4] = {0, 0, 0, 0}, Y4[4] = {0, 0, 0, 0};
+      if (t < G.ntasks) {
+        const int ty = (t * G.inv_runs) >> 16, x0 = (t - ty * G.runs) * 4;
+        blend4(Ib + ty * pitch + x0, pitch, w00, w01, w10, w11, I4);
+        const short2* d0 = dIb + ty * pitch + x0;
+        const short2* d1 = d0 + pitch;
+        short2 da[5], db[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+          da[i] = d0[i];
+          db[i] = d1[i];
+        }
+        int s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          int ix = (__mul24(da[i].x, w00) + __mul24(da[i + 1].x, w01) + __mul24(db[i].x, w10) + __mul24(db[i + 1].x, w11) + 8192) >> 14;
+          int iy = (__mul24(da[i].y, w00) + __mul24(da[i + 1].y, w01) + __mul24(db[i].y, w10) + __mul24(db[i + 1].y, w11) + 8192) >> 14;
+          if (x0 + i >= win) ix = iy = I4[i] = 0;  // beyond the window: contributes nothing anywhere
+          X4[i] = ix;
+          Y4[i] = iy;
+          s11 += __mul24(ix, ix);
+          s12 += __mul24(ix, iy);
+          s22 += __mul24(iy, iy);
+        }
+        a11 += s11;
+        a12 += s12;
+        a22 += s22;
+      }
+      sI[r * 64 + lane] = pack4(I4);
+      sIx[r * 64 + lane] = pack4(X4);
+      sIy[r * 64 + lane] = pack4(Y4);
+    }
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float A11 = (float)wave_sum_i64(a11) * FLT_SCALE, A12 = (float)wave_sum_i64(a12) * FLT_SCALE,
+                A22 = (float)wave_sum_i64(a22) * FLT_SCALE;
+    float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+    const float dif = A11 - A22;
+    const float min_eig = __fsub_rn(A22 + A11, sqrtf(__fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12)))) /
+                          (float)(2 * win * win);
+    if (P.flags & GFS_KLT_GET_MIN_EIGENVALS) err = min_eig;
+    if ((double)min_eig < P.min_eig_thr || D < 1.1920928955078125e-07f) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    D = 1.f / D;
+    nx -= half;
+    ny -= half;
+    float pdx = 0.f, pdy = 0.f;
+    const uint8_t* Jb = Jpyr + org;
+    for (int j = 0; j < P.max_iter; j++) {
+      const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+      if (inx < -win || inx >= w || iny < -win || iny >= h) {
+        if (level == 0) status = 0;
+        break;
+      }
+      bilinear_weights(nx - inx, ny - iny, w00, w01, w10, w11);
+      const uint8_t* Jp = Jb + (long long)iny * pitch + inx;
+      long long b1 = 0, b2 = 0;
+      for (int r = 0; r < G.rounds; r++) {
+        const int t = r * 64 + lane;
+        if (t < G.ntasks) {
+          const int ty = (t * G.inv_runs) >> 16, x0 = (t - ty * G.runs) * 4;
+          int J4[4], I4[4], X4[4], Y4[4];
+          blend4(Jp + ty * pitch + x0, pitch, w00, w01, w10, w11, J4);
+          unpack4(sI[r * 64 + lane], I4);
+          unpack4(sIx[r * 64 + lane], X4);
+          unpack4(sIy[r * 64 + lane], Y4);
+          int s1 = 0, s2 = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int diff = J4[i] - I4[i];
+            s1 += __mul24(diff, X4[i]);
+            s2 += __mul24(diff, Y4[i]);
+          }
+          b1 += s1;
+          b2 += s2;
+        }
+      }
+      const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE, fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
+      const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
+      const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
+      nx += dx;
+      ny += dy;
+      next = make_float2(nx + half, ny + half);
+      if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= P.eps2) break;
+      if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+        next.x = __fsub_rn(next.x, __fmul_rn(dx, 0.5f));
+        next.y = __fsub_rn(next.y, __fmul_rn(dy, 0.5f));
+        break;
+      }
+      pdx = dx;
+      pdy = dy;
+    }
+    if (status && level == 0 && !(P.flags & GFS_KLT_GET_MIN_EIGENVALS)) {  // L1 residual of the final position
+      const float ex = next.x - half, ey = next.y - half;
+      const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+      if (iex < -win || iex >= w || iey < -win || iey >= h) {
+        status = 0;
+        continue;
+      }
+      bilinear_weights(ex - iex, ey - iey, w00, w01, w10, w11);
+      const uint8_t* Jp = Jb + (long long)iey * pitch + iex;
+      long long e = 0;
+      for (int r = 0; r < G.rounds; r++) {
+        const int t = r * 64 + lane;
+        if (t < G.ntasks) {
+          const int ty = (t * G.inv_runs) >> 16, x0 = (t - ty * G.runs) * 4;
+          int J4[4], I4[4];
+          blend4(Jp + ty * pitch + x0, pitch, w00, w01, w10, w11, J4);
+          unpack4(sI[r * 64 + lane], I4);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (x0 + i < win) e += abs(J4[i] - I4[i]);
+        }
+      }
+      err = __fmul_rn((float)wave_sum_i64(e), 1.f) / (float)(32 * win * win);
+    }
+  }
+}
+
+// calcOpticalFlowPyrLK for B pairs: wave = one point.  pts layouts: [B][pt_stride] float2.
+__global__ void __launch_bounds__(kKltThreads) k_klt_track(KltGeom G, KltParams P, const uint8_t* __restrict__ prev_img,
+                                                           const short2* __restrict__ prev_deriv,
+                                                           const uint8_t* __restrict__ next_img, const int* __restrict__ n_pts,
+                                                           int pt_stride, const float2* __restrict__ prev_pts,
+                                                           float2* __restrict__ next_pts, uint8_t* __restrict__ status_out,
+                                                           float* __restrict__ err_out) {
+  extern __shared__ uint2 s_klt[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.y;
+  const int i = blockIdx.x * kKltWavesPerBlock + wave;
+  if (i >= n_pts[f]) return;
+  const long long fo = (long long)f * G.frame_stride, po = (long long)f * pt_stride + i;
+  float2 next = (P.flags & GFS_KLT_USE_INITIAL_FLOW) ? next_pts[po] : make_float2(0.f, 0.f);
+  int status = 1;
+  float err = 0.f;
+  klt_track_point(G, P, prev_img + fo, prev_deriv + fo, next_img + fo, prev_pts[po], next, status, err,
+                  s_klt + wave * 3 * G.rounds * 64, lane);
+  if (lane == 0) {
+    next_pts[po] = next;
+    status_out[po] = (uint8_t)status;
+    err_out[po] = err;
+  }
+}
+
+// fbKltTracking for B pairs: forward (prev -> cur, nbpyrlvl levels), gates (status, err > ferr, inBorder), backward
+// (cur -> prev, level 0, started from the original key point), forward-backward distance.  Wave = one point.
+__global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, const uint8_t* __restrict__ prev_img,
+                                                        const short2* __restrict__ prev_deriv, const uint8_t* __restrict__ cur_img,
+                                                        const short2* __restrict__ cur_deriv, const int* __restrict__ n_pts,
+                                                        int pt_stride, const float2* __restrict__ kps, float2* __restrict__ priors,
+                                                        uint8_t* __restrict__ kpstatus, int* __restrict__ n_good, float ferr,
+                                                        float fmax_fbklt_dist) {
+  extern __shared__ uint2 s_klt[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.y;
+  const int i = blockIdx.x * kKltWavesPerBlock + wave;
+  if (i >= n_pts[f]) return;
+  uint2* lds = s_klt + wave * 3 * G.rounds * 64;
+  const long long fo = (long long)f * G.frame_stride, po = (long long)f * pt_stride + i;
+  const float2 kp = kps[po];
+  float2 fwd = priors[po];
+  int status = 1;
+  float err = 0.f;
+  klt_track_point(G, P, prev_img + fo, prev_deriv + fo, cur_img + fo, kp, fwd, status, err, lds, lane);
+  bool ok = status && !(err > ferr) && 1.f <= fwd.x && fwd.x < (float)G.width - 1.f && 1.f <= fwd.y && fwd.y < (float)G.height - 1.f;
+  if (ok) {
+    KltParams Pb = P;
+    Pb.max_level = 0;
+    float2 back = kp;
+    int bstatus = 1;
+    float berr = 0.f;
+    klt_track_point(G, Pb, cur_img + fo, cur_deriv + fo, prev_img + fo, fwd, back, bstatus, berr, lds, lane);
+    if (!bstatus) {
+      ok = false;
+    } else {
+      const float dx = kp.x - back.x, dy = kp.y - back.y;
+      ok = !(__dsqrt_rn(__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy))) > (double)fmax_fbklt_dist);
+    }
+  }
+  if (lane == 0) {
+    priors[po] = fwd;
+    kpstatus[po] = ok ? 1 : 0;
+    if (ok) atomicAdd(n_good + f, 1);
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+struct gfs_klt {
+  int device = 0, max_batch = 0, max_points = 0;
+  KltGeom G{};
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  size_t lds_bytes = 0;
+  DevBuf<uint8_t> d_images;  // staging for host images
+  PinBuf<uint8_t> h_images;
+  DevBuf<float2> d_a, d_b;   // prev / next (kps / priors)
+  DevBuf<uint8_t> d_status;
+  DevBuf<float> d_err;
+  DevBuf<int> d_n, d_good;
+  PinBuf<float2> h_a, h_b;
+  PinBuf<uint8_t> h_status;
+  PinBuf<float> h_err;
+  PinBuf<int> h_n, h_good;
+};
+
+struct gfs_klt_pyramid {
+  gfs_klt* owner = nullptr;
+  DevBuf<uint8_t> img;
+  DevBuf<short2> deriv;
+  int n_frames = 0;
+};
+
+namespace {
+int klt_build(gfs_klt* h, gfs_klt_pyramid* pyr, const uint8_t* dev_images, int stride, int B, hipStream_t s) {
+  const KltGeom& G = h->G;
+  const int pw0 = G.lw[0] + 2 * G.win, ph0 = G.lh[0] + 2 * G.win;
+  GFS_LAUNCH("k_klt_level0", k_klt_level0, dim3(gfs::div_up(pw0 * ph0, 256), B), dim3(256), 0, s, G, dev_images, stride,
+             (long long)stride * G.height, pyr->img.p);
+  for (int l = 1; l < G.n_levels; l++) {
+    const int n = (G.lw[l] + 2 * G.win) * (G.lh[l] + 2 * G.win);
+    GFS_LAUNCH("k_klt_pyrdown", k_klt_pyrdown, dim3(gfs::div_up(n, 256), B), dim3(256), 0, s, G, l, pyr->img.p);
+  }
+  GFS_LAUNCH("k_klt_scharr", k_klt_scharr, dim3((unsigned)((G.off[G.n_levels] + 255) / 256), B), dim3(256), 0, s, G,
+             (const uint8_t*)pyr->img.p, pyr->deriv.p);
+  pyr->n_frames = B;
+  return GFS_OK;
+}
+
+KltParams fb_params(const gfs_klt* h, int nbpyrlvl) {
+  KltParams P;
+  P.max_level = nbpyrlvl < 0 ? 0 : (nbpyrlvl > h->G.n_levels - 1 ? h->G.n_levels - 1 : nbpyrlvl);  // calcOpticalFlowPyrLK clamps
+  P.max_iter = 30;
+  const double e = (double)0.01f;  // src/ORBmatcher.cc:2217-2221
+  P.eps2 = e * e;
+  P.flags = GFS_KLT_USE_INITIAL_FLOW | GFS_KLT_GET_MIN_EIGENVALS;  // :2227
+  P.min_eig_thr = 1e-4;
+  return P;
+}
+}  // namespace
+
+extern "C" {
+
+int gfs_klt_create(int device, int width, int height, int win, int max_level, int max_batch, int max_points, gfs_klt** out) {
+  GFS_REQUIRE(out, GFS_ERR_INVALID_ARG, "gfs_klt_create: out is NULL");
+  *out = nullptr;
+  GFS_REQUIRE(width > 0 && height > 0 && win >= 3 && win <= 63 && max_level >= 0 && max_batch > 0 && max_points > 0,
+              GFS_ERR_INVALID_ARG, "gfs_klt_create: invalid argument (window 3 .. 63)");
+  GFS_REQUIRE(width <= 8192 && height <= 8192, GFS_ERR_CAPACITY, "gfs_klt_create: image larger than 8192 x 8192");
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  auto h = std::make_unique<gfs_klt>();
+  h->device = device;
+  h->max_batch = max_batch;
+  h->max_points = max_points;
+  KltGeom& G = h->G;
+  G.win = win;
+  G.width = width;
+  G.height = height;
+  G.runs = (win + 3) / 4;
+  G.ntasks = G.runs * win;
+  G.rounds = (G.ntasks + 63) / 64;
+  G.inv_runs = (65536 + G.runs - 1) / G.runs;
+  int cw = width, ch = height;
+  G.off[0] = 0;
+  if (max_level > GFS_KLT_MAX_LEVELS - 1) max_level = GFS_KLT_MAX_LEVELS - 1;
+  for (int l = 0; l <= max_level; l++) {  // buildOpticalFlowPyramid: the next level only while it is larger than the window
+    G.lw[l] = cw;
+    G.lh[l] = ch;
+    G.off[l + 1] = G.off[l] + (long long)(cw + 2 * win) * (ch + 2 * win);
+    G.n_levels = l + 1;
+    cw = (cw + 1) / 2;
+    ch = (ch + 1) / 2;
+    if (cw <= win || ch <= win) break;
+  }
+  G.frame_stride = (long long)gfs::align_up((size_t)G.off[G.n_levels] + kKltSlack, 256);
+  h->lds_bytes = (size_t)kKltWavesPerBlock * 3 * G.rounds * 64 * sizeof(uint2);
+  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_track, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+  GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t NP = (size_t)max_batch * max_points, NI = (size_t)max_batch * width * height;
+  int rc = 0;
+#define A(x) if (!rc) rc = (x)
+  A(h->d_images.alloc(NI));
+  A(h->h_images.alloc(NI));
+  A(h->d_a.alloc(NP));
+  A(h->d_b.alloc(NP));
+  A(h->d_status.alloc(NP));
+  A(h->d_err.alloc(NP));
+  A(h->d_n.alloc(max_batch));
+  A(h->d_good.alloc(max_batch));
+  A(h->h_a.alloc(NP));
+  A(h->h_b.alloc(NP));
+  A(h->h_status.alloc(NP));
+  A(h->h_err.alloc(NP));
+  A(h->h_n.alloc(max_batch));
+  A(h->h_good.alloc(max_batch));
+#undef A
+  if (rc) {
+    (void)hipStreamDestroy(h->stream);
+    return rc;
+  }
+  *out = h.release();
+  return GFS_OK;
+}
+
+void gfs_klt_destroy(gfs_klt* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int gfs_klt_layout(const gfs_klt* h, int32_t* lw, int32_t* lh, int64_t* off) {
+  GFS_REQUIRE(h, GFS_ERR_INVALID_ARG, "gfs_klt_layout: NULL handle");
+  for (int l = 0; l < h->G.n_levels; l++) {
+    if (lw) lw[l] = h->G.lw[l];
+    if (lh) lh[l] = h->G.lh[l];
+  }
+  if (off)
+    for (int l = 0; l <= h->G.n_levels; l++) off[l] = h->G.off[l];
+  return h->G.n_levels;
+}
+
+int gfs_klt_pyramid_create(gfs_klt* h, gfs_klt_pyramid** out) {
+  GFS_REQUIRE(h && out, GFS_ERR_INVALID_ARG, "gfs_klt_pyramid_create: invalid argument");
+  *out = nullptr;
+  GFS_HIP(hipSetDevice(h->device));
+  auto p = std::make_unique<gfs_klt_pyramid>();
+  p->owner = h;
+  const size_t n = (size_t)h->G.frame_stride * h->max_batch;
+  int rc = p->img.alloc(n);
+  if (!rc) rc = p->deriv.alloc(n);
+  if (rc) return rc;
+  GFS_HIP(hipMemset(p->img.p, 0, n));
+  GFS_HIP(hipMemset(p->deriv.p, 0, n * sizeof(short2)));
+  *out = p.release();
+  return GFS_OK;
+}
+
+void gfs_klt_pyramid_destroy(gfs_klt_pyramid* p) {
+  if (!p) return;
+  if (p->owner) {
+    (void)hipSetDevice(p->owner->device);
+    (void)hipStreamSynchronize(p->owner->stream);
+  }
+  delete p;
+}
+
+int gfs_klt_build_pyramid(gfs_klt* h, gfs_klt_pyramid* pyr, const uint8_t* const* images, int stride, int B) {
+  GFS_REQUIRE(h && pyr && images && B > 0, GFS_ERR_INVALID_ARG, "gfs_klt_build_pyramid: invalid argument");
+  GFS_REQUIRE(pyr->owner == h, GFS_ERR_INVALID_ARG, "gfs_klt_build_pyramid: the pyramid belongs to another tracker");
+  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_klt_build_pyramid: batch %d exceeds capacity %d", B, h->max_batch);
+  GFS_REQUIRE(stride >= h->G.width, GFS_ERR_INVALID_ARG, "gfs_klt_build_pyramid: stride %d < width %d", stride, h->G.width);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  const int W = h->G.width, H = h->G.height;
+  for (int f = 0; f < B; f++) {
+    GFS_REQUIRE(images[f], GFS_ERR_INVALID_ARG, "gfs_klt_build_pyramid: image %d is NULL", f);
+    for (int y = 0; y < H; y++) memcpy(h->h_images.p + ((size_t)f * H + y) * W, images[f] + (size_t)y * stride, W);
+  }
+  GFS_HIP(hipMemcpyAsync(h->d_images.p, h->h_images.p, (size_t)B * W * H, hipMemcpyHostToDevice, h->stream));
+  const int rc = klt_build(h, pyr, h->d_images.p, W, B, h->stream);
+  if (rc) return rc;
+  GFS_HIP(hipStreamSynchronize(h->stream));
+  return GFS_OK;
+}
+
+int gfs_klt_build_pyramid_device(gfs_klt* h, gfs_klt_pyramid* pyr, const void* dev_images, int stride, int B, void* stream) {
+  GFS_REQUIRE(h && pyr && dev_images && B > 0, GFS_ERR_INVALID_ARG, "gfs_klt_build_pyramid_device: invalid argument");
+  GFS_REQUIRE(pyr->owner == h, GFS_ERR_INVALID_ARG, "gfs_klt_build_pyramid_device: the pyramid belongs to another tracker");
+  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_klt_build_pyramid_device: batch %d exceeds capacity %d", B, h->max_batch);
+  GFS_REQUIRE(stride >= h->G.width, GFS_ERR_INVALID_ARG, "gfs_klt_build_pyramid_device: stride %d < width %d", stride, h->G.width);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const int rc = klt_build(h, pyr, (const uint8_t*)dev_images, stride, B, s);
+  if (rc) return rc;
+  if (!stream) GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+int gfs_klt_pyramid_download(gfs_klt* h, const gfs_klt_pyramid* pyr, int f, uint8_t* img, int16_t* deriv) {
+  GFS_REQUIRE(h && pyr && pyr->owner == h && (img || deriv), GFS_ERR_INVALID_ARG, "gfs_klt_pyramid_download: invalid argument");
+  GFS_REQUIRE(f >= 0 && f < pyr->n_frames, GFS_ERR_INVALID_ARG, "gfs_klt_pyramid_download: frame %d of %d", f, pyr->n_frames);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  GFS_HIP(hipStreamSynchronize(h->stream));
+  const size_t n = (size_t)h->G.off[h->G.n_levels], o = (size_t)f * h->G.frame_stride;
+  if (img) GFS_HIP(hipMemcpy(img, pyr->img.p + o, n, hipMemcpyDeviceToHost));
+  if (deriv) GFS_HIP(hipMemcpy(deriv, pyr->deriv.p + o, n * sizeof(short2), hipMemcpyDeviceToHost));
+  return GFS_OK;
+}
+
+int gfs_klt_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid* next, int B, const int32_t* n_points,
+                  const float* const* prev_pts, float* const* next_pts, uint8_t* const* status, float* const* err, int max_level,
+                  int max_iter, double eps, int flags, double min_eig_thr) {
+  GFS_REQUIRE(h && prev && next && n_points && prev_pts && next_pts && status && err && B > 0, GFS_ERR_INVALID_ARG,
+              "gfs_klt_track: invalid argument");
+  GFS_REQUIRE(prev->owner == h && next->owner == h, GFS_ERR_INVALID_ARG, "gfs_klt_track: pyramid of another tracker");
+  GFS_REQUIRE(B <= h->max_batch && B <= prev->n_frames && B <= next->n_frames, GFS_ERR_CAPACITY,
+              "gfs_klt_track: batch %d exceeds the capacity %d or the frames held (%d / %d)", B, h->max_batch, prev->n_frames,
+              next->n_frames);
+  GFS_REQUIRE((flags & ~(GFS_KLT_USE_INITIAL_FLOW | GFS_KLT_GET_MIN_EIGENVALS)) == 0, GFS_ERR_INVALID_ARG,
+              "gfs_klt_track: unknown flag bits 0x%x", flags);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  const int S = h->max_points;
+  int nmax = 0;
+  for (int f = 0; f < B; f++) {
+    const int n = n_points[f];
+    GFS_REQUIRE(n >= 0 && n <= S, GFS_ERR_CAPACITY, "gfs_klt_track: pair %d has %d points, capacity %d", f, n, S);
+    GFS_REQUIRE(n == 0 || (prev_pts[f] && next_pts[f] && status[f] && err[f]), GFS_ERR_INVALID_ARG, "gfs_klt_track: pair %d has NULL arrays", f);
+    h->h_n.p[f] = n;
+    if (n) memcpy(h->h_a.p + (size_t)f * S, prev_pts[f], (size_t)n * sizeof(float2));
+    if (n && (flags & GFS_KLT_USE_INITIAL_FLOW)) memcpy(h->h_b.p + (size_t)f * S, next_pts[f], (size_t)n * sizeof(float2));
+    nmax = n > nmax ? n : nmax;
+  }
+  if (nmax == 0) return GFS_OK;
+  KltParams P;
+  P.max_level = max_level < 0 ? 0 : (max_level > h->G.n_levels - 1 ? h->G.n_levels - 1 : max_level);
+  P.max_iter = max_iter < 0 ? 0 : (max_iter > 100 ? 100 : max_iter);
+  const double e = eps < 0 ? 0 : (eps > 10 ? 10 : eps);
+  P.eps2 = e * e;
+  P.flags = flags;
+  P.min_eig_thr = min_eig_thr;
+  hipStream_t s = h->stream;
+  const size_t NP = (size_t)B * S;
+  GFS_HIP(hipMemcpyAsync(h->d_n.p, h->h_n.p, B * sizeof(int), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_a.p, h->h_a.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  if (flags & GFS_KLT_USE_INITIAL_FLOW) GFS_HIP(hipMemcpyAsync(h->d_b.p, h->h_b.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  GFS_LAUNCH("k_klt_track", k_klt_track, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,
+             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)next->img.p, (const int*)h->d_n.p, S,
+             (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_err.p);
+  GFS_HIP(hipMemcpyAsync(h->h_b.p, h->d_b.p, NP * sizeof(float2), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_status.p, h->d_status.p, NP, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_err.p, h->d_err.p, NP * sizeof(float), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int f = 0; f < B; f++) {
+    const int n = n_points[f];
+    if (!n) continue;
+    memcpy(next_pts[f], h->h_b.p + (size_t)f * S, (size_t)n * sizeof(float2));
+    memcpy(status[f], h->h_status.p + (size_t)f * S, (size_t)n);
+    memcpy(err[f], h->h_err.p + (size_t)f * S, (size_t)n * sizeof(float));
+  }
+  return GFS_OK;
+}
+
+int gfs_klt_fb_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid* cur, int B, const int32_t* n_points,
+                     const float* const* kps, float* const* priors, uint8_t* const* kpstatus, int32_t* n_good, int nbpyrlvl,
+                     float ferr, float fmax_fbklt_dist) {
+  GFS_REQUIRE(h && prev && cur && n_points && kps && priors && kpstatus && n_good && B > 0, GFS_ERR_INVALID_ARG,
+              "gfs_klt_fb_track: invalid argument");
+  GFS_REQUIRE(prev->owner == h && cur->owner == h, GFS_ERR_INVALID_ARG, "gfs_klt_fb_track: pyramid of another tracker");
+  GFS_REQUIRE(B <= h->max_batch && B <= prev->n_frames && B <= cur->n_frames, GFS_ERR_CAPACITY,
+              "gfs_klt_fb_track: batch %d exceeds the capacity %d or the frames held (%d / %d)", B, h->max_batch, prev->n_frames,
+              cur->n_frames);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  const int S = h->max_points;
+  int nmax = 0;
+  for (int f = 0; f < B; f++) {
+    const int n = n_points[f];
+    GFS_REQUIRE(n >= 0 && n <= S, GFS_ERR_CAPACITY, "gfs_klt_fb_track: pair %d has %d points, capacity %d", f, n, S);
+    GFS_REQUIRE(n == 0 || (kps[f] && priors[f] && kpstatus[f]), GFS_ERR_INVALID_ARG, "gfs_klt_fb_track: pair %d has NULL arrays", f);
+    h->h_n.p[f] = n;
+    n_good[f] = 0;
+    if (n) {
+      memcpy(h->h_a.p + (size_t)f * S, kps[f], (size_t)n * sizeof(float2));
+      memcpy(h->h_b.p + (size_t)f * S, priors[f], (size_t)n * sizeof(float2));
+    }
+    nmax = n > nmax ? n : nmax;
+  }
+  if (nmax == 0) return GFS_OK;
+  const KltParams P = fb_params(h, nbpyrlvl);
+  hipStream_t s = h->stream;
+  const size_t NP = (size_t)B * S;
+  GFS_HIP(hipMemcpyAsync(h->d_n.p, h->h_n.p, B * sizeof(int), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_a.p, h->h_a.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_b.p, h->h_b.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemsetAsync(h->d_good.p, 0, B * sizeof(int), s));
+  GFS_LAUNCH("k_klt_fb", k_klt_fb, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,
+             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,
+             (const int*)h->d_n.p, S, (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_good.p, ferr, fmax_fbklt_dist);
+  GFS_HIP(hipMemcpyAsync(h->h_b.p, h->d_b.p, NP * sizeof(float2), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_status.p, h->d_status.p, NP, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_good.p, h->d_good.p, B * sizeof(int), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int f = 0; f < B; f++) {
+    const int n = n_points[f];
+    n_good[f] = n ? h->h_good.p[f] : 0;
+    if (!n) continue;
+    memcpy(priors[f], h->h_b.p + (size_t)f * S, (size_t)n * sizeof(float2));
+    memcpy(kpstatus[f], h->h_status.p + (size_t)f * S, (size_t)n);
+  }
+  return GFS_OK;
+}
+
+int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid* cur, int B, int pt_stride,
+                            const void* dev_n, const void* dev_kps, void* dev_priors, void* dev_kpstatus, void* dev_n_good,
+                            int nbpyrlvl, float ferr, float fmax_fbklt_dist, void* stream) {
+  GFS_REQUIRE(h && prev && cur && dev_n && dev_kps && dev_priors && dev_kpstatus && dev_n_good && B > 0 && pt_stride > 0,
+              GFS_ERR_INVALID_ARG, "gfs_klt_fb_track_device: invalid argument");
+  GFS_REQUIRE(prev->owner == h && cur->owner == h, GFS_ERR_INVALID_ARG, "gfs_klt_fb_track_device: pyramid of another tracker");
+  GFS_REQUIRE(B <= h->max_batch && B <= prev->n_frames && B <= cur->n_frames, GFS_ERR_CAPACITY,
+              "gfs_klt_fb_track_device: batch %d exceeds the capacity %d or the frames held (%d / %d)", B, h->max_batch,
+              prev->n_frames, cur->n_frames);
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const KltParams P = fb_params(h, nbpyrlvl);
+  GFS_HIP(hipMemsetAsync(dev_n_good, 0, B * sizeof(int), s));
+  GFS_LAUNCH("k_klt_fb", k_klt_fb, dim3(gfs::div_up(pt_stride, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,
+             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,
+             (const int*)dev_n, pt_stride, (const float2*)dev_kps, (float2*)dev_priors, (uint8_t*)dev_kpstatus, (int*)dev_n_good,
+             ferr, fmax_fbklt_dist);
+  if (!stream) GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+}  // extern "C"

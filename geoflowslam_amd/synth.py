@@ -378,3 +378,41 @@ def _rot_from_quat(q):
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def klt_texture_pair(seed, width=640, height=480, shift=(3.3, -2.1), rot_deg=0.0, gain=1.0, noise=1):
+    """Two views of one analytic texture: image 1 samples the texture at R(p - c) + c + shift, so a point p in image 0 is seen at
+    p' = R^T(p - c - shift) + c ... in image 1 (returned as the callable `flow`).  -> (img0, img1, flow)."""
+    rng = np.random.default_rng(seed)
+    nwave = 24
+    k = rng.uniform(0.02, 0.45, (nwave, 2)) * rng.choice([-1, 1], (nwave, 2))
+    ph = rng.uniform(0, 6.28, nwave)
+    amp = rng.uniform(6, 22, nwave)
+    base = rng.uniform(90, 150)
+    th = np.deg2rad(rot_deg)
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    c = np.array([width / 2.0, height / 2.0])
+
+    def tex(x, y):
+        v = np.full(x.shape, base)
+        for i in range(nwave):
+            v += amp[i] * np.sin(k[i, 0] * x + k[i, 1] * y + ph[i])
+        return v
+
+    u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+    img0 = tex(u, v)
+    # image 1 pixel q shows the texture point R (q - c) + c + shift
+    q = np.stack([u - c[0], v - c[1]], -1) @ R.T
+    img1 = gain * tex(q[..., 0] + c[0] + shift[0], q[..., 1] + c[1] + shift[1])
+    nrng = np.random.default_rng(seed + 17)
+    if noise:
+        img0 = img0 + nrng.integers(-noise, noise + 1, img0.shape)
+        img1 = img1 + nrng.integers(-noise, noise + 1, img1.shape)
+
+    def flow(p):
+        """Position in image 1 of the texture point seen at p ([n, 2]) in image 0."""
+        p = np.asarray(p, np.float64)
+        return (p - c - np.asarray(shift)) @ R + c
+
+    to_u8 = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    return to_u8(img0), to_u8(img1), flow

@@ -1,7 +1,7 @@
 /* gfs_abi.h — C ABI of the MI355X-native GeoFlow-SLAM front-end hot path (libgfs_hip.so).
  *
  * This is the drop-in boundary.  The reference has no FFI layer: the seams are four
- * ordinary C++ methods (sections 1-4), followed by the neighbouring rows of SURVEY.md §8(f) (sections 5-8).  Each entry point below names the reference interface it replaces
+ * ordinary C++ methods (sections 1-4), followed by the neighbouring rows of SURVEY.md §8(f) (sections 5-9).  Each entry point below names the reference interface it replaces
  * (file:line in HorizonRobotics/GeoFlowSlam).  Signatures are plain C: pointers, sizes, POD structs.
  * No torch / OpenCV / Eigen types cross this boundary.  INTEGRATION.md shows the reference-side
  * adaptor (what a maintainer adds to src/ORBextractor.cc etc. to call these).
@@ -401,6 +401,53 @@ int gfs_gms_inlier_mask(gfs_gms* h, const gfs_gms_problem* problems, int B, uint
 int gfs_gms_inlier_mask_batch_device(gfs_gms* h, const void* dev_kps1, const void* dev_n1, const void* dev_kps2, const void* dev_n2,
                                      int B, int kp_stride, const void* dev_train_idx, int width, int height, void* dev_mask,
                                      void* dev_counts, void* stream);
+
+/* ============================================================================================
+ * 9. Optical-flow front end (the "GeoFlow" stream): replaces
+ *      cv::buildOpticalFlowPyramid(image, mImGray, Size(w, w), 3)             src/Frame.cc:373, 505, 1415
+ *      cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, ...)                         src/ORBmatcher.cc:2224, 2271; src/Tracking.cc:3298, 3342
+ *      ORBmatcher::fbKltTracking / Tracking::fbKltTracking                     src/ORBmatcher.cc:2186-2297; src/Tracking.cc:3262-3366
+ *    (the projection of the priors, the mask bookkeeping and cv::findFundamentalMat of SearchByProjectionWithOF,
+ *    src/ORBmatcher.cc:2304-2497, stay with the caller).  A gfs_klt_pyramid holds the pyramids of up to max_batch frames in HBM:
+ *    level l of a frame is an image of (lw[l] + 2*win) x (lh[l] + 2*win) bytes at byte offset off[l] (BORDER_REFLECT_101 border
+ *    of win pixels) plus as many short2 (Scharr dx, dy; zero border); a level is built while both sides exceed the window, as
+ *    OpenCV does.  A frame's pyramid is built once and used as `cur` for one pair and as `prev` for the next.
+ *    Sums of the 2x2 system are exact integer sums rounded once: bit-equal to oracle/klt_oracle.cpp.
+ * ============================================================================================ */
+#define GFS_KLT_MAX_LEVELS 8
+#define GFS_KLT_USE_INITIAL_FLOW 4   /* cv::OPTFLOW_USE_INITIAL_FLOW */
+#define GFS_KLT_GET_MIN_EIGENVALS 8  /* cv::OPTFLOW_LK_GET_MIN_EIGENVALS */
+typedef struct gfs_klt gfs_klt;
+typedef struct gfs_klt_pyramid gfs_klt_pyramid;
+/* win = LKWindowSize (3 .. 63), max_level = the maxLevel given to buildOpticalFlowPyramid (the reference: 3). */
+int gfs_klt_create(int device, int width, int height, int win, int max_level, int max_batch, int max_points, gfs_klt** out);
+void gfs_klt_destroy(gfs_klt* h);
+/* Number of levels held; lw / lh [levels] and off [levels + 1] may be NULL.  off[levels] = bytes of one frame's images. */
+int gfs_klt_layout(const gfs_klt* h, int32_t* lw, int32_t* lh, int64_t* off);
+int gfs_klt_pyramid_create(gfs_klt* h, gfs_klt_pyramid** out);
+void gfs_klt_pyramid_destroy(gfs_klt_pyramid* p);
+/* cv::buildOpticalFlowPyramid for B frames: images[f] = host pointer to height rows of `stride` bytes. */
+int gfs_klt_build_pyramid(gfs_klt* h, gfs_klt_pyramid* pyr, const uint8_t* const* images, int stride, int B);
+/* Same from device memory: dev_images = [B][height][stride] bytes; asynchronous on `stream` when it is not NULL. */
+int gfs_klt_build_pyramid_device(gfs_klt* h, gfs_klt_pyramid* pyr, const void* dev_images, int stride, int B, void* stream);
+/* Copies frame f's pyramid to the host: img [off[levels]] bytes, deriv [off[levels] * 2] int16 (parity tests). */
+int gfs_klt_pyramid_download(gfs_klt* h, const gfs_klt_pyramid* pyr, int f, uint8_t* img, int16_t* deriv);
+/* cv::calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err, Size(win, win), max_level,
+ * TermCriteria(COUNT + EPS, max_iter, eps), flags, min_eig_thr) for B pairs; n_points[f] <= max_points;
+ * prev_pts[f] / next_pts[f]: n x 2 floats (next_pts is read when GFS_KLT_USE_INITIAL_FLOW is set). */
+int gfs_klt_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid* next, int B, const int32_t* n_points,
+                  const float* const* prev_pts, float* const* next_pts, uint8_t* const* status, float* const* err, int max_level,
+                  int max_iter, double eps, int flags, double min_eig_thr);
+/* fbKltTracking(prev, cur, win, nbpyrlvl, ferr, fmax_fbklt_dist, kps, priors, kpstatus) for B pairs, both passes and the gates
+ * in one kernel: priors[f] in/out (vpriorkps), kpstatus[f][i] 0 / 1, n_good[f] = points that survive both passes. */
+int gfs_klt_fb_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid* cur, int B, const int32_t* n_points,
+                     const float* const* kps, float* const* priors, uint8_t* const* kpstatus, int32_t* n_good, int nbpyrlvl,
+                     float ferr, float fmax_fbklt_dist);
+/* Device-resident form: dev_kps / dev_priors [B][pt_stride][2] float, dev_n [B] int32, dev_kpstatus [B][pt_stride] u8,
+ * dev_n_good [B] int32; asynchronous on `stream` when it is not NULL. */
+int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid* cur, int B, int pt_stride,
+                            const void* dev_n, const void* dev_kps, void* dev_priors, void* dev_kpstatus, void* dev_n_good,
+                            int nbpyrlvl, float ferr, float fmax_fbklt_dist, void* stream);
 
 /* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel

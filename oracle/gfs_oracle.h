@@ -239,6 +239,29 @@ int gfso_search_by_projection_map(const gfso_sbp_map_problem*, int32_t* cur_matc
 int gfso_gms_inlier_mask(const float* kp1_xy, int n1, int width1, int height1, const float* kp2_xy, int n2, int width2,
                          int height2, const int32_t* query_idx, const int32_t* train_idx, int n_matches, uint8_t* inlier);
 
+/* ---- optical-flow front end: cv::buildOpticalFlowPyramid (src/Frame.cc:373,505,1415), cv::calcOpticalFlowPyrLK and
+ *      ORBmatcher::fbKltTracking (src/ORBmatcher.cc:2186-2297) == Tracking::fbKltTracking (src/Tracking.cc:3262-3366).
+ *      Pyramid storage (shared with the HIP path so whole buffers can be compared): level l is an image of
+ *      (lw[l] + 2*win) x (lh[l] + 2*win) bytes at byte offset off[l] of pyr_img (reflect-101 border), and the same number of
+ *      short2 (Scharr dx, dy; zero border) at element offset off[l] of pyr_deriv.  See klt_oracle.cpp for the one deliberate
+ *      difference to OpenCV (exact integer sums instead of build-dependent float summation). ---- */
+#define GFSO_KLT_MAX_LEVELS 8
+#define GFSO_KLT_USE_INITIAL_FLOW 4   /* cv::OPTFLOW_USE_INITIAL_FLOW */
+#define GFSO_KLT_GET_MIN_EIGENVALS 8  /* cv::OPTFLOW_LK_GET_MIN_EIGENVALS */
+/* Returns the number of levels buildOpticalFlowPyramid(…, maxLevel) produces; lw/lh [levels], off [levels + 1] (may be NULL). */
+int gfso_klt_layout(int w, int h, int win, int max_level, int32_t* lw, int32_t* lh, int64_t* off);
+int gfso_klt_build_pyramid(const uint8_t* img, int w, int h, int stride, int win, int max_level, uint8_t* pyr_img,
+                           int16_t* pyr_deriv);
+/* calcOpticalFlowPyrLK(prevPyr, nextPyr, prevPts, nextPts, status, err, Size(win, win), maxLevel,
+ * TermCriteria(COUNT + EPS, max_iter, eps), flags, minEigThreshold); pyramids built with pyr_max_level. */
+int gfso_klt_track(const uint8_t* prev_img, const int16_t* prev_deriv, const uint8_t* next_img, int w, int h, int win,
+                   int pyr_max_level, int max_level, int n, const float* prev_pts, float* next_pts, uint8_t* status, float* err,
+                   int max_iter, double eps, int flags, double min_eig_thr);
+/* fbKltTracking: priors in/out (vpriorkps), kpstatus[n] out; returns the number of points that survive both passes. */
+int gfso_fb_klt_tracking(const uint8_t* prev_img, const int16_t* prev_deriv, const uint8_t* cur_img, const int16_t* cur_deriv, int w,
+                         int h, int win, int pyr_max_level, int nbpyrlvl, float ferr, float fmax_fbklt_dist, int n, const float* kps,
+                         float* priors, uint8_t* kpstatus);
+
 #ifdef __cplusplus
 }
 #endif

@@ -533,3 +533,69 @@ def stereo_from_rgbd(kps, depth, bf, kps_un_x=None):
     unx = np.ascontiguousarray(kps_un_x, np.float32) if kps_un_x is not None else None
     L.gfso_stereo_from_rgbd(_p(kps), _p(unx) if unx is not None else None, n, _p(depth), depth.shape[1], bf, _p(ur), _p(vd))
     return ur[:n], vd[:n]
+
+
+KLT_USE_INITIAL_FLOW, KLT_GET_MIN_EIGENVALS = 4, 8
+
+
+def klt_layout(width, height, win, max_level=3):
+    """Level sizes and offsets of cv::buildOpticalFlowPyramid(img, pyr, Size(win, win), max_level) in the shared storage layout.
+    Returns (lw, lh, off) with len(off) == levels + 1."""
+    lw = np.zeros(8, np.int32)
+    lh = np.zeros(8, np.int32)
+    off = np.zeros(9, np.int64)
+    L = lib()
+    L.gfso_klt_layout.restype = C.c_int
+    L.gfso_klt_layout.argtypes = [C.c_int] * 4 + [C.c_void_p] * 3
+    n = L.gfso_klt_layout(width, height, win, max_level, _p(lw), _p(lh), _p(off))
+    return lw[:n].copy(), lh[:n].copy(), off[:n + 1].copy()
+
+
+def klt_build_pyramid(img, win, max_level=3):
+    """cv::buildOpticalFlowPyramid restatement.  Returns (pyr_img u8 [total], pyr_deriv i16 [total, 2])."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    _, _, off = klt_layout(w, h, win, max_level)
+    pimg = np.zeros(int(off[-1]), np.uint8)
+    pder = np.zeros((int(off[-1]), 2), np.int16)
+    L = lib()
+    L.gfso_klt_build_pyramid.restype = C.c_int
+    L.gfso_klt_build_pyramid.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 2
+    L.gfso_klt_build_pyramid(_p(img), w, h, w, win, max_level, _p(pimg), _p(pder))
+    return pimg, pder
+
+
+def klt_track(prev_pyr, next_pyr, width, height, win, prev_pts, next_pts=None, max_level=3, pyr_max_level=3, max_iter=30, eps=0.01,
+              flags=0, min_eig_thr=1e-4):
+    """cv::calcOpticalFlowPyrLK restatement on pyramids from klt_build_pyramid.  Returns (next_pts [n, 2], status [n], err [n])."""
+    prev_pts = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+    n = len(prev_pts)
+    nxt = np.zeros((max(n, 1), 2), np.float32)
+    if next_pts is not None and n:
+        nxt[:n] = np.asarray(next_pts, np.float32).reshape(-1, 2)
+    st = np.zeros(max(n, 1), np.uint8)
+    er = np.zeros(max(n, 1), np.float32)
+    L = lib()
+    L.gfso_klt_track.restype = C.c_int
+    L.gfso_klt_track.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p] * 4 + [C.c_int, C.c_double, C.c_int, C.c_double]
+    rc = L.gfso_klt_track(_p(prev_pyr[0]), _p(prev_pyr[1]), _p(next_pyr[0]), width, height, win, pyr_max_level, max_level, n,
+                          _p(prev_pts), _p(nxt), _p(st), _p(er), max_iter, float(eps), flags, float(min_eig_thr))
+    if rc != 0:
+        raise RuntimeError("gfso_klt_track rc=%d" % rc)
+    return nxt[:n].copy(), st[:n].copy(), er[:n].copy()
+
+
+def fb_klt_tracking(prev_pyr, cur_pyr, width, height, win, nbpyrlvl, ferr, fmax_fbklt_dist, kps, priors, pyr_max_level=3):
+    """ORBmatcher::fbKltTracking restatement.  Returns (priors_out [n, 2], kpstatus bool [n], n_good)."""
+    kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 2)
+    n = len(kps)
+    pri = np.zeros((max(n, 1), 2), np.float32)
+    if n:
+        pri[:n] = np.asarray(priors, np.float32).reshape(-1, 2)
+    st = np.zeros(max(n, 1), np.uint8)
+    L = lib()
+    L.gfso_fb_klt_tracking.restype = C.c_int
+    L.gfso_fb_klt_tracking.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 3
+    good = L.gfso_fb_klt_tracking(_p(prev_pyr[0]), _p(prev_pyr[1]), _p(cur_pyr[0]), _p(cur_pyr[1]), width, height, win,
+                                  pyr_max_level, nbpyrlvl, ferr, fmax_fbklt_dist, n, _p(kps), _p(pri), _p(st))
+    return pri[:n].copy(), st[:n].astype(bool), int(good)
