@@ -8,12 +8,18 @@
 // produces one padded pixel, borders included, so there is no separate border pass and no intra-launch dependency.
 //
 // Tracker: ONE WAVE PER POINT, no workgroup barriers.  The win x win window is cut into runs of 4 pixels in a row; lane l
-// owns runs l, l + 64, ...  A run needs 2 x (dword + byte) unaligned loads from the image (bilinear taps of 4 pixels) instead of
-// 16 byte loads.  The template patch (I << 5, Ix, Iy as int16, 24 B per run) is private to the owning lane and parked in LDS
-// ([round][lane] layout, conflict-free b64 accesses).  All sums (A11, A12, A22, b1, b2, L1 residual) are integer sums: int32
-// per run, int64 per lane, butterfly-reduced over the wave and rounded to float once — independent of the summation order,
-// which is what makes the result reproducible and equal to the oracle.  The scalar 2x2 algebra runs redundantly in all lanes.
-// fbKltTracking's forward pass, gates, backward pass and forward-backward distance run back to back in the same wave.
+// owns runs l, l + 64, ...  Per Newton step the wave first copies the (win + 1)^2 bytes under the window into LDS with a few
+// coalesced unaligned dword loads (the texture addresser, not HBM, is what scattered per-run loads saturate), then every lane
+// blends its runs from LDS: v_perm_b32 pairs neighbouring bytes into 16-bit halves and v_dot2_i32_i16 applies two of the four
+// 14-bit bilinear weights at once.  The template patch (I << 5, Ix, Iy as packed int16, 24 B per run) is private to the owning
+// lane and parked in LDS ([round][lane] layout, conflict-free b64 accesses); residual and mismatch vector again use packed
+// subtract + v_dot2.  All sums (A11, A12, A22, b1, b2, L1 residual) are INTEGER sums: int32 per lane, then split into 16-bit
+// halves, reduced over the wave by recursive halving on DPP (two ds_bpermute in total) and rebuilt exactly in double before
+// the single rounding to float — independent of the summation order, which is what makes the result reproducible and equal to
+// the oracle.  The scalar 2x2 algebra runs redundantly in all lanes; window origins are moved to scalar registers
+// (readfirstlane) so the address arithmetic is SALU work.  fbKltTracking's forward pass, gates, backward pass and
+// forward-backward distance run back to back in the same wave.  Measured (MI355X, 128 pairs x 1000 points, window 35):
+// 11 k VALU instructions per point, VALU ~85 % busy — the kernel is integer-ALU bound, HBM traffic is negligible.
 #include <memory>
 #include <mutex>
 
@@ -29,7 +35,7 @@ constexpr int kKltThreads = 64 * kKltWavesPerBlock;
 constexpr int kKltSlack = 256;  // bytes after the last level: masked tail pixels of a run may be loaded from there
 
 struct KltGeom {
-  int n_levels, win, runs, ntasks, rounds, inv_runs;
+  int n_levels, win, runs, ntasks, rounds, inv_runs, nd, win_dwords, stage_lpr, stage_shift, stage_rows;
   int width, height;
   int lw[GFS_KLT_MAX_LEVELS], lh[GFS_KLT_MAX_LEVELS];
   long long off[GFS_KLT_MAX_LEVELS + 1];
@@ -108,52 +114,115 @@ __global__ void __launch_bounds__(256) k_klt_scharr(KltGeom G, const uint8_t* __
 // ---------------------------------------------------------------------------------------------------------------------
 // Tracker
 // ---------------------------------------------------------------------------------------------------------------------
+typedef short v2s __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ unsigned load_u32(const uint8_t* p) {  // unaligned dword load (gfx950 runs in unaligned-access mode)
   unsigned v;
   __builtin_memcpy(&v, p, 4);
   return v;
+}
+__device__ __forceinline__ v2s as_v2s(unsigned v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ unsigned as_u32(v2s v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ int dot2(unsigned a, unsigned b, int c) {  // a.lo * b.lo + a.hi * b.hi + c on signed 16-bit halves
+  return __builtin_amdgcn_sdot2(as_v2s(a), as_v2s(b), c, false);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int CTRL>
+__device__ __forceinline__ int dpp(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x128;
+
+// Exact wave-wide sums of two per-lane int32 values (|v| < 2^31 per lane, 64 lanes -> up to 37 bits): each value is split
+// into a signed high and an unsigned low 16-bit half, the four halves are reduced together by recursive halving (lane pairs,
+// then quads, split the four between them), row rotations and two cross-row exchanges; every lane then rebuilds
+// (double)hi * 65536 + lo, which is exact, and rounds ONCE to float == (float)(int64 sum).
+__device__ __forceinline__ void wave_sum2_exact(int a, int b, int lane, float& fa, float& fb) {
+  const int ah = a >> 16, al = a & 0xffff, bh = b >> 16, bl = b & 0xffff;
+  const bool o0 = lane & 1, o1 = lane & 2;
+  const int H = (o0 ? bh : ah) + dpp<kDppXor1>(o0 ? ah : bh);  // even lanes: a, odd lanes: b
+  const int L = (o0 ? bl : al) + dpp<kDppXor1>(o0 ? al : bl);
+  int v = (o1 ? L : H) + dpp<kDppXor2>(o1 ? H : L);            // lane & 3: 0 a.hi, 1 b.hi, 2 a.lo, 3 b.lo (sum over the quad)
+  v += dpp<kDppRor4>(v);
+  v += dpp<kDppRor8>(v);                                        // sum over the row of 16
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  const int sah = dpp<0x00>(v), sbh = dpp<0x55>(v), sal = dpp<0xAA>(v), sbl = dpp<0xFF>(v);
+  fa = (float)__dadd_rn(__dmul_rn((double)sah, 65536.0), (double)sal);
+  fb = (float)__dadd_rn(__dmul_rn((double)sbh, 65536.0), (double)sbl);
+}
+// Same for three values (the gradient matrix): lane & 3 selects a, b, c after the pair / quad steps, the fourth slot idles.
+__device__ __forceinline__ void wave_sum3_exact(int a, int b, int c, int lane, float& fa, float& fb, float& fc) {
+  const bool o0 = lane & 1, o1 = lane & 2;
+  // pairs: even lanes keep (a, c), odd lanes keep (b, 0); quads: lanes 0, 1 keep the first, lanes 2, 3 the second of their two
+  auto reduce = [&](int x, int y, int z) {
+    const int P = (o0 ? y : x) + dpp<kDppXor1>(o0 ? x : y);
+    const int Q = (o0 ? 0 : z) + dpp<kDppXor1>(o0 ? z : 0);
+    int v = (o1 ? Q : P) + dpp<kDppXor2>(o1 ? P : Q);  // lane & 3: 0 x, 1 y, 2 z, 3 nothing
+    v += dpp<kDppRor4>(v);
+    v += dpp<kDppRor8>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  };
+  const int hi = reduce(a >> 16, b >> 16, c >> 16), lo = reduce(a & 0xffff, b & 0xffff, c & 0xffff);
+  fa = (float)__dadd_rn(__dmul_rn((double)dpp<0x00>(hi), 65536.0), (double)dpp<0x00>(lo));
+  fb = (float)__dadd_rn(__dmul_rn((double)dpp<0x55>(hi), 65536.0), (double)dpp<0x55>(lo));
+  fc = (float)__dadd_rn(__dmul_rn((double)dpp<0xAA>(hi), 65536.0), (double)dpp<0xAA>(lo));
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
   for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
   return v;
 }
-__device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
-  w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
-  w01 = __float2int_rn(a * (1.f - b) * 16384.f);
-  w10 = __float2int_rn((1.f - a) * b * 16384.f);
-  w11 = 16384 - w00 - w01 - w10;
+__device__ __forceinline__ void bilinear_weights(float a, float b, unsigned& W0, unsigned& W1) {
+  const int w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+  const int w01 = __float2int_rn(a * (1.f - b) * 16384.f);
+  const int w10 = __float2int_rn((1.f - a) * b * 16384.f);
+  const int w11 = 16384 - w00 - w01 - w10;
+  W0 = (unsigned)uniform(w00 | (w01 << 16));  // all four lie in [0, 16384]: they fit the signed halves of v_dot2
+  W1 = (unsigned)uniform(w10 | (w11 << 16));
 }
-// Five bytes of two image rows -> four bilinear samples << 5 (CV_DESCALE(..., W_BITS1 - 5)).
-__device__ __forceinline__ void blend4(const uint8_t* r0, int pitch, int w00, int w01, int w10, int w11, int (&out)[4]) {
-  const unsigned a = load_u32(r0), b = load_u32(r0 + pitch);
-  const int a4 = r0[4], b4 = r0[pitch + 4];
-  int pa[5], pb[5];
+// Copies the (win + 1) rows x 4 * nd bytes of the window whose top-left byte is `base` (wave-uniform) into the wave's LDS
+// window buffer.  16 (nd <= 16) or 32 lanes walk down one column of dwords each, 4 or 2 rows per step: consecutive lanes
+// fetch consecutive (unaligned) dwords of a row, so the texture addresser sees a few coalesced wave loads per window instead
+// of 4 scattered ones per run and round, and the addresses advance by one add per step.
+__device__ __forceinline__ void stage_window(const KltGeom& G, const uint8_t* base, int pitch, unsigned* sWin, int lane) {
+  const int col = lane & (G.stage_lpr - 1), row0 = lane >> G.stage_shift;
+  if (col < G.nd) {
+    const uint8_t* p = base + row0 * pitch + col * 4;
+    unsigned* q = sWin + row0 * G.nd + col;
+    const int dp = pitch * G.stage_rows, dq = G.nd * G.stage_rows;
+    for (int row = row0; row <= G.win; row += 4 * G.stage_rows, p += 4 * dp, q += 4 * dq) {  // four loads in flight
+      unsigned v[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    pa[i] = (a >> (8 * i)) & 0xff;
-    pb[i] = (b >> (8 * i)) & 0xff;
-  }
-  pa[4] = a4;
-  pb[4] = b4;
+      for (int k = 0; k < 4; k++)
+        if (row + k * G.stage_rows <= G.win) v[k] = load_u32(p + k * dp);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int v = __mul24(pa[i], w00) + __mul24(pa[i + 1], w01) + __mul24(pb[i], w10) + __mul24(pb[i + 1], w11);
-    out[i] = (v + 256) >> 9;
+      for (int k = 0; k < 4; k++)
+        if (row + k * G.stage_rows <= G.win) q[k * dq] = v[k];
+    }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ void unpack4(uint2 v, int (&o)[4]) {
-  o[0] = (short)(v.x & 0xffff);
-  o[1] = (int)v.x >> 16;
-  o[2] = (short)(v.y & 0xffff);
-  o[3] = (int)v.y >> 16;
-}
-__device__ __forceinline__ uint2 pack4(const int (&o)[4]) {
-  return make_uint2((unsigned)(o[0] & 0xffff) | ((unsigned)o[1] << 16), (unsigned)(o[2] & 0xffff) | ((unsigned)o[3] << 16));
+// Five bytes of two staged window rows -> four bilinear samples << 5 (CV_DESCALE(..., W_BITS1 - 5)), as two packed pairs.
+// i0 = dword index of the run in the window buffer.
+__device__ __forceinline__ void blend4(const unsigned* sWin, int i0, int nd, unsigned W0, unsigned W1, unsigned& v01, unsigned& v23) {
+  const unsigned a = sWin[i0], a4 = sWin[i0 + 1], b = sWin[i0 + nd], b4 = sWin[i0 + nd + 1];
+  // v_perm_b32: bytes 0-3 select from the second operand, 4-7 from the first, 0x0c = zero
+  const int v0 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c010c00u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c010c00u), W1, 256)) >> 9;
+  const int v1 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c020c01u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c020c01u), W1, 256)) >> 9;
+  const int v2 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c030c02u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c030c02u), W1, 256)) >> 9;
+  const int v3 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c040c03u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c040c03u), W1, 256)) >> 9;
+  v01 = (unsigned)v0 | ((unsigned)v1 << 16);  // samples are in [0, 8160]
+  v23 = (unsigned)v2 | ((unsigned)v3 << 16);
 }
 
 // LKTrackerInvoker::operator() over the levels max_level .. 0 for one point, executed by one wave.
-// lds: this wave's 3 * rounds * 64 uint2.  All arguments and results are wave-uniform.
+// lds: this wave's 3 * rounds * 64 uint2 + the window buffer.  All arguments and results are wave-uniform.
 __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint8_t* __restrict__ Ipyr,
                                 const short2* __restrict__ dIpyr, const uint8_t* __restrict__ Jpyr, float2 prev, float2& next,
                                 int& status, float& err, uint2* lds, int lane) {
@@ -162,6 +231,7 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
   uint2* sI = lds;
   uint2* sIx = lds + G.rounds * 64;
   uint2* sIy = lds + 2 * G.rounds * 64;
+  unsigned* sWin = (unsigned*)(lds + 3 * G.rounds * 64);
   for (int level = P.max_level; level >= 0; level--) {
     const int w = G.lw[level], h = G.lh[level], pitch = w + 2 * win;
     const long long org = G.off[level] + (long long)win * pitch + win;
@@ -183,7 +253,7 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
     next = make_float2(nx, ny);
     px -= half;
     py -= half;
-    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    const int ipx = uniform((int)floorf(px)), ipy = uniform((int)floorf(py));
     if (ipx < -win || ipx >= w || ipy < -win || ipy >= h) {
       if (level == 0) {
         status = 0;
@@ -191,50 +261,55 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
       }
       continue;
     }
-    int w00, w01, w10, w11;
-    bilinear_weights(px - ipx, py - ipy, w00, w01, w10, w11);
+    unsigned W0, W1;
+    bilinear_weights(px - ipx, py - ipy, W0, W1);
 
     // --- template patch + gradient matrix ---
     const uint8_t* Ib = Ipyr + org + (long long)ipy * pitch + ipx;
     const short2* dIb = dIpyr + org + (long long)ipy * pitch + ipx;
-    long long a11 = 0, a12 = 0, a22 = 0;
+    int a11 = 0, a12 = 0, a22 = 0;  // per lane <= 64 pixels x 4080^2 < 2^31
+    stage_window(G, Ib, pitch, sWin, lane);
     for (int r = 0; r < G.rounds; r++) {
       const int t = r * 64 + lane;
-      int I4[4] = {0, 0, 0, 0}, X4[4] = {0, 0, 0, 0}, Y4[4] = {0, 0, 0, 0};
+      unsigned I01 = 0, I23 = 0, X01 = 0, X23 = 0, Y01 = 0, Y23 = 0;
       if (t < G.ntasks) {
         const int ty = (t * G.inv_runs) >> 16, x0 = (t - ty * G.runs) * 4;
-        blend4(Ib + ty * pitch + x0, pitch, w00, w01, w10, w11, I4);
-        const short2* d0 = dIb + ty * pitch + x0;
-        const short2* d1 = d0 + pitch;
-        short2 da[5], db[5];
+        blend4(sWin, t + ty, G.nd, W0, W1, I01, I23);
+        const unsigned* d0 = (const unsigned*)(dIb + (ty * pitch + x0));
+        const unsigned* d1 = d0 + pitch;
+        unsigned da[5], db[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) {
           da[i] = d0[i];
           db[i] = d1[i];
         }
-        int s11 = 0, s12 = 0, s22 = 0;
+        int ix[4], iy[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          int ix = (__mul24(da[i].x, w00) + __mul24(da[i + 1].x, w01) + __mul24(db[i].x, w10) + __mul24(db[i + 1].x, w11) + 8192) >> 14;
-          int iy = (__mul24(da[i].y, w00) + __mul24(da[i + 1].y, w01) + __mul24(db[i].y, w10) + __mul24(db[i + 1].y, w11) + 8192) >> 14;
-          if (x0 + i >= win) ix = iy = I4[i] = 0;  // beyond the window: contributes nothing anywhere
-          X4[i] = ix;
-          Y4[i] = iy;
-          s11 += __mul24(ix, ix);
-          s12 += __mul24(ix, iy);
-          s22 += __mul24(iy, iy);
+        for (int i = 0; i < 4; i++) {  // halves 0 / 1 of element i and i + 1: the x (resp. y) derivatives of two neighbours
+          ix[i] = dot2(__builtin_amdgcn_perm(da[i + 1], da[i], 0x05040100u), W0,
+                       dot2(__builtin_amdgcn_perm(db[i + 1], db[i], 0x05040100u), W1, 8192)) >> 14;
+          iy[i] = dot2(__builtin_amdgcn_perm(da[i + 1], da[i], 0x07060302u), W0,
+                       dot2(__builtin_amdgcn_perm(db[i + 1], db[i], 0x07060302u), W1, 8192)) >> 14;
+          if (x0 + i >= win) ix[i] = iy[i] = 0;  // beyond the window: contributes nothing anywhere
         }
-        a11 += s11;
-        a12 += s12;
-        a22 += s22;
+        X01 = (unsigned)(ix[0] & 0xffff) | ((unsigned)ix[1] << 16);
+        X23 = (unsigned)(ix[2] & 0xffff) | ((unsigned)ix[3] << 16);
+        Y01 = (unsigned)(iy[0] & 0xffff) | ((unsigned)iy[1] << 16);
+        Y23 = (unsigned)(iy[2] & 0xffff) | ((unsigned)iy[3] << 16);
+        a11 = dot2(X01, X01, dot2(X23, X23, a11));
+        a12 = dot2(X01, Y01, dot2(X23, Y23, a12));
+        a22 = dot2(Y01, Y01, dot2(Y23, Y23, a22));
       }
-      sI[r * 64 + lane] = pack4(I4);
-      sIx[r * 64 + lane] = pack4(X4);
-      sIy[r * 64 + lane] = pack4(Y4);
+      sI[r * 64 + lane] = make_uint2(I01, I23);
+      sIx[r * 64 + lane] = make_uint2(X01, X23);
+      sIy[r * 64 + lane] = make_uint2(Y01, Y23);
     }
     const float FLT_SCALE = 1.f / (1 << 20);
-    const float A11 = (float)wave_sum_i64(a11) * FLT_SCALE, A12 = (float)wave_sum_i64(a12) * FLT_SCALE,
-                A22 = (float)wave_sum_i64(a22) * FLT_SCALE;
+    float A11, A12, A22;
+    wave_sum3_exact(a11, a12, a22, lane, A11, A12, A22);
+    A11 *= FLT_SCALE;
+    A12 *= FLT_SCALE;
+    A22 *= FLT_SCALE;
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dif = A11 - A22;
     const float min_eig = __fsub_rn(A22 + A11, sqrtf(__fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12)))) /
@@ -250,35 +325,30 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
     float pdx = 0.f, pdy = 0.f;
     const uint8_t* Jb = Jpyr + org;
     for (int j = 0; j < P.max_iter; j++) {
-      const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+      const int inx = uniform((int)floorf(nx)), iny = uniform((int)floorf(ny));
       if (inx < -win || inx >= w || iny < -win || iny >= h) {
         if (level == 0) status = 0;
         break;
       }
-      bilinear_weights(nx - inx, ny - iny, w00, w01, w10, w11);
+      bilinear_weights(nx - inx, ny - iny, W0, W1);
       const uint8_t* Jp = Jb + (long long)iny * pitch + inx;
-      long long b1 = 0, b2 = 0;
+      int b1 = 0, b2 = 0;  // per lane <= 64 pixels x 8160 x 4080 < 2^31
+      stage_window(G, Jp, pitch, sWin, lane);
       for (int r = 0; r < G.rounds; r++) {
         const int t = r * 64 + lane;
         if (t < G.ntasks) {
-          const int ty = (t * G.inv_runs) >> 16, x0 = (t - ty * G.runs) * 4;
-          int J4[4], I4[4], X4[4], Y4[4];
-          blend4(Jp + ty * pitch + x0, pitch, w00, w01, w10, w11, J4);
-          unpack4(sI[r * 64 + lane], I4);
-          unpack4(sIx[r * 64 + lane], X4);
-          unpack4(sIy[r * 64 + lane], Y4);
-          int s1 = 0, s2 = 0;
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int diff = J4[i] - I4[i];
-            s1 += __mul24(diff, X4[i]);
-            s2 += __mul24(diff, Y4[i]);
-          }
-          b1 += s1;
-          b2 += s2;
+          unsigned J01, J23;
+          blend4(sWin, t + ((t * G.inv_runs) >> 16), G.nd, W0, W1, J01, J23);
+          const uint2 I = sI[r * 64 + lane], X = sIx[r * 64 + lane], Y = sIy[r * 64 + lane];
+          const unsigned d01 = as_u32(as_v2s(J01) - as_v2s(I.x)), d23 = as_u32(as_v2s(J23) - as_v2s(I.y));
+          b1 = dot2(d01, X.x, dot2(d23, X.y, b1));
+          b2 = dot2(d01, Y.x, dot2(d23, Y.y, b2));
         }
       }
-      const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE, fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
+      float fb1, fb2;
+      wave_sum2_exact(b1, b2, lane, fb1, fb2);
+      fb1 *= FLT_SCALE;
+      fb2 *= FLT_SCALE;
       const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
       const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
       nx += dx;
@@ -295,24 +365,27 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
     }
     if (status && level == 0 && !(P.flags & GFS_KLT_GET_MIN_EIGENVALS)) {  // L1 residual of the final position
       const float ex = next.x - half, ey = next.y - half;
-      const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+      const int iex = uniform((int)floorf(ex)), iey = uniform((int)floorf(ey));
       if (iex < -win || iex >= w || iey < -win || iey >= h) {
         status = 0;
         continue;
       }
-      bilinear_weights(ex - iex, ey - iey, w00, w01, w10, w11);
+      bilinear_weights(ex - iex, ey - iey, W0, W1);
       const uint8_t* Jp = Jb + (long long)iey * pitch + iex;
       long long e = 0;
+      stage_window(G, Jp, pitch, sWin, lane);
       for (int r = 0; r < G.rounds; r++) {
         const int t = r * 64 + lane;
         if (t < G.ntasks) {
           const int ty = (t * G.inv_runs) >> 16, x0 = (t - ty * G.runs) * 4;
-          int J4[4], I4[4];
-          blend4(Jp + ty * pitch + x0, pitch, w00, w01, w10, w11, J4);
-          unpack4(sI[r * 64 + lane], I4);
+          unsigned J01, J23;
+          blend4(sWin, t + ty, G.nd, W0, W1, J01, J23);
+          const uint2 I = sI[r * 64 + lane];
+          const v2s d01 = as_v2s(J01) - as_v2s(I.x), d23 = as_v2s(J23) - as_v2s(I.y);
+          const int d[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            if (x0 + i < win) e += abs(J4[i] - I4[i]);
+            if (x0 + i < win) e += abs(d[i]);
         }
       }
       err = __fmul_rn((float)wave_sum_i64(e), 1.f) / (float)(32 * win * win);
@@ -336,7 +409,7 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_track(KltGeom G, KltParams 
   int status = 1;
   float err = 0.f;
   klt_track_point(G, P, prev_img + fo, prev_deriv + fo, next_img + fo, prev_pts[po], next, status, err,
-                  s_klt + wave * 3 * G.rounds * 64, lane);
+                  s_klt + wave * (3 * G.rounds * 64 + (G.win_dwords + 1) / 2), lane);
   if (lane == 0) {
     next_pts[po] = next;
     status_out[po] = (uint8_t)status;
@@ -356,7 +429,7 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.y;
   const int i = blockIdx.x * kKltWavesPerBlock + wave;
   if (i >= n_pts[f]) return;
-  uint2* lds = s_klt + wave * 3 * G.rounds * 64;
+  uint2* lds = s_klt + wave * (3 * G.rounds * 64 + (G.win_dwords + 1) / 2);
   const long long fo = (long long)f * G.frame_stride, po = (long long)f * pt_stride + i;
   const float2 kp = kps[po];
   float2 fwd = priors[po];
@@ -465,6 +538,11 @@ int gfs_klt_create(int device, int width, int height, int win, int max_level, in
   G.ntasks = G.runs * win;
   G.rounds = (G.ntasks + 63) / 64;
   G.inv_runs = (65536 + G.runs - 1) / G.runs;
+  G.nd = G.runs + 1;  // dwords staged per window row: bytes [0, 4 * runs + 4) cover the win + 1 bilinear taps
+  G.stage_lpr = G.nd <= 16 ? 16 : 32;  // lanes per window row while staging
+  G.stage_shift = G.nd <= 16 ? 4 : 5;
+  G.stage_rows = 64 / G.stage_lpr;
+  G.win_dwords = G.nd * (win + 1);
   int cw = width, ch = height;
   G.off[0] = 0;
   if (max_level > GFS_KLT_MAX_LEVELS - 1) max_level = GFS_KLT_MAX_LEVELS - 1;
@@ -478,7 +556,7 @@ int gfs_klt_create(int device, int width, int height, int win, int max_level, in
     if (cw <= win || ch <= win) break;
   }
   G.frame_stride = (long long)gfs::align_up((size_t)G.off[G.n_levels] + kKltSlack, 256);
-  h->lds_bytes = (size_t)kKltWavesPerBlock * 3 * G.rounds * 64 * sizeof(uint2);
+  h->lds_bytes = (size_t)kKltWavesPerBlock * (3 * G.rounds * 64 + (G.win_dwords + 1) / 2) * sizeof(uint2);
   GFS_HIP(hipFuncSetAttribute((const void*)k_klt_track, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
   GFS_HIP(hipFuncSetAttribute((const void*)k_klt_fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

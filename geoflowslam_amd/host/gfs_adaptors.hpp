@@ -169,6 +169,53 @@ class GmsMatcher {
   gfs_gms* h_ = nullptr;
 };
 
+// The optical-flow front end: cv::buildOpticalFlowPyramid (reference src/Frame.cc:373), ORBmatcher::fbKltTracking
+// (src/ORBmatcher.cc:2186-2297 == Tracking::fbKltTracking, src/Tracking.cc:3262-3366).  A Pyramid is what Frame::mImGray holds in
+// the reference (a std::vector<cv::Mat>), kept in HBM; build it once per frame, use it as `cur` and then as `prev`.
+class KltTracker {
+ public:
+  class Pyramid {
+   public:
+    explicit Pyramid(KltTracker& t) : t_(t) { check(gfs_klt_pyramid_create(t.h_, &p_), "gfs_klt_pyramid_create"); }
+    ~Pyramid() { gfs_klt_pyramid_destroy(p_); }
+    Pyramid(const Pyramid&) = delete;
+    Pyramid& operator=(const Pyramid&) = delete;
+    // cv::buildOpticalFlowPyramid(image, pyr, Size(win, win), max_level)
+    void build(const uint8_t* image, int stride) { check(gfs_klt_build_pyramid(t_.h_, p_, &image, stride, 1), "gfs_klt_build_pyramid"); }
+    gfs_klt_pyramid* get() const { return p_; }
+
+   private:
+    KltTracker& t_;
+    gfs_klt_pyramid* p_ = nullptr;
+  };
+
+  KltTracker(int width, int height, int nwinsize, int max_level = 3, int max_points = 8192, int device = 0) {
+    check(gfs_klt_create(device, width, height, nwinsize, max_level, 1, max_points, &h_), "gfs_klt_create");
+  }
+  ~KltTracker() { gfs_klt_destroy(h_); }
+  gfs_klt* handle() const { return h_; }
+  // fbKltTracking(vprevpyr, vcurpyr, nwinsize, nbpyrlvl, ferr, fmax_fbklt_dist, vkps, vpriorkps, vkpstatus): points are
+  // (x, y) float pairs as cv::Point2f; vpriorkps is updated in place, vkpstatus is resized to vkps.size() / 2.
+  void fbKltTracking(const Pyramid& vprevpyr, const Pyramid& vcurpyr, int nbpyrlvl, float ferr, float fmax_fbklt_dist,
+                     const std::vector<float>& vkps, std::vector<float>& vpriorkps, std::vector<uint8_t>& vkpstatus) {
+    const int32_t n = (int32_t)(vkps.size() / 2);
+    vkpstatus.assign((size_t)std::max(n, 1), 0);
+    if (n == 0) {  // src/ORBmatcher.cc:2197-2199: nothing is touched
+      vkpstatus.clear();
+      return;
+    }
+    const float* kp = vkps.data();
+    float* pr = vpriorkps.data();
+    uint8_t* st = vkpstatus.data();
+    int32_t good = 0;
+    check(gfs_klt_fb_track(h_, vprevpyr.get(), vcurpyr.get(), 1, &n, &kp, &pr, &st, &good, nbpyrlvl, ferr, fmax_fbklt_dist), "gfs_klt_fb_track");
+    vkpstatus.resize((size_t)n);
+  }
+
+ private:
+  gfs_klt* h_ = nullptr;
+};
+
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on flattened frames (reference src/ORBmatcher.cc:1853-2063;
 // see INTEGRATION.md §6 for the flattening of Frame / MapPoint)
 class ProjectionMatcher {

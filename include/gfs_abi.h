@@ -412,7 +412,7 @@ int gfs_gms_inlier_mask_batch_device(gfs_gms* h, const void* dev_kps1, const voi
  *    level l of a frame is an image of (lw[l] + 2*win) x (lh[l] + 2*win) bytes at byte offset off[l] (BORDER_REFLECT_101 border
  *    of win pixels) plus as many short2 (Scharr dx, dy; zero border); a level is built while both sides exceed the window, as
  *    OpenCV does.  A frame's pyramid is built once and used as `cur` for one pair and as `prev` for the next.
- *    Sums of the 2x2 system are exact integer sums rounded once (DESIGN.md 9): bit-equal to oracle/klt_oracle.cpp.
+ *    Sums of the 2x2 system are exact integer sums rounded once (DESIGN.md 2 and 8): bit-equal to oracle/klt_oracle.cpp.
  * ============================================================================================ */
 #define GFS_KLT_MAX_LEVELS 8
 #define GFS_KLT_USE_INITIAL_FLOW 4   /* cv::OPTFLOW_USE_INITIAL_FLOW */

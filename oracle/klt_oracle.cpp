@@ -20,7 +20,7 @@
 // that depends on how the library was built (scalar, SSE2, AVX2 with/without FMA all differ in the last bits).  All summands are
 // integers, so this restatement sums them EXACTLY (int64) and rounds once to float — the value every OpenCV build approximates
 // within its own rounding error.  It makes the result independent of summation order (so the GPU can be bit-exact against it)
-// at the price of ulp-level differences to any particular OpenCV binary; see DESIGN.md §9.
+// at the price of ulp-level differences to any particular OpenCV binary; see DESIGN.md §2 (deviations) and §8.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
