@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-klt", action="store_true", help="skip the optical-flow side measurement")
     ap.add_argument("--serial", action="store_true", help="run ORB+match and GICP back to back on one stream")
     ap.add_argument("--lanes", type=int, default=2, help="independent slices of the batch processed concurrently per GPU")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
@@ -311,6 +312,60 @@ def main():
                                   sample=f"{nall} pairs on {ncores} worker threads, single-threaded oracle per pair"),
                    note="CPU restatement of the reference algorithm (reference not buildable here: OpenCV/Eigen/PCL absent)")
 
+    # ---- the optical-flow stream next to the path: reported beside the metric, never part of `value`
+    klt = None
+    if rank == 0 and world == 1 and not args.no_klt:
+        WIN = 35
+        cap = lanes[0].cap
+        trk = api.KltTracker(W, H, WIN, max_level=3, max_batch=B, max_points=cap, device=local_rank)
+        pyr_prev, pyr_cur = api.KltPyramid(trk), api.KltPyramid(trk)
+        kp_all = torch.cat([ln.prev_kps.view(torch.float32).view(ln.n, cap, 7)[:, :, :2] for ln in lanes]).contiguous()
+        cnt_all = torch.cat([ln.prev_cnt for ln in lanes]).contiguous()
+        pri = kp_all.clone()
+        st = torch.zeros(B * cap, dtype=torch.uint8, device=dev)
+        good = torch.zeros(B, dtype=torch.int32, device=dev)
+        trk.build_pyramid_device(gray0.data_ptr(), W, B, pyr_prev)
+
+        def klt_step():  # per new frame: its pyramid (the previous frame's is kept) + forward/backward tracking of the key points
+            trk.build_pyramid_device(gray1.data_ptr(), W, B, pyr_cur)
+            pri.copy_(kp_all)
+            torch.cuda.synchronize()
+            trk.fb_track_device(pyr_prev, pyr_cur, B, cap, cnt_all.data_ptr(), kp_all.data_ptr(), pri.data_ptr(), st.data_ptr(),
+                                good.data_ptr(), 3, 15.0, 0.5)
+
+        for _ in range(2):
+            klt_step()
+        torch.cuda.synchronize()
+        nk = 10
+        t1 = time.perf_counter()
+        for _ in range(nk):
+            klt_step()
+        torch.cuda.synchronize()
+        dtk = (time.perf_counter() - t1) / nk
+        api.profile_reset()
+        api.profile_enable(True)
+        for _ in range(3):
+            klt_step()
+        torch.cuda.synchronize()
+        krep = api.profile_report()
+        api.profile_enable(False)
+        npts_k, ngood_k = int(cnt_all.sum().item()), int(good.sum().item())
+        klt = dict(metric="optical-flow frame pairs/s (buildOpticalFlowPyramid + fbKltTracking, window 35, 4 levels)",
+                   value=round(B / dtk, 1), unit="pairs/s", ms_per_batch=round(dtk * 1e3, 3), batch_pairs=B,
+                   points_per_pair=round(npts_k / B, 1), tracked_frac=round(ngood_k / max(npts_k, 1), 3),
+                   kernels_ms_per_batch={k: round(v[0] / 3, 4) for k, v in sorted(krep.items(), key=lambda kv: -kv[1][0]) if "klt" in k})
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            kp_h = kp_all[:4].cpu().numpy()
+            cn_h = cnt_all[:4].cpu().numpy()
+            t1 = time.perf_counter()
+            o_prev = [O.klt_build_pyramid(pairs[sel[b]]["gray0"], WIN) for b in range(4)]
+            for b in range(4):
+                o_cur = O.klt_build_pyramid(pairs[sel[b]]["gray1"], WIN)
+                O.fb_klt_tracking(o_prev[b], o_cur, W, H, WIN, 3, 15.0, 0.5, kp_h[b, :cn_h[b]], kp_h[b, :cn_h[b]].copy())
+            klt["cpu_oracle"] = dict(value=round(4 / (time.perf_counter() - t1), 3), unit="pairs/s", cores=1,
+                                     sample="4 VGA pairs, single-threaded oracle (5 pyramids + 4 forward/backward passes)")
+
     if rank == 0:
         g = gicp_results()
         out = {
@@ -326,6 +381,8 @@ def main():
                        "gicp_converged_frac": round(float(np.mean([r["converged"] for r in g])), 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if klt:
+            out["optical_flow"] = klt
         if cpu:
             out["gpu_over_cpu"] = round(fps / cpu["value"], 2)
             out["gpu_over_cpu_all_cores"] = round(fps / cpu["all_cores"]["value"], 2)
