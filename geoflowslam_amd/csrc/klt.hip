@@ -19,7 +19,8 @@
 // the oracle.  The scalar 2x2 algebra runs redundantly in all lanes; window origins are moved to scalar registers
 // (readfirstlane) so the address arithmetic is SALU work.  fbKltTracking's forward pass, gates, backward pass and
 // forward-backward distance run back to back in the same wave.  Measured (MI355X, 128 pairs x 1000 points, window 35):
-// 11 k VALU instructions per point, VALU ~85 % busy — the kernel is integer-ALU bound, HBM traffic is negligible.
+// ~10 k VALU instructions per point, VALU ~85 % busy — the kernel is integer-ALU bound, HBM traffic is negligible.
+// The round loops are unrolled at compile time for the window sizes of the reference's configurations (KLT_DISPATCH).
 #include <memory>
 #include <mutex>
 
@@ -137,7 +138,7 @@ constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x1
 // Exact wave-wide sums of two per-lane int32 values (|v| < 2^31 per lane, 64 lanes -> up to 37 bits): each value is split
 // into a signed high and an unsigned low 16-bit half, the four halves are reduced together by recursive halving (lane pairs,
 // then quads, split the four between them), row rotations and two cross-row exchanges; every lane then rebuilds
-// (double)hi * 65536 + lo, which is exact, and rounds ONCE to float == (float)(int64 sum).
+// fma(hi, 65536, lo) on the two halves, which are exact in float: ONE rounding of the exact sum == (float)(int64 sum).
 __device__ __forceinline__ void wave_sum2_exact(int a, int b, int lane, float& fa, float& fb) {
   const int ah = a >> 16, al = a & 0xffff, bh = b >> 16, bl = b & 0xffff;
   const bool o0 = lane & 1, o1 = lane & 2;
@@ -149,8 +150,8 @@ __device__ __forceinline__ void wave_sum2_exact(int a, int b, int lane, float& f
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
   const int sah = dpp<0x00>(v), sbh = dpp<0x55>(v), sal = dpp<0xAA>(v), sbl = dpp<0xFF>(v);
-  fa = (float)__dadd_rn(__dmul_rn((double)sah, 65536.0), (double)sal);
-  fb = (float)__dadd_rn(__dmul_rn((double)sbh, 65536.0), (double)sbl);
+  fa = __fmaf_rn((float)sah, 65536.f, (float)sal);  // both halves are exact in float (< 2^23): one rounding of the exact sum
+  fb = __fmaf_rn((float)sbh, 65536.f, (float)sbl);
 }
 // Same for three values (the gradient matrix): lane & 3 selects a, b, c after the pair / quad steps, the fourth slot idles.
 __device__ __forceinline__ void wave_sum3_exact(int a, int b, int c, int lane, float& fa, float& fb, float& fc) {
@@ -167,9 +168,9 @@ __device__ __forceinline__ void wave_sum3_exact(int a, int b, int c, int lane, f
     return v;
   };
   const int hi = reduce(a >> 16, b >> 16, c >> 16), lo = reduce(a & 0xffff, b & 0xffff, c & 0xffff);
-  fa = (float)__dadd_rn(__dmul_rn((double)dpp<0x00>(hi), 65536.0), (double)dpp<0x00>(lo));
-  fb = (float)__dadd_rn(__dmul_rn((double)dpp<0x55>(hi), 65536.0), (double)dpp<0x55>(lo));
-  fc = (float)__dadd_rn(__dmul_rn((double)dpp<0xAA>(hi), 65536.0), (double)dpp<0xAA>(lo));
+  fa = __fmaf_rn((float)dpp<0x00>(hi), 65536.f, (float)dpp<0x00>(lo));
+  fb = __fmaf_rn((float)dpp<0x55>(hi), 65536.f, (float)dpp<0x55>(lo));
+  fc = __fmaf_rn((float)dpp<0xAA>(hi), 65536.f, (float)dpp<0xAA>(lo));
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
@@ -223,15 +224,17 @@ __device__ __forceinline__ void blend4(const unsigned* sWin, int i0, int nd, uns
 
 // LKTrackerInvoker::operator() over the levels max_level .. 0 for one point, executed by one wave.
 // lds: this wave's 3 * rounds * 64 uint2 + the window buffer.  All arguments and results are wave-uniform.
+template <int R>  // R > 0: the number of rounds (= G.rounds) is a compile-time constant and the round loops unroll; 0: generic
 __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint8_t* __restrict__ Ipyr,
                                 const short2* __restrict__ dIpyr, const uint8_t* __restrict__ Jpyr, float2 prev, float2& next,
                                 int& status, float& err, uint2* lds, int lane) {
   const int win = G.win;
   const float half = (win - 1) * 0.5f;
   uint2* sI = lds;
-  uint2* sIx = lds + G.rounds * 64;
-  uint2* sIy = lds + 2 * G.rounds * 64;
-  unsigned* sWin = (unsigned*)(lds + 3 * G.rounds * 64);
+  const int rounds = R ? R : G.rounds;
+  uint2* sIx = lds + rounds * 64;
+  uint2* sIy = lds + 2 * rounds * 64;
+  unsigned* sWin = (unsigned*)(lds + 3 * rounds * 64);
   for (int level = P.max_level; level >= 0; level--) {
     const int w = G.lw[level], h = G.lh[level], pitch = w + 2 * win;
     const long long org = G.off[level] + (long long)win * pitch + win;
@@ -269,7 +272,8 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
     const short2* dIb = dIpyr + org + (long long)ipy * pitch + ipx;
     int a11 = 0, a12 = 0, a22 = 0;  // per lane <= 64 pixels x 4080^2 < 2^31
     stage_window(G, Ib, pitch, sWin, lane);
-    for (int r = 0; r < G.rounds; r++) {
+#pragma unroll R > 0 ? R : 1
+    for (int r = 0; r < rounds; r++) {
       const int t = r * 64 + lane;
       unsigned I01 = 0, I23 = 0, X01 = 0, X23 = 0, Y01 = 0, Y23 = 0;
       if (t < G.ntasks) {
@@ -334,7 +338,8 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
       const uint8_t* Jp = Jb + (long long)iny * pitch + inx;
       int b1 = 0, b2 = 0;  // per lane <= 64 pixels x 8160 x 4080 < 2^31
       stage_window(G, Jp, pitch, sWin, lane);
-      for (int r = 0; r < G.rounds; r++) {
+  #pragma unroll R > 0 ? R : 1
+    for (int r = 0; r < rounds; r++) {
         const int t = r * 64 + lane;
         if (t < G.ntasks) {
           unsigned J01, J23;
@@ -355,7 +360,7 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
       ny += dy;
       next = make_float2(nx + half, ny + half);
       if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= P.eps2) break;
-      if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+      if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {  // (double)f < 0.01 <=> f <= 0.01f (0.01f < 0.01 < its successor)
         next.x = __fsub_rn(next.x, __fmul_rn(dx, 0.5f));
         next.y = __fsub_rn(next.y, __fmul_rn(dy, 0.5f));
         break;
@@ -374,7 +379,8 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
       const uint8_t* Jp = Jb + (long long)iey * pitch + iex;
       long long e = 0;
       stage_window(G, Jp, pitch, sWin, lane);
-      for (int r = 0; r < G.rounds; r++) {
+  #pragma unroll R > 0 ? R : 1
+    for (int r = 0; r < rounds; r++) {
         const int t = r * 64 + lane;
         if (t < G.ntasks) {
           const int ty = (t * G.inv_runs) >> 16, x0 = (t - ty * G.runs) * 4;
@@ -394,6 +400,7 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
 }
 
 // calcOpticalFlowPyrLK for B pairs: wave = one point.  pts layouts: [B][pt_stride] float2.
+template <int R>
 __global__ void __launch_bounds__(kKltThreads) k_klt_track(KltGeom G, KltParams P, const uint8_t* __restrict__ prev_img,
                                                            const short2* __restrict__ prev_deriv,
                                                            const uint8_t* __restrict__ next_img, const int* __restrict__ n_pts,
@@ -408,7 +415,7 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_track(KltGeom G, KltParams 
   float2 next = (P.flags & GFS_KLT_USE_INITIAL_FLOW) ? next_pts[po] : make_float2(0.f, 0.f);
   int status = 1;
   float err = 0.f;
-  klt_track_point(G, P, prev_img + fo, prev_deriv + fo, next_img + fo, prev_pts[po], next, status, err,
+  klt_track_point<R>(G, P, prev_img + fo, prev_deriv + fo, next_img + fo, prev_pts[po], next, status, err,
                   s_klt + wave * (3 * G.rounds * 64 + (G.win_dwords + 1) / 2), lane);
   if (lane == 0) {
     next_pts[po] = next;
@@ -419,6 +426,7 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_track(KltGeom G, KltParams 
 
 // fbKltTracking for B pairs: forward (prev -> cur, nbpyrlvl levels), gates (status, err > ferr, inBorder), backward
 // (cur -> prev, level 0, started from the original key point), forward-backward distance.  Wave = one point.
+template <int R>
 __global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, const uint8_t* __restrict__ prev_img,
                                                         const short2* __restrict__ prev_deriv, const uint8_t* __restrict__ cur_img,
                                                         const short2* __restrict__ cur_deriv, const int* __restrict__ n_pts,
@@ -435,7 +443,7 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, 
   float2 fwd = priors[po];
   int status = 1;
   float err = 0.f;
-  klt_track_point(G, P, prev_img + fo, prev_deriv + fo, cur_img + fo, kp, fwd, status, err, lds, lane);
+  klt_track_point<R>(G, P, prev_img + fo, prev_deriv + fo, cur_img + fo, kp, fwd, status, err, lds, lane);
   bool ok = status && !(err > ferr) && 1.f <= fwd.x && fwd.x < (float)G.width - 1.f && 1.f <= fwd.y && fwd.y < (float)G.height - 1.f;
   if (ok) {
     KltParams Pb = P;
@@ -443,7 +451,7 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, 
     float2 back = kp;
     int bstatus = 1;
     float berr = 0.f;
-    klt_track_point(G, Pb, cur_img + fo, cur_deriv + fo, prev_img + fo, fwd, back, bstatus, berr, lds, lane);
+    klt_track_point<R>(G, Pb, cur_img + fo, cur_deriv + fo, prev_img + fo, fwd, back, bstatus, berr, lds, lane);
     if (!bstatus) {
       ok = false;
     } else {
@@ -463,6 +471,17 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, 
 // ---------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
+// Round counts of the windows the reference's configurations use (LKWindowSize 15 / 30 / 35 / 40 -> 1 / 4 / 5 / 7 rounds) get
+// their own instantiation; every other window runs the generic loop.
+#define KLT_DISPATCH(rounds, CALL) \
+  switch (rounds) {                \
+    case 1: CALL(1); break;        \
+    case 4: CALL(4); break;        \
+    case 5: CALL(5); break;        \
+    case 7: CALL(7); break;        \
+    default: CALL(0); break;       \
+  }
+
 struct gfs_klt {
   int device = 0, max_batch = 0, max_points = 0;
   KltGeom G{};
@@ -557,8 +576,11 @@ int gfs_klt_create(int device, int width, int height, int win, int max_level, in
   }
   G.frame_stride = (long long)gfs::align_up((size_t)G.off[G.n_levels] + kKltSlack, 256);
   h->lds_bytes = (size_t)kKltWavesPerBlock * (3 * G.rounds * 64 + (G.win_dwords + 1) / 2) * sizeof(uint2);
-  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_track, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+#define KLT_ATTR(R)                                                                                                          \
+  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_track<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes)); \
+  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_fb<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes))
+  KLT_DISPATCH(G.rounds, KLT_ATTR)
+#undef KLT_ATTR
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t NP = (size_t)max_batch * max_points, NI = (size_t)max_batch * width * height;
   int rc = 0;
@@ -712,9 +734,11 @@ int gfs_klt_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid
   GFS_HIP(hipMemcpyAsync(h->d_n.p, h->h_n.p, B * sizeof(int), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_a.p, h->h_a.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   if (flags & GFS_KLT_USE_INITIAL_FLOW) GFS_HIP(hipMemcpyAsync(h->d_b.p, h->h_b.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
-  GFS_LAUNCH("k_klt_track", k_klt_track, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,
-             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)next->img.p, (const int*)h->d_n.p, S,
-             (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_err.p);
+#define KLT_RUN(R) GFS_LAUNCH("k_klt_track", k_klt_track<R>, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
+             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)next->img.p, (const int*)h->d_n.p, S,  \
+             (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_err.p)
+  KLT_DISPATCH(h->G.rounds, KLT_RUN)
+#undef KLT_RUN
   GFS_HIP(hipMemcpyAsync(h->h_b.p, h->d_b.p, NP * sizeof(float2), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_status.p, h->d_status.p, NP, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_err.p, h->d_err.p, NP * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -762,9 +786,11 @@ int gfs_klt_fb_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyra
   GFS_HIP(hipMemcpyAsync(h->d_a.p, h->h_a.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_b.p, h->h_b.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(h->d_good.p, 0, B * sizeof(int), s));
-  GFS_LAUNCH("k_klt_fb", k_klt_fb, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,
-             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,
-             (const int*)h->d_n.p, S, (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_good.p, ferr, fmax_fbklt_dist);
+#define KLT_RUN(R) GFS_LAUNCH("k_klt_fb", k_klt_fb<R>, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
+             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,  \
+             (const int*)h->d_n.p, S, (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_good.p, ferr, fmax_fbklt_dist)
+  KLT_DISPATCH(h->G.rounds, KLT_RUN)
+#undef KLT_RUN
   GFS_HIP(hipMemcpyAsync(h->h_b.p, h->d_b.p, NP * sizeof(float2), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_status.p, h->d_status.p, NP, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_good.p, h->d_good.p, B * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -793,10 +819,12 @@ int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_k
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const KltParams P = fb_params(h, nbpyrlvl);
   GFS_HIP(hipMemsetAsync(dev_n_good, 0, B * sizeof(int), s));
-  GFS_LAUNCH("k_klt_fb", k_klt_fb, dim3(gfs::div_up(pt_stride, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,
-             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,
-             (const int*)dev_n, pt_stride, (const float2*)dev_kps, (float2*)dev_priors, (uint8_t*)dev_kpstatus, (int*)dev_n_good,
-             ferr, fmax_fbklt_dist);
+#define KLT_RUN(R) GFS_LAUNCH("k_klt_fb", k_klt_fb<R>, dim3(gfs::div_up(pt_stride, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
+             (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,  \
+             (const int*)dev_n, pt_stride, (const float2*)dev_kps, (float2*)dev_priors, (uint8_t*)dev_kpstatus, (int*)dev_n_good,  \
+             ferr, fmax_fbklt_dist)
+  KLT_DISPATCH(h->G.rounds, KLT_RUN)
+#undef KLT_RUN
   if (!stream) GFS_HIP(hipStreamSynchronize(s));
   return GFS_OK;
 }
