@@ -3,13 +3,15 @@
 // VertexSE3Expmap / VertexSBAPointXYZ with EdgeSE3ProjectXYZ (mono) and EdgeStereoSE3ProjectXYZ (RGB-D) edges,
 // Huber kernels, Schur complement on the landmarks, 10 LM iterations with up to 10 lambda trials each.
 //
-// MI355X design: one window is far too small to feed 256 CUs (<= ~30 free poses, a few thousand landmarks), and
-// windows of one map cannot be sharded ("replicas only").  So ONE WORKGROUP (1024 threads, one CU)
-// runs the whole Levenberg-Marquardt loop of one window without any host round trip: every phase is a block-wide
-// parallel sweep separated by workgroup barriers, the reduced pose system (packed lower triangle, <= 180x180
-// doubles = 130 KB) lives in LDS for the Schur accumulation, the LDL^T factorisation and the triangular solves,
-// and all sums are taken in a fixed order (deterministic, unlike atomics).  Throughput scales by launching one
-// workgroup per window (grid = #windows).
+// MI355X design: a window (tens of free poses, a few thousand landmarks, ~50 k edges) is small and windows of one map cannot
+// be sharded ("replicas only"), so the work is spread over the chip phase by phase: one launch per phase of
+// a Levenberg-Marquardt trial (edge errors, landmark blocks with 16 lanes per landmark, pose blocks, Schur products with one
+// workgroup per pose pair, the reduced solve, back-substitution / update, the LM decision), the LM state lives in HBM
+// (LbaState) and the host only reads two mapped flags per trial.  The reduced pose system is factored by one workgroup with a
+// blocked 6-wide LDL^T: in LDS while its packed triangle fits (<= 30 free poses, 130 KB), in place in HBM / L2 with the
+// current panel staged in LDS for larger windows.  All sums are taken in a fixed order (deterministic, unlike atomics).
+// GFS_LBA_SINGLE_WG=1 selects the first implementation instead (k_lba: the whole LM loop of a window in ONE workgroup with
+// the reduced system in LDS, no host round trip; windows of <= 30 free poses only).
 //
 // Edge order: edges are stably re-ordered landmark-major on the host so each landmark's observations are
 // contiguous (the reference builds them that way, src/Optimizer.cc:1816-1952); a second CSR lists each free
@@ -27,7 +29,7 @@
 namespace {
 
 constexpr int kThreads = 1024;
-constexpr int kMaxFree = 30;
+constexpr int kMaxFreeLds = 30;  // up to this many free poses the reduced system (180 x 180 packed) is factored in LDS
 
 // LM bookkeeping of the multi-kernel path, resident in HBM (the scalar logic of OptimizationAlgorithmLevenberg::solve)
 struct LbaState {
@@ -774,14 +776,20 @@ __global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) {
   if (i1 == i2 && tk >= 4 && tk < 10) D.bs[6 * i1 + (tk - 4)] = D.bp[6 * i1 + (tk - 4)] - v1;
 }
 
-// LDL^T + triangular solves of the reduced pose system in LDS (single workgroup: n <= 180)
+// LDL^T + triangular solves of the reduced pose system by a single workgroup.  kLds: the packed triangle fits the 160 KB of
+// LDS (n <= 180, i.e. up to 30 free poses) and is factored there.  Otherwise (larger windows) it is factored in place in HBM /
+// L2; only the right-hand side and the current 6-column panel are held in LDS, so the trailing update reads and writes each
+// element once.  Same arithmetic, same order of operations per entry in both variants.
+template <bool kLds>
 __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
   extern __shared__ __align__(16) double lds[];
   __shared__ int s_flag;
   const int n = 6 * D.n_free;
-  double* Hs = lds;
-  double* bs = lds + (size_t)n * (n + 1) / 2;
-  for (int k = threadIdx.x; k < n * (n + 1) / 2; k += kThreads) Hs[k] = D.Hs[k];
+  double* Hs = kLds ? lds : D.Hs;
+  double* bs = kLds ? lds + (size_t)n * (n + 1) / 2 : lds;
+  double* pan = lds + n;  // !kLds only: panel rows [n][6] followed by the 6 pivots
+  if (kLds)
+    for (int k = threadIdx.x; k < n * (n + 1) / 2; k += kThreads) Hs[k] = D.Hs[k];
   for (int k = threadIdx.x; k < n; k += kThreads) bs[k] = D.bs[k];
   if (threadIdx.x == 0) s_flag = 0;
   __syncthreads();
@@ -831,6 +839,11 @@ __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
     }
     __syncthreads();
     const int m = n - jb - 6;  // (c) trailing size
+    if (!kLds) {               // panel and pivots into LDS: the update then touches HBM once per element
+      for (int k = threadIdx.x; k < 6 * m; k += kThreads) pan[k] = Hs[tri(jb + 6 + k / 6, jb + k % 6)];
+      if (threadIdx.x < 6) pan[6 * m + threadIdx.x] = Hs[tri(jb + threadIdx.x, jb + threadIdx.x)];
+      __syncthreads();
+    }
     for (int k = threadIdx.x; k < m * (m + 1) / 2; k += kThreads) {
       int r = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
       while (r * (r + 1) / 2 > k) r--;
@@ -838,7 +851,11 @@ __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
       const int c = k - r * (r + 1) / 2;
       const int ii = jb + 6 + r, kk = jb + 6 + c;
       double v = Hs[tri(ii, kk)];
-      for (int c2 = 0; c2 < 6; c2++) v -= Hs[tri(ii, jb + c2)] * Hs[tri(kk, jb + c2)] * Hs[tri(jb + c2, jb + c2)];
+      if (kLds) {
+        for (int c2 = 0; c2 < 6; c2++) v -= Hs[tri(ii, jb + c2)] * Hs[tri(kk, jb + c2)] * Hs[tri(jb + c2, jb + c2)];
+      } else {
+        for (int c2 = 0; c2 < 6; c2++) v -= pan[6 * r + c2] * pan[6 * c + c2] * pan[6 * m + c2];
+      }
       Hs[tri(ii, kk)] = v;
     }
     __syncthreads();
@@ -1059,8 +1076,6 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
       P.free_pose.push_back(i);
     }
   P.n_free = (int)P.free_pose.size();
-  GFS_REQUIRE(P.n_free <= kMaxFree, GFS_ERR_UNSUPPORTED, "gfs_lba: %d free poses exceed the single-workgroup limit of %d",
-              P.n_free, kMaxFree);
   const int E = p->n_edges, NP = p->n_points;
   P.pt_begin.assign(NP + 1, 0);
   for (int e = 0; e < E; e++) {
@@ -1175,10 +1190,12 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   D.out_stats = h->d_stats.p;
   D.mode = mode;
   const int n = 6 * P.n_free;
-  const size_t lds = ((size_t)n * (n + 1) / 2 + n + 8) * sizeof(double);
+  const bool in_lds = P.n_free <= kMaxFreeLds;
+  const size_t lds = (in_lds ? (size_t)n * (n + 1) / 2 + n + 8 : (size_t)7 * n + 8) * sizeof(double);
+  GFS_REQUIRE(lds <= 160 * 1024, GFS_ERR_CAPACITY, "gfs_lba: %d free poses exceed the solver's workspace", P.n_free);
   static const bool single_wg = getenv("GFS_LBA_SINGLE_WG") != nullptr;  // the round-1a kernel: whole solve in one workgroup
   h->final_cur = 0;
-  if (single_wg) {
+  if (single_wg && in_lds) {
     GFS_HIP(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GFS_LAUNCH("k_lba", k_lba, dim3(1), dim3(kThreads), lds, s, D);
     // setForceStopFlag semantics (src/Optimizer.cc:1679): relay the caller's flag to the device-visible one
@@ -1204,7 +1221,8 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   D.n_upd_blocks = gfs::div_up(std::max(NP, 1), kMk);
   int* d_flags = nullptr;
   GFS_HIP(hipHostGetDevicePointer((void**)&d_flags, h->h_flags, 0));
-  GFS_HIP(hipFuncSetAttribute((const void*)k_lba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GFS_HIP(hipFuncSetAttribute(in_lds ? (const void*)k_lba_solve<true> : (const void*)k_lba_solve<false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 8)), g_upd(D.n_upd_blocks);
   GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
   const bool lin_only = mode == 1 || p->iterations <= 0;
@@ -1232,7 +1250,10 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
     for (;;) {
       GFS_LAUNCH("k_lba_dinv", k_lba_dinv, g_upd, dim3(kMk), 0, s, D);
       if (npairs > 0) GFS_LAUNCH("k_lba_schur", k_lba_schur, dim3(npairs), dim3(kMk), 0, s, D);
-      GFS_LAUNCH("k_lba_solve", k_lba_solve, dim3(1), dim3(kThreads), lds, s, D);
+      if (in_lds)
+        GFS_LAUNCH("k_lba_solve", k_lba_solve<true>, dim3(1), dim3(kThreads), lds, s, D);
+      else
+        GFS_LAUNCH("k_lba_solve", k_lba_solve<false>, dim3(1), dim3(kThreads), lds, s, D);
       GFS_LAUNCH("k_lba_update", k_lba_update, g_upd, dim3(kMk), 0, s, D);
       GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 1);
       GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 0, d_flags);
@@ -1276,7 +1297,7 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   GFS_HIP(hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped));
   GFS_HIP(hipHostMalloc((void**)&h->h_flags, 4 * sizeof(int), hipHostMallocMapped));
-  const size_t NP = max_points, E = max_edges, NQ = max_poses, F = kMaxFree;
+  const size_t NP = max_points, E = max_edges, NQ = max_poses, F = max_poses;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
   A(h->d_q0.alloc(NQ * 4));

@@ -26,10 +26,13 @@ def test_linearize_blocks_match_oracle(gpu_api, oracle):
 @pytest.mark.parametrize("cfg", [dict(seed=0, n_free=20, n_fixed=5, n_points=3000),
                                  dict(seed=1, n_free=8, n_fixed=3, n_points=600),
                                  dict(seed=2, n_free=3, n_fixed=1, n_points=80, mono_frac=1.0),
-                                 dict(seed=3, n_free=30, n_fixed=2, n_points=400)])
+                                 dict(seed=3, n_free=30, n_fixed=2, n_points=400),
+                                 dict(seed=5, n_free=31, n_fixed=2, n_points=500),    # first size factored in HBM instead of LDS
+                                 dict(seed=6, n_free=48, n_fixed=6, n_points=1500),
+                                 dict(seed=7, n_free=80, n_fixed=4, n_points=800)])
 def test_solve_matches_oracle(gpu_api, oracle, cfg):
     w = synth.lba_window(**cfg)
-    opt = gpu_api.Optimizer()
+    opt = gpu_api.Optimizer(max_poses=96, max_points=4096, max_edges=200000)
     r = opt.LocalBundleAdjustment(w)
     ro = oracle.lba_solve(w)
     assert r["iterations_run"] == ro["iterations_run"]
