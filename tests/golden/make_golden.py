@@ -53,6 +53,16 @@ def main():
                         out_pose_t=s["pose_t"], out_points=s["points"], out_edge_chi2=s["edge_chi2"],
                         out_iterations=s["iterations_run"], out_chi2=s["final_chi2"], lin_bp=L["bp"], lin_bl=L["bl"],
                         lin_Hpp=L["Hpp"], lin_chi2=L["chi2"])
+    # 5. optical flow: the ORB key points of frame 0 tracked into frame 1 (window 15, 3 pyramid levels: 40 x 30 is the last
+    #    level larger than the window), forward-backward checked; plus a plain calcOpticalFlowPyrLK call with the L1 error
+    import zlib
+    kps = np.stack([k0["x"], k0["y"]], 1).astype(np.float32)
+    p0, p1 = O.klt_build_pyramid(fp["gray0"], 15), O.klt_build_pyramid(fp["gray1"], 15)
+    pri, ok, good = O.fb_klt_tracking(p0, p1, 160, 120, 15, 3, 15.0, 0.5, kps, kps + np.float32(0.5))
+    nxt, st, er = O.klt_track(p0, p1, 160, 120, 15, kps, max_level=2, flags=0)
+    np.savez_compressed(os.path.join(OUT, "klt_160x120.npz"), kps=kps, priors=pri, status=ok, good=good, next=nxt, st=st, err=er,
+                        pyr_crc=np.array([zlib.crc32(p0[0].tobytes()), zlib.crc32(p0[1].tobytes()), zlib.crc32(p1[0].tobytes()),
+                                          zlib.crc32(p1[1].tobytes())], np.int64))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
