@@ -399,6 +399,21 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
   }
 }
 
+// Workgroup -> (frame, group of 4 points).  Workgroups are handed to the 8 XCDs round-robin by their linear id and every XCD
+// has its own L2: with a multiple of 8 frames in the batch, frame f is worked on by XCD f % 8 only, so each pyramid is
+// fetched into one L2 instead of all eight.  gx = workgroups per frame.
+__device__ __forceinline__ void klt_block_to_work(int gx, int n_frames, int& f, int& bx) {
+  const int L = blockIdx.x;
+  if ((n_frames & 7) == 0) {
+    const int slot = L >> 3;
+    f = (L & 7) + 8 * (slot / gx);
+    bx = slot % gx;
+  } else {
+    f = L / gx;
+    bx = L % gx;
+  }
+}
+
 // calcOpticalFlowPyrLK for B pairs: wave = one point.  pts layouts: [B][pt_stride] float2.
 template <int R>
 __global__ void __launch_bounds__(kKltThreads) k_klt_track(KltGeom G, KltParams P, const uint8_t* __restrict__ prev_img,
@@ -406,10 +421,12 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_track(KltGeom G, KltParams 
                                                            const uint8_t* __restrict__ next_img, const int* __restrict__ n_pts,
                                                            int pt_stride, const float2* __restrict__ prev_pts,
                                                            float2* __restrict__ next_pts, uint8_t* __restrict__ status_out,
-                                                           float* __restrict__ err_out) {
+                                                           float* __restrict__ err_out, int gx, int n_frames) {
   extern __shared__ uint2 s_klt[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.y;
-  const int i = blockIdx.x * kKltWavesPerBlock + wave;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int f, bx;
+  klt_block_to_work(gx, n_frames, f, bx);
+  const int i = bx * kKltWavesPerBlock + wave;
   if (i >= n_pts[f]) return;
   const long long fo = (long long)f * G.frame_stride, po = (long long)f * pt_stride + i;
   float2 next = (P.flags & GFS_KLT_USE_INITIAL_FLOW) ? next_pts[po] : make_float2(0.f, 0.f);
@@ -432,10 +449,12 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, 
                                                         const short2* __restrict__ cur_deriv, const int* __restrict__ n_pts,
                                                         int pt_stride, const float2* __restrict__ kps, float2* __restrict__ priors,
                                                         uint8_t* __restrict__ kpstatus, int* __restrict__ n_good, float ferr,
-                                                        float fmax_fbklt_dist) {
+                                                        float fmax_fbklt_dist, int gx, int n_frames) {
   extern __shared__ uint2 s_klt[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.y;
-  const int i = blockIdx.x * kKltWavesPerBlock + wave;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int f, bx;
+  klt_block_to_work(gx, n_frames, f, bx);
+  const int i = bx * kKltWavesPerBlock + wave;
   if (i >= n_pts[f]) return;
   uint2* lds = s_klt + wave * (3 * G.rounds * 64 + (G.win_dwords + 1) / 2);
   const long long fo = (long long)f * G.frame_stride, po = (long long)f * pt_stride + i;
@@ -734,9 +753,9 @@ int gfs_klt_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid
   GFS_HIP(hipMemcpyAsync(h->d_n.p, h->h_n.p, B * sizeof(int), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_a.p, h->h_a.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   if (flags & GFS_KLT_USE_INITIAL_FLOW) GFS_HIP(hipMemcpyAsync(h->d_b.p, h->h_b.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
-#define KLT_RUN(R) GFS_LAUNCH("k_klt_track", k_klt_track<R>, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
+#define KLT_RUN(R) GFS_LAUNCH("k_klt_track", k_klt_track<R>, dim3(gfs::div_up(nmax, kKltWavesPerBlock) * B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
              (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)next->img.p, (const int*)h->d_n.p, S,  \
-             (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_err.p)
+             (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_err.p, gfs::div_up(nmax, kKltWavesPerBlock), B)
   KLT_DISPATCH(h->G.rounds, KLT_RUN)
 #undef KLT_RUN
   GFS_HIP(hipMemcpyAsync(h->h_b.p, h->d_b.p, NP * sizeof(float2), hipMemcpyDeviceToHost, s));
@@ -786,9 +805,10 @@ int gfs_klt_fb_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyra
   GFS_HIP(hipMemcpyAsync(h->d_a.p, h->h_a.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_b.p, h->h_b.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(h->d_good.p, 0, B * sizeof(int), s));
-#define KLT_RUN(R) GFS_LAUNCH("k_klt_fb", k_klt_fb<R>, dim3(gfs::div_up(nmax, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
+#define KLT_RUN(R) GFS_LAUNCH("k_klt_fb", k_klt_fb<R>, dim3(gfs::div_up(nmax, kKltWavesPerBlock) * B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
              (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,  \
-             (const int*)h->d_n.p, S, (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_good.p, ferr, fmax_fbklt_dist)
+             (const int*)h->d_n.p, S, (const float2*)h->d_a.p, h->d_b.p, h->d_status.p, h->d_good.p, ferr, fmax_fbklt_dist,  \
+             gfs::div_up(nmax, kKltWavesPerBlock), B)
   KLT_DISPATCH(h->G.rounds, KLT_RUN)
 #undef KLT_RUN
   GFS_HIP(hipMemcpyAsync(h->h_b.p, h->d_b.p, NP * sizeof(float2), hipMemcpyDeviceToHost, s));
@@ -819,10 +839,10 @@ int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_k
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const KltParams P = fb_params(h, nbpyrlvl);
   GFS_HIP(hipMemsetAsync(dev_n_good, 0, B * sizeof(int), s));
-#define KLT_RUN(R) GFS_LAUNCH("k_klt_fb", k_klt_fb<R>, dim3(gfs::div_up(pt_stride, kKltWavesPerBlock), B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
+#define KLT_RUN(R) GFS_LAUNCH("k_klt_fb", k_klt_fb<R>, dim3(gfs::div_up(pt_stride, kKltWavesPerBlock) * B), dim3(kKltThreads), h->lds_bytes, s, h->G, P,  \
              (const uint8_t*)prev->img.p, (const short2*)prev->deriv.p, (const uint8_t*)cur->img.p, (const short2*)cur->deriv.p,  \
              (const int*)dev_n, pt_stride, (const float2*)dev_kps, (float2*)dev_priors, (uint8_t*)dev_kpstatus, (int*)dev_n_good,  \
-             ferr, fmax_fbklt_dist)
+             ferr, fmax_fbklt_dist, gfs::div_up(pt_stride, kKltWavesPerBlock), B)
   KLT_DISPATCH(h->G.rounds, KLT_RUN)
 #undef KLT_RUN
   if (!stream) GFS_HIP(hipStreamSynchronize(s));
