@@ -177,13 +177,15 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
   for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
   return v;
 }
-__device__ __forceinline__ void bilinear_weights(float a, float b, unsigned& W0, unsigned& W1) {
+// The four 14-bit weights as two v_dot2 operands: Wl = (w00, w10) multiplies the vertical pair under a pixel's left tap
+// column, Wr = (w01, w11) the pair under its right tap column.
+__device__ __forceinline__ void bilinear_weights(float a, float b, unsigned& Wl, unsigned& Wr) {
   const int w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
   const int w01 = __float2int_rn(a * (1.f - b) * 16384.f);
   const int w10 = __float2int_rn((1.f - a) * b * 16384.f);
   const int w11 = 16384 - w00 - w01 - w10;
-  W0 = (unsigned)uniform(w00 | (w01 << 16));  // all four lie in [0, 16384]: they fit the signed halves of v_dot2
-  W1 = (unsigned)uniform(w10 | (w11 << 16));
+  Wl = (unsigned)uniform(w00 | (w10 << 16));  // all four lie in [0, 16384]: they fit the signed halves of v_dot2
+  Wr = (unsigned)uniform(w01 | (w11 << 16));
 }
 // Copies the (win + 1) rows x 4 * nd bytes of the window whose top-left byte is `base` (wave-uniform) into the wave's LDS
 // window buffer.  16 (nd <= 16) or 32 lanes walk down one column of dwords each, 4 or 2 rows per step: consecutive lanes
@@ -210,14 +212,16 @@ __device__ __forceinline__ void stage_window(const KltGeom& G, const uint8_t* ba
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // Five bytes of two staged window rows -> four bilinear samples << 5 (CV_DESCALE(..., W_BITS1 - 5)), as two packed pairs.
-// i0 = dword index of the run in the window buffer.
-__device__ __forceinline__ void blend4(const unsigned* sWin, int i0, int nd, unsigned W0, unsigned W1, unsigned& v01, unsigned& v23) {
+// i0 = dword index of the run in the window buffer.  Column i of the two rows is paired into one dword (upper, lower) by
+// v_perm_b32 (bytes 0-3 select from the second operand, 4-7 from the first, 0x0c = zero); a column serves as the right taps
+// of pixel i - 1 and as the left taps of pixel i, so 5 permutes feed 8 v_dot2.
+__device__ __forceinline__ void blend4(const unsigned* sWin, int i0, int nd, unsigned Wl, unsigned Wr, unsigned& v01, unsigned& v23) {
   const unsigned a = sWin[i0], a4 = sWin[i0 + 1], b = sWin[i0 + nd], b4 = sWin[i0 + nd + 1];
-  // v_perm_b32: bytes 0-3 select from the second operand, 4-7 from the first, 0x0c = zero
-  const int v0 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c010c00u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c010c00u), W1, 256)) >> 9;
-  const int v1 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c020c01u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c020c01u), W1, 256)) >> 9;
-  const int v2 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c030c02u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c030c02u), W1, 256)) >> 9;
-  const int v3 = dot2(__builtin_amdgcn_perm(a4, a, 0x0c040c03u), W0, dot2(__builtin_amdgcn_perm(b4, b, 0x0c040c03u), W1, 256)) >> 9;
+  const unsigned c0 = __builtin_amdgcn_perm(b, a, 0x0c040c00u), c1 = __builtin_amdgcn_perm(b, a, 0x0c050c01u),
+                 c2 = __builtin_amdgcn_perm(b, a, 0x0c060c02u), c3 = __builtin_amdgcn_perm(b, a, 0x0c070c03u),
+                 c4 = __builtin_amdgcn_perm(b4, a4, 0x0c040c00u);
+  const int v0 = dot2(c0, Wl, dot2(c1, Wr, 256)) >> 9, v1 = dot2(c1, Wl, dot2(c2, Wr, 256)) >> 9;
+  const int v2 = dot2(c2, Wl, dot2(c3, Wr, 256)) >> 9, v3 = dot2(c3, Wl, dot2(c4, Wr, 256)) >> 9;
   v01 = (unsigned)v0 | ((unsigned)v1 << 16);  // samples are in [0, 8160]
   v23 = (unsigned)v2 | ((unsigned)v3 << 16);
 }
@@ -287,13 +291,17 @@ __device__ void klt_track_point(const KltGeom& G, const KltParams& P, const uint
           da[i] = d0[i];
           db[i] = d1[i];
         }
+        unsigned cx[5], cy[5];  // column i of the two rows: (upper, lower) x derivatives, (upper, lower) y derivatives
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+          cx[i] = __builtin_amdgcn_perm(db[i], da[i], 0x05040100u);
+          cy[i] = __builtin_amdgcn_perm(db[i], da[i], 0x07060302u);
+        }
         int ix[4], iy[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {  // halves 0 / 1 of element i and i + 1: the x (resp. y) derivatives of two neighbours
-          ix[i] = dot2(__builtin_amdgcn_perm(da[i + 1], da[i], 0x05040100u), W0,
-                       dot2(__builtin_amdgcn_perm(db[i + 1], db[i], 0x05040100u), W1, 8192)) >> 14;
-          iy[i] = dot2(__builtin_amdgcn_perm(da[i + 1], da[i], 0x07060302u), W0,
-                       dot2(__builtin_amdgcn_perm(db[i + 1], db[i], 0x07060302u), W1, 8192)) >> 14;
+        for (int i = 0; i < 4; i++) {
+          ix[i] = dot2(cx[i], W0, dot2(cx[i + 1], W1, 8192)) >> 14;
+          iy[i] = dot2(cy[i], W0, dot2(cy[i + 1], W1, 8192)) >> 14;
           if (x0 + i >= win) ix[i] = iy[i] = 0;  // beyond the window: contributes nothing anywhere
         }
         X01 = (unsigned)(ix[0] & 0xffff) | ((unsigned)ix[1] << 16);
