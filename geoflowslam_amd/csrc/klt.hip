@@ -57,27 +57,32 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Pyramid kernels
 // ---------------------------------------------------------------------------------------------------------------------
+// Level 0 with its reflect-101 border: thread = 4 consecutive padded pixels (one aligned dword store).  A group that lies
+// inside the image columns is one unaligned dword load; groups that touch the border take the per-byte path.
 __global__ void __launch_bounds__(256) k_klt_level0(KltGeom G, const uint8_t* __restrict__ src, int stride, long long src_frame,
                                                      uint8_t* __restrict__ pyr) {
-  const int pw = G.lw[0] + 2 * G.win, ph = G.lh[0] + 2 * G.win;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= pw * ph) return;
+  const int pw = G.lw[0] + 2 * G.win, ph = G.lh[0] + 2 * G.win, total = pw * ph;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
   const int y = i / pw, x = i - y * pw;
-  const int sx = reflect101(x - G.win, G.lw[0]), sy = reflect101(y - G.win, G.lh[0]);
-  pyr[(long long)blockIdx.y * G.frame_stride + i] = src[(long long)blockIdx.y * src_frame + (long long)sy * stride + sx];
+  const uint8_t* sf = src + (long long)blockIdx.y * src_frame;
+  uint8_t* dst = pyr + (long long)blockIdx.y * G.frame_stride + i;
+  if (x >= G.win && x + 3 < G.win + G.lw[0] && i + 3 < total) {
+    unsigned v;
+    __builtin_memcpy(&v, sf + (long long)reflect101(y - G.win, G.lh[0]) * stride + (x - G.win), 4);
+    *(unsigned*)dst = v;  // frame_stride and i are multiples of 4
+    return;
+  }
+  for (int k = 0; k < 4 && i + k < total; k++) {
+    const int yy = (i + k) / pw, xx = (i + k) - yy * pw;
+    dst[k] = sf[(long long)reflect101(yy - G.win, G.lh[0]) * stride + reflect101(xx - G.win, G.lw[0])];
+  }
 }
 
-// Level l >= 1: pyrDown of level l - 1 (5x5 binomial, (s + 128) >> 8) for every padded pixel.  The taps reach at most two
-// pixels outside level l - 1, where its own reflect-101 border holds exactly what pyrDown's border rule would fetch.
-__global__ void __launch_bounds__(256) k_klt_pyrdown(KltGeom G, int level, uint8_t* __restrict__ pyr) {
-  const int cw = G.lw[level], ch = G.lh[level], pw = cw + 2 * G.win, ph = ch + 2 * G.win;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= pw * ph) return;
-  const int y = i / pw, x = i - y * pw;
-  const int ix = reflect101(x - G.win, cw), iy = reflect101(y - G.win, ch);
-  const int ppw = G.lw[level - 1] + 2 * G.win;
-  uint8_t* frame = pyr + (long long)blockIdx.y * G.frame_stride;
-  const uint8_t* p = frame + G.off[level - 1] + (long long)(2 * iy - 2 + G.win) * ppw + (2 * ix - 2 + G.win);
+// Level l >= 1: pyrDown of level l - 1 (5x5 binomial, (s + 128) >> 8) for every padded pixel; thread = 2 consecutive padded
+// pixels.  The taps reach at most two pixels outside level l - 1, where its own reflect-101 border holds exactly what
+// pyrDown's border rule would fetch.  Two neighbours inside the level share 7 source columns: five unaligned 8-byte loads.
+__device__ __forceinline__ int pyrdown_one(const uint8_t* p, int ppw) {
   int s = 0;
 #pragma unroll
   for (int r = 0; r < 5; r++) {
@@ -85,31 +90,105 @@ __global__ void __launch_bounds__(256) k_klt_pyrdown(KltGeom G, int level, uint8
     const int hs = row[0] + row[4] + 4 * (row[1] + row[3]) + 6 * row[2];
     s += (r == 0 || r == 4) ? hs : (r == 2 ? 6 * hs : 4 * hs);
   }
-  frame[G.off[level] + i] = (uint8_t)((s + 128) >> 8);
+  return (s + 128) >> 8;
+}
+__global__ void __launch_bounds__(256) k_klt_pyrdown(KltGeom G, int level, uint8_t* __restrict__ pyr) {
+  const int cw = G.lw[level], ch = G.lh[level], pw = cw + 2 * G.win, ph = ch + 2 * G.win, total = pw * ph;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= total) return;
+  const int y = i / pw, x = i - y * pw;
+  const int ppw = G.lw[level - 1] + 2 * G.win;
+  uint8_t* frame = pyr + (long long)blockIdx.y * G.frame_stride;
+  const uint8_t* prev = frame + G.off[level - 1] + (long long)(G.win - 2) * ppw + (G.win - 2);  // tap (-2, -2) of source pixel (0, 0)
+  uint8_t* dst = frame + G.off[level] + i;
+  if (x >= G.win && x + 1 < G.win + cw && y >= G.win && y < G.win + ch) {
+    const uint8_t* p = prev + (long long)(2 * (y - G.win)) * ppw + 2 * (x - G.win);
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      unsigned long long v;
+      __builtin_memcpy(&v, p + (long long)r * ppw, 8);
+      const int b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = (v >> 24) & 0xff, b4 = (v >> 32) & 0xff,
+                b5 = (v >> 40) & 0xff, b6 = (v >> 48) & 0xff;
+      const int h0 = b0 + b4 + 4 * (b1 + b3) + 6 * b2, h1 = b2 + b6 + 4 * (b3 + b5) + 6 * b4;
+      const int wr = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
+      s0 += wr * h0;
+      s1 += wr * h1;
+    }
+    dst[0] = (uint8_t)((s0 + 128) >> 8);
+    dst[1] = (uint8_t)((s1 + 128) >> 8);
+    return;
+  }
+  for (int k = 0; k < 2 && i + k < total; k++) {
+    const int yy = (i + k) / pw, xx = (i + k) - yy * pw;
+    const int ix = reflect101(xx - G.win, cw), iy = reflect101(yy - G.win, ch);
+    dst[k] = (uint8_t)pyrdown_one(prev + (long long)(2 * iy) * ppw + 2 * ix, ppw);
+  }
 }
 
-// calcSharrDeriv on every level at once: thread = one padded pixel of one level (zero outside the level itself).  Inside, the
-// 3x3 stencil reads the padded image, whose reflect-101 border equals calcSharrDeriv's own border rule.
+// calcSharrDeriv on every level at once: thread = 4 consecutive padded pixels of one level (zero outside the level itself).
+// The 3x3 stencils read the padded image, whose reflect-101 border equals calcSharrDeriv's own border rule; in flat addressing
+// four neighbouring pixels need bytes [-1, +4] of three rows: three unaligned 8-byte loads instead of 32 byte loads.
 __global__ void __launch_bounds__(256) k_klt_scharr(KltGeom G, const uint8_t* __restrict__ pyr, short2* __restrict__ deriv) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= G.off[G.n_levels]) return;
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long long total = G.off[G.n_levels];
+  if (i >= total) return;
+  const uint8_t* frame = pyr + (long long)blockIdx.y * G.frame_stride;
+  short2* out = deriv + (long long)blockIdx.y * G.frame_stride + i;
   int level = 0;
   while (level + 1 < G.n_levels && i >= G.off[level + 1]) level++;
   const int cw = G.lw[level], ch = G.lh[level], pw = cw + 2 * G.win;
   const int rel = (int)(i - G.off[level]);
-  const int y = rel / pw, x = rel - y * pw;
-  short2 d = make_short2(0, 0);
-  if (x >= G.win && x < G.win + cw && y >= G.win && y < G.win + ch) {
-    const uint8_t* p = pyr + (long long)blockIdx.y * G.frame_stride + i;
-    const int a0 = p[-pw - 1], a1 = p[-pw], a2 = p[-pw + 1];
-    const int b0 = p[-1], b2 = p[1];
-    const int c0 = p[pw - 1], c1 = p[pw], c2 = p[pw + 1];
-    const int t0m = (a0 + c0) * 3 + b0 * 10, t0p = (a2 + c2) * 3 + b2 * 10;
-    const int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
-    d.x = (short)(t0p - t0m);
-    d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+  int y = rel / pw, x = rel - y * pw;
+  const bool one_level = i + 3 < G.off[level + 1];
+  bool any = false;
+  if (one_level) {
+    int xx = x, yy = y;
+    for (int k = 0; k < 4; k++) {
+      any |= xx >= G.win && xx < G.win + cw && yy >= G.win && yy < G.win + ch;
+      if (++xx == pw) xx = 0, yy++;
+    }
   }
-  deriv[(long long)blockIdx.y * G.frame_stride + i] = d;
+  short2 d[4] = {make_short2(0, 0), make_short2(0, 0), make_short2(0, 0), make_short2(0, 0)};
+  if (one_level && any) {
+    const uint8_t* p = frame + i;
+    unsigned long long ra, rb, rc;  // bytes [-1, +6] of the rows above, at and below
+    __builtin_memcpy(&ra, p - pw - 1, 8);
+    __builtin_memcpy(&rb, p - 1, 8);
+    __builtin_memcpy(&rc, p + pw - 1, 8);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (x >= G.win && x < G.win + cw && y >= G.win && y < G.win + ch) {
+        const int a0 = (ra >> (8 * k)) & 0xff, a1 = (ra >> (8 * k + 8)) & 0xff, a2 = (ra >> (8 * k + 16)) & 0xff;
+        const int b0 = (rb >> (8 * k)) & 0xff, b2 = (rb >> (8 * k + 16)) & 0xff;
+        const int c0 = (rc >> (8 * k)) & 0xff, c1 = (rc >> (8 * k + 8)) & 0xff, c2 = (rc >> (8 * k + 16)) & 0xff;
+        const int t0m = (a0 + c0) * 3 + b0 * 10, t0p = (a2 + c2) * 3 + b2 * 10;
+        const int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
+        d[k] = make_short2((short)(t0p - t0m), (short)((t1p + t1m) * 3 + t1c * 10));
+      }
+      if (++x == pw) x = 0, y++;
+    }
+  } else if (!one_level) {  // the group straddles two levels (at most one group per level): pixel by pixel
+    for (int k = 0; k < 4 && i + k < total; k++) {
+      const long long j = i + k;
+      int l2 = level;
+      while (l2 + 1 < G.n_levels && j >= G.off[l2 + 1]) l2++;
+      const int w2 = G.lw[l2], h2 = G.lh[l2], pw2 = w2 + 2 * G.win, r2 = (int)(j - G.off[l2]);
+      const int y2 = r2 / pw2, x2 = r2 - y2 * pw2;
+      if (x2 >= G.win && x2 < G.win + w2 && y2 >= G.win && y2 < G.win + h2) {
+        const uint8_t* p = frame + j;
+        const int a0 = p[-pw2 - 1], a1 = p[-pw2], a2 = p[-pw2 + 1], b0 = p[-1], b2 = p[1], c0 = p[pw2 - 1], c1 = p[pw2], c2 = p[pw2 + 1];
+        d[k] = make_short2((short)(((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10)),
+                           (short)(((c2 - a2) + (c0 - a0)) * 3 + (c1 - a1) * 10));
+      }
+    }
+  }
+  if (i + 3 < total) {
+    *(uint4*)out = make_uint4(__builtin_bit_cast(unsigned, d[0]), __builtin_bit_cast(unsigned, d[1]), __builtin_bit_cast(unsigned, d[2]),
+                              __builtin_bit_cast(unsigned, d[3]));  // 16-byte aligned: frame_stride and i are multiples of 4 elements
+  } else {
+    for (int k = 0; k < 4 && i + k < total; k++) out[k] = d[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -538,13 +617,13 @@ namespace {
 int klt_build(gfs_klt* h, gfs_klt_pyramid* pyr, const uint8_t* dev_images, int stride, int B, hipStream_t s) {
   const KltGeom& G = h->G;
   const int pw0 = G.lw[0] + 2 * G.win, ph0 = G.lh[0] + 2 * G.win;
-  GFS_LAUNCH("k_klt_level0", k_klt_level0, dim3(gfs::div_up(pw0 * ph0, 256), B), dim3(256), 0, s, G, dev_images, stride,
+  GFS_LAUNCH("k_klt_level0", k_klt_level0, dim3(gfs::div_up(gfs::div_up(pw0 * ph0, 4), 256), B), dim3(256), 0, s, G, dev_images, stride,
              (long long)stride * G.height, pyr->img.p);
   for (int l = 1; l < G.n_levels; l++) {
     const int n = (G.lw[l] + 2 * G.win) * (G.lh[l] + 2 * G.win);
-    GFS_LAUNCH("k_klt_pyrdown", k_klt_pyrdown, dim3(gfs::div_up(n, 256), B), dim3(256), 0, s, G, l, pyr->img.p);
+    GFS_LAUNCH("k_klt_pyrdown", k_klt_pyrdown, dim3(gfs::div_up(gfs::div_up(n, 2), 256), B), dim3(256), 0, s, G, l, pyr->img.p);
   }
-  GFS_LAUNCH("k_klt_scharr", k_klt_scharr, dim3((unsigned)((G.off[G.n_levels] + 255) / 256), B), dim3(256), 0, s, G,
+  GFS_LAUNCH("k_klt_scharr", k_klt_scharr, dim3((unsigned)((G.off[G.n_levels] + 1023) / 1024), B), dim3(256), 0, s, G,
              (const uint8_t*)pyr->img.p, pyr->deriv.p);
   pyr->n_frames = B;
   return GFS_OK;
