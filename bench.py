@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-klt", action="store_true", help="skip the optical-flow side measurement")
+    ap.add_argument("--gicp-stream", action="store_true",
+                    help="experiment, not the headline metric: GICP through gfs_gicp_align_next (the previous call's preprocessed "
+                         "source cloud is the target, as in a live stream) instead of preprocessing both clouds per pair")
     ap.add_argument("--serial", action="store_true", help="run ORB+match and GICP back to back on one stream")
     ap.add_argument("--lanes", type=int, default=2, help="independent slices of the batch processed concurrently per GPU")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
@@ -164,6 +167,12 @@ def main():
                                               self.m_inl.data_ptr(), sp)
 
         def gicp(self):
+            if args.gicp_stream and self.gicp_out is not None:
+                self.flip = not getattr(self, "flip", False)
+                c, nn = (self.c0, self.n0) if self.flip else (self.c1, self.n1)
+                self.gicp_out = self.reg.align_next_batch_device(c.data_ptr(), nn.data_ptr(), self.n, SP, None, None,
+                                                                 self.s2.cuda_stream, raw=True)
+                return
             self.gicp_out = self.reg.align_batch_device(self.c0.data_ptr(), self.n0.data_ptr(), self.c1.data_ptr(),
                                                         self.n1.data_ptr(), self.n, SP, None, None, self.s2.cuda_stream, raw=True)
 
@@ -381,6 +390,8 @@ def main():
                        "gicp_converged_frac": round(float(np.mean([r["converged"] for r in g])), 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if args.gicp_stream:
+            out["config"]["workload"] += " [EXPERIMENT --gicp-stream: target preprocessing reused from the previous call]"
         if klt:
             out["optical_flow"] = klt
         if cpu:

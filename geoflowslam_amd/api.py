@@ -184,7 +184,7 @@ ABI_SYMBOLS = [
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
-    "gfs_gicp_fetch_preprocessed",
+    "gfs_gicp_fetch_preprocessed", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device",
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
@@ -236,6 +236,8 @@ def lib():
             L.gfs_gicp_align.argtypes = [vp, vp, i, vp, i, vp, C.POINTER(GicpConfig), C.POINTER(GicpResult)]
             L.gfs_gicp_align_batch_device.argtypes = [vp, vp, vp, vp, vp, i, i, vp, C.POINTER(GicpConfig), vp, vp]
             L.gfs_gicp_fetch_preprocessed.argtypes = [vp, i, i, vp, vp, i, ip]
+            L.gfs_gicp_align_next.argtypes = [vp, vp, i, vp, C.POINTER(GicpConfig), C.POINTER(GicpResult)]
+            L.gfs_gicp_align_next_batch_device.argtypes = [vp, vp, vp, i, i, vp, C.POINTER(GicpConfig), vp, vp]
         if hasattr(L, "gfs_lba_create"):
             L.gfs_lba_create.argtypes = [i, i, i, i, C.POINTER(vp)]
             L.gfs_lba_destroy.argtypes = [vp]
@@ -498,6 +500,28 @@ class RegistrationGICP:
         _check(lib().gfs_gicp_align(self.h, _p(t), len(t), _p(s), len(s), _p(T0c), C.byref(cfg), C.byref(res)),
                "gfs_gicp_align")
         return _result_dict(res)
+
+    def RegisterNext(self, source_points, init_T_target_source=None, cfg=None):
+        """Streaming form: the target is the source cloud of the previous call on this object (kept preprocessed in HBM), as in
+        Tracking::PredictStateICP; bit-identical to RegisterPointClouds(previous source, source_points)."""
+        s = np.ascontiguousarray(source_points, np.float32).reshape(-1, 4)
+        T0 = np.eye(4) if init_T_target_source is None else np.asarray(init_T_target_source, np.float64)
+        T0c = np.ascontiguousarray(T0.T.reshape(-1))
+        cfg = cfg or gicp_default_config()
+        res = GicpResult()
+        _check(lib().gfs_gicp_align_next(self.h, _p(s), len(s), _p(T0c), C.byref(cfg), C.byref(res)), "gfs_gicp_align_next")
+        return _result_dict(res)
+
+    def align_next_batch_device(self, d_source, d_ns, B, stride_pts, init_T=None, cfg=None, stream=None, raw=False):
+        cfg = cfg or gicp_default_config()
+        out = (GicpResult * B)()
+        T0 = None
+        if init_T is not None:
+            T0 = np.ascontiguousarray(np.asarray(init_T, np.float64).transpose(0, 2, 1).reshape(B, 16))
+        _check(lib().gfs_gicp_align_next_batch_device(self.h, C.c_void_p(d_source), C.c_void_p(d_ns), B, stride_pts, _p(T0),
+                                                      C.byref(cfg), out, C.c_void_p(stream) if stream else None),
+               "gfs_gicp_align_next_batch_device")
+        return out if raw else [_result_dict(r) for r in out]
 
     def align_batch_device(self, d_target, d_nt, d_source, d_ns, B, stride_pts, init_T=None, cfg=None, stream=None,
                            raw=False):

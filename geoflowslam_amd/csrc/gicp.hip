@@ -48,6 +48,10 @@ struct GicpParams {
   double inv_leaf, cell, inv_cell, max_dist_sq, rot_eps, trans_eps;
   int max_iterations, k_neighbors;
   int nn_rings;  // ceil(max_corr / cell): rings of cells a 1-NN probe may need to certify "nothing within max_corr"
+  // Cloud slots of pair b are 2b and 2b + 1.  src_slot: which of the two holds the SOURCE cloud (1 in the plain entry points;
+  // the streaming entry alternates so that the previous call's preprocessed source becomes this call's target in place).
+  // only: -1 = preprocess both slots, else only the slot of that parity.
+  int src_slot, only;
 };
 
 __device__ __forceinline__ int fast_floor_d(double v) {  // util/fast_floor.hpp:12-15
@@ -64,8 +68,9 @@ __device__ __forceinline__ u64 pack_key(int cx, int cy, int cz) {
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ tgt, const float4* __restrict__ src,
                                                     const int* __restrict__ nt, const int* __restrict__ ns,
                                                     int stride_pts, int P, double inv_leaf, u64* __restrict__ keys,
-                                                    unsigned* __restrict__ idx, int* __restrict__ counts) {
+                                                    unsigned* __restrict__ idx, int* __restrict__ counts, int only) {
   const int c = blockIdx.y, pair = c >> 1, which = c & 1;
+  if (only >= 0 && which != only) return;
   const int n = min(which ? ns[pair] : nt[pair], P);
   const float4* in = (which ? src : tgt) + (size_t)pair * stride_pts;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ t
 __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u64* __restrict__ keys1,
                                                      unsigned* __restrict__ val0, unsigned* __restrict__ val1,
                                                      const int* __restrict__ counts, int P, int* __restrict__ which,
-                                                     int* __restrict__ kinfo) {
+                                                     int* __restrict__ kinfo, int only) {
   constexpr int kDB = 9, kNB = 1 << kDB;  // digit bits, bins
   constexpr int kEl = 4;                  // elements per thread and tile
   __shared__ unsigned hist[kNB];
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   __shared__ int s_uniform;
   __shared__ int s_mn[3], s_mx[3];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (only >= 0 && (c & 1) != only) return;
   const int n = counts[c];
   u64* ka = keys0 + (size_t)c * P;
   u64* kb = keys1 + (size_t)c * P;
@@ -281,10 +287,11 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
                                                        const unsigned* __restrict__ val1, const int* __restrict__ which,
                                                        const int* __restrict__ counts, int P, double inv_cell,
                                                        double4* __restrict__ tmp_pts, u64* __restrict__ cell_keys,
-                                                       unsigned* __restrict__ cell_idx, int* __restrict__ m_counts) {
+                                                       unsigned* __restrict__ cell_idx, int* __restrict__ m_counts, int only) {
   __shared__ int s_wave[16];
   __shared__ int s_carry;
   const int c = blockIdx.x, pair = c >> 1, tid = threadIdx.x;
+  if (only >= 0 && (c & 1) != only) return;
   const int n = counts[c];
   const u64* keys = (which[c] ? keys1 : keys0) + (size_t)c * P;
   const unsigned* idx = (which[c] ? val1 : val0) + (size_t)c * P;
@@ -336,10 +343,11 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
                                                      const int* __restrict__ m_counts, int P, double4* __restrict__ pts,
                                                      u64* __restrict__ ucell, unsigned* __restrict__ ubegin,
                                                      int* __restrict__ n_ucell, int* __restrict__ bbox,
-                                                     const int* __restrict__ kinfo) {
+                                                     const int* __restrict__ kinfo, int only) {
   __shared__ int s_wave[16];
   __shared__ int s_bb[6];
   const int c = blockIdx.x, tid = threadIdx.x;
+  if (only >= 0 && (c & 1) != only) return;
   if (tid < 3) s_bb[tid] = kCoordMask;
   else if (tid < 6) s_bb[tid] = 0;
   const int m = m_counts[c];
@@ -421,8 +429,9 @@ constexpr int kGridFillParts = 16;  // workgroups per cloud in k_grid_fill
 __global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
                                                     const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
                                                     const int* __restrict__ bbox, int P, unsigned* __restrict__ grid,
-                                                    int* __restrict__ ginfo, int* __restrict__ far2_count) {
+                                                    int* __restrict__ ginfo, int* __restrict__ far2_count, int only) {
   const int c = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (only >= 0 && (c & 1) != only) return;
   const int nu = n_ucell[c], m = m_counts[c];
   const u64* uc = ucell + (size_t)c * (P + 1);
   const unsigned* ub = ubegin + (size_t)c * (P + 1);
@@ -791,6 +800,7 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
                                                  double* __restrict__ cov6) {
   int pair, which, chunk;
   if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
+  if (prm.only >= 0 && which != prm.only) return;
   const int c = 2 * pair + which;
   const int m = m_counts[c];
   const int i = chunk * 128 + threadIdx.x;
@@ -857,6 +867,7 @@ __global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__
   __shared__ int s_query[kQueries];
   int pair, which, chunk;
   if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
+  if (prm.only >= 0 && which != prm.only) return;
   const int c = 2 * pair + which;
   const int m = m_counts[c];
   const unsigned* G = grid + (size_t)c * (kGridCap + 1);
@@ -1038,7 +1049,7 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
   if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
   const PairState S = st[pair];
   if (S.phase != 0) return;
-  const int ct = 2 * pair, cs = 2 * pair + 1;
+  const int cs = 2 * pair + prm.src_slot, ct = 2 * pair + 1 - prm.src_slot;
   const int ms = m_counts[cs];
   if (chunk * kLinBlock >= ms) return;
   const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
@@ -1226,13 +1237,13 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
 __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __restrict__ st, const double4* __restrict__ pts,
                                                            const int* __restrict__ m_counts, int P,
                                                            const int* __restrict__ tgt_index, const double* __restrict__ maha6,
-                                                           double* __restrict__ epartial, int nblk, int nchunks, int npairs) {
+                                                           double* __restrict__ epartial, int nblk, int nchunks, int npairs, int src_slot) {
   __shared__ double s_red[4 * 32];
   int pair, sub, chunk;
   if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
   const PairState& S = st[pair];
   if (S.phase != 1) return;
-  const int ct = 2 * pair, cs = 2 * pair + 1;
+  const int cs = 2 * pair + src_slot, ct = 2 * pair + 1 - src_slot;
   const int ms = m_counts[cs];
   if (chunk * kLinBlock >= ms) return;
   const int i = chunk * kLinBlock + threadIdx.x;
@@ -1392,11 +1403,11 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
 
 // after a linearise pass: fold the per-block partial sums (fixed order), first damped solve
 __global__ __launch_bounds__(256) void k_gicp_solve(PairState* __restrict__ st, const double* __restrict__ partial,
-                                                    const int* __restrict__ m_counts, int nblk_max) {
+                                                    const int* __restrict__ m_counts, int nblk_max, int src_slot) {
   __shared__ double s_part[8 * 32], s_sum[32];
   const int pair = blockIdx.x;
   if (st[pair].phase != 0) return;
-  const int ms = m_counts[2 * pair + 1];
+  const int ms = m_counts[2 * pair + src_slot];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
   fold_partials<kRed>(partial + (size_t)pair * nblk_max * kRed, nblk, kRed, s_part, s_sum);
   if (threadIdx.x == 0) {
@@ -1432,7 +1443,7 @@ __global__ __launch_bounds__(256) void k_gicp_decide(PairState* __restrict__ st,
   __shared__ double s_part[8 * 32], s_sum[32];
   const int pair = blockIdx.x;
   if (st[pair].phase != 1) return;
-  const int ms = m_counts[2 * pair + 1];
+  const int ms = m_counts[2 * pair + prm.src_slot];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
   fold_partials<1>(epartial + (size_t)pair * nblk_max, nblk, 1, s_part, s_sum);
   if (threadIdx.x != 0) return;
@@ -1522,6 +1533,12 @@ struct gfs_gicp {
   hipEvent_t ev_round[2] = {nullptr, nullptr};  // completion of the two LM rounds in flight
   gfs::PinBuf<double> h_initT;
   int last_B = 0;
+  // streaming (gfs_gicp_align_next*): slot parity that holds the preprocessed SOURCE clouds of the last call, and what they
+  // were preprocessed with
+  int last_src_slot = 1, last_stride = 0;
+  double last_leaf = 0, last_cell = 0;
+  int last_k = 0;
+  gfs::DevBuf<int> d_zero;  // [Bmax] zeros: the point counts of the slot that is not re-read in a streaming call
 };
 
 extern "C" {
@@ -1592,7 +1609,9 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   for (int k = 0; k < 2; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_round[k], hipEventDisableTiming));
   A(h->h_m.alloc(C2));
   A(h->h_initT.alloc(B * 16));
+  A(h->d_zero.alloc(B));
 #undef A
+  if (!rc) GFS_HIP(hipMemset(h->d_zero.p, 0, B * sizeof(int)));
   if (rc) return rc;
   *out = h.release();
   return GFS_OK;
@@ -1608,11 +1627,14 @@ void gfs_gicp_destroy(gfs_gicp* h) {
   delete h;
 }
 
-int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void* dev_nt, const void* dev_source,
-                                const void* dev_ns, int B, int stride_pts, const double* init_T,
-                                const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream) {
-  GFS_REQUIRE(h && dev_target && dev_nt && dev_source && dev_ns && B > 0 && stride_pts > 0 && cfg && out,
-              GFS_ERR_INVALID_ARG, "gfs_gicp_align_batch_device: invalid argument");
+// streaming = false: preprocess both clouds of every pair (slots 2b = target, 2b + 1 = source).
+// streaming = true : dev_target / dev_nt are ignored; the slot that holds the previous call's preprocessed source clouds
+//                    becomes the target as it is, the new source clouds go through preprocessing into the other slot.
+static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, const void* dev_source, const void* dev_ns, int B,
+                    int stride_pts, const double* init_T, const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream,
+                    bool streaming) {
+  GFS_REQUIRE(h && (streaming || (dev_target && dev_nt)) && dev_source && dev_ns && B > 0 && stride_pts > 0 && cfg && out,
+              GFS_ERR_INVALID_ARG, "gfs_gicp_align: invalid argument");
   GFS_REQUIRE(B <= h->Bmax, GFS_ERR_CAPACITY, "batch %d exceeds handle max_batch %d", B, h->Bmax);
   GFS_REQUIRE(cfg->downsampling_resolution > 0 && cfg->max_correspondence_distance > 0 && cfg->num_neighbors >= 1 &&
                   cfg->num_neighbors <= 10,
@@ -1636,26 +1658,42 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
   prm.trans_eps = cfg->translation_eps;
   prm.max_iterations = cfg->max_iterations;
   prm.k_neighbors = cfg->num_neighbors;
+  prm.src_slot = 1;
+  prm.only = -1;
+  if (streaming) {
+    GFS_REQUIRE(h->last_B == B && h->last_stride == stride_pts && h->last_leaf == cfg->downsampling_resolution &&
+                    h->last_cell == prm.cell && h->last_k == cfg->num_neighbors,
+                GFS_ERR_INVALID_ARG,
+                "gfs_gicp_align_next: needs a previous call on this handle with the same batch size, stride and preprocessing "
+                "parameters (its source clouds are this call's targets)");
+    prm.src_slot = 1 - h->last_src_slot;
+    prm.only = prm.src_slot;
+  }
+  // k_voxel_keys / k_voxel_reduce read the input of even slots through their `tgt` and of odd slots through their `src` argument
+  const float4* in_even = (const float4*)(streaming ? (prm.src_slot == 0 ? dev_source : nullptr) : dev_target);
+  const float4* in_odd = (const float4*)(streaming ? (prm.src_slot == 1 ? dev_source : nullptr) : dev_source);
+  const int* n_even = (const int*)(streaming ? (prm.src_slot == 0 ? dev_ns : (const void*)h->d_zero.p) : dev_nt);
+  const int* n_odd = (const int*)(streaming ? (prm.src_slot == 1 ? dev_ns : (const void*)h->d_zero.p) : dev_ns);
   for (int b = 0; b < B; b++)
     for (int k = 0; k < 16; k++) h->h_initT.p[16 * b + k] = init_T ? init_T[16 * b + k] : (k % 5 == 0 ? 1.0 : 0.0);
   GFS_HIP(hipMemcpyAsync(h->d_initT.p, h->h_initT.p, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, sizeof(int), s));
   const int npts = std::min(stride_pts, P);
   // ---- preprocess_points x 2B (registration_helper.cpp:22-34)
-  GFS_LAUNCH("k_voxel_keys", k_voxel_keys, dim3(gfs::div_up(npts, 256), C2), dim3(256), 0, s, (const float4*)dev_target,
-             (const float4*)dev_source, (const int*)dev_nt, (const int*)dev_ns, stride_pts, P, prm.inv_leaf, h->d_keys0.p,
-             h->d_val0.p, h->d_counts.p);
+  GFS_LAUNCH("k_voxel_keys", k_voxel_keys, dim3(gfs::div_up(npts, 256), C2), dim3(256), 0, s, in_even, in_odd, n_even, n_odd,
+             stride_pts, P, prm.inv_leaf, h->d_keys0.p, h->d_val0.p, h->d_counts.p, prm.only);
   GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
-             h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p);
-  GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, (const float4*)dev_target,
-             (const float4*)dev_source, stride_pts, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p, h->d_which.p,
-             h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p, h->d_m.p);
+             h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only);
+  GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, in_even, in_odd, stride_pts, h->d_keys0.p, h->d_keys1.p,
+             h->d_val0.p, h->d_val1.p, h->d_which.p, h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p, h->d_m.p,
+             prm.only);
   GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p, h->d_ci1.p,
-             h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p);
+             h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p, prm.only);
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
-             h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p);
+             h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p,
+             prm.only);
   GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(kGridFillParts, C2), dim3(1024), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
-             h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p, h->d_far2.p);
+             h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p, h->d_far2.p, prm.only);
   const int knn_chunks = gfs::div_up(npts, 128);
   GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(xcd_grid(knn_chunks, B, 2)), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
              h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_ginfo.p, h->d_hard.p,
@@ -1677,9 +1715,9 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
     GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
                h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
                nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
-    GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk);
+    GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot);
     GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
-               h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B);
+               h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B, prm.src_slot);
     GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
                h->d_ndone.p);
     // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
@@ -1714,13 +1752,44 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
       }
     for (int k = 0; k < 6; k++) r.b[k] = S.b[k];
     r.error = S.e;
-    r.n_target_downsampled = h->h_m.p[2 * b];
-    r.n_source_downsampled = h->h_m.p[2 * b + 1];
+    r.n_target_downsampled = h->h_m.p[2 * b + 1 - prm.src_slot];
+    r.n_source_downsampled = h->h_m.p[2 * b + prm.src_slot];
     r.n_linearize = S.n_lin;
     r.n_error_evals = S.n_err;
   }
   h->last_B = B;
+  h->last_src_slot = prm.src_slot;
+  h->last_stride = stride_pts;
+  h->last_leaf = cfg->downsampling_resolution;
+  h->last_cell = prm.cell;
+  h->last_k = cfg->num_neighbors;
   return GFS_OK;
+}
+
+int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void* dev_nt, const void* dev_source,
+                                const void* dev_ns, int B, int stride_pts, const double* init_T,
+                                const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream) {
+  return gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, false);
+}
+
+int gfs_gicp_align_next_batch_device(gfs_gicp* h, const void* dev_source, const void* dev_ns, int B, int stride_pts,
+                                     const double* init_T, const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream) {
+  return gicp_run(h, nullptr, nullptr, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, true);
+}
+
+int gfs_gicp_align_next(gfs_gicp* h, const float* source_xyzw, int ns, const double init_T_target_source[16],
+                        const gfs_gicp_config* cfg, gfs_gicp_result* out) {
+  GFS_REQUIRE(h && source_xyzw && ns >= 0 && cfg && out, GFS_ERR_INVALID_ARG, "gfs_gicp_align_next: invalid argument");
+  GFS_REQUIRE(ns <= h->P, GFS_ERR_CAPACITY, "gfs_gicp_align_next: %d points exceed capacity %d", ns, h->P);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    GFS_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (ns) GFS_HIP(hipMemcpyAsync(h->d_in_s.p, source_xyzw, (size_t)ns * 16, hipMemcpyHostToDevice, s));
+    GFS_HIP(hipMemcpyAsync(h->d_ns.p, &ns, sizeof(int), hipMemcpyHostToDevice, s));
+    GFS_HIP(hipStreamSynchronize(s));
+  }
+  return gicp_run(h, nullptr, nullptr, h->d_in_s.p, h->d_ns.p, 1, h->P, init_T_target_source, cfg, out, nullptr, true);
 }
 
 int gfs_gicp_align(gfs_gicp* h, const float* target_xyzw, int nt, const float* source_xyzw, int ns,
@@ -1748,7 +1817,7 @@ int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, doub
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
   GFS_HIP(hipDeviceSynchronize());
-  const int c = 2 * b + which;
+  const int c = 2 * b + (which ? h->last_src_slot : 1 - h->last_src_slot);
   int mm = 0;
   GFS_HIP(hipMemcpy(&mm, h->d_m.p + c, sizeof(int), hipMemcpyDeviceToHost));
   *m = mm;

@@ -121,6 +121,15 @@ class RegistrationGICP {
     check(gfs_gicp_align(h_, target_points, nt, source_points, ns, init_T_target_source, &cfg, &r), "gfs_gicp_align");
     return r;
   }
+  // Streaming form for Tracking::PredictStateICP: the target is the source cloud of the previous call on this object, kept
+  // preprocessed in HBM (bit-identical to RegisterPointClouds(previous source, source_points)).
+  gfs_gicp_result RegisterNext(const float* source_points, int ns, const double init_T_target_source[16]) {
+    gfs_gicp_config cfg;
+    gfs_gicp_default_config(&cfg);
+    gfs_gicp_result r;
+    check(gfs_gicp_align_next(h_, source_points, ns, init_T_target_source, &cfg, &r), "gfs_gicp_align_next");
+    return r;
+  }
 
  private:
   gfs_gicp* h_ = nullptr;

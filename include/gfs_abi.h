@@ -195,6 +195,17 @@ int gfs_gicp_align_batch_device(gfs_gicp* h, const void* dev_target, const void*
                                 const void* dev_ns, int B, int stride_pts, const double* init_T,
                                 const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream);
 
+/* Streaming form (the gfs_gicp_cache of SURVEY.md 8b) for Tracking::PredictStateICP, where the target of every call is the
+ * source of the previous one (src/Tracking.cc:3375-3382: target = mLastFrame.source_points, source = mCurrentFrame's): the
+ * handle keeps the preprocessed clouds (voxel means, covariances, search grid) of its last call's SOURCES in HBM; these
+ * calls register new source clouds against them and preprocess only the new clouds.  The result is bit-identical to
+ * gfs_gicp_align*(previous sources, new sources) — preprocessing is deterministic, so reusing it changes nothing but the time.
+ * GFS_ERR_INVALID_ARG unless the previous call on this handle had the same batch size, stride and preprocessing parameters. */
+int gfs_gicp_align_next(gfs_gicp* h, const float* source_xyzw, int ns, const double init_T_target_source[16],
+                        const gfs_gicp_config* cfg, gfs_gicp_result* out);
+int gfs_gicp_align_next_batch_device(gfs_gicp* h, const void* dev_source, const void* dev_ns, int B, int stride_pts,
+                                     const double* init_T, const gfs_gicp_config* cfg, gfs_gicp_result* out, void* stream);
+
 /* Introspection for parity tests: preprocessing output (voxel means + covariances) of cloud `which`
  * (0 = target, 1 = source) of pair b of the last call. pts: [m][4] f64, covs: [m][9] f64 (3x3 col-major). */
 int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, double* covs, int cap, int* m);

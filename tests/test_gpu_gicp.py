@@ -112,3 +112,87 @@ def test_gicp_pose_equals_the_stable_order_oracle(gpu_api, oracle, seed):
     # 1e-7: an exact distance tie at a 10th neighbour (seed 2 has one) may pick the other point; otherwise ~1e-16
     assert np.linalg.norm(r["T"] - ro["T"]) <= 1e-7 * np.linalg.norm(ro["T"])
     assert abs(r["error"] - ro["error"]) <= 1e-5 * abs(ro["error"])
+
+
+def _same(a, b):
+    return (np.array_equal(a["T"], b["T"]) and a["converged"] == b["converged"] and a["iterations"] == b["iterations"] and
+            a["num_inliers"] == b["num_inliers"] and np.array_equal(a["H"], b["H"]) and np.array_equal(a["b"], b["b"]) and
+            a["error"] == b["error"] and a["n_target_ds"] == b["n_target_ds"] and a["n_source_ds"] == b["n_source_ds"])
+
+
+def test_streaming_form_is_bit_identical(gpu_api):
+    """gfs_gicp_align_next: the previous call's preprocessed source serves as the target (Tracking::PredictStateICP's chain
+    last frame -> current frame) — same bits as preprocessing both clouds again, for a chain of frames of different sizes."""
+    sc = synth.Scene(31)
+    rng = np.random.default_rng(2)
+    clouds = []
+    T = np.eye(4)
+    for k in range(5):
+        T = T @ synth.random_motion(rng)
+        _, d = sc.render(320, 240, T if k else None, k)
+        clouds.append(synth.depth_to_cloud(d, 2 + (k % 2)))      # alternating strides: clouds of different sizes
+    plain = gpu_api.RegistrationGICP(max_points=32768)
+    chain = gpu_api.RegistrationGICP(max_points=32768)
+    r = chain.RegisterPointClouds(clouds[0], clouds[1])
+    assert _same(r, plain.RegisterPointClouds(clouds[0], clouds[1]))
+    for k in range(2, 5):
+        r = chain.RegisterNext(clouds[k])
+        assert _same(r, plain.RegisterPointClouds(clouds[k - 1], clouds[k])), k
+        pts_c, cov_c = chain.preprocessed(0, 0)
+        pts_p, cov_p = plain.preprocessed(0, 0)
+        assert np.array_equal(pts_c, pts_p) and np.array_equal(cov_c, cov_p)
+    # a plain call in between re-bases the chain on its source
+    r = chain.RegisterPointClouds(clouds[1], clouds[0])
+    assert _same(chain.RegisterNext(clouds[3]), plain.RegisterPointClouds(clouds[0], clouds[3]))
+    # with an initial guess and an empty new cloud
+    T0 = np.linalg.inv(synth.random_motion(rng))
+    assert _same(chain.RegisterNext(clouds[4], T0), plain.RegisterPointClouds(clouds[3], clouds[4], T0))
+    e = chain.RegisterNext(clouds[0][:0])
+    assert e["num_inliers"] == 0 and e["n_source_ds"] == 0
+    # a fresh handle has nothing cached; changed preprocessing parameters invalidate the cache
+    with pytest.raises(gpu_api.GfsError):
+        gpu_api.RegistrationGICP(max_points=32768).RegisterNext(clouds[1])
+    cfg = gpu_api.gicp_default_config()
+    cfg.downsampling_resolution = 0.05
+    with pytest.raises(gpu_api.GfsError):
+        chain.RegisterNext(clouds[1], cfg=cfg)
+
+
+def test_streaming_batch_device(gpu_api):
+    from test_gpu_gms import _Hip
+    B, SP = 3, 9216
+    frames = []
+    for b in range(B):
+        sc = synth.Scene(40 + b)
+        rng = np.random.default_rng(b)
+        T = np.eye(4)
+        seq = []
+        for k in range(3):
+            T = T @ synth.random_motion(rng)
+            seq.append(synth.depth_to_cloud(sc.render(320, 240, T if k else None, k)[1], 3))
+        frames.append(seq)
+    hip = _Hip()
+
+    def dev(k):
+        c = np.zeros((B, SP, 4), np.float32)
+        n = np.zeros(B, np.int32)
+        for b in range(B):
+            c[b, :len(frames[b][k])] = frames[b][k]
+            n[b] = len(frames[b][k])
+        return hip.to_device(c), hip.to_device(n)
+
+    d = [dev(k) for k in range(3)]
+    chain = gpu_api.RegistrationGICP(max_points=SP, max_batch=B)
+    plain = gpu_api.RegistrationGICP(max_points=SP, max_batch=B)
+    chain.align_batch_device(d[0][0], d[0][1], d[1][0], d[1][1], B, SP)
+    got = chain.align_next_batch_device(d[2][0], d[2][1], B, SP)
+    want = plain.align_batch_device(d[1][0], d[1][1], d[2][0], d[2][1], B, SP)
+    for b in range(B):
+        assert _same(got[b], want[b]), b
+    got = chain.align_next_batch_device(d[0][0], d[0][1], B, SP)           # third link of the chain: slots swap back
+    want = plain.align_batch_device(d[2][0], d[2][1], d[0][0], d[0][1], B, SP)
+    for b in range(B):
+        assert _same(got[b], want[b]), b
+    with pytest.raises(gpu_api.GfsError):
+        chain.align_next_batch_device(d[0][0], d[0][1], B - 1, SP)           # batch size differs from the cached call
+    hip.free()
