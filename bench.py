@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-klt", action="store_true", help="skip the optical-flow side measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ORB-only and LBA side measurements")
     ap.add_argument("--gicp-stream", action="store_true",
                     help="experiment, not the headline metric: GICP through gfs_gicp_align_next (the previous call's preprocessed "
                          "source cloud is the target, as in a live stream) instead of preprocessing both clouds per pair")
@@ -375,6 +376,44 @@ def main():
             klt["cpu_oracle"] = dict(value=round(4 / (time.perf_counter() - t1), 3), unit="pairs/s", cores=1,
                                      sample="4 VGA pairs, single-threaded oracle (5 pyramids + 4 forward/backward passes)")
 
+    # ---- the other SURVEY.md 8(d) figures, beside the metric (rank 0, N = 1): ORB only (configs[0]) and LBA windows (configs[4])
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        ln0 = lanes[0]
+        for _ in range(2):
+            ln0.ext.extract_batch_device(ln0.g1.data_ptr(), ln0.n, H, W, (0, 0), ln0.s1.cuda_stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ln0.ext.extract_batch_device(ln0.g1.data_ptr(), ln0.n, H, W, (0, 0), ln0.s1.cuda_stream)
+        torch.cuda.synchronize()
+        dto = (time.perf_counter() - t1) / 10
+        extras["orb_only"] = dict(metric="ORB extraction frames/s (640x480, 1000 features, 8 levels; BASELINE.json configs[0] workload)",
+                                  value=round(ln0.n / dto, 1), unit="frames/s", ms_per_batch=round(dto * 1e3, 3), batch_frames=ln0.n)
+        w5 = synth.lba_window(0, n_free=20, n_fixed=5, n_points=3000)
+        opt = api.Optimizer(max_poses=32, max_points=4096, max_edges=65536, device=local_rank)
+        r5 = opt.LocalBundleAdjustment(w5)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            r5 = opt.LocalBundleAdjustment(w5)
+        dtl = (time.perf_counter() - t1) / 5
+        extras["lba"] = dict(metric="LocalBundleAdjustment windows/s (20 free + 5 fixed key-frames x 3000 points; BASELINE.json configs[4])",
+                             value=round(1.0 / dtl, 1), unit="windows/s", ms_per_window=round(dtl * 1e3, 3), edges=int(w5["n_edges"]),
+                             lm_iterations=int(r5["iterations_run"]))
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            orb1 = O.OrbOracle(NF, 1.2, NL, 20, 7)
+            orb1.set_threads(8)
+            t1 = time.perf_counter()
+            for i in range(8):
+                orb1.extract(pairs[i % nd]["gray1"])
+            extras["orb_only"]["cpu_oracle"] = dict(value=round(8 / (time.perf_counter() - t1), 2), unit="frames/s", cores=8,
+                                                    sample="8 VGA frames, OpenMP over the 8 levels as in the reference")
+            t1 = time.perf_counter()
+            O.lba_solve(w5)
+            extras["lba"]["cpu_oracle"] = dict(value=round(1.0 / (time.perf_counter() - t1), 2), unit="windows/s", cores=1,
+                                               sample="the same window once, single-threaded oracle")
+
     if rank == 0:
         g = gicp_results()
         out = {
@@ -394,6 +433,7 @@ def main():
             out["config"]["workload"] += " [EXPERIMENT --gicp-stream: target preprocessing reused from the previous call]"
         if klt:
             out["optical_flow"] = klt
+        out.update(extras)
         if cpu:
             out["gpu_over_cpu"] = round(fps / cpu["value"], 2)
             out["gpu_over_cpu_all_cores"] = round(fps / cpu["all_cores"]["value"], 2)
