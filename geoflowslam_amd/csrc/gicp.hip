@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __
 
 // GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
 // machine is in the "linearise" phase; per-block partial sums of H (upper), b, e and the inlier count.
-__global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* __restrict__ st,
+__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gicp_linearize(const PairState* __restrict__ st,
                                                               const double4* __restrict__ pts,
                                                               const double* __restrict__ cov6, const u64* __restrict__ ucell,
                                                               const unsigned* __restrict__ ubegin,
