@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
     ap.add_argument("--all-ranks-device0", action="store_true", help="dry-run aid: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="frame pairs in the CPU-baseline sample")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 = BASELINE.json configs[1] (640x480, 1000 features, ~19k-pt clouds; the metric's configuration); "
+                         "c3 = configs[2] (1280x720, 2000 features, ~37k-pt clouds; use --batch 32)")
     args = ap.parse_args()
 
     import torch
@@ -96,7 +99,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from geoflowslam_amd import api, synth
-    W, H, STRIDE, NF, NL = 640, 480, 4, 1000, 8
+    W, H, STRIDE, NF, NL = (640, 480, 4, 1000, 8) if args.workload == "c2" else (1280, 720, 5, 2000, 8)
     B = args.batch
     nd = max(1, min(args.distinct, B))
     pairs = gen_pairs(nd, 1000 + 100 * rank, W, H, STRIDE)
@@ -259,11 +262,11 @@ def main():
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_serial.json")))  # newest round last
         pmc_all = json.load(open(pmcs[-1])) if pmcs else {}
-        if pmc_all.get("_batch_pairs") == B:
+        if pmc_all.get("_batch_pairs") == B and args.workload == "c2":
             t = pmc_all.get(name)
             if t:  # HBM-side bytes per STEP measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)
                 traffic = int((t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
-                traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, B=64, 1 lane, serial), KB*1024, "
+                traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, same batch, 1 lane, serial), KB*1024, "
                                 "per step / launches per step; FETCH_SIZE left uncorrected (gather pattern uncalibrated, "
                                 "MI355X_MICROARCH.md §HBM)")
         roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 2) if ach else None, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -421,8 +424,10 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 (ORB, match) + f64 (GICP)", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 640x480 RGBD frame pair, ORB extract (1000 feats, 8 levels) "
-                                   "+ BF Hamming match + GMS filter + GICP on ~19k-pt clouds (stride-4 depth grid)",
+            "config": {"workload": ("BASELINE.json configs[1]: 640x480 RGBD frame pair, ORB extract (1000 feats, 8 levels) "
+                                    "+ BF Hamming match + GMS filter + GICP on ~19k-pt clouds (stride-4 depth grid)") if args.workload == "c2" else
+                                   ("BASELINE.json configs[2] (NOT the metric's configuration): 1280x720 RGBD frame pair, ORB extract (2000 feats, "
+                                    "8 levels) + BF Hamming match + GMS filter + GICP on ~37k-pt clouds (stride-5 depth grid)"),
                        "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
                        "gicp_mean_outer_iterations": round(float(np.mean([r["n_linearize"] for r in g])), 2),
                        "gicp_mean_error_evals": round(float(np.mean([r["n_error_evals"] for r in g])), 2),
