@@ -1186,6 +1186,10 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
     }
     int ti = -1;
     if (bj >= 0 && !(best > prm.max_dist_sq)) {  // DistanceRejector: reject iff sq_dist > max_dist_sq
+      // The factor is ~900 double-precision multiplies and adds per point, and FP64 issues at half rate: fused multiply-adds
+      // halve them.  The bar for GICP is 1e-5 on the pose (the sums are re-associated by the reduction tree anyway); the
+      // search above stays un-contracted so that the correspondences are decided on the same distances as in the oracle.
+#pragma clang fp contract(fast)
       ti = bj;
       const double* Cs = cov6 + ((size_t)cs * P + i) * 6;
       const double* Ct = cov6 + ((size_t)ct * P + bj) * 6;
