@@ -1364,7 +1364,8 @@ int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, v
   GFS_HIP(hipSetDevice(h->device));
   static const bool timing = getenv("GFS_LBA_TIMING") != nullptr;
   const auto T0 = std::chrono::steady_clock::now();
-  HostPrep P;
+  static thread_local HostPrep tl_prep;  // vectors keep their capacity between calls (no allocation on the hot path)
+  HostPrep& P = tl_prep;
   int rc = prepare(h, p, P);
   if (rc) return rc;
   const auto T1 = std::chrono::steady_clock::now();
@@ -1429,7 +1430,8 @@ int gfs_lba_linearize(gfs_lba* h, const gfs_lba_problem* p, double* Hpp, double*
   GFS_REQUIRE(h && p, GFS_ERR_INVALID_ARG, "gfs_lba_linearize: NULL argument");
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
-  HostPrep P;
+  static thread_local HostPrep tl_prep;  // vectors keep their capacity between calls (no allocation on the hot path)
+  HostPrep& P = tl_prep;
   int rc = prepare(h, p, P);
   if (rc) return rc;
   rc = run(h, p, P, 1, nullptr);
