@@ -194,6 +194,7 @@ ABI_SYMBOLS = [
     "gfs_klt_create", "gfs_klt_destroy", "gfs_klt_layout", "gfs_klt_pyramid_create", "gfs_klt_pyramid_destroy",
     "gfs_klt_build_pyramid", "gfs_klt_build_pyramid_device", "gfs_klt_pyramid_download", "gfs_klt_track", "gfs_klt_fb_track",
     "gfs_klt_fb_track_device",
+    "gfs_fmat_create", "gfs_fmat_destroy", "gfs_find_fundamental_ransac",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
 ]
@@ -264,6 +265,10 @@ def lib():
             L.gfs_klt_track.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, i, d, i, d]
             L.gfs_klt_fb_track.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, f]
             L.gfs_klt_fb_track_device.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, vp, i, f, f, vp]
+        if hasattr(L, "gfs_fmat_create"):
+            L.gfs_fmat_create.argtypes = [i, i, i, C.POINTER(vp)]
+            L.gfs_fmat_destroy.argtypes = [vp]
+            L.gfs_find_fundamental_ransac.argtypes = [vp, i, vp, vp, vp, C.c_double, C.c_double, i, vp, vp, vp]
         L.gfs_timer_create.argtypes = [i, C.POINTER(vp)]
         L.gfs_timer_destroy.argtypes = [vp]
         L.gfs_timer_start.argtypes = [vp, vp]
@@ -795,6 +800,38 @@ class KltTracker:
         _check(lib().gfs_klt_fb_track_device(self.h, prev.h, cur.h, B, pt_stride, C.c_void_p(d_n), C.c_void_p(d_kps),
                                              C.c_void_p(d_priors), C.c_void_p(d_kpstatus), C.c_void_p(d_n_good), nbpyrlvl, ferr,
                                              fmax_fbklt_dist, C.c_void_p(stream) if stream else None), "gfs_klt_fb_track_device")
+
+
+class FundamentalMatcher:
+    """cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) for n >= 15 points (reference call sites
+    src/ORBmatcher.cc:236, 2399, 2463; src/Tracking.cc:1974)."""
+
+    def __init__(self, max_points=4096, max_batch=1, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_fmat_create(device, max_points, max_batch, C.byref(self.h)), "gfs_fmat_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_fmat_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def findFundamentalMat(self, pts1, pts2, threshold=3.0, confidence=0.99, max_iters=1000):
+        """pts1 / pts2: [n, 2] arrays or lists of them -> (mask bool [n], F [3, 3] or None, n_inliers) per problem."""
+        single = isinstance(pts1, np.ndarray)
+        P1 = [np.ascontiguousarray(p, np.float32).reshape(-1, 2) for p in ([pts1] if single else pts1)]
+        P2 = [np.ascontiguousarray(p, np.float32).reshape(-1, 2) for p in ([pts2] if single else pts2)]
+        B = len(P1)
+        n = np.array([len(p) for p in P1], np.int32)
+        M = [np.zeros(max(len(p), 1), np.uint8) for p in P1]
+        F = np.zeros((B, 9))
+        cnt = np.zeros(B, np.int32)
+        arr = lambda L: (C.c_void_p * B)(*[a.ctypes.data for a in L])
+        _check(lib().gfs_find_fundamental_ransac(self.h, B, _p(n), arr(P1), arr(P2), float(threshold), float(confidence), max_iters,
+                                                 arr(M), _p(F), _p(cnt)), "gfs_find_fundamental_ransac")
+        out = [(M[b][:n[b]].astype(bool), F[b].reshape(3, 3).copy() if cnt[b] > 0 else None, int(cnt[b])) for b in range(B)]
+        return out[0] if single else out
 
 
 class ProjectionMatcher:

@@ -1,0 +1,507 @@
+// cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, threshold, confidence, mask) on MI355X, as the reference calls it in the
+// optical-flow matcher (src/ORBmatcher.cc:2399-2405, 2463-2469, also :236) and Tracking::EstimatePoseByOF (src/Tracking.cc:1973-1974):
+// the 7-point RANSAC of OpenCV's RANSACPointSetRegistrator (calib3d/src/ptsetreg.cpp, fundam.cpp; restated in
+// oracle/fmat_oracle.cpp, which also lists the two deliberate differences: null space by Gauss-Jordan elimination and cubic roots by
+// bisection, so that every step is +, -, *, /, sqrt and the device reproduces the oracle's bits).
+//
+// RANSAC looks sequential (the iteration budget shrinks whenever a better model is found) but the random subsets do not depend
+// on the models: the cv::RNG stream is consumed the same way whatever is accepted.  So a launch evaluates a CHUNK of 64
+// iterations of every problem at once — one lane draws the 64 subsets (the only sequential part), 64 lanes solve the 7-point
+// problems, the four waves of the workgroup count the inliers of the up to 192 models over all points — and the host replays
+// the accept / update-budget logic over the 64 results in order (its libm evaluates RANSACUpdateNumIters exactly like the
+// oracle).  With a third or fewer outliers one chunk is all it takes; harder problems continue chunk by chunk from the saved
+// generator state.  One workgroup per problem, problems of a batch in parallel.
+#include <cmath>
+#include <memory>
+#include <mutex>
+
+#include "gfs_common.hpp"
+
+namespace {
+
+using gfs::DevBuf;
+using gfs::PinBuf;
+
+constexpr int kFmChunk = 64;      // RANSAC iterations evaluated per launch
+constexpr int kFmThreads = 256;
+constexpr double kFltEps = 1.1920928955078125e-07, kDblEps = 2.220446049250313e-16;
+
+struct FmProblem {
+  int n;                         // points
+  int active;                    // this problem still needs the current chunk
+  unsigned long long rng;        // cv::RNG state before the chunk / after it
+  float t2;                      // (float)(threshold^2)
+};
+
+__device__ __forceinline__ unsigned rng_next(unsigned long long& s) {  // cv::RNG::next
+  s = (unsigned long long)(unsigned)s * 4164903690u + (unsigned)(s >> 32);
+  return (unsigned)s;
+}
+
+__device__ bool have_collinear_points(const float2* m, const int* idx) {  // the last of 7 points against every earlier pair
+  const int i = 6;
+  for (int j = 0; j < i; j++) {
+    const double dx1 = (double)(m[idx[j]].x - m[idx[i]].x), dy1 = (double)(m[idx[j]].y - m[idx[i]].y);
+    for (int k = 0; k < j; k++) {
+      const double dx2 = (double)(m[idx[k]].x - m[idx[i]].x), dy2 = (double)(m[idx[k]].y - m[idx[i]].y);
+      if (fabs(dx2 * dy1 - dy2 * dx1) <= kFltEps * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+    }
+  }
+  return false;
+}
+
+__device__ bool get_subset(unsigned long long& rng, const float2* m1, const float2* m2, int count, int* idx) {
+  for (int iters = 0; iters < 10000; ++iters) {
+    for (int i = 0; i < 7; ++i) {
+      int v;
+      for (;;) {
+        v = (int)(rng_next(rng) % (unsigned)count);
+        bool dup = false;
+        for (int j = 0; j < i; j++) dup |= idx[j] == v;
+        if (!dup) break;
+      }
+      idx[i] = v;
+    }
+    if (!have_collinear_points(m1, idx) && !have_collinear_points(m2, idx)) return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ double cubic_eval(double B, double C, double D, double x) { return ((x + B) * x + C) * x + D; }
+__device__ double cubic_bisect(double B, double C, double D, double lo, double hi) {
+  const bool neg_lo = cubic_eval(B, C, D, lo) < 0;
+  for (;;) {
+    const double mid = 0.5 * (lo + hi);
+    if (mid == lo || mid == hi) break;
+    if ((cubic_eval(B, C, D, mid) < 0) == neg_lo)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return hi;
+}
+__device__ int cubic_real_roots(const double* c, double* r) {
+  if (c[0] == 0) {
+    if (c[1] == 0) {
+      if (c[2] == 0) return 0;
+      r[0] = -c[3] / c[2];
+      return 1;
+    }
+    const double d = c[2] * c[2] - 4 * c[1] * c[3];
+    if (d < 0) return 0;
+    const double sq = __dsqrt_rn(d);
+    const double x0 = (-c[2] - sq) / (2 * c[1]), x1 = (-c[2] + sq) / (2 * c[1]);
+    r[0] = x0 < x1 ? x0 : x1;
+    r[1] = x0 < x1 ? x1 : x0;
+    return d > 0 ? 2 : 1;
+  }
+  const double inv = 1. / c[0];
+  const double B = c[1] * inv, C = c[2] * inv, D = c[3] * inv;
+  double bound = fabs(B);
+  if (fabs(C) > bound) bound = fabs(C);
+  if (fabs(D) > bound) bound = fabs(D);
+  bound += 1.0;
+  double knots[4];
+  int nk = 0;
+  knots[nk++] = -bound;  // Cauchy: every root lies in (-bound, bound)
+  const double disc = B * B - 3 * C;
+  if (disc > 0) {
+    const double sq = __dsqrt_rn(disc);
+    knots[nk++] = (-B - sq) / 3;
+    knots[nk++] = (-B + sq) / 3;
+  }
+  knots[nk++] = bound;
+  int n = 0;
+  for (int k = 0; k + 1 < nk; k++) {
+    const double lo = knots[k], hi = knots[k + 1];
+    if (!(lo < hi)) continue;
+    if ((cubic_eval(B, C, D, lo) < 0) != (cubic_eval(B, C, D, hi) < 0)) r[n++] = cubic_bisect(B, C, D, lo, hi);
+  }
+  return n;
+}
+
+// FMEstimatorCallback::runKernel for 7 points: up to three 3x3 matrices (row-major) in Fm
+__device__ int seven_point(const float2* m1, const float2* m2, const int* idx, double* Fm) {
+  double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+  for (int i = 0; i < 7; i++) {
+    c1x += (double)m1[idx[i]].x;
+    c1y += (double)m1[idx[i]].y;
+    c2x += (double)m2[idx[i]].x;
+    c2y += (double)m2[idx[i]].y;
+  }
+  const double t = 1. / 7;
+  c1x *= t;
+  c1y *= t;
+  c2x *= t;
+  c2y *= t;
+  double s1 = 0, s2 = 0;
+  for (int i = 0; i < 7; i++) {
+    const double ax = (double)m1[idx[i]].x - c1x, ay = (double)m1[idx[i]].y - c1y, bx = (double)m2[idx[i]].x - c2x,
+                 by = (double)m2[idx[i]].y - c2y;
+    s1 += __dsqrt_rn(ax * ax + ay * ay);
+    s2 += __dsqrt_rn(bx * bx + by * by);
+  }
+  s1 *= t;
+  s2 *= t;
+  if (s1 < kFltEps || s2 < kFltEps) return 0;
+  s1 = __dsqrt_rn(2.) / s1;
+  s2 = __dsqrt_rn(2.) / s2;
+  double a[7][9];
+  for (int i = 0; i < 7; i++) {
+    const double x0 = ((double)m1[idx[i]].x - c1x) * s1, y0 = ((double)m1[idx[i]].y - c1y) * s1;
+    const double x1 = ((double)m2[idx[i]].x - c2x) * s2, y1 = ((double)m2[idx[i]].y - c2y) * s2;
+    a[i][0] = x1 * x0;
+    a[i][1] = x1 * y0;
+    a[i][2] = x1;
+    a[i][3] = y1 * x0;
+    a[i][4] = y1 * y0;
+    a[i][5] = y1;
+    a[i][6] = x0;
+    a[i][7] = y0;
+    a[i][8] = 1;
+  }
+  int perm[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+  for (int r = 0; r < 7; r++) {  // Gauss-Jordan with full pivoting
+    int pi = r, pj = r;
+    double pv = -1;
+    for (int i = r; i < 7; i++)
+      for (int j = r; j < 9; j++)
+        if (fabs(a[i][j]) > pv) {
+          pv = fabs(a[i][j]);
+          pi = i;
+          pj = j;
+        }
+    if (!(pv > 0)) return 0;
+    for (int j = 0; j < 9; j++) {
+      const double tmp = a[r][j];
+      a[r][j] = a[pi][j];
+      a[pi][j] = tmp;
+    }
+    for (int i = 0; i < 7; i++) {
+      const double tmp = a[i][r];
+      a[i][r] = a[i][pj];
+      a[i][pj] = tmp;
+    }
+    {
+      const int tmp = perm[r];
+      perm[r] = perm[pj];
+      perm[pj] = tmp;
+    }
+    const double ip = 1. / a[r][r];
+    for (int j = 0; j < 9; j++) a[r][j] *= ip;
+    for (int i = 0; i < 7; i++) {
+      if (i == r) continue;
+      const double f = a[i][r];
+      for (int j = 0; j < 9; j++) a[i][j] -= f * a[r][j];
+    }
+  }
+  double f1[9], f2[9];
+  for (int j = 0; j < 9; j++) f1[j] = f2[j] = 0;
+  for (int r = 0; r < 7; r++) {
+    f1[perm[r]] = -a[r][7];
+    f2[perm[r]] = -a[r][8];
+  }
+  f1[perm[7]] = 1;
+  f2[perm[8]] = 1;
+  for (int i = 0; i < 9; i++) f1[i] -= f2[i];
+  double c[4];
+  double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
+  c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+  c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) + f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) -
+         f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) + f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+         f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+  t0 = f1[4] * f1[8] - f1[5] * f1[7];
+  t1 = f1[3] * f1[8] - f1[5] * f1[6];
+  t2 = f1[3] * f1[7] - f1[4] * f1[6];
+  c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) + f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) -
+         f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) + f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+         f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+  c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+  double roots[3];
+  const int n = cubic_real_roots(c, roots);
+  for (int k = 0; k < n; k++) {
+    double* F = Fm + 9 * k;
+    double lambda = roots[k], mu = 1.;
+    const double s = f1[8] * roots[k] + f2[8];
+    if (fabs(s) > kDblEps) {
+      mu = 1. / s;
+      lambda *= mu;
+      F[8] = 1.;
+    } else {
+      F[8] = 0.;
+    }
+    for (int i = 0; i < 8; i++) F[i] = f1[i] * lambda + f2[i] * mu;
+    double G[9];
+    for (int rr = 0; rr < 3; rr++) {
+      G[3 * rr] = F[3 * rr] * s1;
+      G[3 * rr + 1] = F[3 * rr + 1] * s1;
+      G[3 * rr + 2] = F[3 * rr] * (-s1 * c1x) + F[3 * rr + 1] * (-s1 * c1y) + F[3 * rr + 2];
+    }
+    for (int cc = 0; cc < 3; cc++) {
+      F[cc] = s2 * G[cc];
+      F[3 + cc] = s2 * G[3 + cc];
+      F[6 + cc] = (-s2 * c2x) * G[cc] + (-s2 * c2y) * G[3 + cc] + G[6 + cc];
+    }
+    if (fabs(F[8]) > kFltEps) {
+      const double sc = 1. / F[8];
+      for (int i = 0; i < 9; i++) F[i] *= sc;
+    }
+  }
+  return n;
+}
+
+__device__ __forceinline__ float epipolar_error(const double* F, float2 p1, float2 p2) {  // FMEstimatorCallback::computeError
+  const double x1 = (double)p1.x, y1 = (double)p1.y, x2 = (double)p2.x, y2 = (double)p2.y;
+  double a = F[0] * x1 + F[1] * y1 + F[2];
+  double b = F[3] * x1 + F[4] * y1 + F[5];
+  double c = F[6] * x1 + F[7] * y1 + F[8];
+  const double s2 = 1. / (a * a + b * b);
+  const double d2 = x2 * a + y2 * b + c;
+  a = F[0] * x2 + F[3] * y2 + F[6];
+  b = F[1] * x2 + F[4] * y2 + F[7];
+  c = F[2] * x2 + F[5] * y2 + F[8];
+  const double s1 = 1. / (a * a + b * b);
+  const double d1 = x1 * a + y1 * b + c;
+  const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+  return (float)(e1 > e2 ? e1 : e2);
+}
+
+// One chunk of kFmChunk RANSAC iterations of every active problem.  pts1 / pts2: [B][stride] float2.
+// models [B][kFmChunk][27], nmodels [B][kFmChunk] (-1 = getSubset failed), good [B][kFmChunk][3].
+__global__ void __launch_bounds__(kFmThreads) k_fmat_chunk(FmProblem* __restrict__ prob, const float2* __restrict__ pts1,
+                                                          const float2* __restrict__ pts2, int stride, double* __restrict__ models,
+                                                          int* __restrict__ nmodels, int* __restrict__ good) {
+  __shared__ int s_idx[kFmChunk][7];
+  __shared__ int s_nm[kFmChunk];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  FmProblem P = prob[b];
+  if (!P.active) return;
+  const float2* m1 = pts1 + (size_t)b * stride;
+  const float2* m2 = pts2 + (size_t)b * stride;
+  double* Fm = models + (size_t)b * kFmChunk * 27;
+  if (tid == 0) {  // the generator is sequential; its consumption does not depend on what the models turn out to be
+    unsigned long long rng = P.rng;
+    bool ok = true;
+    for (int k = 0; k < kFmChunk; k++) {
+      int idx[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (ok) ok = get_subset(rng, m1, m2, P.n, idx);
+      for (int i = 0; i < 7; i++) s_idx[k][i] = idx[i];
+      s_nm[k] = ok ? 0 : -1;
+    }
+    prob[b].rng = rng;
+  }
+  __syncthreads();
+  if (tid < kFmChunk) {
+    int nm = s_nm[tid];
+    if (nm == 0) {
+      int idx[7];
+      for (int i = 0; i < 7; i++) idx[i] = s_idx[tid][i];
+      double F[27];
+      nm = seven_point(m1, m2, idx, F);
+      for (int i = 0; i < 9 * nm; i++) Fm[(size_t)tid * 27 + i] = F[i];
+      s_nm[tid] = nm;
+    }
+    nmodels[(size_t)b * kFmChunk + tid] = nm;
+  }
+  __syncthreads();
+  // inlier counts: wave w takes the (iteration, model) pairs w, w + 4, ...; lanes over the points
+  for (int q = wave; q < kFmChunk * 3; q += kFmThreads / 64) {
+    const int k = q / 3, m = q - 3 * k;
+    if (m >= s_nm[k]) continue;  // wave-uniform
+    double F[9];
+    for (int i = 0; i < 9; i++) F[i] = Fm[(size_t)k * 27 + 9 * m + i];
+    int cnt = 0;
+    for (int i = lane; i < P.n; i += 64) cnt += epipolar_error(F, m1[i], m2[i]) <= P.t2 ? 1 : 0;
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+    if (lane == 0) good[((size_t)b * kFmChunk + k) * 3 + m] = cnt;
+  }
+}
+
+// mask[i] = inlier of the chosen model; sel [B] = iteration * 3 + model inside the last chunk of that problem, or -1 (no model)
+__global__ void __launch_bounds__(kFmThreads) k_fmat_mask(const FmProblem* __restrict__ prob, const int* __restrict__ sel,
+                                                         const double* __restrict__ best, const float2* __restrict__ pts1,
+                                                         const float2* __restrict__ pts2, int stride, uint8_t* __restrict__ mask) {
+  const int b = blockIdx.y, i = blockIdx.x * kFmThreads + threadIdx.x;
+  const FmProblem P = prob[b];
+  if (i >= P.n) return;
+  uint8_t v = 0;
+  if (sel[b] >= 0) {
+    double F[9];
+    for (int k = 0; k < 9; k++) F[k] = best[(size_t)b * 9 + k];
+    v = epipolar_error(F, pts1[(size_t)b * stride + i], pts2[(size_t)b * stride + i]) <= P.t2 ? 1 : 0;
+  }
+  mask[(size_t)b * stride + i] = v;
+}
+
+int update_num_iters(double p, double ep, int max_iters) {  // RANSACUpdateNumIters(p, ep, 7, maxIters), host libm like the oracle
+  p = p < 0 ? 0 : (p > 1 ? 1 : p);
+  ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
+  double num = 1 - p > 2.2250738585072014e-308 ? 1 - p : 2.2250738585072014e-308;
+  double denom = 1 - std::pow(1 - ep, 7);
+  if (denom < 2.2250738585072014e-308) return 0;
+  num = std::log(num);
+  denom = std::log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+
+}  // namespace
+
+struct gfs_fmat {
+  int device = 0, max_points = 0, max_batch = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  DevBuf<FmProblem> d_prob;
+  DevBuf<float2> d_p1, d_p2;
+  DevBuf<double> d_models, d_best;
+  DevBuf<int> d_nm, d_good, d_sel;
+  DevBuf<uint8_t> d_mask;
+  PinBuf<FmProblem> h_prob;
+  PinBuf<float2> h_p1, h_p2;
+  PinBuf<double> h_models, h_best;
+  PinBuf<int> h_nm, h_good, h_sel;
+  PinBuf<uint8_t> h_mask;
+};
+
+extern "C" {
+
+int gfs_fmat_create(int device, int max_points, int max_batch, gfs_fmat** out) {
+  GFS_REQUIRE(out && max_points >= 15 && max_batch > 0, GFS_ERR_INVALID_ARG, "gfs_fmat_create: invalid argument");
+  *out = nullptr;
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  auto h = std::make_unique<gfs_fmat>();
+  h->device = device;
+  h->max_points = max_points;
+  h->max_batch = max_batch;
+  GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t B = max_batch, NP = B * max_points;
+  int rc = 0;
+#define A(x) if (!rc) rc = (x)
+  A(h->d_prob.alloc(B));
+  A(h->d_p1.alloc(NP));
+  A(h->d_p2.alloc(NP));
+  A(h->d_models.alloc(B * kFmChunk * 27));
+  A(h->d_best.alloc(B * 9));
+  A(h->d_nm.alloc(B * kFmChunk));
+  A(h->d_good.alloc(B * kFmChunk * 3));
+  A(h->d_sel.alloc(B));
+  A(h->d_mask.alloc(NP));
+  A(h->h_prob.alloc(B));
+  A(h->h_p1.alloc(NP));
+  A(h->h_p2.alloc(NP));
+  A(h->h_models.alloc(B * kFmChunk * 27));
+  A(h->h_best.alloc(B * 9));
+  A(h->h_nm.alloc(B * kFmChunk));
+  A(h->h_good.alloc(B * kFmChunk * 3));
+  A(h->h_sel.alloc(B));
+  A(h->h_mask.alloc(NP));
+#undef A
+  if (rc) {
+    (void)hipStreamDestroy(h->stream);
+    return rc;
+  }
+  *out = h.release();
+  return GFS_OK;
+}
+
+void gfs_fmat_destroy(gfs_fmat* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, const float* const* pts1, const float* const* pts2,
+                                double threshold, double confidence, int max_iters, uint8_t* const* mask, double* F,
+                                int32_t* n_inliers) {
+  GFS_REQUIRE(h && n_points && pts1 && pts2 && mask && n_inliers && B > 0, GFS_ERR_INVALID_ARG,
+              "gfs_find_fundamental_ransac: invalid argument");
+  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac: batch %d exceeds capacity %d", B, h->max_batch);
+  if (threshold <= 0) threshold = 3;
+  if (confidence < kDblEps || confidence > 1 - kDblEps) confidence = 0.99;
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  const int S = h->max_points;
+  int nmax = 0;
+  for (int b = 0; b < B; b++) {
+    const int n = n_points[b];
+    GFS_REQUIRE(n <= S, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac: problem %d has %d points, capacity %d", b, n, S);
+    GFS_REQUIRE(n >= 15, GFS_ERR_UNSUPPORTED,
+                "gfs_find_fundamental_ransac: problem %d has %d points; below 15 OpenCV switches FM_RANSAC to LMedS, which is not "
+                "implemented", b, n);
+    GFS_REQUIRE(pts1[b] && pts2[b] && mask[b], GFS_ERR_INVALID_ARG, "gfs_find_fundamental_ransac: problem %d has NULL arrays", b);
+    memcpy(h->h_p1.p + (size_t)b * S, pts1[b], (size_t)n * sizeof(float2));
+    memcpy(h->h_p2.p + (size_t)b * S, pts2[b], (size_t)n * sizeof(float2));
+    h->h_prob.p[b] = FmProblem{n, 1, 0xffffffffffffffffull, (float)(threshold * threshold)};
+    nmax = n > nmax ? n : nmax;
+  }
+  hipStream_t s = h->stream;
+  const size_t NP = (size_t)B * S;
+  GFS_HIP(hipMemcpyAsync(h->d_p1.p, h->h_p1.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_p2.p, h->h_p2.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  // host replay state of RANSACPointSetRegistrator::run per problem
+  std::vector<int> niters(B, max_iters > 1 ? max_iters : 1), max_good(B, 0), iter(B, 0), done(B, 0);
+  for (int b = 0; b < B; b++) h->h_sel.p[b] = -1;
+  int remaining = B;
+  while (remaining > 0) {
+    GFS_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, B * sizeof(FmProblem), hipMemcpyHostToDevice, s));
+    GFS_LAUNCH("k_fmat_chunk", k_fmat_chunk, dim3(B), dim3(kFmThreads), 0, s, h->d_prob.p, (const float2*)h->d_p1.p,
+               (const float2*)h->d_p2.p, S, h->d_models.p, h->d_nm.p, h->d_good.p);
+    GFS_HIP(hipMemcpyAsync(h->h_prob.p, h->d_prob.p, B * sizeof(FmProblem), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(h->h_nm.p, h->d_nm.p, (size_t)B * kFmChunk * sizeof(int), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(h->h_good.p, h->d_good.p, (size_t)B * kFmChunk * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(h->h_models.p, h->d_models.p, (size_t)B * kFmChunk * 27 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipStreamSynchronize(s));
+    for (int b = 0; b < B; b++) {
+      if (done[b]) continue;
+      const int n = n_points[b];
+      for (int k = 0; k < kFmChunk && !done[b]; k++) {
+        if (iter[b] >= niters[b]) {
+          done[b] = 1;
+          break;
+        }
+        const int nm = h->h_nm.p[(size_t)b * kFmChunk + k];
+        if (nm < 0) {  // getSubset failed: the loop ends (with no model at all if it was the first iteration)
+          done[b] = 1;
+          break;
+        }
+        for (int m = 0; m < nm; m++) {
+          const int g = h->h_good.p[((size_t)b * kFmChunk + k) * 3 + m];
+          if (g > (max_good[b] > 6 ? max_good[b] : 6)) {
+            max_good[b] = g;
+            h->h_sel.p[b] = 1;
+            memcpy(h->h_best.p + (size_t)b * 9, h->h_models.p + ((size_t)b * kFmChunk + k) * 27 + 9 * m, 9 * sizeof(double));
+            niters[b] = update_num_iters(confidence, (double)(n - g) / n, niters[b]);
+          }
+        }
+        iter[b]++;
+      }
+      if (!done[b] && iter[b] >= niters[b]) done[b] = 1;
+      if (done[b]) {
+        h->h_prob.p[b].active = 0;
+        remaining--;
+      }
+    }
+  }
+  GFS_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, B * sizeof(FmProblem), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_sel.p, h->h_sel.p, B * sizeof(int), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_best.p, h->h_best.p, (size_t)B * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+  GFS_LAUNCH("k_fmat_mask", k_fmat_mask, dim3(gfs::div_up(nmax, kFmThreads), B), dim3(kFmThreads), 0, s, (const FmProblem*)h->d_prob.p,
+             (const int*)h->d_sel.p, (const double*)h->d_best.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, h->d_mask.p);
+  GFS_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, NP, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int b = 0; b < B; b++) {
+    memcpy(mask[b], h->h_mask.p + (size_t)b * S, (size_t)n_points[b]);
+    n_inliers[b] = max_good[b];
+    if (F) {
+      if (max_good[b] > 0)
+        memcpy(F + 9 * (size_t)b, h->h_best.p + (size_t)b * 9, 9 * sizeof(double));
+      else
+        memset(F + 9 * (size_t)b, 0, 9 * sizeof(double));
+    }
+  }
+  return GFS_OK;
+}
+
+}  // extern "C"

@@ -225,6 +225,30 @@ class KltTracker {
   gfs_klt* h_ = nullptr;
 };
 
+// cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, threshold, confidence, status) for 15 or more points (reference call
+// sites src/ORBmatcher.cc:236, 2399, 2463; src/Tracking.cc:1974)
+class FundamentalMatcher {
+ public:
+  explicit FundamentalMatcher(int max_points = 8192, int device = 0) { check(gfs_fmat_create(device, max_points, 1, &h_), "gfs_fmat_create"); }
+  ~FundamentalMatcher() { gfs_fmat_destroy(h_); }
+  // points: (x, y) float pairs as cv::Point2f; returns the consensus size, status[i] = 0 / 1, F = row-major 3x3 (zeros: no model)
+  int findFundamentalMat(const std::vector<float>& points1, const std::vector<float>& points2, double threshold, double confidence,
+                         std::vector<uint8_t>& status, double F[9] = nullptr) {
+    const int32_t n = (int32_t)(points1.size() / 2);
+    status.assign((size_t)std::max(n, 1), 0);
+    const float* a = points1.data();
+    const float* b = points2.data();
+    uint8_t* st = status.data();
+    int32_t n_in = 0;
+    check(gfs_find_fundamental_ransac(h_, 1, &n, &a, &b, threshold, confidence, 1000, &st, F, &n_in), "gfs_find_fundamental_ransac");
+    status.resize((size_t)n);
+    return n_in;
+  }
+
+ private:
+  gfs_fmat* h_ = nullptr;
+};
+
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on flattened frames (reference src/ORBmatcher.cc:1853-2063;
 // see INTEGRATION.md §6 for the flattening of Frame / MapPoint)
 class ProjectionMatcher {

@@ -416,3 +416,25 @@ def klt_texture_pair(seed, width=640, height=480, shift=(3.3, -2.1), rot_deg=0.0
 
     to_u8 = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
     return to_u8(img0), to_u8(img1), flow
+
+
+def two_view_points(seed, n=400, outlier_frac=0.25, noise=0.3, width=640, height=480, trans=0.15, rot_deg=3.0):
+    """Image points of n random 3-D points in two views related by a general motion (so that a fundamental matrix exists), pixel
+    noise `noise`, a fraction replaced by gross mismatches.  -> (pts1 f32 [n, 2], pts2 f32 [n, 2], inlier bool [n], F_true [3, 3])."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = intrinsics(width, height)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    X = np.c_[rng.uniform(-2.5, 2.5, n), rng.uniform(-1.8, 1.8, n), rng.uniform(2.0, 7.0, n)]
+    R = _rot(*np.deg2rad(rng.uniform(-rot_deg, rot_deg, 3)))
+    t = rng.uniform(-trans, trans, 3)
+    t[0] += trans  # never a pure rotation
+    x1 = (K @ X.T).T
+    x2 = (K @ (R @ X.T + t[:, None])).T
+    p1 = x1[:, :2] / x1[:, 2:3] + rng.normal(0, noise, (n, 2))
+    p2 = x2[:, :2] / x2[:, 2:3] + rng.normal(0, noise, (n, 2))
+    out = rng.random(n) < outlier_frac
+    p2[out] = np.c_[rng.uniform(0, width, out.sum()), rng.uniform(0, height, out.sum())]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(K)
+    F = Ki.T @ tx @ R @ Ki
+    return p1.astype(np.float32), p2.astype(np.float32), ~out, F / F[2, 2]

@@ -1,7 +1,7 @@
 /* gfs_abi.h — C ABI of the MI355X-native GeoFlow-SLAM front-end hot path (libgfs_hip.so).
  *
  * This is the drop-in boundary.  The reference has no FFI layer: the seams are four
- * ordinary C++ methods (sections 1-4), followed by the neighbouring rows of SURVEY.md §8(f) (sections 5-9).  Each entry point below names the reference interface it replaces
+ * ordinary C++ methods (sections 1-4), followed by the neighbouring rows of SURVEY.md §8(f) (sections 5-10).  Each entry point below names the reference interface it replaces
  * (file:line in HorizonRobotics/GeoFlowSlam).  Signatures are plain C: pointers, sizes, POD structs.
  * No torch / OpenCV / Eigen types cross this boundary.  INTEGRATION.md shows the reference-side
  * adaptor (what a maintainer adds to src/ORBextractor.cc etc. to call these).
@@ -459,6 +459,25 @@ int gfs_klt_fb_track(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyra
 int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_klt_pyramid* cur, int B, int pt_stride,
                             const void* dev_n, const void* dev_kps, void* dev_priors, void* dev_kpstatus, void* dev_n_good,
                             int nbpyrlvl, float ferr, float fmax_fbklt_dist, void* stream);
+
+/* ============================================================================================
+ * 10. cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, threshold, confidence, mask) — the F check of the optical-flow
+ *     matcher (src/ORBmatcher.cc:236, 2399-2405, 2463-2469) and of Tracking::EstimatePoseByOF (src/Tracking.cc:1973-1974):
+ *     OpenCV's 7-point RANSAC (cv::RNG((uint64)-1), getSubset / checkSubset, symmetric epipolar distance against threshold^2,
+ *     adaptive iteration budget, maxIters 1000) for n >= 15 points.  Below 15 points OpenCV switches FM_RANSAC to LMedS:
+ *     GFS_ERR_UNSUPPORTED, the caller keeps its cv:: call for that case.  The null space of the 7-point system and the roots
+ *     of its cubic are computed with +, -, *, /, sqrt only (oracle/fmat_oracle.cpp): same inlier sets as the oracle
+ *     bit for bit; against OpenCV the models agree to rounding noise, the order of the up to three models of a subset can differ.
+ * ============================================================================================ */
+typedef struct gfs_fmat gfs_fmat;
+int gfs_fmat_create(int device, int max_points, int max_batch, gfs_fmat** out);
+void gfs_fmat_destroy(gfs_fmat* h);
+/* B independent problems (host pointers): pts1[b] / pts2[b] = n_points[b] x 2 floats (cv::Point2f), mask[b][i] = status[i] (0 / 1),
+ * n_inliers[b] = size of the consensus set (0 = no model), F (may be NULL) = [B][9] row-major 3x3 of the best model.
+ * threshold <= 0 -> 3, confidence outside (0, 1) -> 0.99, like the cv:: wrapper. */
+int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, const float* const* pts1, const float* const* pts2,
+                                double threshold, double confidence, int max_iters, uint8_t* const* mask, double* F,
+                                int32_t* n_inliers);
 
 /* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel

@@ -262,6 +262,13 @@ int gfso_fb_klt_tracking(const uint8_t* prev_img, const int16_t* prev_deriv, con
                          int h, int win, int pyr_max_level, int nbpyrlvl, float ferr, float fmax_fbklt_dist, int n, const float* kps,
                          float* priors, uint8_t* kpstatus);
 
+/* ---- cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) for n >= 15 points (call sites
+ *      src/ORBmatcher.cc:236, 2399, 2463; src/Tracking.cc:1974): 7-point RANSAC with cv::RNG((uint64)-1).  See fmat_oracle.cpp for the
+ *      two deliberate differences (null-space basis and cubic solver in basic arithmetic only).  pts: n x 2 floats.  Returns the
+ *      inlier count of the best model (0 = no model, -2 = fewer than 15 points: OpenCV runs LMedS there, not restated). ---- */
+int gfso_fundamental_ransac(const float* pts1, const float* pts2, int n, double threshold, double confidence, int max_iters,
+                            uint8_t* mask, double* F_out, int* iterations_run);
+
 #ifdef __cplusplus
 }
 #endif

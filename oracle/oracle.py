@@ -599,3 +599,22 @@ def fb_klt_tracking(prev_pyr, cur_pyr, width, height, win, nbpyrlvl, ferr, fmax_
     good = L.gfso_fb_klt_tracking(_p(prev_pyr[0]), _p(prev_pyr[1]), _p(cur_pyr[0]), _p(cur_pyr[1]), width, height, win,
                                   pyr_max_level, nbpyrlvl, ferr, fmax_fbklt_dist, n, _p(kps), _p(pri), _p(st))
     return pri[:n].copy(), st[:n].astype(bool), int(good)
+
+
+def fundamental_ransac(pts1, pts2, threshold=3.0, confidence=0.99, max_iters=1000):
+    """cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) restatement (oracle/fmat_oracle.cpp), n >= 15.
+    Returns (mask bool [n], F [3, 3] or None, n_inliers, iterations_run)."""
+    p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = len(p1)
+    mask = np.zeros(max(n, 1), np.uint8)
+    F = np.zeros(9)
+    it = C.c_int(0)
+    L = lib()
+    L.gfso_fundamental_ransac.restype = C.c_int
+    L.gfso_fundamental_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_int)]
+    rc = L.gfso_fundamental_ransac(_p(p1), _p(p2), n, threshold, confidence, max_iters, _p(mask), _p(F), C.byref(it))
+    if rc == -2:
+        raise ValueError("fewer than 15 points: OpenCV switches to LMedS (not restated)")
+    return mask[:n].astype(bool), (F.reshape(3, 3).copy() if rc > 0 else None), int(rc), int(it.value)

@@ -35,9 +35,11 @@ def test_no_cpu_fallback_without_gpu(api):
         api.RegistrationGICP()
     with pytest.raises(api.GfsError):
         api.Optimizer()
-    for cls in (api.Frame, api.ProjectionMatcher, api.PoseOptimizer):
+    for cls in (api.Frame, api.ProjectionMatcher, api.PoseOptimizer, api.GmsMatcher, api.FundamentalMatcher):
         with pytest.raises(api.GfsError):
             cls()
+    with pytest.raises(api.GfsError):
+        api.KltTracker(640, 480, 35)
 
 
 def test_product_does_not_reference_the_oracle():

@@ -1,0 +1,71 @@
+"""GPU parity tests for the fundamental-matrix RANSAC (MI355X, k_fmat_chunk / k_fmat_mask through gfs_find_fundamental_ransac):
+inlier masks, consensus sizes and the model matrices are bit-equal to the CPU oracle (every step of the method is +, -, *, /,
+sqrt in the same order on both sides; the iteration budget is evaluated by the same host libm)."""
+import numpy as np
+import pytest
+
+from geoflowslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(g, o):
+    mask, F, cnt = g
+    mo, Fo, co, _ = o
+    assert cnt == co and np.array_equal(mask, mo)
+    assert (F is None) == (Fo is None)
+    if F is not None:
+        assert np.array_equal(F.view(np.uint64), Fo.view(np.uint64))
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=1, of=0.25), dict(seed=2, of=0.5), dict(seed=3, of=0.05), dict(seed=4, of=0.7),
+                                 dict(seed=5, of=0.0, noise=0.0), dict(seed=6, of=0.35, n=40), dict(seed=7, of=0.2, n=15),
+                                 dict(seed=8, of=0.3, n=1500, thr=1.5), dict(seed=9, of=0.4, thr=0.5, conf=0.999)])
+def test_matches_oracle(gpu_api, oracle, cfg):
+    n = cfg.get("n", 500)
+    p1, p2, inl, _ = synth.two_view_points(cfg["seed"], n, cfg["of"], cfg.get("noise", 0.3))
+    fm = gpu_api.FundamentalMatcher(max_points=2048, max_batch=1)
+    thr, conf = cfg.get("thr", 3.0), cfg.get("conf", 0.99)
+    _check(fm.findFundamentalMat(p1, p2, thr, conf), oracle.fundamental_ransac(p1, p2, thr, conf))
+    if n >= 200 and cfg["of"] <= 0.5 and thr >= 1.5:
+        assert (fm.findFundamentalMat(p1, p2, thr, conf)[0] == inl).mean() > 0.9
+
+
+def test_batch_of_ragged_problems_and_budgets(gpu_api, oracle):
+    B = 6
+    probs = [synth.two_view_points(20 + b, [300, 15, 800, 64, 500, 120][b], [0.1, 0.2, 0.6, 0.3, 0.45, 0.0][b]) for b in range(B)]
+    fm = gpu_api.FundamentalMatcher(max_points=1024, max_batch=B)
+    for max_iters in (1000, 70, 1):
+        G = fm.findFundamentalMat([p[0] for p in probs], [p[1] for p in probs], 2.0, 0.99, max_iters)
+        for b in range(B):
+            _check(G[b], oracle.fundamental_ransac(probs[b][0], probs[b][1], 2.0, 0.99, max_iters))
+
+
+def test_tracked_points_of_rendered_frames(gpu_api, oracle):
+    """The reference's use: the forward-backward-consistent optical-flow tracks of a frame pair go through the F check."""
+    fp = synth.frame_pair(5, 640, 480, 8)
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=480, max_cols=640)
+    _, k0, _ = ext(fp["gray0"])
+    kps = np.stack([k0["x"], k0["y"]], 1).astype(np.float32)
+    trk = gpu_api.KltTracker(640, 480, 35, max_batch=1, max_points=2048)
+    p0, p1 = trk.buildOpticalFlowPyramid(fp["gray0"]), trk.buildOpticalFlowPyramid(fp["gray1"])
+    pri, ok, good = trk.fbKltTracking(p0, p1, 3, 15.0, 0.5, kps, kps.copy())
+    a, b = kps[ok], pri[ok]
+    fm = gpu_api.FundamentalMatcher(max_points=2048)
+    g = fm.findFundamentalMat(a, b, 1.0, 0.99)
+    _check(g, oracle.fundamental_ransac(a, b, 1.0, 0.99))
+    assert g[2] > 0.8 * len(a)
+
+
+def test_degenerate_and_unsupported(gpu_api, oracle):
+    fm = gpu_api.FundamentalMatcher(max_points=256)
+    x = np.linspace(10, 600, 40, dtype=np.float32)
+    line = np.stack([x, x], 1).astype(np.float32)
+    other = np.random.default_rng(0).uniform(0, 400, (40, 2)).astype(np.float32)
+    _check(fm.findFundamentalMat(line, other), oracle.fundamental_ransac(line, other))
+    assert fm.findFundamentalMat(line, other)[1] is None
+    _check(fm.findFundamentalMat(other, other), oracle.fundamental_ransac(other, other))
+    with pytest.raises(gpu_api.GfsError):
+        fm.findFundamentalMat(other[:14], other[:14])       # OpenCV: LMedS below 15 points
+    with pytest.raises(gpu_api.GfsError):
+        fm.findFundamentalMat(np.zeros((300, 2), np.float32), np.zeros((300, 2), np.float32))   # capacity
