@@ -5,12 +5,13 @@
 // bisection, so that every step is +, -, *, /, sqrt and the device reproduces the oracle's bits).
 //
 // RANSAC looks sequential (the iteration budget shrinks whenever a better model is found) but the random subsets do not depend
-// on the models: the cv::RNG stream is consumed the same way whatever is accepted.  So a launch evaluates a CHUNK of 64
-// iterations of every problem at once — one lane draws the 64 subsets (the only sequential part), 64 lanes solve the 7-point
-// problems, the four waves of the workgroup count the inliers of the up to 192 models over all points — and the host replays
+// on the models: the cv::RNG stream is consumed the same way whatever is accepted.  So a round evaluates a CHUNK of iterations
+// (16 first, then 64) of every problem at once — k_fmat_hyp: one lane draws the subsets (the only sequential part), a lane per
+// iteration solves the 7-point problem (its 7 x 9 system in LDS); k_fmat_count: one wave per model counts its inliers over all
+// points — and the host replays
 // the accept / update-budget logic over the 64 results in order (its libm evaluates RANSACUpdateNumIters exactly like the
-// oracle).  With a third or fewer outliers one chunk is all it takes; harder problems continue chunk by chunk from the saved
-// generator state.  One workgroup per problem, problems of a batch in parallel.
+// oracle).  With a quarter or fewer outliers the first chunk is all it takes; harder problems continue chunk by chunk from the
+// saved generator state.  Problems of a batch run in parallel.
 #include <cmath>
 #include <memory>
 #include <mutex>
@@ -38,33 +39,44 @@ __device__ __forceinline__ unsigned rng_next(unsigned long long& s) {  // cv::RN
   return (unsigned)s;
 }
 
-__device__ bool have_collinear_points(const float2* m, const int* idx) {  // the last of 7 points against every earlier pair
-  const int i = 6;
-  for (int j = 0; j < i; j++) {
-    const double dx1 = (double)(m[idx[j]].x - m[idx[i]].x), dy1 = (double)(m[idx[j]].y - m[idx[i]].y);
-    for (int k = 0; k < j; k++) {
-      const double dx2 = (double)(m[idx[k]].x - m[idx[i]].x), dy2 = (double)(m[idx[k]].y - m[idx[i]].y);
+__device__ __forceinline__ bool have_collinear_points(const float2 (&p)[7]) {  // the last of 7 points against every earlier pair
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const double dx1 = (double)(p[j].x - p[6].x), dy1 = (double)(p[j].y - p[6].y);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      if (k >= j) continue;
+      const double dx2 = (double)(p[k].x - p[6].x), dy2 = (double)(p[k].y - p[6].y);
       if (fabs(dx2 * dy1 - dy2 * dx1) <= kFltEps * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
     }
   }
   return false;
 }
 
-__device__ bool get_subset(unsigned long long& rng, const float2* m1, const float2* m2, int count, int* idx) {
-  for (int iters = 0; iters < 10000; ++iters) {
-    for (int i = 0; i < 7; ++i) {
-      int v;
-      for (;;) {
-        v = (int)(rng_next(rng) % (unsigned)count);
-        bool dup = false;
-        for (int j = 0; j < i; j++) dup |= idx[j] == v;
-        if (!dup) break;
-      }
-      idx[i] = v;
+// 7 distinct indices from the generator (the drawing half of getSubset)
+__device__ __forceinline__ void draw_subset(unsigned long long& rng, int count, int (&idx)[7]) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    int v;
+    for (;;) {
+      v = (int)(rng_next(rng) % (unsigned)count);
+      bool dup = false;
+#pragma unroll
+      for (int j = 0; j < 7; j++) dup |= j < i && idx[j] == v;
+      if (!dup) break;
     }
-    if (!have_collinear_points(m1, idx) && !have_collinear_points(m2, idx)) return true;
+    idx[i] = v;
   }
-  return false;
+}
+// FMEstimatorCallback::checkSubset: the 14 points are fetched together, the pair tests run on registers
+__device__ __forceinline__ bool subset_ok(const float2* m1, const float2* m2, const int (&idx)[7]) {
+  float2 a[7], b[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    a[i] = m1[idx[i]];
+    b[i] = m2[idx[i]];
+  }
+  return !have_collinear_points(a) && !have_collinear_points(b);
 }
 
 __device__ __forceinline__ double cubic_eval(double B, double C, double D, double x) { return ((x + B) * x + C) * x + D; }
@@ -121,7 +133,10 @@ __device__ int cubic_real_roots(const double* c, double* r) {
 }
 
 // FMEstimatorCallback::runKernel for 7 points: up to three 3x3 matrices (row-major) in Fm
-__device__ int seven_point(const float2* m1, const float2* m2, const int* idx, double* Fm) {
+// `sa`: this lane's 7 x 9 system in LDS, element (i, j) at sa[(i * 9 + j) * kFmChunk] (lane-minor: conflict-free); the pivoting
+// indexes it dynamically, which would push a register array into scratch memory.
+__device__ int seven_point(const float2* m1, const float2* m2, const int* idx, double* Fm, double* sa) {
+#define A_(i, j) sa[((i) * 9 + (j)) * kFmChunk]
   double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
   for (int i = 0; i < 7; i++) {
     c1x += (double)m1[idx[i]].x;
@@ -146,19 +161,18 @@ __device__ int seven_point(const float2* m1, const float2* m2, const int* idx, d
   if (s1 < kFltEps || s2 < kFltEps) return 0;
   s1 = __dsqrt_rn(2.) / s1;
   s2 = __dsqrt_rn(2.) / s2;
-  double a[7][9];
   for (int i = 0; i < 7; i++) {
     const double x0 = ((double)m1[idx[i]].x - c1x) * s1, y0 = ((double)m1[idx[i]].y - c1y) * s1;
     const double x1 = ((double)m2[idx[i]].x - c2x) * s2, y1 = ((double)m2[idx[i]].y - c2y) * s2;
-    a[i][0] = x1 * x0;
-    a[i][1] = x1 * y0;
-    a[i][2] = x1;
-    a[i][3] = y1 * x0;
-    a[i][4] = y1 * y0;
-    a[i][5] = y1;
-    a[i][6] = x0;
-    a[i][7] = y0;
-    a[i][8] = 1;
+    A_(i, 0) = x1 * x0;
+    A_(i, 1) = x1 * y0;
+    A_(i, 2) = x1;
+    A_(i, 3) = y1 * x0;
+    A_(i, 4) = y1 * y0;
+    A_(i, 5) = y1;
+    A_(i, 6) = x0;
+    A_(i, 7) = y0;
+    A_(i, 8) = 1;
   }
   int perm[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
   for (int r = 0; r < 7; r++) {  // Gauss-Jordan with full pivoting
@@ -166,40 +180,40 @@ __device__ int seven_point(const float2* m1, const float2* m2, const int* idx, d
     double pv = -1;
     for (int i = r; i < 7; i++)
       for (int j = r; j < 9; j++)
-        if (fabs(a[i][j]) > pv) {
-          pv = fabs(a[i][j]);
+        if (fabs(A_(i, j)) > pv) {
+          pv = fabs(A_(i, j));
           pi = i;
           pj = j;
         }
     if (!(pv > 0)) return 0;
     for (int j = 0; j < 9; j++) {
-      const double tmp = a[r][j];
-      a[r][j] = a[pi][j];
-      a[pi][j] = tmp;
+      const double tmp = A_(r, j);
+      A_(r, j) = A_(pi, j);
+      A_(pi, j) = tmp;
     }
     for (int i = 0; i < 7; i++) {
-      const double tmp = a[i][r];
-      a[i][r] = a[i][pj];
-      a[i][pj] = tmp;
+      const double tmp = A_(i, r);
+      A_(i, r) = A_(i, pj);
+      A_(i, pj) = tmp;
     }
     {
       const int tmp = perm[r];
       perm[r] = perm[pj];
       perm[pj] = tmp;
     }
-    const double ip = 1. / a[r][r];
-    for (int j = 0; j < 9; j++) a[r][j] *= ip;
+    const double ip = 1. / A_(r, r);
+    for (int j = 0; j < 9; j++) A_(r, j) *= ip;
     for (int i = 0; i < 7; i++) {
       if (i == r) continue;
-      const double f = a[i][r];
-      for (int j = 0; j < 9; j++) a[i][j] -= f * a[r][j];
+      const double f = A_(i, r);
+      for (int j = 0; j < 9; j++) A_(i, j) -= f * A_(r, j);
     }
   }
   double f1[9], f2[9];
   for (int j = 0; j < 9; j++) f1[j] = f2[j] = 0;
   for (int r = 0; r < 7; r++) {
-    f1[perm[r]] = -a[r][7];
-    f2[perm[r]] = -a[r][8];
+    f1[perm[r]] = -A_(r, 7);
+    f2[perm[r]] = -A_(r, 8);
   }
   f1[perm[7]] = 1;
   f2[perm[8]] = 1;
@@ -248,6 +262,7 @@ __device__ int seven_point(const float2* m1, const float2* m2, const int* idx, d
     }
   }
   return n;
+#undef A_
 }
 
 __device__ __forceinline__ float epipolar_error(const double* F, float2 p1, float2 p2) {  // FMEstimatorCallback::computeError
@@ -266,55 +281,107 @@ __device__ __forceinline__ float epipolar_error(const double* F, float2 p1, floa
   return (float)(e1 > e2 ? e1 : e2);
 }
 
-// One chunk of kFmChunk RANSAC iterations of every active problem.  pts1 / pts2: [B][stride] float2.
-// models [B][kFmChunk][27], nmodels [B][kFmChunk] (-1 = getSubset failed), good [B][kFmChunk][3].
-__global__ void __launch_bounds__(kFmThreads) k_fmat_chunk(FmProblem* __restrict__ prob, const float2* __restrict__ pts1,
-                                                          const float2* __restrict__ pts2, int stride, double* __restrict__ models,
-                                                          int* __restrict__ nmodels, int* __restrict__ good) {
+// Hypotheses of one chunk of K <= kFmChunk RANSAC iterations of every active problem: 64 threads per problem.
+// pts1 / pts2: [B][stride] float2; models [B][kFmChunk][27], nmodels [B][kFmChunk] (-1 = getSubset failed).
+__global__ void __launch_bounds__(kFmChunk) k_fmat_hyp(FmProblem* __restrict__ prob, const float2* __restrict__ pts1,
+                                                       const float2* __restrict__ pts2, int stride, int K, double* __restrict__ models,
+                                                       int* __restrict__ nmodels) {
   __shared__ int s_idx[kFmChunk][7];
   __shared__ int s_nm[kFmChunk];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ unsigned long long s_state[kFmChunk + 1];
+  __shared__ int s_bad, s_fail;
+  __shared__ double s_a[63 * kFmChunk];
+  const int b = blockIdx.x, tid = threadIdx.x;
   FmProblem P = prob[b];
   if (!P.active) return;
   const float2* m1 = pts1 + (size_t)b * stride;
   const float2* m2 = pts2 + (size_t)b * stride;
   double* Fm = models + (size_t)b * kFmChunk * 27;
-  if (tid == 0) {  // the generator is sequential; its consumption does not depend on what the models turn out to be
-    unsigned long long rng = P.rng;
-    bool ok = true;
-    for (int k = 0; k < kFmChunk; k++) {
-      int idx[7] = {0, 0, 0, 0, 0, 0, 0};
-      if (ok) ok = get_subset(rng, m1, m2, P.n, idx);
-      for (int i = 0; i < 7; i++) s_idx[k][i] = idx[i];
-      s_nm[k] = ok ? 0 : -1;
+  // getSubset for the K iterations.  Drawing is sequential but needs no data; checkSubset needs the points but is independent per
+  // subset.  So lane 0 draws all subsets as if none were rejected, the lanes test them in parallel, and only if one is rejected
+  // (collinear points: rare) lane 0 redraws that one the serial way and the subsets after it are drawn again.
+  int start = 0;
+  for (;;) {
+    if (tid == 0) {
+      unsigned long long rng = start == 0 ? P.rng : s_state[start];
+      for (int k = start; k < K; k++) {
+        int idx[7] = {0, 0, 0, 0, 0, 0, 0};
+        draw_subset(rng, P.n, idx);
+        for (int i = 0; i < 7; i++) s_idx[k][i] = idx[i];
+        s_state[k + 1] = rng;
+        s_nm[k] = 0;
+      }
+      s_bad = K;
     }
-    prob[b].rng = rng;
+    __syncthreads();
+    if (tid >= start && tid < K) {
+      int idx[7];
+      for (int i = 0; i < 7; i++) idx[i] = s_idx[tid][i];
+      if (!subset_ok(m1, m2, idx)) atomicMin(&s_bad, tid);
+    }
+    __syncthreads();
+    const int bad = s_bad;
+    if (bad >= K) break;
+    if (tid == 0) {  // attempts 2 .. 10000 of that getSubset call
+      unsigned long long rng = s_state[bad + 1];
+      bool ok = false;
+      int idx[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int iters = 1; iters < 10000 && !ok; ++iters) {
+        draw_subset(rng, P.n, idx);
+        ok = subset_ok(m1, m2, idx);
+      }
+      for (int i = 0; i < 7; i++) s_idx[bad][i] = idx[i];
+      s_state[bad + 1] = rng;
+      s_fail = ok ? 0 : 1;
+      if (!ok)
+        for (int k = bad; k < K; k++) s_nm[k] = -1;  // the RANSAC loop ends at this iteration
+    }
+    __syncthreads();
+    if (s_fail) break;
+    start = bad + 1;
+    if (start >= K) break;
   }
+  if (tid == 0) prob[b].rng = s_state[K];
   __syncthreads();
-  if (tid < kFmChunk) {
+  if (tid < K) {
     int nm = s_nm[tid];
     if (nm == 0) {
       int idx[7];
       for (int i = 0; i < 7; i++) idx[i] = s_idx[tid][i];
       double F[27];
-      nm = seven_point(m1, m2, idx, F);
+      nm = seven_point(m1, m2, idx, F, s_a + tid);
       for (int i = 0; i < 9 * nm; i++) Fm[(size_t)tid * 27 + i] = F[i];
-      s_nm[tid] = nm;
     }
     nmodels[(size_t)b * kFmChunk + tid] = nm;
   }
-  __syncthreads();
-  // inlier counts: wave w takes the (iteration, model) pairs w, w + 4, ...; lanes over the points
-  for (int q = wave; q < kFmChunk * 3; q += kFmThreads / 64) {
-    const int k = q / 3, m = q - 3 * k;
-    if (m >= s_nm[k]) continue;  // wave-uniform
-    double F[9];
-    for (int i = 0; i < 9; i++) F[i] = Fm[(size_t)k * 27 + 9 * m + i];
-    int cnt = 0;
-    for (int i = lane; i < P.n; i += 64) cnt += epipolar_error(F, m1[i], m2[i]) <= P.t2 ? 1 : 0;
-    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
-    if (lane == 0) good[((size_t)b * kFmChunk + k) * 3 + m] = cnt;
-  }
+}
+
+// Inlier counts of the up to 3 K models of a chunk: one wave per (iteration, model), lanes over the points; good [B][kFmChunk][3].
+__global__ void __launch_bounds__(kFmThreads) k_fmat_count(const FmProblem* __restrict__ prob, const float2* __restrict__ pts1,
+                                                          const float2* __restrict__ pts2, int stride, int K,
+                                                          const double* __restrict__ models, const int* __restrict__ nmodels,
+                                                          int* __restrict__ good) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int q = blockIdx.x * (kFmThreads / 64) + (threadIdx.x >> 6);
+  const FmProblem P = prob[b];
+  if (!P.active || q >= 3 * K) return;
+  const int k = q / 3, m = q - 3 * k;
+  if (m >= nmodels[(size_t)b * kFmChunk + k]) return;  // wave-uniform
+  const float2* m1 = pts1 + (size_t)b * stride;
+  const float2* m2 = pts2 + (size_t)b * stride;
+  double F[9];
+  for (int i = 0; i < 9; i++) F[i] = models[((size_t)b * kFmChunk + k) * 27 + 9 * m + i];
+  int cnt = 0;
+  for (int i = lane; i < P.n; i += 64) cnt += epipolar_error(F, m1[i], m2[i]) <= P.t2 ? 1 : 0;
+  for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+  if (lane == 0) good[((size_t)b * kFmChunk + k) * 3 + m] = cnt;
+}
+
+// best[b] = the model accepted last in this chunk (keep[b] = iteration * 3 + model, or -1: nothing new for problem b)
+__global__ void k_fmat_keep(const int* __restrict__ keep, const double* __restrict__ models, double* __restrict__ best, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || keep[b] < 0) return;
+  for (int i = 0; i < 9; i++) best[(size_t)b * 9 + i] = models[(size_t)b * kFmChunk * 27 + (size_t)keep[b] * 9 + i];
 }
 
 // mask[i] = inlier of the chosen model; sel [B] = iteration * 3 + model inside the last chunk of that problem, or -1 (no model)
@@ -353,12 +420,12 @@ struct gfs_fmat {
   DevBuf<FmProblem> d_prob;
   DevBuf<float2> d_p1, d_p2;
   DevBuf<double> d_models, d_best;
-  DevBuf<int> d_nm, d_good, d_sel;
+  DevBuf<int> d_nm, d_good, d_sel, d_keep;
   DevBuf<uint8_t> d_mask;
   PinBuf<FmProblem> h_prob;
   PinBuf<float2> h_p1, h_p2;
-  PinBuf<double> h_models, h_best;
-  PinBuf<int> h_nm, h_good, h_sel;
+  PinBuf<double> h_best;
+  PinBuf<int> h_nm, h_good, h_sel, h_keep;
   PinBuf<uint8_t> h_mask;
 };
 
@@ -385,15 +452,16 @@ int gfs_fmat_create(int device, int max_points, int max_batch, gfs_fmat** out) {
   A(h->d_nm.alloc(B * kFmChunk));
   A(h->d_good.alloc(B * kFmChunk * 3));
   A(h->d_sel.alloc(B));
+  A(h->d_keep.alloc(B));
   A(h->d_mask.alloc(NP));
   A(h->h_prob.alloc(B));
   A(h->h_p1.alloc(NP));
   A(h->h_p2.alloc(NP));
-  A(h->h_models.alloc(B * kFmChunk * 27));
   A(h->h_best.alloc(B * 9));
   A(h->h_nm.alloc(B * kFmChunk));
   A(h->h_good.alloc(B * kFmChunk * 3));
   A(h->h_sel.alloc(B));
+  A(h->h_keep.alloc(B));
   A(h->h_mask.alloc(NP));
 #undef A
   if (rc) {
@@ -441,22 +509,26 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
   GFS_HIP(hipMemcpyAsync(h->d_p1.p, h->h_p1.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_p2.p, h->h_p2.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   // host replay state of RANSACPointSetRegistrator::run per problem
-  std::vector<int> niters(B, max_iters > 1 ? max_iters : 1), max_good(B, 0), iter(B, 0), done(B, 0);
+  std::vector<int> niters(B, max_iters > 1 ? max_iters : 1), max_good(B, 0), iter(B, 0), done(B, 0), best_here(B, 0);
   for (int b = 0; b < B; b++) h->h_sel.p[b] = -1;
   int remaining = B;
+  int K = 16;  // the first chunk is short: with a quarter of outliers or fewer the budget drops below 16 after the first good model
   while (remaining > 0) {
     GFS_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, B * sizeof(FmProblem), hipMemcpyHostToDevice, s));
-    GFS_LAUNCH("k_fmat_chunk", k_fmat_chunk, dim3(B), dim3(kFmThreads), 0, s, h->d_prob.p, (const float2*)h->d_p1.p,
-               (const float2*)h->d_p2.p, S, h->d_models.p, h->d_nm.p, h->d_good.p);
+    GFS_LAUNCH("k_fmat_hyp", k_fmat_hyp, dim3(B), dim3(kFmChunk), 0, s, h->d_prob.p, (const float2*)h->d_p1.p,
+               (const float2*)h->d_p2.p, S, K, h->d_models.p, h->d_nm.p);
+    GFS_LAUNCH("k_fmat_count", k_fmat_count, dim3(gfs::div_up(3 * K, kFmThreads / 64), B), dim3(kFmThreads), 0, s,
+               (const FmProblem*)h->d_prob.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, K, (const double*)h->d_models.p,
+               (const int*)h->d_nm.p, h->d_good.p);
     GFS_HIP(hipMemcpyAsync(h->h_prob.p, h->d_prob.p, B * sizeof(FmProblem), hipMemcpyDeviceToHost, s));
     GFS_HIP(hipMemcpyAsync(h->h_nm.p, h->d_nm.p, (size_t)B * kFmChunk * sizeof(int), hipMemcpyDeviceToHost, s));
     GFS_HIP(hipMemcpyAsync(h->h_good.p, h->d_good.p, (size_t)B * kFmChunk * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
-    GFS_HIP(hipMemcpyAsync(h->h_models.p, h->d_models.p, (size_t)B * kFmChunk * 27 * sizeof(double), hipMemcpyDeviceToHost, s));
     GFS_HIP(hipStreamSynchronize(s));
+    std::fill(best_here.begin(), best_here.end(), 0);
     for (int b = 0; b < B; b++) {
       if (done[b]) continue;
       const int n = n_points[b];
-      for (int k = 0; k < kFmChunk && !done[b]; k++) {
+      for (int k = 0; k < K && !done[b]; k++) {
         if (iter[b] >= niters[b]) {
           done[b] = 1;
           break;
@@ -470,8 +542,8 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
           const int g = h->h_good.p[((size_t)b * kFmChunk + k) * 3 + m];
           if (g > (max_good[b] > 6 ? max_good[b] : 6)) {
             max_good[b] = g;
-            h->h_sel.p[b] = 1;
-            memcpy(h->h_best.p + (size_t)b * 9, h->h_models.p + ((size_t)b * kFmChunk + k) * 27 + 9 * m, 9 * sizeof(double));
+            h->h_sel.p[b] = k * 3 + m;
+            best_here[b] = 1;
             niters[b] = update_num_iters(confidence, (double)(n - g) / n, niters[b]);
           }
         }
@@ -483,13 +555,26 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
         remaining--;
       }
     }
+    // the accepted models of this chunk stay on the device (the next chunk overwrites d_models)
+    bool any_new = false;
+    for (int b = 0; b < B; b++) {
+      h->h_keep.p[b] = best_here[b] ? h->h_sel.p[b] : -1;
+      any_new |= best_here[b] != 0;
+    }
+    if (any_new) {
+      GFS_HIP(hipMemcpyAsync(h->d_keep.p, h->h_keep.p, B * sizeof(int), hipMemcpyHostToDevice, s));
+      GFS_LAUNCH("k_fmat_keep", k_fmat_keep, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, (const int*)h->d_keep.p,
+                 (const double*)h->d_models.p, h->d_best.p, B);
+      GFS_HIP(hipStreamSynchronize(s));  // h_keep is rewritten by the next round
+    }
+    K = kFmChunk;
   }
   GFS_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, B * sizeof(FmProblem), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_sel.p, h->h_sel.p, B * sizeof(int), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_best.p, h->h_best.p, (size_t)B * 9 * sizeof(double), hipMemcpyHostToDevice, s));
   GFS_LAUNCH("k_fmat_mask", k_fmat_mask, dim3(gfs::div_up(nmax, kFmThreads), B), dim3(kFmThreads), 0, s, (const FmProblem*)h->d_prob.p,
              (const int*)h->d_sel.p, (const double*)h->d_best.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, h->d_mask.p);
   GFS_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, NP, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->h_best.p, h->d_best.p, (size_t)B * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
   for (int b = 0; b < B; b++) {
     memcpy(mask[b], h->h_mask.p + (size_t)b * S, (size_t)n_points[b]);

@@ -69,3 +69,14 @@ def test_degenerate_and_unsupported(gpu_api, oracle):
         fm.findFundamentalMat(other[:14], other[:14])       # OpenCV: LMedS below 15 points
     with pytest.raises(gpu_api.GfsError):
         fm.findFundamentalMat(np.zeros((300, 2), np.float32), np.zeros((300, 2), np.float32))   # capacity
+
+
+def test_rejected_subsets_follow_the_generator(gpu_api, oracle):
+    """Half of the points of image 1 lie exactly on a line: many drawn subsets fail checkSubset and are redrawn, which shifts every
+    later draw — the device draws speculatively and must fall back to the serial order exactly there."""
+    p1, p2, _, _ = synth.two_view_points(31, 200, 0.2)
+    t = np.linspace(20, 600, 100, dtype=np.float32)
+    p1[::2] = np.stack([t, t], 1)
+    fm = gpu_api.FundamentalMatcher(max_points=256)
+    for thr, it in ((3.0, 1000), (0.7, 1000), (3.0, 5)):
+        _check(fm.findFundamentalMat(p1, p2, thr, 0.99, it), oracle.fundamental_ransac(p1, p2, thr, 0.99, it))
