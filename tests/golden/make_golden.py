@@ -63,6 +63,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "klt_160x120.npz"), kps=kps, priors=pri, status=ok, good=good, next=nxt, st=st, err=er,
                         pyr_crc=np.array([zlib.crc32(p0[0].tobytes()), zlib.crc32(p0[1].tobytes()), zlib.crc32(p1[0].tobytes()),
                                           zlib.crc32(p1[1].tobytes())], np.int64))
+    # 6. fundamental-matrix RANSAC on synthetic two-view matches (200 points, 30 % gross mismatches)
+    q1, q2, _, _ = synth.two_view_points(77, 200, 0.3)
+    fmask, fF, fcnt, fit = O.fundamental_ransac(q1, q2, 2.0, 0.99)
+    np.savez_compressed(os.path.join(OUT, "fmat_200.npz"), pts1=q1, pts2=q2, mask=fmask, F=fF, count=fcnt, iterations=fit)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
