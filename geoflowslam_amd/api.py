@@ -803,8 +803,8 @@ class KltTracker:
 
 
 class FundamentalMatcher:
-    """cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) for n >= 15 points (reference call sites
-    src/ORBmatcher.cc:236, 2399, 2463; src/Tracking.cc:1974)."""
+    """cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) (reference call sites src/ORBmatcher.cc:236,
+    2399, 2463; src/Tracking.cc:1974): RANSAC for 15 or more points, LMedS for 8 .. 14 like the cv:: wrapper."""
 
     def __init__(self, max_points=4096, max_batch=1, device=0):
         self.h = C.c_void_p()
@@ -830,7 +830,7 @@ class FundamentalMatcher:
         arr = lambda L: (C.c_void_p * B)(*[a.ctypes.data for a in L])
         _check(lib().gfs_find_fundamental_ransac(self.h, B, _p(n), arr(P1), arr(P2), float(threshold), float(confidence), max_iters,
                                                  arr(M), _p(F), _p(cnt)), "gfs_find_fundamental_ransac")
-        out = [(M[b][:n[b]].astype(bool), F[b].reshape(3, 3).copy() if cnt[b] > 0 else None, int(cnt[b])) for b in range(B)]
+        out = [(M[b][:n[b]].astype(bool), F[b].reshape(3, 3).copy() if cnt[b] > 0 and F[b].any() else None, int(cnt[b])) for b in range(B)]
         return out[0] if single else out
 
 

@@ -2,7 +2,8 @@
 // optical-flow matcher (src/ORBmatcher.cc:2399-2405, 2463-2469, also :236) and Tracking::EstimatePoseByOF (src/Tracking.cc:1973-1974):
 // the 7-point RANSAC of OpenCV's RANSACPointSetRegistrator (calib3d/src/ptsetreg.cpp, fundam.cpp; restated in
 // oracle/fmat_oracle.cpp, which also lists the two deliberate differences: null space by Gauss-Jordan elimination and cubic roots by
-// bisection, so that every step is +, -, *, /, sqrt and the device reproduces the oracle's bits).
+// bisection, so that every step is +, -, *, /, sqrt and the device reproduces the oracle's bits).  15 or more points: RANSAC;
+// 8 .. 14 points: the LMedS registrator cv::findFundamentalMat switches to (k_fmat_median instead of k_fmat_count).
 //
 // RANSAC looks sequential (the iteration budget shrinks whenever a better model is found) but the random subsets do not depend
 // on the models: the cv::RNG stream is consumed the same way whatever is accepted.  So a round evaluates a CHUNK of iterations
@@ -31,7 +32,9 @@ struct FmProblem {
   int n;                         // points
   int active;                    // this problem still needs the current chunk
   unsigned long long rng;        // cv::RNG state before the chunk / after it
-  float t2;                      // (float)(threshold^2)
+  float t2;                      // (float)(threshold^2); LMedS: (float)(sigma^2) once the best model is known
+  int lmeds;                     // 8 .. 14 points: LMeDSPointSetRegistrator instead of RANSAC
+  int max_attempts;              // getSubset: 10000 (RANSAC) / 1000 (LMedS)
 };
 
 __device__ __forceinline__ unsigned rng_next(unsigned long long& s) {  // cv::RNG::next
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(kFmChunk) k_fmat_hyp(FmProblem* __restrict__ p
       unsigned long long rng = s_state[bad + 1];
       bool ok = false;
       int idx[7] = {0, 0, 0, 0, 0, 0, 0};
-      for (int iters = 1; iters < 10000 && !ok; ++iters) {
+      for (int iters = 1; iters < P.max_attempts && !ok; ++iters) {
         draw_subset(rng, P.n, idx);
         ok = subset_ok(m1, m2, idx);
       }
@@ -364,7 +367,7 @@ __global__ void __launch_bounds__(kFmThreads) k_fmat_count(const FmProblem* __re
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int q = blockIdx.x * (kFmThreads / 64) + (threadIdx.x >> 6);
   const FmProblem P = prob[b];
-  if (!P.active || q >= 3 * K) return;
+  if (!P.active || P.lmeds || q >= 3 * K) return;
   const int k = q / 3, m = q - 3 * k;
   if (m >= nmodels[(size_t)b * kFmChunk + k]) return;  // wave-uniform
   const float2* m1 = pts1 + (size_t)b * stride;
@@ -375,6 +378,30 @@ __global__ void __launch_bounds__(kFmThreads) k_fmat_count(const FmProblem* __re
   for (int i = lane; i < P.n; i += 64) cnt += epipolar_error(F, m1[i], m2[i]) <= P.t2 ? 1 : 0;
   for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
   if (lane == 0) good[((size_t)b * kFmChunk + k) * 3 + m] = cnt;
+}
+
+// LMedS problems (8 .. 14 points): the median error of every model of the chunk, one thread per (iteration, model);
+// med [B][kFmChunk][3] (what std::nth_element leaves at position n / 2: the (n / 2)-th smallest of the float errors)
+__global__ void __launch_bounds__(kFmThreads) k_fmat_median(const FmProblem* __restrict__ prob, const float2* __restrict__ pts1,
+                                                           const float2* __restrict__ pts2, int stride, int K,
+                                                           const double* __restrict__ models, const int* __restrict__ nmodels,
+                                                           float* __restrict__ med) {
+  const int b = blockIdx.y, q = blockIdx.x * kFmThreads + threadIdx.x;
+  const FmProblem P = prob[b];
+  if (!P.active || !P.lmeds || q >= 3 * K) return;
+  const int k = q / 3, m = q - 3 * k;
+  if (m >= nmodels[(size_t)b * kFmChunk + k]) return;
+  double F[9];
+  for (int i = 0; i < 9; i++) F[i] = models[((size_t)b * kFmChunk + k) * 27 + 9 * m + i];
+  float e[16];
+  for (int i = 0; i < P.n; i++) e[i] = epipolar_error(F, pts1[(size_t)b * stride + i], pts2[(size_t)b * stride + i]);
+  for (int i = 1; i < P.n; i++) {
+    const float v = e[i];
+    int j = i;
+    for (; j > 0 && e[j - 1] > v; j--) e[j] = e[j - 1];
+    e[j] = v;
+  }
+  med[((size_t)b * kFmChunk + k) * 3 + m] = e[P.n / 2];
 }
 
 // best[b] = the model accepted last in this chunk (keep[b] = iteration * 3 + model, or -1: nothing new for problem b)
@@ -421,6 +448,8 @@ struct gfs_fmat {
   DevBuf<float2> d_p1, d_p2;
   DevBuf<double> d_models, d_best;
   DevBuf<int> d_nm, d_good, d_sel, d_keep;
+  DevBuf<float> d_med;
+  PinBuf<float> h_med;
   DevBuf<uint8_t> d_mask;
   PinBuf<FmProblem> h_prob;
   PinBuf<float2> h_p1, h_p2;
@@ -452,6 +481,8 @@ int gfs_fmat_create(int device, int max_points, int max_batch, gfs_fmat** out) {
   A(h->d_nm.alloc(B * kFmChunk));
   A(h->d_good.alloc(B * kFmChunk * 3));
   A(h->d_sel.alloc(B));
+  A(h->d_med.alloc(B * kFmChunk * 3));
+  A(h->h_med.alloc(B * kFmChunk * 3));
   A(h->d_keep.alloc(B));
   A(h->d_mask.alloc(NP));
   A(h->h_prob.alloc(B));
@@ -492,16 +523,16 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
   GFS_HIP(hipSetDevice(h->device));
   const int S = h->max_points;
   int nmax = 0;
+  bool any_lmeds = false;
   for (int b = 0; b < B; b++) {
     const int n = n_points[b];
     GFS_REQUIRE(n <= S, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac: problem %d has %d points, capacity %d", b, n, S);
-    GFS_REQUIRE(n >= 15, GFS_ERR_UNSUPPORTED,
-                "gfs_find_fundamental_ransac: problem %d has %d points; below 15 OpenCV switches FM_RANSAC to LMedS, which is not "
-                "implemented", b, n);
+    GFS_REQUIRE(n >= 8, GFS_ERR_UNSUPPORTED, "gfs_find_fundamental_ransac: problem %d has %d points (at least 8 needed)", b, n);
     GFS_REQUIRE(pts1[b] && pts2[b] && mask[b], GFS_ERR_INVALID_ARG, "gfs_find_fundamental_ransac: problem %d has NULL arrays", b);
     memcpy(h->h_p1.p + (size_t)b * S, pts1[b], (size_t)n * sizeof(float2));
     memcpy(h->h_p2.p + (size_t)b * S, pts2[b], (size_t)n * sizeof(float2));
-    h->h_prob.p[b] = FmProblem{n, 1, 0xffffffffffffffffull, (float)(threshold * threshold)};
+    h->h_prob.p[b] = FmProblem{n, 1, 0xffffffffffffffffull, (float)(threshold * threshold), n < 15 ? 1 : 0, n < 15 ? 1000 : 10000};
+    any_lmeds |= n < 15;
     nmax = n > nmax ? n : nmax;
   }
   hipStream_t s = h->stream;
@@ -510,6 +541,12 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
   GFS_HIP(hipMemcpyAsync(h->d_p2.p, h->h_p2.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
   // host replay state of RANSACPointSetRegistrator::run per problem
   std::vector<int> niters(B, max_iters > 1 ? max_iters : 1), max_good(B, 0), iter(B, 0), done(B, 0), best_here(B, 0);
+  std::vector<double> min_median(B, 1.7976931348623157e308);
+  for (int b = 0; b < B; b++)
+    if (h->h_prob.p[b].lmeds) {  // LMeDSPointSetRegistrator::run: budget from a 45 % outlier assumption, at least 3
+      niters[b] = update_num_iters(confidence, 0.45, 1000);
+      if (niters[b] < 3) niters[b] = 3;
+    }
   for (int b = 0; b < B; b++) h->h_sel.p[b] = -1;
   int remaining = B;
   int K = 16;  // the first chunk is short: with a quarter of outliers or fewer the budget drops below 16 after the first good model
@@ -520,6 +557,12 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
     GFS_LAUNCH("k_fmat_count", k_fmat_count, dim3(gfs::div_up(3 * K, kFmThreads / 64), B), dim3(kFmThreads), 0, s,
                (const FmProblem*)h->d_prob.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, K, (const double*)h->d_models.p,
                (const int*)h->d_nm.p, h->d_good.p);
+    if (any_lmeds) {
+      GFS_LAUNCH("k_fmat_median", k_fmat_median, dim3(gfs::div_up(3 * K, kFmThreads), B), dim3(kFmThreads), 0, s,
+                 (const FmProblem*)h->d_prob.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, K, (const double*)h->d_models.p,
+                 (const int*)h->d_nm.p, h->d_med.p);
+      GFS_HIP(hipMemcpyAsync(h->h_med.p, h->d_med.p, (size_t)B * kFmChunk * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     GFS_HIP(hipMemcpyAsync(h->h_prob.p, h->d_prob.p, B * sizeof(FmProblem), hipMemcpyDeviceToHost, s));
     GFS_HIP(hipMemcpyAsync(h->h_nm.p, h->d_nm.p, (size_t)B * kFmChunk * sizeof(int), hipMemcpyDeviceToHost, s));
     GFS_HIP(hipMemcpyAsync(h->h_good.p, h->d_good.p, (size_t)B * kFmChunk * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -539,6 +582,15 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
           break;
         }
         for (int m = 0; m < nm; m++) {
+          if (h->h_prob.p[b].lmeds) {
+            const double median = h->h_med.p[((size_t)b * kFmChunk + k) * 3 + m];
+            if (median < min_median[b]) {
+              min_median[b] = median;
+              h->h_sel.p[b] = k * 3 + m;
+              best_here[b] = 1;
+            }
+            continue;
+          }
           const int g = h->h_good.p[((size_t)b * kFmChunk + k) * 3 + m];
           if (g > (max_good[b] > 6 ? max_good[b] : 6)) {
             max_good[b] = g;
@@ -569,6 +621,12 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
     }
     K = kFmChunk;
   }
+  for (int b = 0; b < B; b++)
+    if (h->h_prob.p[b].lmeds && h->h_sel.p[b] >= 0) {  // inliers of the least-median model: within sigma of it
+      double sigma = 2.5 * 1.4826 * (1 + 5. / (n_points[b] - 7)) * std::sqrt(min_median[b]);
+      if (sigma < 0.001) sigma = 0.001;
+      h->h_prob.p[b].t2 = (float)(sigma * sigma);
+    }
   GFS_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, B * sizeof(FmProblem), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_sel.p, h->h_sel.p, B * sizeof(int), hipMemcpyHostToDevice, s));
   GFS_LAUNCH("k_fmat_mask", k_fmat_mask, dim3(gfs::div_up(nmax, kFmThreads), B), dim3(kFmThreads), 0, s, (const FmProblem*)h->d_prob.p,
@@ -578,6 +636,12 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
   GFS_HIP(hipStreamSynchronize(s));
   for (int b = 0; b < B; b++) {
     memcpy(mask[b], h->h_mask.p + (size_t)b * S, (size_t)n_points[b]);
+    if (h->h_prob.p[b].lmeds) {  // the count is taken from the mask; "result = count >= modelPoints" decides whether F is returned
+      int c = 0;
+      for (int i = 0; i < n_points[b]; i++) c += mask[b][i];
+      max_good[b] = c;
+      if (c < 7 && F) memset(h->h_best.p + (size_t)b * 9, 0, 9 * sizeof(double));
+    }
     n_inliers[b] = max_good[b];
     if (F) {
       if (max_good[b] > 0)

@@ -225,7 +225,7 @@ class KltTracker {
   gfs_klt* h_ = nullptr;
 };
 
-// cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, threshold, confidence, status) for 15 or more points (reference call
+// cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, threshold, confidence, status), 8 or more points (reference call
 // sites src/ORBmatcher.cc:236, 2399, 2463; src/Tracking.cc:1974)
 class FundamentalMatcher {
  public:

@@ -464,8 +464,9 @@ int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_k
  * 10. cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, threshold, confidence, mask) — the F check of the optical-flow
  *     matcher (src/ORBmatcher.cc:236, 2399-2405, 2463-2469) and of Tracking::EstimatePoseByOF (src/Tracking.cc:1973-1974):
  *     OpenCV's 7-point RANSAC (cv::RNG((uint64)-1), getSubset / checkSubset, symmetric epipolar distance against threshold^2,
- *     adaptive iteration budget, maxIters 1000) for n >= 15 points.  Below 15 points OpenCV switches FM_RANSAC to LMedS:
- *     GFS_ERR_UNSUPPORTED, the caller keeps its cv:: call for that case.  The null space of the 7-point system and the roots
+ *     adaptive iteration budget, maxIters 1000) for n >= 15 points; for 8 .. 14 points the LMedS registrator the cv:: wrapper
+ *     switches to (least median of the errors, inliers within 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median); `threshold` unused).
+ *     Fewer than 8 points: GFS_ERR_UNSUPPORTED (the reference only calls it with more than 8).  The null space of the 7-point system and the roots
  *     of its cubic are computed with +, -, *, /, sqrt only (oracle/fmat_oracle.cpp): same inlier sets as the oracle
  *     bit for bit; against OpenCV the models agree to rounding noise, the order of the up to three models of a subset can differ.
  * ============================================================================================ */

@@ -4,8 +4,9 @@
 // it: the F check of the optical-flow matcher (src/ORBmatcher.cc:2399-2405, 2463-2469; also :236) and
 // Tracking::EstimatePoseByOF (src/Tracking.cc:1973-1974).  OpenCV (calib3d/src/fundam.cpp, ptsetreg.cpp; 4.5.4 semantics) is NOT in
 // the container; restated from the published sources from memory:
-//   * n >= 15 points -> RANSACPointSetRegistrator(FMEstimatorCallback, modelPoints = 7, threshold, confidence, maxIters = 1000)
-//     (below 15 OpenCV runs LMedS instead: not restated, the entry returns -2),
+//   * n >= 15 points -> RANSACPointSetRegistrator(FMEstimatorCallback, modelPoints = 7, threshold, confidence, maxIters = 1000);
+//     8 .. 14 points -> LMeDSPointSetRegistrator(same callback, 7, confidence): iteration count fixed by a 45 % outlier
+//     assumption, the model with the least MEDIAN error wins, inliers = errors within (2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median))^2,
 //   * cv::RNG rng((uint64)-1): state = (uint32)state * 4164903690 + (state >> 32); uniform(0, n) = next() % n,
 //   * getSubset: 7 draws, a draw is repeated while the index is already in the subset; checkSubset rejects a subset whose last
 //     point is collinear with two earlier ones in either image (haveCollinearPoints); up to 10000 attempts,
@@ -50,8 +51,8 @@ bool have_collinear_points(const float* m, const int* idx, int count) {  // mode
   return false;
 }
 
-bool get_subset(Rng& rng, const float* m1, const float* m2, int count, int* idx) {  // RANSACPointSetRegistrator::getSubset
-  for (int iters = 0; iters < 10000; ++iters) {
+bool get_subset(Rng& rng, const float* m1, const float* m2, int count, int* idx, int max_attempts) {  // ...::getSubset
+  for (int iters = 0; iters < max_attempts; ++iters) {
     for (int i = 0; i < 7; ++i) {
       int v;
       for (;;) {
@@ -285,9 +286,61 @@ int update_num_iters(double p, double ep, int max_iters) {  // RANSACUpdateNumIt
 extern "C" int gfso_fundamental_ransac(const float* pts1, const float* pts2, int n, double threshold, double confidence, int max_iters,
                                        uint8_t* mask, double* F_out, int* iterations_run) {
   using namespace gfs_fmat;
-  if (n < 15) return -2;  // OpenCV: LMedS for fewer than 15 points (not restated)
+  if (n < 8) return -2;  // 7 points: the 7-point solutions themselves; fewer: no result (neither is restated)
   if (threshold <= 0) threshold = 3;
   if (confidence < 2.220446049250313e-16 || confidence > 1 - 2.220446049250313e-16) confidence = 0.99;
+  if (n < 15) {
+    // findFundamentalMat: "(method & ~3) == FM_RANSAC && npoints >= 15" -> RANSAC, else LMeDSPointSetRegistrator(cb, 7, confidence)
+    // ::run — least median of the errors instead of a consensus count, threshold unused
+    Rng rng;
+    int niters = update_num_iters(confidence, 0.45, 1000);
+    if (niters < 3) niters = 3;
+    double min_median = 1.7976931348623157e308;
+    double best[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int iters = 0;
+    for (int iter = 0; iter < niters; iter++) {
+      int idx[7];
+      if (!get_subset(rng, pts1, pts2, n, idx, 1000)) {
+        if (iter == 0) return 0;
+        break;
+      }
+      iters++;
+      double Fm[27];
+      const int nm = seven_point(pts1, pts2, idx, Fm);
+      for (int m = 0; m < nm; m++) {
+        float e[16];
+        for (int i = 0; i < n; i++) e[i] = epipolar_error(Fm + 9 * m, pts1 + 2 * i, pts2 + 2 * i);
+        for (int i = 1; i < n; i++) {  // the (n / 2)-th smallest error: what std::nth_element leaves at position n / 2
+          const float v = e[i];
+          int j = i;
+          for (; j > 0 && e[j - 1] > v; j--) e[j] = e[j - 1];
+          e[j] = v;
+        }
+        const double median = e[n / 2];
+        if (median < min_median) {
+          min_median = median;
+          std::memcpy(best, Fm + 9 * m, sizeof(best));
+        }
+      }
+    }
+    if (iterations_run) *iterations_run = iters;
+    if (!(min_median < 1.7976931348623157e308)) {
+      for (int i = 0; i < n; i++) mask[i] = 0;
+      return 0;
+    }
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * std::sqrt(min_median);
+    if (sigma < 0.001) sigma = 0.001;
+    const float ts = (float)(sigma * sigma);
+    int count = 0;
+    for (int i = 0; i < n; i++) count += mask[i] = epipolar_error(best, pts1 + 2 * i, pts2 + 2 * i) <= ts;
+    if (F_out) {
+      if (count >= 7)
+        std::memcpy(F_out, best, sizeof(best));  // "result = count >= modelPoints": fewer inliers -> an empty matrix is returned
+      else
+        std::memset(F_out, 0, sizeof(best));
+    }
+    return count;
+  }
   Rng rng;
   int niters = max_iters > 1 ? max_iters : 1;
   int max_good = 0, iters = 0;
@@ -295,7 +348,7 @@ extern "C" int gfso_fundamental_ransac(const float* pts1, const float* pts2, int
   const float t2 = (float)(threshold * threshold);  // findInliers compares float errors with a float threshold
   for (int iter = 0; iter < niters; iter++) {
     int idx[7];
-    if (!get_subset(rng, pts1, pts2, n, idx)) {
+    if (!get_subset(rng, pts1, pts2, n, idx, 10000)) {
       if (iter == 0) return 0;
       break;
     }

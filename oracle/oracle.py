@@ -602,7 +602,7 @@ def fb_klt_tracking(prev_pyr, cur_pyr, width, height, win, nbpyrlvl, ferr, fmax_
 
 
 def fundamental_ransac(pts1, pts2, threshold=3.0, confidence=0.99, max_iters=1000):
-    """cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) restatement (oracle/fmat_oracle.cpp), n >= 15.
+    """cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) restatement (oracle/fmat_oracle.cpp): RANSAC for n >= 15, LMedS for 8 <= n < 15 like the cv:: wrapper.
     Returns (mask bool [n], F [3, 3] or None, n_inliers, iterations_run)."""
     p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
     p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
@@ -616,5 +616,5 @@ def fundamental_ransac(pts1, pts2, threshold=3.0, confidence=0.99, max_iters=100
                                           C.POINTER(C.c_int)]
     rc = L.gfso_fundamental_ransac(_p(p1), _p(p2), n, threshold, confidence, max_iters, _p(mask), _p(F), C.byref(it))
     if rc == -2:
-        raise ValueError("fewer than 15 points: OpenCV switches to LMedS (not restated)")
-    return mask[:n].astype(bool), (F.reshape(3, 3).copy() if rc > 0 else None), int(rc), int(it.value)
+        raise ValueError("fewer than 8 points")
+    return mask[:n].astype(bool), (F.reshape(3, 3).copy() if rc > 0 and F.any() else None), int(rc), int(it.value)

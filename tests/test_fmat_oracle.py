@@ -85,7 +85,7 @@ def test_iteration_budget_and_determinism():
 
 def test_degenerate_inputs():
     with pytest.raises(ValueError):
-        O.fundamental_ransac(np.zeros((14, 2)), np.zeros((14, 2)))        # < 15 points: LMedS in OpenCV
+        O.fundamental_ransac(np.zeros((7, 2)), np.zeros((7, 2)))          # fewer than 8 points
     # all points on one line in image 1: every subset is rejected by checkSubset, no model
     x = np.linspace(10, 600, 40, dtype=np.float32)
     line = np.stack([x, x], 1).astype(np.float32)                      # exactly collinear in float arithmetic
@@ -95,3 +95,20 @@ def test_degenerate_inputs():
     # identical images: F is not unique, but every point is an inlier of whatever is found
     mask, F, cnt, _ = O.fundamental_ransac(other, other)
     assert cnt == 40 and mask.all()
+
+
+def test_lmeds_branch_below_15_points():
+    """8 .. 14 points: LMeDSPointSetRegistrator — 300 iterations (45 % outlier assumption at confidence 0.99), the model with the
+    least median error, inliers within sigma of it; the threshold argument plays no role."""
+    for n in (8, 11, 14):
+        p1, p2, _, _ = synth.two_view_points(60 + n, n, 0.1, 0.2)
+        m, F, cnt, it = O.fundamental_ransac(p1, p2, 1.0, 0.99)
+        assert it == 300 and cnt == m.sum() and cnt >= 7 and F is not None
+        m2, F2, cnt2, _ = O.fundamental_ransac(p1, p2, 25.0, 0.99)
+        assert np.array_equal(m, m2) and np.array_equal(F, F2)
+        err = _sym_epi_err(F, p1, p2)
+        med = np.sort(err.astype(np.float32))[n // 2]
+        sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * np.sqrt(float(med)), 0.001)
+        edge = np.abs(err - sigma ** 2) < 1e-9 + 1e-6 * sigma ** 2
+        assert np.array_equal(m[~edge], (err <= sigma ** 2)[~edge])
+    assert O.fundamental_ransac(p1, p2, 1.0, 0.5)[3] < 300        # lower confidence -> fewer iterations (at least 3)

@@ -66,7 +66,7 @@ def test_degenerate_and_unsupported(gpu_api, oracle):
     assert fm.findFundamentalMat(line, other)[1] is None
     _check(fm.findFundamentalMat(other, other), oracle.fundamental_ransac(other, other))
     with pytest.raises(gpu_api.GfsError):
-        fm.findFundamentalMat(other[:14], other[:14])       # OpenCV: LMedS below 15 points
+        fm.findFundamentalMat(other[:7], other[:7])         # fewer than 8 points
     with pytest.raises(gpu_api.GfsError):
         fm.findFundamentalMat(np.zeros((300, 2), np.float32), np.zeros((300, 2), np.float32))   # capacity
 
@@ -80,3 +80,16 @@ def test_rejected_subsets_follow_the_generator(gpu_api, oracle):
     fm = gpu_api.FundamentalMatcher(max_points=256)
     for thr, it in ((3.0, 1000), (0.7, 1000), (3.0, 5)):
         _check(fm.findFundamentalMat(p1, p2, thr, 0.99, it), oracle.fundamental_ransac(p1, p2, thr, 0.99, it))
+
+
+def test_lmeds_branch_and_mixed_batches(gpu_api, oracle):
+    """8 .. 14 points take OpenCV's LMedS path; a batch may mix both kinds of problem."""
+    sizes = [8, 9, 14, 300, 12, 15, 11, 64]
+    probs = [synth.two_view_points(70 + i, n, 0.15, 0.25) for i, n in enumerate(sizes)]
+    fm = gpu_api.FundamentalMatcher(max_points=512, max_batch=len(sizes))
+    for conf in (0.99, 0.6):
+        G = fm.findFundamentalMat([p[0] for p in probs], [p[1] for p in probs], 1.5, conf)
+        for b in range(len(sizes)):
+            _check(G[b], oracle.fundamental_ransac(probs[b][0], probs[b][1], 1.5, conf))
+    one = gpu_api.FundamentalMatcher(max_points=64)
+    _check(one.findFundamentalMat(probs[2][0], probs[2][1]), oracle.fundamental_ransac(probs[2][0], probs[2][1]))
