@@ -328,94 +328,100 @@ def main():
     # ---- the optical-flow stream next to the path: reported beside the metric, never part of `value`
     klt = None
     if rank == 0 and world == 1 and not args.no_klt:
-        WIN = 35
-        cap = lanes[0].cap
-        trk = api.KltTracker(W, H, WIN, max_level=3, max_batch=B, max_points=cap, device=local_rank)
-        pyr_prev, pyr_cur = api.KltPyramid(trk), api.KltPyramid(trk)
-        kp_all = torch.cat([ln.prev_kps.view(torch.float32).view(ln.n, cap, 7)[:, :, :2] for ln in lanes]).contiguous()
-        cnt_all = torch.cat([ln.prev_cnt for ln in lanes]).contiguous()
-        pri = kp_all.clone()
-        st = torch.zeros(B * cap, dtype=torch.uint8, device=dev)
-        good = torch.zeros(B, dtype=torch.int32, device=dev)
-        trk.build_pyramid_device(gray0.data_ptr(), W, B, pyr_prev)
+        try:
+            WIN = 35
+            cap = lanes[0].cap
+            trk = api.KltTracker(W, H, WIN, max_level=3, max_batch=B, max_points=cap, device=local_rank)
+            pyr_prev, pyr_cur = api.KltPyramid(trk), api.KltPyramid(trk)
+            kp_all = torch.cat([ln.prev_kps.view(torch.float32).view(ln.n, cap, 7)[:, :, :2] for ln in lanes]).contiguous()
+            cnt_all = torch.cat([ln.prev_cnt for ln in lanes]).contiguous()
+            pri = kp_all.clone()
+            st = torch.zeros(B * cap, dtype=torch.uint8, device=dev)
+            good = torch.zeros(B, dtype=torch.int32, device=dev)
+            trk.build_pyramid_device(gray0.data_ptr(), W, B, pyr_prev)
 
-        def klt_step():  # per new frame: its pyramid (the previous frame's is kept) + forward/backward tracking of the key points
-            trk.build_pyramid_device(gray1.data_ptr(), W, B, pyr_cur)
-            pri.copy_(kp_all)
+            def klt_step():  # per new frame: its pyramid (the previous frame's is kept) + forward/backward tracking of the key points
+                trk.build_pyramid_device(gray1.data_ptr(), W, B, pyr_cur)
+                pri.copy_(kp_all)
+                torch.cuda.synchronize()
+                trk.fb_track_device(pyr_prev, pyr_cur, B, cap, cnt_all.data_ptr(), kp_all.data_ptr(), pri.data_ptr(), st.data_ptr(),
+                                    good.data_ptr(), 3, 15.0, 0.5)
+
+            for _ in range(2):
+                klt_step()
             torch.cuda.synchronize()
-            trk.fb_track_device(pyr_prev, pyr_cur, B, cap, cnt_all.data_ptr(), kp_all.data_ptr(), pri.data_ptr(), st.data_ptr(),
-                                good.data_ptr(), 3, 15.0, 0.5)
-
-        for _ in range(2):
-            klt_step()
-        torch.cuda.synchronize()
-        nk = 10
-        t1 = time.perf_counter()
-        for _ in range(nk):
-            klt_step()
-        torch.cuda.synchronize()
-        dtk = (time.perf_counter() - t1) / nk
-        api.profile_reset()
-        api.profile_enable(True)
-        for _ in range(3):
-            klt_step()
-        torch.cuda.synchronize()
-        krep = api.profile_report()
-        api.profile_enable(False)
-        npts_k, ngood_k = int(cnt_all.sum().item()), int(good.sum().item())
-        klt = dict(metric="optical-flow frame pairs/s (buildOpticalFlowPyramid + fbKltTracking, window 35, 4 levels)",
-                   value=round(B / dtk, 1), unit="pairs/s", ms_per_batch=round(dtk * 1e3, 3), batch_pairs=B,
-                   points_per_pair=round(npts_k / B, 1), tracked_frac=round(ngood_k / max(npts_k, 1), 3),
-                   kernels_ms_per_batch={k: round(v[0] / 3, 4) for k, v in sorted(krep.items(), key=lambda kv: -kv[1][0]) if "klt" in k})
-        if not args.no_cpu_baseline:
-            from oracle import oracle as O
-            kp_h = kp_all[:4].cpu().numpy()
-            cn_h = cnt_all[:4].cpu().numpy()
+            nk = 10
             t1 = time.perf_counter()
-            o_prev = [O.klt_build_pyramid(pairs[sel[b]]["gray0"], WIN) for b in range(4)]
-            for b in range(4):
-                o_cur = O.klt_build_pyramid(pairs[sel[b]]["gray1"], WIN)
-                O.fb_klt_tracking(o_prev[b], o_cur, W, H, WIN, 3, 15.0, 0.5, kp_h[b, :cn_h[b]], kp_h[b, :cn_h[b]].copy())
-            klt["cpu_oracle"] = dict(value=round(4 / (time.perf_counter() - t1), 3), unit="pairs/s", cores=1,
-                                     sample="4 VGA pairs, single-threaded oracle (5 pyramids + 4 forward/backward passes)")
+            for _ in range(nk):
+                klt_step()
+            torch.cuda.synchronize()
+            dtk = (time.perf_counter() - t1) / nk
+            api.profile_reset()
+            api.profile_enable(True)
+            for _ in range(3):
+                klt_step()
+            torch.cuda.synchronize()
+            krep = api.profile_report()
+            api.profile_enable(False)
+            npts_k, ngood_k = int(cnt_all.sum().item()), int(good.sum().item())
+            klt = dict(metric="optical-flow frame pairs/s (buildOpticalFlowPyramid + fbKltTracking, window 35, 4 levels)",
+                       value=round(B / dtk, 1), unit="pairs/s", ms_per_batch=round(dtk * 1e3, 3), batch_pairs=B,
+                       points_per_pair=round(npts_k / B, 1), tracked_frac=round(ngood_k / max(npts_k, 1), 3),
+                       kernels_ms_per_batch={k: round(v[0] / 3, 4) for k, v in sorted(krep.items(), key=lambda kv: -kv[1][0]) if "klt" in k})
+            if not args.no_cpu_baseline:
+                from oracle import oracle as O
+                kp_h = kp_all[:4].cpu().numpy()
+                cn_h = cnt_all[:4].cpu().numpy()
+                t1 = time.perf_counter()
+                o_prev = [O.klt_build_pyramid(pairs[sel[b]]["gray0"], WIN) for b in range(4)]
+                for b in range(4):
+                    o_cur = O.klt_build_pyramid(pairs[sel[b]]["gray1"], WIN)
+                    O.fb_klt_tracking(o_prev[b], o_cur, W, H, WIN, 3, 15.0, 0.5, kp_h[b, :cn_h[b]], kp_h[b, :cn_h[b]].copy())
+                klt["cpu_oracle"] = dict(value=round(4 / (time.perf_counter() - t1), 3), unit="pairs/s", cores=1,
+                                         sample="4 VGA pairs, single-threaded oracle (5 pyramids + 4 forward/backward passes)")
+        except Exception as e:  # a side figure must never cost the headline line
+            klt = dict(error=f"{type(e).__name__}: {e}")
 
     # ---- the other SURVEY.md 8(d) figures, beside the metric (rank 0, N = 1): ORB only (configs[0]) and LBA windows (configs[4])
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
-        ln0 = lanes[0]
-        for _ in range(2):
-            ln0.ext.extract_batch_device(ln0.g1.data_ptr(), ln0.n, H, W, (0, 0), ln0.s1.cuda_stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            ln0.ext.extract_batch_device(ln0.g1.data_ptr(), ln0.n, H, W, (0, 0), ln0.s1.cuda_stream)
-        torch.cuda.synchronize()
-        dto = (time.perf_counter() - t1) / 10
-        extras["orb_only"] = dict(metric="ORB extraction frames/s (640x480, 1000 features, 8 levels; BASELINE.json configs[0] workload)",
-                                  value=round(ln0.n / dto, 1), unit="frames/s", ms_per_batch=round(dto * 1e3, 3), batch_frames=ln0.n)
-        w5 = synth.lba_window(0, n_free=20, n_fixed=5, n_points=3000)
-        opt = api.Optimizer(max_poses=32, max_points=4096, max_edges=65536, device=local_rank)
-        r5 = opt.LocalBundleAdjustment(w5)
-        t1 = time.perf_counter()
-        for _ in range(5):
+        try:
+            ln0 = lanes[0]
+            for _ in range(2):
+                ln0.ext.extract_batch_device(ln0.g1.data_ptr(), ln0.n, H, W, (0, 0), ln0.s1.cuda_stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                ln0.ext.extract_batch_device(ln0.g1.data_ptr(), ln0.n, H, W, (0, 0), ln0.s1.cuda_stream)
+            torch.cuda.synchronize()
+            dto = (time.perf_counter() - t1) / 10
+            extras["orb_only"] = dict(metric="ORB extraction frames/s (640x480, 1000 features, 8 levels; BASELINE.json configs[0] workload)",
+                                      value=round(ln0.n / dto, 1), unit="frames/s", ms_per_batch=round(dto * 1e3, 3), batch_frames=ln0.n)
+            w5 = synth.lba_window(0, n_free=20, n_fixed=5, n_points=3000)
+            opt = api.Optimizer(max_poses=32, max_points=4096, max_edges=65536, device=local_rank)
             r5 = opt.LocalBundleAdjustment(w5)
-        dtl = (time.perf_counter() - t1) / 5
-        extras["lba"] = dict(metric="LocalBundleAdjustment windows/s (20 free + 5 fixed key-frames x 3000 points; BASELINE.json configs[4])",
-                             value=round(1.0 / dtl, 1), unit="windows/s", ms_per_window=round(dtl * 1e3, 3), edges=int(w5["n_edges"]),
-                             lm_iterations=int(r5["iterations_run"]))
-        if not args.no_cpu_baseline:
-            from oracle import oracle as O
-            orb1 = O.OrbOracle(NF, 1.2, NL, 20, 7)
-            orb1.set_threads(8)
             t1 = time.perf_counter()
-            for i in range(8):
-                orb1.extract(pairs[i % nd]["gray1"])
-            extras["orb_only"]["cpu_oracle"] = dict(value=round(8 / (time.perf_counter() - t1), 2), unit="frames/s", cores=8,
-                                                    sample="8 VGA frames, OpenMP over the 8 levels as in the reference")
-            t1 = time.perf_counter()
-            O.lba_solve(w5)
-            extras["lba"]["cpu_oracle"] = dict(value=round(1.0 / (time.perf_counter() - t1), 2), unit="windows/s", cores=1,
-                                               sample="the same window once, single-threaded oracle")
+            for _ in range(5):
+                r5 = opt.LocalBundleAdjustment(w5)
+            dtl = (time.perf_counter() - t1) / 5
+            extras["lba"] = dict(metric="LocalBundleAdjustment windows/s (20 free + 5 fixed key-frames x 3000 points; BASELINE.json configs[4])",
+                                 value=round(1.0 / dtl, 1), unit="windows/s", ms_per_window=round(dtl * 1e3, 3), edges=int(w5["n_edges"]),
+                                 lm_iterations=int(r5["iterations_run"]))
+            if not args.no_cpu_baseline:
+                from oracle import oracle as O
+                orb1 = O.OrbOracle(NF, 1.2, NL, 20, 7)
+                orb1.set_threads(8)
+                t1 = time.perf_counter()
+                for i in range(8):
+                    orb1.extract(pairs[i % nd]["gray1"])
+                extras["orb_only"]["cpu_oracle"] = dict(value=round(8 / (time.perf_counter() - t1), 2), unit="frames/s", cores=8,
+                                                        sample="8 VGA frames, OpenMP over the 8 levels as in the reference")
+                t1 = time.perf_counter()
+                O.lba_solve(w5)
+                extras["lba"]["cpu_oracle"] = dict(value=round(1.0 / (time.perf_counter() - t1), 2), unit="windows/s", cores=1,
+                                                   sample="the same window once, single-threaded oracle")
+        except Exception as e:
+            extras["side_figures_error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         g = gicp_results()
