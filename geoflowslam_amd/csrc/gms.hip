@@ -2,7 +2,8 @@
 // Thirdparty/GMS/include/gms_matcher.h:43-60, 289-301, 356-455) on MI355X — the grid-based motion-statistics filter the
 // reference runs right after every cv::BFMatcher::match of the hot path (src/ORBmatcher.cc:761-762, 812-813, 893-894).
 //
-// One 256-thread workgroup per frame pair.  The reference builds a dense 400 x 400 vote matrix per shifted grid; with
+// One 256-thread workgroup per (frame pair, shifted grid): the four grids vote independently, k_gms_merge ORs their verdicts and
+// counts the inliers.  The reference builds a dense 400 x 400 vote matrix per shifted grid; with
 // ~1000 matches it is almost empty, so the votes are kept as a CSR list of right-cell indices per left cell in LDS:
 // a left cell's best partner (first maximum over ascending right index) and its 3 x 3 neighbourhood score are counted
 // from those lists.  Integer work, bit-exact; the float / double grid arithmetic follows the header's expressions.
@@ -50,15 +51,13 @@ __device__ __forceinline__ int gms_nb(int idx, int j) {  // GetNB9 :190-211, ent
 __global__ __launch_bounds__(kGmsThreads) void k_gms(const GmsPair* __restrict__ pairs, GmsPair common, const gfs_keypoint* __restrict__ kp1_all,
                                                      const gfs_keypoint* __restrict__ kp2_all, const int* __restrict__ n1_dev,
                                                      const int* __restrict__ n2_dev, int kp_stride, const int* __restrict__ q_all,
-                                                     const int* __restrict__ t_all, int m_stride, uint8_t* __restrict__ mask_all,
-                                                     int* __restrict__ counts) {
+                                                     const int* __restrict__ t_all, int m_stride, uint8_t* __restrict__ vote_all) {
   __shared__ short s_l[kGmsMaxMatches], s_r[kGmsMaxMatches];
   __shared__ unsigned short s_items[kGmsMaxMatches];  // right-cell index of the valid votes, grouped by left cell
   __shared__ int s_cnt[kGmsCells], s_start[kGmsCells + 1], s_cur[kGmsCells];
   __shared__ int s_pair[kGmsCells];
-  __shared__ int s_scan[kGmsThreads];
-  __shared__ int s_total;
-  const int f = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_scan[kGmsThreads / 64];
+  const int f = blockIdx.y, type = blockIdx.x + 1, tid = threadIdx.x;  // one workgroup per (frame pair, shifted grid)
   GmsPair P = pairs ? pairs[f] : common;
   if (n1_dev) {  // device-resident batch: counts come from the extractor's device results
     P.n1 = n1_dev[f];
@@ -69,11 +68,9 @@ __global__ __launch_bounds__(kGmsThreads) void k_gms(const GmsPair* __restrict__
   const gfs_keypoint* kp2 = kp2_all + (size_t)f * kp_stride;
   const int* qi = q_all ? q_all + (size_t)f * m_stride : nullptr;
   const int* ti = t_all + (size_t)f * m_stride;
-  uint8_t* mask = mask_all + (size_t)f * m_stride;
+  uint8_t* vote = vote_all + ((size_t)f * 4 + (type - 1)) * m_stride;  // this grid's verdict on every match; k_gms_merge ORs the four
   const int M = P.n_matches;
-  for (int i = tid; i < M; i += kGmsThreads) mask[i] = 0;
-  if (tid == 0) s_total = 0;
-  for (int type = 1; type <= 4; type++) {
+  {
     for (int c = tid; c < kGmsCells; c += kGmsThreads) {
       s_cnt[c] = 0;
       s_pair[c] = -1;
@@ -87,30 +84,32 @@ __global__ __launch_bounds__(kGmsThreads) void k_gms(const GmsPair* __restrict__
       const int l = gms_left_index(lx, ly, type);
       s_l[i] = (short)l;
       int r;
-      if (type == 1) {
+      {  // the right grid is not shifted: the same index for all four types (the reference computes it once, for type 1)
         const gfs_keypoint b = kp2[ti[i]];
         const float rx = b.x / P.w2, ry = b.y / P.h2;
         r = (int)floorf(rx * kGmsW) + (int)floorf(ry * kGmsH) * kGmsW;  // GetGridIndexRight :178-183 (no range check)
         r = max(min(r, 32767), -32768);
         s_r[i] = (short)r;
-      } else {
-        r = s_r[i];
       }
       if (l >= 0 && r >= 0 && r < kGmsCells) atomicAdd(&s_cnt[l], 1);
     }
     __syncthreads();
     {  // exclusive scan of the 400 cell counts
-      const int c0 = 2 * tid, c1 = 2 * tid + 1;
+      const int c0 = 2 * tid, c1 = 2 * tid + 1, lane = tid & 63, wave = tid >> 6;
       const int a = c0 < kGmsCells ? s_cnt[c0] : 0, b = c1 < kGmsCells ? s_cnt[c1] : 0;
-      s_scan[tid] = a + b;
-      __syncthreads();
-      for (int ofs = 1; ofs < kGmsThreads; ofs <<= 1) {
-        const int v = tid >= ofs ? s_scan[tid - ofs] : 0;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
+      int incl = a + b;  // wave scan + four wave totals: two barriers instead of sixteen
+      for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const int v = __shfl_up(incl, ofs, 64);
+        if (lane >= ofs) incl += v;
       }
-      const int base = s_scan[tid] - (a + b);
+      if (lane == 63) s_scan[wave] = incl;
+      __syncthreads();
+      int wbase = 0, total = 0;
+      for (int w = 0; w < kGmsThreads / 64; w++) {
+        if (w < wave) wbase += s_scan[w];
+        total += s_scan[w];
+      }
+      const int base = wbase + incl - (a + b);
       if (c0 < kGmsCells) {
         s_start[c0] = base;
         s_cur[c0] = base;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(kGmsThreads) void k_gms(const GmsPair* __restrict__
         s_start[c1] = base + a;
         s_cur[c1] = base + a;
       }
-      if (tid == kGmsThreads - 1) s_start[kGmsCells] = s_scan[tid];
+      if (tid == kGmsThreads - 1) s_start[kGmsCells] = total;
     }
     __syncthreads();
     for (int i = tid; i < M; i += kGmsThreads) {
@@ -157,12 +156,30 @@ __global__ __launch_bounds__(kGmsThreads) void k_gms(const GmsPair* __restrict__
     for (int i = tid; i < M; i += kGmsThreads) {
       const int l = s_l[i];
       // (the reference reads mCellPairs[-1], out of bounds, for l == -1: never equal to a right index)
-      if (l >= 0 && s_pair[l] == (int)s_r[i]) mask[i] = 1;
+      vote[i] = l >= 0 && s_pair[l] == (int)s_r[i] ? 1 : 0;
     }
-    __syncthreads();
   }
+}
+
+// mvbInlierMask |= over the four shifted grids (gms_matcher::run :440-452) and the inlier count
+__global__ __launch_bounds__(kGmsThreads) void k_gms_merge(const GmsPair* __restrict__ pairs, GmsPair common, const int* __restrict__ n1_dev,
+                                                           const int* __restrict__ n2_dev, int m_stride,
+                                                           const uint8_t* __restrict__ vote_all, uint8_t* __restrict__ mask_all,
+                                                           int* __restrict__ counts) {
+  __shared__ int s_total;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  GmsPair P = pairs ? pairs[f] : common;
+  if (n1_dev) P.n_matches = n2_dev[f] > 0 ? min(n1_dev[f], kGmsMaxMatches) : 0;
+  const uint8_t* v = vote_all + (size_t)f * 4 * m_stride;
+  uint8_t* mask = mask_all + (size_t)f * m_stride;
+  if (tid == 0) s_total = 0;
+  __syncthreads();
   int local = 0;
-  for (int i = tid; i < M; i += kGmsThreads) local += mask[i];
+  for (int i = tid; i < P.n_matches; i += kGmsThreads) {
+    const uint8_t m = v[i] | v[m_stride + i] | v[2 * m_stride + i] | v[3 * m_stride + i];
+    mask[i] = m;
+    local += m;
+  }
   if (local) atomicAdd(&s_total, local);
   __syncthreads();
   if (tid == 0) counts[f] = s_total;
@@ -177,7 +194,7 @@ struct gfs_gms {
   gfs::DevBuf<GmsPair> d_pairs;
   gfs::DevBuf<gfs_keypoint> d_kp1, d_kp2;
   gfs::DevBuf<int> d_q, d_t, d_counts;
-  gfs::DevBuf<uint8_t> d_mask;
+  gfs::DevBuf<uint8_t> d_mask, d_vote;
   gfs::PinBuf<GmsPair> h_pairs;
   gfs::PinBuf<gfs_keypoint> h_kp1, h_kp2;
   gfs::PinBuf<int> h_q, h_t, h_counts;
@@ -205,6 +222,7 @@ int gfs_gms_create(int device, int max_keypoints, int max_batch, gfs_gms** out) 
   A(h->d_q.alloc(K));
   A(h->d_t.alloc(K));
   A(h->d_mask.alloc(K));
+  A(h->d_vote.alloc(4 * K));
   A(h->d_counts.alloc(B));
   A(h->h_pairs.alloc(B));
   A(h->h_kp1.alloc(K));
@@ -262,8 +280,10 @@ int gfs_gms_inlier_mask(gfs_gms* h, const gfs_gms_problem* problems, int B, uint
   GFS_HIP(hipMemcpyAsync(h->d_kp2.p, h->h_kp2.p, K * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_q.p, h->h_q.p, K * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_t.p, h->h_t.p, K * 4, hipMemcpyHostToDevice, s));
-  GFS_LAUNCH("k_gms", k_gms, dim3(B), dim3(kGmsThreads), 0, s, h->d_pairs.p, GmsPair{}, h->d_kp1.p, h->d_kp2.p, (const int*)nullptr,
-             (const int*)nullptr, S, h->d_q.p, h->d_t.p, S, h->d_mask.p, h->d_counts.p);
+  GFS_LAUNCH("k_gms", k_gms, dim3(4, B), dim3(kGmsThreads), 0, s, h->d_pairs.p, GmsPair{}, h->d_kp1.p, h->d_kp2.p, (const int*)nullptr,
+             (const int*)nullptr, S, h->d_q.p, h->d_t.p, S, h->d_vote.p);
+  GFS_LAUNCH("k_gms_merge", k_gms_merge, dim3(B), dim3(kGmsThreads), 0, s, h->d_pairs.p, GmsPair{}, (const int*)nullptr,
+             (const int*)nullptr, S, (const uint8_t*)h->d_vote.p, h->d_mask.p, h->d_counts.p);
   GFS_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, K, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_counts.p, h->d_counts.p, B * 4, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
@@ -279,16 +299,18 @@ int gfs_gms_inlier_mask_batch_device(gfs_gms* h, const void* dev_kps1, const voi
                                      void* dev_counts, void* stream) {
   GFS_REQUIRE(h && dev_kps1 && dev_n1 && dev_kps2 && dev_n2 && dev_train_idx && dev_mask && dev_counts && B > 0, GFS_ERR_INVALID_ARG,
               "gfs_gms_inlier_mask_batch_device: invalid argument");
-  GFS_REQUIRE(B <= h->max_batch && kp_stride <= kGmsMaxMatches && kp_stride > 0, GFS_ERR_CAPACITY,
-              "gfs_gms_inlier_mask_batch_device: batch %d / stride %d exceed the capacity (%d / %d)", B, kp_stride, h->max_batch, kGmsMaxMatches);
+  GFS_REQUIRE(B <= h->max_batch && kp_stride <= h->max_kps && kp_stride > 0, GFS_ERR_CAPACITY,
+              "gfs_gms_inlier_mask_batch_device: batch %d / stride %d exceed the capacity (%d / %d)", B, kp_stride, h->max_batch, h->max_kps);
   GFS_REQUIRE(width > 0 && height > 0, GFS_ERR_INVALID_ARG, "gfs_gms_inlier_mask_batch_device: empty frame size");
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-  GFS_LAUNCH("k_gms", k_gms, dim3(B), dim3(kGmsThreads), 0, s, (const GmsPair*)nullptr, GmsPair{0, 0, 0, width, height, width, height, 1},
-             (const gfs_keypoint*)dev_kps1, (const gfs_keypoint*)dev_kps2,
-             (const int*)dev_n1, (const int*)dev_n2, kp_stride, (const int*)nullptr, (const int*)dev_train_idx, kp_stride,
-             (uint8_t*)dev_mask, (int*)dev_counts);
+  const GmsPair common{0, 0, 0, width, height, width, height, 1};
+  GFS_LAUNCH("k_gms", k_gms, dim3(4, B), dim3(kGmsThreads), 0, s, (const GmsPair*)nullptr, common, (const gfs_keypoint*)dev_kps1,
+             (const gfs_keypoint*)dev_kps2, (const int*)dev_n1, (const int*)dev_n2, kp_stride, (const int*)nullptr,
+             (const int*)dev_train_idx, kp_stride, h->d_vote.p);
+  GFS_LAUNCH("k_gms_merge", k_gms_merge, dim3(B), dim3(kGmsThreads), 0, s, (const GmsPair*)nullptr, common, (const int*)dev_n1,
+             (const int*)dev_n2, kp_stride, (const uint8_t*)h->d_vote.p, (uint8_t*)dev_mask, (int*)dev_counts);
   if (!stream) GFS_HIP(hipStreamSynchronize(s));
   return GFS_OK;
 }
