@@ -370,10 +370,35 @@ def main():
             krep = api.profile_report()
             api.profile_enable(False)
             npts_k, ngood_k = int(cnt_all.sum().item()), int(good.sum().item())
+            # ... followed by the F check of the tracks (cv::findFundamentalMat FM_RANSAC) and the status update, all device-resident
+            fmt = api.FundamentalMatcher(max_points=cap, max_batch=B, device=local_rank)
+            t_a, t_b = torch.zeros_like(kp_all), torch.zeros_like(kp_all)
+            t_idx = torch.zeros(B * cap, dtype=torch.int32, device=dev)
+            t_m = torch.zeros(B, dtype=torch.int32, device=dev)
+            t_mask = torch.zeros(B * cap, dtype=torch.uint8, device=dev)
+
+            def chain_step():
+                klt_step()
+                trk.compact_tracks_device(B, cap, cnt_all.data_ptr(), kp_all.data_ptr(), pri.data_ptr(), st.data_ptr(), t_a.data_ptr(),
+                                          t_b.data_ptr(), t_idx.data_ptr(), t_m.data_ptr())
+                _, cnt_f = fmt.find_device(B, cap, t_m.data_ptr(), t_a.data_ptr(), t_b.data_ptr(), t_mask.data_ptr(), 1.0, 0.99)
+                trk.apply_mask_device(B, cap, t_m.data_ptr(), t_idx.data_ptr(), t_mask.data_ptr(), st.data_ptr())
+                return cnt_f
+
+            chain_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                cnt_f = chain_step()
+            torch.cuda.synchronize()
+            dtc = (time.perf_counter() - t1) / 5
             klt = dict(metric="optical-flow frame pairs/s (buildOpticalFlowPyramid + fbKltTracking, window 35, 4 levels)",
                        value=round(B / dtk, 1), unit="pairs/s", ms_per_batch=round(dtk * 1e3, 3), batch_pairs=B,
                        points_per_pair=round(npts_k / B, 1), tracked_frac=round(ngood_k / max(npts_k, 1), 3),
                        kernels_ms_per_batch={k: round(v[0] / 3, 4) for k, v in sorted(krep.items(), key=lambda kv: -kv[1][0]) if "klt" in k})
+            klt["with_f_check"] = dict(value=round(B / dtc, 1), unit="pairs/s", ms_per_batch=round(dtc * 1e3, 3),
+                                       f_inlier_frac=round(float(cnt_f.sum()) / max(ngood_k, 1), 3),
+                                       note="+ compaction of the tracks, findFundamentalMat(FM_RANSAC, 1 px, 0.99), status update")
             if not args.no_cpu_baseline:
                 from oracle import oracle as O
                 kp_h = kp_all[:4].cpu().numpy()

@@ -194,7 +194,8 @@ ABI_SYMBOLS = [
     "gfs_klt_create", "gfs_klt_destroy", "gfs_klt_layout", "gfs_klt_pyramid_create", "gfs_klt_pyramid_destroy",
     "gfs_klt_build_pyramid", "gfs_klt_build_pyramid_device", "gfs_klt_pyramid_download", "gfs_klt_track", "gfs_klt_fb_track",
     "gfs_klt_fb_track_device",
-    "gfs_fmat_create", "gfs_fmat_destroy", "gfs_find_fundamental_ransac",
+    "gfs_fmat_create", "gfs_fmat_destroy", "gfs_find_fundamental_ransac", "gfs_find_fundamental_ransac_device",
+    "gfs_klt_compact_tracks_device", "gfs_klt_apply_mask_device",
     "gfs_timer_create", "gfs_timer_destroy", "gfs_timer_start", "gfs_timer_stop", "gfs_timer_elapsed_ms",
     "gfs_profile_enable", "gfs_profile_report", "gfs_profile_reset",
 ]
@@ -265,10 +266,13 @@ def lib():
             L.gfs_klt_track.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, i, d, i, d]
             L.gfs_klt_fb_track.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, f]
             L.gfs_klt_fb_track_device.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, vp, i, f, f, vp]
+            L.gfs_klt_compact_tracks_device.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+            L.gfs_klt_apply_mask_device.argtypes = [vp, i, i, vp, vp, vp, vp, vp]
         if hasattr(L, "gfs_fmat_create"):
             L.gfs_fmat_create.argtypes = [i, i, i, C.POINTER(vp)]
             L.gfs_fmat_destroy.argtypes = [vp]
             L.gfs_find_fundamental_ransac.argtypes = [vp, i, vp, vp, vp, C.c_double, C.c_double, i, vp, vp, vp]
+            L.gfs_find_fundamental_ransac_device.argtypes = [vp, i, i, vp, vp, vp, C.c_double, C.c_double, i, vp, vp, vp]
         L.gfs_timer_create.argtypes = [i, C.POINTER(vp)]
         L.gfs_timer_destroy.argtypes = [vp]
         L.gfs_timer_start.argtypes = [vp, vp]
@@ -795,6 +799,17 @@ class KltTracker:
         out = [(Pr[b][:n[b]].copy(), S[b][:n[b]].astype(bool), int(good[b])) for b in range(B)]
         return out[0] if single else out
 
+    def compact_tracks_device(self, B, pt_stride, d_n, d_kps, d_priors, d_kpstatus, d_a, d_b, d_index, d_m, stream=None):
+        _check(lib().gfs_klt_compact_tracks_device(self.h, B, pt_stride, C.c_void_p(d_n), C.c_void_p(d_kps), C.c_void_p(d_priors),
+                                                   C.c_void_p(d_kpstatus), C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_index),
+                                                   C.c_void_p(d_m), C.c_void_p(stream) if stream else None),
+               "gfs_klt_compact_tracks_device")
+
+    def apply_mask_device(self, B, pt_stride, d_m, d_index, d_mask, d_kpstatus, stream=None):
+        _check(lib().gfs_klt_apply_mask_device(self.h, B, pt_stride, C.c_void_p(d_m), C.c_void_p(d_index), C.c_void_p(d_mask),
+                                               C.c_void_p(d_kpstatus), C.c_void_p(stream) if stream else None),
+               "gfs_klt_apply_mask_device")
+
     def fb_track_device(self, prev, cur, B, pt_stride, d_n, d_kps, d_priors, d_kpstatus, d_n_good, nbpyrlvl=3, ferr=15.0,
                         fmax_fbklt_dist=0.5, stream=None):
         _check(lib().gfs_klt_fb_track_device(self.h, prev.h, cur.h, B, pt_stride, C.c_void_p(d_n), C.c_void_p(d_kps),
@@ -832,6 +847,15 @@ class FundamentalMatcher:
                                                  arr(M), _p(F), _p(cnt)), "gfs_find_fundamental_ransac")
         out = [(M[b][:n[b]].astype(bool), F[b].reshape(3, 3).copy() if cnt[b] > 0 and F[b].any() else None, int(cnt[b])) for b in range(B)]
         return out[0] if single else out
+
+    def find_device(self, B, stride, d_n, d_pts1, d_pts2, d_mask, threshold=3.0, confidence=0.99, max_iters=1000):
+        """Device-resident batch -> (F [B, 3, 3], n_inliers [B]); the masks are written to d_mask [B][stride]."""
+        F = np.zeros((B, 9))
+        cnt = np.zeros(B, np.int32)
+        _check(lib().gfs_find_fundamental_ransac_device(self.h, B, stride, C.c_void_p(d_n), C.c_void_p(d_pts1), C.c_void_p(d_pts2),
+                                                        float(threshold), float(confidence), max_iters, C.c_void_p(d_mask), _p(F),
+                                                        _p(cnt)), "gfs_find_fundamental_ransac_device")
+        return F.reshape(B, 3, 3), cnt
 
 
 class ProjectionMatcher:

@@ -411,20 +411,27 @@ __global__ void k_fmat_keep(const int* __restrict__ keep, const double* __restri
   for (int i = 0; i < 9; i++) best[(size_t)b * 9 + i] = models[(size_t)b * kFmChunk * 27 + (size_t)keep[b] * 9 + i];
 }
 
-// mask[i] = inlier of the chosen model; sel [B] = iteration * 3 + model inside the last chunk of that problem, or -1 (no model)
+// mask[i] = inlier of the chosen model; sel [B] >= 0: a model exists, -1: none (mask 0), -2: problem passed through (mask 1);
+// count [B] (zeroed by the caller) receives the number of ones
 __global__ void __launch_bounds__(kFmThreads) k_fmat_mask(const FmProblem* __restrict__ prob, const int* __restrict__ sel,
                                                          const double* __restrict__ best, const float2* __restrict__ pts1,
-                                                         const float2* __restrict__ pts2, int stride, uint8_t* __restrict__ mask) {
+                                                         const float2* __restrict__ pts2, int stride, uint8_t* __restrict__ mask,
+                                                         int* __restrict__ count) {
   const int b = blockIdx.y, i = blockIdx.x * kFmThreads + threadIdx.x;
   const FmProblem P = prob[b];
-  if (i >= P.n) return;
   uint8_t v = 0;
-  if (sel[b] >= 0) {
-    double F[9];
-    for (int k = 0; k < 9; k++) F[k] = best[(size_t)b * 9 + k];
-    v = epipolar_error(F, pts1[(size_t)b * stride + i], pts2[(size_t)b * stride + i]) <= P.t2 ? 1 : 0;
+  if (i < P.n) {
+    if (sel[b] >= 0) {
+      double F[9];
+      for (int k = 0; k < 9; k++) F[k] = best[(size_t)b * 9 + k];
+      v = epipolar_error(F, pts1[(size_t)b * stride + i], pts2[(size_t)b * stride + i]) <= P.t2 ? 1 : 0;
+    } else if (sel[b] == -2) {
+      v = 1;
+    }
+    mask[(size_t)b * stride + i] = v;
   }
-  mask[(size_t)b * stride + i] = v;
+  const unsigned long long ball = __ballot(v != 0);
+  if ((threadIdx.x & 63) == 0 && ball) atomicAdd(count + b, __popcll(ball));
 }
 
 int update_num_iters(double p, double ep, int max_iters) {  // RANSACUpdateNumIters(p, ep, 7, maxIters), host libm like the oracle
@@ -447,7 +454,8 @@ struct gfs_fmat {
   DevBuf<FmProblem> d_prob;
   DevBuf<float2> d_p1, d_p2;
   DevBuf<double> d_models, d_best;
-  DevBuf<int> d_nm, d_good, d_sel, d_keep;
+  DevBuf<int> d_nm, d_good, d_sel, d_keep, d_cnt;
+  PinBuf<int> h_cnt;
   DevBuf<float> d_med;
   PinBuf<float> h_med;
   DevBuf<uint8_t> d_mask;
@@ -484,6 +492,8 @@ int gfs_fmat_create(int device, int max_points, int max_batch, gfs_fmat** out) {
   A(h->d_med.alloc(B * kFmChunk * 3));
   A(h->h_med.alloc(B * kFmChunk * 3));
   A(h->d_keep.alloc(B));
+  A(h->d_cnt.alloc(B));
+  A(h->h_cnt.alloc(B));
   A(h->d_mask.alloc(NP));
   A(h->h_prob.alloc(B));
   A(h->h_p1.alloc(NP));
@@ -511,55 +521,45 @@ void gfs_fmat_destroy(gfs_fmat* h) {
   delete h;
 }
 
-int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, const float* const* pts1, const float* const* pts2,
-                                double threshold, double confidence, int max_iters, uint8_t* const* mask, double* F,
-                                int32_t* n_inliers) {
-  GFS_REQUIRE(h && n_points && pts1 && pts2 && mask && n_inliers && B > 0, GFS_ERR_INVALID_ARG,
-              "gfs_find_fundamental_ransac: invalid argument");
-  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac: batch %d exceeds capacity %d", B, h->max_batch);
-  if (threshold <= 0) threshold = 3;
-  if (confidence < kDblEps || confidence > 1 - kDblEps) confidence = 0.99;
-  std::lock_guard<std::mutex> lk(h->mu);
-  GFS_HIP(hipSetDevice(h->device));
-  const int S = h->max_points;
-  int nmax = 0;
-  bool any_lmeds = false;
-  for (int b = 0; b < B; b++) {
-    const int n = n_points[b];
-    GFS_REQUIRE(n <= S, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac: problem %d has %d points, capacity %d", b, n, S);
-    GFS_REQUIRE(n >= 8, GFS_ERR_UNSUPPORTED, "gfs_find_fundamental_ransac: problem %d has %d points (at least 8 needed)", b, n);
-    GFS_REQUIRE(pts1[b] && pts2[b] && mask[b], GFS_ERR_INVALID_ARG, "gfs_find_fundamental_ransac: problem %d has NULL arrays", b);
-    memcpy(h->h_p1.p + (size_t)b * S, pts1[b], (size_t)n * sizeof(float2));
-    memcpy(h->h_p2.p + (size_t)b * S, pts2[b], (size_t)n * sizeof(float2));
-    h->h_prob.p[b] = FmProblem{n, 1, 0xffffffffffffffffull, (float)(threshold * threshold), n < 15 ? 1 : 0, n < 15 ? 1000 : 10000};
-    any_lmeds |= n < 15;
-    nmax = n > nmax ? n : nmax;
-  }
+}  // extern "C"
+
+namespace {
+// The RANSAC / LMedS rounds on device-resident points d1 / d2 [B][S]; h->h_prob [b] = {n, active, ...} prepared by the caller
+// (active = 0 and h_sel = -2: the problem is passed through with an all-ones mask).  Leaves the mask in d_mask [B][S] (device),
+// the inlier counts in h->h_cnt and the best models in h->h_best.
+int fmat_run(gfs_fmat* h, int B, int S, const float2* d1, const float2* d2, double confidence, int max_iters, uint8_t* d_mask,
+             std::vector<int>& max_good) {
   hipStream_t s = h->stream;
-  const size_t NP = (size_t)B * S;
-  GFS_HIP(hipMemcpyAsync(h->d_p1.p, h->h_p1.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_p2.p, h->h_p2.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  bool any_lmeds = false;
+  int nmax = 1, remaining = 0;
+  std::vector<int> n_points(B);
+  for (int b = 0; b < B; b++) {
+    n_points[b] = h->h_prob.p[b].n;
+    any_lmeds |= h->h_prob.p[b].lmeds != 0 && h->h_prob.p[b].active;
+    nmax = n_points[b] > nmax ? n_points[b] : nmax;
+    remaining += h->h_prob.p[b].active ? 1 : 0;
+  }
   // host replay state of RANSACPointSetRegistrator::run per problem
-  std::vector<int> niters(B, max_iters > 1 ? max_iters : 1), max_good(B, 0), iter(B, 0), done(B, 0), best_here(B, 0);
+  std::vector<int> niters(B, max_iters > 1 ? max_iters : 1), iter(B, 0), done(B, 0), best_here(B, 0);
+  max_good.assign(B, 0);
+  for (int b = 0; b < B; b++) done[b] = h->h_prob.p[b].active ? 0 : 1;
   std::vector<double> min_median(B, 1.7976931348623157e308);
   for (int b = 0; b < B; b++)
     if (h->h_prob.p[b].lmeds) {  // LMeDSPointSetRegistrator::run: budget from a 45 % outlier assumption, at least 3
       niters[b] = update_num_iters(confidence, 0.45, 1000);
       if (niters[b] < 3) niters[b] = 3;
     }
-  for (int b = 0; b < B; b++) h->h_sel.p[b] = -1;
-  int remaining = B;
   int K = 16;  // the first chunk is short: with a quarter of outliers or fewer the budget drops below 16 after the first good model
   while (remaining > 0) {
     GFS_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, B * sizeof(FmProblem), hipMemcpyHostToDevice, s));
-    GFS_LAUNCH("k_fmat_hyp", k_fmat_hyp, dim3(B), dim3(kFmChunk), 0, s, h->d_prob.p, (const float2*)h->d_p1.p,
-               (const float2*)h->d_p2.p, S, K, h->d_models.p, h->d_nm.p);
+    GFS_LAUNCH("k_fmat_hyp", k_fmat_hyp, dim3(B), dim3(kFmChunk), 0, s, h->d_prob.p, d1,
+               d2, S, K, h->d_models.p, h->d_nm.p);
     GFS_LAUNCH("k_fmat_count", k_fmat_count, dim3(gfs::div_up(3 * K, kFmThreads / 64), B), dim3(kFmThreads), 0, s,
-               (const FmProblem*)h->d_prob.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, K, (const double*)h->d_models.p,
+               (const FmProblem*)h->d_prob.p, d1, d2, S, K, (const double*)h->d_models.p,
                (const int*)h->d_nm.p, h->d_good.p);
     if (any_lmeds) {
       GFS_LAUNCH("k_fmat_median", k_fmat_median, dim3(gfs::div_up(3 * K, kFmThreads), B), dim3(kFmThreads), 0, s,
-                 (const FmProblem*)h->d_prob.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, K, (const double*)h->d_models.p,
+                 (const FmProblem*)h->d_prob.p, d1, d2, S, K, (const double*)h->d_models.p,
                  (const int*)h->d_nm.p, h->d_med.p);
       GFS_HIP(hipMemcpyAsync(h->h_med.p, h->d_med.p, (size_t)B * kFmChunk * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     }
@@ -629,27 +629,98 @@ int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, con
     }
   GFS_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, B * sizeof(FmProblem), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_sel.p, h->h_sel.p, B * sizeof(int), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemsetAsync(h->d_cnt.p, 0, B * sizeof(int), s));
   GFS_LAUNCH("k_fmat_mask", k_fmat_mask, dim3(gfs::div_up(nmax, kFmThreads), B), dim3(kFmThreads), 0, s, (const FmProblem*)h->d_prob.p,
-             (const int*)h->d_sel.p, (const double*)h->d_best.p, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, S, h->d_mask.p);
-  GFS_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, NP, hipMemcpyDeviceToHost, s));
+             (const int*)h->d_sel.p, (const double*)h->d_best.p, d1, d2, S, d_mask, h->d_cnt.p);
+  GFS_HIP(hipMemcpyAsync(h->h_cnt.p, h->d_cnt.p, B * sizeof(int), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_best.p, h->d_best.p, (size_t)B * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+// F [B][9] and n_inliers [B] from the state fmat_run left (after the stream was synchronised)
+void fmat_results(gfs_fmat* h, int B, const std::vector<int>& max_good, double* F, int32_t* n_inliers) {
   for (int b = 0; b < B; b++) {
-    memcpy(mask[b], h->h_mask.p + (size_t)b * S, (size_t)n_points[b]);
-    if (h->h_prob.p[b].lmeds) {  // the count is taken from the mask; "result = count >= modelPoints" decides whether F is returned
-      int c = 0;
-      for (int i = 0; i < n_points[b]; i++) c += mask[b][i];
-      max_good[b] = c;
-      if (c < 7 && F) memset(h->h_best.p + (size_t)b * 9, 0, 9 * sizeof(double));
+    const FmProblem& P = h->h_prob.p[b];
+    int c = h->h_sel.p[b] == -2 ? P.n : max_good[b];
+    bool have = max_good[b] > 0;
+    if (P.lmeds && h->h_sel.p[b] >= 0) {  // LMedS counts from the mask; "result = count >= modelPoints" decides whether F is returned
+      c = h->h_cnt.p[b];
+      have = c >= 7;
     }
-    n_inliers[b] = max_good[b];
+    n_inliers[b] = c;
     if (F) {
-      if (max_good[b] > 0)
+      if (have && h->h_sel.p[b] >= 0)
         memcpy(F + 9 * (size_t)b, h->h_best.p + (size_t)b * 9, 9 * sizeof(double));
       else
         memset(F + 9 * (size_t)b, 0, 9 * sizeof(double));
     }
   }
+}
+}  // namespace
+
+extern "C" {
+
+int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, const float* const* pts1, const float* const* pts2,
+                                double threshold, double confidence, int max_iters, uint8_t* const* mask, double* F,
+                                int32_t* n_inliers) {
+  GFS_REQUIRE(h && n_points && pts1 && pts2 && mask && n_inliers && B > 0, GFS_ERR_INVALID_ARG,
+              "gfs_find_fundamental_ransac: invalid argument");
+  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac: batch %d exceeds capacity %d", B, h->max_batch);
+  if (threshold <= 0) threshold = 3;
+  if (confidence < kDblEps || confidence > 1 - kDblEps) confidence = 0.99;
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  const int S = h->max_points;
+  for (int b = 0; b < B; b++) {
+    const int n = n_points[b];
+    GFS_REQUIRE(n <= S, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac: problem %d has %d points, capacity %d", b, n, S);
+    GFS_REQUIRE(n >= 8, GFS_ERR_UNSUPPORTED, "gfs_find_fundamental_ransac: problem %d has %d points (at least 8 needed)", b, n);
+    GFS_REQUIRE(pts1[b] && pts2[b] && mask[b], GFS_ERR_INVALID_ARG, "gfs_find_fundamental_ransac: problem %d has NULL arrays", b);
+    memcpy(h->h_p1.p + (size_t)b * S, pts1[b], (size_t)n * sizeof(float2));
+    memcpy(h->h_p2.p + (size_t)b * S, pts2[b], (size_t)n * sizeof(float2));
+    h->h_prob.p[b] = FmProblem{n, 1, 0xffffffffffffffffull, (float)(threshold * threshold), n < 15 ? 1 : 0, n < 15 ? 1000 : 10000};
+    h->h_sel.p[b] = -1;
+  }
+  hipStream_t s = h->stream;
+  const size_t NP = (size_t)B * S;
+  GFS_HIP(hipMemcpyAsync(h->d_p1.p, h->h_p1.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_p2.p, h->h_p2.p, NP * sizeof(float2), hipMemcpyHostToDevice, s));
+  std::vector<int> max_good;
+  const int rc = fmat_run(h, B, S, (const float2*)h->d_p1.p, (const float2*)h->d_p2.p, confidence, max_iters, h->d_mask.p, max_good);
+  if (rc) return rc;
+  GFS_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, NP, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int b = 0; b < B; b++) memcpy(mask[b], h->h_mask.p + (size_t)b * S, (size_t)n_points[b]);
+  fmat_results(h, B, max_good, F, n_inliers);
+  return GFS_OK;
+}
+
+int gfs_find_fundamental_ransac_device(gfs_fmat* h, int B, int stride, const void* dev_n, const void* dev_pts1, const void* dev_pts2,
+                                       double threshold, double confidence, int max_iters, void* dev_mask, double* F,
+                                       int32_t* n_inliers) {
+  GFS_REQUIRE(h && dev_n && dev_pts1 && dev_pts2 && dev_mask && n_inliers && B > 0 && stride > 0, GFS_ERR_INVALID_ARG,
+              "gfs_find_fundamental_ransac_device: invalid argument");
+  GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_find_fundamental_ransac_device: batch %d exceeds capacity %d", B, h->max_batch);
+  if (threshold <= 0) threshold = 3;
+  if (confidence < kDblEps || confidence > 1 - kDblEps) confidence = 0.99;
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  GFS_HIP(hipMemcpyAsync(h->h_cnt.p, dev_n, B * sizeof(int), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  for (int b = 0; b < B; b++) {
+    const int n = h->h_cnt.p[b];
+    GFS_REQUIRE(n >= 0 && n <= stride, GFS_ERR_INVALID_ARG, "gfs_find_fundamental_ransac_device: problem %d has %d points, stride %d", b, n, stride);
+    // SearchByProjectionWithOF runs the check only for more than 8 points (src/ORBmatcher.cc:2397, 2461): fewer pass through
+    const int run = n > 8 ? 1 : 0;
+    h->h_prob.p[b] = FmProblem{n, run, 0xffffffffffffffffull, (float)(threshold * threshold), n < 15 ? 1 : 0, n < 15 ? 1000 : 10000};
+    h->h_sel.p[b] = run ? -1 : -2;
+  }
+  std::vector<int> max_good;
+  const int rc = fmat_run(h, B, stride, (const float2*)dev_pts1, (const float2*)dev_pts2, confidence, max_iters, (uint8_t*)dev_mask, max_good);
+  if (rc) return rc;
+  GFS_HIP(hipStreamSynchronize(s));
+  fmat_results(h, B, max_good, F, n_inliers);
   return GFS_OK;
 }
 

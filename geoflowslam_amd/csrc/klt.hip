@@ -572,6 +572,49 @@ __global__ void __launch_bounds__(kKltThreads) k_klt_fb(KltGeom G, KltParams P, 
   }
 }
 
+// The points fbKltTracking kept, in order (the un_cur_pts / un_forw_pts / index vectors of SearchByProjectionWithOF,
+// src/ORBmatcher.cc:2386-2395): one workgroup per frame, ballot + prefix sums keep the order.
+__global__ void __launch_bounds__(256) k_klt_compact(const int* __restrict__ n_pts, int pt_stride, const float2* __restrict__ kps,
+                                                      const float2* __restrict__ priors, const uint8_t* __restrict__ kpstatus,
+                                                      float2* __restrict__ out_a, float2* __restrict__ out_b, int* __restrict__ out_index,
+                                                      int* __restrict__ out_n) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = n_pts[f];
+  const size_t fo = (size_t)f * pt_stride;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    const bool keep = i < n && kpstatus[fo + i] != 0;
+    const unsigned long long ball = __ballot(keep);
+    if (lane == 0) s_wave[wave] = __popcll(ball);
+    __syncthreads();
+    int ofs = s_base;
+    for (int w = 0; w < wave; w++) ofs += s_wave[w];
+    if (keep) {
+      const int dst = ofs + __popcll(ball & ((1ull << lane) - 1));
+      out_a[fo + dst] = kps[fo + i];
+      out_b[fo + dst] = priors[fo + i];
+      out_index[fo + dst] = i;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (tid == 0) out_n[f] = s_base;
+}
+
+// vkpstatus.at(index.at(i)) = false for every track the F check rejected (src/ORBmatcher.cc:2401-2405)
+__global__ void __launch_bounds__(256) k_klt_apply_mask(const int* __restrict__ m_pts, int pt_stride, const int* __restrict__ index,
+                                                         const uint8_t* __restrict__ mask, uint8_t* __restrict__ kpstatus) {
+  const int f = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m_pts[f]) return;
+  const size_t fo = (size_t)f * pt_stride;
+  if (!mask[fo + j]) kpstatus[fo + index[fo + j]] = 0;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -932,6 +975,34 @@ int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_k
              ferr, fmax_fbklt_dist, gfs::div_up(pt_stride, kKltWavesPerBlock), B)
   KLT_DISPATCH(h->G.rounds, KLT_RUN)
 #undef KLT_RUN
+  if (!stream) GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+int gfs_klt_compact_tracks_device(gfs_klt* h, int B, int pt_stride, const void* dev_n, const void* dev_kps, const void* dev_priors,
+                                  const void* dev_kpstatus, void* dev_out_a, void* dev_out_b, void* dev_out_index, void* dev_out_n,
+                                  void* stream) {
+  GFS_REQUIRE(h && dev_n && dev_kps && dev_priors && dev_kpstatus && dev_out_a && dev_out_b && dev_out_index && dev_out_n && B > 0 &&
+                  pt_stride > 0, GFS_ERR_INVALID_ARG, "gfs_klt_compact_tracks_device: invalid argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  GFS_LAUNCH("k_klt_compact", k_klt_compact, dim3(B), dim3(256), 0, s, (const int*)dev_n, pt_stride, (const float2*)dev_kps,
+             (const float2*)dev_priors, (const uint8_t*)dev_kpstatus, (float2*)dev_out_a, (float2*)dev_out_b, (int*)dev_out_index,
+             (int*)dev_out_n);
+  if (!stream) GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+int gfs_klt_apply_mask_device(gfs_klt* h, int B, int pt_stride, const void* dev_m, const void* dev_index, const void* dev_mask,
+                              void* dev_kpstatus, void* stream) {
+  GFS_REQUIRE(h && dev_m && dev_index && dev_mask && dev_kpstatus && B > 0 && pt_stride > 0, GFS_ERR_INVALID_ARG,
+              "gfs_klt_apply_mask_device: invalid argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  GFS_LAUNCH("k_klt_apply_mask", k_klt_apply_mask, dim3(gfs::div_up(pt_stride, 256), B), dim3(256), 0, s, (const int*)dev_m, pt_stride,
+             (const int*)dev_index, (const uint8_t*)dev_mask, (uint8_t*)dev_kpstatus);
   if (!stream) GFS_HIP(hipStreamSynchronize(s));
   return GFS_OK;
 }

@@ -460,6 +460,16 @@ int gfs_klt_fb_track_device(gfs_klt* h, const gfs_klt_pyramid* prev, const gfs_k
                             const void* dev_n, const void* dev_kps, void* dev_priors, void* dev_kpstatus, void* dev_n_good,
                             int nbpyrlvl, float ferr, float fmax_fbklt_dist, void* stream);
 
+/* The bookkeeping around the F check of SearchByProjectionWithOF on the device (src/ORBmatcher.cc:2386-2406): the tracks that survived
+ * fbKltTracking, in order, as the two point lists of the check plus their original indices (dev_out_a / dev_out_b
+ * [B][pt_stride][2] float, dev_out_index [B][pt_stride] int32, dev_out_n [B] int32) ... */
+int gfs_klt_compact_tracks_device(gfs_klt* h, int B, int pt_stride, const void* dev_n, const void* dev_kps, const void* dev_priors,
+                                  const void* dev_kpstatus, void* dev_out_a, void* dev_out_b, void* dev_out_index, void* dev_out_n,
+                                  void* stream);
+/* ... and, after gfs_find_fundamental_ransac_device, kpstatus[index[j]] = 0 for every track j whose mask is 0. */
+int gfs_klt_apply_mask_device(gfs_klt* h, int B, int pt_stride, const void* dev_m, const void* dev_index, const void* dev_mask,
+                              void* dev_kpstatus, void* stream);
+
 /* ============================================================================================
  * 10. cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, threshold, confidence, mask) — the F check of the optical-flow
  *     matcher (src/ORBmatcher.cc:236, 2399-2405, 2463-2469) and of Tracking::EstimatePoseByOF (src/Tracking.cc:1973-1974):
@@ -479,6 +489,12 @@ void gfs_fmat_destroy(gfs_fmat* h);
 int gfs_find_fundamental_ransac(gfs_fmat* h, int B, const int32_t* n_points, const float* const* pts1, const float* const* pts2,
                                 double threshold, double confidence, int max_iters, uint8_t* const* mask, double* F,
                                 int32_t* n_inliers);
+/* Device-resident form: dev_pts1 / dev_pts2 [B][stride][2] float, dev_n [B] int32, dev_mask [B][stride] u8 (device); F and n_inliers
+ * on the host.  Problems with 8 or fewer points are passed through (mask all ones, n_inliers = n): SearchByProjectionWithOF only runs
+ * the check for more than 8 (src/ORBmatcher.cc:2397, 2461).  Synchronous (the acceptance rule is replayed on the host). */
+int gfs_find_fundamental_ransac_device(gfs_fmat* h, int B, int stride, const void* dev_n, const void* dev_pts1, const void* dev_pts2,
+                                       double threshold, double confidence, int max_iters, void* dev_mask, double* F,
+                                       int32_t* n_inliers);
 
 /* ============================================================================================
  * Timing helper for the harness: HIP events on a given stream (bench.py measures the dominant kernel

@@ -93,3 +93,54 @@ def test_lmeds_branch_and_mixed_batches(gpu_api, oracle):
             _check(G[b], oracle.fundamental_ransac(probs[b][0], probs[b][1], 1.5, conf))
     one = gpu_api.FundamentalMatcher(max_points=64)
     _check(one.findFundamentalMat(probs[2][0], probs[2][1]), oracle.fundamental_ransac(probs[2][0], probs[2][1]))
+
+
+def test_device_resident_optical_flow_chain(gpu_api, oracle):
+    """fbKltTracking -> ordered compaction of the surviving tracks -> F check -> status update, without leaving HBM: the same
+    statuses as the host-pointer entries (and hence the oracle) give; frames with 8 or fewer tracks pass through unchecked."""
+    from test_gpu_gms import _Hip
+    w, h, win, B, S = 320, 240, 21, 4, 512
+    rng = np.random.default_rng(3)
+    pairs = [synth.klt_texture_pair(80 + b, w, h, shift=(rng.uniform(-4, 4), rng.uniform(-4, 4)), rot_deg=rng.uniform(-1, 1)) for b in range(B)]
+    n = [400, 6, 12, 512]
+    kps = [np.stack([rng.uniform(8, w - 8, k), rng.uniform(8, h - 8, k)], 1).astype(np.float32) for k in n]
+    trk = gpu_api.KltTracker(w, h, win, max_batch=B, max_points=S)
+    prev = trk.buildOpticalFlowPyramid([p[0] for p in pairs])
+    cur = trk.buildOpticalFlowPyramid([p[1] for p in pairs])
+    fm = gpu_api.FundamentalMatcher(max_points=S, max_batch=B)
+    # host-pointer chain (the reference's flow of control)
+    host = trk.fbKltTracking(prev, cur, 3, 15.0, 0.5, kps, [k.copy() for k in kps])
+    want = []
+    for b in range(B):
+        pri, ok, _ = host[b]
+        st = ok.copy()
+        idx = np.flatnonzero(ok)
+        if len(idx) > 8:
+            m, _, _ = fm.findFundamentalMat(kps[b][idx], pri[idx], 1.0, 0.99)
+            mo = oracle.fundamental_ransac(kps[b][idx], pri[idx], 1.0, 0.99)[0]
+            assert np.array_equal(m, mo)
+            st[idx[~m]] = False
+        want.append(st)
+    # device chain
+    hip = _Hip()
+    K = np.zeros((B, S, 2), np.float32)
+    for b in range(B):
+        K[b, :n[b]] = kps[b]
+    d_n, d_k, d_p = hip.to_device(np.array(n, np.int32)), hip.to_device(K), hip.to_device(K)
+    d_s, d_g = hip.to_device(np.zeros((B, S), np.uint8)), hip.to_device(np.zeros(B, np.int32))
+    d_a, d_b = hip.to_device(np.zeros((B, S, 2), np.float32)), hip.to_device(np.zeros((B, S, 2), np.float32))
+    d_i, d_m, d_mask = hip.to_device(np.zeros((B, S), np.int32)), hip.to_device(np.zeros(B, np.int32)), hip.to_device(np.zeros((B, S), np.uint8))
+    trk.fb_track_device(prev, cur, B, S, d_n, d_k, d_p, d_s, d_g)
+    trk.compact_tracks_device(B, S, d_n, d_k, d_p, d_s, d_a, d_b, d_i, d_m)
+    m_cnt = hip.to_host(d_m, (B,), np.int32)
+    idx_d = hip.to_host(d_i, (B, S), np.int32)
+    for b in range(B):
+        assert m_cnt[b] == host[b][1].sum() and np.array_equal(idx_d[b, :m_cnt[b]], np.flatnonzero(host[b][1]))
+    F, cnt = fm.find_device(B, S, d_m, d_a, d_b, d_mask, 1.0, 0.99)
+    trk.apply_mask_device(B, S, d_m, d_i, d_mask, d_s)
+    st_d = hip.to_host(d_s, (B, S), np.uint8)
+    for b in range(B):
+        assert np.array_equal(st_d[b, :n[b]].astype(bool), want[b]), b
+        assert cnt[b] == (want[b].sum() if m_cnt[b] > 8 else m_cnt[b])
+    assert not F[1].any() and F[0].any()                       # the 6-track frame is passed through, no model
+    hip.free()
