@@ -103,6 +103,7 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   __shared__ unsigned bin_base[kNB];
   __shared__ unsigned wave_hist[16][kNB];
   __shared__ int s_uniform;
+  __shared__ unsigned s_wtot[8];
   __shared__ int s_mn[3], s_mx[3];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (only >= 0 && (c & 1) != only) return;
@@ -177,17 +178,23 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
     if (tid < kNB && hist[tid] == (unsigned)n) s_uniform = 1;
     __syncthreads();
     if (s_uniform) continue;  // block-uniform
-    if (tid < kNB) bin_base[tid] = hist[tid];
-    __syncthreads();
-    for (int ofs = 1; ofs < kNB; ofs <<= 1) {  // inclusive scan
-      unsigned v = 0;
-      if (tid < kNB && tid >= ofs) v = bin_base[tid - ofs];
+    {  // exclusive scan of the 512 bin counts: a shuffle scan per wave of 64 bins + the totals of the 8 waves (two barriers)
+      const unsigned own = tid < kNB ? hist[tid] : 0u;
+      unsigned incl = own;
+#pragma unroll
+      for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const unsigned v = __shfl_up(incl, ofs, 64);
+        if (lane >= ofs) incl += v;
+      }
+      if (tid < kNB && lane == 63) s_wtot[wave] = incl;
       __syncthreads();
-      if (tid < kNB) bin_base[tid] += v;
+      if (tid < kNB) {
+        unsigned base = 0;
+        for (int w = 0; w < wave; w++) base += s_wtot[w];
+        bin_base[tid] = base + incl - own;
+      }
       __syncthreads();
     }
-    if (tid < kNB) bin_base[tid] -= hist[tid];  // exclusive
-    __syncthreads();
     for (int t0 = 0; t0 < n; t0 += 1024 * kEl) {
       for (int k = tid; k < 16 * kNB; k += 1024) (&wave_hist[0][0])[k] = 0;
       __syncthreads();
