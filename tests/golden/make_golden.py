@@ -67,6 +67,19 @@ def main():
     q1, q2, _, _ = synth.two_view_points(77, 200, 0.3)
     fmask, fF, fcnt, fit = O.fundamental_ransac(q1, q2, 2.0, 0.99)
     np.savez_compressed(os.path.join(OUT, "fmat_200.npz"), pts1=q1, pts2=q2, mask=fmask, F=fF, count=fcnt, iterations=fit)
+    # 7. the SURVEY 8(f) rows next to the path: windowed matching (both overloads), motion-only BA, the GMS filter of the ORB matches
+    sp = synth.sbp_pair(3, n_points=200, n_extra_cur=40)
+    sm, sn = O.search_by_projection(sp)
+    mp = synth.sbp_map_frame(4, n_points=200, n_extra_cur=40)
+    mm, mn = O.search_by_projection_map(mp)
+    pf = synth.pose_frame(3, n_obs=150)
+    pr = O.pose_optimization(pf)
+    gq = np.arange(len(ti), dtype=np.int32)
+    gmask, gcnt = O.gms_inlier_mask(k0, (160, 120), k1, (160, 120), gq, ti)
+    np.savez_compressed(os.path.join(OUT, "next_rows.npz"), **{"sbp_" + k: np.asarray(v) for k, v in sp.items()}, sbp_out=sm, sbp_n=sn,
+                        **{"map_" + k: np.asarray(v) for k, v in mp.items()}, map_out=mm, map_n=mn,
+                        **{"pose_" + k: np.asarray(v) for k, v in pf.items()}, poseout_outlier=pr["outlier"], poseout_q=pr["q"], poseout_t=pr["t"],
+                        poseout_inliers=pr["n_inliers"], poseout_iterations=pr["iterations_run"], gms_mask=gmask, gms_count=gcnt)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
