@@ -85,7 +85,7 @@ __device__ __forceinline__ bool subset_ok(const float2* m1, const float2* m2, co
 __device__ __forceinline__ double cubic_eval(double B, double C, double D, double x) { return ((x + B) * x + C) * x + D; }
 __device__ double cubic_bisect(double B, double C, double D, double lo, double hi) {
   const bool neg_lo = cubic_eval(B, C, D, lo) < 0;
-  for (;;) {
+  for (int it = 0; it < 4096; it++) {  // an interval of doubles collapses in < 2200 halvings; the cap only guards against NaN
     const double mid = 0.5 * (lo + hi);
     if (mid == lo || mid == hi) break;
     if ((cubic_eval(B, C, D, mid) < 0) == neg_lo)
@@ -116,6 +116,7 @@ __device__ int cubic_real_roots(const double* c, double* r) {
   if (fabs(C) > bound) bound = fabs(C);
   if (fabs(D) > bound) bound = fabs(D);
   bound += 1.0;
+  if (!(bound < 1.0e300)) return 0;  // a vanishing leading coefficient blew the monic form up (or NaN): no usable root
   double knots[4];
   int nk = 0;
   knots[nk++] = -bound;  // Cauchy: every root lies in (-bound, bound)

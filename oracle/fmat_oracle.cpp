@@ -72,7 +72,7 @@ inline double cubic_eval(double B, double C, double D, double x) { return ((x + 
 // the root of the monic cubic inside [lo, hi], p(lo) and p(hi) on different sides of zero: bisection until the interval collapses
 inline double cubic_bisect(double B, double C, double D, double lo, double hi) {
   const bool neg_lo = cubic_eval(B, C, D, lo) < 0;
-  for (;;) {
+  for (int it = 0; it < 4096; it++) {  // an interval of doubles collapses in < 2200 halvings; the cap only guards against NaN
     const double mid = 0.5 * (lo + hi);
     if (mid == lo || mid == hi) break;
     if ((cubic_eval(B, C, D, mid) < 0) == neg_lo)
@@ -103,7 +103,8 @@ int cubic_real_roots(const double* c, double* r) {
   double bound = std::fabs(B);
   if (std::fabs(C) > bound) bound = std::fabs(C);
   if (std::fabs(D) > bound) bound = std::fabs(D);
-  bound += 1.0;  // Cauchy: every root lies in (-bound, bound)
+  bound += 1.0;
+  if (!(bound < 1.0e300)) return 0;  // a vanishing leading coefficient blew the monic form up (or NaN): no usable root
   double knots[4];
   int nk = 0;
   knots[nk++] = -bound;

@@ -144,3 +144,17 @@ def test_device_resident_optical_flow_chain(gpu_api, oracle):
         assert cnt[b] == (want[b].sum() if m_cnt[b] > 8 else m_cnt[b])
     assert not F[1].any() and F[0].any()                       # the 6-track frame is passed through, no model
     hip.free()
+
+
+def test_non_finite_and_huge_coordinates_terminate(gpu_api, oracle):
+    """NaN / inf / enormous coordinates must neither hang the device nor part from the oracle."""
+    p1, p2, _, _ = synth.two_view_points(41, 60, 0.2)
+    fm = gpu_api.FundamentalMatcher(max_points=64)
+    for poison in (np.nan, np.inf, 3.0e37):
+        a, b = p1.copy(), p2.copy()
+        a[::7, 0] = poison
+        b[3::11, 1] = -poison if np.isfinite(poison) else poison
+        g, o = fm.findFundamentalMat(a, b, 2.0, 0.99, 200), oracle.fundamental_ransac(a, b, 2.0, 0.99, 200)
+        assert g[2] == o[2] and np.array_equal(g[0], o[0])
+        if g[1] is not None:
+            assert np.array_equal(g[1].view(np.uint64), o[1].view(np.uint64))
