@@ -181,3 +181,21 @@ def test_argument_checks(gpu_api):
         trk.calcOpticalFlowPyrLK(p, p, pts[:8], flags=1)
     empty = trk.fbKltTracking(p, p, 3, 15.0, 0.5, pts[:0], pts[:0])
     assert empty[2] == 0 and len(empty[1]) == 0
+
+
+def test_huge_and_infinite_coordinates(gpu_api, oracle):
+    """Key points / priors far outside any image (1e30, inf): dropped like any out-of-range point, nothing hangs."""
+    w, h, win = 160, 120, 15
+    i0, i1, _ = synth.klt_texture_pair(3, w, h, shift=(1.0, 0.5))
+    trk = gpu_api.KltTracker(w, h, win, max_batch=1, max_points=64)
+    p0, p1 = trk.buildOpticalFlowPyramid(i0), trk.buildOpticalFlowPyramid(i1)
+    o0, o1 = oracle.klt_build_pyramid(i0, win), oracle.klt_build_pyramid(i1, win)
+    kps = _points(np.random.default_rng(0), 24, w, h, 10.0)
+    pri = kps.copy()
+    kps[0], kps[1], kps[2] = (1e30, 5.0), (-1e30, 7.0), (np.inf, 9.0)
+    pri[3], pri[4], pri[5] = (1e30, 1e30), (20.0, -np.inf), (-3e38, 3e38)
+    g = trk.fbKltTracking(p0, p1, 3, 15.0, 0.5, kps, pri)
+    o = oracle.fb_klt_tracking(o0, o1, w, h, win, 3, 15.0, 0.5, kps, pri)
+    assert g[2] == o[2] and np.array_equal(g[1], o[1]) and not g[1][:6].any() and g[1][6:].all()
+    ok = g[1]
+    assert np.array_equal(_bits(g[0][ok]), _bits(o[0][ok]))
