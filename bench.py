@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prime", type=int, default=10, help="untimed set-up passes before the W warm-up steps (code objects, clocks)")
@@ -73,7 +73,7 @@ def main():
                     help="experiment, not the headline metric: GICP through gfs_gicp_align_next (the previous call's preprocessed "
                          "source cloud is the target, as in a live stream) instead of preprocessing both clouds per pair")
     ap.add_argument("--serial", action="store_true", help="run ORB+match and GICP back to back on one stream")
-    ap.add_argument("--lanes", type=int, default=2, help="independent slices of the batch processed concurrently per GPU")
+    ap.add_argument("--lanes", type=int, default=4, help="independent slices of the batch processed concurrently per GPU")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
     ap.add_argument("--all-ranks-device0", action="store_true", help="dry-run aid: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="frame pairs in the CPU-baseline sample")

@@ -44,7 +44,7 @@ for suffix in ("stats", "stats_serial"):
     for f in glob.glob(os.path.join(out, f"{tag}_{suffix}", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(out, f"{tag}_kernel_{suffix}.csv"))
 
-traffic = {"_batch_pairs": int(os.environ.get("GFS_BENCH_BATCH", "128"))}
+traffic = {"_batch_pairs": int(os.environ.get("GFS_BENCH_BATCH", "512"))}  # bench.py's default --batch (the PMC passes use it)
 for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     acc, n = counters(os.path.join(out, f"{tag}_pmc_{c}"))
     for k, v in acc.items():
