@@ -231,6 +231,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fps = world * B * args.steps / dt
+    free_b, total_b = torch.cuda.mem_get_info(dev)  # everything the path holds in HBM (workspaces are sized once, at handle creation)
+    hbm_used_gb = round((total_b - free_b) / 2**30, 1)
 
     # ---- dominant-kernel roofline: per-kernel HIP-event timing on the launch stream (extra, untimed steps, run one
     #      module at a time so that a kernel's events do not include waiting for kernels of other streams)
@@ -465,7 +467,7 @@ def main():
                                     "+ BF Hamming match + GMS filter + GICP on ~19k-pt clouds (stride-4 depth grid)") if args.workload == "c2" else
                                    ("BASELINE.json configs[2] (NOT the metric's configuration): 1280x720 RGBD frame pair, ORB extract (2000 feats, "
                                     "8 levels) + BF Hamming match + GMS filter + GICP on ~37k-pt clouds (stride-5 depth grid)"),
-                       "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
+                       "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "hbm_in_use_gb": hbm_used_gb, "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
                        "gicp_mean_outer_iterations": round(float(np.mean([r["n_linearize"] for r in g])), 2),
                        "gicp_mean_error_evals": round(float(np.mean([r["n_error_evals"] for r in g])), 2),
                        "gicp_converged_frac": round(float(np.mean([r["converged"] for r in g])), 3)},
