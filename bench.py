@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes per GPU (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-join", action="store_true",
+                    help="join all lanes after every pass (default: every (lane, half) chain runs its K passes back to back)")
     ap.add_argument("--prime", type=int, default=10, help="untimed set-up passes before the W warm-up steps (code objects, clocks)")
     ap.add_argument("--no-klt", action="store_true", help="skip the optical-flow side measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the ORB-only and LBA side measurements")
@@ -203,6 +205,24 @@ def main():
 
     step = step_serial if args.serial else step_overlapped
 
+    def run_steps(k):
+        """k passes of the hot path over the batch.  The two halves of a lane never exchange data, and neither do the lanes, so
+        (unless --step-join) every (lane, half) chain runs its k passes back to back on its own host thread and HIP stream: a
+        chain does not wait at the end of each pass for the slowest one (whose Levenberg-Marquardt tail leaves the GPU half
+        empty).  Every pass is still executed k times in full; the caller brackets the k passes with barriers."""
+        if args.serial or args.step_join:
+            for _ in range(k):
+                step()
+            return
+
+        def chain(f):
+            for _ in range(k):
+                f()
+
+        futs = [pool.submit(chain, f) for ln in lanes for f in (ln.orb_and_match, ln.gicp)]
+        for f in futs:
+            f.result()
+
     def gicp_results():
         return [dict(n_linearize=r.n_linearize, n_error_evals=r.n_error_evals, n_source_ds=r.n_source_ds,
                      n_target_ds=r.n_target_ds, converged=bool(r.converged)) for ln in lanes for r in ln.gicp_out]
@@ -215,15 +235,12 @@ def main():
 
     # set-up, not part of the W + K contract: on a fresh box the first passes pay for loading the code objects and ramping the
     # clocks (the narrow one-workgroup-per-cloud kernels run 2-5x slower then); run the pipeline a few times before warm-up
-    for _ in range(args.prime):
-        step()
+    run_steps(args.prime)
     barrier()
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -467,7 +484,8 @@ def main():
                                     "+ BF Hamming match + GMS filter + GICP on ~19k-pt clouds (stride-4 depth grid)") if args.workload == "c2" else
                                    ("BASELINE.json configs[2] (NOT the metric's configuration): 1280x720 RGBD frame pair, ORB extract (2000 feats, "
                                     "8 levels) + BF Hamming match + GMS filter + GICP on ~37k-pt clouds (stride-5 depth grid)"),
-                       "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "hbm_in_use_gb": hbm_used_gb, "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
+                       "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "hbm_in_use_gb": hbm_used_gb,
+                       "passes": "joined after every pass" if (args.step_join or args.serial) else "K passes per lane chain, joined once", "distinct_scenes_per_gpu": nd, "parallelism": f"frames sharded x{world}, no collective",
                        "gicp_mean_outer_iterations": round(float(np.mean([r["n_linearize"] for r in g])), 2),
                        "gicp_mean_error_evals": round(float(np.mean([r["n_error_evals"] for r in g])), 2),
                        "gicp_converged_frac": round(float(np.mean([r["converged"] for r in g])), 3)},
