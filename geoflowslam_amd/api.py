@@ -184,7 +184,7 @@ ABI_SYMBOLS = [
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
-    "gfs_gicp_fetch_preprocessed", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device",
+    "gfs_gicp_fetch_preprocessed", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort",
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
@@ -238,6 +238,7 @@ def lib():
             L.gfs_gicp_align.argtypes = [vp, vp, i, vp, i, vp, C.POINTER(GicpConfig), C.POINTER(GicpResult)]
             L.gfs_gicp_align_batch_device.argtypes = [vp, vp, vp, vp, vp, i, i, vp, C.POINTER(GicpConfig), vp, vp]
             L.gfs_gicp_fetch_preprocessed.argtypes = [vp, i, i, vp, vp, i, ip]
+            L.gfs_test_voxel_sort.argtypes = [vp, vp, i, vp]
             L.gfs_gicp_align_next.argtypes = [vp, vp, i, vp, C.POINTER(GicpConfig), C.POINTER(GicpResult)]
             L.gfs_gicp_align_next_batch_device.argtypes = [vp, vp, vp, i, i, vp, C.POINTER(GicpConfig), vp, vp]
         if hasattr(L, "gfs_lba_create"):
@@ -509,6 +510,13 @@ class RegistrationGICP:
         _check(lib().gfs_gicp_align(self.h, _p(t), len(t), _p(s), len(s), _p(T0c), C.byref(cfg), C.byref(res)),
                "gfs_gicp_align")
         return _result_dict(res)
+
+    def voxel_sort_perm(self, keys):
+        """Test hook: permutation of the preprocessing's voxel sort (small_gicp quick_sort_omp replica) for caller keys."""
+        k = np.ascontiguousarray(keys, np.uint64)
+        perm = np.zeros(max(len(k), 1), np.uint32)
+        _check(lib().gfs_test_voxel_sort(self.h, _p(k), len(k), _p(perm)), "gfs_test_voxel_sort")
+        return perm[:len(k)].astype(np.int64)
 
     def RegisterNext(self, source_points, init_T_target_source=None, cfg=None):
         """Streaming form: the target is the source cloud of the previous call on this object (kept preprocessed in HBM), as in

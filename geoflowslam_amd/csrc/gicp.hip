@@ -18,6 +18,7 @@
 #include <memory>
 
 #include "gfs_common.hpp"
+#include "voxel_qsort.hpp"
 #include "wave_reduce.hpp"
 
 namespace {
@@ -1528,7 +1529,7 @@ __global__ void k_gicp_init(PairState* __restrict__ st, const double* __restrict
 struct gfs_gicp {
   int device, P, Bmax, nblk;
   hipStream_t stream;
-  std::mutex mu;
+  std::recursive_mutex mu;  // the host-pointer entries hold it across staging upload + run
   gfs::DevBuf<float4> d_in_t, d_in_s;  // staging for the host-pointer entry
   gfs::DevBuf<unsigned> d_hard;  // per cloud: indices of the points k_knn_cov deferred to k_knn_cov_far
   gfs::DevBuf<double> d_hard_d;  // ... and the squared distance bounding their k nearest (same slots)
@@ -1536,6 +1537,11 @@ struct gfs_gicp {
   gfs::DevBuf<int> d_nt, d_ns, d_counts, d_which, d_m, d_which2, d_nucell, d_tgt_index, d_ndone, d_bbox, d_ginfo, d_kinfo1, d_kinfo2;
   gfs::DevBuf<u64> d_keys0, d_keys1, d_ck0, d_ck1, d_ucell;
   gfs::DevBuf<unsigned> d_val0, d_val1, d_ci0, d_ci1, d_ubegin, d_grid;
+  gfs::DevBuf<unsigned> d_leaf;  // per cloud: (begin, end) of the < 1024-element ranges of the voxel sort (voxel_qsort.hpp)
+  gfs::DevBuf<int> d_nleaf, d_nheap;
+  gfs::DevBuf<unsigned> d_heap;  // per cloud: (begin, end) of the ranges that hit std::sort's depth limit (heap-sort fallback)
+  int heap_cap = 0;
+  bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
   gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
   gfs::DevBuf<PairState> d_state;
@@ -1552,6 +1558,49 @@ struct gfs_gicp {
   gfs::DevBuf<int> d_zero;  // [Bmax] zeros: the point counts of the slot that is not re-read in a streaming call
 };
 
+// The n >= 1024 levels of the voxel sort: the register-cached kernel for clouds whose keys compact to 31 bits (it flags the
+// others), then the general kernel for the flagged ones.
+static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only) {
+  const int P = h->P;
+  int flagged_only = 1;
+#define VQS_TOP_REG(E)                                                                                                         \
+  do {                                                                                                                         \
+    const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top_reg", s) : -1;                              \
+    hipLaunchKernelGGL(vqs::k_voxel_qsort_top_reg<E>, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_val0.p, h->d_keys1.p,     \
+                       h->d_val1.p, h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only);           \
+    if (_pid >= 0) ::gfs::profile_end(_pid, s);                                                                                \
+  } while (0)
+  if (P <= 1024 * 20)
+    VQS_TOP_REG(20);
+  else if (P <= 1024 * 40)
+    VQS_TOP_REG(40);
+  else
+    flagged_only = 0;
+#undef VQS_TOP_REG
+  {
+    const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top", s) : -1;
+    hipLaunchKernelGGL(vqs::k_voxel_qsort_top, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_val0.p, h->d_keys1.p, h->d_val1.p,
+                       h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only, flagged_only);
+    if (_pid >= 0) ::gfs::profile_end(_pid, s);
+  }
+  return hipGetLastError();
+}
+
+// std::sort of the < 1024-element ranges (both key widths), then the heap-sort fallbacks they deferred
+static int voxel_qsort_leaves(gfs_gicp* h, int C2, int leaf_parts, hipStream_t s, int only) {
+  const int P = h->P;
+  GFS_LAUNCH("k_voxel_qsort_leaf", vqs::k_voxel_qsort_leaf<unsigned>, dim3(leaf_parts, C2), dim3(256), 0, s, h->d_keys0.p,
+             h->d_val0.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, P, only, h->d_heap.p, h->d_nheap.p, h->heap_cap);
+  GFS_LAUNCH("k_voxel_qsort_leaf64", vqs::k_voxel_qsort_leaf<u64>, dim3(leaf_parts, C2), dim3(256), 0, s, h->d_keys0.p,
+             h->d_val0.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, P, only, h->d_heap.p, h->d_nheap.p, h->heap_cap);
+  const int heap_parts = std::max(1, std::min(16, P / 4096));
+  GFS_LAUNCH("k_voxel_qsort_heap", vqs::k_voxel_qsort_heap<unsigned>, dim3(heap_parts, C2), dim3(256), 0, s, h->d_keys0.p,
+             h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only);
+  GFS_LAUNCH("k_voxel_qsort_heap64", vqs::k_voxel_qsort_heap<u64>, dim3(heap_parts, C2), dim3(256), 0, s, h->d_keys0.p,
+             h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only);
+  return GFS_OK;
+}
+
 extern "C" {
 
 void gfs_gicp_default_config(gfs_gicp_config* c) {
@@ -1567,6 +1616,7 @@ void gfs_gicp_default_config(gfs_gicp_config* c) {
 
 int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   GFS_REQUIRE(out && max_points > 0 && max_batch > 0, GFS_ERR_INVALID_ARG, "gfs_gicp_create: invalid argument");
+  GFS_REQUIRE(max_points <= (1 << 20), GFS_ERR_CAPACITY, "gfs_gicp_create: at most 2^20 points per cloud");
   if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
   GFS_HIP(hipSetDevice(device));
   std::unique_ptr<gfs_gicp> h(new gfs_gicp);
@@ -1575,6 +1625,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   h->Bmax = max_batch;
   h->nblk = gfs::div_up(h->P, kLinBlock);
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  if (const char* e = getenv("GFS_GICP_VOXEL_ORDER")) h->stable_voxel_order = strcmp(e, "stable") == 0;
   const size_t P = h->P, B = max_batch, C2 = 2 * B;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
@@ -1600,6 +1651,11 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_keys1.alloc(C2 * P));
   A(h->d_val0.alloc(C2 * P));
   A(h->d_val1.alloc(C2 * P));
+  A(h->d_leaf.alloc(C2 * P));
+  A(h->d_nleaf.alloc(C2));
+  A(h->d_nheap.alloc(C2));
+  h->heap_cap = (int)(P / 8 + 2);  // ranges are disjoint and longer than 16 elements
+  A(h->d_heap.alloc(C2 * (size_t)h->heap_cap));
   A(h->d_ck0.alloc(C2 * P));
   A(h->d_ck1.alloc(C2 * P));
   A(h->d_ci0.alloc(C2 * P));
@@ -1650,7 +1706,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   GFS_REQUIRE(cfg->downsampling_resolution > 0 && cfg->max_correspondence_distance > 0 && cfg->num_neighbors >= 1 &&
                   cfg->num_neighbors <= 10,
               GFS_ERR_UNSUPPORTED, "gfs_gicp: need resolution > 0, max_corr > 0, 1 <= num_neighbors <= 10");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::lock_guard<std::recursive_mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const int P = h->P, C2 = 2 * B;
@@ -1693,8 +1749,18 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   // ---- preprocess_points x 2B (registration_helper.cpp:22-34)
   GFS_LAUNCH("k_voxel_keys", k_voxel_keys, dim3(gfs::div_up(npts, 256), C2), dim3(256), 0, s, in_even, in_odd, n_even, n_odd,
              stride_pts, P, prm.inv_leaf, h->d_keys0.p, h->d_val0.p, h->d_counts.p, prm.only);
-  GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
-             h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only);
+  if (h->stable_voxel_order) {
+    GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
+               h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only);
+  } else {
+    // the reference's (unstable) quick_sort_omp permutation, reproduced exactly: util/sort_omp.hpp:58-85
+    const int leaf_parts = std::max(1, std::min(64, P / 2048));
+    int rc_leaf = 0;
+    GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, (size_t)C2 * sizeof(int), s));
+    GFS_HIP(voxel_qsort_top(h, C2, s, prm.only));
+    rc_leaf = voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only);
+    if (rc_leaf) return rc_leaf;
+  }
   GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, in_even, in_odd, stride_pts, h->d_keys0.p, h->d_keys1.p,
              h->d_val0.p, h->d_val1.p, h->d_which.p, h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p, h->d_m.p,
              prm.only);
@@ -1792,14 +1858,12 @@ int gfs_gicp_align_next(gfs_gicp* h, const float* source_xyzw, int ns, const dou
                         const gfs_gicp_config* cfg, gfs_gicp_result* out) {
   GFS_REQUIRE(h && source_xyzw && ns >= 0 && cfg && out, GFS_ERR_INVALID_ARG, "gfs_gicp_align_next: invalid argument");
   GFS_REQUIRE(ns <= h->P, GFS_ERR_CAPACITY, "gfs_gicp_align_next: %d points exceed capacity %d", ns, h->P);
-  {
-    std::lock_guard<std::mutex> lk(h->mu);
-    GFS_HIP(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    if (ns) GFS_HIP(hipMemcpyAsync(h->d_in_s.p, source_xyzw, (size_t)ns * 16, hipMemcpyHostToDevice, s));
-    GFS_HIP(hipMemcpyAsync(h->d_ns.p, &ns, sizeof(int), hipMemcpyHostToDevice, s));
-    GFS_HIP(hipStreamSynchronize(s));
-  }
+  std::lock_guard<std::recursive_mutex> lk(h->mu);  // staging buffers are shared: upload + run are one critical section
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  if (ns) GFS_HIP(hipMemcpyAsync(h->d_in_s.p, source_xyzw, (size_t)ns * 16, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_ns.p, &ns, sizeof(int), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipStreamSynchronize(s));
   return gicp_run(h, nullptr, nullptr, h->d_in_s.p, h->d_ns.p, 1, h->P, init_T_target_source, cfg, out, nullptr, true);
 }
 
@@ -1808,24 +1872,48 @@ int gfs_gicp_align(gfs_gicp* h, const float* target_xyzw, int nt, const float* s
   GFS_REQUIRE(h && target_xyzw && source_xyzw && nt >= 0 && ns >= 0 && cfg && out, GFS_ERR_INVALID_ARG,
               "gfs_gicp_align: invalid argument");
   GFS_REQUIRE(nt <= h->P && ns <= h->P, GFS_ERR_CAPACITY, "gfs_gicp_align: %d / %d points exceed capacity %d", nt, ns, h->P);
-  {
-    std::lock_guard<std::mutex> lk(h->mu);
-    GFS_HIP(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    if (nt) GFS_HIP(hipMemcpyAsync(h->d_in_t.p, target_xyzw, (size_t)nt * 16, hipMemcpyHostToDevice, s));
-    if (ns) GFS_HIP(hipMemcpyAsync(h->d_in_s.p, source_xyzw, (size_t)ns * 16, hipMemcpyHostToDevice, s));
-    GFS_HIP(hipMemcpyAsync(h->d_nt.p, &nt, sizeof(int), hipMemcpyHostToDevice, s));
-    GFS_HIP(hipMemcpyAsync(h->d_ns.p, &ns, sizeof(int), hipMemcpyHostToDevice, s));
-    GFS_HIP(hipStreamSynchronize(s));
-  }
+  std::lock_guard<std::recursive_mutex> lk(h->mu);  // staging buffers are shared: upload + run are one critical section
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  if (nt) GFS_HIP(hipMemcpyAsync(h->d_in_t.p, target_xyzw, (size_t)nt * 16, hipMemcpyHostToDevice, s));
+  if (ns) GFS_HIP(hipMemcpyAsync(h->d_in_s.p, source_xyzw, (size_t)ns * 16, hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_nt.p, &nt, sizeof(int), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemcpyAsync(h->d_ns.p, &ns, sizeof(int), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipStreamSynchronize(s));
   return gfs_gicp_align_batch_device(h, h->d_in_t.p, h->d_nt.p, h->d_in_s.p, h->d_ns.p, 1, h->P, init_T_target_source, cfg,
                                      out, nullptr);
+}
+
+// Test hook (tests/test_gpu_gicp.py): runs the voxel sort of the preprocessing (voxel_qsort.hpp) on n caller-supplied 64-bit
+// keys laid out like voxel keys (3 x 21 bits, or all ones = invalid) and returns the permutation.
+int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsigned* perm_out) {
+  GFS_REQUIRE(h && keys && perm_out && n >= 0 && n <= h->P, GFS_ERR_INVALID_ARG, "gfs_test_voxel_sort: invalid argument");
+  std::lock_guard<std::recursive_mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int P = h->P;
+  std::vector<unsigned> iota((size_t)std::max(n, 1));
+  for (int i = 0; i < n; i++) iota[i] = (unsigned)i;
+  int counts[2] = {n, 0};
+  GFS_HIP(hipMemcpyAsync(h->d_counts.p, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+  if (n) GFS_HIP(hipMemcpyAsync(h->d_keys0.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  if (n) GFS_HIP(hipMemcpyAsync(h->d_val0.p, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  const int leaf_parts = std::max(1, std::min(64, P / 2048));
+  GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, 2 * sizeof(int), s));
+  GFS_HIP(voxel_qsort_top(h, 2, s, -1));
+  {
+    const int rc_leaf = voxel_qsort_leaves(h, 2, leaf_parts, s, -1);
+    if (rc_leaf) return rc_leaf;
+  }
+  if (n) GFS_HIP(hipMemcpyAsync(perm_out, h->d_val0.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
 }
 
 int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, double* covs, int cap, int* m) {
   GFS_REQUIRE(h && b >= 0 && b < h->last_B && (which == 0 || which == 1) && m, GFS_ERR_INVALID_ARG,
               "gfs_gicp_fetch_preprocessed: invalid argument");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::lock_guard<std::recursive_mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
   GFS_HIP(hipDeviceSynchronize());
   const int c = 2 * b + (which ? h->last_src_slot : 1 - h->last_src_slot);

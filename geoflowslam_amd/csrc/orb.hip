@@ -1242,6 +1242,9 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
                   G.cells.size() <= h->cap_cells && G.kp_cap <= h->cap_kp,
               GFS_ERR_CAPACITY, "image %dx%d needs more workspace than the handle reserved", cols, rows);
   hipStream_t s = h->stream;
+  // A batch launched on a caller-supplied stream (gfs_orb_extract_batch_device returns without waiting) may still be reading
+  // the tables of the previous image size: wait for everything in flight on the device before they are rewritten (rare path).
+  if (h->geom_rows != 0) GFS_HIP(hipDeviceSynchronize());
   GFS_HIP(hipMemcpyAsync(h->d_levels.p, G.levels.data(), G.levels.size() * sizeof(LevelDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_cells.p, G.cells.data(), G.cells.size() * sizeof(CellDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_tiles.p, G.blur_tiles.data(), G.blur_tiles.size() * sizeof(BlurTileDev), hipMemcpyHostToDevice, s));

@@ -1,0 +1,1276 @@
+// Device replica of small_gicp's quick_sort_omp (reference Thirdparty/small_gicp/include/small_gicp/util/sort_omp.hpp:58-85)
+// as it is used by voxelgrid_sampling_omp (util/downsampling_omp.hpp:57) on (voxel key, point index) pairs with a
+// comparator that looks at the key only.  That sort is NOT stable, and which points of a voxel end up on either side
+// of a 1024-element block boundary of the sorted array (downsampling_omp.hpp:63-90) follows from the exact permutation
+// it produces.  The permutation is a deterministic function of the key sequence (the OpenMP tasks work on disjoint
+// ranges), so it is reproduced here step for step:
+//
+//   quick_sort_omp_impl, n >= 1024:  pivot = median of three medians of three (9 samples at n/8 strides),
+//       middle1 = std::partition(first, last, key < pivot), middle2 = std::partition(middle1, last, !(pivot < key)),
+//       recurse on [first, middle1) and [middle2, last)                                   -> k_voxel_qsort_top
+//   n < 1024: std::sort = libstdc++ introsort (median-of-3 to first, unguarded Hoare partition, depth limit
+//       2 lg n with heap-sort fallback, final insertion sort)                             -> k_voxel_qsort_leaf
+//
+// Parallel form (validated against libstdc++ on the CPU before it was written for the GPU):
+//   * std::partition (bidirectional version, bits/stl_algo.h __partition): with m = number of elements satisfying the
+//     predicate, the k-th non-satisfying element among the first m positions (from the left) is swapped with the k-th
+//     satisfying element among the remaining positions (from the right); nothing else moves.  Ranks come from prefix
+//     counts, the exchange goes through a side buffer -> one workgroup partitions ALL active ranges of a cloud per sweep.
+//   * __unguarded_partition(first + 1, last, pivot = *first): left stoppers L (key >= pivot, ascending positions), right
+//     stoppers R (key <= pivot, descending positions); pairs k with L_k < R_k are swapped; cut = min(L_K, R_{K-1}).
+//   * __final_insertion_sort is a stable insertion sort of a sequence of chunks (<= 16 elements, the leaves of the
+//     introsort recursion) that are already in order among themselves: it equals a stable sort of every chunk, i.e.
+//     final position = chunk start + rank of (key, position) inside the chunk.
+// tests/test_gpu_gicp.py compares the permutation with the oracle's (which calls libstdc++'s std::partition / std::sort).
+#pragma once
+
+namespace vqs {
+
+typedef unsigned long long u64;
+constexpr int kMaxSeg = 1024;      // active ranges (each >= 1024 elements) of one cloud: clouds of up to 2^20 points
+constexpr int kLeafThreshold = 1024;  // sort_omp.hpp:61
+constexpr int kIntroThreshold = 16;   // libstdc++ _S_threshold
+
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// block-wide exclusive scan, 1024 threads (same helper as gicp.hip's, local copy to keep this header self-contained)
+__device__ __forceinline__ int scan_1024(int v, int* s_wave /*16*/, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int ofs = 1; ofs < 64; ofs <<= 1) {
+    const int t = __shfl_up(incl, ofs, 64);
+    if (lane >= ofs) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < 16; w++) {
+    const int t = s_wave[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+__device__ __forceinline__ u64 med3(u64 a, u64 b, u64 c) {  // sort_omp.hpp:66-68 on the keys
+  return a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b));
+}
+
+// One sweep over the elements of all active ranges ("virtual" index space = the ranges concatenated): wave w owns the
+// virtual indices [w * 64 * E, (w + 1) * 64 * E), row r of it is one coalesced 64-element access.  Ranges are >= 1024
+// long, so a row touches at most two of them.  f(valid, s, v) is called by all lanes of the wave for every row.
+template <class F>
+__device__ __forceinline__ void sweep(int A, int E, int nseg, const int* seg_v, F&& f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v0 = wave * 64 * E;
+  if (v0 >= A) return;
+  int lo = 0, hi = nseg;  // last s with seg_v[s] <= v0
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_v[mid] <= v0)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  int s_w = lo;
+  for (int r = 0; r < E; r++) {
+    const int row0 = v0 + r * 64;
+    if (row0 >= A) break;
+    const int v = row0 + lane;
+    const bool valid = v < A;
+    const int nxt = seg_v[s_w + 1];
+    const int s = (valid && v >= nxt) ? s_w + 1 : s_w;
+    f(valid, s, v);
+    if (row0 + 64 >= nxt && s_w + 1 < nseg) s_w++;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_voxel_qsort_top: one 1024-thread workgroup per cloud.  Compacts the 3 x 21-bit voxel keys to the cloud's extent
+// (order preserving, like k_radix_sort), then runs the n >= 1024 levels of quick_sort_omp_impl for all ranges of a level
+// at once; ranges that drop below 1024 elements are appended to the cloud's leaf list for k_voxel_qsort_leaf.
+// keys / vals are permuted in place; side_k / side_v hold the elements in flight of a partition sweep.
+// kinfo[8c ..] = {xmin, ymin, zmin, bx, by, total bits}.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_voxel_qsort_top(u64* keys_all, unsigned* vals_all, u64* side_k_all, unsigned* side_v_all,
+                                                          const int* __restrict__ counts, int P, int* __restrict__ which,
+                                                          int* __restrict__ kinfo, unsigned* __restrict__ leaf_all,
+                                                          int* __restrict__ nleaf, int only, int only_flagged) {
+  constexpr u64 kInvalid = ~0ull;
+  constexpr int kCB = 21, kCM = (1 << kCB) - 1;
+  __shared__ int seg_b[kMaxSeg], seg_e[kMaxSeg], seg_v[kMaxSeg + 1], seg_base[kMaxSeg + 1], seg_off[kMaxSeg], seg_m1[kMaxSeg];
+  __shared__ u64 seg_pv[kMaxSeg];
+  __shared__ int s_wave[16];
+  __shared__ int s_nseg, s_nleaf, s_A;
+  __shared__ int s_mn[3], s_mx[3];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (only >= 0 && (c & 1) != only) return;
+  if (only_flagged && kinfo[8 * c + 6] == 0) return;  // k_voxel_qsort_top_reg took this cloud
+  const int n = counts[c];
+  u64* ka = keys_all + (size_t)c * P;
+  unsigned* va = vals_all + (size_t)c * P;
+  u64* sk = side_k_all + (size_t)c * P;
+  unsigned* sv = side_v_all + (size_t)c * P;
+  unsigned* leaf = leaf_all + (size_t)c * P;
+  // ---- key compaction (see k_radix_sort)
+  if (tid < 3) {
+    s_mn[tid] = 0x7fffffff;
+    s_mx[tid] = -1;
+  }
+  __syncthreads();
+  {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+    for (int i = tid; i < n; i += 1024) {
+      const u64 k = ka[i];
+      if (k == kInvalid) continue;
+      const int f[3] = {(int)(k & kCM), (int)((k >> kCB) & kCM), (int)(k >> (2 * kCB))};
+      for (int a = 0; a < 3; a++) {
+        mn[a] = min(mn[a], f[a]);
+        mx[a] = max(mx[a], f[a]);
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      if (mx[a] >= 0) {
+        atomicMin(&s_mn[a], mn[a]);
+        atomicMax(&s_mx[a], mx[a]);
+      }
+    }
+  }
+  __syncthreads();
+  const bool any_valid = s_mx[0] >= 0;
+  const int mnx = any_valid ? s_mn[0] : 0, mny = any_valid ? s_mn[1] : 0, mnz = any_valid ? s_mn[2] : 0;
+  auto nbits = [](int range) {
+    int b = 1;
+    while ((1 << b) <= range) b++;
+    return b;
+  };
+  const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
+            bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
+  for (int i = tid; i < n; i += 1024) {
+    const u64 k = ka[i];
+    if (k == kInvalid) continue;
+    const u64 x = (k & kCM) - mnx, y = ((k >> kCB) & kCM) - mny, z = (k >> (2 * kCB)) - mnz;
+    ka[i] = x | (y << bx) | (z << (bx + by));
+  }
+  if (tid == 0) {
+    int* ki = kinfo + 8 * c;
+    ki[0] = mnx;
+    ki[1] = mny;
+    ki[2] = mnz;
+    ki[3] = bx;
+    ki[4] = by;
+    ki[5] = bx + by + bz;
+    which[c] = 0;  // sorted in place
+    s_nleaf = 0;
+    s_nseg = 0;
+    if (n >= kLeafThreshold) {
+      seg_b[0] = 0;
+      seg_e[0] = n;
+      s_nseg = 1;
+    } else if (n >= 2) {
+      leaf[0] = 0u;
+      leaf[1] = (unsigned)n;
+      s_nleaf = 1;
+    }
+  }
+  __syncthreads();
+  // ---- levels of the 3-way quicksort
+  while (true) {
+    const int nseg = s_nseg;  // uniform (read after a barrier)
+    if (nseg == 0) break;
+    int my_b = 0, my_e = 0;
+    if (tid < nseg) {
+      my_b = seg_b[tid];
+      my_e = seg_e[tid];
+      const int len = my_e - my_b, off = len / 8;  // sort_omp.hpp:70-75
+      const u64* f = ka + my_b;
+      const u64 m1 = med3(f[0], f[off], f[off * 2]), m2 = med3(f[off * 3], f[off * 4], f[off * 5]),
+                m3 = med3(f[off * 6], f[off * 7], f[len - 1]);
+      seg_pv[tid] = med3(m1, m2, m3);
+      seg_off[tid] = 0;
+    }
+    {
+      int tot;
+      const int ex = scan_1024(tid < nseg ? my_e - my_b : 0, s_wave, &tot);
+      if (tid < nseg) seg_v[tid] = ex;
+      if (tid == 0) {
+        seg_v[nseg] = tot;
+        s_A = tot;
+      }
+    }
+    __syncthreads();
+    const int A = s_A, E = (A + 1023) / 1024;
+    for (int pass = 0; pass < 2; pass++) {
+      // pass 0: std::partition(first, last, key < pivot); pass 1: std::partition(middle1, last, !(pivot < key))
+      auto flag_of = [&](bool valid, int s, int v, u64* key_out, int* i_out) {
+        bool flag = false;
+        if (valid) {
+          const int li = v - seg_v[s], i = seg_b[s] + li;
+          const u64 key = ka[i], pv = seg_pv[s];
+          *key_out = key;
+          *i_out = i;
+          flag = pass == 0 ? key < pv : (li >= seg_off[s] && !(pv < key));
+        }
+        return flag;
+      };
+      // (1) flagged elements per wave
+      {
+        int cnt = 0;
+        sweep(A, E, nseg, seg_v, [&](bool valid, int s, int v) {
+          u64 key;
+          int i;
+          const bool flag = flag_of(valid, s, v, &key, &i);
+          cnt += __popcll(__ballot(flag));
+        });
+        if (lane == 0) s_wave[wave] = cnt;
+      }
+      __syncthreads();
+      // (2) prefix count at the first element of every range
+      int wave_base = 0, total = 0;
+      for (int w = 0; w < 16; w++) {
+        const int t = s_wave[w];
+        if (w < wave) wave_base += t;
+        total += t;
+      }
+      {
+        int run = wave_base;
+        sweep(A, E, nseg, seg_v, [&](bool valid, int s, int v) {
+          u64 key;
+          int i;
+          const bool flag = flag_of(valid, s, v, &key, &i);
+          const u64 b = __ballot(flag);
+          if (valid && v == seg_v[s]) seg_base[s] = run + __popcll(b & lanemask_lt());
+          run += __popcll(b);
+        });
+        if (tid == 0) seg_base[nseg] = total;
+      }
+      __syncthreads();
+      // (3) the elements that std::partition swaps park themselves in the side buffer, (4) and fetch their partner
+      for (int step = 0; step < 2; step++) {
+        int run = wave_base;
+        sweep(A, E, nseg, seg_v, [&](bool valid, int s, int v) {
+          u64 key = 0;
+          int i = 0;
+          const bool flag = flag_of(valid, s, v, &key, &i);
+          const u64 b = __ballot(flag);
+          const int pre = run + __popcll(b & lanemask_lt());
+          run += __popcll(b);
+          if (!valid) return;
+          const int vs = seg_v[s], off = seg_off[s], len = seg_e[s] - seg_b[s];
+          const int lr = v - vs - off;  // index inside the partitioned region
+          if (lr < 0) return;
+          const int m = seg_base[s + 1] - seg_base[s], r = pre - seg_base[s];
+          int mine = -1, theirs = -1;
+          if (lr < m && !flag) {  // k-th misplaced element of the front part, from the left
+            const int k = lr - r;
+            mine = vs + off + k;
+            theirs = vs + len - 1 - k;
+          } else if (lr >= m && flag) {  // k-th misplaced element of the back part, from the right
+            const int k = m - r - 1;
+            mine = vs + len - 1 - k;
+            theirs = vs + off + k;
+          }
+          if (mine < 0) return;
+          if (step == 0) {
+            sk[mine] = key;
+            sv[mine] = va[i];
+          } else {
+            ka[i] = sk[theirs];
+            va[i] = sv[theirs];
+          }
+        });
+        __syncthreads();
+      }
+      if (tid < nseg) {
+        const int m = seg_base[tid + 1] - seg_base[tid];
+        if (pass == 0) {
+          seg_m1[tid] = my_b + m;
+          seg_off[tid] = m;
+        } else {
+          seg_off[tid] += m;  // middle2 - first
+        }
+      }
+      __syncthreads();
+    }
+    // ---- children: [first, middle1) and [middle2, last)
+    int child_b[2] = {0, 0}, child_e[2] = {0, 0}, nact = 0;
+    if (tid < nseg) {
+      child_b[0] = my_b;
+      child_e[0] = seg_m1[tid];
+      child_b[1] = my_b + seg_off[tid];
+      child_e[1] = my_e;
+      for (int k = 0; k < 2; k++) nact += (child_e[k] - child_b[k] >= kLeafThreshold) ? 1 : 0;
+    }
+    int tot_act;
+    int pos = scan_1024(nact, s_wave, &tot_act);
+    __syncthreads();  // everybody has read the old tables
+    if (tid < nseg) {
+      for (int k = 0; k < 2; k++) {
+        const int len = child_e[k] - child_b[k];
+        if (len >= kLeafThreshold) {
+          seg_b[pos] = child_b[k];
+          seg_e[pos] = child_e[k];
+          pos++;
+        } else if (len >= 2) {
+          const int slot = atomicAdd(&s_nleaf, 1);
+          leaf[2 * slot] = (unsigned)child_b[k];
+          leaf[2 * slot + 1] = (unsigned)child_e[k];
+        }
+      }
+    }
+    if (tid == 0) s_nseg = tot_act;
+    __syncthreads();
+  }
+  if (tid == 0) nleaf[c] = s_nleaf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_voxel_qsort_top_reg<EMAX>: the same levels for the common case — keys that compact to <= 31 bits and clouds of at most
+// 1024 * EMAX points — with every thread caching its E <= EMAX elements (wave w owns positions [64 E w, 64 E (w + 1)), row r
+// = one coalesced access) in registers for the whole partition sweep: per level one load, the four steps of std::partition
+// (flag counts per wave -> prefix at the range starts -> misplaced elements parked in the side buffer -> partners fetched),
+// one store.  The second std::partition of a level (elements equal to the pivot to the front of [middle1, last)) moves at
+// most as many elements as there are points in the pivot's voxel: the lanes that end up holding such a key report their
+// positions, and one thread per range replays the few swaps directly in memory (a full register sweep only if a range has
+// more than kEq of them).  Clouds that do not qualify are flagged (kinfo[8c + 6] = 1) for k_voxel_qsort_top.
+// ------------------------------------------------------------------------------------------------
+template <int EMAX>
+__global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, unsigned* vals_all, u64* side_all, unsigned* kscr_all,
+                                                              const int* __restrict__ counts, int P, int* __restrict__ which,
+                                                              int* __restrict__ kinfo, unsigned* __restrict__ leaf_all,
+                                                              int* __restrict__ nleaf, int only) {
+  constexpr u64 kInvalid = ~0ull;
+  constexpr int kCB = 21, kCM = (1 << kCB) - 1;
+  constexpr int kSeg = EMAX + 1, kEq = 32;
+  __shared__ int seg_b[kSeg], seg_e[kSeg], seg_base[kSeg + 1], seg_m1[kSeg], seg_m2[kSeg], eq_cnt[kSeg], eq_pos[kSeg][kEq];
+  __shared__ unsigned seg_pv[kSeg];
+  __shared__ int s_wave[16];
+  __shared__ int s_nseg, s_nleaf, s_over;
+  __shared__ int s_mn[3], s_mx[3];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (only >= 0 && (c & 1) != only) return;
+  const int n = counts[c];
+  u64* ka = keys_all + (size_t)c * P;
+  unsigned* va = vals_all + (size_t)c * P;
+  u64* side = side_all + (size_t)c * P;
+  unsigned* kscr = kscr_all + (size_t)c * P;
+  unsigned* leaf = leaf_all + (size_t)c * P;
+  if (tid < 3) {
+    s_mn[tid] = 0x7fffffff;
+    s_mx[tid] = -1;
+  }
+  __syncthreads();
+  {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+    for (int i = tid; i < n; i += 1024) {
+      const u64 k = ka[i];
+      if (k == kInvalid) continue;
+      const int f[3] = {(int)(k & kCM), (int)((k >> kCB) & kCM), (int)(k >> (2 * kCB))};
+      for (int a = 0; a < 3; a++) {
+        mn[a] = min(mn[a], f[a]);
+        mx[a] = max(mx[a], f[a]);
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      if (mx[a] >= 0) {
+        atomicMin(&s_mn[a], mn[a]);
+        atomicMax(&s_mx[a], mx[a]);
+      }
+    }
+  }
+  __syncthreads();
+  const bool any_valid = s_mx[0] >= 0;
+  const int mnx = any_valid ? s_mn[0] : 0, mny = any_valid ? s_mn[1] : 0, mnz = any_valid ? s_mn[2] : 0;
+  auto nbits = [](int range) {
+    int b = 1;
+    while ((1 << b) <= range) b++;
+    return b;
+  };
+  const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
+            bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
+  if (bx + by + bz > 31 || n > 1024 * EMAX) {  // uniform: left to the general kernel
+    if (tid == 0) kinfo[8 * c + 6] = 1;
+    return;
+  }
+  for (int i = tid; i < n; i += 1024) {
+    const u64 k = ka[i];
+    unsigned kk = 0xffffffffu;
+    if (k != kInvalid) kk = (unsigned)((k & kCM) - mnx) | ((unsigned)(((k >> kCB) & kCM) - mny) << bx) | ((unsigned)((k >> (2 * kCB)) - mnz) << (bx + by));
+    kscr[i] = kk;
+  }
+  if (tid == 0) {
+    int* ki = kinfo + 8 * c;
+    ki[0] = mnx;
+    ki[1] = mny;
+    ki[2] = mnz;
+    ki[3] = bx;
+    ki[4] = by;
+    ki[5] = bx + by + bz;
+    ki[6] = 0;
+    which[c] = 0;
+    s_nleaf = 0;
+    s_nseg = 0;
+    if (n >= kLeafThreshold) {
+      seg_b[0] = 0;
+      seg_e[0] = n;
+      s_nseg = 1;
+    } else if (n >= 2) {
+      leaf[0] = 0u;
+      leaf[1] = (unsigned)n;
+      s_nleaf = 1;
+    }
+  }
+  __syncthreads();
+  const int E = (n + 1023) / 1024, i0 = wave * E * 64 + lane;
+  const u64 ltm = lanemask_lt();
+  unsigned key[EMAX], val[EMAX];
+  while (true) {
+    const int nseg = s_nseg;
+    if (nseg == 0) break;
+    if (tid < nseg) {
+      const int b = seg_b[tid], len = seg_e[tid] - b, off = len / 8;  // sort_omp.hpp:70-75
+      const unsigned* f = kscr + b;
+      auto m3 = [](unsigned x, unsigned y, unsigned z) { return x < y ? (y < z ? y : (x < z ? z : x)) : (x < z ? x : (y < z ? z : y)); };
+      const unsigned m1 = m3(f[0], f[off], f[off * 2]), m2 = m3(f[off * 3], f[off * 4], f[off * 5]),
+                     mm = m3(f[off * 6], f[off * 7], f[len - 1]);
+      seg_pv[tid] = m3(m1, m2, mm);
+      eq_cnt[tid] = 0;
+    }
+    if (tid == 0) s_over = 0;
+#pragma unroll
+    for (int r = 0; r < EMAX; r++) {
+      key[r] = 0;
+      val[r] = 0;
+      if (r < E) {
+        const int i = i0 + r * 64;
+        if (i < n) {
+          key[r] = kscr[i];
+          val[r] = va[i];
+        }
+      }
+    }
+    __syncthreads();
+    // one std::partition sweep over all ranges, on the cached elements.  mode 0: key < pivot over [first, last);
+    // mode 1: !(pivot < key) over [middle1, last).  The rows of a wave walk through the (sorted) ranges: the parameters of
+    // the current range A and the next one B are wave-uniform, a row touches at most these two.
+    struct SegP {
+      int b, e, first, base, m;
+      unsigned pv;
+    };
+    auto partition_sweep = [&](int mode) {
+      auto load_seg = [&](int sidx, bool with_counts) {
+        SegP q;
+        q.b = q.e = q.first = 0x7fffffff;
+        q.base = q.m = 0;
+        q.pv = 0;
+        if (sidx < nseg) {  // wave-uniform: kept in scalar registers
+          q.b = __builtin_amdgcn_readfirstlane(seg_b[sidx]);
+          q.e = __builtin_amdgcn_readfirstlane(seg_e[sidx]);
+          q.first = mode == 0 ? q.b : __builtin_amdgcn_readfirstlane(seg_m1[sidx]);
+          q.pv = (unsigned)__builtin_amdgcn_readfirstlane((int)seg_pv[sidx]);
+          if (with_counts) {
+            q.base = __builtin_amdgcn_readfirstlane(seg_base[sidx]);
+            q.m = __builtin_amdgcn_readfirstlane(seg_base[sidx + 1]) - q.base;
+          }
+        }
+        return q;
+      };
+      // per row: advance (A, B), then flag / range parameters of every lane
+#define VQS_ROW_BEGIN(with_counts)                                       \
+  const int row0 = (wave * E + r) * 64, i = row0 + lane;                 \
+  while (row0 >= A.e && sA < nseg) {                                     \
+    A = B;                                                               \
+    sA++;                                                                \
+    B = load_seg(sA + 1, with_counts);                                   \
+  }                                                                      \
+  const bool inB = i >= B.b, in = inB || (i >= A.b && i < A.e);          \
+  const unsigned pv = inB ? B.pv : A.pv;                                 \
+  const int first = inB ? B.first : A.first;                             \
+  const bool flag = in && (mode == 0 ? key[r] < pv : (i >= first && !(pv < key[r])));
+      int cnt = 0;
+      {
+        int sA = 0;
+        SegP A = load_seg(0, false), B = load_seg(1, false);
+#pragma unroll
+        for (int r = 0; r < EMAX; r++)
+          if (r < E) {
+            VQS_ROW_BEGIN(false)
+            cnt += __popcll(__ballot(flag));
+          }
+      }
+      if (lane == 0) s_wave[wave] = cnt;
+      __syncthreads();
+      int wave_base = 0, total = 0;
+      for (int w = 0; w < 16; w++) {
+        const int t = s_wave[w];
+        if (w < wave) wave_base += t;
+        total += t;
+      }
+      {
+        int run = wave_base, sA = 0;
+        SegP A = load_seg(0, false), B = load_seg(1, false);
+#pragma unroll
+        for (int r = 0; r < EMAX; r++)
+          if (r < E) {
+            VQS_ROW_BEGIN(false)
+            const u64 bl = __ballot(flag);
+            if (in && i == (inB ? B.b : A.b)) seg_base[inB ? sA + 1 : sA] = run + __popcll(bl & ltm);
+            run += __popcll(bl);
+          }
+        if (tid == 0) seg_base[nseg] = total;
+      }
+      __syncthreads();
+      for (int step = 0; step < 2; step++) {
+        int run = wave_base, sA = 0;
+        SegP A = load_seg(0, true), B = load_seg(1, true);
+#pragma unroll
+        for (int r = 0; r < EMAX; r++)
+          if (r < E) {
+            VQS_ROW_BEGIN(true)
+            const u64 bl = __ballot(flag);
+            const int pre = run + __popcll(bl & ltm);
+            run += __popcll(bl);
+            if (in) {
+              const int lr = i - first, last = inB ? B.e : A.e;
+              if (lr >= 0) {
+                const int m = inB ? B.m : A.m, rk = pre - (inB ? B.base : A.base);
+                int mine = -1, theirs = -1;
+                if (lr < m && !flag) {  // k-th misplaced element of the front part, from the left
+                  const int k = lr - rk;
+                  mine = first + k;
+                  theirs = last - 1 - k;
+                } else if (lr >= m && flag) {  // k-th misplaced element of the back part, from the right
+                  const int k = m - rk - 1;
+                  mine = last - 1 - k;
+                  theirs = first + k;
+                }
+                if (mine >= 0) {
+                  if (step == 0) {
+                    side[mine] = (u64)key[r] | ((u64)val[r] << 32);
+                  } else {
+                    const u64 t = side[theirs];
+                    key[r] = (unsigned)t;
+                    val[r] = (unsigned)(t >> 32);
+                  }
+                }
+              }
+              // after the first partition: who holds a key equal to the pivot (they all sit in [middle1, last) now)
+              if (step == 1 && mode == 0 && key[r] == pv) {
+                const int sidx = inB ? sA + 1 : sA;
+                const int slot = atomicAdd(&eq_cnt[sidx], 1);
+                if (slot < kEq) eq_pos[sidx][slot] = i;
+              }
+            }
+          }
+        __syncthreads();
+      }
+#undef VQS_ROW_BEGIN
+    };
+    auto store_back = [&]() {
+#pragma unroll
+      for (int r = 0; r < EMAX; r++)
+        if (r < E) {
+          const int i = i0 + r * 64;
+          if (i < n) {
+            kscr[i] = key[r];
+            va[i] = val[r];
+          }
+        }
+    };
+    partition_sweep(0);
+    if (tid < nseg) seg_m1[tid] = seg_b[tid] + (seg_base[tid + 1] - seg_base[tid]);
+    store_back();
+    __syncthreads();
+    if (tid < nseg) {  // second partition by replaying its few swaps
+      const int m = eq_cnt[tid], m1 = seg_m1[tid];
+      seg_m2[tid] = m1 + m;
+      if (m > kEq) {
+        s_over = 1;
+      } else {
+        int* q = eq_pos[tid];  // sorted in place (ascending positions)
+#pragma unroll 1
+        for (int a = 1; a < m; a++) {
+          const int v = q[a];
+          int bpos = a;
+          while (bpos > 0 && q[bpos - 1] > v) {
+            q[bpos] = q[bpos - 1];
+            bpos--;
+          }
+          q[bpos] = v;
+        }
+        // k-th position of [m1, m1 + m) not holding a pivot key (from the left) <-> k-th pivot key beyond (from the right)
+        int a = 0, t = m - 1;
+#pragma unroll 1
+        for (int j = m1; j < m1 + m; j++) {
+          if (a < m && q[a] == j) {
+            a++;
+            continue;
+          }
+          const int jt = q[t--];  // >= m1 + m by counting
+          const unsigned kj = kscr[j], vj = va[j];
+          kscr[j] = kscr[jt];
+          va[j] = va[jt];
+          kscr[jt] = kj;
+          va[jt] = vj;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_over) {  // a voxel with more than kEq points: the general sweep (reload, partition, store)
+#pragma unroll
+      for (int r = 0; r < EMAX; r++)
+        if (r < E) {
+          const int i = i0 + r * 64;
+          if (i < n) {
+            key[r] = kscr[i];
+            val[r] = va[i];
+          }
+        }
+      partition_sweep(1);
+      if (tid < nseg) seg_m2[tid] = seg_m1[tid] + (seg_base[tid + 1] - seg_base[tid]);
+      store_back();
+      __syncthreads();
+    }
+    // children [first, middle1) and [middle2, last)
+    int child_b[2] = {0, 0}, child_e[2] = {0, 0}, nact = 0;
+    if (tid < nseg) {
+      child_b[0] = seg_b[tid];
+      child_e[0] = seg_m1[tid];
+      child_b[1] = seg_m2[tid];
+      child_e[1] = seg_e[tid];
+      for (int k = 0; k < 2; k++) nact += (child_e[k] - child_b[k] >= kLeafThreshold) ? 1 : 0;
+    }
+    int tot_act;
+    int pos = scan_1024(nact, s_wave, &tot_act);
+    __syncthreads();
+    if (tid < nseg) {
+      for (int k = 0; k < 2; k++) {
+        const int len = child_e[k] - child_b[k];
+        if (len >= kLeafThreshold) {
+          seg_b[pos] = child_b[k];
+          seg_e[pos] = child_e[k];
+          pos++;
+        } else if (len >= 2) {
+          const int slot = atomicAdd(&s_nleaf, 1);
+          leaf[2 * slot] = (unsigned)child_b[k];
+          leaf[2 * slot + 1] = (unsigned)child_e[k];
+        }
+      }
+    }
+    if (tid == 0) s_nseg = tot_act;
+    __syncthreads();
+  }
+  // the keys go back as 64-bit compacted keys (k_voxel_qsort_leaf, k_voxel_reduce)
+  for (int i = tid; i < n; i += 1024) {
+    const unsigned k = kscr[i];
+    ka[i] = k == 0xffffffffu ? kInvalid : (u64)k;
+  }
+  if (tid == 0) nleaf[c] = s_nleaf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_voxel_qsort_leaf<KT>: std::sort of every leaf range (< 1024 elements) by one wave, in LDS.  KT = unsigned when the
+// cloud's compacted keys fit 31 bits (kinfo[5] <= 31; the invalid key becomes 0xffffffff), else u64; clouds of the
+// other width are skipped (both instantiations are launched).
+// ------------------------------------------------------------------------------------------------
+template <typename KT>
+struct LeafLds {
+  KT K[4][1024];
+  unsigned short Pm[4][1024], l0[4][1024], l1[4][1024], cl[4][1024];
+  unsigned short st[4][3 * 40];
+};
+
+template <typename KT>
+__device__ __forceinline__ void heap_adjust_soa(KT* K, unsigned short* Pm, int first, int hole, int len, KT vk,
+                                                unsigned short vp) {  // libstdc++ __adjust_heap + __push_heap
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (K[first + child] < K[first + child - 1]) child--;
+    K[first + hole] = K[first + child];
+    Pm[first + hole] = Pm[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    K[first + hole] = K[first + child - 1];
+    Pm[first + hole] = Pm[first + child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && K[first + parent] < vk) {
+    K[first + hole] = K[first + parent];
+    Pm[first + hole] = Pm[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  K[first + hole] = vk;
+  Pm[first + hole] = vp;
+}
+
+template <typename KT>
+__device__ void heap_sort_soa(KT* K, unsigned short* Pm, int lo, int hi) {  // __partial_sort(first, last, last), one lane
+  const int len = hi - lo;
+  if (len >= 2) {
+    int parent = (len - 2) / 2;
+    while (true) {
+      heap_adjust_soa<KT>(K, Pm, lo, parent, len, K[lo + parent], Pm[lo + parent]);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  int last = hi;
+  while (last - lo > 1) {
+    --last;
+    const KT vk = K[last];
+    const unsigned short vp = Pm[last];
+    K[last] = K[lo];
+    Pm[last] = Pm[lo];
+    heap_adjust_soa<KT>(K, Pm, lo, 0, last - lo, vk, vp);
+  }
+}
+
+#define VQS_WAVE_SYNC()                                  \
+  do {                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// Wave-cooperative __partial_sort(first, last, last) (= __make_heap + __sort_heap) on K / Pm [lo, hi) in LDS: the same
+// comparisons and moves as libstdc++'s serial code, arranged so that a pop costs a few LDS round trips instead of ~3 per
+// heap level.  __make_heap sifts the nodes in decreasing index order; nodes of one depth have disjoint subtrees, so a whole
+// depth is done at once (one lane per node, each running the serial __adjust_heap).  A pop walks the hole from the root to a
+// leaf along the larger children (bottom-up variant: no comparison with the value on the way down): the 63 lanes read the
+// child pairs of the next SIX levels below the hole at once, the walk through them is scalar bit arithmetic on two ballots,
+// and the lanes on the path write the chosen children up; __push_heap then climbs (rarely more than a level).
+template <typename KT>
+__device__ void heap_sort_wave(KT* K, unsigned short* Pm, int lo, int hi) {
+  const int lane = threadIdx.x & 63;
+  const int len = hi - lo;
+  KT* H = K + lo;
+  unsigned short* Q = Pm + lo;
+  if (len < 2) return;
+  {
+    const int last_parent = (len - 2) / 2;
+    for (int d = 31 - __clz(last_parent + 1); d >= 0; d--) {
+      const int first_node = (1 << d) - 1, end_node = min((2 << d) - 2, last_parent);
+      for (int base = first_node; base <= end_node; base += 64) {
+        const int node = base + lane;
+        if (node <= end_node) heap_adjust_soa<KT>(K, Pm, lo, node, len, H[node], Q[node]);
+      }
+      VQS_WAVE_SYNC();
+    }
+  }
+  const int t = lane + 1, dt = 31 - __clz(t), tofs = t - (1 << dt);  // local node t (1-based) of the 6-level subtree below the hole
+  auto bcast = [](KT v, int from) {  // value of lane `from` (wave-uniform index)
+    if constexpr (sizeof(KT) == 4) {
+      return (KT)__builtin_amdgcn_readlane((int)v, from);
+    } else {
+      const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, from);
+      const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), from);
+      return (KT)(((u64)hi32 << 32) | lo32);
+    }
+  };
+#ifdef VQS_NO_POPS
+  return;
+#endif
+  for (int L = len - 1; L >= 1; L--) {  // __pop_heap(first, first + L, first + L): value = H[L], H[L] = H[0], sift in [0, L)
+    // (the popped value and the old root are not needed by the descent: no wait on these reads until the end of the pop)
+    const KT vk = H[L], rk = H[0];
+    const unsigned short vp = Q[L], rp = Q[0];
+    const int half = (L - 1) / 2;  // nodes below `half` have two children
+    int hole = 0;
+    KT upk = 0;  // the key just moved into the parent of the hole: __push_heap's first comparison needs no LDS read
+    unsigned short upp = 0;
+    bool moved = false;
+    while (hole < half) {
+      const int g = ((hole + 1) << dt) + tofs - 1;
+      const bool valid = lane < 63 && g < half;
+      KT kl = 0, kr = 0;
+      unsigned short pl = 0, pr = 0;
+      if (valid) {
+        kl = H[2 * g + 1];
+        kr = H[2 * g + 2];
+        pl = Q[2 * g + 1];
+        pr = Q[2 * g + 2];
+      }
+      const bool left = valid && kr < kl;  // __adjust_heap: the second child unless it is smaller than the first
+      // the walk: every lane knows the local node its hole moves to next (0: no two children), lane to lane by readlane
+      const int nxt = valid ? 2 * t + (left ? 0 : 1) : 0;
+      int tt = 1, last_t = 1;
+      u64 pathmask = 0;
+      while (tt < 64) {
+        const int nx = __builtin_amdgcn_readlane(nxt, tt - 1);
+        if (nx == 0) break;
+        pathmask |= 1ull << (tt - 1);
+        last_t = tt;
+        tt = nx;
+      }
+      const KT ck = left ? kl : kr;
+      const unsigned short cp = left ? pl : pr;
+      if ((pathmask >> lane) & 1ull) {
+        H[g] = ck;
+        Q[g] = cp;
+      }
+      if (pathmask) {
+        upk = bcast(ck, last_t - 1);
+        upp = (unsigned short)__builtin_amdgcn_readlane((int)cp, last_t - 1);
+        moved = true;
+      }
+      const int dtt = 31 - __clz(tt);
+      hole = ((hole + 1) << dtt) + (tt - (1 << dtt)) - 1;
+      VQS_WAVE_SYNC();
+    }
+    if ((L & 1) == 0 && hole == (L - 2) / 2) {  // a last node with a single child
+      const int child = 2 * (hole + 1) - 1;
+      const KT ck = H[child];
+      const unsigned short cp = Q[child];
+      VQS_WAVE_SYNC();
+      if (lane == 0) {
+        H[hole] = ck;
+        Q[hole] = cp;
+      }
+      upk = ck;
+      upp = cp;
+      moved = true;
+      hole = child;
+      VQS_WAVE_SYNC();
+    }
+    if (lane == 0) {  // H[L] = H[0] of __pop_heap (node L is outside the sifted heap [0, L))
+      H[L] = rk;
+      Q[L] = rp;
+    }
+    bool first = moved;
+    while (hole > 0) {  // __push_heap
+      const int parent = (hole - 1) / 2;
+      KT pk;
+      unsigned short pp;
+      if (first) {
+        pk = upk;
+        pp = upp;
+        first = false;
+      } else {
+        pk = H[parent];
+        pp = Q[parent];
+      }
+      if (!(pk < vk)) break;
+      VQS_WAVE_SYNC();
+      if (lane == 0) {
+        H[hole] = pk;
+        Q[hole] = pp;
+      }
+      hole = parent;
+      VQS_WAVE_SYNC();
+    }
+    if (lane == 0) {
+      H[hole] = vk;
+      Q[hole] = vp;
+    }
+    VQS_WAVE_SYNC();
+  }
+}
+
+template <typename KT>
+__global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigned* vals_all,
+                                                          const int* __restrict__ kinfo, const unsigned* __restrict__ leaf_all,
+                                                          const int* __restrict__ nleaf, int P, int only,
+                                                          unsigned* __restrict__ heap_all, int* __restrict__ nheap, int heap_cap) {
+  constexpr bool kNarrow = sizeof(KT) == 4;
+  __shared__ LeafLds<KT> S;
+  const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (only >= 0 && (c & 1) != only) return;
+  if ((kinfo[8 * c + 5] <= 31) != kNarrow) return;
+  const int nl = nleaf[c];
+  u64* ka = keys_all + (size_t)c * P;
+  unsigned* va = vals_all + (size_t)c * P;
+  const unsigned* leaf = leaf_all + (size_t)c * P;
+  unsigned* heap = heap_all + (size_t)c * heap_cap;
+  KT* K = S.K[wave];
+  unsigned short* Pm = S.Pm[wave];
+  unsigned short* l0 = S.l0[wave];
+  unsigned short* l1 = S.l1[wave];
+  unsigned short* cl = S.cl[wave];
+  unsigned short* st = S.st[wave];
+  const u64 lt = lanemask_lt();
+  for (int l = blockIdx.x * 4 + wave; l < nl; l += gridDim.x * 4) {
+    const int b = __builtin_amdgcn_readfirstlane((int)leaf[2 * l]), n = __builtin_amdgcn_readfirstlane((int)leaf[2 * l + 1]) - b;
+    for (int p = lane; p < n; p += 64) {
+      const u64 k = ka[b + p];
+      K[p] = kNarrow ? (KT)(k == ~0ull ? 0xffffffffull : k) : (KT)k;
+      Pm[p] = (unsigned short)p;
+    }
+    int lg = 0;
+    for (int v = n; v > 1; v >>= 1) lg++;
+    int sp = 0;
+    if (lane == 0) {
+      st[0] = 0;
+      st[1] = (unsigned short)n;
+      st[2] = (unsigned short)(2 * lg);
+    }
+    sp = 1;
+    VQS_WAVE_SYNC();
+    while (sp > 0) {  // __introsort_loop, the recursion on [cut, last) through a stack
+      sp--;
+      int lo = __builtin_amdgcn_readfirstlane((int)st[3 * sp]), hi = __builtin_amdgcn_readfirstlane((int)st[3 * sp + 1]),
+          depth = __builtin_amdgcn_readfirstlane((int)st[3 * sp + 2]);
+      bool heaped = false;
+      while (hi - lo > kIntroThreshold) {
+        if constexpr (kNarrow) {
+          if (hi - lo <= 64 && depth > 0) {
+            // Ranges of <= 64 elements: one element per lane, the rest of their introsort recursion runs in registers (no
+            // stack: both parts of a partition stay in the lanes of their range); further small ranges from the stack share
+            // the wave as long as they fit.  Lane-space coordinates: a range occupies lanes [mylo, myhi).
+            int mylo = 0, myhi = 0, mydepth = 0, myS = 0, mypos0 = 0, total = 0;
+            bool valid = false;
+            int blo = lo, bhi = hi, bdepth = depth;
+            while (true) {
+              const int len = bhi - blo;
+              if (lane >= total && lane < total + len) {
+                valid = true;
+                mylo = total;
+                myhi = total + len;
+                mydepth = bdepth;
+                myS = total;
+                mypos0 = blo;
+              }
+              total += len;
+              if (sp == 0) break;
+              const int tlo = __builtin_amdgcn_readfirstlane((int)st[3 * (sp - 1)]),
+                        thi = __builtin_amdgcn_readfirstlane((int)st[3 * (sp - 1) + 1]),
+                        td = __builtin_amdgcn_readfirstlane((int)st[3 * (sp - 1) + 2]);
+              if (thi - tlo > 64 - total || (td == 0 && thi - tlo > kIntroThreshold)) break;
+              sp--;
+              blo = tlo;
+              bhi = thi;
+              bdepth = td;
+            }
+            const int p = valid ? mypos0 + (lane - myS) : 0;
+            unsigned k = valid ? (unsigned)K[p] : 0u, pm = valid ? (unsigned)Pm[p] : 0u;
+            const u64 bit = 1ull << lane, ltm = bit - 1ull, gtm = ~(bit | ltm);
+            bool bail = false;
+            while (true) {
+              const bool act = valid && (myhi - mylo > kIntroThreshold);
+              if (__ballot(act) == 0ull) break;
+              if (__ballot(act && mydepth == 0) != 0ull) {  // depth limit inside the batch: back to the stack (heap sort there)
+                bail = true;
+                break;
+              }
+              if (act) mydepth--;
+              auto pull = [&](unsigned v, int from) { return (unsigned)__builtin_amdgcn_ds_bpermute(from << 2, (int)v); };
+              // __move_median_to_first(first, first + 1, mid, last - 1)
+              const int A = act ? mylo + 1 : lane, B = act ? mylo + (myhi - mylo) / 2 : lane, C = act ? myhi - 1 : lane;
+              const unsigned ka_ = pull(k, A), kb_ = pull(k, B), kc_ = pull(k, C);
+              int pick;
+              if (ka_ < kb_) {
+                if (kb_ < kc_)
+                  pick = B;
+                else if (ka_ < kc_)
+                  pick = C;
+                else
+                  pick = A;
+              } else if (ka_ < kc_)
+                pick = A;
+              else if (kb_ < kc_)
+                pick = C;
+              else
+                pick = B;
+              const unsigned pv = pick == A ? ka_ : pick == B ? kb_ : kc_;
+              int src = lane;
+              if (act) src = lane == mylo ? pick : lane == pick ? mylo : lane;
+              k = pull(k, src);
+              pm = pull(pm, src);
+              // __unguarded_partition(first + 1, last, first): left stoppers (key >= pivot) ascending, right stoppers
+              // (key <= pivot) descending, pair r is swapped while L_r < R_r
+              const bool interior = act && lane > mylo;
+              const bool geL = interior && !(k < pv), leR = interior && !(pv < k);
+              const u64 hi_m = myhi >= 64 ? ~0ull : ((1ull << myhi) - 1ull), lo_m = (2ull << mylo) - 1ull;
+              const u64 rmask = hi_m & ~lo_m;  // lanes (mylo, myhi)
+              const u64 bL = __ballot(geL) & rmask, bR = __ballot(leR) & rmask;
+              const int rankL = __popcll(bL & ltm), rankR = __popcll(bR & gtm), nL = __popcll(bL), nR = __popcll(bR);
+              const int park = valid ? mylo : lane;  // a lane nobody reads (pair slots start at mylo + 1)
+              const int Lp = __builtin_amdgcn_ds_permute((geL ? mylo + 1 + rankL : park) << 2, lane);
+              const int Rp = __builtin_amdgcn_ds_permute((leR ? mylo + 1 + rankR : park) << 2, lane);
+              const int r = lane - (mylo + 1);
+              const bool cond = interior && r < min(nL, nR) && Lp < Rp;
+              const int ksw = __popcll(__ballot(cond) & rmask);
+              const int pR = (int)pull((unsigned)Rp, geL ? mylo + 1 + rankL : lane);
+              const int pL = (int)pull((unsigned)Lp, leR ? mylo + 1 + rankR : lane);
+              src = lane;
+              if (geL && rankL < ksw)
+                src = pR;
+              else if (leR && rankR < ksw)
+                src = pL;
+              k = pull(k, src);
+              pm = pull(pm, src);
+              const int cL = (int)pull((unsigned)Lp, act && ksw < nL ? mylo + 1 + ksw : lane);
+              const int cR = (int)pull((unsigned)Rp, act && ksw > 0 ? mylo + ksw : lane);
+              if (act) {
+                int cut = myhi;
+                if (ksw > 0) cut = cR;
+                if (ksw < nL) cut = min(cut, cL);
+                if (lane < cut)
+                  myhi = cut;
+                else
+                  mylo = cut;
+              }
+            }
+            if (valid) {
+              K[p] = (KT)k;
+              Pm[p] = (unsigned short)pm;
+              const int len = myhi - mylo;
+              if (len <= kIntroThreshold) cl[p] = (unsigned short)((mypos0 + (mylo - myS)) | (len << 10));
+            }
+            if (bail) {
+              const bool mgr = valid && lane == mylo && (myhi - mylo > kIntroThreshold);
+              const u64 bm = __ballot(mgr);
+              const int slot = sp + __popcll(bm & ltm);
+              if (mgr) {
+                st[3 * slot] = (unsigned short)(mypos0 + (mylo - myS));
+                st[3 * slot + 1] = (unsigned short)(mypos0 + (myhi - myS));
+                st[3 * slot + 2] = (unsigned short)mydepth;
+              }
+              sp += __popcll(bm);
+            }
+            VQS_WAVE_SYNC();
+            heaped = true;  // chunks are marked
+            break;
+          }
+        }
+        if (depth == 0) {
+          // depth limit: the range goes to k_voxel_qsort_heap (a heap sort is one long serial chain; it gets a wave of its own
+          // instead of holding up this leaf and its workgroup).  It stays as it is here: chunks of one below = identity.
+          if (lane == 0) {
+            const int slot = atomicAdd(&nheap[c], 1);
+            heap[2 * slot] = (unsigned)(b + lo);
+            heap[2 * slot + 1] = (unsigned)(b + hi);
+          }
+          for (int p = lo + lane; p < hi; p += 64) cl[p] = (unsigned short)(p | (1 << 10));  // final: chunks of one
+          VQS_WAVE_SYNC();
+          heaped = true;
+          break;
+        }
+        depth--;
+        {  // __move_median_to_first(first, first + 1, mid, last - 1)
+          const int mid = lo + (hi - lo) / 2, A = lo + 1, B = mid, C = hi - 1;
+          const KT ka_ = K[A], kb_ = K[B], kc_ = K[C];
+          int pick;
+          if (ka_ < kb_) {
+            if (kb_ < kc_)
+              pick = B;
+            else if (ka_ < kc_)
+              pick = C;
+            else
+              pick = A;
+          } else if (ka_ < kc_)
+            pick = A;
+          else if (kb_ < kc_)
+            pick = C;
+          else
+            pick = B;
+          VQS_WAVE_SYNC();
+          if (lane == 0) {
+            const KT tk = K[lo];
+            K[lo] = K[pick];
+            K[pick] = tk;
+            const unsigned short tp = Pm[lo];
+            Pm[lo] = Pm[pick];
+            Pm[pick] = tp;
+          }
+          VQS_WAVE_SYNC();
+        }
+        // __unguarded_partition(first + 1, last, first)
+        const KT pv = K[lo];
+        const int cntn = hi - lo - 1;
+        int cntL = 0, cntR = 0;
+        for (int r0 = 0; r0 < cntn; r0 += 64) {
+          const int t = r0 + lane;
+          const bool valid = t < cntn;
+          const int iL = lo + 1 + t, iR = hi - 1 - t;
+          const bool geL = valid && !(K[valid ? iL : lo] < pv);
+          const bool leR = valid && !(pv < K[valid ? iR : lo]);
+          const u64 bL = __ballot(geL), bR = __ballot(leR);
+          if (geL) l0[cntL + __popcll(bL & lt)] = (unsigned short)iL;
+          if (leR) l1[cntR + __popcll(bR & lt)] = (unsigned short)iR;
+          cntL += __popcll(bL);
+          cntR += __popcll(bR);
+        }
+        VQS_WAVE_SYNC();
+        const int nmin = min(cntL, cntR);
+        int ksw = 0;
+        for (int r0 = 0; r0 < nmin; r0 += 64) {
+          const int k = r0 + lane;
+          const bool ok = k < nmin && l0[k] < l1[k];
+          const u64 bb = __ballot(ok);
+          ksw += __popcll(bb);
+          if (bb != ~0ull) break;
+        }
+        int cut = hi;
+        if (ksw > 0) cut = l1[ksw - 1];
+        if (ksw < cntL) cut = min(cut, (int)l0[ksw]);
+        cut = __builtin_amdgcn_readfirstlane(cut);
+        for (int r0 = 0; r0 < ksw; r0 += 64) {
+          const int k = r0 + lane;
+          if (k < ksw) {
+            const int i = l0[k], j = l1[k];
+            const KT tk = K[i];
+            K[i] = K[j];
+            K[j] = tk;
+            const unsigned short tp = Pm[i];
+            Pm[i] = Pm[j];
+            Pm[j] = tp;
+          }
+        }
+        VQS_WAVE_SYNC();
+        if (lane == 0) {
+          st[3 * sp] = (unsigned short)cut;
+          st[3 * sp + 1] = (unsigned short)hi;
+          st[3 * sp + 2] = (unsigned short)depth;
+        }
+        sp++;
+        VQS_WAVE_SYNC();
+        hi = cut;
+      }
+      if (!heaped) {
+        const int len = hi - lo;  // <= 16: one chunk of the final insertion sort
+        if (lane < len) cl[lo + lane] = (unsigned short)(lo | (len << 10));
+        VQS_WAVE_SYNC();
+      }
+    }
+    // __final_insertion_sort = stable sort of every chunk; then the permutation is applied to the point indices
+    unsigned myv[16];
+    unsigned short dst[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int p = r * 64 + lane;
+      myv[r] = 0;
+      dst[r] = 0;
+      if (p < n) {
+        const int cinfo = cl[p], c0 = cinfo & 1023, len = cinfo >> 10;
+        const KT kp = K[p];
+        int rank = 0;
+        for (int q = c0; q < c0 + len; q++) {
+          const KT kq = K[q];
+          rank += (kq < kp || (kq == kp && q < p)) ? 1 : 0;
+        }
+        dst[r] = (unsigned short)(c0 + rank);
+        myv[r] = va[b + Pm[p]];
+      }
+    }
+    __threadfence_block();
+    VQS_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int p = r * 64 + lane;
+      if (p < n) {
+        const KT kp = K[p];
+        ka[b + dst[r]] = kNarrow ? (kp == (KT)0xffffffffull ? ~0ull : (u64)kp) : (u64)kp;
+        va[b + dst[r]] = myv[r];
+      }
+    }
+    VQS_WAVE_SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_voxel_qsort_heap<KT>: the ranges whose introsort recursion ran into libstdc++'s depth limit (2 lg n partitions deep):
+// std::__partial_sort(first, last, last), i.e. heap sort, one wave per range (heap_sort_wave).  Such a range is final
+// afterwards (the final insertion sort moves nothing in it).
+// ------------------------------------------------------------------------------------------------
+template <typename KT>
+struct HeapLds {
+  KT K[4][1024];
+  unsigned short Pm[4][1024];
+};
+
+template <typename KT>
+__global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigned* vals_all, const int* __restrict__ kinfo,
+                                                          const unsigned* __restrict__ heap_all, const int* __restrict__ nheap,
+                                                          int heap_cap, int P, int only) {
+  constexpr bool kNarrow = sizeof(KT) == 4;
+  __shared__ HeapLds<KT> S;
+  const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (only >= 0 && (c & 1) != only) return;
+  if ((kinfo[8 * c + 5] <= 31) != kNarrow) return;
+  const int nh = nheap[c];
+  u64* ka = keys_all + (size_t)c * P;
+  unsigned* va = vals_all + (size_t)c * P;
+  const unsigned* heap = heap_all + (size_t)c * heap_cap;
+  KT* K = S.K[wave];
+  unsigned short* Pm = S.Pm[wave];
+  for (int l = blockIdx.x * 4 + wave; l < nh; l += gridDim.x * 4) {
+    const int b = __builtin_amdgcn_readfirstlane((int)heap[2 * l]), n = __builtin_amdgcn_readfirstlane((int)heap[2 * l + 1]) - b;
+    for (int p = lane; p < n; p += 64) {
+      const u64 k = ka[b + p];
+      K[p] = kNarrow ? (KT)(k == ~0ull ? 0xffffffffull : k) : (KT)k;
+      Pm[p] = (unsigned short)p;
+    }
+    VQS_WAVE_SYNC();
+    // A heap sort is one long serial chain (~1 us per element here), and these ranges come from the far, sparsely sampled parts
+    // of a depth image where nearly every voxel holds one point.  When all keys of the range are distinct the result of ANY
+    // correct sort is the reference's: rank every element by counting smaller keys (all lanes in parallel), and replay
+    // libstdc++'s heap sort only if two elements collide on a rank (equal keys: their order is the heap's).
+    bool replay = false;
+    {
+      KT mykey[16];
+      int rank[16];
+      const int rows = (n + 63) >> 6;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        mykey[r] = r * 64 + lane < n ? K[r * 64 + lane] : (KT)0;
+        rank[r] = 0;
+      }
+      for (int j = 0; j < n; j++) {
+        const KT kj = K[j];  // same address in every lane: an LDS broadcast
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (r < rows) rank[r] += kj < mykey[r] ? 1 : 0;
+      }
+      VQS_WAVE_SYNC();
+      unsigned short* slot = Pm;  // Pm is the identity so far: reuse it as the rendezvous (rank -> who claims it)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (r * 64 + lane < n) slot[rank[r]] = (unsigned short)(r * 64 + lane);
+      VQS_WAVE_SYNC();
+      bool clash = false;
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (r * 64 + lane < n) clash |= slot[rank[r]] != (unsigned short)(r * 64 + lane);
+      replay = __ballot(clash) != 0ull;
+      VQS_WAVE_SYNC();
+      if (!replay) {  // slot[] = Pm[] is already the sorting permutation; the keys follow it
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (r * 64 + lane < n) K[rank[r]] = mykey[r];
+      } else {
+        for (int p = lane; p < n; p += 64) Pm[p] = (unsigned short)p;
+      }
+      VQS_WAVE_SYNC();
+    }
+    if (replay) heap_sort_wave<KT>(K, Pm, 0, n);
+    unsigned myv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int p = r * 64 + lane;
+      myv[r] = p < n ? va[b + Pm[p]] : 0u;
+    }
+    __threadfence_block();
+    VQS_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int p = r * 64 + lane;
+      if (p < n) {
+        const KT kp = K[p];
+        ka[b + p] = kNarrow ? (kp == (KT)0xffffffffull ? ~0ull : (u64)kp) : (u64)kp;
+        va[b + p] = myv[r];
+      }
+    }
+    VQS_WAVE_SYNC();
+  }
+}
+
+}  // namespace vqs

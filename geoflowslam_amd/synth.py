@@ -438,3 +438,15 @@ def two_view_points(seed, n=400, outlier_frac=0.25, noise=0.3, width=640, height
     Ki = np.linalg.inv(K)
     F = Ki.T @ tx @ R @ Ki
     return p1.astype(np.float32), p2.astype(np.float32), ~out, F / F[2, 2]
+
+
+def cloud_pair(seed, width=160, height=120, trans=0.03, rot_deg=1.5):
+    """Clouds only (no images): the depth maps are rendered at width x height and unprojected at stride 1, which gives the point
+    density of a (4 width) x (4 height) depth image sampled at stride 4 (the intrinsics scale with the width) at 1/16 of the
+    rendering cost.  -> (cloud0, cloud1, T_01)."""
+    sc = Scene(seed)
+    rng = np.random.default_rng(seed + 0x6F5)
+    T1 = random_motion(rng, trans, rot_deg)
+    d0 = sc.render(width, height, None, 0)[1]
+    d1 = sc.render(width, height, T1, 1)[1]
+    return depth_to_cloud(d0, 1), depth_to_cloud(d1, 1), T1

@@ -209,6 +209,12 @@ int gfs_gicp_align_next_batch_device(gfs_gicp* h, const void* dev_source, const 
 /* Introspection for parity tests: preprocessing output (voxel means + covariances) of cloud `which`
  * (0 = target, 1 = source) of pair b of the last call. pts: [m][4] f64, covs: [m][9] f64 (3x3 col-major). */
 int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, double* covs, int cap, int* m);
+/* GPU test hook: the voxel sort of the preprocessing — the device replica of small_gicp's quick_sort_omp
+ * (util/sort_omp.hpp:58-85: 3-way quicksort above 1024 elements, libstdc++ std::sort below), whose permutation of
+ * equal keys decides the 1024-block splits of voxelgrid_sampling_omp (util/downsampling_omp.hpp:57-90) — on n <=
+ * max_points caller keys (3 x 21-bit voxel fields, or all ones = invalid).  perm_out[i] = input index of the i-th
+ * element of the sorted sequence. */
+int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsigned* perm_out);
 
 /* ============================================================================================
  * 4. Local bundle adjustment — replaces the numeric core of Optimizer::LocalBundleAdjustment

@@ -106,6 +106,11 @@ void gfso_gicp_default_cfg(gfso_gicp_cfg*);
 /* on != 0: equal voxel keys are ordered by point index instead of by the reference's quick_sort_omp permutation
  * (util/sort_omp.hpp:58-85). Only which points fall on either side of a 1024-block split changes. Default 0. */
 void gfso_gicp_set_stable_voxel_order(int on);
+/* quick_sort_omp (util/sort_omp.hpp:58-85) of (key, index) pairs by key, through libstdc++'s std::partition / std::sort:
+ * idx_io holds the payload (0..n-1 on entry), both arrays are permuted in place */
+void gfso_quick_sort_pairs(uint64_t* keys_io, uint64_t* idx_io, int n);
+/* adversarial input for libstdc++'s std::sort (McIlroy's antiqsort): a permutation of 0..n-1 that reaches the heap-sort fallback */
+void gfso_antiqsort_keys(int n, int32_t* out);
 /* OpenMP threads for timing runs (the reference hard-codes 4, src/RegistrationGICP.cc:10); default 1 = deterministic */
 void gfso_gicp_set_threads(int n);
 /* RegistrationGICP::RegisterPointClouds, src/RegistrationGICP.cc:5-20 */

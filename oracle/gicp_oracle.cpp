@@ -628,6 +628,41 @@ void gfso_gicp_default_cfg(gfso_gicp_cfg* c) {
 static int g_stable_order = 0;
 static int g_omp_threads = 1;  // 1 = deterministic; the reference hard-codes 4 (src/RegistrationGICP.cc:10) — used for timing
 void gfso_gicp_set_stable_voxel_order(int on) { g_stable_order = on; }
+// Test-input generator: M. D. McIlroy, "A Killer Adversary for Quicksort" (1999), run against libstdc++'s std::sort: the
+// returned key sequence (a permutation of 0 .. n-1) drives that std::sort into its depth limit, i.e. into the heap-sort
+// fallback of __introsort_loop, which the device replica (voxel_qsort.hpp) must reproduce as well.
+void gfso_antiqsort_keys(int n, int32_t* out) {
+  std::vector<int> val((size_t)std::max(n, 0)), ptr(val.size());
+  const int gas = n - 1;
+  int nsolid = 0, candidate = 0;
+  for (int i = 0; i < n; i++) {
+    ptr[i] = i;
+    val[i] = gas;
+  }
+  std::sort(ptr.begin(), ptr.end(), [&](int x, int y) {
+    if (val[x] == gas && val[y] == gas) {
+      if (x == candidate)
+        val[x] = nsolid++;
+      else
+        val[y] = nsolid++;
+    }
+    if (val[x] == gas)
+      candidate = x;
+    else if (val[y] == gas)
+      candidate = y;
+    return val[x] < val[y];
+  });
+  for (int i = 0; i < n; i++) out[i] = val[i];
+}
+void gfso_quick_sort_pairs(uint64_t* keys_io, uint64_t* idx_io, int n) {
+  std::vector<KeyIdx> v((size_t)std::max(n, 0));
+  for (int i = 0; i < n; i++) v[i] = {keys_io[i], (size_t)idx_io[i]};
+  quick_sort_impl(v.data(), v.data() + n);
+  for (int i = 0; i < n; i++) {
+    keys_io[i] = v[i].first;
+    idx_io[i] = v[i].second;
+  }
+}
 void gfso_gicp_set_threads(int n) { g_omp_threads = n < 1 ? 1 : n; }
 
 void gfso_gicp_align(const float* target_xyzw, int nt, const float* source_xyzw, int ns, const double init_T[16],

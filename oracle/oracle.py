@@ -271,6 +271,20 @@ def gicp_set_stable_voxel_order(on):
     lib().gfso_gicp_set_stable_voxel_order(int(on))
 
 
+def quick_sort_perm(keys):
+    """small_gicp quick_sort_omp on (key, index) pairs -> the permutation (input index of every sorted element)."""
+    k = np.ascontiguousarray(keys, np.uint64).copy()
+    idx = np.arange(len(k), dtype=np.uint64)
+    lib().gfso_quick_sort_pairs(_p(k), _p(idx), len(k))
+    return idx.astype(np.int64), k
+
+
+def antiqsort_keys(n):
+    out = np.zeros(n, np.int32)
+    lib().gfso_antiqsort_keys(n, _p(out))
+    return out
+
+
 def gicp_set_threads(n):
     lib().gfso_gicp_set_threads(int(n))
 

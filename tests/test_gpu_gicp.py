@@ -14,13 +14,67 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
+def _voxel_keys(x, y, z):
+    return (x.astype(np.uint64) | (y.astype(np.uint64) << np.uint64(21)) | (z.astype(np.uint64) << np.uint64(42)))
+
+
+def _sort_cases():
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in (0, 1, 2, 3, 16, 17, 18, 64, 65, 500, 1023, 1024, 1025, 2047, 2048, 5000, 19200, 40000):
+        for mode in range(6):
+            if mode == 0:      # depth-camera like: most voxels unique, ~10 % shared
+                x, y, z = rng.integers(0, 200, n), rng.integers(0, 150, n), rng.integers(0, 4, n)
+            elif mode == 1:    # heavy ties
+                x, y, z = rng.integers(0, 5, n), rng.integers(0, 3, n), np.zeros(n, np.int64)
+            elif mode == 2:    # already sorted with ties
+                x, y, z = np.arange(n) // 3 % 1024, np.arange(n) // 3 // 1024, np.zeros(n, np.int64)
+            elif mode == 3:    # reversed
+                x, y, z = (n - np.arange(n)) // 2 % 512, (n - np.arange(n)) // 2 // 512, np.zeros(n, np.int64)
+            elif mode == 4:    # wide extent: the compacted keys need more than 31 bits (64-bit leaf path)
+                x, y, z = rng.integers(0, 1 << 15, n), rng.integers(0, 1 << 12, n), rng.integers(0, 1 << 10, n)
+                if n > 4:
+                    x[:n // 3] = x[n // 3:2 * (n // 3)]
+                    y[:n // 3] = y[n // 3:2 * (n // 3)]
+                    z[:n // 3] = z[n // 3:2 * (n // 3)]
+            else:              # all equal
+                x, y, z = np.full(n, 7), np.full(n, 9), np.full(n, 11)
+            k = _voxel_keys(np.asarray(x) + 1000, np.asarray(y) + 2000, np.asarray(z) + 3000)
+            if mode in (0, 4) and n > 10:  # some out-of-range points: key = all ones
+                k[rng.integers(0, n, max(1, n // 50))] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            cases.append((f"n{n}-m{mode}", k))
+    return cases
+
+
+def test_voxel_sort_permutation_is_the_references(gpu_api, oracle):
+    """The preprocessing's voxel sort must produce small_gicp quick_sort_omp's permutation (util/sort_omp.hpp:58-85; the sort is
+    not stable and the 1024-block splits of voxelgrid_sampling_omp depend on it): 3-way quicksort levels, libstdc++ introsort
+    leaves, final insertion sort — and the heap-sort fallback, reached with McIlroy's adversarial input for std::sort."""
+    reg = gpu_api.RegistrationGICP(max_points=40960)
+    cases = _sort_cases()
+    for n in (100, 700, 1000, 1023):
+        a = oracle.antiqsort_keys(n).astype(np.int64)
+        for div in (1, 2, 3):
+            cases.append((f"antiqsort{n}/{div}", _voxel_keys(a // div + 5, np.full(n, 3), np.full(n, 1))))
+    # leaves inside a big sort: the adversarial block sits between two key ranges of a 20000-element cloud
+    a = oracle.antiqsort_keys(1000).astype(np.int64) // 2
+    rng = np.random.default_rng(1)
+    lo, hi = rng.integers(0, 1000, 9000), rng.integers(3000, 4000, 10000)
+    mix = np.concatenate([lo, a + 1500, hi])
+    cases.append(("antiqsort-embedded", _voxel_keys(mix[rng.permutation(len(mix))], np.full(len(mix), 2), np.full(len(mix), 2))))
+    cases.append(("antiqsort-embedded-inorder", _voxel_keys(mix, np.full(len(mix), 2), np.full(len(mix), 2))))
+    for name, k in cases:
+        got = reg.voxel_sort_perm(k)
+        want, _ = oracle.quick_sort_perm(k)
+        assert np.array_equal(got, want), (name, int((got != want).sum()), len(k))
+
+
 def test_preprocess_stage_matches_oracle(gpu_api, oracle):
-    """Voxel means must be bit-identical (same summation order) and covariances equal to 1e-9 when the oracle
-    orders equal voxel keys by point index like the GPU's stable radix sort."""
-    fp = synth.frame_pair(2)
-    reg = gpu_api.RegistrationGICP(max_points=20480)
-    oracle.gicp_set_stable_voxel_order(1)
-    try:
+    """Voxel means bit-identical to the (unmodified, reference-order) oracle — same permutation of equal voxel keys, same
+    1024-block splits, same summation order — and covariances equal to 1e-9."""
+    for seed, res in ((2, (640, 480, 4)), (202, (640, 480, 4)), (12, (1280, 720, 5))):
+        fp = synth.frame_pair(seed, *res)
+        reg = gpu_api.RegistrationGICP(max_points=61440)
         reg.RegisterPointClouds(fp["cloud0"], fp["cloud1"])
         for which, key in ((0, "cloud0"), (1, "cloud1")):
             pts, covs = reg.preprocessed(0, which)
@@ -36,8 +90,6 @@ def test_preprocess_stage_matches_oracle(gpu_api, oracle):
             assert tie.sum() <= 5
             diff = np.abs(covs[ig] - co[io][:, :3, :3]).reshape(len(pts), -1).max(1)
             assert diff[~tie].max() < 1e-9, "covariances differ"
-    finally:
-        oracle.gicp_set_stable_voxel_order(0)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
@@ -50,7 +102,30 @@ def test_gicp_pose_parity_vga(gpu_api, oracle, seed):
     assert r["converged"] == ro["converged"] and r["iterations"] == ro["iterations"]
     assert abs(r["num_inliers"] - ro["num_inliers"]) <= max(1, int(1e-3 * ro["num_inliers"]))
     assert r["n_target_ds"] == ro["n_target_ds"] and r["n_source_ds"] == ro["n_source_ds"]
-    assert _rel(r["H"], ro["H"]) < 1e-3 and abs(r["error"] - ro["error"]) < 1e-3 * abs(ro["error"])
+    # 1e-5 on H / error: an exact distance tie at a 10th neighbour (seed 2 has one) picks another point than the KdTree order
+    assert _rel(r["H"], ro["H"]) < 1e-5 and abs(r["error"] - ro["error"]) < 1e-5 * abs(ro["error"])
+
+
+def test_gicp_pose_parity_sweep_40_seeds(gpu_api, oracle):
+    """Every one of 40 synthetic VGA pairs meets the north_star bar against the UNMODIFIED (reference-order) oracle; seed 202 was
+    at 5.4e-5 in round 1 when the voxel sort was a stable radix sort.  What is left is rounding noise plus exact k-th-neighbour
+    distance ties (1e-7)."""
+    import concurrent.futures as cf
+    seeds = list(range(200, 240))
+    pairs = [synth.frame_pair(s, 640, 480, 4) for s in seeds]
+    with cf.ThreadPoolExecutor(max_workers=16) as ex:
+        want = list(ex.map(lambda fp: oracle.gicp_align(fp["cloud0"], fp["cloud1"]), pairs))
+    reg = gpu_api.RegistrationGICP(max_points=20480)
+    worst = 0.0
+    for s, fp, ro in zip(seeds, pairs, want):
+        r = reg.RegisterPointClouds(fp["cloud0"], fp["cloud1"])
+        e = _rel(r["T"], ro["T"])
+        worst = max(worst, e)
+        assert e < 1e-6, (s, e)
+        assert r["converged"] == ro["converged"] and r["iterations"] == ro["iterations"], s
+        assert r["num_inliers"] == ro["num_inliers"] and r["n_source_ds"] == ro["n_source_ds"], s
+        assert _rel(r["H"], ro["H"]) < 1e-5 and abs(r["error"] - ro["error"]) <= 1e-5 * abs(ro["error"]), s
+    print("worst rel. Frobenius over 40 seeds:", worst)
 
 
 def test_gicp_with_init_and_small_config(gpu_api, oracle):
@@ -95,12 +170,11 @@ def test_gicp_720p_cloud(gpu_api, oracle):
     assert _rel(r["T"], ro["T"]) < TOL and r["converged"] == ro["converged"]
 
 
-@pytest.mark.parametrize("seed", [1, 2, 202, 231])
-def test_gicp_pose_equals_the_stable_order_oracle(gpu_api, oracle, seed):
-    """With the oracle ordering equal voxel keys by point index (the GPU's stable radix order) the whole alignment agrees to
-    rounding noise: the only algorithmic deviation from the reference is which points of a voxel that straddles a 1024-block
-    boundary fall on either side (seed 202 is the worst of 40 seeds: 5.4e-5 against the reference order)."""
-    fp = synth.frame_pair(seed, 640, 480, 4)
+def test_stable_voxel_order_knob(gpu_api, oracle, monkeypatch):
+    """GFS_GICP_VOXEL_ORDER=stable keeps round 1's stable radix order (equal voxel keys by point index): equal to the oracle's
+    stable-order switch to rounding noise, and a documented deviation from the reference (seed 202: 5.4e-5)."""
+    monkeypatch.setenv("GFS_GICP_VOXEL_ORDER", "stable")
+    fp = synth.frame_pair(202, 640, 480, 4)
     reg = gpu_api.RegistrationGICP(max_points=32768)
     oracle.gicp_set_stable_voxel_order(1)
     try:
@@ -109,9 +183,7 @@ def test_gicp_pose_equals_the_stable_order_oracle(gpu_api, oracle, seed):
     finally:
         oracle.gicp_set_stable_voxel_order(0)
     assert r["iterations"] == ro["iterations"] and r["num_inliers"] == ro["num_inliers"] and r["converged"] == ro["converged"]
-    # 1e-7: an exact distance tie at a 10th neighbour (seed 2 has one) may pick the other point; otherwise ~1e-16
     assert np.linalg.norm(r["T"] - ro["T"]) <= 1e-7 * np.linalg.norm(ro["T"])
-    assert abs(r["error"] - ro["error"]) <= 1e-5 * abs(ro["error"])
 
 
 def _same(a, b):

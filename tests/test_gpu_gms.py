@@ -73,6 +73,12 @@ class _Hip:
         assert self.lib.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), out.nbytes, 2) == 0
         return out
 
+    def stream(self):
+        """A HIP stream: the *_batch_device entry points return without waiting, a chain of them must share one stream."""
+        st = C.c_void_p()
+        assert self.lib.hipStreamCreate(C.byref(st)) == 0
+        return st.value
+
     def free(self):
         for p in self.ptrs:
             self.lib.hipFree(p)
@@ -87,18 +93,19 @@ def test_device_chain_matches_oracle(gpu_api, oracle):
     g1 = hip.to_device(np.stack([p["gray1"] for p in pairs]))
     e0 = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=H, max_cols=W, max_batch=B)
     e1 = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=H, max_cols=W, max_batch=B)
-    e0.extract_batch_device(g0, B, H, W, (0, 0))
-    e1.extract_batch_device(g1, B, H, W, (0, 0))
+    st = hip.stream()
+    e0.extract_batch_device(g0, B, H, W, (0, 0), st)
+    e1.extract_batch_device(g1, B, H, W, (0, 0), st)
     r0, r1 = e0.device_results(), e1.device_results()
     cap = e0.cap
     mt = gpu_api.ORBmatcher(max_query=cap, max_train=cap, max_batch=B)
     idx = hip.to_device(np.zeros(B * cap, np.int32))
     dist = hip.to_device(np.zeros(B * cap, np.int32))
-    mt.match_batch_device(r0["desc"], r0["counts"], r1["desc"], r1["counts"], B, cap, idx, dist)
+    mt.match_batch_device(r0["desc"], r0["counts"], r1["desc"], r1["counts"], B, cap, idx, dist, st)
     mask = hip.to_device(np.zeros(B * cap, np.uint8))
     cnt = hip.to_device(np.zeros(B, np.int32))
     gm = gpu_api.GmsMatcher(max_keypoints=cap, max_batch=B)
-    gm.inlier_mask_batch_device(r0["kps"], r0["counts"], r1["kps"], r1["counts"], B, cap, idx, W, H, mask, cnt)
+    gm.inlier_mask_batch_device(r0["kps"], r0["counts"], r1["kps"], r1["counts"], B, cap, idx, W, H, mask, cnt, st)
     mask_h = hip.to_host(mask, (B, cap), np.uint8)
     cnt_h = hip.to_host(cnt, B, np.int32)
     idx_h = hip.to_host(idx, (B, cap), np.int32)
