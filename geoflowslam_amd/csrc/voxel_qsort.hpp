@@ -64,7 +64,7 @@ __device__ __forceinline__ u64 med3(u64 a, u64 b, u64 c) {  // sort_omp.hpp:66-6
 // long, so a row touches at most two of them.  f(valid, s, v) is called by all lanes of the wave for every row.
 template <class F>
 __device__ __forceinline__ void sweep(int A, int E, int nseg, const int* seg_v, F&& f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int v0 = wave * 64 * E;
   if (v0 >= A) return;
   int lo = 0, hi = nseg;  // last s with seg_v[s] <= v0
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top(u64* keys_all, unsigne
   __shared__ int s_wave[16];
   __shared__ int s_nseg, s_nleaf, s_A;
   __shared__ int s_mn[3], s_mx[3];
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
   if (only >= 0 && (c & 1) != only) return;
   if (only_flagged && kinfo[8 * c + 6] == 0) return;  // k_voxel_qsort_top_reg took this cloud
   const int n = counts[c];
@@ -346,16 +346,18 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   constexpr int kCB = 21, kCM = (1 << kCB) - 1;
   constexpr int kSeg = EMAX + 1, kEq = 32;
   __shared__ int seg_b[kSeg], seg_e[kSeg], seg_base[kSeg + 1], seg_m1[kSeg], seg_m2[kSeg], eq_cnt[kSeg], eq_pos[kSeg][kEq];
+  __shared__ int seg_local[kSeg], seg_wave[kSeg];  // flagged count before a range's first element inside its wave's chunk; that wave
   __shared__ unsigned seg_pv[kSeg];
-  __shared__ int s_wave[16];
+  __shared__ int s_wave[16], s_wbase[17];
+  __shared__ unsigned short side_pos[1024 * EMAX];  // rendezvous of a partition sweep: slot (rank from either end) -> position
   __shared__ int s_nseg, s_nleaf, s_over;
   __shared__ int s_mn[3], s_mx[3];
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
   if (only >= 0 && (c & 1) != only) return;
-  const int n = counts[c];
+  const int n = __builtin_amdgcn_readfirstlane(counts[c]);
   u64* ka = keys_all + (size_t)c * P;
   unsigned* va = vals_all + (size_t)c * P;
-  u64* side = side_all + (size_t)c * P;
+  (void)side_all;  // (the partition sweep exchanges positions through LDS)
   unsigned* kscr = kscr_all + (size_t)c * P;
   unsigned* leaf = leaf_all + (size_t)c * P;
   if (tid < 3) {
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   const u64 ltm = lanemask_lt();
   unsigned key[EMAX], val[EMAX];
   while (true) {
-    const int nseg = s_nseg;
+    const int nseg = __builtin_amdgcn_readfirstlane(s_nseg);
     if (nseg == 0) break;
     if (tid < nseg) {
       const int b = seg_b[tid], len = seg_e[tid] - b, off = len / 8;  // sort_omp.hpp:70-75
@@ -453,13 +455,13 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
       }
     }
     __syncthreads();
-    // one std::partition sweep over all ranges, on the cached elements.  mode 0: key < pivot over [first, last);
-    // mode 1: !(pivot < key) over [middle1, last).  The rows of a wave walk through the (sorted) ranges: the parameters of
-    // the current range A and the next one B are wave-uniform, a row touches at most these two.
     struct SegP {
       int b, e, first, base, m;
       unsigned pv;
     };
+    // Stores every cached element where std::partition leaves it: the k-th misplaced element of the front part (from the
+    // left) and the k-th misplaced element of the back part (from the right) announce their positions in side_pos and take
+    // each other's place; everything else stays.  (All elements are in registers, so the scatter is in place.)
     auto partition_sweep = [&](int mode) {
       auto load_seg = [&](int sidx, bool with_counts) {
         SegP q;
@@ -478,7 +480,6 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
         }
         return q;
       };
-      // per row: advance (A, B), then flag / range parameters of every lane
 #define VQS_ROW_BEGIN(with_counts)                                       \
   const int row0 = (wave * E + r) * 64, i = row0 + lane;                 \
   while (row0 >= A.e && sA < nseg) {                                     \
@@ -490,40 +491,39 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   const unsigned pv = inB ? B.pv : A.pv;                                 \
   const int first = inB ? B.first : A.first;                             \
   const bool flag = in && (mode == 0 ? key[r] < pv : (i >= first && !(pv < key[r])));
-      int cnt = 0;
-      {
-        int sA = 0;
-        SegP A = load_seg(0, false), B = load_seg(1, false);
-#pragma unroll
-        for (int r = 0; r < EMAX; r++)
-          if (r < E) {
-            VQS_ROW_BEGIN(false)
-            cnt += __popcll(__ballot(flag));
-          }
-      }
-      if (lane == 0) s_wave[wave] = cnt;
-      __syncthreads();
-      int wave_base = 0, total = 0;
-      for (int w = 0; w < 16; w++) {
-        const int t = s_wave[w];
-        if (w < wave) wave_base += t;
-        total += t;
-      }
-      {
-        int run = wave_base, sA = 0;
+      {  // (A) flagged elements per wave, and before every range start inside its wave
+        int cnt = 0, sA = 0;
         SegP A = load_seg(0, false), B = load_seg(1, false);
 #pragma unroll
         for (int r = 0; r < EMAX; r++)
           if (r < E) {
             VQS_ROW_BEGIN(false)
             const u64 bl = __ballot(flag);
-            if (in && i == (inB ? B.b : A.b)) seg_base[inB ? sA + 1 : sA] = run + __popcll(bl & ltm);
-            run += __popcll(bl);
+            if (in && i == (inB ? B.b : A.b)) {
+              const int sidx = inB ? sA + 1 : sA;
+              seg_local[sidx] = cnt + __popcll(bl & ltm);
+              seg_wave[sidx] = wave;
+            }
+            cnt += __popcll(bl);
+            __builtin_amdgcn_sched_barrier(0);  // rows one after the other: interleaving them only costs registers
           }
-        if (tid == 0) seg_base[nseg] = total;
+        if (lane == 0) s_wave[wave] = cnt;
       }
       __syncthreads();
-      for (int step = 0; step < 2; step++) {
+      if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 16; w++) {
+          s_wbase[w] = acc;
+          acc += s_wave[w];
+        }
+        s_wbase[16] = acc;
+      }
+      __syncthreads();
+      if (tid < nseg) seg_base[tid] = s_wbase[seg_wave[tid]] + seg_local[tid];
+      if (tid == 0) seg_base[nseg] = s_wbase[16];
+      const int wave_base = __builtin_amdgcn_readfirstlane(s_wbase[wave]);
+      __syncthreads();
+      for (int step = 0; step < 2; step++) {  // (B) announce, (C) take the partner's place
         int run = wave_base, sA = 0;
         SegP A = load_seg(0, true), B = load_seg(1, true);
 #pragma unroll
@@ -535,9 +535,9 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
             run += __popcll(bl);
             if (in) {
               const int lr = i - first, last = inB ? B.e : A.e;
+              int mine = -1, theirs = -1;
               if (lr >= 0) {
                 const int m = inB ? B.m : A.m, rk = pre - (inB ? B.base : A.base);
-                int mine = -1, theirs = -1;
                 if (lr < m && !flag) {  // k-th misplaced element of the front part, from the left
                   const int k = lr - rk;
                   mine = first + k;
@@ -547,45 +547,31 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
                   mine = last - 1 - k;
                   theirs = first + k;
                 }
-                if (mine >= 0) {
-                  if (step == 0) {
-                    side[mine] = (u64)key[r] | ((u64)val[r] << 32);
-                  } else {
-                    const u64 t = side[theirs];
-                    key[r] = (unsigned)t;
-                    val[r] = (unsigned)(t >> 32);
-                  }
+              }
+              if (step == 0) {
+                if (mine >= 0) side_pos[mine] = (unsigned short)i;
+              } else {
+                const int dest = mine >= 0 ? (int)side_pos[theirs] : i;
+                kscr[dest] = key[r];
+                va[dest] = val[r];
+                // after the first partition: where the keys equal to the pivot sit (all of them in [middle1, last) now)
+                if (mode == 0 && key[r] == pv) {
+                  const int sidx = inB ? sA + 1 : sA;
+                  const int slot = atomicAdd(&eq_cnt[sidx], 1);
+                  if (slot < kEq) eq_pos[sidx][slot] = dest;
                 }
               }
-              // after the first partition: who holds a key equal to the pivot (they all sit in [middle1, last) now)
-              if (step == 1 && mode == 0 && key[r] == pv) {
-                const int sidx = inB ? sA + 1 : sA;
-                const int slot = atomicAdd(&eq_cnt[sidx], 1);
-                if (slot < kEq) eq_pos[sidx][slot] = i;
-              }
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         __syncthreads();
       }
 #undef VQS_ROW_BEGIN
     };
-    auto store_back = [&]() {
-#pragma unroll
-      for (int r = 0; r < EMAX; r++)
-        if (r < E) {
-          const int i = i0 + r * 64;
-          if (i < n) {
-            kscr[i] = key[r];
-            va[i] = val[r];
-          }
-        }
-    };
     partition_sweep(0);
-    if (tid < nseg) seg_m1[tid] = seg_b[tid] + (seg_base[tid + 1] - seg_base[tid]);
-    store_back();
-    __syncthreads();
     if (tid < nseg) {  // second partition by replaying its few swaps
-      const int m = eq_cnt[tid], m1 = seg_m1[tid];
+      const int m = eq_cnt[tid], m1 = seg_b[tid] + (seg_base[tid + 1] - seg_base[tid]);
+      seg_m1[tid] = m1;
       seg_m2[tid] = m1 + m;
       if (m > kEq) {
         s_over = 1;
@@ -619,7 +605,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
       }
     }
     __syncthreads();
-    if (s_over) {  // a voxel with more than kEq points: the general sweep (reload, partition, store)
+    if (__builtin_amdgcn_readfirstlane(s_over)) {  // a voxel with more than kEq points: the general sweep (reload, partition, store)
 #pragma unroll
       for (int r = 0; r < EMAX; r++)
         if (r < E) {
@@ -631,7 +617,6 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
         }
       partition_sweep(1);
       if (tid < nseg) seg_m2[tid] = seg_m1[tid] + (seg_base[tid + 1] - seg_base[tid]);
-      store_back();
       __syncthreads();
     }
     // children [first, middle1) and [middle2, last)

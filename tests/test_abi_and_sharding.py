@@ -103,3 +103,28 @@ def test_two_rank_sharding_gloo(api, tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0]
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_spawns_its_own_ranks(api):
+    if api.device_count() > 0:
+        pytest.skip("checks the launcher up to the point where a GPU is required")
+    """`python bench.py --gpus 2` (no torchrun) must itself start 2 ranks that form a process group; here (no GPU) every rank
+    stops at the device check, after rendezvous, reporting the world size and its block of the global batch (--strong)."""
+    cp = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--batch", "3", "--distinct", "1", "--gen-procs", "1", "--strong", "--verify", "0"])
+    assert cp.returncode != 0
+    err = cp.stderr
+    assert "rank 0 of 2" in err and "rank 1 of 2" in err, err
+    assert "process group of 2 ranks is up" in err
+    assert "block of 2 pairs from pair 0" in err and "block of 1 pairs from pair 2" in err, err  # shard_range(3, r, 2)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    cp = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=60)
+    assert cp.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in cp.stderr
