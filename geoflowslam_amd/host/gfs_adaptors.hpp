@@ -16,9 +16,17 @@
 // Anything the GPU library reports as an error is raised as std::runtime_error (there is no CPU fallback).
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <list>
+#include <map>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/gfs_abi.h"
@@ -150,10 +158,254 @@ class LocalBundleAdjuster {
     check(rc, "gfs_lba_solve");
     return true;
   }
+  // Optimizer::LocalBundleAdjustment on the reference's own KeyFrame / MapPoint / Map classes (see LocalBundleAdjustment below)
+  template <class Access, class KeyFrame, class Map>
+  void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs,
+                             int& num_edges);
 
  private:
   gfs_lba* h_ = nullptr;
 };
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, bool pbICPFlag, Map* pMap, int& num_fixedKF,
+//                                  int& num_OptKF, int& num_MPs, int& num_edges)          reference src/Optimizer.cc:1588-2040
+// as real code around the flat solver: the pointer-graph gather (:1592-1660), the vertices and edges of the g2o graph flattened
+// into a gfs_lba_problem in the reference's creation order (:1686-1721, 1816-1952), the stop-flag checks (:1679, 1955-1956),
+// the chi2 / depth classification (:1961-1999) and the write-back under mMutexMapUpdate (:2003-2039).
+//
+// It is a template over the reference's own classes: KeyFrame, MapPoint and Map are used through exactly the members the
+// reference function uses (mnId, mnBALocalForKF, mnBAFixedForKF, isBad(), GetMap(), GetVectorCovisibleKeyFrames(),
+// GetMapPointMatches(), GetObservations(), mvKeysUn[i].pt / .octave, mvuRight, mvInvLevelSigma2, fx, fy, cx, cy, mbf, mpCamera2,
+// EraseMapPointMatch(), EraseObservation(), UpdateNormalAndDepth(), GetInitKFid(), mMutexMapUpdate, IncreaseChangeIndex(),
+// msOptKFs / msFixedKFs).  The four places that touch Sophus / Eigen value types go through `Access`:
+//     static void pose(const KeyFrame*, float q_xyzw[4], float t[3]);        // GetPose(): unit_quaternion(), translation()
+//     static void set_pose(KeyFrame*, const float q_xyzw[4], const float t[3]);   // SetPose(Sophus::SE3f(q, t))
+//     static void world_pos(const MapPoint*, float p[3]);                    // GetWorldPos()
+//     static void set_world_pos(MapPoint*, const float p[3]);                // SetWorldPos()
+// (INTEGRATION.md section 4 gives the Access for the reference's types; tests/host/lba_adaptor_test.cpp one for plain structs.)
+// `solve(problem, solution, stop)` is the numeric core: LocalBundleAdjuster::solve below (gfs_lba_solve on the GPU).
+//
+// Arithmetic the reference performs on the way in and out, reproduced here:
+//   * poses: Sophus::SE3<float> -> g2o::SE3Quat(q.cast<double>(), t.cast<double>()) (the constructor's normalizeRotation() is
+//     part of gfs_lba_solve), back through .cast<float>();
+//   * points: Eigen::Vector3f -> cast<double>() and back;
+//   * observations: kpUn.pt.x, kpUn.pt.y, mvuRight[idx] are floats assigned to doubles;
+//   * information: Identity * invSigma2 with `const float& invSigma2` -> the float value as a double;
+//   * Huber deltas: `const float thHuberMono = sqrt(5.991)` -> (double)(float)sqrt(5.991), same for sqrt(7.815).
+// Not supported (GFS_ERR_UNSUPPORTED is raised): key-frames with a second camera (mpCamera2, EdgeSE3ProjectXYZToBody
+// :1906-1949).  The ICP block :1762-1814 is dead code in the reference and has no counterpart.
+// ------------------------------------------------------------------------------------------------------------------------
+struct LbaFlat {  // the flattened graph, in the reference's vertex / edge creation order
+  std::vector<double> pose_q, pose_t, points, edge_obs, edge_inv_sigma2;
+  std::vector<uint8_t> pose_fixed, edge_stereo;
+  std::vector<int32_t> edge_pose, edge_point;
+  gfs_lba_problem problem{};
+  void finish(double fx, double fy, double cx, double cy, double bf) {
+    problem.n_poses = (int32_t)pose_fixed.size();
+    problem.n_points = (int32_t)(points.size() / 3);
+    problem.n_edges = (int32_t)edge_pose.size();
+    problem.pose_q = pose_q.data();
+    problem.pose_t = pose_t.data();
+    problem.pose_fixed = pose_fixed.data();
+    problem.points = points.data();
+    problem.edge_pose = edge_pose.data();
+    problem.edge_point = edge_point.data();
+    problem.edge_obs = edge_obs.data();
+    problem.edge_inv_sigma2 = edge_inv_sigma2.data();
+    problem.edge_stereo = edge_stereo.data();
+    problem.fx = fx;
+    problem.fy = fy;
+    problem.cx = cx;
+    problem.cy = cy;
+    problem.bf = bf;
+    const float thHuberMono = (float)std::sqrt(5.991), thHuberStereo = (float)std::sqrt(7.815);  // src/Optimizer.cc:1728-1729
+    problem.huber_mono = thHuberMono;
+    problem.huber_stereo = thHuberStereo;
+    problem.iterations = 10;  // optimizer.optimize(10), :1959
+  }
+};
+
+template <class Access, class KeyFrame, class MapPoint, class Map, class Solve>
+void LocalBundleAdjustment(Solve&& solve, KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
+                           int& /*num_MPs: never written by the reference either*/, int& num_edges) {
+  // ---- Local KeyFrames: first breadth search from the current key-frame (:1592-1607)
+  std::list<KeyFrame*> lLocalKeyFrames;
+  lLocalKeyFrames.push_back(pKF);
+  pKF->mnBALocalForKF = pKF->mnId;
+  Map* pCurrentMap = pKF->GetMap();
+  const std::vector<KeyFrame*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+  for (int i = 0, iend = (int)vNeighKFs.size(); i < iend; i++) {
+    KeyFrame* pKFi = vNeighKFs[i];
+    pKFi->mnBALocalForKF = pKF->mnId;
+    if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lLocalKeyFrames.push_back(pKFi);
+  }
+  // ---- Local MapPoints seen in local key-frames (:1609-1634)
+  num_fixedKF = 0;
+  std::list<MapPoint*> lLocalMapPoints;
+  for (KeyFrame* pKFi : lLocalKeyFrames) {
+    if (pKFi->mnId == pMap->GetInitKFid()) num_fixedKF = 1;
+    std::vector<MapPoint*> vpMPs = pKFi->GetMapPointMatches();
+    for (MapPoint* pMP : vpMPs)
+      if (pMP)
+        if (!pMP->isBad() && pMP->GetMap() == pCurrentMap)
+          if (pMP->mnBALocalForKF != pKF->mnId) {
+            lLocalMapPoints.push_back(pMP);
+            pMP->mnBALocalForKF = pKF->mnId;
+          }
+  }
+  // ---- Fixed key-frames: see local MapPoints but are not local (:1636-1660)
+  std::list<KeyFrame*> lFixedCameras;
+  for (MapPoint* pMP : lLocalMapPoints) {
+    auto observations = pMP->GetObservations();  // std::map<KeyFrame*, std::tuple<int, int>>
+    for (auto mit = observations.begin(), mend = observations.end(); mit != mend; ++mit) {
+      KeyFrame* pKFi = mit->first;
+      if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+        pKFi->mnBAFixedForKF = pKF->mnId;
+        if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lFixedCameras.push_back(pKFi);
+      }
+    }
+  }
+  num_fixedKF = (int)lFixedCameras.size() + num_fixedKF;
+  if (num_fixedKF == 0) return;  // "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted" (:1662-1667)
+
+  // ---- vertices (:1686-1721): pose index = creation order, local key-frames first
+  LbaFlat F;
+  std::map<const KeyFrame*, int32_t> pose_index;  // == optimizer.vertex(pKFi->mnId) != NULL
+  pCurrentMap->msOptKFs.clear();
+  pCurrentMap->msFixedKFs.clear();
+  auto add_pose = [&](KeyFrame* pKFi, bool fixed) {
+    float q[4], t[3];
+    Access::pose(pKFi, q, t);
+    pose_index[pKFi] = (int32_t)F.pose_fixed.size();
+    for (int k = 0; k < 4; k++) F.pose_q.push_back((double)q[k]);  // .cast<double>()
+    for (int k = 0; k < 3; k++) F.pose_t.push_back((double)t[k]);
+    F.pose_fixed.push_back(fixed ? 1 : 0);
+  };
+  for (KeyFrame* pKFi : lLocalKeyFrames) {
+    add_pose(pKFi, pKFi->mnId == pMap->GetInitKFid());  // vSE3->setFixed(pKFi->mnId == pMap->GetInitKFid())
+    pCurrentMap->msOptKFs.insert(pKFi->mnId);
+  }
+  num_OptKF = (int)lLocalKeyFrames.size();
+  for (KeyFrame* pKFi : lFixedCameras) {
+    add_pose(pKFi, true);
+    pCurrentMap->msFixedKFs.insert(pKFi->mnId);
+  }
+  // ---- MapPoint vertices and edges (:1816-1952).  The mono, body and stereo edges live in three vectors in the reference and
+  //      are classified in that order afterwards; here every edge records its kind and (key-frame, point).
+  struct EdgeRef {
+    KeyFrame* kf;
+    MapPoint* mp;
+  };
+  std::vector<EdgeRef> vpEdgesMono, vpEdgesStereo;
+  std::vector<int32_t> mono_edge, stereo_edge;  // flat edge index of the k-th mono / stereo edge
+  int nEdges = 0;
+  int32_t point_index = 0;
+  for (MapPoint* pMP : lLocalMapPoints) {
+    float X[3];
+    Access::world_pos(pMP, X);
+    for (int k = 0; k < 3; k++) F.points.push_back((double)X[k]);
+    const auto observations = pMP->GetObservations();
+    for (auto mit = observations.begin(), mend = observations.end(); mit != mend; ++mit) {
+      KeyFrame* pKFi = mit->first;
+      if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) {
+        const int leftIndex = std::get<0>(mit->second);
+        const auto pit = pose_index.find(pKFi);
+        if (leftIndex != -1) {
+          const bool stereo = pKFi->mvuRight[leftIndex] >= 0;
+          if (pit != pose_index.end()) {  // optimizer.vertex(pKFi->mnId) == NULL -> continue
+            const auto& kpUn = pKFi->mvKeysUn[leftIndex];
+            F.edge_pose.push_back(pit->second);
+            F.edge_point.push_back(point_index);
+            F.edge_obs.push_back((double)kpUn.pt.x);
+            F.edge_obs.push_back((double)kpUn.pt.y);
+            F.edge_obs.push_back(stereo ? (double)pKFi->mvuRight[leftIndex] : 0.0);
+            const float& invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave];
+            F.edge_inv_sigma2.push_back((double)invSigma2);
+            F.edge_stereo.push_back(stereo ? 1 : 0);
+            (stereo ? vpEdgesStereo : vpEdgesMono).push_back(EdgeRef{pKFi, pMP});
+            (stereo ? stereo_edge : mono_edge).push_back((int32_t)F.edge_pose.size() - 1);
+            nEdges++;
+          } else {
+            continue;  // (the reference's `continue` also skips the second-camera block of this observation)
+          }
+        }
+        if (pKFi->mpCamera2 && std::get<1>(mit->second) != -1)
+          throw std::runtime_error("LocalBundleAdjustment: second-camera observations (EdgeSE3ProjectXYZToBody) are not supported");
+      }
+    }
+    point_index++;
+  }
+  num_edges = nEdges;
+  if (pbStopFlag)
+    if (*pbStopFlag) return;  // :1955-1956
+  F.finish(pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf);
+
+  // ---- optimizer.initializeOptimization(); optimizer.optimize(10);
+  std::vector<double> out_q(F.pose_q.size()), out_t(F.pose_t.size()), out_p(F.points.size()), chi2((size_t)std::max(nEdges, 1));
+  std::vector<uint8_t> depth_pos((size_t)std::max(nEdges, 1));
+  gfs_lba_solution S{};
+  S.pose_q = out_q.data();
+  S.pose_t = out_t.data();
+  S.points = out_p.data();
+  S.edge_chi2 = chi2.data();
+  S.edge_depth_positive = depth_pos.data();
+  if (!solve(F.problem, S, pbStopFlag)) return;
+
+  // ---- check inlier observations (:1961-1999): mono edges first, then stereo, each in creation order
+  std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;
+  vToErase.reserve(vpEdgesMono.size() + vpEdgesStereo.size());
+  for (size_t i = 0; i < vpEdgesMono.size(); i++) {
+    MapPoint* pMP = vpEdgesMono[i].mp;
+    if (pMP->isBad()) continue;
+    const int32_t e = mono_edge[i];
+    if (chi2[e] > 5.991 || !depth_pos[e]) vToErase.push_back(std::make_pair(vpEdgesMono[i].kf, pMP));
+  }
+  for (size_t i = 0; i < vpEdgesStereo.size(); i++) {
+    MapPoint* pMP = vpEdgesStereo[i].mp;
+    if (pMP->isBad()) continue;
+    const int32_t e = stereo_edge[i];
+    if (chi2[e] > 7.815 || !depth_pos[e]) vToErase.push_back(std::make_pair(vpEdgesStereo[i].kf, pMP));
+  }
+  // ---- write-back under the map mutex (:2001-2039)
+  std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+  for (size_t i = 0; i < vToErase.size(); i++) {
+    KeyFrame* pKFi = vToErase[i].first;
+    MapPoint* pMPi = vToErase[i].second;
+    pKFi->EraseMapPointMatch(pMPi);
+    pMPi->EraseObservation(pKFi);
+  }
+  {
+    int32_t k = 0;
+    for (KeyFrame* pKFi : lLocalKeyFrames) {  // SE3quat.rotation().cast<float>(), translation().cast<float>()
+      float q[4], t[3];
+      for (int c = 0; c < 4; c++) q[c] = (float)out_q[4 * (size_t)k + c];
+      for (int c = 0; c < 3; c++) t[c] = (float)out_t[3 * (size_t)k + c];
+      Access::set_pose(pKFi, q, t);
+      k++;
+    }
+  }
+  {
+    int32_t k = 0;
+    for (MapPoint* pMP : lLocalMapPoints) {
+      float X[3];
+      for (int c = 0; c < 3; c++) X[c] = (float)out_p[3 * (size_t)k + c];
+      Access::set_world_pos(pMP, X);
+      pMP->UpdateNormalAndDepth();
+      k++;
+    }
+  }
+  pMap->IncreaseChangeIndex();
+}
+
+template <class Access, class KeyFrame, class Map>
+void LocalBundleAdjuster::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
+                                                int& num_MPs, int& num_edges) {
+  using MapPoint = typename std::remove_pointer<typename decltype(pKF->GetMapPointMatches())::value_type>::type;
+  gfs_host::LocalBundleAdjustment<Access, KeyFrame, MapPoint, Map>(
+      [this](const gfs_lba_problem& p, gfs_lba_solution& s, const bool* stop) { return this->solve(p, s, stop); }, pKF, pbStopFlag,
+      pMap, num_fixedKF, num_OptKF, num_MPs, num_edges);
+}
 
 // gms_matcher(kp1, size1, kp2, size2, matches).GetInlierMask(mask, false, false) (reference Thirdparty/GMS/include/gms_matcher.h;
 // the filter SearchWithGMS applies to the brute-force matches, src/ORBmatcher.cc:761-762)

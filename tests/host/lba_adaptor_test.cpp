@@ -1,0 +1,201 @@
+// Test harness for gfs_host::LocalBundleAdjustment (geoflowslam_amd/host/gfs_adaptors.hpp): plain-struct stand-ins for the
+// members of KeyFrame / MapPoint / Map that Optimizer::LocalBundleAdjustment touches (reference src/Optimizer.cc:1588-2040),
+// filled from a flat synthetic window; the adaptor gathers, solves (CPU oracle through dlopen, or the GPU library) and writes
+// back; the caller inspects the stand-ins.  Built by tests/test_lba_adaptor.py with g++.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <memory>
+
+#include "../../geoflowslam_amd/host/gfs_adaptors.hpp"
+
+namespace {
+struct MockMap;
+struct MockMapPoint;
+struct MockKeyFrame {
+  unsigned long mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
+  bool bad = false;
+  MockMap* map = nullptr;
+  float q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+  std::vector<MockMapPoint*> mvpMapPoints;
+  std::vector<MockKeyFrame*> covisible;
+  struct KP {
+    struct {
+      float x, y;
+    } pt;
+    int octave;
+  };
+  std::vector<KP> mvKeysUn;
+  std::vector<float> mvuRight, mvInvLevelSigma2;
+  float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+  void* mpCamera2 = nullptr;
+  int n_set_pose = 0;
+  bool isBad() const { return bad; }
+  MockMap* GetMap() const { return map; }
+  std::vector<MockKeyFrame*> GetVectorCovisibleKeyFrames() const { return covisible; }
+  std::vector<MockMapPoint*> GetMapPointMatches() const { return mvpMapPoints; }
+  void EraseMapPointMatch(MockMapPoint* p) {
+    for (auto& m : mvpMapPoints)
+      if (m == p) m = nullptr;
+  }
+};
+struct MockMapPoint {
+  unsigned long mnId = 0, mnBALocalForKF = ~0ul;
+  bool bad = false;
+  MockMap* map = nullptr;
+  float pos[3] = {0, 0, 0};
+  std::map<MockKeyFrame*, std::tuple<int, int>> obs;
+  int n_update = 0;
+  bool isBad() const { return bad; }
+  MockMap* GetMap() const { return map; }
+  std::map<MockKeyFrame*, std::tuple<int, int>> GetObservations() const { return obs; }
+  void EraseObservation(MockKeyFrame* kf) { obs.erase(kf); }
+  void UpdateNormalAndDepth() { n_update++; }
+};
+struct MockMap {
+  unsigned long init_id = ~0ul;
+  std::mutex mMutexMapUpdate;
+  int change_index = 0;
+  std::set<unsigned long> msOptKFs, msFixedKFs;
+  unsigned long GetInitKFid() const { return init_id; }
+  void IncreaseChangeIndex() { change_index++; }
+};
+struct MockAccess {
+  static void pose(const MockKeyFrame* k, float q[4], float t[3]) {
+    std::memcpy(q, k->q, 16);
+    std::memcpy(t, k->t, 12);
+  }
+  static void set_pose(MockKeyFrame* k, const float q[4], const float t[3]) {
+    std::memcpy(k->q, q, 16);
+    std::memcpy(k->t, t, 12);
+    k->n_set_pose++;
+  }
+  static void world_pos(const MockMapPoint* p, float x[3]) { std::memcpy(x, p->pos, 12); }
+  static void set_world_pos(MockMapPoint* p, const float x[3]) { std::memcpy(p->pos, x, 12); }
+};
+}  // namespace
+
+extern "C" int lba_adaptor_test(const char* solver_lib, int n_poses, int n_points, int n_edges, const double* pose_q,
+                                const double* pose_t, const uint8_t* pose_fixed, const double* points, const int32_t* edge_pose,
+                                const int32_t* edge_point, const double* edge_obs, const double* edge_inv_sigma2,
+                                const uint8_t* edge_stereo, double fx, double fy, double cx, double cy, double bf, int init_kf_pose,
+                                int bad_point, int stop_flag, float* out_pose_q, float* out_pose_t, float* out_points,
+                                int32_t* erased_pairs, int32_t* counts /*[8]*/, double* hubers /*[2]*/, double* flat_inv_sigma2,
+                                double* flat_obs, int32_t* flat_edge_pose_id, int32_t* flat_edge_point_id) {
+  try {
+    MockMap map;
+    std::vector<MockKeyFrame> kfs((size_t)n_poses);
+    std::vector<MockMapPoint> mps((size_t)n_points);
+    int pkf = -1;
+    for (int i = 0; i < n_poses; i++) {
+      MockKeyFrame& k = kfs[i];
+      k.mnId = 10 + (unsigned long)i;
+      k.map = &map;
+      for (int c = 0; c < 4; c++) k.q[c] = (float)pose_q[4 * i + c];
+      for (int c = 0; c < 3; c++) k.t[c] = (float)pose_t[3 * i + c];
+      k.fx = (float)fx;
+      k.fy = (float)fy;
+      k.cx = (float)cx;
+      k.cy = (float)cy;
+      k.mbf = (float)bf;
+      k.mvInvLevelSigma2.assign(n_edges > 0 ? 1 : 0, 0.f);  // per-"octave" table: one entry per key-point below
+      if (!pose_fixed[i] && pkf < 0) pkf = i;
+    }
+    if (pkf < 0) return -100;
+    for (int i = 0; i < n_poses; i++)
+      if (!pose_fixed[i] && i != pkf) kfs[pkf].covisible.push_back(&kfs[i]);
+    if (init_kf_pose >= 0) map.init_id = kfs[init_kf_pose].mnId;
+    for (int j = 0; j < n_points; j++) {
+      mps[j].mnId = 1000 + (unsigned long)j;
+      mps[j].map = &map;
+      for (int c = 0; c < 3; c++) mps[j].pos[c] = (float)points[3 * j + c];
+    }
+    if (bad_point >= 0) mps[bad_point].bad = true;
+    for (int e = 0; e < n_edges; e++) {  // key-point e' of its key-frame: "octave" = its own index into mvInvLevelSigma2
+      MockKeyFrame& k = kfs[edge_pose[e]];
+      const int kp = (int)k.mvKeysUn.size();
+      MockKeyFrame::KP u;
+      u.pt.x = (float)edge_obs[3 * e];
+      u.pt.y = (float)edge_obs[3 * e + 1];
+      u.octave = kp;
+      k.mvKeysUn.push_back(u);
+      k.mvuRight.push_back(edge_stereo[e] ? (float)edge_obs[3 * e + 2] : -1.f);
+      if ((int)k.mvInvLevelSigma2.size() <= kp) k.mvInvLevelSigma2.resize((size_t)kp + 1);
+      k.mvInvLevelSigma2[kp] = (float)edge_inv_sigma2[e];
+      k.mvpMapPoints.push_back(&mps[edge_point[e]]);
+      mps[edge_point[e]].obs[&k] = std::make_tuple(kp, -1);
+    }
+    bool stop = stop_flag != 0;
+    int num_fixedKF = -1, num_OptKF = -1, num_MPs = -7, num_edges = -1;
+    gfs_lba_problem seen{};
+    std::vector<double> seen_is2, seen_obs;
+    std::vector<int32_t> seen_ep, seen_el;
+    std::vector<double> seen_pose_t;
+    auto record = [&](const gfs_lba_problem& p) {
+      seen = p;
+      seen_is2.assign(p.edge_inv_sigma2, p.edge_inv_sigma2 + p.n_edges);
+      seen_obs.assign(p.edge_obs, p.edge_obs + 3 * (size_t)p.n_edges);
+      seen_ep.assign(p.edge_pose, p.edge_pose + p.n_edges);
+      seen_el.assign(p.edge_point, p.edge_point + p.n_edges);
+    };
+    if (solver_lib) {  // the CPU oracle (identical struct layouts): int gfso_lba_solve(const problem*, solution*)
+      void* so = dlopen(solver_lib, RTLD_NOW | RTLD_LOCAL);
+      if (!so) return -101;
+      typedef int (*fn_t)(const gfs_lba_problem*, gfs_lba_solution*);
+      fn_t fn = (fn_t)dlsym(so, "gfso_lba_solve");
+      if (!fn) return -102;
+      gfs_host::LocalBundleAdjustment<MockAccess, MockKeyFrame, MockMapPoint, MockMap>(
+          [&](const gfs_lba_problem& p, gfs_lba_solution& s, const bool*) {
+            record(p);
+            fn(&p, &s);
+            return true;
+          },
+          &kfs[pkf], stop_flag >= 0 ? &stop : nullptr, &map, num_fixedKF, num_OptKF, num_MPs, num_edges);
+    } else {
+      gfs_host::LocalBundleAdjuster lba(std::max(n_poses, 8), std::max(n_points, 64), std::max(n_edges, 64));
+      gfs_host::LocalBundleAdjustment<MockAccess, MockKeyFrame, MockMapPoint, MockMap>(
+          [&](const gfs_lba_problem& p, gfs_lba_solution& s, const bool* st) {
+            record(p);
+            return lba.solve(p, s, st);
+          },
+          &kfs[pkf], stop_flag >= 0 ? &stop : nullptr, &map, num_fixedKF, num_OptKF, num_MPs, num_edges);
+    }
+    for (int i = 0; i < n_poses; i++) {
+      std::memcpy(out_pose_q + 4 * i, kfs[i].q, 16);
+      std::memcpy(out_pose_t + 3 * i, kfs[i].t, 12);
+    }
+    for (int j = 0; j < n_points; j++) std::memcpy(out_points + 3 * j, mps[j].pos, 12);
+    int ner = 0;
+    for (int e = 0; e < n_edges; e++) {  // observations that were erased: (pose, point) pairs no longer linked
+      MockKeyFrame& k = kfs[edge_pose[e]];
+      if (mps[edge_point[e]].obs.find(&k) == mps[edge_point[e]].obs.end()) {
+        erased_pairs[2 * ner] = edge_pose[e];
+        erased_pairs[2 * ner + 1] = edge_point[e];
+        ner++;
+      }
+    }
+    int n_set = 0, n_upd = 0;
+    for (auto& k : kfs) n_set += k.n_set_pose;
+    for (auto& m : mps) n_upd += m.n_update;
+    counts[0] = num_fixedKF;
+    counts[1] = num_OptKF;
+    counts[2] = num_edges;
+    counts[3] = map.change_index;
+    counts[4] = ner;
+    counts[5] = n_set;
+    counts[6] = n_upd;
+    counts[7] = num_MPs;
+    hubers[0] = seen.huber_mono;
+    hubers[1] = seen.huber_stereo;
+    for (int e = 0; e < seen.n_edges; e++) {
+      flat_inv_sigma2[e] = seen_is2[e];
+      for (int c = 0; c < 3; c++) flat_obs[3 * e + c] = seen_obs[3 * e + c];
+      flat_edge_pose_id[e] = seen_ep[e];
+      flat_edge_point_id[e] = seen_el[e];
+    }
+    return seen.n_edges * 1000 + seen.n_poses;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "lba_adaptor_test: %s\n", ex.what());
+    return -1;
+  }
+}
