@@ -1041,35 +1041,19 @@ __device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __
   if (threadIdx.x < N) dst[threadIdx.x] = r;
 }
 
-// GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
-// machine is in the "linearise" phase; per-block partial sums of H (upper), b, e and the inlier count.
-__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gicp_linearize(const PairState* __restrict__ st,
-                                                              const double4* __restrict__ pts,
-                                                              const double* __restrict__ cov6, const u64* __restrict__ ucell,
-                                                              const unsigned* __restrict__ ubegin,
-                                                              const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
-                                                              const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
-                                                              int nchunks, int npairs, int P, GicpParams prm,
-                                                              int* __restrict__ tgt_index, double* __restrict__ maha6,
-                                                              double* __restrict__ partial, int nblk) {
-  __shared__ double s_red[4 * 32];
-  int pair, sub, chunk;
-  if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
-  const PairState S = st[pair];
-  if (S.phase != 0) return;
-  const int cs = 2 * pair + prm.src_slot, ct = 2 * pair + 1 - prm.src_slot;
-  const int ms = m_counts[cs];
-  if (chunk * kLinBlock >= ms) return;
-  const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
-  const int* gi = ginfo + 8 * ct;
-  const int i = chunk * kLinBlock + threadIdx.x;
-  double acc[kRed];
-#pragma unroll
-  for (int k = 0; k < kRed; k++) acc[k] = 0;
-  if (i < ms) {
+// GICPFactor::linearize (factors/gicp_factor.hpp:35-73) of source point i of a pair under the pose T12 (R col-major | t): exact
+// 1-NN in the target cloud, rejection beyond max_dist, the Mahalanobis matrix, and this point's terms ADDED to acc (H upper
+// triangle 21, b 6, e, inlier count).  Records the correspondence and the matrix for the error evaluations that follow.
+__device__ __forceinline__ void gicp_lin_point(int i, const double* __restrict__ T12, bool has_prev, int pair, int cs, int ct, int P,
+                                               const double4* __restrict__ pts, const double* __restrict__ cov6,
+                                               const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
+                                               const int* __restrict__ n_ucell, const unsigned* __restrict__ G,
+                                               const int* __restrict__ gi, const GicpParams& prm, int* __restrict__ tgt_index,
+                                               double* __restrict__ maha6, double (&acc)[kRed]) {
+  {
     const double4 p = pts[(size_t)cs * P + i];
-    const double* R = S.T;
-    const double* t = S.T + 9;
+    const double* R = T12;
+    const double* t = T12 + 9;
     const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
     const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
     const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
@@ -1088,7 +1072,7 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
         // from the correspondence of the previous linearisation (re-evaluated under the new pose) when there is one,
         // so most lanes visit their own cell and little else; each lane walks only its surviving cells (nn_scan_runs4).
         double B = prm.max_dist_sq;
-        if (S.n_lin > 0) {
+        if (has_prev) {
           const int pj = tgt_index[(size_t)pair * P + i];
           if (pj >= 0) {
             const double4 q = tp[pj];
@@ -1233,15 +1217,44 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
         for (int r = 0; r < 3; r++) MJ[r + 3 * cc] = M[r] * J[3 * cc] + M[r + 3] * J[3 * cc + 1] + M[r + 6] * J[3 * cc + 2];
       int o = 0;
       for (int r = 0; r < 6; r++)
-        for (int cc = r; cc < 6; cc++) acc[o++] = J[3 * r] * MJ[3 * cc] + J[3 * r + 1] * MJ[3 * cc + 1] + J[3 * r + 2] * MJ[3 * cc + 2];
+        for (int cc = r; cc < 6; cc++) acc[o++] += J[3 * r] * MJ[3 * cc] + J[3 * r + 1] * MJ[3 * cc + 1] + J[3 * r + 2] * MJ[3 * cc + 2];
       double Mr[3];
       for (int r = 0; r < 3; r++) Mr[r] = M[r] * res[0] + M[r + 3] * res[1] + M[r + 6] * res[2];
-      for (int r = 0; r < 6; r++) acc[21 + r] = J[3 * r] * Mr[0] + J[3 * r + 1] * Mr[1] + J[3 * r + 2] * Mr[2];
-      acc[27] = 0.5 * (res[0] * Mr[0] + res[1] * Mr[1] + res[2] * Mr[2]);
-      acc[28] = 1.0;
+      for (int r = 0; r < 6; r++) acc[21 + r] += J[3 * r] * Mr[0] + J[3 * r + 1] * Mr[1] + J[3 * r + 2] * Mr[2];
+      acc[27] += 0.5 * (res[0] * Mr[0] + res[1] * Mr[1] + res[2] * Mr[2]);
+      acc[28] += 1.0;
     }
     tgt_index[(size_t)pair * P + i] = ti;
   }
+}
+
+// GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
+// machine is in the "linearise" phase; per-block partial sums of H (upper), b, e and the inlier count.
+__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gicp_linearize(const PairState* __restrict__ st,
+                                                              const double4* __restrict__ pts,
+                                                              const double* __restrict__ cov6, const u64* __restrict__ ucell,
+                                                              const unsigned* __restrict__ ubegin,
+                                                              const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
+                                                              const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
+                                                              int nchunks, int npairs, int P, GicpParams prm,
+                                                              int* __restrict__ tgt_index, double* __restrict__ maha6,
+                                                              double* __restrict__ partial, int nblk) {
+  __shared__ double s_red[4 * 32];
+  int pair, sub, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
+  const PairState S = st[pair];
+  if (S.phase != 0) return;
+  const int cs = 2 * pair + prm.src_slot, ct = 2 * pair + 1 - prm.src_slot;
+  const int ms = m_counts[cs];
+  if (chunk * kLinBlock >= ms) return;
+  const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
+  const int* gi = ginfo + 8 * ct;
+  const int i = chunk * kLinBlock + threadIdx.x;
+  double acc[kRed];
+#pragma unroll
+  for (int k = 0; k < kRed; k++) acc[k] = 0;
+  if (i < ms)
+    gicp_lin_point(i, S.T, S.n_lin > 0, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm, tgt_index, maha6, acc);
   block_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + chunk) * kRed, s_red);
 }
 
@@ -1500,6 +1513,131 @@ __global__ __launch_bounds__(256) void k_gicp_decide(PairState* __restrict__ st,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gicp_lm: LevenbergMarquardtOptimizer::optimize (registration/optimizer.hpp:83-147) of ONE pair per workgroup, start to
+// finish: linearise -> damped solve -> error of the trial -> accept / reject, until converged or out of iterations.  The
+// pairs of a batch converge after different numbers of iterations (3 ... 20): with one launch per step of the state machine
+// (k_gicp_linearize / solve / error / decide, the default) the late rounds run for a handful of pairs on an otherwise idle GPU
+// and every round pays four launches and a host poll; here a finished pair simply frees its compute unit.  Selected with
+// GFS_GICP_LM=persistent; results are identical to rounding (the sums are folded in a different fixed order).
+// 512 threads walk the source points with a stride, every thread adds its points into its own 29 sums, which are then
+// folded in a fixed order (wave halving tree, 8 waves in order): deterministic and independent of the batch.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLmBlock = 512;
+
+__global__ __launch_bounds__(kLmBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_gicp_lm(
+    PairState* __restrict__ st, const double4* __restrict__ pts, const double* __restrict__ cov6, const u64* __restrict__ ucell,
+    const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
+    const unsigned* __restrict__ grid, const int* __restrict__ ginfo, int npairs, int P, GicpParams prm, int* __restrict__ tgt_index,
+    double* __restrict__ maha6) {
+  __shared__ PairState S;
+  __shared__ double s_red[(kLmBlock / 64) * 32], s_sum[32];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (pair >= npairs) return;
+  if (tid == 0) S = st[pair];  // initialised by k_gicp_init
+  __syncthreads();
+  const int cs = 2 * pair + prm.src_slot, ct = 2 * pair + 1 - prm.src_slot;
+  const int ms = m_counts[cs];
+  const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
+  const int* gi = ginfo + 8 * ct;
+  while (true) {
+    const int phase = S.phase;  // uniform: read after a barrier
+    if (phase == 2) break;
+    if (phase == 0) {
+      double acc[kRed];
+#pragma unroll
+      for (int k = 0; k < kRed; k++) acc[k] = 0;
+      const bool has_prev = S.n_lin > 0;
+      for (int i = tid; i < ms; i += kLmBlock)
+        gicp_lin_point(i, S.T, has_prev, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm, tgt_index, maha6, acc);
+      const double r = gfs_red::block_sum_many<kRed, kLmBlock / 64>(acc, s_red);
+      if (tid < kRed) s_sum[tid] = r;
+      __syncthreads();
+      if (tid == 0) {  // as k_gicp_solve
+        double H[21], b[6], T[12], delta[6], newT[12];
+#pragma unroll
+        for (int k = 0; k < 21; k++) H[k] = s_sum[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) b[k] = s_sum[21 + k];
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = S.T[k];
+        solve_and_propose(H, b, S.lambda, T, delta, newT);
+#pragma unroll
+        for (int k = 0; k < 21; k++) S.H[k] = H[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) S.b[k] = b[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) S.delta[k] = delta[k];
+#pragma unroll
+        for (int k = 0; k < 12; k++) S.newT[k] = newT[k];
+        S.e = s_sum[27];
+        S.inliers = (int)(s_sum[28] + 0.5);
+        S.n_lin++;
+        S.inner = 0;
+        S.phase = 1;
+      }
+      __threadfence_block();  // tgt_index / maha6 of this linearisation are read by other threads below
+      __syncthreads();
+    } else {
+      double e[1] = {0.0};
+      const double* R = S.newT;
+      const double* t = S.newT + 9;
+      for (int i = tid; i < ms; i += kLmBlock) {  // GICPFactor::error with the frozen correspondences (as k_gicp_error)
+        const int ti = tgt_index[(size_t)pair * P + i];
+        if (ti >= 0) {
+          const double4 p = pts[(size_t)cs * P + i];
+          const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
+          const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
+          const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
+          const double4 q = pts[(size_t)ct * P + ti];
+          const double r0 = q.x - tx, r1 = q.y - ty, r2 = q.z - tz;
+          const double* M = maha6 + ((size_t)pair * P + i) * 6;
+          const double m0 = M[0] * r0 + M[1] * r1 + M[2] * r2, m1 = M[1] * r0 + M[3] * r1 + M[4] * r2,
+                       m2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
+          e[0] += 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
+        }
+      }
+      const double r = gfs_red::block_sum_many<1, kLmBlock / 64>(e, s_red);
+      if (tid == 0) {  // as k_gicp_decide (registration/optimizer.hpp:115-141)
+        const double new_e = r;
+        S.n_err++;
+        if (new_e <= S.e) {
+          const double dr = sqrt(S.delta[0] * S.delta[0] + S.delta[1] * S.delta[1] + S.delta[2] * S.delta[2]);
+          const double dt = sqrt(S.delta[3] * S.delta[3] + S.delta[4] * S.delta[4] + S.delta[5] * S.delta[5]);
+          S.converged = (dr <= prm.rot_eps && dt <= prm.trans_eps) ? 1 : 0;
+          for (int k = 0; k < 12; k++) S.T[k] = S.newT[k];
+          S.lambda /= 10.0;
+          S.iterations = S.outer;
+          S.outer++;
+          S.phase = (S.converged || S.outer >= prm.max_iterations) ? 2 : 0;
+        } else {
+          S.lambda *= 10.0;
+          S.inner++;
+          if (S.inner >= 10) {  // max_inner_iterations: !success -> break
+            S.iterations = S.outer;
+            S.phase = 2;
+          } else {
+            double H[21], b[6], T[12], delta[6], newT[12];
+#pragma unroll
+            for (int k = 0; k < 21; k++) H[k] = S.H[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) b[k] = S.b[k];
+#pragma unroll
+            for (int k = 0; k < 12; k++) T[k] = S.T[k];
+            solve_and_propose(H, b, S.lambda, T, delta, newT);
+#pragma unroll
+            for (int k = 0; k < 6; k++) S.delta[k] = delta[k];
+#pragma unroll
+            for (int k = 0; k < 12; k++) S.newT[k] = newT[k];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) st[pair] = S;
+}
+
 __global__ void k_gicp_init(PairState* __restrict__ st, const double* __restrict__ init_T, int B, int max_iterations,
                             int* __restrict__ n_done) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1541,6 +1679,10 @@ struct gfs_gicp {
   gfs::DevBuf<int> d_nleaf, d_nheap;
   gfs::DevBuf<unsigned> d_heap;  // per cloud: (begin, end) of the ranges that hit std::sort's depth limit (heap-sort fallback)
   int heap_cap = 0;
+  // one launch per step of the LM state machine (default).  GFS_GICP_LM=persistent: the whole loop of a pair in one workgroup
+  // (k_gicp_lm) — no launches / host polls inside the loop, but only one workgroup of parallelism per pair: measured 4x slower at
+  // 128 pairs per batch (25 vs 6 ms per 512 pairs), it pays only for batches of many thousand small pairs.
+  bool lm_rounds = true;
   bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
   gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
@@ -1626,6 +1768,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   h->nblk = gfs::div_up(h->P, kLinBlock);
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   if (const char* e = getenv("GFS_GICP_VOXEL_ORDER")) h->stable_voxel_order = strcmp(e, "stable") == 0;
+  if (const char* e = getenv("GFS_GICP_LM")) h->lm_rounds = strcmp(e, "persistent") != 0;
   const size_t P = h->P, B = max_batch, C2 = 2 * B;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
@@ -1786,24 +1929,30 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
   GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
              prm.max_iterations, h->d_ndone.p);
-  const int nblk_run = gfs::div_up(npts, kLinBlock);
-  const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
-  for (int round = 0; round < max_rounds; round++) {
-    GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
-               h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
-               nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
-    GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot);
-    GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
-               h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B, prm.src_slot);
-    GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
-               h->d_ndone.p);
-    // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
-    // speculative round after convergence finds every pair in phase 2 and its blocks exit at once.
-    GFS_HIP(hipMemcpyAsync(h->h_ndone.p + (round & 1), h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    GFS_HIP(hipEventRecord(h->ev_round[round & 1], s));
-    if (round >= 1) {
-      GFS_HIP(hipEventSynchronize(h->ev_round[(round - 1) & 1]));
-      if (h->h_ndone.p[(round - 1) & 1] >= B) break;
+  if (!h->lm_rounds) {
+    // the whole Levenberg-Marquardt loop of a pair in one workgroup (k_gicp_lm): one launch, no host poll
+    GFS_LAUNCH("k_gicp_lm", k_gicp_lm, dim3(B), dim3(kLmBlock), 0, s, h->d_state.p, h->d_pts.p, h->d_cov6.p, h->d_ucell.p,
+               h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p, B, P, prm, h->d_tgt_index.p, h->d_maha6.p);
+  } else {
+    const int nblk_run = gfs::div_up(npts, kLinBlock);
+    const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
+    for (int round = 0; round < max_rounds; round++) {
+      GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
+                 h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
+                 nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
+      GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot);
+      GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
+                 h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B, prm.src_slot);
+      GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
+                 h->d_ndone.p);
+      // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
+      // speculative round after convergence finds every pair in phase 2 and its blocks exit at once.
+      GFS_HIP(hipMemcpyAsync(h->h_ndone.p + (round & 1), h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      GFS_HIP(hipEventRecord(h->ev_round[round & 1], s));
+      if (round >= 1) {
+        GFS_HIP(hipEventSynchronize(h->ev_round[(round - 1) & 1]));
+        if (h->h_ndone.p[(round - 1) & 1] >= B) break;
+      }
     }
   }
   GFS_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, (size_t)B * sizeof(PairState), hipMemcpyDeviceToHost, s));

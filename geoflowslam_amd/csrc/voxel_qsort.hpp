@@ -357,8 +357,12 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   const int n = __builtin_amdgcn_readfirstlane(counts[c]);
   u64* ka = keys_all + (size_t)c * P;
   unsigned* va = vals_all + (size_t)c * P;
-  (void)side_all;  // (the partition sweep exchanges positions through LDS)
+  // Two copies of (key, point index): a partition sweep reads one and writes the other (elements are re-read in every step of a
+  // sweep, coalesced and from L2, rather than held in registers: it keeps the kernel at 2 workgroups per compute unit)
   unsigned* kscr = kscr_all + (size_t)c * P;
+  unsigned* kbuf[2] = {kscr, (unsigned*)(side_all + (size_t)c * P)};
+  unsigned* vbuf[2] = {va, (unsigned*)(side_all + (size_t)c * P) + P};
+  int cur = 0;
   unsigned* leaf = leaf_all + (size_t)c * P;
   if (tid < 3) {
     s_mn[tid] = 0x7fffffff;
@@ -426,15 +430,14 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
     }
   }
   __syncthreads();
-  const int E = (n + 1023) / 1024, i0 = wave * E * 64 + lane;
+  const int E = (n + 1023) / 1024;
   const u64 ltm = lanemask_lt();
-  unsigned key[EMAX], val[EMAX];
   while (true) {
     const int nseg = __builtin_amdgcn_readfirstlane(s_nseg);
     if (nseg == 0) break;
     if (tid < nseg) {
       const int b = seg_b[tid], len = seg_e[tid] - b, off = len / 8;  // sort_omp.hpp:70-75
-      const unsigned* f = kscr + b;
+      const unsigned* f = kbuf[cur] + b;
       auto m3 = [](unsigned x, unsigned y, unsigned z) { return x < y ? (y < z ? y : (x < z ? z : x)) : (x < z ? x : (y < z ? z : y)); };
       const unsigned m1 = m3(f[0], f[off], f[off * 2]), m2 = m3(f[off * 3], f[off * 4], f[off * 5]),
                      mm = m3(f[off * 6], f[off * 7], f[len - 1]);
@@ -442,18 +445,6 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
       eq_cnt[tid] = 0;
     }
     if (tid == 0) s_over = 0;
-#pragma unroll
-    for (int r = 0; r < EMAX; r++) {
-      key[r] = 0;
-      val[r] = 0;
-      if (r < E) {
-        const int i = i0 + r * 64;
-        if (i < n) {
-          key[r] = kscr[i];
-          val[r] = va[i];
-        }
-      }
-    }
     __syncthreads();
     struct SegP {
       int b, e, first, base, m;
@@ -463,6 +454,10 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
     // left) and the k-th misplaced element of the back part (from the right) announce their positions in side_pos and take
     // each other's place; everything else stays.  (All elements are in registers, so the scatter is in place.)
     auto partition_sweep = [&](int mode) {
+      const unsigned* kin = kbuf[cur];
+      const unsigned* vin = vbuf[cur];
+      unsigned* kout = kbuf[cur ^ 1];
+      unsigned* vout = vbuf[cur ^ 1];
       auto load_seg = [&](int sidx, bool with_counts) {
         SegP q;
         q.b = q.e = q.first = 0x7fffffff;
@@ -490,13 +485,13 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   const bool inB = i >= B.b, in = inB || (i >= A.b && i < A.e);          \
   const unsigned pv = inB ? B.pv : A.pv;                                 \
   const int first = inB ? B.first : A.first;                             \
-  const bool flag = in && (mode == 0 ? key[r] < pv : (i >= first && !(pv < key[r])));
+  const unsigned key_r = i < n ? kin[i] : 0u;                            \
+  const bool flag = in && (mode == 0 ? key_r < pv : (i >= first && !(pv < key_r)));
       {  // (A) flagged elements per wave, and before every range start inside its wave
         int cnt = 0, sA = 0;
         SegP A = load_seg(0, false), B = load_seg(1, false);
-#pragma unroll
-        for (int r = 0; r < EMAX; r++)
-          if (r < E) {
+#pragma unroll 4
+        for (int r = 0; r < E; r++) {
             VQS_ROW_BEGIN(false)
             const u64 bl = __ballot(flag);
             if (in && i == (inB ? B.b : A.b)) {
@@ -526,16 +521,15 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
       for (int step = 0; step < 2; step++) {  // (B) announce, (C) take the partner's place
         int run = wave_base, sA = 0;
         SegP A = load_seg(0, true), B = load_seg(1, true);
-#pragma unroll
-        for (int r = 0; r < EMAX; r++)
-          if (r < E) {
+#pragma unroll 4
+        for (int r = 0; r < E; r++) {
             VQS_ROW_BEGIN(true)
             const u64 bl = __ballot(flag);
             const int pre = run + __popcll(bl & ltm);
             run += __popcll(bl);
+            int mine = -1, theirs = -1;
             if (in) {
               const int lr = i - first, last = inB ? B.e : A.e;
-              int mine = -1, theirs = -1;
               if (lr >= 0) {
                 const int m = inB ? B.m : A.m, rk = pre - (inB ? B.base : A.base);
                 if (lr < m && !flag) {  // k-th misplaced element of the front part, from the left
@@ -548,18 +542,18 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
                   theirs = first + k;
                 }
               }
-              if (step == 0) {
-                if (mine >= 0) side_pos[mine] = (unsigned short)i;
-              } else {
-                const int dest = mine >= 0 ? (int)side_pos[theirs] : i;
-                kscr[dest] = key[r];
-                va[dest] = val[r];
-                // after the first partition: where the keys equal to the pivot sit (all of them in [middle1, last) now)
-                if (mode == 0 && key[r] == pv) {
-                  const int sidx = inB ? sA + 1 : sA;
-                  const int slot = atomicAdd(&eq_cnt[sidx], 1);
-                  if (slot < kEq) eq_pos[sidx][slot] = dest;
-                }
+            }
+            if (step == 0) {
+              if (mine >= 0) side_pos[mine] = (unsigned short)i;
+            } else if (i < n) {  // every element goes to the other buffer: to its partner's place, or where it is
+              const int dest = mine >= 0 ? (int)side_pos[theirs] : i;
+              kout[dest] = key_r;
+              vout[dest] = vin[i];
+              // after the first partition: where the keys equal to the pivot sit (all of them in [middle1, last) now)
+              if (in && mode == 0 && key_r == pv) {
+                const int sidx = inB ? sA + 1 : sA;
+                const int slot = atomicAdd(&eq_cnt[sidx], 1);
+                if (slot < kEq) eq_pos[sidx][slot] = dest;
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -567,6 +561,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
         __syncthreads();
       }
 #undef VQS_ROW_BEGIN
+      cur ^= 1;
     };
     partition_sweep(0);
     if (tid < nseg) {  // second partition by replaying its few swaps
@@ -596,25 +591,18 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
             continue;
           }
           const int jt = q[t--];  // >= m1 + m by counting
-          const unsigned kj = kscr[j], vj = va[j];
-          kscr[j] = kscr[jt];
-          va[j] = va[jt];
-          kscr[jt] = kj;
-          va[jt] = vj;
+          unsigned* kc = kbuf[cur];
+          unsigned* vc = vbuf[cur];
+          const unsigned kj = kc[j], vj = vc[j];
+          kc[j] = kc[jt];
+          vc[j] = vc[jt];
+          kc[jt] = kj;
+          vc[jt] = vj;
         }
       }
     }
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(s_over)) {  // a voxel with more than kEq points: the general sweep (reload, partition, store)
-#pragma unroll
-      for (int r = 0; r < EMAX; r++)
-        if (r < E) {
-          const int i = i0 + r * 64;
-          if (i < n) {
-            key[r] = kscr[i];
-            val[r] = va[i];
-          }
-        }
+    if (__builtin_amdgcn_readfirstlane(s_over)) {  // a voxel with more than kEq points: the general sweep
       partition_sweep(1);
       if (tid < nseg) seg_m2[tid] = seg_m1[tid] + (seg_base[tid + 1] - seg_base[tid]);
       __syncthreads();
@@ -649,9 +637,15 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
     __syncthreads();
   }
   // the keys go back as 64-bit compacted keys (k_voxel_qsort_leaf, k_voxel_reduce)
-  for (int i = tid; i < n; i += 1024) {
-    const unsigned k = kscr[i];
-    ka[i] = k == 0xffffffffu ? kInvalid : (u64)k;
+  {
+    const unsigned* kc = kbuf[cur];
+    const unsigned* vc = vbuf[cur];
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned k = kc[i];
+      const unsigned v = vc[i];
+      ka[i] = k == 0xffffffffu ? kInvalid : (u64)k;
+      if (cur) va[i] = v;
+    }
   }
   if (tid == 0) nleaf[c] = s_nleaf;
 }
@@ -785,16 +779,19 @@ __device__ void heap_sort_wave(KT* K, unsigned short* Pm, int lo, int hi) {
         pr = Q[2 * g + 2];
       }
       const bool left = valid && kr < kl;  // __adjust_heap: the second child unless it is smaller than the first
-      // the walk: every lane knows the local node its hole moves to next (0: no two children), lane to lane by readlane
-      const int nxt = valid ? 2 * t + (left ? 0 : 1) : 0;
-      int tt = 1, last_t = 1;
+      // the walk through the six levels: scalar bit arithmetic on the two ballots, branch free (a finished walk idles)
+      const u64 bv = __ballot(valid), bl = __ballot(left);
+      int tt = 1, last_t = 1, alive = 1;
       u64 pathmask = 0;
-      while (tt < 64) {
-        const int nx = __builtin_amdgcn_readlane(nxt, tt - 1);
-        if (nx == 0) break;
-        pathmask |= 1ull << (tt - 1);
-        last_t = tt;
-        tt = nx;
+#pragma unroll
+      for (int lev = 0; lev < 6; lev++) {
+        const int idx = tt - 1;
+        const int ok = alive & (int)((bv >> idx) & 1ull);
+        const int lf = (int)((bl >> idx) & 1ull);
+        pathmask |= (u64)ok << idx;
+        last_t = ok ? tt : last_t;
+        tt = ok ? 2 * tt + 1 - lf : tt;
+        alive = ok;
       }
       const KT ck = left ? kl : kr;
       const unsigned short cp = left ? pl : pr;
@@ -1209,11 +1206,21 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigne
         mykey[r] = r * 64 + lane < n ? K[r * 64 + lane] : (KT)0;
         rank[r] = 0;
       }
-      for (int j = 0; j < n; j++) {
-        const KT kj = K[j];  // same address in every lane: an LDS broadcast
+      // (keys are read eight at a time — same addresses in every lane, LDS broadcasts — so that one LDS round trip feeds 128
+      // comparisons; the tail of the last group is padded with the largest key, which is smaller than nothing)
+      const int n8 = (n + 7) & ~7;
+      for (int p = n + lane; p < n8; p += 64) K[p] = ~(KT)0;
+      VQS_WAVE_SYNC();
+      for (int j = 0; j < n8; j += 8) {
+        KT kj[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) kj[u] = K[j + u];
 #pragma unroll
         for (int r = 0; r < 16; r++)
-          if (r < rows) rank[r] += kj < mykey[r] ? 1 : 0;
+          if (r < rows) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) rank[r] += kj[u] < mykey[r] ? 1 : 0;
+          }
       }
       VQS_WAVE_SYNC();
       unsigned short* slot = Pm;  // Pm is the identity so far: reuse it as the rendezvous (rank -> who claims it)
