@@ -728,7 +728,7 @@ __device__ void heap_sort_soa(KT* K, unsigned short* Pm, int lo, int hi) {  // _
 // child pairs of the next SIX levels below the hole at once, the walk through them is scalar bit arithmetic on two ballots,
 // and the lanes on the path write the chosen children up; __push_heap then climbs (rarely more than a level).
 template <typename KT>
-__device__ void heap_sort_wave(KT* K, unsigned short* Pm, int lo, int hi) {
+__device__ void heap_sort_wave(KT* K, unsigned short* Pm, int lo, int hi, int stop_len = 1) {
   const int lane = threadIdx.x & 63;
   const int len = hi - lo;
   KT* H = K + lo;
@@ -758,7 +758,8 @@ __device__ void heap_sort_wave(KT* K, unsigned short* Pm, int lo, int hi) {
 #ifdef VQS_NO_POPS
   return;
 #endif
-  for (int L = len - 1; L >= 1; L--) {  // __pop_heap(first, first + L, first + L): value = H[L], H[L] = H[0], sift in [0, L)
+  // (stop_len > 1: only the pops down to a heap of stop_len elements are replayed — see k_voxel_qsort_heap)
+  for (int L = len - 1; L >= max(1, stop_len); L--) {  // __pop_heap(first, first + L, first + L): value = H[L], H[L] = H[0], sift in [0, L)
     // (the popped value and the old root are not needed by the descent: no wait on these reads until the end of the pop)
     const KT vk = H[L], rk = H[0];
     const unsigned short vp = Q[L], rp = Q[0];
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigne
 template <typename KT>
 struct HeapLds {
   KT K[4][1024];
-  unsigned short Pm[4][1024];
+  unsigned short Pm[4][1024], Rk[4][1024];
 };
 
 template <typename KT>
@@ -1197,6 +1198,8 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigne
     // correct sort is the reference's: rank every element by counting smaller keys (all lanes in parallel), and replay
     // libstdc++'s heap sort only if two elements collide on a rank (equal keys: their order is the heap's).
     bool replay = false;
+    int keep = 1;
+    unsigned short* Rk = S.Rk[wave];
     {
       KT mykey[16];
       int rank[16];
@@ -1239,11 +1242,48 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigne
         for (int r = 0; r < 16; r++)
           if (r * 64 + lane < n) K[rank[r]] = mykey[r];
       } else {
+        // Equal keys exist: their order is the heap's.  The pops come out in descending key order, so once every key >= the
+        // smallest tied key has been popped, what is left in the heap are distinct keys whose places are their ranks: only the
+        // first n - (number of keys below the smallest tied key) pops are replayed.
+        int below = n;  // rank of the smallest tied key = number of keys below it
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const bool cl = r * 64 + lane < n && slot[rank[r]] != (unsigned short)(r * 64 + lane);
+          below = min(below, cl ? rank[r] : n);
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) below = min(below, __shfl_xor(below, ofs, 64));
+        keep = below;
+        VQS_WAVE_SYNC();
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (r * 64 + lane < n) Rk[r * 64 + lane] = (unsigned short)rank[r];
         for (int p = lane; p < n; p += 64) Pm[p] = (unsigned short)p;
       }
       VQS_WAVE_SYNC();
     }
-    if (replay) heap_sort_wave<KT>(K, Pm, 0, n);
+    if (replay) {
+      heap_sort_wave<KT>(K, Pm, 0, n, keep);
+      if (keep > 1) {  // the `keep` smallest keys (all distinct) are still in heap order in [0, keep): each to its rank
+        KT kh[16];
+        unsigned short ph[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int hpos = r * 64 + lane;
+          kh[r] = hpos < keep ? K[hpos] : (KT)0;
+          ph[r] = hpos < keep ? Pm[hpos] : (unsigned short)0;
+        }
+        VQS_WAVE_SYNC();
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (r * 64 + lane < keep) {
+            const int dest = Rk[ph[r]];
+            K[dest] = kh[r];
+            Pm[dest] = ph[r];
+          }
+        VQS_WAVE_SYNC();
+      }
+    }
     unsigned myv[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
