@@ -485,12 +485,17 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   const bool inB = i >= B.b, in = inB || (i >= A.b && i < A.e);          \
   const unsigned pv = inB ? B.pv : A.pv;                                 \
   const int first = inB ? B.first : A.first;                             \
-  const unsigned key_r = i < n ? kin[i] : 0u;                            \
+  const unsigned key_r = key_nx;                                         \
+  {                                                                      \
+    const int i_nx = i + 64;  /* next row of this wave, fetched while this one is processed */ \
+    key_nx = (r + 1 < E && i_nx < n) ? kin[i_nx] : 0u;                   \
+  }                                                                      \
   const bool flag = in && (mode == 0 ? key_r < pv : (i >= first && !(pv < key_r)));
       {  // (A) flagged elements per wave, and before every range start inside its wave
         int cnt = 0, sA = 0;
         SegP A = load_seg(0, false), B = load_seg(1, false);
-#pragma unroll 4
+        unsigned key_nx = (wave * E * 64 + lane) < n ? kin[wave * E * 64 + lane] : 0u;
+#pragma unroll 1
         for (int r = 0; r < E; r++) {
             VQS_ROW_BEGIN(false)
             const u64 bl = __ballot(flag);
@@ -521,7 +526,8 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
       for (int step = 0; step < 2; step++) {  // (B) announce, (C) take the partner's place
         int run = wave_base, sA = 0;
         SegP A = load_seg(0, true), B = load_seg(1, true);
-#pragma unroll 4
+        unsigned key_nx = (wave * E * 64 + lane) < n ? kin[wave * E * 64 + lane] : 0u;
+#pragma unroll 1
         for (int r = 0; r < E; r++) {
             VQS_ROW_BEGIN(true)
             const u64 bl = __ballot(flag);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the measured evidence of a round on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r01c'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r02a'
 # Outputs land in gpurun_out/<tag>_*; copy the summaries into profiles/ (see profiles/README.md).
 # PMC counters are collected in their own passes (no trace domains), one counter set per pass.
 set -u
@@ -15,23 +15,23 @@ timeout 900 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 
 # 2. kernel trace + stats of the same workload (overlapped lanes)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- \
-  python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --prime 0 > $OUT/${TAG}_stats.log 2>&1
+  python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_stats.log 2>&1
 # ... and one module at a time (the per-kernel durations the roofline object is computed from)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -- \
-  python $R/bench.py --steps 5 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --prime 0 > $OUT/${TAG}_stats_serial.log 2>&1
+  python $R/bench.py --steps 5 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_stats_serial.log 2>&1
 
 # 3. HBM-side traffic: FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md, PMC slots)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- \
-    python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --prime 0 > $OUT/${TAG}_pmc_$c.log 2>&1
+    python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 # 4. issue / wait mix of the hot kernels
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
   --output-format csv -d $OUT/${TAG}_pmc_sq -- \
-  python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --prime 0 > $OUT/${TAG}_pmc_sq.log 2>&1
+  python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_pmc_sq.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE \
   --output-format csv -d $OUT/${TAG}_pmc_sq2 -- \
-  python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --prime 0 > $OUT/${TAG}_pmc_sq2.log 2>&1
+  python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_pmc_sq2.log 2>&1
 
 python $R/profiles/summarize.py $OUT $TAG
 tail -c 600 $OUT/${TAG}_bench.json
