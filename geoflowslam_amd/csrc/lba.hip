@@ -38,6 +38,7 @@ struct LbaState {
   int qmax, n_bad, iters;
   int solve_ok;                  // LinearSolver succeeded in the current trial
   int again, terminate;          // outputs of k_lba_decide for the host loop
+  int phase, it;                 // batched entry: 0 = build next, 1 = trial next, 2 = done; index of the running LM iteration
 };
 
 struct LbaDev {
@@ -549,8 +550,8 @@ __device__ double block_sum256(double v, double* s4) {
   return ((s4[0] + s4[1]) + s4[2]) + s4[3];
 }
 
-__global__ __launch_bounds__(kMk) void k_lba_init(LbaDev D) {
-  const int g = blockIdx.x * kMk + threadIdx.x, G = gridDim.x * kMk;
+__device__ __forceinline__ void b_init(const LbaDev& D, const int bx, const int gdx) {
+  const int g = bx * kMk + threadIdx.x, G = gdx * kMk;
   for (int i = g; i < D.n_poses; i += G) {
     double q[4] = {D.pose_q0[4 * i], D.pose_q0[4 * i + 1], D.pose_q0[4 * i + 2], D.pose_q0[4 * i + 3]};
     normalize_rotation(q);
@@ -567,18 +568,21 @@ __global__ __launch_bounds__(kMk) void k_lba_init(LbaDev D) {
     S.qmax = S.n_bad = S.iters = 0;
     S.solve_ok = 1;
     S.again = S.terminate = 0;
+    S.phase = S.it = 0;
   }
 }
+__global__ __launch_bounds__(kMk) void k_lba_init(LbaDev D) { b_init(D, blockIdx.x, gridDim.x); }
+
 
 // computeActiveErrors on the accepted (trial = 0) or the trial estimate (trial = 1; falls back to the accepted one when the
 // linear solve failed, like the reference which restores the estimate before recomputing the errors)
-__global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial) {
+__device__ __forceinline__ void b_errors(const LbaDev& D, const int bx, const int gdx, int trial) {
   __shared__ double s4[4];
   const LbaState& S = *D.S;
   const int which = (trial && S.solve_ok) ? (S.cur ^ 1) : S.cur;
   const double *q = sel(D.q, D.q_try, which), *t = sel(D.t, D.t_try, which), *X = sel(D.X, D.X_try, which);
   double local = 0;
-  const int e = blockIdx.x * kMk + threadIdx.x;
+  const int e = bx * kMk + threadIdx.x;
   if (e < D.n_edges) {
     double xc[3], r[3];
     edge_residual(D, e, q, t, X, xc, r);
@@ -592,16 +596,18 @@ __global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial) {
     local = r0;
   }
   const double tot = block_sum256(local, s4);
-  if (threadIdx.x == 0) D.part_chi[blockIdx.x] = tot;
+  if (threadIdx.x == 0) D.part_chi[bx] = tot;
 }
+__global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial) { b_errors(D, blockIdx.x, gridDim.x, trial); }
+
 
 // buildSystem, landmark side: Hll, bl and the per-edge pose-landmark blocks.  16 lanes per landmark (its edges over the
 // lanes, the 9 sums folded by xor-shuffles inside the group in a fixed order), 8 landmarks per 128-thread workgroup.
-__global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) {
+__device__ __forceinline__ void b_build_landmarks(const LbaDev& D, const int bx, const int gdx) {
   const LbaState& S = *D.S;
   const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
   const int gl = threadIdx.x & 15;
-  const int l = blockIdx.x * 8 + (threadIdx.x >> 4);
+  const int l = bx * 8 + (threadIdx.x >> 4);
   const bool live = l < D.n_points;  // (whole 16-lane groups are live or not: the shuffles below stay inside a group)
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx,xy,xz,yy,yz,zz), b
   if (live) {
@@ -638,13 +644,15 @@ __global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) {
     for (int k = 0; k < 3; k++) D.bl[3 * (size_t)l + k] = acc[6 + k];
   }
 }
+__global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) { b_build_landmarks(D, blockIdx.x, gridDim.x); }
+
 
 // buildSystem, pose side: one workgroup per free pose, threads over its edges, fixed-order reduction
-__global__ __launch_bounds__(kMk) void k_lba_build_poses(LbaDev D) {
+__device__ __forceinline__ void b_build_poses(const LbaDev& D, const int bx, const int gdx) {
   __shared__ double s_buf[(kMk / 64) * 32];
   const LbaState& S = *D.S;
   const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
-  const int f = blockIdx.x;
+  const int f = bx;
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0;
@@ -672,9 +680,11 @@ __global__ __launch_bounds__(kMk) void k_lba_build_poses(LbaDev D) {
   else if (threadIdx.x < 27)
     D.bp[6 * f + (threadIdx.x - 21)] = v;
 }
+__global__ __launch_bounds__(kMk) void k_lba_build_poses(LbaDev D) { b_build_poses(D, blockIdx.x, gridDim.x); }
+
 
 // start of an LM iteration: currentChi, and at iteration 0 computeLambdaInit (tau * max |diag H|)
-__global__ __launch_bounds__(kThreads) void k_lba_begin(LbaDev D, int iteration) {
+__device__ __forceinline__ void b_begin(const LbaDev& D, const int bx, const int gdx, int iteration) {
   __shared__ double s16[16];
   LbaState& S = *D.S;
   double chi = 0;
@@ -704,17 +714,21 @@ __global__ __launch_bounds__(kThreads) void k_lba_begin(LbaDev D, int iteration)
     S.again = 0;
   }
 }
+__global__ __launch_bounds__(kThreads) void k_lba_begin(LbaDev D, int iteration) { b_begin(D, blockIdx.x, gridDim.x, iteration); }
 
-__global__ __launch_bounds__(kMk) void k_lba_dinv(LbaDev D) {
-  const int l = blockIdx.x * kMk + threadIdx.x;
+
+__device__ __forceinline__ void b_dinv(const LbaDev& D, const int bx, const int gdx) {
+  const int l = bx * kMk + threadIdx.x;
   if (l < D.n_points) inv3_sym(D.Hll + 6 * (size_t)l, D.S->lambda, D.Dinv + 6 * (size_t)l);
 }
+__global__ __launch_bounds__(kMk) void k_lba_dinv(LbaDev D) { b_dinv(D, blockIdx.x, gridDim.x); }
+
 
 // Schur complement, one workgroup per pose pair (i1 >= i2): Hs(i1,i2) = [i1==i2](Hpp + lambda I) - sum_l B_i1 Dinv_l B_i2^T
-__global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) {
+__device__ __forceinline__ void b_schur(const LbaDev& D, const int bx, const int gdx) {
   __shared__ double s_buf[(kMk / 64) * 32];
   const double lambda = D.S->lambda;
-  const int pr = blockIdx.x;
+  const int pr = bx;
   int i1 = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
   while (i1 * (i1 + 1) / 2 > pr) i1--;
   while ((i1 + 1) * (i1 + 2) / 2 <= pr) i1++;
@@ -775,13 +789,15 @@ __global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) {
   if (tk < 4) store_h(32 + tk, v1);
   if (i1 == i2 && tk >= 4 && tk < 10) D.bs[6 * i1 + (tk - 4)] = D.bp[6 * i1 + (tk - 4)] - v1;
 }
+__global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) { b_schur(D, blockIdx.x, gridDim.x); }
+
 
 // LDL^T + triangular solves of the reduced pose system by a single workgroup.  kLds: the packed triangle fits the 160 KB of
 // LDS (n <= 180, i.e. up to 30 free poses) and is factored there.  Otherwise (larger windows) it is factored in place in HBM /
 // L2; only the right-hand side and the current 6-column panel are held in LDS, so the trailing update reads and writes each
 // element once.  Same arithmetic, same order of operations per entry in both variants.
 template <bool kLds>
-__global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
+__device__ __forceinline__ void b_solve(const LbaDev& D) {
   extern __shared__ __align__(16) double lds[];
   __shared__ int s_flag;
   const int n = 6 * D.n_free;
@@ -917,9 +933,12 @@ __global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
   }
   if (threadIdx.x == 0) D.S->solve_ok = ok ? 1 : 0;
 }
+template <bool kLds>
+__global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) { b_solve<kLds>(D); }
+
 
 // landmark back-substitution, update of the trial estimate, computeScale partial sums
-__global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D) {
+__device__ __forceinline__ void b_update(const LbaDev& D, const int bx, const int gdx) {
   __shared__ double s4[4];
   const LbaState& S = *D.S;
   double loc = 0;
@@ -928,7 +947,7 @@ __global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D) {
     const double *q = sel(D.q, D.q_try, cur), *t = sel(D.t, D.t_try, cur), *X = sel(D.X, D.X_try, cur);
     double *qn = sel(D.q, D.q_try, cur ^ 1), *tn = sel(D.t, D.t_try, cur ^ 1), *Xn = sel(D.X, D.X_try, cur ^ 1);
     const double lambda = S.lambda;
-    const int l = blockIdx.x * kMk + threadIdx.x;
+    const int l = bx * kMk + threadIdx.x;
     if (l < D.n_points) {
       double cl[3] = {D.bl[3 * (size_t)l], D.bl[3 * (size_t)l + 1], D.bl[3 * (size_t)l + 2]};
       for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
@@ -947,7 +966,7 @@ __global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D) {
         loc += xl[c] * (lambda * xl[c] + D.bl[3 * (size_t)l + c]);
       }
     }
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
       for (int f = threadIdx.x; f < D.n_free; f += kMk) {
         const int p = D.free_pose[f];
         pose_oplus(q + 4 * p, t + 3 * p, D.xp + 6 * f, qn + 4 * p, tn + 3 * p);
@@ -956,12 +975,14 @@ __global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D) {
     }
   }
   const double tot = block_sum256(loc, s4);
-  if (threadIdx.x == 0) D.part_scale[blockIdx.x] = tot;
+  if (threadIdx.x == 0) D.part_scale[bx] = tot;
 }
+__global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D) { b_update(D, blockIdx.x, gridDim.x); }
+
 
 // end of an LM trial (and, when the trial loop ends, of the iteration): rho test, lambda update, termination tests
-__global__ void k_lba_decide(LbaDev D, int force_end, int* __restrict__ host_flags) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void b_decide(const LbaDev& D, const int bx, int force_end, int* __restrict__ host_flags) {
+  if (threadIdx.x != 0 || bx != 0) return;
   LbaState& S = *D.S;
   if (!force_end) {
     double temp_chi = 0, scale = 0;
@@ -1008,15 +1029,19 @@ __global__ void k_lba_decide(LbaDev D, int force_end, int* __restrict__ host_fla
   host_flags[2] = S.cur;
   host_flags[3] = S.iters;
 }
+__global__ void k_lba_decide(LbaDev D, int force_end, int* __restrict__ host_flags) { b_decide(D, blockIdx.x, force_end, host_flags); }
 
-__global__ void k_lba_finish(LbaDev D) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+
+__device__ __forceinline__ void b_finish(const LbaDev& D, const int bx) {
+  if (threadIdx.x != 0 || bx != 0) return;
   const LbaState& S = *D.S;
   D.out_info[0] = S.iters;
   D.out_info[1] = S.cur;
   D.out_stats[0] = D.mode == 1 ? S.current_chi : S.last_chi;
   D.out_stats[1] = D.mode == 1 ? 0.0 : S.lambda;
 }
+__global__ void k_lba_finish(LbaDev D) { b_finish(D, blockIdx.x); }
+
 
 // host -> device through the pinned arena (bump allocation; the arena outlives the asynchronous copies of one call)
 struct Stager {
