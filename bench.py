@@ -545,7 +545,25 @@ def main():
                                 algorithmic_bytes_per_build=int(lba_bytes), builds=int(nbuild), avg_build_us=round(build_ms / nbuild * 1e3, 2),
                                 kernels_ms_per_window={k: round(v[0], 4) for k, v in sorted(lrep.items(), key=lambda kv: -kv[1][0]) if "lba" in k},
                                 note="one window = one workgroup-chain: launch-latency bound, see DESIGN.md")
-            extras["lba"] = dict(roofline=lba_roof, metric="LocalBundleAdjustment windows/s (20 free + 5 fixed key-frames x 3000 points; BASELINE.json configs[4])",
+            # ... and 64 independent windows solved together (gfs_lba_solve_batch: replicas, the LBA of one map does not shard)
+            lba_batch = None
+            try:
+                NW = 64
+                wl = [synth.lba_window(k, n_free=20, n_fixed=5, n_points=3000) for k in range(8)]
+                wl = [wl[k % 8] for k in range(NW)]
+                bat = api.BatchOptimizer(max_windows=NW, max_poses=32, max_points=4096, max_edges=65536, device=local_rank)
+                Pb, Sb, _, keep_b = bat.prepare(wl)
+                bat.solve_prepared(Pb, Sb, NW)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    bat.solve_prepared(Pb, Sb, NW)
+                dtb = (time.perf_counter() - t1) / 3
+                lba_batch = dict(value=round(NW / dtb, 1), unit="windows/s", windows=NW, distinct_windows=8, ms_per_batch=round(dtb * 1e3, 2),
+                                 note="host preparation, upload, solve and download of 64 windows per call; per window bit-identical to gfs_lba_solve")
+                bat.close()
+            except Exception as e:
+                lba_batch = dict(error=f"{type(e).__name__}: {e}")
+            extras["lba"] = dict(roofline=lba_roof, batched=lba_batch, metric="LocalBundleAdjustment windows/s (20 free + 5 fixed key-frames x 3000 points; BASELINE.json configs[4])",
                                  value=round(1.0 / dtl, 1), unit="windows/s", ms_per_window=round(dtl * 1e3, 3), edges=int(w5["n_edges"]),
                                  lm_iterations=int(r5["iterations_run"]))
             if not args.no_cpu_baseline:

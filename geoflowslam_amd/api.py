@@ -185,7 +185,8 @@ ABI_SYMBOLS = [
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
     "gfs_gicp_fetch_preprocessed", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort",
-    "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize",
+    "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize", "gfs_lba_batch_create", "gfs_lba_batch_destroy",
+    "gfs_lba_solve_batch",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
     "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
@@ -246,6 +247,9 @@ def lib():
             L.gfs_lba_destroy.argtypes = [vp]
             L.gfs_lba_solve.argtypes = [vp, C.POINTER(LbaProblem), C.POINTER(LbaSolution), vp]
             L.gfs_lba_linearize.argtypes = [vp, C.POINTER(LbaProblem), vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
+            L.gfs_lba_batch_create.argtypes = [i, i, i, i, i, C.POINTER(vp)]
+            L.gfs_lba_batch_destroy.argtypes = [vp]
+            L.gfs_lba_solve_batch.argtypes = [vp, vp, vp, i, vp]
         if hasattr(L, "gfs_frame_create"):
             f = C.c_float
             L.gfs_frame_create.argtypes = [i, i, i, i, C.POINTER(vp)]
@@ -659,6 +663,49 @@ class Optimizer:
                                        C.byref(tot)), "gfs_lba_linearize")
         return dict(Hpp=Hpp.reshape(nf, 6, 6).transpose(0, 2, 1).copy(), Hll=Hll.reshape(-1, 3, 3).transpose(0, 2, 1).copy(),
                     Hpl=Hpl.reshape(-1, 3, 6).transpose(0, 2, 1).copy(), bp=bp, bl=bl, edge_chi2=chi, chi2=tot.value)
+
+
+class BatchOptimizer:
+    """n independent LocalBundleAdjustment windows solved together (gfs_lba_solve_batch)."""
+
+    def __init__(self, max_windows=64, max_poses=32, max_points=4096, max_edges=65536, device=0):
+        self.h = C.c_void_p()
+        _check(lib().gfs_lba_batch_create(device, max_windows, max_poses, max_points, max_edges, C.byref(self.h)), "gfs_lba_batch_create")
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gfs_lba_batch_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def prepare(self, probs):
+        """ctypes views (kept alive by the returned object) so that repeated solves pay no Python conversion"""
+        n = len(probs)
+        P = (LbaProblem * n)()
+        S = (LbaSolution * n)()
+        keep, outs = [], []
+        for k, prob in enumerate(probs):
+            pk, kp = _lba_problem(prob)
+            P[k] = pk
+            keep.append(kp)
+            out = dict(pose_q=np.zeros((pk.n_poses, 4)), pose_t=np.zeros((pk.n_poses, 3)), points=np.zeros((pk.n_points, 3)),
+                       edge_chi2=np.zeros(pk.n_edges), edge_depth_positive=np.zeros(pk.n_edges, np.uint8))
+            for name, v in out.items():
+                setattr(S[k], name, v.ctypes.data)
+            outs.append(out)
+        return P, S, outs, keep
+
+    def solve_prepared(self, P, S, n, stop_flag=None):
+        stop = stop_flag.ctypes.data_as(C.c_void_p) if stop_flag is not None else None
+        _check(lib().gfs_lba_solve_batch(self.h, P, S, n, stop), "gfs_lba_solve_batch")
+
+    def LocalBundleAdjustment(self, probs, stop_flag=None):
+        P, S, outs, keep = self.prepare(probs)
+        self.solve_prepared(P, S, len(probs), stop_flag)
+        for k, out in enumerate(outs):
+            out.update(iterations_run=S[k].iterations_run, final_chi2=S[k].final_chi2, final_lambda=S[k].final_lambda)
+        return outs
 
 
 class GmsMatcher:

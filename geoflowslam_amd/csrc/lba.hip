@@ -1043,6 +1043,79 @@ __device__ __forceinline__ void b_finish(const LbaDev& D, const int bx) {
 __global__ void k_lba_finish(LbaDev D) { b_finish(D, blockIdx.x); }
 
 
+// ------------------------------------------------------------------------------------------------
+// Batched windows (gfs_lba_solve_batch): the same phase kernels with the window index in blockIdx.y.  Every window carries its
+// own LM state machine (LbaState::phase: 0 = build the system next, 1 = a trial step next, 2 = done); the host launches
+// "rounds" of [build group][trial group] over all windows, a kernel leaves at once when its window is in another phase or its
+// block index is beyond that window's size.  Same bodies, same arithmetic: a window's result does not depend on the batch.
+// ------------------------------------------------------------------------------------------------
+#define GFS_LBAB_PROLOGUE(PHASE, NEED)                         \
+  const LbaDev D = DD[blockIdx.y];                             \
+  if (D.S->phase != (PHASE)) return;                           \
+  const int need = (NEED);                                     \
+  if ((int)blockIdx.x >= need) return;
+
+__global__ __launch_bounds__(kMk) void kb_lba_init(const LbaDev* __restrict__ DD) {
+  const LbaDev D = DD[blockIdx.y];
+  b_init(D, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(kMk) void kb_lba_errors(const LbaDev* __restrict__ DD, int trial) {
+  GFS_LBAB_PROLOGUE(trial ? 1 : 0, D.n_err_blocks)
+  b_errors(D, blockIdx.x, need, trial);
+}
+__global__ __launch_bounds__(128) void kb_lba_build_landmarks(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(0, (D.n_points + 7) / 8)
+  b_build_landmarks(D, blockIdx.x, need);
+}
+__global__ __launch_bounds__(kMk) void kb_lba_build_poses(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(0, D.n_free)
+  b_build_poses(D, blockIdx.x, need);
+}
+__global__ __launch_bounds__(kThreads) void kb_lba_begin(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(0, 1)
+  b_begin(D, blockIdx.x, need, D.S->it);
+  __syncthreads();
+  if (threadIdx.x == 0) D.S->phase = 1;  // the build group is complete for this window: trials follow
+}
+__global__ __launch_bounds__(kMk) void kb_lba_dinv(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, D.n_upd_blocks)
+  b_dinv(D, blockIdx.x, need);
+}
+__global__ __launch_bounds__(kMk) void kb_lba_schur(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, D.n_free * (D.n_free + 1) / 2)
+  b_schur(D, blockIdx.x, need);
+}
+template <bool kLds>
+__global__ __launch_bounds__(kThreads) void kb_lba_solve(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, 1)
+  b_solve<kLds>(D);
+}
+__global__ __launch_bounds__(kMk) void kb_lba_update(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, D.n_upd_blocks)
+  b_update(D, blockIdx.x, need);
+}
+// end of a trial: the scalar LM logic of k_lba_decide, then the window's next phase (another trial, the next iteration's build,
+// or done: optimize(iterations) ran out or the algorithm terminated)
+__global__ void kb_lba_decide(const LbaDev* __restrict__ DD, int force_end, int* __restrict__ flags_all, int* __restrict__ n_done) {
+  const LbaDev D = DD[blockIdx.x];
+  if (threadIdx.x != 0 || D.S->phase != 1) return;
+  b_decide(D, 0, force_end, flags_all + 4 * blockIdx.x);
+  LbaState& S = *D.S;
+  if (S.again) return;  // phase stays 1
+  S.it++;
+  if (S.terminate || S.it >= D.iterations || force_end) {
+    S.phase = 2;
+    atomicAdd(n_done, 1);
+  } else {
+    S.phase = 0;
+  }
+}
+__global__ void kb_lba_finish(const LbaDev* __restrict__ DD) {
+  const LbaDev D = DD[blockIdx.x];
+  b_finish(D, 0);
+}
+#undef GFS_LBAB_PROLOGUE
+
 // host -> device through the pinned arena (bump allocation; the arena outlives the asynchronous copies of one call)
 struct Stager {
   unsigned char* base;
@@ -1148,8 +1221,8 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
   return GFS_OK;
 }
 
-int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volatile const int* stop) {
-  hipStream_t s = h->stream;
+// uploads one problem into the handle's buffers (through its pinned arena, on stream s) and describes it for the kernels
+int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, hipStream_t s, LbaDev& D) {
   const int E = p->n_edges, NP = p->n_points;
   int rc;
   Stager st{h->h_stage.p, h->h_stage.n, 0, s};
@@ -1164,7 +1237,7 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
       (rc = st.put(h->d_edge_of.p, P.edge_of.data(), P.edge_of.size())))
     return rc;
   if (E) GFS_HIP(hipMemsetAsync(h->d_Hpl.p, 0, (size_t)E * 18 * sizeof(double), s));
-  LbaDev D{};
+  D = LbaDev{};
   D.n_poses = p->n_poses;
   D.n_points = NP;
   D.n_edges = E;
@@ -1214,6 +1287,23 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   D.out_info = h->d_info.p;
   D.out_stats = h->d_stats.p;
   D.mode = mode;
+  D.S = h->d_state.p;
+  D.part_chi = h->d_part_chi.p;
+  D.part_scale = h->d_part_scale.p;
+  D.Hs = h->d_Hs.p;
+  D.bs = h->d_bs.p;
+  D.n_err_blocks = gfs::div_up(std::max(E, 1), kMk);
+  D.n_upd_blocks = gfs::div_up(std::max(NP, 1), kMk);
+  return GFS_OK;
+}
+
+int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volatile const int* stop) {
+  hipStream_t s = h->stream;
+  const int NP = p->n_points, E = p->n_edges;
+  (void)E;
+  LbaDev D;
+  int rc = upload_and_fill(h, p, P, mode, s, D);
+  if (rc) return rc;
   const int n = 6 * P.n_free;
   const bool in_lds = P.n_free <= kMaxFreeLds;
   const size_t lds = (in_lds ? (size_t)n * (n + 1) / 2 + n + 8 : (size_t)7 * n + 8) * sizeof(double);
@@ -1237,13 +1327,6 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   static const bool timing = getenv("GFS_LBA_TIMING") != nullptr;
   if (timing) GFS_HIP(hipStreamSynchronize(s));
   const auto Ta = std::chrono::steady_clock::now();
-  D.S = h->d_state.p;
-  D.part_chi = h->d_part_chi.p;
-  D.part_scale = h->d_part_scale.p;
-  D.Hs = h->d_Hs.p;
-  D.bs = h->d_bs.p;
-  D.n_err_blocks = gfs::div_up(std::max(E, 1), kMk);
-  D.n_upd_blocks = gfs::div_up(std::max(NP, 1), kMk);
   int* d_flags = nullptr;
   GFS_HIP(hipHostGetDevicePointer((void**)&d_flags, h->h_flags, 0));
   GFS_HIP(hipFuncSetAttribute(in_lds ? (const void*)k_lba_solve<true> : (const void*)k_lba_solve<false>,
@@ -1379,6 +1462,65 @@ void gfs_lba_destroy(gfs_lba* h) {
   delete h;
 }
 
+// result download of one window, in two halves so that a batch can queue all copies before one synchronisation
+struct LbaFetch {
+  double *chi, *q, *t, *X, *stats;
+  int* info;
+};
+static int lba_fetch_issue(gfs_lba* h, const gfs_lba_problem* p, hipStream_t s, int final_cur, LbaFetch& F) {
+  const int E = p->n_edges, NP = p->n_points;
+  const double* rq = final_cur ? h->d_qt.p : h->d_q.p;  // the accepted estimate (the two buffers swap roles)
+  const double* rt = final_cur ? h->d_tt.p : h->d_t.p;
+  const double* rX = final_cur ? h->d_Xt.p : h->d_X.p;
+  // results come back through the pinned arena too (the uploads of this call have completed)
+  unsigned char* base = h->h_stage.p;
+  size_t at = 0;
+  auto take = [&](size_t bytes) {
+    unsigned char* r = base + at;
+    at = (at + bytes + 63) & ~(size_t)63;
+    return r;
+  };
+  F.chi = (double*)take((size_t)E * 8);
+  F.q = (double*)take((size_t)p->n_poses * 32);
+  F.t = (double*)take((size_t)p->n_poses * 24);
+  F.X = (double*)take((size_t)NP * 24);
+  F.info = (int*)take(2 * sizeof(int));
+  F.stats = (double*)take(2 * sizeof(double));
+  GFS_REQUIRE(at <= h->h_stage.n, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
+  if (E) GFS_HIP(hipMemcpyAsync(F.chi, h->d_chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
+  if (p->n_poses) {
+    GFS_HIP(hipMemcpyAsync(F.q, rq, (size_t)p->n_poses * 32, hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(F.t, rt, (size_t)p->n_poses * 24, hipMemcpyDeviceToHost, s));
+  }
+  if (NP) GFS_HIP(hipMemcpyAsync(F.X, rX, (size_t)NP * 24, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(F.info, h->d_info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(F.stats, h->d_stats.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  return GFS_OK;
+}
+static void lba_fetch_finish(const gfs_lba_problem* p, const HostPrep& P, const LbaFetch& F, gfs_lba_solution* sol) {
+  const int E = p->n_edges, NP = p->n_points;
+  const double *chi = F.chi, *q = F.q, *t = F.t, *X = F.X, *stats = F.stats;
+  const int* info = F.info;
+  if (p->n_poses && sol->pose_q) memcpy(sol->pose_q, q, (size_t)p->n_poses * 32);
+  if (p->n_poses && sol->pose_t) memcpy(sol->pose_t, t, (size_t)p->n_poses * 24);
+  if (NP && sol->points) memcpy(sol->points, X, (size_t)NP * 24);
+  for (int k = 0; k < E; k++) {
+    const int e = P.order[k];
+    if (sol->edge_chi2) sol->edge_chi2[e] = chi[k];
+    if (sol->edge_depth_positive) {  // isDepthPositive() at the final estimates (host side, trivial)
+      const double* qq = &q[4 * (size_t)p->edge_pose[e]];
+      const double* v = &X[3 * (size_t)p->edge_point[e]];
+      const double ux = 2 * (qq[1] * v[2] - qq[2] * v[1]), uy = 2 * (qq[2] * v[0] - qq[0] * v[2]);
+      const double uz = 2 * (qq[0] * v[1] - qq[1] * v[0]);
+      const double z = v[2] + qq[3] * uz + (qq[0] * uy - qq[1] * ux) + t[3 * (size_t)p->edge_pose[e] + 2];
+      sol->edge_depth_positive[e] = z > 0.0;
+    }
+  }
+  sol->iterations_run = info[0];
+  sol->final_chi2 = stats[0];
+  sol->final_lambda = stats[1];
+}
+
 int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, volatile const int* stop) {
   GFS_REQUIRE(h && p && sol, GFS_ERR_INVALID_ARG, "gfs_lba_solve: NULL argument");
   if (stop && *stop) {  // if (pbStopFlag) if (*pbStopFlag) return;  (src/Optimizer.cc:1955-1956)
@@ -1400,53 +1542,165 @@ int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, v
   if (timing)
     fprintf(stderr, "gfs_lba_solve: prepare %.2f ms, upload + solve %.2f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(),
             std::chrono::duration<double, std::milli>(T2 - T1).count());
-  hipStream_t s = h->stream;
-  const int E = p->n_edges, NP = p->n_points;
-  const double* rq = h->final_cur ? h->d_qt.p : h->d_q.p;  // the accepted estimate (the two buffers swap roles)
-  const double* rt = h->final_cur ? h->d_tt.p : h->d_t.p;
-  const double* rX = h->final_cur ? h->d_Xt.p : h->d_X.p;
-  // results come back through the pinned arena too (the uploads of this call have completed)
-  unsigned char* base = h->h_stage.p;
-  size_t at = 0;
-  auto take = [&](size_t bytes) {
-    unsigned char* r = base + at;
-    at = (at + bytes + 63) & ~(size_t)63;
-    return r;
-  };
-  double* chi = (double*)take((size_t)E * 8);
-  double* q = (double*)take((size_t)p->n_poses * 32);
-  double* t = (double*)take((size_t)p->n_poses * 24);
-  double* X = (double*)take((size_t)NP * 24);
-  int* info = (int*)take(2 * sizeof(int));
-  double* stats = (double*)take(2 * sizeof(double));
-  GFS_REQUIRE(at <= h->h_stage.n, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
-  if (E) GFS_HIP(hipMemcpyAsync(chi, h->d_chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
-  if (p->n_poses) {
-    GFS_HIP(hipMemcpyAsync(q, rq, (size_t)p->n_poses * 32, hipMemcpyDeviceToHost, s));
-    GFS_HIP(hipMemcpyAsync(t, rt, (size_t)p->n_poses * 24, hipMemcpyDeviceToHost, s));
+  LbaFetch F;
+  rc = lba_fetch_issue(h, p, h->stream, h->final_cur, F);
+  if (rc) return rc;
+  GFS_HIP(hipStreamSynchronize(h->stream));
+  lba_fetch_finish(p, P, F, sol);
+  return GFS_OK;
+}
+
+// ---- batched windows -----------------------------------------------------------------------------------------------
+struct gfs_lba_batch {
+  int device = 0, max_windows = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::vector<gfs_lba*> win;       // one workspace per window (their kernels run together: window index = blockIdx.y)
+  gfs::DevBuf<LbaDev> d_desc;
+  gfs::PinBuf<LbaDev> h_desc;
+  gfs::DevBuf<int> d_flags, d_done;
+  int* h_done = nullptr;           // pinned copy target of the done counter
+  gfs::PinBuf<int> h_cur;          // per window: which estimate buffer holds the result
+  std::vector<HostPrep> prep;
+};
+
+int gfs_lba_batch_create(int device, int max_windows, int max_poses, int max_points, int max_edges, gfs_lba_batch** out) {
+  GFS_REQUIRE(out && max_windows > 0, GFS_ERR_INVALID_ARG, "gfs_lba_batch_create: invalid argument");
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  std::unique_ptr<gfs_lba_batch> b(new gfs_lba_batch);
+  b->device = device;
+  b->max_windows = max_windows;
+  GFS_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  for (int w = 0; w < max_windows; w++) {
+    gfs_lba* h = nullptr;
+    const int rc = gfs_lba_create(device, max_poses, max_points, max_edges, &h);
+    if (rc) {
+      for (gfs_lba* x : b->win) gfs_lba_destroy(x);
+      return rc;
+    }
+    b->win.push_back(h);
   }
-  if (NP) GFS_HIP(hipMemcpyAsync(X, rX, (size_t)NP * 24, hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(info, h->d_info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(stats, h->d_stats.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipStreamSynchronize(s));
-  if (p->n_poses && sol->pose_q) memcpy(sol->pose_q, q, (size_t)p->n_poses * 32);
-  if (p->n_poses && sol->pose_t) memcpy(sol->pose_t, t, (size_t)p->n_poses * 24);
-  if (NP && sol->points) memcpy(sol->points, X, (size_t)NP * 24);
-  for (int k = 0; k < E; k++) {
-    const int e = P.order[k];
-    if (sol->edge_chi2) sol->edge_chi2[e] = chi[k];
-    if (sol->edge_depth_positive) {  // isDepthPositive() at the final estimates (host side, trivial)
-      const double* qq = &q[4 * (size_t)p->edge_pose[e]];
-      const double* v = &X[3 * (size_t)p->edge_point[e]];
-      const double ux = 2 * (qq[1] * v[2] - qq[2] * v[1]), uy = 2 * (qq[2] * v[0] - qq[0] * v[2]);
-      const double uz = 2 * (qq[0] * v[1] - qq[1] * v[0]);
-      const double z = v[2] + qq[3] * uz + (qq[0] * uy - qq[1] * ux) + t[3 * (size_t)p->edge_pose[e] + 2];
-      sol->edge_depth_positive[e] = z > 0.0;
+  int rc = 0;
+  if ((rc = b->d_desc.alloc(max_windows)) || (rc = b->h_desc.alloc(max_windows)) || (rc = b->d_flags.alloc(4 * (size_t)max_windows)) ||
+      (rc = b->d_done.alloc(1)) || (rc = b->h_cur.alloc(max_windows)))
+    return rc;
+  GFS_HIP(hipHostMalloc((void**)&b->h_done, 2 * sizeof(int), hipHostMallocDefault));
+  b->prep.resize(max_windows);
+  *out = b.release();
+  return GFS_OK;
+}
+
+void gfs_lba_batch_destroy(gfs_lba_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  (void)hipStreamSynchronize(b->stream);
+  for (gfs_lba* x : b->win) gfs_lba_destroy(x);
+  (void)hipStreamDestroy(b->stream);
+  if (b->h_done) (void)hipHostFree(b->h_done);
+  delete b;
+}
+
+// n independent windows (replicas of the single-window solve: "LBA of one map does not shard") solved
+// together: per window exactly the arithmetic of gfs_lba_solve, the launches shared by all of them.
+int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_lba_solution* solutions, int n,
+                        volatile const int* stop) {
+  GFS_REQUIRE(b && problems && solutions && n > 0, GFS_ERR_INVALID_ARG, "gfs_lba_solve_batch: invalid argument");
+  GFS_REQUIRE(n <= b->max_windows, GFS_ERR_CAPACITY, "gfs_lba_solve_batch: %d windows exceed the handle's %d", n, b->max_windows);
+  if (stop && *stop) {
+    gfs::set_error("gfs_lba_solve_batch: stop flag raised before optimisation");
+    return GFS_ERR_STOPPED;
+  }
+  std::lock_guard<std::mutex> lk(b->mu);
+  GFS_HIP(hipSetDevice(b->device));
+  hipStream_t s = b->stream;
+  // ---- host preparation of every window (edge re-ordering, CSR tables), on a few threads
+  std::vector<int> rcs((size_t)n, 0);
+  {
+    const int nthreads = std::max(1, std::min(n, std::min(32, (int)std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++)
+      th.emplace_back([&, t]() {
+        for (int w = t; w < n; w += nthreads) rcs[w] = prepare(b->win[w], &problems[w], b->prep[w]);
+      });
+    for (auto& x : th) x.join();
+  }
+  for (int w = 0; w < n; w++)
+    if (rcs[w]) return rcs[w];
+  int max_free = 0, max_err = 1, max_upd = 1, max_lm = 1, max_iter = 0;
+  for (int w = 0; w < n; w++) {
+    LbaDev D;
+    const int rc = upload_and_fill(b->win[w], &problems[w], b->prep[w], 0, s, D);
+    if (rc) return rc;
+    GFS_HIP(hipHostGetDevicePointer((void**)&D.stop, b->win[w]->h_stop, 0));
+    *b->win[w]->h_stop = 0;
+    b->h_desc.p[w] = D;
+    max_free = std::max(max_free, D.n_free);
+    max_err = std::max(max_err, D.n_err_blocks);
+    max_upd = std::max(max_upd, D.n_upd_blocks);
+    max_lm = std::max(max_lm, gfs::div_up(std::max(D.n_points, 1), 8));
+    max_iter = std::max(max_iter, problems[w].iterations);
+  }
+  GFS_HIP(hipMemcpyAsync(b->d_desc.p, b->h_desc.p, (size_t)n * sizeof(LbaDev), hipMemcpyHostToDevice, s));
+  GFS_HIP(hipMemsetAsync(b->d_done.p, 0, sizeof(int), s));
+  const int nmax = 6 * max_free;
+  const bool in_lds = max_free <= kMaxFreeLds;
+  const size_t lds = (in_lds ? (size_t)nmax * (nmax + 1) / 2 + nmax + 8 : (size_t)7 * nmax + 8) * sizeof(double);
+  GFS_REQUIRE(lds <= 160 * 1024, GFS_ERR_CAPACITY, "gfs_lba_solve_batch: %d free poses exceed the solver's workspace", max_free);
+  GFS_HIP(hipFuncSetAttribute(in_lds ? (const void*)kb_lba_solve<true> : (const void*)kb_lba_solve<false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const LbaDev* DD = b->d_desc.p;
+  const int npairs = std::max(1, max_free * (max_free + 1) / 2);
+  GFS_LAUNCH("kb_lba_init", kb_lba_init, dim3(64, n), dim3(kMk), 0, s, DD);
+  // windows with iterations <= 0 finish at once (optimize(0) leaves the estimate alone): handled by max_rounds = 0 below
+  const int max_rounds = max_iter > 0 ? max_iter * 11 + 1 : 0;
+  bool stopped = false;
+  for (int round = 0; round < max_rounds; round++) {
+    GFS_LAUNCH("kb_lba_errors", kb_lba_errors, dim3(max_err, n), dim3(kMk), 0, s, DD, 0);
+    GFS_LAUNCH("kb_lba_build_landmarks", kb_lba_build_landmarks, dim3(max_lm, n), dim3(128), 0, s, DD);
+    if (max_free > 0) GFS_LAUNCH("kb_lba_build_poses", kb_lba_build_poses, dim3(max_free, n), dim3(kMk), 0, s, DD);
+    GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD);
+    GFS_LAUNCH("kb_lba_dinv", kb_lba_dinv, dim3(max_upd, n), dim3(kMk), 0, s, DD);
+    if (max_free > 0) GFS_LAUNCH("kb_lba_schur", kb_lba_schur, dim3(npairs, n), dim3(kMk), 0, s, DD);
+    if (in_lds)
+      GFS_LAUNCH("kb_lba_solve", kb_lba_solve<true>, dim3(1, n), dim3(kThreads), lds, s, DD);
+    else
+      GFS_LAUNCH("kb_lba_solve", kb_lba_solve<false>, dim3(1, n), dim3(kThreads), lds, s, DD);
+    GFS_LAUNCH("kb_lba_update", kb_lba_update, dim3(max_upd, n), dim3(kMk), 0, s, DD);
+    GFS_LAUNCH("kb_lba_errors", kb_lba_errors, dim3(max_err, n), dim3(kMk), 0, s, DD, 1);
+    const bool force_end = stop && *stop;  // setForceStopFlag: the running iteration is closed, nothing further starts
+    GFS_LAUNCH("kb_lba_decide", kb_lba_decide, dim3(n), dim3(64), 0, s, DD, force_end ? 1 : 0, b->d_flags.p, b->d_done.p);
+    GFS_HIP(hipMemcpyAsync(b->h_done, b->d_done.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipStreamSynchronize(s));
+    if (b->h_done[0] >= n) break;
+    if (force_end) {
+      stopped = true;
+      break;
     }
   }
-  sol->iterations_run = info[0];
-  sol->final_chi2 = stats[0];
-  sol->final_lambda = stats[1];
+  (void)stopped;
+  GFS_LAUNCH("kb_lba_finish", kb_lba_finish, dim3(n), dim3(64), 0, s, DD);
+  std::vector<LbaFetch> F((size_t)n);
+  std::vector<int> info_cur((size_t)n, 0);
+  {  // which estimate buffer holds each window's result
+    for (int w = 0; w < n; w++) GFS_HIP(hipMemcpyAsync(b->h_cur.p + w, b->win[w]->d_info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipStreamSynchronize(s));
+    for (int w = 0; w < n; w++) info_cur[w] = b->h_cur.p[w];
+  }
+  for (int w = 0; w < n; w++) {
+    const int rc = lba_fetch_issue(b->win[w], &problems[w], s, info_cur[w], F[w]);
+    if (rc) return rc;
+  }
+  GFS_HIP(hipStreamSynchronize(s));
+  {
+    const int nthreads = std::max(1, std::min(n, std::min(32, (int)std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++)
+      th.emplace_back([&, t]() {
+        for (int w = t; w < n; w += nthreads) lba_fetch_finish(&problems[w], b->prep[w], F[w], &solutions[w]);
+      });
+    for (auto& x : th) x.join();
+  }
   return GFS_OK;
 }
 

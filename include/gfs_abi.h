@@ -258,6 +258,15 @@ int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* s, vol
  * edges on fixed poses), bp [n_free][6], bl [n_points][3], edge_chi2 [n_edges]. Returns robust chi2 in *chi2. */
 int gfs_lba_linearize(gfs_lba* h, const gfs_lba_problem* p, double* Hpp, double* Hll, double* Hpl, double* bp,
                       double* bl, double* edge_chi2, double* chi2);
+/* n independent windows solved together (replicas: the LBA of one map does not shard; a server bundle-adjusting many maps, or
+ * several candidate windows, fills the GPU this way).  Per window the result is bit-identical to gfs_lba_solve; the phase
+ * kernels of all windows share their launches.  `stop` (may be NULL) is polled between LM trials: when raised, every window
+ * closes its running iteration like SparseOptimizer::terminate() and returns what it has. */
+typedef struct gfs_lba_batch gfs_lba_batch;
+int gfs_lba_batch_create(int device, int max_windows, int max_poses, int max_points, int max_edges, gfs_lba_batch** out);
+void gfs_lba_batch_destroy(gfs_lba_batch* h);
+int gfs_lba_solve_batch(gfs_lba_batch* h, const gfs_lba_problem* problems, gfs_lba_solution* solutions, int n,
+                        volatile const int* stop);
 
 /* ============================================================================================
  * 5. Frame helpers next to the hot path — keep GICP input and RGB-D "stereo" coordinates on device

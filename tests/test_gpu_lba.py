@@ -94,3 +94,32 @@ def test_stop_flag_raised_while_solving(gpu_api, oracle):
     if r["iterations_run"] < full["iterations_run"]:  # stopped early: the cost is not above the starting cost
         chi0 = oracle.lba_linearize(w)["chi2"]
         assert r["final_chi2"] <= chi0 * (1 + 1e-12)
+
+
+def test_lba_batched_windows_match_oracle_and_single(gpu_api, oracle):
+    """gfs_lba_solve_batch: windows of different sizes (3 ... 20 free key-frames, 80 ... 3000 points, different iteration
+    counts and numbers of rejected trials) solved together; every window against the oracle and, bit for bit, against the same
+    window solved alone."""
+    cfgs = [(1, 20, 5, 3000), (2, 4, 2, 120), (3, 3, 2, 80), (4, 12, 4, 1200), (5, 8, 3, 600), (6, 20, 5, 2500), (7, 5, 2, 300),
+            (8, 16, 3, 2000)] * 2
+    wins = [synth.lba_window(100 + k if k >= 8 else s, n_free=f, n_fixed=x, n_points=n) for k, (s, f, x, n) in enumerate(cfgs)]
+    wins[3]["iterations"] = 4          # optimize(4) next to optimize(10)
+    bat = gpu_api.BatchOptimizer(max_windows=len(wins), max_poses=32, max_points=4096, max_edges=65536)
+    got = bat.LocalBundleAdjustment(wins)
+    one = gpu_api.Optimizer(max_poses=32, max_points=4096, max_edges=65536)
+    its = set()
+    for w, r in zip(wins, got):
+        ro = oracle.lba_solve(w)
+        assert r["iterations_run"] == ro["iterations_run"]
+        assert np.linalg.norm(r["points"] - ro["points"]) <= 1e-5 * np.linalg.norm(ro["points"])
+        assert np.abs(r["pose_t"] - ro["pose_t"]).max() <= 1e-6
+        assert np.array_equal(r["edge_depth_positive"], ro["edge_depth_positive"])
+        r1 = one.LocalBundleAdjustment(w)
+        for k in ("pose_q", "pose_t", "points", "edge_chi2", "edge_depth_positive"):
+            assert np.array_equal(r[k], r1[k]), k
+        assert r["iterations_run"] == r1["iterations_run"] and r["final_chi2"] == r1["final_chi2"] and r["final_lambda"] == r1["final_lambda"]
+        its.add(r["iterations_run"])
+    assert len(its) >= 2  # the windows really finish at different times
+    # the stop flag raised before the call: nothing is optimised (src/Optimizer.cc:1955-1956)
+    with pytest.raises(gpu_api.GfsError):
+        bat.LocalBundleAdjustment(wins[:2], stop_flag=np.ones(1, np.int32))
