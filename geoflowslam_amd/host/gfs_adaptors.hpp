@@ -501,6 +501,166 @@ class FundamentalMatcher {
   gfs_fmat* h_ = nullptr;
 };
 
+// ------------------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjectionWithOF(CurrentFrame, LastFrame, mask, th, winsize, F_THRESHOLD, DIST_THRESHOLD, bMono)
+// (reference src/ORBmatcher.cc:2303-2497): the bookkeeping around the two forward-backward KLT passes and their F checks —
+// prior projection of the last frame's map points into the current frame (:2320-2373), the occupancy mask (cv::circle filled
+// discs, :2296-2302, 2326-2332), the hand-over of failed 3-D tracks to the 2-D pass (:2434-2442), the tracked key-point lists
+// that the caller passes to Frame::AddPts (:2444, 2492) — on plain arrays.  The numeric parts run on the GPU through KltTracker
+// and FundamentalMatcher above.  What stays with the caller (it touches Frame / MapPoint members only): mnLastFrameSeen of the
+// tracked map points, track_feature_pts_, the two AddPts calls and AssignFeaturesToGrid.
+// ------------------------------------------------------------------------------------------------------------------------
+struct OfFrames {
+  int n_last = 0;                         // LastFrame.mvpMapPoints.size() == LastFrame.mvKeys.size()
+  const gfs_keypoint* last_keys = nullptr;  // LastFrame.mvKeys (cv::KeyPoint layout)
+  const uint8_t* last_has_mp = nullptr;   // mvpMapPoints[i] != nullptr
+  const uint8_t* last_mp_bad = nullptr;   // mp->isBad()
+  const uint8_t* last_outlier = nullptr;  // LastFrame.mvbOutlier[i]
+  const float* last_mp_xw = nullptr;      // [n_last][3] mp->GetWorldPos()
+  int n_cur = 0;
+  const gfs_keypoint* cur_keys = nullptr;  // CurrentFrame.mvKeys
+  float Tcw_q[4] = {0, 0, 0, 1}, Tcw_t[3] = {0, 0, 0};  // CurrentFrame.GetPose(): unit quaternion (x, y, z, w), translation
+  float fx = 0, fy = 0, cx = 0, cy = 0, min_x = 0, max_x = 0, min_y = 0, max_y = 0;  // CurrentFrame.fx ... mnMaxY
+  int img_w = 0, img_h = 0;               // CurrentFrame.image.cols / rows
+};
+struct OfTracked {                         // one AddPts call: tracked_kps[i] continues LastFrame key-point last_index[i]
+  std::vector<gfs_keypoint> kps;
+  std::vector<int32_t> last_index;
+};
+
+// cv::circle(mask, pt, radius, Scalar(255), FILLED) on CV_8UC1 (OpenCV 4.5.4 imgproc/src/drawing.cpp Circle(): the midpoint
+// recurrence, filled with horizontal spans, clipped to the image; the float centre converts with cvRound like Point2f -> Point)
+inline void fill_circle_u8(uint8_t* img, int rows, int cols, int stride, float fx_, float fy_, int radius) {
+  const int cx = (int)std::lrint(fx_), cy = (int)std::lrint(fy_);  // saturate_cast<int>(float): round half to even
+  auto hline = [&](int y, int x0, int x1) {
+    if (y < 0 || y >= rows) return;
+    x0 = std::max(x0, 0);
+    x1 = std::min(x1, cols - 1);
+    for (int x = x0; x <= x1; x++) img[(size_t)y * stride + x] = 255;
+  };
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    hline(cy - dy, cx - dx, cx + dx);
+    hline(cy + dy, cx - dx, cx + dx);
+    hline(cy - dx, cx - dy, cx + dy);
+    hline(cy + dx, cx - dy, cx + dy);
+    dy++;
+    err += plus;
+    plus += 2;
+    const int m = (err <= 0) - 1;
+    err -= minus & m;
+    dx += m;
+    minus -= m & 2;
+  }
+}
+
+// returns nbgood; mask: img_h x img_w bytes (stride img_w), updated like the reference's cv::Mat& mask
+inline int SearchByProjectionWithOF(KltTracker& klt, FundamentalMatcher& fmat, const KltTracker::Pyramid& last_pyr,
+                                    const KltTracker::Pyramid& cur_pyr, const OfFrames& in, uint8_t* mask, float F_THRESHOLD,
+                                    int DIST_THRESHOLD, OfTracked& tracked3d, OfTracked& tracked2d) {
+  int nbgood = 0;
+  std::vector<int32_t> v3dkpids, v2dkpids;
+  std::vector<float> v3dkps, v3dpriors, v2dkps, v2dpriors;  // (x, y) pairs
+  tracked3d.kps.clear();
+  tracked3d.last_index.clear();
+  tracked2d.kps.clear();
+  tracked2d.last_index.clear();
+  const int W = in.img_w, H = in.img_h;
+  for (int i = 0; i < in.n_cur; i++) {  // mask of the key points already extracted in the current frame (:2326-2332)
+    const float x = in.cur_keys[i].x, y = in.cur_keys[i].y;
+    if (x > 0 && x < W && y > 0 && y < H) mask[(size_t)(int)y * W + (int)x] = 255;  // Mat::at<uchar>(float, float) truncates
+  }
+  auto push2d = [&](int cnt) {
+    const float u = in.last_keys[cnt].x, v = in.last_keys[cnt].y;
+    v2dkps.push_back(u);
+    v2dkps.push_back(v);
+    v2dpriors.push_back(u);
+    v2dpriors.push_back(v);
+    v2dkpids.push_back(cnt);
+  };
+  const float qx = in.Tcw_q[0], qy = in.Tcw_q[1], qz = in.Tcw_q[2], qw = in.Tcw_q[3];
+  for (int cnt = 0; cnt < in.n_last; cnt++) {
+    if (!in.last_has_mp[cnt]) {  // key points without a map point are tracked in the image only
+      push2d(cnt);
+      continue;
+    }
+    if (in.last_mp_bad[cnt] || in.last_outlier[cnt]) continue;
+    // x3Dc = Tcw * x3Dw (Sophus: unit_quaternion()._transformVector in float: v + w t + q x t, t = 2 q x v)
+    const float* X = in.last_mp_xw + 3 * (size_t)cnt;
+    const float tx = 2.f * (qy * X[2] - qz * X[1]), ty = 2.f * (qz * X[0] - qx * X[2]), tz = 2.f * (qx * X[1] - qy * X[0]);
+    const float xc = X[0] + qw * tx + (qy * tz - qz * ty) + in.Tcw_t[0];
+    const float yc = X[1] + qw * ty + (qz * tx - qx * tz) + in.Tcw_t[1];
+    const float zc = X[2] + qw * tz + (qx * ty - qy * tx) + in.Tcw_t[2];
+    const float invzc = (float)(1.0 / (double)zc);  // `const float invzc = 1.0 / x3Dc(2)`
+    const float u = in.fx * xc * invzc + in.cx, v = in.fy * yc * invzc + in.cy;
+    if (invzc < 0 || u < in.min_x || u > in.max_x || v < in.min_y || v > in.max_y) {
+      push2d(cnt);
+      continue;
+    }
+    v3dkps.push_back(in.last_keys[cnt].x);
+    v3dkps.push_back(in.last_keys[cnt].y);
+    v3dpriors.push_back(u);
+    v3dpriors.push_back(v);
+    v3dkpids.push_back(cnt);
+  }
+  const float nklt_err = 15.f, max_fbklt_dist = 0.5f;
+  auto track_and_check = [&](int nbpyrlvl, const std::vector<float>& kps, std::vector<float>& priors, float f_thr,
+                             std::vector<uint8_t>& vkpstatus) {
+    klt.fbKltTracking(last_pyr, cur_pyr, nbpyrlvl, nklt_err, max_fbklt_dist, kps, priors, vkpstatus);
+    std::vector<int32_t> index;
+    std::vector<float> un_cur, un_forw;
+    for (size_t i = 0; i < vkpstatus.size(); i++)
+      if (vkpstatus[i]) {
+        index.push_back((int32_t)i);
+        un_cur.push_back(kps[2 * i]);
+        un_cur.push_back(kps[2 * i + 1]);
+        un_forw.push_back(priors[2 * i]);
+        un_forw.push_back(priors[2 * i + 1]);
+      }
+    if (index.size() > 8) {  // cv::findFundamentalMat(un_cur_pts, un_forw_pts, FM_RANSAC, f_thr, 0.99, status)
+      std::vector<uint8_t> status;
+      fmat.findFundamentalMat(un_cur, un_forw, (double)f_thr, 0.99, status);
+      for (size_t i = 0; i < status.size(); i++)
+        if (!status[i]) vkpstatus[(size_t)index[i]] = 0;
+    }
+  };
+  auto is_nearby = [&](float x, float y) { return mask[(size_t)(int)y * W + (int)x] == 255; };  // cv::Point(pt.x, pt.y): truncation
+  if (!v3dkpids.empty()) {  // 1st: key points with a map point, prior = projection (3 pyramid levels)
+    std::vector<uint8_t> vkpstatus;
+    track_and_check(3, v3dkps, v3dpriors, F_THRESHOLD, vkpstatus);
+    for (size_t i = 0; i < v3dkpids.size(); i++) {
+      if (vkpstatus[i]) {
+        gfs_keypoint pt = in.last_keys[v3dkpids[i]];
+        pt.x = v3dpriors[2 * i];
+        pt.y = v3dpriors[2 * i + 1];
+        if (is_nearby(pt.x, pt.y)) continue;
+        tracked3d.kps.push_back(pt);
+        tracked3d.last_index.push_back(v3dkpids[i]);
+        nbgood++;
+        fill_circle_u8(mask, H, W, W, pt.x, pt.y, DIST_THRESHOLD);
+      } else {
+        push2d(v3dkpids[i]);  // not tracked: tried again as a 2-D point
+      }
+    }
+  }
+  if (!v2dkpids.empty()) {  // 2nd: image-only tracking (6 pyramid levels requested), F threshold halved
+    std::vector<uint8_t> vkpstatus;
+    track_and_check(6, v2dkps, v2dpriors, F_THRESHOLD * 0.5f, vkpstatus);
+    for (size_t i = 0; i < v2dkpids.size(); i++)
+      if (vkpstatus[i]) {
+        gfs_keypoint pt = in.last_keys[v2dkpids[i]];
+        pt.x = v2dpriors[2 * i];
+        pt.y = v2dpriors[2 * i + 1];
+        if (is_nearby(pt.x, pt.y)) continue;
+        tracked2d.kps.push_back(pt);
+        tracked2d.last_index.push_back(v2dkpids[i]);
+        fill_circle_u8(mask, H, W, W, pt.x, pt.y, DIST_THRESHOLD);
+        nbgood++;
+      }
+  }
+  return nbgood;
+}
+
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on flattened frames (reference src/ORBmatcher.cc:1853-2063;
 // see INTEGRATION.md §6 for the flattening of Frame / MapPoint)
 class ProjectionMatcher {

@@ -59,6 +59,13 @@ def main():
     mm = bf.match(m["q"], m["t"])
     report("A6 BFMatcher(NORM_HAMMING).match: lowest train index on ties", [x.trainIdx for x in mm] == m["train_idx2"].tolist()
            and [int(x.distance) for x in mm] == m["dist2"].tolist())
+    # A8: cv::circle(mask, Point2f, r, 255, FILLED) (the occupancy mask of SearchByProjectionWithOF)
+    okc = True
+    for r, (x, y) in ((10, (40.0, 37.0)), (10, (40.5, 36.5)), (3, (2.2, 3.7)), (30, (78.9, 59.1)), (0, (5.0, 5.0))):
+        a = np.zeros((60, 80), np.uint8)
+        cv2.circle(a, (int(np.rint(np.float32(x))), int(np.rint(np.float32(y)))), r, 255, cv2.FILLED)
+        okc &= np.array_equal(a, exp["circle_r%d_%d" % (r, int(x))])
+    report("A8 cv::circle filled disc (midpoint recurrence, spans)", okc)
     # optical flow: pyramid + tracker agree to ~1e-3 px (float summation order is build dependent)
     k = np.load(os.path.join(HERE, "klt_160x120.npz"))
     p0 = cv2.buildOpticalFlowPyramid(g0, (15, 15), 3)[1]
