@@ -679,6 +679,18 @@ __device__ void eig3_direct(const double* cov6, double* V) {
 // util/normal_estimation.hpp:69) through ring-expanding cell probes, 3x3 covariance, closed-form
 // eigen-decomposition, cov := V diag(1e-3, 1, 1) V^T.  Stored as 6 doubles (xx, xy, xz, yy, yz, zz).
 // ------------------------------------------------------------------------------------------------
+// v_min_f64 / v_max_f64 as they are (fmin / fmax add a canonicalising v_max_f64 per operand; no NaN reaches these)
+__device__ __forceinline__ double min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <int K>
 struct TopK {
   double d[K];
@@ -692,29 +704,23 @@ struct TopK {
     }
     found = 0;
   }
-  // ann/knn_result.hpp:80-101 (sorted insertion, after equal distances), walked from the BACK of the list: a candidate
-  // that passes the k-th-distance test usually lands in the last few slots, and once every lane of the wave has placed
-  // its element the remaining stages run with an empty EXEC mask (skipped).
+  // ann/knn_result.hpp:80-101 (sorted insertion, after equal distances) without a branch per slot: with
+  // c[i] = (dist < d[i]) the list after the insertion is  d'[i] = c[i-1] ? d[i-1] : (c[i] ? dist : d[i])
+  //                                                             = min(max(dist, d[i-1]), d[i])   (d ascending),
+  // and the indices follow the same two selects.  Five instructions per slot, the same for every lane of the wave (the
+  // slot-by-slot walk with an early exit costs four times that once any lane of the wave inserts, which is always).
   __device__ void push(int index, double dist) {
     if (dist >= d[K - 1]) return;
-    bool active = true;
+    bool ci = true;  // dist < d[K-1]
 #pragma unroll
     for (int i = K - 1; i >= 1; i--) {
-      if (active) {
-        if (dist < d[i - 1]) {
-          d[i] = d[i - 1];
-          id[i] = id[i - 1];
-        } else {
-          d[i] = dist;
-          id[i] = index;
-          active = false;
-        }
-      }
+      const bool cp = dist < d[i - 1];
+      id[i] = cp ? id[i - 1] : (ci ? index : id[i]);
+      d[i] = min_f64(max_f64(dist, d[i - 1]), d[i]);
+      ci = cp;
     }
-    if (active) {
-      d[0] = dist;
-      id[0] = index;
-    }
+    id[0] = ci ? index : id[0];
+    d[0] = min_f64(dist, d[0]);
     found = min(found + 1, K);
   }
   __device__ double nth(int n) const {  // d[n] without dynamic register indexing (keeps the arrays out of scratch)
