@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <thread>
 
@@ -88,6 +89,11 @@ struct LbaDev {
   double* Hs;          // packed lower triangle of the Schur complement (6 n_free)^2 / 2
   double* bs;          // [6 n_free]
   int n_err_blocks, n_upd_blocks;
+  double* out_pack;  // results in one block: chi2 [n_edges], q [n_poses][4], t [n_poses][3], X [n_points][3], chi2 / lambda, iterations / buffer
+  // Schur products by landmark chunks: partial blocks [chunk][pose pair][36] and right-hand sides [chunk][free pose][6]
+  double* schur_part;
+  double* schur_part_b;
+  int n_schur_chunks, n_pair_tiles, schur_sub;  // chunks of kSchurPts landmarks; tiles of kMk pose pairs; landmarks staged at a time
 };
 
 using namespace gfs_se3;
@@ -559,6 +565,7 @@ __device__ __forceinline__ void b_init(const LbaDev& D, const int bx, const int 
     for (int k = 0; k < 3; k++) D.t[3 * i + k] = D.t_try[3 * i + k] = D.pose_t0[3 * i + k];
   }
   for (int i = g; i < 3 * D.n_points; i += G) D.X[i] = D.X_try[i] = D.points0[i];
+  for (size_t i = g; i < (size_t)D.n_edges * 18; i += G) D.Hpl[i] = 0;  // the blocks of fixed-pose edges stay zero
   if (g == 0) {
     LbaState& S = *D.S;
     S.lambda = -1;
@@ -790,6 +797,131 @@ __device__ __forceinline__ void b_schur(const LbaDev& D, const int bx, const int
   if (i1 == i2 && tk >= 4 && tk < 10) D.bs[6 * i1 + (tk - 4)] = D.bp[6 * i1 + (tk - 4)] - v1;
 }
 __global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) { b_schur(D, blockIdx.x, gridDim.x); }
+
+// The same products taken landmark by landmark.  b_schur gives a workgroup to a pose pair, and every pair re-reads the 6x3
+// blocks of its two poses for each common landmark: Hpl is read ~n_free times (L2 traffic, 0.8 MB per pair).  Here a workgroup
+// takes a chunk of kSchurPts landmarks: the blocks B_f (6x3) of every free pose seeing a landmark, and B_f Dinv_l, are staged
+// in LDS once (schur_sub landmarks at a time), and thread <-> pose pair (i1 >= i2) accumulates its 6x6 block (and, on the
+// diagonal, B Dinv b_l) over the chunk's landmarks in index order.  Per-chunk partial blocks go to HBM; b_schur_reduce adds
+// them in chunk order: the sums have a fixed order that does not depend on the launch (a window solved alone or in a batch
+// gives the same bits).  Pose pairs beyond kMk: blockIdx.x = chunk * n_pair_tiles + tile.
+constexpr int kSchurPts = 64;
+constexpr int kSchurSlot = 38;  // doubles per staged (landmark, pose): B (18), B Dinv (18), + 2: 16 lanes' 16-byte reads of consecutive poses hit distinct banks
+
+__device__ __forceinline__ void b_schur_chunks(const LbaDev& D, const int bx) {
+  extern __shared__ __align__(16) double lds[];
+  const int F = D.n_free, NP = D.n_points, SB = D.schur_sub;
+  const int chunk = bx / D.n_pair_tiles, tile = bx - chunk * D.n_pair_tiles;
+  double* s_blk = lds;                                   // [SB][F][kSchurSlot]
+  double* s_bl = s_blk + (size_t)SB * F * kSchurSlot;    // [SB][4]
+  int* s_edge = (int*)(s_bl + 4 * SB);                   // [SB][F] edge id or -1
+  const int npairs = F * (F + 1) / 2;
+  const int pr = tile * kMk + threadIdx.x;
+  int i1 = 0, i2 = 0;
+  if (pr < npairs) {
+    i1 = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+    while (i1 * (i1 + 1) / 2 > pr) i1--;
+    while ((i1 + 1) * (i1 + 2) / 2 <= pr) i1++;
+    i2 = pr - i1 * (i1 + 1) / 2;
+  }
+  double acc[36], accb[6];
+#pragma unroll
+  for (int k = 0; k < 36; k++) acc[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) accb[k] = 0;
+  const int l_begin = chunk * kSchurPts, l_end = min(l_begin + kSchurPts, NP);
+  for (int l0 = l_begin; l0 < l_end; l0 += SB) {
+    const int nl = min(SB, l_end - l0);
+    __syncthreads();  // the previous sub-batch has been consumed
+    for (int u = threadIdx.x; u < nl * F; u += kMk) {
+      const int p = u / F, f = u - p * F, l = l0 + p;
+      const int e = D.edge_of[(size_t)f * NP + l];
+      s_edge[p * F + f] = e;
+      if (e >= 0) {
+        const double* B = D.Hpl + 18 * (size_t)e;
+        const double* Di = D.Dinv + 6 * (size_t)l;
+        const double d9[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
+        double* o = s_blk + (size_t)(p * F + f) * kSchurSlot;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          const double b0 = B[3 * a], b1 = B[3 * a + 1], b2 = B[3 * a + 2];
+          o[3 * a] = b0;
+          o[3 * a + 1] = b1;
+          o[3 * a + 2] = b2;
+#pragma unroll
+          for (int c = 0; c < 3; c++) o[18 + 3 * a + c] = b0 * d9[c] + b1 * d9[3 + c] + b2 * d9[6 + c];
+        }
+      }
+    }
+    if (threadIdx.x < nl * 3) s_bl[4 * (threadIdx.x / 3) + threadIdx.x % 3] = D.bl[3 * (size_t)l0 + threadIdx.x];
+    __syncthreads();
+    if (pr < npairs) {
+      for (int p = 0; p < nl; p++) {
+        if (s_edge[p * F + i1] < 0 || s_edge[p * F + i2] < 0) continue;
+        const double* BD = s_blk + (size_t)(p * F + i1) * kSchurSlot + 18;
+        const double* Bj = s_blk + (size_t)(p * F + i2) * kSchurSlot;
+        double bd[18], bj[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+          bd[k] = BD[k];
+          bj[k] = Bj[k];
+        }
+        // fused multiply-adds: this loop is the kernel's VALU time, and the order of the sums already differs from g2o's
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = 0; c < 6; c++)
+            acc[6 * a + c] = fma(bd[3 * a + 2], bj[3 * c + 2], fma(bd[3 * a + 1], bj[3 * c + 1], fma(bd[3 * a], bj[3 * c], acc[6 * a + c])));
+        if (i1 == i2) {
+          const double* bl = s_bl + 4 * p;
+#pragma unroll
+          for (int a = 0; a < 6; a++) accb[a] = fma(bd[3 * a + 2], bl[2], fma(bd[3 * a + 1], bl[1], fma(bd[3 * a], bl[0], accb[a])));
+        }
+      }
+    }
+  }
+  if (pr < npairs) {
+    double* o = D.schur_part + ((size_t)chunk * npairs + pr) * 36;
+#pragma unroll
+    for (int k = 0; k < 36; k++) o[k] = acc[k];
+    if (i1 == i2) {
+      double* ob = D.schur_part_b + ((size_t)chunk * F + i1) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) ob[k] = accb[k];
+    }
+  }
+}
+__global__ __launch_bounds__(kMk) void k_lba_schur_chunks(LbaDev D) { b_schur_chunks(D, blockIdx.x); }
+
+// Hs = [diagonal block](Hpp + lambda I) - sum over chunks (in chunk order), bs = bp - sum: one thread per entry of the packed
+// lower triangle, then one per entry of the right-hand side
+__device__ __forceinline__ void b_schur_reduce(const LbaDev& D, const int bx) {
+  const int F = D.n_free, n = 6 * F, ntri = n * (n + 1) / 2, npairs = F * (F + 1) / 2;
+  const int k = bx * kMk + threadIdx.x;
+  if (k < ntri) {
+    int r = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > k) r--;
+    while ((r + 1) * (r + 2) / 2 <= k) r++;
+    const int c = k - r * (r + 1) / 2;
+    const int i1 = r / 6, a = r - 6 * i1, i2 = c / 6, cc = c - 6 * i2;
+    const double* part = D.schur_part + ((size_t)(i1 * (i1 + 1) / 2 + i2)) * 36 + 6 * a + cc;
+    double sum = 0;
+    for (int ch = 0; ch < D.n_schur_chunks; ch++) sum += part[(size_t)ch * npairs * 36];
+    if (i1 != i2) {
+      D.Hs[k] = -sum;
+    } else {  // a >= cc: Hpp's upper-triangle entry (cc, a)
+      const double hpp = D.Hpp[21 * i1 + (cc * 6 - cc * (cc - 1) / 2 + (a - cc))];
+      D.Hs[k] = hpp + (a == cc ? D.S->lambda : 0.0) - sum;
+    }
+  } else if (k < ntri + n) {
+    const int j = k - ntri;
+    double sum = 0;
+    for (int ch = 0; ch < D.n_schur_chunks; ch++) sum += D.schur_part_b[(size_t)ch * n + j];
+    D.bs[j] = D.bp[j] - sum;
+  }
+}
+__global__ __launch_bounds__(kMk) void k_lba_schur_reduce(LbaDev D) { b_schur_reduce(D, blockIdx.x); }
+
 
 
 // LDL^T + triangular solves of the reduced pose system by a single workgroup.  kLds: the packed triangle fits the 160 KB of
@@ -1042,6 +1174,30 @@ __device__ __forceinline__ void b_finish(const LbaDev& D, const int bx) {
 }
 __global__ void k_lba_finish(LbaDev D) { b_finish(D, blockIdx.x); }
 
+// the results of a window gathered into one block (one copy to the host instead of six): layout of LbaDev::out_pack
+__device__ __forceinline__ void b_pack(const LbaDev& D, const int bx, const int gdx) {
+  const int cur = D.out_info[1];  // which estimate buffer holds the accepted state (b_finish; 0 on the single-workgroup path)
+  const double *q = sel(D.q, D.q_try, cur), *t = sel(D.t, D.t_try, cur), *X = sel(D.X, D.X_try, cur);
+  const int E = D.n_edges, NQ = D.n_poses, NP = D.n_points;
+  double* o = D.out_pack;
+  const int g = bx * kMk + threadIdx.x, G = gdx * kMk;
+  for (int i = g; i < E; i += G) o[i] = D.chi2[i];
+  o += E;
+  for (int i = g; i < 4 * NQ; i += G) o[i] = q[i];
+  o += 4 * NQ;
+  for (int i = g; i < 3 * NQ; i += G) o[i] = t[i];
+  o += 3 * NQ;
+  for (int i = g; i < 3 * NP; i += G) o[i] = X[i];
+  o += 3 * NP;
+  if (g == 0) {
+    o[0] = D.out_stats[0];
+    o[1] = D.out_stats[1];
+    o[2] = (double)D.out_info[0];
+    o[3] = (double)cur;
+  }
+}
+__global__ __launch_bounds__(kMk) void k_lba_pack(LbaDev D) { b_pack(D, blockIdx.x, gridDim.x); }
+
 
 // ------------------------------------------------------------------------------------------------
 // Batched windows (gfs_lba_solve_batch): the same phase kernels with the window index in blockIdx.y.  Every window carries its
@@ -1082,8 +1238,16 @@ __global__ __launch_bounds__(kMk) void kb_lba_dinv(const LbaDev* __restrict__ DD
   b_dinv(D, blockIdx.x, need);
 }
 __global__ __launch_bounds__(kMk) void kb_lba_schur(const LbaDev* __restrict__ DD) {
-  GFS_LBAB_PROLOGUE(1, D.n_free * (D.n_free + 1) / 2)
+  GFS_LBAB_PROLOGUE(1, D.schur_sub ? 0 : D.n_free * (D.n_free + 1) / 2)
   b_schur(D, blockIdx.x, need);
+}
+__global__ __launch_bounds__(kMk) void kb_lba_schur_chunks(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, D.schur_sub ? D.n_schur_chunks * D.n_pair_tiles : 0)
+  b_schur_chunks(D, blockIdx.x);
+}
+__global__ __launch_bounds__(kMk) void kb_lba_schur_reduce(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, D.schur_sub ? (6 * D.n_free * (6 * D.n_free + 1) / 2 + 6 * D.n_free + kMk - 1) / kMk : 0)
+  b_schur_reduce(D, blockIdx.x);
 }
 template <bool kLds>
 __global__ __launch_bounds__(kThreads) void kb_lba_solve(const LbaDev* __restrict__ DD) {
@@ -1114,25 +1278,13 @@ __global__ void kb_lba_finish(const LbaDev* __restrict__ DD) {
   const LbaDev D = DD[blockIdx.x];
   b_finish(D, 0);
 }
+__global__ __launch_bounds__(kMk) void kb_lba_pack(const LbaDev* __restrict__ DD) {
+  const LbaDev D = DD[blockIdx.y];
+  b_pack(D, blockIdx.x, gridDim.x);
+}
 #undef GFS_LBAB_PROLOGUE
 
 // host -> device through the pinned arena (bump allocation; the arena outlives the asynchronous copies of one call)
-struct Stager {
-  unsigned char* base;
-  size_t cap, used = 0;
-  hipStream_t s;
-  template <typename T>
-  int put(T* dev, const T* host, size_t count) {
-    if (count == 0) return GFS_OK;
-    const size_t bytes = count * sizeof(T), at = (used + 63) & ~(size_t)63;
-    GFS_REQUIRE(at + bytes <= cap, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
-    memcpy(base + at, host, bytes);
-    used = at + bytes;
-    GFS_HIP(hipMemcpyAsync(dev, base + at, bytes, hipMemcpyHostToDevice, s));
-    return GFS_OK;
-  }
-};
-
 }  // namespace
 
 struct gfs_lba {
@@ -1141,24 +1293,30 @@ struct gfs_lba {
   std::mutex mu;
   int* h_stop = nullptr;  // host-mapped
   int* h_flags = nullptr;  // host-mapped: {again, terminate, cur, iters} written by k_lba_decide
-  int final_cur = 0;       // estimate buffer holding the result of the last solve
+  LbaDev last_desc;        // the window of the last run()
   gfs::DevBuf<LbaState> d_state;
   gfs::PinBuf<unsigned char> h_stage;  // pinned staging arena for the problem upload (pageable copies cost ~2 ms each)
   gfs::DevBuf<double> d_part_chi, d_part_scale, d_Hs, d_bs;
-  gfs::DevBuf<double> d_q0, d_t0, d_X0, d_obs, d_w, d_q, d_t, d_X, d_qt, d_tt, d_Xt, d_chi2, d_err, d_Hpl, d_Hll, d_bl, d_Dinv,
-      d_Hpp, d_bp, d_xl, d_xp, d_stats;
-  gfs::DevBuf<int> d_free_index, d_free_pose, d_e_pose, d_e_point, d_pt_begin, d_pose_begin, d_pose_edges, d_edge_of, d_info;
-  gfs::DevBuf<unsigned char> d_stereo;
+  gfs::DevBuf<double> d_schur_part, d_schur_part_b;  // grown on demand (upload_and_fill)
+  gfs::DevBuf<unsigned char> d_in;      // the window's inputs, same layout as h_stage (Stager)
+  gfs::DevBuf<double> d_out;            // the window's results (b_pack)
+  gfs::PinBuf<double> h_out;
+  gfs::DevBuf<double> d_q, d_t, d_X, d_qt, d_tt, d_Xt, d_chi2, d_err, d_Hpl, d_Hll, d_bl, d_Dinv, d_Hpp, d_bp, d_xl, d_xp, d_stats;
+  gfs::DevBuf<int> d_info;
 };
 
 namespace {
 
+// Host preparation of a window, written straight into the handle's pinned arena (the device block d_in has the same layout, one
+// copy moves it): landmark-major edge order, the CSR tables, the co-visibility table.
 struct HostPrep {
   std::vector<int> order;  // landmark-major position -> original edge
-  std::vector<int> free_index, free_pose, e_pose, e_point, pt_begin, pose_begin, pose_edges, edge_of;
-  std::vector<double> obs, w;
-  std::vector<unsigned char> stereo;
   int n_free = 0;
+  double *q0 = nullptr, *t0 = nullptr, *X0 = nullptr, *obs = nullptr, *w = nullptr;
+  int *free_index = nullptr, *free_pose = nullptr, *e_pose = nullptr, *e_point = nullptr, *pt_begin = nullptr, *pose_begin = nullptr,
+      *pose_edges = nullptr, *edge_of = nullptr;
+  unsigned char* stereo = nullptr;
+  size_t used = 0;  // bytes of the arena in use
 };
 
 int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
@@ -1166,34 +1324,60 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
   GFS_REQUIRE(p->n_poses <= h->max_poses && p->n_points <= h->max_points && p->n_edges <= h->max_edges, GFS_ERR_CAPACITY,
               "gfs_lba: problem (%d poses, %d points, %d edges) exceeds handle capacity (%d, %d, %d)", p->n_poses,
               p->n_points, p->n_edges, h->max_poses, h->max_points, h->max_edges);
-  P.free_index.assign(p->n_poses, -1);
-  P.free_pose.clear();
-  for (int i = 0; i < p->n_poses; i++)
+  const int E = p->n_edges, NP = p->n_points, NQ = p->n_poses;
+  int nf = 0;
+  for (int i = 0; i < NQ; i++) nf += p->pose_fixed[i] ? 0 : 1;
+  P.n_free = nf;
+  {  // carve the arena
+    unsigned char* base = h->h_stage.p;
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+      unsigned char* r = base + at;
+      at = (at + bytes + 63) & ~(size_t)63;
+      return r;
+    };
+    P.q0 = (double*)take((size_t)NQ * 32);
+    P.t0 = (double*)take((size_t)NQ * 24);
+    P.X0 = (double*)take((size_t)NP * 24);
+    P.obs = (double*)take((size_t)E * 24);
+    P.w = (double*)take((size_t)E * 8);
+    P.free_index = (int*)take((size_t)NQ * 4);
+    P.free_pose = (int*)take((size_t)nf * 4);
+    P.e_pose = (int*)take((size_t)E * 4);
+    P.e_point = (int*)take((size_t)E * 4);
+    P.pt_begin = (int*)take((size_t)(NP + 1) * 4);
+    P.pose_begin = (int*)take((size_t)(nf + 1) * 4);
+    P.pose_edges = (int*)take((size_t)E * 4);
+    P.edge_of = (int*)take((size_t)nf * NP * 4);
+    P.stereo = take((size_t)E);
+    P.used = at;
+    GFS_REQUIRE(at <= h->h_stage.n, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
+  }
+  if (NQ) memcpy(P.q0, p->pose_q, (size_t)NQ * 32);
+  if (NQ) memcpy(P.t0, p->pose_t, (size_t)NQ * 24);
+  if (NP) memcpy(P.X0, p->points, (size_t)NP * 24);
+  nf = 0;
+  for (int i = 0; i < NQ; i++) {
+    P.free_index[i] = -1;
     if (!p->pose_fixed[i]) {
-      P.free_index[i] = (int)P.free_pose.size();
-      P.free_pose.push_back(i);
+      P.free_index[i] = nf;
+      P.free_pose[nf++] = i;
     }
-  P.n_free = (int)P.free_pose.size();
-  const int E = p->n_edges, NP = p->n_points;
-  P.pt_begin.assign(NP + 1, 0);
+  }
+  std::fill(P.pt_begin, P.pt_begin + NP + 1, 0);
   for (int e = 0; e < E; e++) {
-    GFS_REQUIRE(p->edge_point[e] >= 0 && p->edge_point[e] < NP && p->edge_pose[e] >= 0 && p->edge_pose[e] < p->n_poses,
+    GFS_REQUIRE(p->edge_point[e] >= 0 && p->edge_point[e] < NP && p->edge_pose[e] >= 0 && p->edge_pose[e] < NQ,
                 GFS_ERR_INVALID_ARG, "gfs_lba: edge %d references an unknown vertex", e);
     P.pt_begin[p->edge_point[e] + 1]++;
   }
   for (int l = 0; l < NP; l++) P.pt_begin[l + 1] += P.pt_begin[l];
   P.order.assign(E, 0);
   {
-    std::vector<int> pos(P.pt_begin.begin(), P.pt_begin.end() - 1);
+    std::vector<int> pos(P.pt_begin, P.pt_begin + NP);
     for (int e = 0; e < E; e++) P.order[pos[p->edge_point[e]]++] = e;  // stable
   }
-  P.e_pose.resize(E);
-  P.e_point.resize(E);
-  P.obs.resize((size_t)E * 3);
-  P.w.resize(E);
-  P.stereo.resize(E);
-  P.pose_begin.assign(P.n_free + 1, 0);
-  P.edge_of.assign((size_t)P.n_free * NP, -1);
+  std::fill(P.pose_begin, P.pose_begin + P.n_free + 1, 0);
+  std::fill(P.edge_of, P.edge_of + (size_t)P.n_free * NP, -1);
   for (int k = 0; k < E; k++) {
     const int e = P.order[k];
     P.e_pose[k] = p->edge_pose[e];
@@ -1210,9 +1394,8 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
     }
   }
   for (int f = 0; f < P.n_free; f++) P.pose_begin[f + 1] += P.pose_begin[f];
-  P.pose_edges.assign(P.pose_begin[P.n_free], 0);
   {
-    std::vector<int> pos(P.pose_begin.begin(), P.pose_begin.end() - 1);
+    std::vector<int> pos(P.pose_begin, P.pose_begin + P.n_free);
     for (int k = 0; k < E; k++) {
       const int f = P.free_index[P.e_pose[k]];
       if (f >= 0) P.pose_edges[pos[f]++] = k;
@@ -1221,41 +1404,37 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
   return GFS_OK;
 }
 
-// uploads one problem into the handle's buffers (through its pinned arena, on stream s) and describes it for the kernels
-int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, hipStream_t s, LbaDev& D) {
+// the arena of a prepared window -> the device block (one copy, on stream s)
+int upload(gfs_lba* h, const HostPrep& P, hipStream_t s) {
+  if (P.used) GFS_HIP(hipMemcpyAsync(h->d_in.p, h->h_stage.p, P.used, hipMemcpyHostToDevice, s));
+  return GFS_OK;
+}
+
+// describes an uploaded window for the kernels
+int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, hipStream_t s, LbaDev& D, bool do_upload = true) {
   const int E = p->n_edges, NP = p->n_points;
   int rc;
-  Stager st{h->h_stage.p, h->h_stage.n, 0, s};
-  if ((rc = st.put(h->d_q0.p, p->pose_q, (size_t)p->n_poses * 4)) || (rc = st.put(h->d_t0.p, p->pose_t, (size_t)p->n_poses * 3)) ||
-      (rc = st.put(h->d_X0.p, p->points, (size_t)NP * 3)) || (rc = st.put(h->d_free_index.p, P.free_index.data(), P.free_index.size())) ||
-      (rc = st.put(h->d_free_pose.p, P.free_pose.data(), P.free_pose.size())) || (rc = st.put(h->d_e_pose.p, P.e_pose.data(), P.e_pose.size())) ||
-      (rc = st.put(h->d_e_point.p, P.e_point.data(), P.e_point.size())) || (rc = st.put(h->d_obs.p, P.obs.data(), P.obs.size())) ||
-      (rc = st.put(h->d_w.p, P.w.data(), P.w.size())) || (rc = st.put(h->d_stereo.p, P.stereo.data(), P.stereo.size())) ||
-      (rc = st.put(h->d_pt_begin.p, P.pt_begin.data(), P.pt_begin.size())) ||
-      (rc = st.put(h->d_pose_begin.p, P.pose_begin.data(), P.pose_begin.size())) ||
-      (rc = st.put(h->d_pose_edges.p, P.pose_edges.data(), P.pose_edges.size())) ||
-      (rc = st.put(h->d_edge_of.p, P.edge_of.data(), P.edge_of.size())))
-    return rc;
-  if (E) GFS_HIP(hipMemsetAsync(h->d_Hpl.p, 0, (size_t)E * 18 * sizeof(double), s));
+  if (do_upload && (rc = upload(h, P, s))) return rc;
   D = LbaDev{};
+  auto dev = [&](const void* host) { return (const void*)(h->d_in.p + ((const unsigned char*)host - h->h_stage.p)); };
+  D.pose_q0 = (const double*)dev(P.q0);
+  D.pose_t0 = (const double*)dev(P.t0);
+  D.points0 = (const double*)dev(P.X0);
+  D.free_index = (const int*)dev(P.free_index);
+  D.free_pose = (const int*)dev(P.free_pose);
+  D.e_pose = (const int*)dev(P.e_pose);
+  D.e_point = (const int*)dev(P.e_point);
+  D.e_obs = (const double*)dev(P.obs);
+  D.e_w = (const double*)dev(P.w);
+  D.pt_begin = (const int*)dev(P.pt_begin);
+  D.pose_begin = (const int*)dev(P.pose_begin);
+  D.pose_edges = (const int*)dev(P.pose_edges);
+  D.edge_of = (const int*)dev(P.edge_of);
+  D.e_stereo = (const unsigned char*)dev(P.stereo);
   D.n_poses = p->n_poses;
   D.n_points = NP;
   D.n_edges = E;
   D.n_free = P.n_free;
-  D.pose_q0 = h->d_q0.p;
-  D.pose_t0 = h->d_t0.p;
-  D.free_index = h->d_free_index.p;
-  D.free_pose = h->d_free_pose.p;
-  D.points0 = h->d_X0.p;
-  D.e_pose = h->d_e_pose.p;
-  D.e_point = h->d_e_point.p;
-  D.e_obs = h->d_obs.p;
-  D.e_w = h->d_w.p;
-  D.e_stereo = h->d_stereo.p;
-  D.pt_begin = h->d_pt_begin.p;
-  D.pose_begin = h->d_pose_begin.p;
-  D.pose_edges = h->d_pose_edges.p;
-  D.edge_of = h->d_edge_of.p;
   D.fx = p->fx;
   D.fy = p->fy;
   D.cx = p->cx;
@@ -1286,6 +1465,7 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
   D.stop = d_stop;
   D.out_info = h->d_info.p;
   D.out_stats = h->d_stats.p;
+  D.out_pack = h->d_out.p;
   D.mode = mode;
   D.S = h->d_state.p;
   D.part_chi = h->d_part_chi.p;
@@ -1294,13 +1474,40 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
   D.bs = h->d_bs.p;
   D.n_err_blocks = gfs::div_up(std::max(E, 1), kMk);
   D.n_upd_blocks = gfs::div_up(std::max(NP, 1), kMk);
+  // Schur products by landmark chunks (b_schur_chunks); windows too wide for its LDS staging keep the pair-per-workgroup kernel
+  {
+    const int F = P.n_free;
+    const size_t per_landmark = (size_t)F * (kSchurSlot * sizeof(double) + sizeof(int)) + 4 * sizeof(double);
+    const int sub = F > 0 ? (int)std::min<size_t>(8, (96 * 1024) / per_landmark) : 0;
+    const size_t npairs = (size_t)F * (F + 1) / 2, chunks = gfs::div_up(std::max(NP, 1), kSchurPts);
+    const size_t need = chunks * npairs * 36, need_b = chunks * (size_t)F * 6;
+    static const bool by_pairs = getenv("GFS_LBA_SCHUR") && !strcmp(getenv("GFS_LBA_SCHUR"), "pairs");
+    D.schur_sub = (sub >= 1 && need * sizeof(double) <= ((size_t)1 << 30) && !by_pairs) ? sub : 0;
+    if (D.schur_sub) {
+      if (h->d_schur_part.n < need) {
+        GFS_HIP(hipStreamSynchronize(s));
+        if ((rc = h->d_schur_part.alloc(need + need / 4))) return rc;
+      }
+      if (h->d_schur_part_b.n < need_b) {
+        GFS_HIP(hipStreamSynchronize(s));
+        if ((rc = h->d_schur_part_b.alloc(need_b + need_b / 4))) return rc;
+      }
+      D.schur_part = h->d_schur_part.p;
+      D.schur_part_b = h->d_schur_part_b.p;
+      D.n_schur_chunks = (int)chunks;
+      D.n_pair_tiles = (int)gfs::div_up((int)npairs, kMk);
+    }
+  }
   return GFS_OK;
+}
+
+inline size_t schur_lds_bytes(const LbaDev& D) {
+  return (size_t)D.schur_sub * ((size_t)D.n_free * (kSchurSlot * sizeof(double) + sizeof(int)) + 4 * sizeof(double));
 }
 
 int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volatile const int* stop) {
   hipStream_t s = h->stream;
   const int NP = p->n_points, E = p->n_edges;
-  (void)E;
   LbaDev D;
   int rc = upload_and_fill(h, p, P, mode, s, D);
   if (rc) return rc;
@@ -1309,9 +1516,10 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   const size_t lds = (in_lds ? (size_t)n * (n + 1) / 2 + n + 8 : (size_t)7 * n + 8) * sizeof(double);
   GFS_REQUIRE(lds <= 160 * 1024, GFS_ERR_CAPACITY, "gfs_lba: %d free poses exceed the solver's workspace", P.n_free);
   static const bool single_wg = getenv("GFS_LBA_SINGLE_WG") != nullptr;  // the round-1a kernel: whole solve in one workgroup
-  h->final_cur = 0;
+  h->last_desc = D;
   if (single_wg && in_lds) {
     GFS_HIP(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (E) GFS_HIP(hipMemsetAsync(h->d_Hpl.p, 0, (size_t)E * 18 * sizeof(double), s));
     GFS_LAUNCH("k_lba", k_lba, dim3(1), dim3(kThreads), lds, s, D);
     // setForceStopFlag semantics (src/Optimizer.cc:1679): relay the caller's flag to the device-visible one
     if (stop) {
@@ -1331,6 +1539,8 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   GFS_HIP(hipHostGetDevicePointer((void**)&d_flags, h->h_flags, 0));
   GFS_HIP(hipFuncSetAttribute(in_lds ? (const void*)k_lba_solve<true> : (const void*)k_lba_solve<false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (D.schur_sub)
+    GFS_HIP(hipFuncSetAttribute((const void*)k_lba_schur_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds_bytes(D)));
   const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 8)), g_upd(D.n_upd_blocks);
   GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
   const bool lin_only = mode == 1 || p->iterations <= 0;
@@ -1357,7 +1567,12 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
     bool terminate = false;
     for (;;) {
       GFS_LAUNCH("k_lba_dinv", k_lba_dinv, g_upd, dim3(kMk), 0, s, D);
-      if (npairs > 0) GFS_LAUNCH("k_lba_schur", k_lba_schur, dim3(npairs), dim3(kMk), 0, s, D);
+      if (npairs > 0 && D.schur_sub) {
+        GFS_LAUNCH("k_lba_schur_chunks", k_lba_schur_chunks, dim3(D.n_schur_chunks * D.n_pair_tiles), dim3(kMk), schur_lds_bytes(D), s, D);
+        GFS_LAUNCH("k_lba_schur_reduce", k_lba_schur_reduce, dim3(gfs::div_up(n * (n + 1) / 2 + n, kMk)), dim3(kMk), 0, s, D);
+      } else if (npairs > 0) {
+        GFS_LAUNCH("k_lba_schur", k_lba_schur, dim3(npairs), dim3(kMk), 0, s, D);
+      }
       if (in_lds)
         GFS_LAUNCH("k_lba_solve", k_lba_solve<true>, dim3(1), dim3(kThreads), lds, s, D);
       else
@@ -1379,12 +1594,9 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
     if (terminate) break;
   }
   GFS_LAUNCH("k_lba_finish", k_lba_finish, dim3(1), dim3(64), 0, s, D);
-  GFS_HIP(hipStreamSynchronize(s));
-  if (timing) fprintf(stderr, "  run: LM loop %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - Ta).count());
-  {
-    int info[2] = {0, 0};
-    GFS_HIP(hipMemcpy(info, h->d_info.p, sizeof(info), hipMemcpyDeviceToHost));
-    h->final_cur = info[1];
+  if (timing) {
+    GFS_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "  run: LM loop %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - Ta).count());
   }
   return GFS_OK;
 }
@@ -1408,11 +1620,6 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   const size_t NP = max_points, E = max_edges, NQ = max_poses, F = max_poses;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
-  A(h->d_q0.alloc(NQ * 4));
-  A(h->d_t0.alloc(NQ * 3));
-  A(h->d_X0.alloc(NP * 3));
-  A(h->d_obs.alloc(E * 3));
-  A(h->d_w.alloc(E));
   A(h->d_q.alloc(NQ * 4));
   A(h->d_t.alloc(NQ * 3));
   A(h->d_X.alloc(NP * 3));
@@ -1430,18 +1637,12 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   A(h->d_xl.alloc(NP * 3));
   A(h->d_xp.alloc(F * 6));
   A(h->d_stats.alloc(2));
-  A(h->d_free_index.alloc(NQ));
-  A(h->d_free_pose.alloc(F));
-  A(h->d_e_pose.alloc(E));
-  A(h->d_e_point.alloc(E));
-  A(h->d_pt_begin.alloc(NP + 1));
-  A(h->d_pose_begin.alloc(F + 1));
-  A(h->d_pose_edges.alloc(E));
-  A(h->d_edge_of.alloc(F * NP));
   A(h->d_info.alloc(2));
-  A(h->d_stereo.alloc(E));
   A(h->d_state.alloc(1));
   A(h->h_stage.alloc(NQ * (32 + 24 + 4) + NP * (24 + 4) + E * (4 + 4 + 24 + 8 + 1 + 4) + F * (4 + 4 + NP * 4) + 4096));
+  A(h->d_in.alloc(h->h_stage.n));
+  A(h->d_out.alloc(E + 7 * NQ + 3 * NP + 4));
+  A(h->h_out.alloc(E + 7 * NQ + 3 * NP + 4));
   A(h->d_part_chi.alloc(E / kMk + 2));
   A(h->d_part_scale.alloc(NP / kMk + 2));
   A(h->d_Hs.alloc((size_t)(6 * F) * (6 * F + 1) / 2 + 8));
@@ -1462,45 +1663,26 @@ void gfs_lba_destroy(gfs_lba* h) {
   delete h;
 }
 
-// result download of one window, in two halves so that a batch can queue all copies before one synchronisation
+// result download of one window, in two halves so that a batch can queue all copies before one synchronisation: the packed
+// block of b_pack comes back in one copy
 struct LbaFetch {
-  double *chi, *q, *t, *X, *stats;
-  int* info;
+  const double *chi, *q, *t, *X, *stats;
 };
-static int lba_fetch_issue(gfs_lba* h, const gfs_lba_problem* p, hipStream_t s, int final_cur, LbaFetch& F) {
-  const int E = p->n_edges, NP = p->n_points;
-  const double* rq = final_cur ? h->d_qt.p : h->d_q.p;  // the accepted estimate (the two buffers swap roles)
-  const double* rt = final_cur ? h->d_tt.p : h->d_t.p;
-  const double* rX = final_cur ? h->d_Xt.p : h->d_X.p;
-  // results come back through the pinned arena too (the uploads of this call have completed)
-  unsigned char* base = h->h_stage.p;
-  size_t at = 0;
-  auto take = [&](size_t bytes) {
-    unsigned char* r = base + at;
-    at = (at + bytes + 63) & ~(size_t)63;
-    return r;
-  };
-  F.chi = (double*)take((size_t)E * 8);
-  F.q = (double*)take((size_t)p->n_poses * 32);
-  F.t = (double*)take((size_t)p->n_poses * 24);
-  F.X = (double*)take((size_t)NP * 24);
-  F.info = (int*)take(2 * sizeof(int));
-  F.stats = (double*)take(2 * sizeof(double));
-  GFS_REQUIRE(at <= h->h_stage.n, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
-  if (E) GFS_HIP(hipMemcpyAsync(F.chi, h->d_chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
-  if (p->n_poses) {
-    GFS_HIP(hipMemcpyAsync(F.q, rq, (size_t)p->n_poses * 32, hipMemcpyDeviceToHost, s));
-    GFS_HIP(hipMemcpyAsync(F.t, rt, (size_t)p->n_poses * 24, hipMemcpyDeviceToHost, s));
-  }
-  if (NP) GFS_HIP(hipMemcpyAsync(F.X, rX, (size_t)NP * 24, hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(F.info, h->d_info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(F.stats, h->d_stats.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+static int lba_fetch_issue(gfs_lba* h, const gfs_lba_problem* p, hipStream_t s, LbaFetch& F) {
+  const size_t E = p->n_edges, NP = p->n_points, NQ = p->n_poses, total = E + 7 * NQ + 3 * NP + 4;
+  GFS_REQUIRE(total <= h->h_out.n, GFS_ERR_CAPACITY, "gfs_lba: result arena too small");
+  const double* base = h->h_out.p;
+  F.chi = base;
+  F.q = base + E;
+  F.t = F.q + 4 * NQ;
+  F.X = F.t + 3 * NQ;
+  F.stats = F.X + 3 * NP;
+  GFS_HIP(hipMemcpyAsync(h->h_out.p, h->d_out.p, total * sizeof(double), hipMemcpyDeviceToHost, s));
   return GFS_OK;
 }
 static void lba_fetch_finish(const gfs_lba_problem* p, const HostPrep& P, const LbaFetch& F, gfs_lba_solution* sol) {
   const int E = p->n_edges, NP = p->n_points;
   const double *chi = F.chi, *q = F.q, *t = F.t, *X = F.X, *stats = F.stats;
-  const int* info = F.info;
   if (p->n_poses && sol->pose_q) memcpy(sol->pose_q, q, (size_t)p->n_poses * 32);
   if (p->n_poses && sol->pose_t) memcpy(sol->pose_t, t, (size_t)p->n_poses * 24);
   if (NP && sol->points) memcpy(sol->points, X, (size_t)NP * 24);
@@ -1516,7 +1698,7 @@ static void lba_fetch_finish(const gfs_lba_problem* p, const HostPrep& P, const 
       sol->edge_depth_positive[e] = z > 0.0;
     }
   }
-  sol->iterations_run = info[0];
+  sol->iterations_run = (int)stats[2];
   sol->final_chi2 = stats[0];
   sol->final_lambda = stats[1];
 }
@@ -1543,7 +1725,8 @@ int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, v
     fprintf(stderr, "gfs_lba_solve: prepare %.2f ms, upload + solve %.2f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(),
             std::chrono::duration<double, std::milli>(T2 - T1).count());
   LbaFetch F;
-  rc = lba_fetch_issue(h, p, h->stream, h->final_cur, F);
+  GFS_LAUNCH("k_lba_pack", k_lba_pack, dim3(16), dim3(kMk), 0, h->stream, h->last_desc);
+  rc = lba_fetch_issue(h, p, h->stream, F);
   if (rc) return rc;
   GFS_HIP(hipStreamSynchronize(h->stream));
   lba_fetch_finish(p, P, F, sol);
@@ -1614,6 +1797,12 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   std::lock_guard<std::mutex> lk(b->mu);
   GFS_HIP(hipSetDevice(b->device));
   hipStream_t s = b->stream;
+  static const bool timing = getenv("GFS_LBA_TIMING") != nullptr;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
+    return std::chrono::duration<double, std::milli>(c - a).count();
+  };
+  const auto T0 = now();
   // ---- host preparation of every window (edge re-ordering, CSR tables), on a few threads
   std::vector<int> rcs((size_t)n, 0);
   {
@@ -1621,16 +1810,22 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++)
       th.emplace_back([&, t]() {
-        for (int w = t; w < n; w += nthreads) rcs[w] = prepare(b->win[w], &problems[w], b->prep[w]);
+        (void)hipSetDevice(b->device);
+        for (int w = t; w < n; w += nthreads) {
+          rcs[w] = prepare(b->win[w], &problems[w], b->prep[w]);
+          if (!rcs[w]) rcs[w] = upload(b->win[w], b->prep[w], s);  // the copy leaves as soon as the window is ready
+        }
       });
     for (auto& x : th) x.join();
   }
   for (int w = 0; w < n; w++)
     if (rcs[w]) return rcs[w];
-  int max_free = 0, max_err = 1, max_upd = 1, max_lm = 1, max_iter = 0;
+  const auto T1 = now();
+  int max_free = 0, max_err = 1, max_upd = 1, max_lm = 1, max_iter = 0, max_chunk_blocks = 0, max_pair_blocks = 0;
+  size_t schur_lds = 0;
   for (int w = 0; w < n; w++) {
     LbaDev D;
-    const int rc = upload_and_fill(b->win[w], &problems[w], b->prep[w], 0, s, D);
+    const int rc = upload_and_fill(b->win[w], &problems[w], b->prep[w], 0, s, D, false);
     if (rc) return rc;
     GFS_HIP(hipHostGetDevicePointer((void**)&D.stop, b->win[w]->h_stop, 0));
     *b->win[w]->h_stop = 0;
@@ -1640,7 +1835,15 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     max_upd = std::max(max_upd, D.n_upd_blocks);
     max_lm = std::max(max_lm, gfs::div_up(std::max(D.n_points, 1), 8));
     max_iter = std::max(max_iter, problems[w].iterations);
+    if (D.schur_sub) {
+      max_chunk_blocks = std::max(max_chunk_blocks, D.n_schur_chunks * D.n_pair_tiles);
+      schur_lds = std::max(schur_lds, schur_lds_bytes(D));
+    } else {
+      max_pair_blocks = std::max(max_pair_blocks, D.n_free * (D.n_free + 1) / 2);
+    }
   }
+  if (schur_lds)
+    GFS_HIP(hipFuncSetAttribute((const void*)kb_lba_schur_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
   GFS_HIP(hipMemcpyAsync(b->d_desc.p, b->h_desc.p, (size_t)n * sizeof(LbaDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(b->d_done.p, 0, sizeof(int), s));
   const int nmax = 6 * max_free;
@@ -1650,7 +1853,8 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   GFS_HIP(hipFuncSetAttribute(in_lds ? (const void*)kb_lba_solve<true> : (const void*)kb_lba_solve<false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const LbaDev* DD = b->d_desc.p;
-  const int npairs = std::max(1, max_free * (max_free + 1) / 2);
+  const auto T2 = now();
+  int rounds_run = 0;
   GFS_LAUNCH("kb_lba_init", kb_lba_init, dim3(64, n), dim3(kMk), 0, s, DD);
   // windows with iterations <= 0 finish at once (optimize(0) leaves the estimate alone): handled by max_rounds = 0 below
   const int max_rounds = max_iter > 0 ? max_iter * 11 + 1 : 0;
@@ -1661,7 +1865,11 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     if (max_free > 0) GFS_LAUNCH("kb_lba_build_poses", kb_lba_build_poses, dim3(max_free, n), dim3(kMk), 0, s, DD);
     GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD);
     GFS_LAUNCH("kb_lba_dinv", kb_lba_dinv, dim3(max_upd, n), dim3(kMk), 0, s, DD);
-    if (max_free > 0) GFS_LAUNCH("kb_lba_schur", kb_lba_schur, dim3(npairs, n), dim3(kMk), 0, s, DD);
+    if (max_chunk_blocks > 0) {
+      GFS_LAUNCH("kb_lba_schur_chunks", kb_lba_schur_chunks, dim3(max_chunk_blocks, n), dim3(kMk), schur_lds, s, DD);
+      GFS_LAUNCH("kb_lba_schur_reduce", kb_lba_schur_reduce, dim3(gfs::div_up(nmax * (nmax + 1) / 2 + nmax, kMk), n), dim3(kMk), 0, s, DD);
+    }
+    if (max_pair_blocks > 0) GFS_LAUNCH("kb_lba_schur", kb_lba_schur, dim3(max_pair_blocks, n), dim3(kMk), 0, s, DD);
     if (in_lds)
       GFS_LAUNCH("kb_lba_solve", kb_lba_solve<true>, dim3(1, n), dim3(kThreads), lds, s, DD);
     else
@@ -1672,6 +1880,7 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     GFS_LAUNCH("kb_lba_decide", kb_lba_decide, dim3(n), dim3(64), 0, s, DD, force_end ? 1 : 0, b->d_flags.p, b->d_done.p);
     GFS_HIP(hipMemcpyAsync(b->h_done, b->d_done.p, sizeof(int), hipMemcpyDeviceToHost, s));
     GFS_HIP(hipStreamSynchronize(s));
+    rounds_run++;
     if (b->h_done[0] >= n) break;
     if (force_end) {
       stopped = true;
@@ -1679,19 +1888,16 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     }
   }
   (void)stopped;
+  const auto T3 = now();
   GFS_LAUNCH("kb_lba_finish", kb_lba_finish, dim3(n), dim3(64), 0, s, DD);
+  GFS_LAUNCH("kb_lba_pack", kb_lba_pack, dim3(8, n), dim3(kMk), 0, s, DD);
   std::vector<LbaFetch> F((size_t)n);
-  std::vector<int> info_cur((size_t)n, 0);
-  {  // which estimate buffer holds each window's result
-    for (int w = 0; w < n; w++) GFS_HIP(hipMemcpyAsync(b->h_cur.p + w, b->win[w]->d_info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    GFS_HIP(hipStreamSynchronize(s));
-    for (int w = 0; w < n; w++) info_cur[w] = b->h_cur.p[w];
-  }
   for (int w = 0; w < n; w++) {
-    const int rc = lba_fetch_issue(b->win[w], &problems[w], s, info_cur[w], F[w]);
+    const int rc = lba_fetch_issue(b->win[w], &problems[w], s, F[w]);
     if (rc) return rc;
   }
   GFS_HIP(hipStreamSynchronize(s));
+  const auto T4 = now();
   {
     const int nthreads = std::max(1, std::min(n, std::min(32, (int)std::thread::hardware_concurrency())));
     std::vector<std::thread> th;
@@ -1701,6 +1907,9 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
       });
     for (auto& x : th) x.join();
   }
+  if (timing)
+    fprintf(stderr, "gfs_lba_solve_batch(%d): prepare %.2f, upload %.2f, %d rounds %.2f, download %.2f, scatter %.2f ms\n", n, ms(T0, T1),
+            ms(T1, T2), rounds_run, ms(T2, T3), ms(T3, T4), ms(T4, now()));
   return GFS_OK;
 }
 
