@@ -94,6 +94,7 @@ struct LbaDev {
   double* schur_part;
   double* schur_part_b;
   int n_schur_chunks, n_pair_tiles, schur_sub;  // chunks of kSchurPts landmarks; tiles of kMk pose pairs; landmarks staged at a time
+  int schur_mfma;  // 1: b_schur_mfma (n_schur_chunks chunks of kSchurMPts landmarks, n_pair_tiles = 128 x 128 blocks of the lower triangle)
 };
 
 using namespace gfs_se3;
@@ -893,6 +894,218 @@ __device__ __forceinline__ void b_schur_chunks(const LbaDev& D, const int bx) {
 }
 __global__ __launch_bounds__(kMk) void k_lba_schur_chunks(LbaDev D) { b_schur_chunks(D, blockIdx.x); }
 
+// ---- the same sum on the matrix cores.  With W_l (6F x 3: the blocks B_f of landmark l stacked, zero where pose f does not see
+// it) the Schur sum over landmarks is  S = sum_l (W_l Dinv_l) W_l^T = [WD_1 WD_2 ...] [W_1 W_2 ...]^T : one (6F x 3L)(3L x 6F)
+// product, double precision, v_mfma_f64_16x16x4_f64.  The right-hand side rides along as one more row: row n = 6F of WD holds
+// Dinv_l b_l, so that S[n][c] = sum_l B_c Dinv_l b_l.  A workgroup takes a chunk of kSchurMPts landmarks and one 128 x 128 block
+// (bi >= bj) of S: kSchurSub landmarks (24 columns = 6 k-steps, nothing padded) are staged at a time in LDS, column-major with a
+// row stride of 144 doubles (the four k-groups of a fragment read land in disjoint bank halves), each of the 4 waves owns a share
+// of the block's 16 x 16 tiles and keeps them in registers across the chunk (diagonal block: tile rows w and 7 - w of the lower
+// triangle, 9 tiles a wave; off-diagonal: rows 2w, 2w + 1, 16 tiles).  The edges of a run of landmarks are contiguous
+// (landmark-major order), so the staging threads read e_pose / e_point / Hpl of edge e0 + tid directly, one sub-batch ahead of the
+// products.  Per-chunk partial blocks go to HBM ([chunk][row][col], leading dimension 128 NB) and b_schur_reduce adds them in
+// chunk order.  Operands are products of single roundings (fused multiply-add inside the matrix core), like b_schur_chunks.
+constexpr int kSchurMPts = 128;  // landmarks per workgroup
+constexpr int kSchurSub = 8;     // landmarks staged at a time
+constexpr int kSchurLd = 144;    // row stride (doubles) of a staged column
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <bool DIAG, int W>
+__device__ __forceinline__ void schur_mfma_ksteps(const double* __restrict__ s_a, const double* __restrict__ s_b, d4_t (&acc0)[8],
+                                                  d4_t (&acc1)[8]) {
+  constexpr int r0 = DIAG ? W : 2 * W, r1 = DIAG ? 7 - W : 2 * W + 1;
+  constexpr int nc0 = DIAG ? r0 + 1 : 8, nc1 = DIAG ? r1 + 1 : 8;
+  const int lane = threadIdx.x & 63, row = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 3 * kSchurSub / 4; ks++) {
+    const double* ca = s_a + (4 * ks + kk) * kSchurLd + row;
+    const double* cb = s_b + (4 * ks + kk) * kSchurLd + row;
+    const double a0 = ca[16 * r0], a1 = ca[16 * r1];
+    double b[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+      if (c < nc1 || c < nc0) b[c] = cb[16 * c];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      if (c < nc0) acc0[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[c], acc0[c], 0, 0, 0);
+      if (c < nc1) acc1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[c], acc1[c], 0, 0, 0);
+    }
+  }
+}
+
+template <bool DIAG, int W>
+__device__ __forceinline__ void schur_mfma_store(double* __restrict__ out, int ld, const d4_t (&acc0)[8], const d4_t (&acc1)[8]) {
+  constexpr int r0 = DIAG ? W : 2 * W, r1 = DIAG ? 7 - W : 2 * W + 1;
+  constexpr int nc0 = DIAG ? r0 + 1 : 8, nc1 = DIAG ? r1 + 1 : 8;
+  const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (c < nc0) out[(size_t)(16 * r0 + rq + 4 * i) * ld + 16 * c + col] = acc0[c][i];
+      if (c < nc1) out[(size_t)(16 * r1 + rq + 4 * i) * ld + 16 * c + col] = acc1[c][i];
+    }
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the vector-memory counter, i.e. it
+// would wait for the global loads of the NEXT sub-batch that are meant to stay in flight across the products
+#define GFS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <bool kOneBlock>
+__device__ __forceinline__ void b_schur_mfma(const LbaDev& D, const int bx) {
+  extern __shared__ __align__(16) double lds[];
+  const int F = D.n_free, NP = D.n_points, n = 6 * F;
+  const int NB = (n + 1 + 127) / 128, nbp = NB * (NB + 1) / 2, ld = 128 * NB;
+  const int chunk = bx / nbp, bp = bx - chunk * nbp;
+  int bi = (int)((sqrt(8.0 * bp + 1.0) - 1.0) * 0.5);
+  while (bi * (bi + 1) / 2 > bp) bi--;
+  while ((bi + 1) * (bi + 2) / 2 <= bp) bi++;
+  const int bj = bp - bi * (bi + 1) / 2;
+  double* s_a = lds;                                  // [24][kSchurLd]  rows of block bi of [WD; Dinv b]
+  double* s_b = s_a + 3 * kSchurSub * kSchurLd;       // [24][kSchurLd]  rows of block bj of W
+  double* s_dinv = s_b + 3 * kSchurSub * kSchurLd;    // [kSchurMPts][6]
+  double* s_v = s_dinv + 6 * kSchurMPts;              // [kSchurMPts][3]  Dinv_l b_l
+  int* s_ptb = (int*)(s_v + 3 * kSchurMPts);          // [kSchurMPts + 1]
+  int* s_free = s_ptb + kSchurMPts + 1;               // [n_poses]
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int l_begin = chunk * kSchurMPts, l_end = min(l_begin + kSchurMPts, NP), nlm = l_end - l_begin;
+  for (int i = tid; i < 6 * nlm; i += kMk) s_dinv[i] = D.Dinv[6 * (size_t)l_begin + i];
+  for (int i = tid; i <= nlm; i += kMk) s_ptb[i] = D.pt_begin[l_begin + i];
+  for (int i = tid; i < D.n_poses; i += kMk) s_free[i] = D.free_index[i];
+  __syncthreads();
+  for (int p = tid; p < nlm; p += kMk) {
+    const double* Di = s_dinv + 6 * p;
+    const double* bl = D.bl + 3 * (size_t)(l_begin + p);
+    const double b0 = bl[0], b1 = bl[1], b2 = bl[2];
+    s_v[3 * p] = fma(Di[2], b2, fma(Di[1], b1, Di[0] * b0));
+    s_v[3 * p + 1] = fma(Di[4], b2, fma(Di[3], b1, Di[1] * b0));
+    s_v[3 * p + 2] = fma(Di[5], b2, fma(Di[4], b1, Di[2] * b0));
+  }
+  d4_t acc0[8], acc1[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) acc0[c] = acc1[c] = d4_t{0, 0, 0, 0};
+  // edge prefetch registers (one edge per thread and pass; a sub-batch has at most kSchurSub * n_poses edges)
+  double Bn[18];
+  int pose_n = -1, lm_n = 0;
+  auto fetch = [&](int sb_l0, int pass) {
+    pose_n = -1;
+    if (sb_l0 >= l_end) return;
+    const int e0 = s_ptb[sb_l0 - l_begin], e1 = s_ptb[min(sb_l0 + kSchurSub, l_end) - l_begin];
+    const int e = e0 + pass * kMk + tid;
+    if (e < e1) {
+      pose_n = D.e_pose[e];
+      lm_n = D.e_point[e];
+      const double* B = D.Hpl + 18 * (size_t)e;
+#pragma unroll
+      for (int k = 0; k < 18; k++) Bn[k] = B[k];
+    }
+  };
+  const int a_lo = 128 * bi, b_lo = 128 * bj;
+  fetch(l_begin, 0);
+  for (int l0 = l_begin; l0 < l_end; l0 += kSchurSub) {
+    GFS_LDS_BARRIER();  // the previous sub-batch has been consumed (and s_v is complete the first time round)
+    for (int i = tid; i < 2 * 3 * kSchurSub * kSchurLd / 2; i += kMk) ((double2*)s_a)[i] = double2{0.0, 0.0};  // s_a and s_b are adjacent
+    GFS_LDS_BARRIER();
+    const int e0 = s_ptb[l0 - l_begin], e1 = s_ptb[min(l0 + kSchurSub, l_end) - l_begin];
+    const int npass = (e1 - e0 + kMk - 1) / kMk;
+    for (int pass = 0; pass < npass; pass++) {
+      if (pass > 0) fetch(l0, pass);
+      if (pose_n >= 0) {
+        const int f = s_free[pose_n], p = lm_n - l0;
+        if (f >= 0) {
+          const double* Di = s_dinv + 6 * (lm_n - l_begin);
+          const double d9[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+            const int rg = 6 * f + a;  // global row
+            const double b0 = Bn[3 * a], b1 = Bn[3 * a + 1], b2 = Bn[3 * a + 2];
+            if ((unsigned)(rg - b_lo) < 128u) {
+#pragma unroll
+              for (int k = 0; k < 3; k++) s_b[(3 * p + k) * kSchurLd + rg - b_lo] = Bn[3 * a + k];
+            }
+            if ((unsigned)(rg - a_lo) < 128u) {
+#pragma unroll
+              for (int k = 0; k < 3; k++) s_a[(3 * p + k) * kSchurLd + rg - a_lo] = fma(b2, d9[6 + k], fma(b1, d9[3 + k], b0 * d9[k]));
+            }
+          }
+        }
+      }
+    }
+    // the extra row: Dinv_l b_l at global row n
+    if ((unsigned)(n - a_lo) < 128u && tid < 3 * kSchurSub && l0 + tid / 3 < l_end)
+      s_a[tid * kSchurLd + n - a_lo] = s_v[3 * (l0 - l_begin) + tid];
+    fetch(l0 + kSchurSub, 0);  // the next sub-batch's edges travel while the products run
+    GFS_LDS_BARRIER();
+    if (kOneBlock || bi == bj) {
+      switch (wave) {
+        case 0: schur_mfma_ksteps<true, 0>(s_a, s_b, acc0, acc1); break;
+        case 1: schur_mfma_ksteps<true, 1>(s_a, s_b, acc0, acc1); break;
+        case 2: schur_mfma_ksteps<true, 2>(s_a, s_b, acc0, acc1); break;
+        default: schur_mfma_ksteps<true, 3>(s_a, s_b, acc0, acc1); break;
+      }
+    } else {
+      switch (wave) {
+        case 0: schur_mfma_ksteps<false, 0>(s_a, s_b, acc0, acc1); break;
+        case 1: schur_mfma_ksteps<false, 1>(s_a, s_b, acc0, acc1); break;
+        case 2: schur_mfma_ksteps<false, 2>(s_a, s_b, acc0, acc1); break;
+        default: schur_mfma_ksteps<false, 3>(s_a, s_b, acc0, acc1); break;
+      }
+    }
+  }
+  double* out = D.schur_part + (size_t)chunk * ld * ld + (size_t)a_lo * ld + b_lo;
+  if (kOneBlock || bi == bj) {
+    switch (wave) {
+      case 0: schur_mfma_store<true, 0>(out, ld, acc0, acc1); break;
+      case 1: schur_mfma_store<true, 1>(out, ld, acc0, acc1); break;
+      case 2: schur_mfma_store<true, 2>(out, ld, acc0, acc1); break;
+      default: schur_mfma_store<true, 3>(out, ld, acc0, acc1); break;
+    }
+  } else {
+    switch (wave) {
+      case 0: schur_mfma_store<false, 0>(out, ld, acc0, acc1); break;
+      case 1: schur_mfma_store<false, 1>(out, ld, acc0, acc1); break;
+      case 2: schur_mfma_store<false, 2>(out, ld, acc0, acc1); break;
+      default: schur_mfma_store<false, 3>(out, ld, acc0, acc1); break;
+    }
+  }
+}
+template <bool kOneBlock>
+__global__ __launch_bounds__(kMk, kOneBlock ? 2 : 1) void k_lba_schur_mfma(LbaDev D) {
+  b_schur_mfma<kOneBlock>(D, blockIdx.x);
+}
+
+// the reduction for b_schur_mfma's partial blocks: Hs entry (r, c), r >= c, and bs[c] = bp[c] - S[n][c]
+__device__ __forceinline__ void b_schur_reduce_mfma(const LbaDev& D, const int bx) {
+  const int F = D.n_free, n = 6 * F, ntri = n * (n + 1) / 2;
+  const int NB = (n + 1 + 127) / 128, ld = 128 * NB;
+  const int k = bx * kMk + threadIdx.x;
+  if (k >= ntri + n) return;
+  int r, c;
+  if (k < ntri) {
+    r = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > k) r--;
+    while ((r + 1) * (r + 2) / 2 <= k) r++;
+    c = k - r * (r + 1) / 2;
+  } else {
+    r = n;
+    c = k - ntri;
+  }
+  const double* part = D.schur_part + (size_t)r * ld + c;
+  double sum = 0;
+  for (int ch = 0; ch < D.n_schur_chunks; ch++) sum += part[(size_t)ch * ld * ld];
+  if (k >= ntri) {
+    D.bs[c] = D.bp[c] - sum;
+  } else {
+    const int i1 = r / 6, a = r - 6 * i1, i2 = c / 6, cc = c - 6 * i2;
+    if (i1 != i2) {
+      D.Hs[k] = -sum;
+    } else {
+      const double hpp = D.Hpp[21 * i1 + (cc * 6 - cc * (cc - 1) / 2 + (a - cc))];
+      D.Hs[k] = hpp + (a == cc ? D.S->lambda : 0.0) - sum;
+    }
+  }
+}
+__global__ __launch_bounds__(kMk) void k_lba_schur_reduce_mfma(LbaDev D) { b_schur_reduce_mfma(D, blockIdx.x); }
+
 // Hs = [diagonal block](Hpp + lambda I) - sum over chunks (in chunk order), bs = bp - sum: one thread per entry of the packed
 // lower triangle, then one per entry of the right-hand side
 __device__ __forceinline__ void b_schur_reduce(const LbaDev& D, const int bx) {
@@ -1238,7 +1451,7 @@ __global__ __launch_bounds__(kMk) void kb_lba_dinv(const LbaDev* __restrict__ DD
   b_dinv(D, blockIdx.x, need);
 }
 __global__ __launch_bounds__(kMk) void kb_lba_schur(const LbaDev* __restrict__ DD) {
-  GFS_LBAB_PROLOGUE(1, D.schur_sub ? 0 : D.n_free * (D.n_free + 1) / 2)
+  GFS_LBAB_PROLOGUE(1, (D.schur_sub || D.schur_mfma) ? 0 : D.n_free * (D.n_free + 1) / 2)
   b_schur(D, blockIdx.x, need);
 }
 __global__ __launch_bounds__(kMk) void kb_lba_schur_chunks(const LbaDev* __restrict__ DD) {
@@ -1248,6 +1461,15 @@ __global__ __launch_bounds__(kMk) void kb_lba_schur_chunks(const LbaDev* __restr
 __global__ __launch_bounds__(kMk) void kb_lba_schur_reduce(const LbaDev* __restrict__ DD) {
   GFS_LBAB_PROLOGUE(1, D.schur_sub ? (6 * D.n_free * (6 * D.n_free + 1) / 2 + 6 * D.n_free + kMk - 1) / kMk : 0)
   b_schur_reduce(D, blockIdx.x);
+}
+template <bool kOneBlock>
+__global__ __launch_bounds__(kMk, kOneBlock ? 2 : 1) void kb_lba_schur_mfma(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, D.schur_mfma ? D.n_schur_chunks * D.n_pair_tiles : 0)
+  b_schur_mfma<kOneBlock>(D, blockIdx.x);
+}
+__global__ __launch_bounds__(kMk) void kb_lba_schur_reduce_mfma(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(1, D.schur_mfma ? (6 * D.n_free * (6 * D.n_free + 1) / 2 + 6 * D.n_free + kMk - 1) / kMk : 0)
+  b_schur_reduce_mfma(D, blockIdx.x);
 }
 template <bool kLds>
 __global__ __launch_bounds__(kThreads) void kb_lba_solve(const LbaDev* __restrict__ DD) {
@@ -1474,16 +1696,35 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
   D.bs = h->d_bs.p;
   D.n_err_blocks = gfs::div_up(std::max(E, 1), kMk);
   D.n_upd_blocks = gfs::div_up(std::max(NP, 1), kMk);
-  // Schur products by landmark chunks (b_schur_chunks); windows too wide for its LDS staging keep the pair-per-workgroup kernel
+  // Schur products: on the matrix cores by landmark chunks (b_schur_mfma), GFS_LBA_SCHUR=chunks | pairs select the vector kernels
+  // (b_schur_chunks; one workgroup per pose pair, which also takes the windows too wide for the others' staging)
   {
     const int F = P.n_free;
-    const size_t per_landmark = (size_t)F * (kSchurSlot * sizeof(double) + sizeof(int)) + 4 * sizeof(double);
-    const int sub = F > 0 ? (int)std::min<size_t>(8, (96 * 1024) / per_landmark) : 0;
-    const size_t npairs = (size_t)F * (F + 1) / 2, chunks = gfs::div_up(std::max(NP, 1), kSchurPts);
-    const size_t need = chunks * npairs * 36, need_b = chunks * (size_t)F * 6;
-    static const bool by_pairs = getenv("GFS_LBA_SCHUR") && !strcmp(getenv("GFS_LBA_SCHUR"), "pairs");
-    D.schur_sub = (sub >= 1 && need * sizeof(double) <= ((size_t)1 << 30) && !by_pairs) ? sub : 0;
-    if (D.schur_sub) {
+    static const char* mode = getenv("GFS_LBA_SCHUR");
+    static const bool by_pairs = mode && !strcmp(mode, "pairs"), by_chunks = mode && !strcmp(mode, "chunks");
+    size_t need = 0, need_b = 0;
+    if (F > 0 && !by_pairs && !by_chunks) {
+      const size_t NB = (6 * (size_t)F + 1 + 127) / 128, ld = 128 * NB, chunks = gfs::div_up(std::max(NP, 1), kSchurMPts);
+      need = chunks * ld * ld;
+      if (need * sizeof(double) <= ((size_t)2 << 30) && p->n_poses <= 4096) {
+        D.schur_mfma = 1;
+        D.n_schur_chunks = (int)chunks;
+        D.n_pair_tiles = (int)(NB * (NB + 1) / 2);
+      }
+    }
+    if (F > 0 && !by_pairs && !D.schur_mfma) {
+      const size_t per_landmark = (size_t)F * (kSchurSlot * sizeof(double) + sizeof(int)) + 4 * sizeof(double);
+      const int sub = (int)std::min<size_t>(8, (96 * 1024) / per_landmark);
+      const size_t npairs = (size_t)F * (F + 1) / 2, chunks = gfs::div_up(std::max(NP, 1), kSchurPts);
+      need = chunks * npairs * 36;
+      need_b = chunks * (size_t)F * 6;
+      if (sub >= 1 && need * sizeof(double) <= ((size_t)1 << 30)) {
+        D.schur_sub = sub;
+        D.n_schur_chunks = (int)chunks;
+        D.n_pair_tiles = (int)gfs::div_up((int)npairs, kMk);
+      }
+    }
+    if (D.schur_sub || D.schur_mfma) {
       if (h->d_schur_part.n < need) {
         GFS_HIP(hipStreamSynchronize(s));
         if ((rc = h->d_schur_part.alloc(need + need / 4))) return rc;
@@ -1494,13 +1735,14 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
       }
       D.schur_part = h->d_schur_part.p;
       D.schur_part_b = h->d_schur_part_b.p;
-      D.n_schur_chunks = (int)chunks;
-      D.n_pair_tiles = (int)gfs::div_up((int)npairs, kMk);
     }
   }
   return GFS_OK;
 }
 
+inline size_t schur_mfma_lds_bytes(const LbaDev& D) {
+  return (size_t)(2 * 3 * kSchurSub * kSchurLd + 9 * kSchurMPts) * sizeof(double) + (size_t)(kSchurMPts + 1 + D.n_poses) * sizeof(int);
+}
 inline size_t schur_lds_bytes(const LbaDev& D) {
   return (size_t)D.schur_sub * ((size_t)D.n_free * (kSchurSlot * sizeof(double) + sizeof(int)) + 4 * sizeof(double));
 }
@@ -1541,6 +1783,9 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (D.schur_sub)
     GFS_HIP(hipFuncSetAttribute((const void*)k_lba_schur_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds_bytes(D)));
+  if (D.schur_mfma)
+    GFS_HIP(hipFuncSetAttribute(D.n_pair_tiles == 1 ? (const void*)k_lba_schur_mfma<true> : (const void*)k_lba_schur_mfma<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_mfma_lds_bytes(D)));
   const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 8)), g_upd(D.n_upd_blocks);
   GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
   const bool lin_only = mode == 1 || p->iterations <= 0;
@@ -1567,7 +1812,13 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
     bool terminate = false;
     for (;;) {
       GFS_LAUNCH("k_lba_dinv", k_lba_dinv, g_upd, dim3(kMk), 0, s, D);
-      if (npairs > 0 && D.schur_sub) {
+      if (npairs > 0 && D.schur_mfma) {
+        if (D.n_pair_tiles == 1)
+          GFS_LAUNCH("k_lba_schur_mfma", k_lba_schur_mfma<true>, dim3(D.n_schur_chunks), dim3(kMk), schur_mfma_lds_bytes(D), s, D);
+        else
+          GFS_LAUNCH("k_lba_schur_mfma", k_lba_schur_mfma<false>, dim3(D.n_schur_chunks * D.n_pair_tiles), dim3(kMk), schur_mfma_lds_bytes(D), s, D);
+        GFS_LAUNCH("k_lba_schur_reduce", k_lba_schur_reduce_mfma, dim3(gfs::div_up(n * (n + 1) / 2 + n, kMk)), dim3(kMk), 0, s, D);
+      } else if (npairs > 0 && D.schur_sub) {
         GFS_LAUNCH("k_lba_schur_chunks", k_lba_schur_chunks, dim3(D.n_schur_chunks * D.n_pair_tiles), dim3(kMk), schur_lds_bytes(D), s, D);
         GFS_LAUNCH("k_lba_schur_reduce", k_lba_schur_reduce, dim3(gfs::div_up(n * (n + 1) / 2 + n, kMk)), dim3(kMk), 0, s, D);
       } else if (npairs > 0) {
@@ -1822,7 +2073,9 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     if (rcs[w]) return rcs[w];
   const auto T1 = now();
   int max_free = 0, max_err = 1, max_upd = 1, max_lm = 1, max_iter = 0, max_chunk_blocks = 0, max_pair_blocks = 0;
-  size_t schur_lds = 0;
+  size_t schur_lds = 0, mfma_lds = 0;
+  int max_mfma_blocks = 0;
+  bool one_block = true;
   for (int w = 0; w < n; w++) {
     LbaDev D;
     const int rc = upload_and_fill(b->win[w], &problems[w], b->prep[w], 0, s, D, false);
@@ -1835,7 +2088,11 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     max_upd = std::max(max_upd, D.n_upd_blocks);
     max_lm = std::max(max_lm, gfs::div_up(std::max(D.n_points, 1), 8));
     max_iter = std::max(max_iter, problems[w].iterations);
-    if (D.schur_sub) {
+    if (D.schur_mfma) {
+      max_mfma_blocks = std::max(max_mfma_blocks, D.n_schur_chunks * D.n_pair_tiles);
+      one_block = one_block && D.n_pair_tiles == 1;
+      mfma_lds = std::max(mfma_lds, schur_mfma_lds_bytes(D));
+    } else if (D.schur_sub) {
       max_chunk_blocks = std::max(max_chunk_blocks, D.n_schur_chunks * D.n_pair_tiles);
       schur_lds = std::max(schur_lds, schur_lds_bytes(D));
     } else {
@@ -1844,6 +2101,9 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   }
   if (schur_lds)
     GFS_HIP(hipFuncSetAttribute((const void*)kb_lba_schur_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
+  if (mfma_lds)
+    GFS_HIP(hipFuncSetAttribute(one_block ? (const void*)kb_lba_schur_mfma<true> : (const void*)kb_lba_schur_mfma<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
   GFS_HIP(hipMemcpyAsync(b->d_desc.p, b->h_desc.p, (size_t)n * sizeof(LbaDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(b->d_done.p, 0, sizeof(int), s));
   const int nmax = 6 * max_free;
@@ -1865,6 +2125,13 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     if (max_free > 0) GFS_LAUNCH("kb_lba_build_poses", kb_lba_build_poses, dim3(max_free, n), dim3(kMk), 0, s, DD);
     GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD);
     GFS_LAUNCH("kb_lba_dinv", kb_lba_dinv, dim3(max_upd, n), dim3(kMk), 0, s, DD);
+    if (max_mfma_blocks > 0) {
+      if (one_block)
+        GFS_LAUNCH("kb_lba_schur_mfma", kb_lba_schur_mfma<true>, dim3(max_mfma_blocks, n), dim3(kMk), mfma_lds, s, DD);
+      else
+        GFS_LAUNCH("kb_lba_schur_mfma", kb_lba_schur_mfma<false>, dim3(max_mfma_blocks, n), dim3(kMk), mfma_lds, s, DD);
+      GFS_LAUNCH("kb_lba_schur_reduce", kb_lba_schur_reduce_mfma, dim3(gfs::div_up(nmax * (nmax + 1) / 2 + nmax, kMk), n), dim3(kMk), 0, s, DD);
+    }
     if (max_chunk_blocks > 0) {
       GFS_LAUNCH("kb_lba_schur_chunks", kb_lba_schur_chunks, dim3(max_chunk_blocks, n), dim3(kMk), schur_lds, s, DD);
       GFS_LAUNCH("kb_lba_schur_reduce", kb_lba_schur_reduce, dim3(gfs::div_up(nmax * (nmax + 1) / 2 + nmax, kMk), n), dim3(kMk), 0, s, DD);
