@@ -545,9 +545,7 @@ def main():
                                 algorithmic_bytes_per_build=int(lba_bytes), builds=int(nbuild), avg_build_us=round(build_ms / nbuild * 1e3, 2),
                                 kernels_ms_per_window={k: round(v[0], 4) for k, v in sorted(lrep.items(), key=lambda kv: -kv[1][0]) if "lba" in k},
                                 note="one window = one workgroup-chain: launch-latency bound, see DESIGN.md")
-            # ... and 64 independent windows solved together (gfs_lba_solve_batch: replicas, the LBA of one map does not shard):
-            # one handle called back to back, and two handles on two host threads (the host preparation / scatter of one batch
-            # overlaps the device work of the other, the way a server with several maps would run it)
+            # ... and 64 independent windows solved together (gfs_lba_solve_batch: replicas, the LBA of one map does not shard)
             lba_batch = None
             try:
                 import threading
@@ -555,33 +553,43 @@ def main():
                 wl = [synth.lba_window(k, n_free=20, n_fixed=5, n_points=3000) for k in range(ND)]
                 wl = [wl[k % ND] for k in range(NW)]
                 bat = api.BatchOptimizer(max_windows=NW, max_poses=32, max_points=4096, max_edges=65536, device=local_rank)
-                Pb, Sb, _, keep_b = bat.prepare(wl)
+                Pb, Sb, outs_b, keep_b = bat.prepare(wl)  # (the result arrays must outlive the calls)
                 bat.solve_prepared(Pb, Sb, NW)
                 t1 = time.perf_counter()
                 for _ in range(3):
                     bat.solve_prepared(Pb, Sb, NW)
                 dtb = (time.perf_counter() - t1) / 3
-                bat2 = api.BatchOptimizer(max_windows=NW, max_poses=32, max_points=4096, max_edges=65536, device=local_rank)
-                Pb2, Sb2, _, keep_b2 = bat2.prepare(wl[::-1])
-                bat2.solve_prepared(Pb2, Sb2, NW)
-                reps = 4
-
-                def _loop(bt, P_, S_):
-                    for _ in range(reps):
+                # several handles on as many host threads: the host preparation / scatter of one batch overlaps the device work of the
+                # others (a server with several maps)
+                hs = [(bat, Pb, Sb, keep_b)]
+                flight = {}
+                for NH in (2, 4):
+                    while len(hs) < NH:
+                        bt = api.BatchOptimizer(max_windows=NW, max_poses=32, max_points=4096, max_edges=65536, device=local_rank)
+                        k0 = len(hs)
+                        P_, S_, _o, keep_ = bt.prepare(wl[k0:] + wl[:k0])
                         bt.solve_prepared(P_, S_, NW)
+                        hs.append((bt, P_, S_, keep_))
+                    reps = 4
 
-                th = [threading.Thread(target=_loop, args=a) for a in ((bat, Pb, Sb), (bat2, Pb2, Sb2))]
-                t1 = time.perf_counter()
-                for t_ in th:
-                    t_.start()
-                for t_ in th:
-                    t_.join()
-                dt2 = time.perf_counter() - t1
-                lba_batch = dict(value=round(2 * reps * NW / dt2, 1), unit="windows/s", windows=NW, handles_in_flight=2, distinct_windows=ND,
+                    def _loop(bt, P_, S_, keep_):
+                        for _ in range(reps):
+                            bt.solve_prepared(P_, S_, NW)
+
+                    th = [threading.Thread(target=_loop, args=a) for a in hs[:NH]]
+                    t1 = time.perf_counter()
+                    for t_ in th:
+                        t_.start()
+                    for t_ in th:
+                        t_.join()
+                    flight[NH] = round(NH * reps * NW / (time.perf_counter() - t1), 1)
+                lba_batch = dict(value=flight[4], unit="windows/s", windows=NW, handles_in_flight=4, distinct_windows=ND,
+                                 two_handles=dict(value=flight[2], unit="windows/s"),
                                  one_handle=dict(value=round(NW / dtb, 1), unit="windows/s", ms_per_batch=round(dtb * 1e3, 2)),
                                  note="host preparation, upload, solve and download of 64 windows per call, every call included; per window "
                                       "bit-identical to gfs_lba_solve")
-                bat2.close()
+                for h_ in hs[1:]:
+                    h_[0].close()
                 bat.close()
             except Exception as e:
                 lba_batch = dict(error=f"{type(e).__name__}: {e}")

@@ -694,6 +694,7 @@ class BatchOptimizer:
             for name, v in out.items():
                 setattr(S[k], name, v.ctypes.data)
             outs.append(out)
+        keep.append(outs)  # S points into these arrays: whoever holds `keep` keeps them alive
         return P, S, outs, keep
 
     def solve_prepared(self, P, S, n, stop_flag=None):

@@ -2057,7 +2057,8 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   // ---- host preparation of every window (edge re-ordering, CSR tables), on a few threads
   std::vector<int> rcs((size_t)n, 0);
   {
-    const int nthreads = std::max(1, std::min(n, std::min(32, (int)std::thread::hardware_concurrency())));
+    static const int cap = getenv("GFS_LBA_THREADS") ? atoi(getenv("GFS_LBA_THREADS")) : 32;
+    const int nthreads = std::max(1, std::min(n, std::min(cap, (int)std::thread::hardware_concurrency())));
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++)
       th.emplace_back([&, t]() {
