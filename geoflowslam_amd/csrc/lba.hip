@@ -58,7 +58,8 @@ struct LbaDev {
   const int* pt_begin;     // [n_points+1]
   const int* pose_begin;   // [n_free+1]
   const int* pose_edges;   // edge ids (landmark-major numbering), ascending, per free pose
-  const int* edge_of;      // [n_free][n_points] edge id or -1
+  const int* edge_of;      // [n_free][n_points] edge id or -1 (the FIRST edge of a (pose, landmark) pair)
+  const int* e_dup;        // [n_edges] first edge of the same (pose, landmark) pair, -1 for a first edge; NULL: no duplicates
   double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
   int iterations;
   // state / workspace
@@ -651,6 +652,25 @@ __device__ __forceinline__ void b_build_landmarks(const LbaDev& D, const int bx,
     for (int k = 0; k < 6; k++) D.Hll[6 * (size_t)l + k] = acc[k];
     for (int k = 0; k < 3; k++) D.bl[3 * (size_t)l + k] = acc[6 + k];
   }
+  // several edges between one pose and one landmark (a rig seeing the point with two cameras): g2o adds their J_pose^T Omega J_point
+  // into the one Hpl block of that vertex pair (core/block_solver.hpp:143-295 allocates it once).  The first edge's block takes
+  // the sum, in edge order, and the later ones are cleared: everything downstream (Schur products, back-substitution) sums over
+  // edges.  gfs_lba_linearize (mode 1) reports the per-edge blocks instead.
+  if (D.e_dup && D.mode == 0) {
+    __threadfence_block();
+    if (live && gl == 0) {
+      for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
+        const int first = D.e_dup[e];
+        if (first < 0 || D.free_index[D.e_pose[e]] < 0) continue;
+        double* B = D.Hpl + 18 * (size_t)e;
+        double* A = D.Hpl + 18 * (size_t)first;
+        for (int k = 0; k < 18; k++) {
+          A[k] += B[k];
+          B[k] = 0;
+        }
+      }
+    }
+  }
 }
 __global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) { b_build_landmarks(D, blockIdx.x, gridDim.x); }
 
@@ -991,7 +1011,7 @@ __device__ __forceinline__ void b_schur_mfma(const LbaDev& D, const int bx) {
     if (sb_l0 >= l_end) return;
     const int e0 = s_ptb[sb_l0 - l_begin], e1 = s_ptb[min(sb_l0 + kSchurSub, l_end) - l_begin];
     const int e = e0 + pass * kMk + tid;
-    if (e < e1) {
+    if (e < e1 && !(D.e_dup && D.e_dup[e] >= 0)) {  // (a duplicate's block has been added to its first edge's)
       pose_n = D.e_pose[e];
       lm_n = D.e_point[e];
       const double* B = D.Hpl + 18 * (size_t)e;
@@ -1538,6 +1558,7 @@ struct HostPrep {
   int *free_index = nullptr, *free_pose = nullptr, *e_pose = nullptr, *e_point = nullptr, *pt_begin = nullptr, *pose_begin = nullptr,
       *pose_edges = nullptr, *edge_of = nullptr;
   unsigned char* stereo = nullptr;
+  int* e_dup = nullptr;  // NULL when the window has no duplicate (pose, landmark) edges
   size_t used = 0;  // bytes of the arena in use
 };
 
@@ -1572,9 +1593,11 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
     P.pose_edges = (int*)take((size_t)E * 4);
     P.edge_of = (int*)take((size_t)nf * NP * 4);
     P.stereo = take((size_t)E);
-    P.used = at;
+    P.used = at;  // (grows by the duplicate table below when the window has any)
+    P.e_dup = (int*)take((size_t)E * 4);
     GFS_REQUIRE(at <= h->h_stage.n, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
   }
+  bool any_dup = false;
   if (NQ) memcpy(P.q0, p->pose_q, (size_t)NQ * 32);
   if (NQ) memcpy(P.t0, p->pose_t, (size_t)NQ * 24);
   if (NP) memcpy(P.X0, p->points, (size_t)NP * 24);
@@ -1608,13 +1631,22 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
     P.w[k] = p->edge_inv_sigma2[e];
     P.stereo[k] = p->edge_stereo[e] ? 1 : 0;
     const int f = P.free_index[P.e_pose[k]];
+    P.e_dup[k] = -1;
     if (f >= 0) {
       P.pose_begin[f + 1]++;
-      GFS_REQUIRE(P.edge_of[(size_t)f * NP + P.e_point[k]] < 0, GFS_ERR_UNSUPPORTED,
-                  "gfs_lba: more than one edge between pose %d and point %d", P.e_pose[k], P.e_point[k]);
-      P.edge_of[(size_t)f * NP + P.e_point[k]] = k;
+      int& slot = P.edge_of[(size_t)f * NP + P.e_point[k]];
+      if (slot < 0) {
+        slot = k;
+      } else {  // a second edge between this pose and this landmark
+        P.e_dup[k] = slot;
+        any_dup = true;
+      }
     }
   }
+  if (any_dup)
+    P.used = (size_t)((unsigned char*)(P.e_dup + E) - h->h_stage.p);
+  else
+    P.e_dup = nullptr;
   for (int f = 0; f < P.n_free; f++) P.pose_begin[f + 1] += P.pose_begin[f];
   {
     std::vector<int> pos(P.pose_begin, P.pose_begin + P.n_free);
@@ -1653,6 +1685,7 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
   D.pose_edges = (const int*)dev(P.pose_edges);
   D.edge_of = (const int*)dev(P.edge_of);
   D.e_stereo = (const unsigned char*)dev(P.stereo);
+  D.e_dup = P.e_dup ? (const int*)dev(P.e_dup) : nullptr;
   D.n_poses = p->n_poses;
   D.n_points = NP;
   D.n_edges = E;
@@ -1760,6 +1793,7 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   static const bool single_wg = getenv("GFS_LBA_SINGLE_WG") != nullptr;  // the round-1a kernel: whole solve in one workgroup
   h->last_desc = D;
   if (single_wg && in_lds) {
+    GFS_REQUIRE(!D.e_dup, GFS_ERR_UNSUPPORTED, "gfs_lba: GFS_LBA_SINGLE_WG does not take several edges between one pose and one point");
     GFS_HIP(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (E) GFS_HIP(hipMemsetAsync(h->d_Hpl.p, 0, (size_t)E * 18 * sizeof(double), s));
     GFS_LAUNCH("k_lba", k_lba, dim3(1), dim3(kThreads), lds, s, D);
@@ -1890,7 +1924,7 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   A(h->d_stats.alloc(2));
   A(h->d_info.alloc(2));
   A(h->d_state.alloc(1));
-  A(h->h_stage.alloc(NQ * (32 + 24 + 4) + NP * (24 + 4) + E * (4 + 4 + 24 + 8 + 1 + 4) + F * (4 + 4 + NP * 4) + 4096));
+  A(h->h_stage.alloc(NQ * (32 + 24 + 4) + NP * (24 + 4) + E * (4 + 4 + 24 + 8 + 1 + 4 + 4) + F * (4 + 4 + NP * 4) + 4096));
   A(h->d_in.alloc(h->h_stage.n));
   A(h->d_out.alloc(E + 7 * NQ + 3 * NP + 4));
   A(h->h_out.alloc(E + 7 * NQ + 3 * NP + 4));

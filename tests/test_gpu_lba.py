@@ -96,6 +96,46 @@ def test_stop_flag_raised_while_solving(gpu_api, oracle):
         assert r["final_chi2"] <= chi0 * (1 + 1e-12)
 
 
+def _with_second_camera_edges(w, seed, frac=0.15):
+    """the window with a second edge between some (key-frame, point) pairs, the way a two-camera rig adds a right-camera
+    observation of a point the left camera sees too (src/Optimizer.cc:1859-1925): a monocular observation ~0.7 px away"""
+    rng = np.random.default_rng(seed)
+    E = w["n_edges"]
+    pick = np.sort(rng.choice(E, int(frac * E), replace=False))
+    w2 = dict(w)
+    obs2 = w["edge_obs"][pick].copy()
+    obs2[:, :2] += rng.normal(0, 0.7, (len(pick), 2))
+    obs2[:, 2] = 0
+    # point-major order like the reference builds it: the second edge right after the first
+    order = np.argsort(np.r_[np.arange(E), pick + 0.5], kind="stable")
+    for k, extra in (("edge_pose", w["edge_pose"][pick]), ("edge_point", w["edge_point"][pick]), ("edge_obs", obs2),
+                     ("edge_inv_sigma2", w["edge_inv_sigma2"][pick]), ("edge_stereo", np.zeros(len(pick), w["edge_stereo"].dtype))):
+        w2[k] = np.ascontiguousarray(np.concatenate([w[k], extra])[order])
+    w2["n_edges"] = E + len(pick)
+    return w2
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=11, n_free=20, n_fixed=5, n_points=3000), dict(seed=12, n_free=6, n_fixed=2, n_points=300),
+                                 dict(seed=13, n_free=30, n_fixed=3, n_points=500)])
+def test_several_edges_between_one_pose_and_one_point(gpu_api, oracle, cfg):
+    """g2o takes any number of edges between two vertices (their Hpl contributions share one block,
+    Thirdparty/g2o/g2o/core/block_solver.hpp:143-295): blocks, solution and flags against the oracle; alone and in a batch."""
+    w = _with_second_camera_edges(synth.lba_window(**cfg), cfg["seed"])
+    opt = gpu_api.Optimizer(max_poses=64, max_points=4096, max_edges=100000)
+    L, Lo = opt.linearize(w), oracle.lba_linearize(w)
+    for k in ("Hpp", "Hll", "Hpl", "bp", "bl", "edge_chi2"):
+        assert _rel(L[k], Lo[k]) < 1e-10, (k, _rel(L[k], Lo[k]))
+    r, ro = opt.LocalBundleAdjustment(w), oracle.lba_solve(w)
+    assert r["iterations_run"] == ro["iterations_run"]
+    assert _rel(r["pose_q"], ro["pose_q"]) < 1e-5 and _rel(r["pose_t"], ro["pose_t"]) < 1e-5 and _rel(r["points"], ro["points"]) < 1e-5
+    assert _rel(r["final_chi2"], ro["final_chi2"]) < 1e-6
+    assert (r["edge_depth_positive"] == ro["edge_depth_positive"]).all()
+    bat = gpu_api.BatchOptimizer(max_windows=2, max_poses=64, max_points=4096, max_edges=100000)
+    rb = bat.LocalBundleAdjustment([w, synth.lba_window(1, n_free=8, n_fixed=3, n_points=600)])[0]
+    for k in ("pose_q", "pose_t", "points", "edge_chi2"):
+        assert np.array_equal(rb[k], r[k]), k
+
+
 def test_lba_batched_windows_match_oracle_and_single(gpu_api, oracle):
     """gfs_lba_solve_batch: windows of different sizes (3 ... 20 free key-frames, 80 ... 3000 points, different iteration
     counts and numbers of rejected trials) solved together; every window against the oracle and, bit for bit, against the same
