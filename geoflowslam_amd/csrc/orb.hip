@@ -401,10 +401,12 @@ __global__ __launch_bounds__(256) void k_cand_pack(const LevelDev* __restrict__ 
 //     a replica of libstdc++'s std::sort on one lane (tie order matters), evaluates all candidate splits in parallel,
 //     finds the break index with a scan and applies the prefix.
 //   * finally the first maximum-response key of every node is emitted in list order (:751-765).
-// Keys stay in global memory (L2-resident permutation ping-pong), the node arrays live in LDS.
+// Keys stay in global memory (a ping-pong pair of key arrays in list order: every thread walks a contiguous piece, served by
+// L1 / L2), the node arrays live in LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int kOctThreads = 256;
 constexpr int kOctMaxNodes = 768;
+inline size_t oct_lds_bytes(int node_cap) { return (size_t)node_cap * (2 * 16 + 2 * 16 + 8 + 2 * 8 + 8 + 1) + 16; }
 
 struct ONode {
   short x0, x1, y0, y1;
@@ -498,14 +500,21 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
                                                         size_t cand_frame, uint32_t* __restrict__ perm0,
                                                         uint32_t* __restrict__ perm1, unsigned short* __restrict__ seg0,
                                                         unsigned short* __restrict__ seg1, const int* __restrict__ kept_off,
-                                                        int kp_cap, uint32_t* __restrict__ kept, int* __restrict__ kept_cnt) {
-  __shared__ ONode s_nodes[2][kOctMaxNodes];
-  __shared__ U128 s_start[kOctMaxNodes], s_end[kOctMaxNodes];
-  __shared__ unsigned short s_newidx[kOctMaxNodes][4];
-  __shared__ unsigned long long s_npre[kOctMaxNodes];  // per node: exclusive prefix of (children | multi << 20 | single << 40)
-  __shared__ OVs s_vs[2][kOctMaxNodes];
-  __shared__ unsigned char s_proc[kOctMaxNodes];
+                                                        int kp_cap, uint32_t* __restrict__ kept, int* __restrict__ kept_cnt,
+                                                        int node_cap) {
+  // node tables in dynamic LDS, node_cap entries each (the largest level's quota + slack, oct_lds_bytes): the kernel is a chain
+  // of short dependent phases, so it is the number of workgroups a CU holds at once that sets its speed (97 B a node: 6
+  // workgroups a CU for 1000 features; the fixed 768-entry tables allowed 2)
+  extern __shared__ __align__(16) unsigned char oct_lds[];
+  ONode* s_nodes[2] = {(ONode*)oct_lds, (ONode*)oct_lds + node_cap};
+  U128* s_start = (U128*)(s_nodes[1] + node_cap);
+  U128* s_end = s_start + node_cap;
+  unsigned long long* s_npre = (unsigned long long*)(s_end + node_cap);  // per node: exclusive prefix of (children | multi << 20 | single << 40)
+  OVs* s_vs[2] = {(OVs*)(s_npre + node_cap), (OVs*)(s_npre + node_cap) + node_cap};
+  unsigned short(*s_newidx)[4] = (unsigned short(*)[4])(s_vs[1] + node_cap);
+  unsigned char* s_proc = (unsigned char*)(s_newidx + node_cap);
   __shared__ U128 s_w128[4];
+  __shared__ gfs::SortFrame s_stack[32];  // 2 lg(768) + 1 = 19 pending parts at most
   __shared__ unsigned long long s_w64[4];
   __shared__ int s_ctl[8];
   const int tid = threadIdx.x;
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
   const int chunk = (n + kOctThreads - 1) / kOctThreads;
   const int p0 = min(tid * chunk, n), p1 = min(p0 + chunk, n);
   for (int p = p0; p < p1; p++) {
-    perm[0][p] = (uint32_t)p;
+    perm[0][p] = c[p];  // the permutation arrays carry the keys themselves: no gather through an index in the sweeps
     seg[0][p] = 0;
   }
   if (tid == 0) {
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
     for (int p = p0; p < p1; p++) {
       const ONode nd = nodes[sa[p]];
       if (!init && nd.ke - nd.kb <= 1) continue;
-      const uint32_t key = c[pa[p]];
+      const uint32_t key = pa[p];
       const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
       local = u128_add(local, u128_one(q));
     }
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
       const ONode nd = nodes[ni];
       if (p == nd.kb) s_start[ni] = run;
       if (init || nd.ke - nd.kb > 1) {
-        const uint32_t key = c[pa[p]];
+        const uint32_t key = pa[p];
         const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
         run = u128_add(run, u128_one(q));
       }
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
       const int ni = sa[p];
       const ONode nd = nodes[ni];
       if (init || nd.ke - nd.kb > 1) {
-        const uint32_t key = c[pa[p]];
+        const uint32_t key = pa[p];
         const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
         unsigned ofs = 0;
         for (int qq = 0; qq < q; qq++) ofs += u128_field(s_end[ni], qq) - u128_field(s_start[ni], qq);
@@ -687,11 +696,11 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
         const int V = nvs;
         ONode* nodes = s_nodes[cur];
         if (tid == 0)
-          gfs::replica_std_sort(vs, vs + V, [](const OVs& a, const OVs& e) {  // compareNodes :552-565
+          gfs::replica_std_sort_on(vs, vs + V, [](const OVs& a, const OVs& e) {  // compareNodes :552-565
             if (a.size < e.size) return true;
             if (a.size > e.size) return false;
             return a.x0 < e.x0;
-          });
+          }, s_stack, 32);
         for (int i = tid; i < nn; i += kOctThreads) s_proc[i] = 0;
         __syncthreads();
         // candidate splits of every entry; processing order k = 0.. is j = V-1-k (from the back)
@@ -701,12 +710,13 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
         for (int k = k0; k < k1; k++) {
           const int j = V - 1 - k;
           const ONode nd = nodes[vs[j].node];
-          int cnt[4] = {0, 0, 0, 0};
-          for (int p = nd.kb; p < nd.ke; p++) cnt[oct_quadrant(nd, c[perm[pc][p]])]++;
+          unsigned long long pk = 0;  // four 16-bit quadrant counters (an indexed private array would live in scratch memory)
+          for (int p = nd.kb; p < nd.ke; p++) pk += 1ull << (16 * oct_quadrant(nd, perm[pc][p]));
           int cc = 0, mm = 0;
           for (int q = 0; q < 4; q++) {
-            cc += cnt[q] > 0;
-            mm += cnt[q] > 1;
+            const int cq = (int)((pk >> (16 * q)) & 0xffff);
+            cc += cq > 0;
+            mm += cq > 1;
           }
           s_npre[k] = (unsigned long long)cc | ((unsigned long long)mm << 20);
           lsum += s_npre[k];
@@ -746,12 +756,18 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
           pbase += v;
           const int ci = (int)(v & 0xfffff);
           // stable 4-way partition of this node's keys (through the other permutation buffer, then back)
-          int cnt[4] = {0, 0, 0, 0};
           uint32_t* pa = perm[pc];  // partitioned through the other buffer and copied back: pc does not flip here
           uint32_t* pb = perm[pc ^ 1];
-          for (int p = nd.kb; p < nd.ke; p++) cnt[oct_quadrant(nd, c[pa[p]])]++;
-          int pos[4] = {nd.kb, nd.kb + cnt[0], nd.kb + cnt[0] + cnt[1], nd.kb + cnt[0] + cnt[1] + cnt[2]};
-          for (int p = nd.kb; p < nd.ke; p++) pb[pos[oct_quadrant(nd, c[pa[p]])]++] = pa[p];
+          unsigned long long pk = 0;  // four 16-bit quadrant counters, then the four running positions
+          for (int p = nd.kb; p < nd.ke; p++) pk += 1ull << (16 * oct_quadrant(nd, pa[p]));
+          const int cnt[4] = {(int)(pk & 0xffff), (int)((pk >> 16) & 0xffff), (int)((pk >> 32) & 0xffff), (int)(pk >> 48)};
+          unsigned long long pos = (unsigned long long)cnt[0] << 16 | (unsigned long long)(cnt[0] + cnt[1]) << 32 |
+                                   (unsigned long long)(cnt[0] + cnt[1] + cnt[2]) << 48;  // offsets from nd.kb
+          for (int p = nd.kb; p < nd.ke; p++) {
+            const int sh = 16 * oct_quadrant(nd, pa[p]);
+            pb[nd.kb + (int)((pos >> sh) & 0xffff)] = pa[p];
+            pos += 1ull << sh;
+          }
           for (int p = nd.kb; p < nd.ke; p++) pa[p] = pb[p];
           int kb = nd.kb, before = 0, mrank = 0;
           for (int q = 0; q < 4; q++) {
@@ -796,9 +812,9 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
   uint32_t* out = kept + (size_t)b * kp_cap + kept_off[l];
   for (int i = tid; i < nn; i += kOctThreads) {
     const ONode nd = nodes[i];
-    uint32_t best = c[perm[pc][nd.kb]];
+    uint32_t best = perm[pc][nd.kb];
     for (int p = nd.kb + 1; p < nd.ke; p++) {
-      const uint32_t k2 = c[perm[pc][p]];
+      const uint32_t k2 = perm[pc][p];
       if ((k2 >> 24) > (best >> 24)) best = k2;
     }
     out[i] = best;
@@ -1210,6 +1226,7 @@ struct gfs_orb {
   gfs::DevBuf<uint32_t> d_slab, d_cand, d_perm0, d_perm1, d_kept;
   gfs::DevBuf<unsigned short> d_seg0, d_seg1;
   gfs::DevBuf<int> d_kept_cnt, d_kept_off;
+  int oct_node_cap = kOctMaxNodes;
   bool device_octree = true;   // DistributeOctTree on the GPU (k_octree); false = host quadtree (GFS_ORB_OCTREE=host)
   bool octree_supported = true;
   bool host_counts_valid = false, host_cands_valid = false;
@@ -1257,6 +1274,7 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
   GFS_HIP(hipMemcpyAsync(h->d_yt_alpha.p, G.yt_alpha.data(), G.yt_alpha.size() * 4, hipMemcpyHostToDevice, s));
   std::vector<int> kept_off(G.levels.size());
   bool oct_ok = true;
+  int oct_cap = 8;
   {
     int o = 0;
     for (size_t l = 0; l < G.levels.size(); l++) {
@@ -1266,11 +1284,13 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
       int nIni = (int)std::round((float)(L.max_bx - 16) / (float)(L.max_by - 16));
       if (nIni == 0) nIni = 1;
       if (nIni > 4 || L.quota + 4 * nIni + 8 > kOctMaxNodes) oct_ok = false;  // outside what k_octree holds in LDS
+      oct_cap = std::max(oct_cap, (L.quota + 4 * nIni + 8 + 7) / 8 * 8);
     }
   }
   GFS_HIP(hipMemcpyAsync(h->d_kept_off.p, kept_off.data(), kept_off.size() * sizeof(int), hipMemcpyHostToDevice, s));
   GFS_HIP(hipStreamSynchronize(s));
   h->octree_supported = oct_ok;
+  h->oct_node_cap = std::min(oct_cap, kOctMaxNodes);
   h->G = std::move(G);
   h->geom_rows = rows;
   h->geom_cols = cols;
@@ -1303,9 +1323,9 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   const int* tp = kBlurTaps[h->P.blur_variant ? 1 : 0];
   if (h->device_octree && h->octree_supported) {
     // 3-6 (device): quadtree, slot assignment, blur, orientation + descriptors — no host round trip at all
-    GFS_LAUNCH("k_octree", k_octree, dim3(B * nl), dim3(kOctThreads), 0, s, h->d_levels.p, nl, h->d_cand.p, h->d_cand_off.p,
-               cap_slab, h->d_perm0.p, h->d_perm1.p, h->d_seg0.p, h->d_seg1.p, h->d_kept_off.p, h->cap_kp, h->d_kept.p,
-               h->d_kept_cnt.p);
+    GFS_LAUNCH("k_octree", k_octree, dim3(B * nl), dim3(kOctThreads), oct_lds_bytes(h->oct_node_cap), s, h->d_levels.p, nl, h->d_cand.p,
+               h->d_cand_off.p, cap_slab, h->d_perm0.p, h->d_perm1.p, h->d_seg0.p, h->d_seg1.p, h->d_kept_off.p, h->cap_kp, h->d_kept.p,
+               h->d_kept_cnt.p, h->oct_node_cap);
     GFS_LAUNCH("k_kp_finalize", k_kp_finalize, dim3(B), dim3(256), 0, s, h->d_levels.p, nl, h->d_kept.p, h->d_kept_cnt.p,
                h->d_kept_off.p, h->cap_kp, lap0, lap1, h->d_kpin.p, h->d_kp_count.p, h->d_mono.p);
     GFS_LAUNCH("k_blur7", k_blur7, dim3((unsigned)G.blur_tiles.size(), B), dim3(256), 0, s, h->d_levels.p, h->d_tiles.p, l0,
@@ -1460,6 +1480,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   A(h->d_tiles.alloc(G.blur_tiles.size() + 64));
   A(h->d_strip_rows.alloc((size_t)2 * gfs::OrbGeometry::kPyrMaxStrips * 16));
   GFS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_area<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  GFS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(kOctMaxNodes)));
   A(h->d_xt_start.alloc(tab_x));
   A(h->d_xt_n.alloc(tab_x));
   A(h->d_xt_alpha.alloc(tab_x * 4));
@@ -1706,8 +1727,10 @@ int gfs_orb_octree_device(int device, const int32_t* x, const int32_t* y, const 
   GFS_HIP(hipMemcpy(dc.p, c.data(), c.size() * 4, hipMemcpyHostToDevice));
   GFS_HIP(hipMemcpy(doff.p, off, sizeof(off), hipMemcpyHostToDevice));
   GFS_HIP(hipMemcpy(dko.p, &ko, sizeof(ko), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_octree, dim3(1), dim3(kOctThreads), 0, 0, dL.p, 1, dc.p, doff.p, c.size(), p0.p, p1.p, s0.p, s1.p, dko.p, kcap,
-                     dk.p, dcnt.p);
+  const int node_cap = (n_features + 4 * nIni + 8 + 7) / 8 * 8;
+  GFS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(kOctMaxNodes)));
+  hipLaunchKernelGGL(k_octree, dim3(1), dim3(kOctThreads), oct_lds_bytes(node_cap), 0, dL.p, 1, dc.p, doff.p, c.size(), p0.p, p1.p, s0.p, s1.p,
+                     dko.p, kcap, dk.p, dcnt.p, node_cap);
   GFS_HIP(hipDeviceSynchronize());
   int cnt = 0;
   GFS_HIP(hipMemcpy(&cnt, dcnt.p, sizeof(int), hipMemcpyDeviceToHost));

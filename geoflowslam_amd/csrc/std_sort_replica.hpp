@@ -83,26 +83,26 @@ GFS_HD inline void replica_insertion_sort(T* first, T* last, Less less) {
   }
 }
 
+// the pending right-hand parts of __introsort_loop: at most 2 lg(n) + 1 at a time (every level of the depth limit leaves one)
+struct SortFrame {
+  int lo, hi, depth;
+};
+
+// stack: caller-provided storage for the recursion (on the device: LDS, a private array would live in scratch memory)
 template <typename T, typename Less>
-GFS_HD inline void replica_std_sort(T* first, T* last, Less less) {
+GFS_HD inline void replica_std_sort_on(T* first, T* last, Less less, SortFrame* stack, int stack_cap) {
   const long n = last - first;
   if (n <= 0) return;
   constexpr long kThreshold = 16;
   long lg = 0;
   for (long v = n; v > 1; v >>= 1) lg++;
   // __introsort_loop with an explicit stack for the recursion on the right part
-  struct Frame {
-    T* first;
-    T* last;
-    long depth;
-  };
-  Frame stack[96];
   int sp = 0;
-  stack[sp++] = Frame{first, last, lg * 2};
+  stack[sp++] = SortFrame{0, (int)n, (int)(lg * 2)};
   while (sp > 0) {
-    Frame f = stack[--sp];
-    T* lo = f.first;
-    T* hi = f.last;
+    const SortFrame f = stack[--sp];
+    T* lo = first + f.lo;
+    T* hi = first + f.hi;
     long depth = f.depth;
     while (hi - lo > kThreshold) {
       if (depth == 0) {
@@ -151,7 +151,7 @@ GFS_HD inline void replica_std_sort(T* first, T* last, Less less) {
       // recurse on [cut, hi) first (the reference recursion runs to completion before the loop continues on
       // [lo, cut)); the two ranges are disjoint, so running the left loop first and the right part later from
       // the stack performs the same comparisons and moves inside each range.
-      if (sp < 96) stack[sp++] = Frame{cut, hi, depth};
+      if (sp < stack_cap) stack[sp++] = SortFrame{(int)(cut - first), (int)(hi - first), (int)depth};
       hi = cut;
     }
   }
@@ -162,6 +162,12 @@ GFS_HD inline void replica_std_sort(T* first, T* last, Less less) {
   } else {
     replica_insertion_sort(first, last, less);
   }
+}
+
+template <typename T, typename Less>
+GFS_HD inline void replica_std_sort(T* first, T* last, Less less) {
+  SortFrame stack[96];
+  replica_std_sort_on(first, last, less, stack, 96);
 }
 
 }  // namespace gfs
