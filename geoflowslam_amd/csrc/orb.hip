@@ -60,26 +60,6 @@ __device__ __forceinline__ const uint8_t* level_ptr(const LevelDev& L, int level
 // saturate_cast<uchar>(cvRound(sum)).  One thread per destination pixel; <= 4x4 source taps.
 // Reference call: src/ORBextractor.cc:1240-1241.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint8_t area_pixel(const uint8_t* __restrict__ src, int sp, int xi, int yi,
-                                              const int* __restrict__ xt_start, const int* __restrict__ xt_n,
-                                              const float* __restrict__ xt_alpha, const int* __restrict__ yt_start,
-                                              const int* __restrict__ yt_n, const float* __restrict__ yt_alpha) {
-  const int sx0 = xt_start[xi], nx = xt_n[xi], sy0 = yt_start[yi], ny = yt_n[yi];
-  const float4 ax = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)xi);
-  const float4 ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)yi);
-  const float axs[4] = {ax.x, ax.y, ax.z, ax.w}, ays[4] = {ay.x, ay.y, ay.z, ay.w};
-  float sum = 0.f;
-  for (int j = 0; j < ny; j++) {
-    const uint8_t* row = src + (size_t)(sy0 + j) * sp + sx0;
-    float buf = 0.f;
-    for (int k = 0; k < nx; k++) buf = __fadd_rn(buf, __fmul_rn((float)row[k], axs[k]));
-    const float t = __fmul_rn(ays[j], buf);
-    sum = (j == 0) ? t : __fadd_rn(sum, t);
-  }
-  int r = __float2int_rn(sum);  // cvRound: round-half-even
-  return (uint8_t)min(max(r, 0), 255);
-}
-
 // One launch for the whole chain: workgroup (k, b) produces, level after level, a horizontal strip of every level of
 // frame b (OrbGeometry::strip_rows: its share of the level plus the halo rows its own higher levels read), so a level
 // only ever reads rows the same workgroup produced.  Neighbouring strips recompute a few identical halo rows instead of
@@ -137,18 +117,38 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area(const LevelDev* __rest
       src = level_ptr(S, level - 1, b, l0, pyr, pyr_frame, &sp);
     }
     uint8_t* dst = pyr + (size_t)b * pyr_frame + L.plane_off;
-    const int total = (r1 - r0) * L.cols;
-    const int sy = kPyrThreads / L.cols, sx = kPyrThreads - sy * L.cols;  // raster step of one workgroup stride
-    int dx = tid % L.cols, dy = r0 + tid / L.cols;
-    for (int i = tid; i < total; i += kPyrThreads) {
-      const uint8_t v = area_pixel(src, sp, L.xtab_off + dx, L.ytab_off + dy, xt_start, xt_n, xt_alpha, yt_start, yt_n, yt_alpha);
-      dst[(size_t)dy * L.pitch + dx] = v;
-      if (LDS && keep) keep[i] = v;  // i == (dy - r0) * cols + dx
-      dx += sx;
-      dy += sy;
-      if (dx >= L.cols) {
-        dx -= L.cols;
-        dy++;
+    // thread <-> (column, row phase): the column's taps (start, count, four weights) stay in registers down the strip, the
+    // row's taps are the same for (nearly) every lane of a wave; per pixel that leaves the source bytes and the arithmetic
+    const int ncolt = min(L.cols, kPyrThreads), rows_par = kPyrThreads / ncolt;
+    const int cxi = tid % ncolt, ry = tid / ncolt;
+    if (ry < rows_par) {
+      for (int dx = cxi; dx < L.cols; dx += ncolt) {
+        const int xi = L.xtab_off + dx;
+        const int sx0 = xt_start[xi], nx = xt_n[xi];
+        const float4 ax = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)xi);
+        for (int dy = r0 + ry; dy < r1; dy += rows_par) {
+          const int yi = L.ytab_off + dy;
+          const int sy0 = yt_start[yi], ny = yt_n[yi];
+          const float4 ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)yi);
+          const float ays[4] = {ay.x, ay.y, ay.z, ay.w};
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (j < ny) {
+              const uint8_t* row = src + (size_t)(sy0 + j) * sp + sx0;
+              float buf = __fadd_rn(0.f, __fmul_rn((float)row[0], ax.x));
+              if (nx > 1) buf = __fadd_rn(buf, __fmul_rn((float)row[1], ax.y));
+              if (nx > 2) buf = __fadd_rn(buf, __fmul_rn((float)row[2], ax.z));
+              if (nx > 3) buf = __fadd_rn(buf, __fmul_rn((float)row[3], ax.w));
+              const float t = __fmul_rn(ays[j], buf);
+              sum = (j == 0) ? t : __fadd_rn(sum, t);
+            }
+          }
+          const int r = __float2int_rn(sum);  // cvRound: round-half-even
+          const uint8_t v = (uint8_t)min(max(r, 0), 255);
+          dst[(size_t)dy * L.pitch + dx] = v;
+          if (LDS && keep) keep[(dy - r0) * L.cols + dx] = v;
+        }
       }
     }
     if (!LDS) __threadfence_block();
