@@ -241,7 +241,8 @@ __device__ __forceinline__ int arc_score_full(const uint8_t* __restrict__ c, int
   return max(A, -Bm);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__ levels,
+constexpr int kFastThreads = 256;  // a cell is ~900 pixels and a chain of short phases: small workgroups, many of them per CU
+__global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __restrict__ levels,
                                                     const CellDev* __restrict__ cells, Lvl0 l0,
                                                     const uint8_t* __restrict__ pyr, size_t pyr_frame, int ini_th,
                                                     int min_th, int n_cells, size_t slab_frame,
@@ -261,15 +262,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
   uint8_t* tile = smem;             // [h][w]
   uint8_t* sc = smem + (size_t)w * h;  // [h][w] arc score - 1 (0 = not a corner at the low threshold)
   unsigned short* clist = reinterpret_cast<unsigned short*>(smem + (((size_t)2 * w * h + 3) & ~(size_t)3));  // corner offsets
-  __shared__ int s_ncorner;
+  __shared__ int s_ncorner, s_nquick;
   int sp;
   const uint8_t* src = level_ptr(L, C.level, b, l0, pyr, pyr_frame, &sp);
   src += (size_t)C.y0 * sp + C.x0;
   {
-    const int sy = 256 / w, sx = 256 - sy * w;  // raster step of 256 pixels
+    const int sy = kFastThreads / w, sx = kFastThreads - sy * w;  // raster step of one workgroup stride
     int x = tid % w;
     size_t g = (size_t)(tid / w) * sp + x;
-    for (int i = tid; i < w * h; i += 256) {
+    for (int i = tid; i < w * h; i += kFastThreads) {
       tile[i] = src[g];
       sc[i] = 0;
       x += sx;
@@ -283,41 +284,79 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
   if (tid == 0) {
     s_count = 0;
     s_ncorner = 0;
+    s_nquick = 0;
   }
   __syncthreads();
   const int th_hi = min(max(ini_th, 0), 255), th_lo = min(max(min_th, 0), 255);
-  const int th_low = min(th_hi, th_lo);
-  // phase 1: cheap 9-arc test on every pixel; corners (a few %) are compacted into a list ...
-  {
-    const int sy = 256 / dw, sx = 256 - sy * dw;  // raster step of 256 pixels
-    int xx = tid % dw, o = (tid / dw + 3) * w + xx + 3;
-    for (int i = tid; i < dw * dh; i += 256) {
-      if (arc_is_corner(tile + o, w, th_low)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
-      xx += sx;
-      o += sy * w + sx;
-      if (xx >= dw) {
-        xx -= dw;
-        o += w - dw;
+  unsigned short* qlist = clist + (size_t)w * h;
+  unsigned short* klist = reinterpret_cast<unsigned short*>(tile);  // phase 3's output overwrites the tile (when there is any)
+  int nk = 0;
+  // FAST with iniThFAST and, only if the cell produced nothing, again with minThFAST (src/ORBextractor.cc:815-827): at the low
+  // threshold several times as many pixels are corners, and nearly every cell is settled by the first pass
+  for (int pass = 0; pass < 2; pass++) {
+    const int th = pass == 0 ? th_hi : th_lo;
+    const int T = max(th, 1);
+    if (pass == 1) {
+      if (tid == 0) {
+        s_ncorner = 0;
+        s_nquick = 0;
+      }
+      __syncthreads();
+    }
+    // phase 0: the four compass points of the ring.  Nine contiguous ring pixels always contain at least two of them, so a
+    // corner at threshold th has two compass points darker than v - th or two brighter than v + th; the pixels that pass are
+    // compacted, wave by wave, into a list ...
+    {
+      const int sy = kFastThreads / dw, sx = kFastThreads - sy * dw;  // raster step of one workgroup stride
+      int xx = tid % dw, o = (tid / dw + 3) * w + xx + 3;
+      const int total = dw * dh, lane = tid & 63;
+      for (int base = 0; base < total; base += kFastThreads) {
+        bool ok = false;
+        if (base + tid < total) {
+          const uint8_t* c = tile + o;
+          const int v = c[0], lo = v - th, hi = v + th;
+          const int a = c[3 * w], b4 = c[3], e = c[-3 * w], f = c[-3];
+          const int nd = (a < lo) + (b4 < lo) + (e < lo) + (f < lo), nb = (a > hi) + (b4 > hi) + (e > hi) + (f > hi);
+          ok = nd >= 2 || nb >= 2;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+          int at = 0;
+          if (lane == 0) at = atomicAdd(&s_nquick, (int)__popcll(m));
+          at = __shfl(at, 0, 64);
+          if (ok) qlist[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)o;
+        }
+        xx += sx;
+        o += sy * w + sx;
+        if (xx >= dw) {
+          xx -= dw;
+          o += w - dw;
+        }
       }
     }
-  }
-  __syncthreads();
-  // ... phase 2: the expensive exact score runs on dense lanes over the corner list only
-  const int ncorner = s_ncorner;
-  for (int k = tid; k < ncorner; k += 256) {
-    const int o = clist[k];
-    sc[o] = (uint8_t)(arc_score_full(tile + o, w) - 1);  // corner at th_low => S > th_low >= 0
-  }
-  __syncthreads();
-  // phase 3: 3x3 non-maximum suppression (scores below the threshold count as 0 outside the corner set, and the cell
-  // border is outside the detection area: nonmaxSuppression of cv::FAST on the cell image) over the corner list only.
-  // Survivors are collected unordered; the tile is no longer needed and is reused for their offsets (at most one
-  // survivor per 2x2 block -> w*h/4 entries of 2 bytes).
-  unsigned short* klist = reinterpret_cast<unsigned short*>(tile);
-  int T = max(th_hi, 1);
-  int nk = 0;
-  for (int pass = 0; pass < 2; pass++) {
-    for (int k = tid; k < ncorner; k += 256) {
+    __syncthreads();
+    // ... phase 1: the 9-arc test on dense lanes over that list; corners (a few %) are compacted into a second list ...
+    {
+      const int nq = s_nquick;
+      for (int k = tid; k < nq; k += kFastThreads) {
+        const int o = qlist[k];
+        if (arc_is_corner(tile + o, w, th)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
+      }
+    }
+    __syncthreads();
+    // ... phase 2: the expensive exact score runs on dense lanes over the corner list only
+    const int ncorner = s_ncorner;
+    for (int k = tid; k < ncorner; k += kFastThreads) {
+      const int o = clist[k];
+      sc[o] = (uint8_t)(arc_score_full(tile + o, w) - 1);  // corner at th => S > th >= 0
+    }
+    __syncthreads();
+    // phase 3: 3x3 non-maximum suppression (scores below the threshold count as 0 outside the corner set, and the cell
+    // border is outside the detection area: nonmaxSuppression of cv::FAST on the cell image) over the corner list only.
+    // Survivors are collected unordered; with a survivor the tile is no longer needed and is reused for their offsets (at
+    // most one survivor per 2x2 block -> w*h/4 entries of 2 bytes).  The decisions are taken before the first offset is
+    // written (the arc tests above read the tile, this phase does not).
+    for (int k = tid; k < ncorner; k += kFastThreads) {
       const int o = clist[k];
       const int s = sc[o];
       if (s < T) continue;
@@ -329,13 +368,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelDev* __restrict__
     }
     __syncthreads();
     nk = s_count;
-    if (nk > 0 || pass == 1) break;
-    T = max(th_lo, 1);  // vKeysCell.empty() -> retry with minThFAST (src/ORBextractor.cc:825-827)
+    if (nk > 0) break;
   }
   // phase 4: raster order = ascending tile offset; every survivor finds its rank among the (few) survivors
   uint32_t* out = slab + (size_t)b * slab_frame + C.slab_off;
   const int offx = C.x0 - 16, offy = C.y0 - 16;  // + j*wCell, + i*hCell (src/ORBextractor.cc:847-848)
-  for (int k = tid; k < nk; k += 256) {
+  for (int k = tid; k < nk; k += kFastThreads) {
     const int o = klist[k];
     int r = 0;
     for (int j = 0; j < nk; j++) r += klist[j] < o ? 1 : 0;
@@ -1315,8 +1353,8 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                h->d_yt_alpha.p);
   }
   // 2. FAST cells of all levels, all frames in one launch
-  const size_t lds = 4 * (size_t)G.max_tile_w * G.max_tile_h + 8;  // tile + score map + corner list (u16)
-  GFS_LAUNCH("k_fast_cells", k_fast_cells, dim3(n_cells, B), dim3(256), lds, s, h->d_levels.p, h->d_cells.p, l0,
+  const size_t lds = 6 * (size_t)G.max_tile_w * G.max_tile_h + 8;  // tile + score map + corner list (u16) + compass-test list (u16)
+  GFS_LAUNCH("k_fast_cells", k_fast_cells, dim3(n_cells, B), dim3(kFastThreads), lds, s, h->d_levels.p, h->d_cells.p, l0,
              h->d_pyr.p, cap_pyr, h->P.ini_th, h->P.min_th, n_cells, cap_slab, h->d_slab.p, h->d_cell_cnt.p);
   GFS_LAUNCH("k_cand_pack", k_cand_pack, dim3(B), dim3(256), 0, s, h->d_levels.p, h->d_cells.p, nl, n_cells, cap_slab,
              h->d_slab.p, h->d_cell_cnt.p, cap_slab, h->d_cand.p, h->d_cand_off.p);
@@ -1459,7 +1497,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   G.build(h->P, cfg->max_rows, cfg->max_cols);
   GFS_REQUIRE(G.supported, GFS_ERR_UNSUPPORTED, "ORB geometry for max size %dx%d unsupported: %s", cfg->max_cols,
               cfg->max_rows, G.why);
-  GFS_REQUIRE(4 * (size_t)G.max_tile_w * G.max_tile_h + 8 <= 60000, GFS_ERR_UNSUPPORTED, "FAST cell tile too large for LDS");
+  GFS_REQUIRE(6 * (size_t)G.max_tile_w * G.max_tile_h + 8 <= 64000, GFS_ERR_UNSUPPORTED, "FAST cell tile too large for LDS");
   const size_t B = cfg->max_batch;
   h->cap_pyr = G.pyr_bytes + 4096;
   h->cap_blur = G.blur_bytes + 4096;
