@@ -229,7 +229,7 @@ typedef struct {
   const uint8_t* pose_fixed; /* [n_poses] 1 = fixed (setFixed(true), src/Optimizer.cc:1697,1715) */
   const double* points;      /* [n_points][3] world coordinates */
   const int32_t* edge_pose;  /* [n_edges] */
-  const int32_t* edge_point; /* [n_edges] */
+  const int32_t* edge_point; /* [n_edges]; several edges may join the same (pose, point) pair, as in g2o */
   const double* edge_obs;    /* [n_edges][3] (u, v, u_right); u_right ignored for mono edges */
   const double* edge_inv_sigma2; /* [n_edges] information = inv_sigma2 * I */
   const uint8_t* edge_stereo;    /* [n_edges] 1 = EdgeStereoSE3ProjectXYZ, 0 = EdgeSE3ProjectXYZ */
