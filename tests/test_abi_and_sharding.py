@@ -128,3 +128,17 @@ def test_bench_spawns_its_own_ranks(api):
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     cp = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=60)
     assert cp.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in cp.stderr
+
+
+def test_bench_has_no_local_import_shadowing_a_module_import():
+    """`import x` inside main() makes x a local of the whole function: an earlier use of the module-level x then raises
+    UnboundLocalError, but only on the legs that run on a GPU box (this cost a collection run in round 2)."""
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+    top = {(a.asname or a.name).split(".")[0] for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) for a in n.names}
+    bad = [(f.name, (a.asname or a.name), n.lineno) for f in ast.walk(tree) if isinstance(f, ast.FunctionDef)
+           for n in ast.walk(f) if isinstance(n, (ast.Import, ast.ImportFrom)) for a in n.names
+           if (a.asname or a.name).split(".")[0] in top]
+    assert not bad, bad
