@@ -725,9 +725,12 @@ int gfs_klt_create(int device, int width, int height, int win, int max_level, in
   }
   G.frame_stride = (long long)gfs::align_up((size_t)G.off[G.n_levels] + kKltSlack, 256);
   h->lds_bytes = (size_t)kKltWavesPerBlock * (3 * G.rounds * 64 + (G.win_dwords + 1) / 2) * sizeof(uint2);
-#define KLT_ATTR(R)                                                                                                          \
-  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_track<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes)); \
-  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_fb<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes))
+  // (the ceiling is one global setting per kernel: always the hardware limit, so that trackers with different windows — on
+  // different host threads or created one after the other — cannot undercut each other)
+  GFS_REQUIRE(h->lds_bytes <= 160 * 1024 - 2048, GFS_ERR_UNSUPPORTED, "gfs_klt: window %d needs %zu bytes of LDS", win, h->lds_bytes);
+#define KLT_ATTR(R)                                                                                                            \
+  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_track<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); \
+  GFS_HIP(hipFuncSetAttribute((const void*)k_klt_fb<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048))
   KLT_DISPATCH(G.rounds, KLT_ATTR)
 #undef KLT_ATTR
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

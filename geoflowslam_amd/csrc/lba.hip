@@ -1780,6 +1780,23 @@ inline size_t schur_lds_bytes(const LbaDev& D) {
   return (size_t)D.schur_sub * ((size_t)D.n_free * (kSchurSlot * sizeof(double) + sizeof(int)) + 4 * sizeof(double));
 }
 
+// The dynamic-LDS ceiling of a kernel is one global setting per function: raising it per call to that call's need would let
+// two host threads with different windows undercut each other.  Set once per device to the hardware limit instead.
+int lba_raise_lds_limits(int device) {
+  static std::mutex mu;
+  static bool done[64] = {};
+  std::lock_guard<std::mutex> lk(mu);
+  if (device >= 0 && device < 64 && done[device]) return GFS_OK;
+  const int lim = 160 * 1024 - 1024;
+  const void* fns[] = {(const void*)k_lba, (const void*)k_lba_solve<true>, (const void*)k_lba_solve<false>, (const void*)kb_lba_solve<true>,
+                       (const void*)kb_lba_solve<false>, (const void*)k_lba_schur_chunks, (const void*)kb_lba_schur_chunks,
+                       (const void*)k_lba_schur_mfma<true>, (const void*)k_lba_schur_mfma<false>, (const void*)kb_lba_schur_mfma<true>,
+                       (const void*)kb_lba_schur_mfma<false>};
+  for (const void* f : fns) GFS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+  if (device >= 0 && device < 64) done[device] = true;
+  return GFS_OK;
+}
+
 int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volatile const int* stop) {
   hipStream_t s = h->stream;
   const int NP = p->n_points, E = p->n_edges;
@@ -1794,7 +1811,6 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   h->last_desc = D;
   if (single_wg && in_lds) {
     GFS_REQUIRE(!D.e_dup, GFS_ERR_UNSUPPORTED, "gfs_lba: GFS_LBA_SINGLE_WG does not take several edges between one pose and one point");
-    GFS_HIP(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (E) GFS_HIP(hipMemsetAsync(h->d_Hpl.p, 0, (size_t)E * 18 * sizeof(double), s));
     GFS_LAUNCH("k_lba", k_lba, dim3(1), dim3(kThreads), lds, s, D);
     // setForceStopFlag semantics (src/Optimizer.cc:1679): relay the caller's flag to the device-visible one
@@ -1813,13 +1829,6 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   const auto Ta = std::chrono::steady_clock::now();
   int* d_flags = nullptr;
   GFS_HIP(hipHostGetDevicePointer((void**)&d_flags, h->h_flags, 0));
-  GFS_HIP(hipFuncSetAttribute(in_lds ? (const void*)k_lba_solve<true> : (const void*)k_lba_solve<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (D.schur_sub)
-    GFS_HIP(hipFuncSetAttribute((const void*)k_lba_schur_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds_bytes(D)));
-  if (D.schur_mfma)
-    GFS_HIP(hipFuncSetAttribute(D.n_pair_tiles == 1 ? (const void*)k_lba_schur_mfma<true> : (const void*)k_lba_schur_mfma<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_mfma_lds_bytes(D)));
   const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 8)), g_upd(D.n_upd_blocks);
   GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
   const bool lin_only = mode == 1 || p->iterations <= 0;
@@ -1900,6 +1909,7 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   h->max_points = max_points;
   h->max_edges = max_edges;
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  if (int rc0 = lba_raise_lds_limits(device)) return rc0;
   GFS_HIP(hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped));
   GFS_HIP(hipHostMalloc((void**)&h->h_flags, 4 * sizeof(int), hipHostMallocMapped));
   const size_t NP = max_points, E = max_edges, NQ = max_poses, F = max_poses;
@@ -2134,19 +2144,12 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
       max_pair_blocks = std::max(max_pair_blocks, D.n_free * (D.n_free + 1) / 2);
     }
   }
-  if (schur_lds)
-    GFS_HIP(hipFuncSetAttribute((const void*)kb_lba_schur_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
-  if (mfma_lds)
-    GFS_HIP(hipFuncSetAttribute(one_block ? (const void*)kb_lba_schur_mfma<true> : (const void*)kb_lba_schur_mfma<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
   GFS_HIP(hipMemcpyAsync(b->d_desc.p, b->h_desc.p, (size_t)n * sizeof(LbaDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(b->d_done.p, 0, sizeof(int), s));
   const int nmax = 6 * max_free;
   const bool in_lds = max_free <= kMaxFreeLds;
   const size_t lds = (in_lds ? (size_t)nmax * (nmax + 1) / 2 + nmax + 8 : (size_t)7 * nmax + 8) * sizeof(double);
   GFS_REQUIRE(lds <= 160 * 1024, GFS_ERR_CAPACITY, "gfs_lba_solve_batch: %d free poses exceed the solver's workspace", max_free);
-  GFS_HIP(hipFuncSetAttribute(in_lds ? (const void*)kb_lba_solve<true> : (const void*)kb_lba_solve<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const LbaDev* DD = b->d_desc.p;
   const auto T2 = now();
   int rounds_run = 0;
