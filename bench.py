@@ -568,6 +568,26 @@ def main():
                 for _ in range(3):
                     bat.solve_prepared(Pb, Sb, NW)
                 dtb = (time.perf_counter() - t1) / 3
+                # the build kernels' roofline with the chip filled (same bytes per window as lba.roofline above)
+                api.profile_reset()
+                api.profile_enable(True)
+                bat.solve_prepared(Pb, Sb, NW)
+                torch.cuda.synchronize()
+                brep = api.profile_report()
+                api.profile_enable(False)
+                bb = [brep[k] for k in ("kb_lba_errors", "kb_lba_build_landmarks", "kb_lba_build_poses") if k in brep]
+                nb_b = brep["kb_lba_build_landmarks"][1] if "kb_lba_build_landmarks" in brep else 0
+                batch_roof = None
+                if nb_b and sum(v[0] for v in bb) > 0:
+                    bms = sum(v[0] for v in bb)
+                    # every launch covers the windows still iterating; count a window's build once per LM iteration it ran
+                    builds = float(sum(int(S_.iterations_run) for S_ in Sb))
+                    bytes_b = sum(7.0e6 * float(w_["n_edges"]) / 36000.0 * int(S_.iterations_run) for w_, S_ in zip(wl, Sb))
+                    ach_b = bytes_b / (bms * 1e-3) / 1e9
+                    batch_roof = dict(bound="hbm", kernel="kb_lba_errors + kb_lba_build_landmarks + kb_lba_build_poses", achieved=round(ach_b, 2),
+                                      peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_b / HBM_PEAK_GBS, 5), window_builds=int(builds),
+                                      build_kernels_ms=round(bms, 3),
+                                      kernels_ms_per_batch={k: round(v[0], 3) for k, v in sorted(brep.items(), key=lambda kv: -kv[1][0]) if "lba" in k})
                 # several handles on as many host threads: the host preparation / scatter of one batch overlaps the device work of the
                 # others (a server with several maps)
                 hs = [(bat, Pb, Sb, keep_b)]
@@ -595,6 +615,7 @@ def main():
                 lba_batch = dict(value=flight[4], unit="windows/s", windows=NW, handles_in_flight=4, distinct_windows=ND,
                                  two_handles=dict(value=flight[2], unit="windows/s"),
                                  one_handle=dict(value=round(NW / dtb, 1), unit="windows/s", ms_per_batch=round(dtb * 1e3, 2)),
+                                 roofline=batch_roof,
                                  note="host preparation, upload, solve and download of 64 windows per call, every call included; per window "
                                       "bit-identical to gfs_lba_solve")
                 for h_ in hs[1:]:
