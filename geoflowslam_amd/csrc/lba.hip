@@ -39,6 +39,7 @@ struct LbaState {
   int qmax, n_bad, iters;
   int solve_ok;                  // LinearSolver succeeded in the current trial
   int again, terminate;          // outputs of k_lba_decide for the host loop
+  int err_at_cur;                // chi2 / err / part_chi already hold the accepted estimate's values (the accepted trial computed them)
   int phase, it;                 // batched entry: 0 = build next, 1 = trial next, 2 = done; index of the running LM iteration
 };
 
@@ -59,6 +60,8 @@ struct LbaDev {
   const int* pose_begin;   // [n_free+1]
   const int* pose_edges;   // edge ids (landmark-major numbering), ascending, per free pose
   const int* edge_of;      // [n_free][n_points] edge id or -1 (the FIRST edge of a (pose, landmark) pair)
+  const int* lm_wg;        // [n_lm_wg + 1] landmark ranges of the workgroups of b_build_landmarks (<= kMk edges each, or one landmark)
+  int n_lm_wg;
   const int* e_dup;        // [n_edges] first edge of the same (pose, landmark) pair, -1 for a first edge; NULL: no duplicates
   double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
   int iterations;
@@ -578,6 +581,7 @@ __device__ __forceinline__ void b_init(const LbaDev& D, const int bx, const int 
     S.solve_ok = 1;
     S.again = S.terminate = 0;
     S.phase = S.it = 0;
+    S.err_at_cur = 0;
   }
 }
 __global__ __launch_bounds__(kMk) void k_lba_init(LbaDev D) { b_init(D, blockIdx.x, gridDim.x); }
@@ -588,6 +592,9 @@ __global__ __launch_bounds__(kMk) void k_lba_init(LbaDev D) { b_init(D, blockIdx
 __device__ __forceinline__ void b_errors(const LbaDev& D, const int bx, const int gdx, int trial) {
   __shared__ double s4[4];
   const LbaState& S = *D.S;
+  // computeActiveErrors at the top of an iteration that follows an accepted trial would recompute, at the same estimate, what that
+  // trial's own evaluation left in chi2 / err / part_chi
+  if (!trial && S.err_at_cur) return;
   const int which = (trial && S.solve_ok) ? (S.cur ^ 1) : S.cur;
   const double *q = sel(D.q, D.q_try, which), *t = sel(D.t, D.t_try, which), *X = sel(D.X, D.X_try, which);
   double local = 0;
@@ -613,44 +620,54 @@ __global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial) { b_err
 // buildSystem, landmark side: Hll, bl and the per-edge pose-landmark blocks.  16 lanes per landmark (its edges over the
 // lanes, the 9 sums folded by xor-shuffles inside the group in a fixed order), 8 landmarks per 128-thread workgroup.
 __device__ __forceinline__ void b_build_landmarks(const LbaDev& D, const int bx, const int gdx) {
+  // One thread per EDGE: a workgroup takes a run of whole landmarks holding at most kMk edges (lm_wg, packed by the host; a
+  // landmark with more than kMk edges gets a workgroup to itself and the threads stride over its edges).  The nine landmark
+  // sums (Hll, bl) of an edge go through LDS and thread <-> (landmark, component) adds its landmark's edges in edge order.
+  // (16 lanes per landmark, the round-1 mapping, left half the lanes idle: a landmark of this window has 16.5 edges on
+  // average, so nearly every group ran a second, almost empty pass.)
+  __shared__ double s_c[kMk][9];
   const LbaState& S = *D.S;
   const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
-  const int gl = threadIdx.x & 15;
-  const int l = bx * 8 + (threadIdx.x >> 4);
-  const bool live = l < D.n_points;  // (whole 16-lane groups are live or not: the shuffles below stay inside a group)
+  const int l0 = D.lm_wg[bx], l1 = D.lm_wg[bx + 1];
+  const int e0 = D.pt_begin[l0], e1 = D.pt_begin[l1];
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx,xy,xz,yy,yz,zz), b
-  if (live) {
-    for (int e = D.pt_begin[l] + gl; e < D.pt_begin[l + 1]; e += 16) {
-      double xc[3], r[3], Ji[9], Jj[18];
-      edge_residual(D, e, q, t, X, xc, r);
-      edge_jacobians(D, e, q, xc, Ji, Jj);
-      double r0, r1;
-      huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
-      const double w = r1 * D.e_w[e];
-      double omr[3];
-      for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
-      int o = 0;
-      for (int a = 0; a < 3; a++) {
-        acc[6 + a] += Ji[a] * omr[0] + Ji[3 + a] * omr[1] + Ji[6 + a] * omr[2];
-        for (int c = a; c < 3; c++) acc[o++] += Ji[a] * w * Ji[c] + Ji[3 + a] * w * Ji[3 + c] + Ji[6 + a] * w * Ji[6 + c];
-      }
-      if (D.free_index[D.e_pose[e]] >= 0) {
-        double* B = D.Hpl + 18 * (size_t)e;
-        for (int a = 0; a < 6; a++)
-          for (int c = 0; c < 3; c++) B[3 * a + c] = Jj[a] * w * Ji[c] + Jj[6 + a] * w * Ji[3 + c] + Jj[12 + a] * w * Ji[6 + c];
-      }
+  for (int e = e0 + threadIdx.x; e < e1; e += kMk) {
+    double xc[3], r[3], Ji[9], Jj[18];
+    edge_residual(D, e, q, t, X, xc, r);
+    edge_jacobians(D, e, q, xc, Ji, Jj);
+    double r0, r1;
+    huber(D.chi2[e], D.e_stereo[e] ? D.huber_stereo : D.huber_mono, &r0, &r1);
+    const double w = r1 * D.e_w[e];
+    double omr[3];
+    for (int k = 0; k < 3; k++) omr[k] = -(D.e_w[e] * D.err[3 * e + k]) * r1;
+    int o = 0;
+    for (int a = 0; a < 3; a++) {
+      acc[6 + a] += Ji[a] * omr[0] + Ji[3 + a] * omr[1] + Ji[6 + a] * omr[2];
+      for (int c = a; c < 3; c++) acc[o++] += Ji[a] * w * Ji[c] + Ji[3 + a] * w * Ji[3 + c] + Ji[6 + a] * w * Ji[6 + c];
+    }
+    if (D.free_index[D.e_pose[e]] >= 0) {
+      double* B = D.Hpl + 18 * (size_t)e;
+      for (int a = 0; a < 6; a++)
+        for (int c = 0; c < 3; c++) B[3 * a + c] = Jj[a] * w * Ji[c] + Jj[6 + a] * w * Ji[3 + c] + Jj[12 + a] * w * Ji[6 + c];
     }
   }
 #pragma unroll
-  for (int k = 0; k < 9; k++) {
-    double v = acc[k];
-#pragma unroll
-    for (int ofs = 8; ofs > 0; ofs >>= 1) v += __shfl_xor(v, ofs, 16);
-    acc[k] = v;
-  }
-  if (live && gl == 0) {
-    for (int k = 0; k < 6; k++) D.Hll[6 * (size_t)l + k] = acc[k];
-    for (int k = 0; k < 3; k++) D.bl[3 * (size_t)l + k] = acc[6 + k];
+  for (int k = 0; k < 9; k++) s_c[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  const int nl = l1 - l0;
+  for (int u = threadIdx.x; u < nl * 9; u += kMk) {
+    const int l = l0 + u / 9, k = u - (u / 9) * 9;
+    int s0 = D.pt_begin[l] - e0, s1 = D.pt_begin[l + 1] - e0;
+    if (e1 - e0 > kMk) {  // one landmark with more edges than threads: every thread holds a partial sum of it
+      s0 = 0;
+      s1 = kMk;
+    }
+    double v = 0;
+    for (int sl = s0; sl < s1; sl++) v += s_c[sl][k];
+    if (k < 6)
+      D.Hll[6 * (size_t)l + k] = v;
+    else
+      D.bl[3 * (size_t)l + (k - 6)] = v;
   }
   // several edges between one pose and one landmark (a rig seeing the point with two cameras): g2o adds their J_pose^T Omega J_point
   // into the one Hpl block of that vertex pair (core/block_solver.hpp:143-295 allocates it once).  The first edge's block takes
@@ -658,7 +675,8 @@ __device__ __forceinline__ void b_build_landmarks(const LbaDev& D, const int bx,
   // edges.  gfs_lba_linearize (mode 1) reports the per-edge blocks instead.
   if (D.e_dup && D.mode == 0) {
     __threadfence_block();
-    if (live && gl == 0) {
+    __syncthreads();
+    for (int l = l0 + threadIdx.x; l < l1; l += kMk) {
       for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
         const int first = D.e_dup[e];
         if (first < 0 || D.free_index[D.e_pose[e]] < 0) continue;
@@ -672,7 +690,7 @@ __device__ __forceinline__ void b_build_landmarks(const LbaDev& D, const int bx,
     }
   }
 }
-__global__ __launch_bounds__(128) void k_lba_build_landmarks(LbaDev D) { b_build_landmarks(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kMk) void k_lba_build_landmarks(LbaDev D) { b_build_landmarks(D, blockIdx.x, gridDim.x); }
 
 
 // buildSystem, pose side: one workgroup per free pose, threads over its edges, fixed-order reduction
@@ -1366,14 +1384,17 @@ __device__ __forceinline__ void b_decide(const LbaDev& D, const int bx, int forc
       S.ni = 2;
       S.current_chi = temp_chi;
       S.cur ^= 1;  // discardTop: the trial becomes the estimate
+      S.err_at_cur = 1;
     } else {
       S.lambda *= S.ni;
       S.ni *= 2;
+      S.err_at_cur = 0;  // (the arrays hold the rejected trial's values)
     }
     S.qmax++;
     S.again = (S.rho < 0 && S.qmax < 10) ? 1 : 0;
   } else {
     S.again = 0;  // the stop flag ended the trial loop
+    S.err_at_cur = 0;
   }
   S.terminate = 0;
   if (!S.again) {
@@ -1452,8 +1473,8 @@ __global__ __launch_bounds__(kMk) void kb_lba_errors(const LbaDev* __restrict__ 
   GFS_LBAB_PROLOGUE(trial ? 1 : 0, D.n_err_blocks)
   b_errors(D, blockIdx.x, need, trial);
 }
-__global__ __launch_bounds__(128) void kb_lba_build_landmarks(const LbaDev* __restrict__ DD) {
-  GFS_LBAB_PROLOGUE(0, (D.n_points + 7) / 8)
+__global__ __launch_bounds__(kMk) void kb_lba_build_landmarks(const LbaDev* __restrict__ DD) {
+  GFS_LBAB_PROLOGUE(0, D.n_lm_wg)
   b_build_landmarks(D, blockIdx.x, need);
 }
 __global__ __launch_bounds__(kMk) void kb_lba_build_poses(const LbaDev* __restrict__ DD) {
@@ -1559,6 +1580,8 @@ struct HostPrep {
       *pose_edges = nullptr, *edge_of = nullptr;
   unsigned char* stereo = nullptr;
   int* e_dup = nullptr;  // NULL when the window has no duplicate (pose, landmark) edges
+  int* lm_wg = nullptr;  // landmark ranges of b_build_landmarks' workgroups
+  int n_lm_wg = 0;
   size_t used = 0;  // bytes of the arena in use
 };
 
@@ -1593,6 +1616,7 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
     P.pose_edges = (int*)take((size_t)E * 4);
     P.edge_of = (int*)take((size_t)nf * NP * 4);
     P.stereo = take((size_t)E);
+    P.lm_wg = (int*)take((size_t)(NP + 2) * 4);
     P.used = at;  // (grows by the duplicate table below when the window has any)
     P.e_dup = (int*)take((size_t)E * 4);
     GFS_REQUIRE(at <= h->h_stage.n, GFS_ERR_CAPACITY, "gfs_lba: staging arena too small");
@@ -1616,6 +1640,18 @@ int prepare(gfs_lba* h, const gfs_lba_problem* p, HostPrep& P) {
     P.pt_begin[p->edge_point[e] + 1]++;
   }
   for (int l = 0; l < NP; l++) P.pt_begin[l + 1] += P.pt_begin[l];
+  {  // whole landmarks packed into workgroups of at most kMk edges (b_build_landmarks)
+    int nw = 0, l = 0;
+    while (l < NP) {
+      P.lm_wg[nw++] = l;
+      const int base = P.pt_begin[l];
+      int l2 = l + 1;
+      while (l2 < NP && P.pt_begin[l2 + 1] - base <= kMk) l2++;
+      l = l2;
+    }
+    P.lm_wg[nw] = NP;
+    P.n_lm_wg = nw;
+  }
   P.order.assign(E, 0);
   {
     std::vector<int> pos(P.pt_begin, P.pt_begin + NP);
@@ -1686,6 +1722,8 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
   D.edge_of = (const int*)dev(P.edge_of);
   D.e_stereo = (const unsigned char*)dev(P.stereo);
   D.e_dup = P.e_dup ? (const int*)dev(P.e_dup) : nullptr;
+  D.lm_wg = (const int*)dev(P.lm_wg);
+  D.n_lm_wg = P.n_lm_wg;
   D.n_poses = p->n_poses;
   D.n_points = NP;
   D.n_edges = E;
@@ -1799,7 +1837,7 @@ int lba_raise_lds_limits(int device) {
 
 int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volatile const int* stop) {
   hipStream_t s = h->stream;
-  const int NP = p->n_points, E = p->n_edges;
+  const int E = p->n_edges;
   LbaDev D;
   int rc = upload_and_fill(h, p, P, mode, s, D);
   if (rc) return rc;
@@ -1829,13 +1867,13 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   const auto Ta = std::chrono::steady_clock::now();
   int* d_flags = nullptr;
   GFS_HIP(hipHostGetDevicePointer((void**)&d_flags, h->h_flags, 0));
-  const dim3 g_err(D.n_err_blocks), g_lm(gfs::div_up(std::max(NP, 1), 8)), g_upd(D.n_upd_blocks);
+  const dim3 g_err(D.n_err_blocks), g_lm(std::max(D.n_lm_wg, 1)), g_upd(D.n_upd_blocks);
   GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
   const bool lin_only = mode == 1 || p->iterations <= 0;
   if (lin_only) {
     GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
     if (mode == 1) {
-      GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(128), 0, s, D);
+      if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D);
       if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kMk), 0, s, D);
     }
     GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, 1);
@@ -1849,7 +1887,7 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volat
   for (int iteration = 0; iteration < p->iterations; iteration++) {
     if (stop && *stop) break;  // SparseOptimizer::terminate() at the top of the iteration
     GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
-    GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(128), 0, s, D);
+    if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D);
     if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kMk), 0, s, D);
     GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, iteration);
     bool terminate = false;
@@ -1934,7 +1972,7 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   A(h->d_stats.alloc(2));
   A(h->d_info.alloc(2));
   A(h->d_state.alloc(1));
-  A(h->h_stage.alloc(NQ * (32 + 24 + 4) + NP * (24 + 4) + E * (4 + 4 + 24 + 8 + 1 + 4 + 4) + F * (4 + 4 + NP * 4) + 4096));
+  A(h->h_stage.alloc(NQ * (32 + 24 + 4) + NP * (24 + 4) + E * (4 + 4 + 24 + 8 + 1 + 4 + 4) + F * (4 + 4 + NP * 4) + (NP + 2) * 4 + 4096));
   A(h->d_in.alloc(h->h_stage.n));
   A(h->d_out.alloc(E + 7 * NQ + 3 * NP + 4));
   A(h->h_out.alloc(E + 7 * NQ + 3 * NP + 4));
@@ -2131,7 +2169,7 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     max_free = std::max(max_free, D.n_free);
     max_err = std::max(max_err, D.n_err_blocks);
     max_upd = std::max(max_upd, D.n_upd_blocks);
-    max_lm = std::max(max_lm, gfs::div_up(std::max(D.n_points, 1), 8));
+    max_lm = std::max(max_lm, D.n_lm_wg);
     max_iter = std::max(max_iter, problems[w].iterations);
     if (D.schur_mfma) {
       max_mfma_blocks = std::max(max_mfma_blocks, D.n_schur_chunks * D.n_pair_tiles);
@@ -2159,7 +2197,7 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   bool stopped = false;
   for (int round = 0; round < max_rounds; round++) {
     GFS_LAUNCH("kb_lba_errors", kb_lba_errors, dim3(max_err, n), dim3(kMk), 0, s, DD, 0);
-    GFS_LAUNCH("kb_lba_build_landmarks", kb_lba_build_landmarks, dim3(max_lm, n), dim3(128), 0, s, DD);
+    GFS_LAUNCH("kb_lba_build_landmarks", kb_lba_build_landmarks, dim3(max_lm, n), dim3(kMk), 0, s, DD);
     if (max_free > 0) GFS_LAUNCH("kb_lba_build_poses", kb_lba_build_poses, dim3(max_free, n), dim3(kMk), 0, s, DD);
     GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD);
     GFS_LAUNCH("kb_lba_dinv", kb_lba_dinv, dim3(max_upd, n), dim3(kMk), 0, s, DD);
