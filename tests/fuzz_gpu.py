@@ -1,0 +1,121 @@
+"""Randomised parity fuzz on an MI355X against the CPU oracle (not collected by pytest; run it by hand):
+    python tests/fuzz_gpu.py [seconds] [seed]
+voxel-sort permutations (random / tied / raster-like / adversarial keys, 1 .. 50 000 elements) bit-exact, GICP on random cloud
+pairs (sizes, truncations, motions) with equal iteration / inlier counts and the pose within the 1e-5 bar (the largest error is
+printed), ORB on odd image sizes / feature counts / level counts bit-exact, LocalBundleAdjustment windows of random size with
+and without second-camera edges.  Exit code 1 on any failure.  Round 2: 190 k sorts, 1 576 GICP pairs (largest pose error
+6.8e-6: one covariance at an exact k-th-distance tie), 215 ORB frames, 558 LBA windows, no failure."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from geoflowslam_amd import api, synth
+from oracle import oracle as O
+fails = []
+T0 = time.time()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(1234 + seed0)
+
+def vk(x, y, z):
+    return (x.astype(np.uint64) | (y.astype(np.uint64) << np.uint64(21)) | (z.astype(np.uint64) << np.uint64(42)))
+
+# ---- 1. voxel sort
+reg = api.RegistrationGICP(max_points=65536)
+nsort = 0
+while time.time() - T0 < budget * 0.25:
+    n = int(rng.choice([rng.integers(1, 70), rng.integers(70, 1100), rng.integers(1100, 6000), rng.integers(6000, 50000)]))
+    mode = rng.integers(0, 7)
+    if mode == 0:
+        x, y, z = rng.integers(0, 300, n), rng.integers(0, 200, n), rng.integers(0, 6, n)
+    elif mode == 1:
+        m = rng.integers(1, 40); x, y, z = rng.integers(0, m, n), rng.integers(0, 3, n), np.zeros(n, np.int64)
+    elif mode == 2:   # raster-like: sorted runs with local jitter (depth image order)
+        base = np.arange(n) // rng.integers(1, 5); j = rng.integers(-2, 3, n)
+        x, y, z = (base + j) % 700 + 5, (base // 700) + 5, rng.integers(0, 2, n)
+    elif mode == 3:   # sawtooth / organ pipe
+        t = np.arange(n); p = rng.integers(2, 200)
+        x, y, z = np.minimum(t % p, p - t % p) + 3, np.full(n, 4), np.full(n, 5)
+    elif mode == 4:   # adversarial block embedded
+        a = O.antiqsort_keys(min(n, int(rng.integers(20, 1024)))).astype(np.int64) // int(rng.integers(1, 4))
+        rest = rng.integers(0, 5000, max(n - len(a), 0))
+        mix = np.concatenate([rest[:len(rest) // 2], a + 6000, rest[len(rest) // 2:] + 9000])
+        if rng.integers(0, 2): mix = mix[rng.permutation(len(mix))]
+        x, y, z = mix, np.full(len(mix), 2), np.full(len(mix), 2)
+    elif mode == 5:   # wide extent (64-bit path) with ties
+        x, y, z = rng.integers(0, 1 << 16, n), rng.integers(0, 1 << 13, n), rng.integers(0, 1 << 9, n)
+        if n > 6:
+            c = n // 3; x[:c] = x[c:2 * c]; y[:c] = y[c:2 * c]; z[:c] = z[c:2 * c]
+    else:             # few distinct + sorted descending
+        x = np.sort(rng.integers(0, 50, n))[::-1].copy(); y = np.zeros(n, np.int64); z = np.zeros(n, np.int64)
+    k = vk(np.asarray(x) + 1000, np.asarray(y) + 2000, np.asarray(z) + 3000)
+    if rng.integers(0, 3) == 0 and len(k) > 10:
+        k[rng.integers(0, len(k), max(1, len(k) // 40))] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    got = reg.voxel_sort_perm(k); want, _ = O.quick_sort_perm(k)
+    nsort += 1
+    if not np.array_equal(got, want):
+        fails.append(("sort", int(mode), len(k), int((got != want).sum())))
+print("sort cases", nsort, "fails", len(fails), flush=True)
+
+# ---- 2. GICP pairs of random size / motion
+ngicp = 0
+worst = 0.0
+while time.time() - T0 < budget * 0.5:
+    s = int(rng.integers(0, 1 << 30))
+    w, h = int(rng.choice([96, 128, 160, 200])), int(rng.choice([72, 96, 120, 150]))
+    c0, c1, T = synth.cloud_pair(s, w, h, trans=float(rng.uniform(0.0, 0.15)), rot_deg=float(rng.uniform(0, 5)))
+    if rng.integers(0, 4) == 0: c0 = c0[:int(len(c0) * rng.uniform(0.2, 1.0))]
+    if rng.integers(0, 4) == 0: c1 = c1[::int(rng.integers(1, 4))]
+    r = reg.RegisterPointClouds(c0, c1); ro = O.gicp_align(c0, c1)
+    ngicp += 1
+    rel = np.linalg.norm(r["T"] - ro["T"]) / np.linalg.norm(ro["T"])
+    worst = max(worst, float(rel))
+    if not (r["converged"] == ro["converged"] and r["iterations"] == ro["iterations"] and r["num_inliers"] == ro["num_inliers"]
+            and r["n_target_ds"] == ro["n_target_ds"] and r["n_source_ds"] == ro["n_source_ds"] and rel < 1e-5):
+        fails.append(("gicp", s, w, h, len(c0), len(c1), rel, r["iterations"], ro["iterations"], r["num_inliers"], ro["num_inliers"]))
+print("gicp cases", ngicp, "largest pose error", worst, "fails", len(fails), flush=True)
+
+# ---- 3. ORB on odd sizes
+norb = 0
+while time.time() - T0 < budget * 0.7:
+    W, H = int(rng.integers(200, 900)), int(rng.integers(160, 640))
+    nf = int(rng.choice([300, 500, 1000, 1500, 2000])); nl = int(rng.choice([4, 6, 8])); sf = float(rng.choice([1.2, 1.25, 1.5]))
+    s = int(rng.integers(0, 1 << 30))
+    img = synth.frame_pair(s, W, H, 4)["gray0"]
+    if rng.integers(0, 5) == 0: img = (img // 8 * 8).astype(np.uint8)  # flat-ish
+    try:
+        ext = api.ORBextractor(nf, sf, nl, 20, 7, max_rows=H, max_cols=W)
+        _, k, d = ext(img)
+        orc = O.OrbOracle(nf, sf, nl, 20, 7); _, ko, do = orc.extract(img)
+        norb += 1
+        if len(k) != len(ko) or not (k == ko).all() or not (d == do).all():
+            fails.append(("orb", s, W, H, nf, nl, sf, len(k), len(ko)))
+        ext.close() if hasattr(ext, "close") else None
+    except Exception as e:
+        if "unsupported" not in repr(e):
+            fails.append(("orb-exc", s, W, H, nf, nl, sf, repr(e)[:200]))
+print("orb cases", norb, "fails", len(fails), flush=True)
+
+# ---- 4. LBA random windows (+ duplicate edges)
+import test_gpu_lba as TL
+opt = api.Optimizer(max_poses=128, max_points=4096, max_edges=300000)
+nlba = 0
+while time.time() - T0 < budget:
+    s = int(rng.integers(0, 1 << 30))
+    nfree, nfix, npts = int(rng.integers(1, 70)), int(rng.integers(1, 6)), int(rng.integers(10, 1500))
+    w = synth.lba_window(s, n_free=nfree, n_fixed=nfix, n_points=npts, mono_frac=float(rng.choice([0.0, 0.1, 1.0])))
+    if rng.integers(0, 3) == 0: w = TL._with_second_camera_edges(w, s, frac=float(rng.uniform(0.01, 0.3)))
+    if rng.integers(0, 5) == 0: w["iterations"] = int(rng.integers(1, 6))
+    try:
+        r = opt.LocalBundleAdjustment(w); ro = O.lba_solve(w)
+        nlba += 1
+        rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+        if not (r["iterations_run"] == ro["iterations_run"] and rel(r["pose_q"], ro["pose_q"]) < 1e-5 and rel(r["pose_t"], ro["pose_t"]) < 1e-5
+                and rel(r["points"], ro["points"]) < 1e-5 and rel(r["final_chi2"], ro["final_chi2"]) < 1e-6):
+            fails.append(("lba", s, nfree, nfix, npts, w["n_edges"], r["iterations_run"], ro["iterations_run"], rel(r["points"], ro["points"]),
+                          rel(r["final_chi2"], ro["final_chi2"])))
+    except Exception as e:
+        fails.append(("lba-exc", s, nfree, nfix, npts, repr(e)[:200]))
+print("lba cases", nlba, "fails", len(fails), flush=True)
+for f in fails[:40]: print("FAIL", f)
+sys.exit(1 if fails else 0)
