@@ -767,6 +767,52 @@ def main():
                        bytes_in_per_pair=W * H * (1 + 4 + 4), clouds_match_host_built=bool(same),
                        note="per pass: gray image + both depth maps pinned host -> HBM, depth -> cloud on device (gfs_depth_to_cloud_batch_device), "
                             "ORB + match + GMS + GICP, match indices / GMS mask / poses back to pinned host memory; never part of `value`")
+            # the same with the depth maps as the sensor delivers them (CV_16U, 1 / 5000 m): 2 bytes a pixel over PCIe, converted on the
+            # device (imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor), src/Tracking.cc:1622-1623)
+            try:
+                FACT = 1.0 / 5000.0
+                q16 = lambda key: torch.from_numpy(np.stack([np.clip(np.rint(pairs[i][key] * 5000.0), 0, 65535).astype(np.uint16) for i in sel])).pin_memory()
+                h_q0, h_q1 = q16("depth0"), q16("depth1")
+                for ln in lanes:
+                    ln.qq0 = torch.empty((ln.n, H, W), dtype=torch.uint16, device=dev)
+                    ln.qq1 = torch.empty((ln.n, H, W), dtype=torch.uint16, device=dev)
+
+                def gicp_h2d_u16(ln):
+                    with torch.cuda.stream(ln.s2):
+                        ln.qq0.copy_(h_q0[ln.b0:ln.b0 + ln.n], non_blocking=True)
+                        ln.qq1.copy_(h_q1[ln.b0:ln.b0 + ln.n], non_blocking=True)
+                    sp = ln.s2.cuda_stream
+                    ln.frm.depth_convert_u16_batch_device(ln.qq0.data_ptr(), ln.n, H, W, FACT, ln.dd0.data_ptr(), sp)
+                    ln.frm.depth_convert_u16_batch_device(ln.qq1.data_ptr(), ln.n, H, W, FACT, ln.dd1.data_ptr(), sp)
+                    ln.frm.depth_to_cloud_batch_device(ln.dd0.data_ptr(), ln.n, H, W, STRIDE, fx, fy, cx_, cy_, ln.cc0.data_ptr(), SP, ln.nn0.data_ptr(), sp)
+                    ln.frm.depth_to_cloud_batch_device(ln.dd1.data_ptr(), ln.n, H, W, STRIDE, fx, fy, cx_, cy_, ln.cc1.data_ptr(), SP, ln.nn1.data_ptr(), sp)
+                    ln.gicp_out = ln.reg.align_batch_device(ln.cc0.data_ptr(), ln.nn0.data_ptr(), ln.cc1.data_ptr(), ln.nn1.data_ptr(), ln.n, SP,
+                                                            None, None, sp, raw=True)
+
+                def u16_steps(k):
+                    def chain(f, *a):
+                        for _ in range(k):
+                            f(*a)
+                    futs = [pool.submit(chain, orb_h2d, ln, hr) for ln, hr in zip(lanes, h_res)] + [pool.submit(chain, gicp_h2d_u16, ln) for ln in lanes]
+                    for f in futs:
+                        f.result()
+
+                u16_steps(2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                u16_steps(kh)
+                torch.cuda.synchronize()
+                dtu = (time.perf_counter() - t1) / kh
+                ln0_ = lanes[0]
+                want = [int((((q := h_q1[ln0_.b0 + j].numpy().astype(np.float32) * np.float32(FACT))[::STRIDE, ::STRIDE] > 0) & (q[::STRIDE, ::STRIDE] < 10)).sum())
+                        for j in range(min(4, ln0_.n))]
+                h2d["u16_depth"] = dict(value=round(B / dtu, 1), unit="frames/s", ms_per_step=round(dtu * 1e3, 3), bytes_in_per_pair=W * H * (1 + 2 + 2),
+                                        cloud_sizes_match_host=bool(want == ln0_.nn1.cpu().tolist()[:len(want)]),
+                                        note="depth maps as CV_16U (1/5000 m) over PCIe, gfs_depth_convert_u16_batch_device on arrival")
+                for ln in lanes:
+                    del ln.qq0, ln.qq1
+            except Exception as e:
+                h2d["u16_depth"] = dict(error=f"{type(e).__name__}: {e}")
             for ln in lanes:
                 del ln.dd0, ln.dd1, ln.gg, ln.cc0, ln.cc1
         except Exception as e:

@@ -187,7 +187,7 @@ ABI_SYMBOLS = [
     "gfs_gicp_fetch_preprocessed", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort",
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize", "gfs_lba_batch_create", "gfs_lba_batch_destroy",
     "gfs_lba_solve_batch",
-    "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_stereo_from_rgbd",
+    "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_depth_convert_u16_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
     "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
     "gfs_gms_create", "gfs_gms_destroy", "gfs_gms_inlier_mask", "gfs_gms_inlier_mask_batch_device",
@@ -256,6 +256,7 @@ def lib():
             L.gfs_frame_destroy.argtypes = [vp]
             L.gfs_depth_to_cloud.argtypes = [vp, vp, i, i, i, i, f, f, f, f, vp, i, ip]
             L.gfs_depth_to_cloud_batch_device.argtypes = [vp, vp, i, i, i, i, f, f, f, f, vp, i, vp, vp]
+            L.gfs_depth_convert_u16_batch_device.argtypes = [vp, vp, i, i, i, f, vp, vp]
             L.gfs_stereo_from_rgbd.argtypes = [vp, vp, vp, i, vp, i, i, i, f, vp, vp]
             L.gfs_stereo_from_rgbd_batch_device.argtypes = [vp, vp, vp, vp, i, i, vp, i, i, f, vp, vp, vp]
         if hasattr(L, "gfs_klt_create"):
@@ -1037,6 +1038,11 @@ class Frame:
         _check(lib().gfs_stereo_from_rgbd(self.h, _p(kps), _p(unx), n, _p(depth), depth.shape[0], depth.shape[1], depth.shape[1],
                                           bf, _p(ur), _p(vd)), "gfs_stereo_from_rgbd")
         return ur[:n], vd[:n]
+
+    def depth_convert_u16_batch_device(self, d_u16, B, rows, cols, factor, d_f32, stream=None):
+        """imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) for CV_16U depth maps already in HBM (src/Tracking.cc:1622-1623)"""
+        _check(lib().gfs_depth_convert_u16_batch_device(self.h, C.c_void_p(d_u16), B, rows, cols, float(factor), C.c_void_p(d_f32),
+                                                        C.c_void_p(stream) if stream else None), "gfs_depth_convert_u16_batch_device")
 
     def depth_to_cloud_batch_device(self, d_depth, B, rows, cols, ds, fx, fy, cx, cy, d_out, stride_pts, d_counts, stream=None):
         _check(lib().gfs_depth_to_cloud_batch_device(self.h, C.c_void_p(d_depth), B, rows, cols, ds, fx, fy, cx, cy,

@@ -57,6 +57,20 @@ __global__ __launch_bounds__(1024) void k_depth_to_cloud(const float* __restrict
   if (tid == 0) counts[b] = s_carry;  // may exceed stride_pts: the host entry reports GFS_ERR_CAPACITY
 }
 
+// imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) on a CV_16U sensor image (reference src/Tracking.cc:1622-1623; OpenCV
+// cvtScale16u32f: float(src) * float(alpha) + 0 in single precision, one rounding with or without FMA)
+__global__ __launch_bounds__(256) void k_depth_u16_to_f32(const unsigned short* __restrict__ src, size_t n, float factor,
+                                                          float* __restrict__ dst) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {  // (the batches are rows x cols x B: eight-byte aligned groups of four)
+    const ushort4 v = *reinterpret_cast<const ushort4*>(src + i);
+    *reinterpret_cast<float4*>(dst + i) = make_float4(__fmul_rn((float)v.x, factor), __fmul_rn((float)v.y, factor),
+                                                       __fmul_rn((float)v.z, factor), __fmul_rn((float)v.w, factor));
+  } else {
+    for (size_t k = i; k < n; k++) dst[k] = __fmul_rn((float)src[k], factor);
+  }
+}
+
 __global__ void k_stereo_from_rgbd(const gfs_keypoint* __restrict__ kps, const float* __restrict__ kps_un_x,
                                    const int* __restrict__ n_arr, int kp_stride, const float* __restrict__ depth,
                                    size_t frame_stride, int pitch, float bf, float* __restrict__ u_right,
@@ -132,6 +146,20 @@ int gfs_depth_to_cloud_batch_device(gfs_frame* h, const void* dev_depth, int B, 
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   GFS_LAUNCH("k_depth_to_cloud", k_depth_to_cloud, dim3(B), dim3(1024), 0, s, (const float*)dev_depth, (size_t)rows * cols, rows,
              cols, cols, downsample, fx, fy, cx, cy, (float4*)dev_out_xyzw, stride_pts, (int*)dev_counts);
+  return GFS_OK;
+}
+
+int gfs_depth_convert_u16_batch_device(gfs_frame* h, const void* dev_depth_u16, int B, int rows, int cols, float factor,
+                                       void* dev_depth_f32, void* stream) {
+  GFS_REQUIRE(h && dev_depth_u16 && dev_depth_f32 && B > 0 && rows > 0 && cols > 0, GFS_ERR_INVALID_ARG,
+              "gfs_depth_convert_u16_batch_device: invalid argument");
+  GFS_REQUIRE(((uintptr_t)dev_depth_u16 & 7) == 0 && ((uintptr_t)dev_depth_f32 & 15) == 0, GFS_ERR_INVALID_ARG,
+              "gfs_depth_convert_u16_batch_device: buffers must be 8 / 16 byte aligned");
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const size_t n = (size_t)B * rows * cols;
+  GFS_LAUNCH("k_depth_u16_to_f32", k_depth_u16_to_f32, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s,
+             (const unsigned short*)dev_depth_u16, n, factor, (float*)dev_depth_f32);
   return GFS_OK;
 }
 

@@ -286,6 +286,11 @@ int gfs_depth_to_cloud(gfs_frame* h, const float* depth, int rows, int cols, int
 int gfs_depth_to_cloud_batch_device(gfs_frame* h, const void* dev_depth, int B, int rows, int cols, int downsample, float fx,
                                     float fy, float cx, float cy, void* dev_out_xyzw, int stride_pts, void* dev_counts,
                                     void* stream);
+/* imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) for a CV_16U sensor image (src/Tracking.cc:1622-1623), on the device: the
+ * depth maps then cross PCIe as 2 bytes a pixel.  dev_depth_u16 [B][rows][cols] u16 (8-byte aligned) -> dev_depth_f32 (16-byte
+ * aligned), float(raw) * factor in single precision like cv::Mat::convertTo. */
+int gfs_depth_convert_u16_batch_device(gfs_frame* h, const void* dev_depth_u16, int B, int rows, int cols, float factor,
+                                       void* dev_depth_f32, void* stream);
 /* mvDepth[i] = d = imDepth.at<float>(kp.pt.y, kp.pt.x) (float -> int truncation), mvuRight[i] = kpUn.pt.x - bf / d when
  * d > 0, else both -1.  kps_un_x may be NULL (no distortion: mvKeysUn == mvKeys). */
 int gfs_stereo_from_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x, int n, const float* depth, int rows,

@@ -45,3 +45,37 @@ def test_gpu_depth_to_cloud_and_stereo(gpu_api, oracle):
     uo, vo = oracle.stereo_from_rgbd(kps, fp["depth0"], bf)
     assert (ur.view(np.uint32) == uo.view(np.uint32)).all() and (vd.view(np.uint32) == vo.view(np.uint32)).all()
     assert (vd == -1).any() or (fp["depth0"] > 0).all()
+
+
+@pytest.mark.gpu
+def test_gpu_u16_depth_conversion_is_convert_to(gpu_api, oracle):
+    """gfs_depth_convert_u16_batch_device = imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) (src/Tracking.cc:1622-1623):
+    float(raw) * float(factor), one rounding (cvtScale16u32f computes src * a + b in float with b = 0); then the cloud of the
+    converted map equals the oracle's cloud of the host-converted map, bit for bit."""
+    from test_gpu_gms import _Hip
+    hip = _Hip()
+    try:
+        fr = gpu_api.Frame(max_rows=480, max_cols=640)
+        rng = np.random.default_rng(3)
+        for B, h, w, factor in ((3, 480, 640, 1.0 / 5000.0), (1, 37, 52, 0.001), (2, 120, 160, 1.0)):
+            raw = rng.integers(0, 65536, (B, h, w), dtype=np.uint16)
+            raw[:, ::7] = 0
+            d_raw = hip.to_device(raw)
+            d_f = hip.to_device(np.zeros((B, h, w), np.float32))
+            fr.depth_convert_u16_batch_device(d_raw, B, h, w, factor, d_f)
+            got = hip.to_host(d_f, (B, h, w), np.float32)
+            want = raw.astype(np.float32) * np.float32(factor)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # ... and on into the cloud
+        fx, fy, cx, cy = (float(np.float32(v)) for v in synth.intrinsics(640, 480))
+        raw = np.clip(np.rint(_depth(9, 640, 480) * 5000.0), 0, 65535).astype(np.uint16)[None]
+        d_raw, d_f = hip.to_device(raw), hip.to_device(np.zeros((1, 480, 640), np.float32))
+        fr.depth_convert_u16_batch_device(d_raw, 1, 480, 640, 1.0 / 5000.0, d_f)
+        cap = 32768
+        d_out, d_cnt = hip.to_device(np.zeros((cap, 4), np.float32)), hip.to_device(np.zeros(1, np.int32))
+        fr.depth_to_cloud_batch_device(d_f, 1, 480, 640, 4, fx, fy, cx, cy, d_out, cap, d_cnt)
+        n = int(hip.to_host(d_cnt, 1, np.int32)[0])
+        co = oracle.depth_to_cloud(raw[0].astype(np.float32) * np.float32(1.0 / 5000.0), 4, fx, fy, cx, cy)
+        assert n == len(co) and np.array_equal(hip.to_host(d_out, (cap, 4), np.float32)[:n].view(np.uint32), co.view(np.uint32))
+    finally:
+        hip.free()
