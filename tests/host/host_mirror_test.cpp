@@ -1,6 +1,6 @@
 // Test harness for the plain-container mirror of the reference's classes (namespace gfs_host, geoflowslam_amd/host/gfs_adaptors.hpp):
 // ORBextractor::operator(), ORBmatcher::DescriptorDistance / match, RegistrationGICP::RegisterPointClouds / RegisterNext and
-// GmsMatcher::GetInlierMask are driven from C++ exactly as a maintainer's adaptor would drive them, and hand their results back to
+// GmsMatcher::GetInlierMask, ProjectionMatcher::SearchByProjection and PoseOptimizer::PoseOptimization are driven from C++ exactly as a maintainer's adaptor would drive them, and hand their results back to
 // the Python test (tests/test_gpu_host_mirror.py), which compares them with the oracle.
 #include <cstring>
 
@@ -74,6 +74,27 @@ int hm_gms(const gfs_keypoint* k1, int n1, int w1, int h1, const gfs_keypoint* k
     const int nin = g.GetInlierMask(k1, n1, w1, h1, k2, n2, w2, h2, q, t, m);
     if (nm) memcpy(mask, m.data(), (size_t)nm);
     return nin;
+  } catch (const std::exception&) {
+    return -2000;
+  }
+}
+
+int hm_sbp(const gfs_sbp_problem* p, int32_t* cur_match) {
+  try {
+    gfs_host::ProjectionMatcher pm(8192, 4096);
+    std::vector<int32_t> m;
+    const int n = pm.SearchByProjection(*p, m);
+    if (!m.empty()) memcpy(cur_match, m.data(), m.size() * sizeof(int32_t));
+    return n;
+  } catch (const std::exception&) {
+    return -2000;
+  }
+}
+
+int hm_pose(const gfs_pose_problem* p, gfs_pose_solution* s) {
+  try {
+    gfs_host::PoseOptimizer po(8192);
+    return po.PoseOptimization(*p, *s);
   } catch (const std::exception&) {
     return -2000;
   }

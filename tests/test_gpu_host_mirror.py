@@ -1,6 +1,7 @@
 """The C++ host mirror of the reference's classes (namespace gfs_host, geoflowslam_amd/host/gfs_adaptors.hpp) driven from C++
 (tests/host/host_mirror_test.cpp, built here with g++ against libgfs_hip.so): ORBextractor::operator() with its tables and
-lapping area, ORBmatcher::match / DescriptorDistance, RegistrationGICP::RegisterPointClouds / RegisterNext, GmsMatcher — against
+lapping area, ORBmatcher::match / DescriptorDistance, RegistrationGICP::RegisterPointClouds / RegisterNext, GmsMatcher,
+ProjectionMatcher, PoseOptimizer — against
 the CPU oracle."""
 import ctypes as C
 import os
@@ -84,3 +85,19 @@ def test_registration_gicp_and_streaming_form(harness, gpu_api, oracle):
         T = np.array(r.T[:]).reshape(4, 4).T
         assert bool(r.converged) == ro["converged"] and int(r.iterations) == ro["iterations"] and int(r.num_inliers) == ro["num_inliers"]
         assert np.linalg.norm(T - ro["T"]) / np.linalg.norm(ro["T"]) < 1e-6
+
+
+def test_projection_matcher_and_pose_optimizer(harness, gpu_api, oracle):
+    from geoflowslam_amd import api as A
+    q = synth.sbp_pair(41, n_points=700, n_extra_cur=200, dup_frac=0.2, zero_obs_frac=0.3)
+    P, keep = A.sbp_struct(q)
+    out = np.full(max(P.n_cur, 1), -9, np.int32)
+    n = harness.hm_sbp(C.byref(P), _p(out))
+    mo, no = oracle.search_by_projection(q)
+    assert n == no and np.array_equal(out[:P.n_cur], mo)
+    f = synth.pose_frame(42, n_obs=400, outlier_frac=0.15)
+    PP, SS, keep2, nobs = A.pose_structs(f)
+    ninl = harness.hm_pose(C.byref(PP), C.byref(SS))
+    r, ro = A.pose_result(SS, keep2, nobs), oracle.pose_optimization(f)
+    assert ninl == ro["n_inliers"] and np.array_equal(r["outlier"], ro["outlier"]) and r["rounds_run"] == ro["rounds_run"]
+    assert np.linalg.norm(r["q"] - ro["q"]) < 1e-5 * np.linalg.norm(ro["q"]) and np.linalg.norm(r["t"] - ro["t"]) < 1e-5 * max(np.linalg.norm(ro["t"]), 1e-30)
