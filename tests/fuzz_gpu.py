@@ -19,13 +19,23 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(1234 + seed0)
 
+
+def case_rng(section, index):  # a case's draws depend on (seed, section, index) only: any failure can be replayed
+    return np.random.default_rng([1234 + seed0, section, index])
+
+
+ONLY = None  # "section:index" as the third argument replays one case
+if len(sys.argv) > 3:
+    ONLY = tuple(int(v) for v in sys.argv[3].split(":"))
+
 def vk(x, y, z):
     return (x.astype(np.uint64) | (y.astype(np.uint64) << np.uint64(21)) | (z.astype(np.uint64) << np.uint64(42)))
 
 # ---- 1. voxel sort
 reg = api.RegistrationGICP(max_points=65536)
 nsort = 0
-while time.time() - T0 < budget * 0.25:
+while time.time() - T0 < budget * 0.25 and ONLY is None:
+    rng = case_rng(1, nsort)
     n = int(rng.choice([rng.integers(1, 70), rng.integers(70, 1100), rng.integers(1100, 6000), rng.integers(6000, 50000)]))
     mode = rng.integers(0, 7)
     if mode == 0:
@@ -56,17 +66,20 @@ while time.time() - T0 < budget * 0.25:
     got = reg.voxel_sort_perm(k); want, _ = O.quick_sort_perm(k)
     nsort += 1
     if not np.array_equal(got, want):
-        fails.append(("sort", int(mode), len(k), int((got != want).sum())))
+        fails.append(("sort", "case 1:%d" % (nsort - 1), int(mode), len(k), int((got != want).sum())))
 print("sort cases", nsort, "fails", len(fails), flush=True)
 
 # ---- 2. GICP pairs of random size / motion
 ngicp = 0
 worst = 0.0
 tie_cases = []
-while time.time() - T0 < budget * 0.5:
+while (time.time() - T0 < budget * 0.5 and ONLY is None) or (ONLY is not None and ONLY[0] == 2 and ngicp == 0):
+    ci = ngicp if ONLY is None else ONLY[1]
+    rng = case_rng(2, ci)
     s = int(rng.integers(0, 1 << 30))
     w, h = int(rng.choice([96, 128, 160, 200])), int(rng.choice([72, 96, 120, 150]))
-    c0, c1, T = synth.cloud_pair(s, w, h, trans=float(rng.uniform(0.0, 0.15)), rot_deg=float(rng.uniform(0, 5)))
+    tr_, rd_ = float(rng.uniform(0.0, 0.15)), float(rng.uniform(0, 5))
+    c0, c1, T = synth.cloud_pair(s, w, h, trans=tr_, rot_deg=rd_)
     if rng.integers(0, 4) == 0: c0 = c0[:int(len(c0) * rng.uniform(0.2, 1.0))]
     if rng.integers(0, 4) == 0: c1 = c1[::int(rng.integers(1, 4))]
     r = reg.RegisterPointClouds(c0, c1); ro = O.gicp_align(c0, c1)
@@ -88,14 +101,17 @@ while time.time() - T0 < budget * 0.5:
                 _, sq = O.knn(po[io], po[io], 11)
                 nt += int((sq[:, 9] == sq[:, 10]).sum())
         if same and nt > 0 and rel < 5e-5 and abs(int(r["num_inliers"]) - int(ro["num_inliers"])) <= 2 and abs(int(r["iterations"]) - int(ro["iterations"])) <= 1:
-            tie_cases.append((s, w, h, float(rel), nt))
+            tie_cases.append(("case 2:%d" % ci, float(rel), nt))
         else:
-            fails.append(("gicp", s, w, h, len(c0), len(c1), rel, r["iterations"], ro["iterations"], r["num_inliers"], ro["num_inliers"], nt, same))
+            fails.append(("gicp", "case 2:%d" % ci, s, w, h, tr_, rd_, len(c0), len(c1), rel, r["iterations"], ro["iterations"], r["num_inliers"], ro["num_inliers"], nt, same))
 print("gicp cases", ngicp, "largest pose error", worst, "pairs over the bar through a k-th-distance tie", tie_cases, "fails", len(fails), flush=True)
 
 # ---- 3. ORB on odd sizes
 norb = 0
-while time.time() - T0 < budget * 0.7:
+i3 = 0
+while time.time() - T0 < budget * 0.7 and ONLY is None:
+    rng = case_rng(3, i3)
+    i3 += 1
     W, H = int(rng.integers(200, 900)), int(rng.integers(160, 640))
     nf = int(rng.choice([300, 500, 1000, 1500, 2000])); nl = int(rng.choice([4, 6, 8])); sf = float(rng.choice([1.2, 1.25, 1.5]))
     s = int(rng.integers(0, 1 << 30))
@@ -107,7 +123,7 @@ while time.time() - T0 < budget * 0.7:
         orc = O.OrbOracle(nf, sf, nl, 20, 7); _, ko, do = orc.extract(img)
         norb += 1
         if len(k) != len(ko) or not (k == ko).all() or not (d == do).all():
-            fails.append(("orb", s, W, H, nf, nl, sf, len(k), len(ko)))
+            fails.append(("orb", "case 3:%d" % (i3 - 1), s, W, H, nf, nl, sf, len(k), len(ko)))
         ext.close() if hasattr(ext, "close") else None
     except Exception as e:
         if "unsupported" not in repr(e):
@@ -118,7 +134,10 @@ print("orb cases", norb, "fails", len(fails), flush=True)
 import test_gpu_lba as TL
 opt = api.Optimizer(max_poses=128, max_points=4096, max_edges=300000)
 nlba = 0
-while time.time() - T0 < budget:
+i4 = 0
+while time.time() - T0 < budget and ONLY is None:
+    rng = case_rng(4, i4)
+    i4 += 1
     s = int(rng.integers(0, 1 << 30))
     nfree, nfix, npts = int(rng.integers(1, 70)), int(rng.integers(1, 6)), int(rng.integers(10, 1500))
     w = synth.lba_window(s, n_free=nfree, n_fixed=nfix, n_points=npts, mono_frac=float(rng.choice([0.0, 0.1, 1.0])))
@@ -130,7 +149,7 @@ while time.time() - T0 < budget:
         rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
         if not (r["iterations_run"] == ro["iterations_run"] and rel(r["pose_q"], ro["pose_q"]) < 1e-5 and rel(r["pose_t"], ro["pose_t"]) < 1e-5
                 and rel(r["points"], ro["points"]) < 1e-5 and rel(r["final_chi2"], ro["final_chi2"]) < 1e-6):
-            fails.append(("lba", s, nfree, nfix, npts, w["n_edges"], r["iterations_run"], ro["iterations_run"], rel(r["points"], ro["points"]),
+            fails.append(("lba", "case 4:%d" % (i4 - 1), s, nfree, nfix, npts, w["n_edges"], r["iterations_run"], ro["iterations_run"], rel(r["points"], ro["points"]),
                           rel(r["final_chi2"], ro["final_chi2"])))
     except Exception as e:
         fails.append(("lba-exc", s, nfree, nfix, npts, repr(e)[:200]))
@@ -145,7 +164,10 @@ mt = api.ORBmatcher()
 fm = api.FundamentalMatcher(max_points=2048, max_batch=1)
 ext = api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=480, max_cols=640)
 trk = api.KltTracker(640, 480, 35, max_batch=1, max_points=2048)
-while time.time() - T1 < extra:
+i5 = 0
+while time.time() - T1 < extra and ONLY is None:
+    rng = case_rng(5, i5)
+    i5 += 1
     s = int(rng.integers(0, 1 << 30))
     which = int(rng.integers(0, 5))
     try:
@@ -155,7 +177,7 @@ while time.time() - T1 < extra:
                                dup_frac=float(rng.uniform(0, 0.5)), zero_obs_frac=float(rng.uniform(0, 1)), preassigned_frac=float(rng.uniform(0, 0.2)))
             m, n = pm.SearchByProjection(q); mo, no = O.search_by_projection(q)
             nx["sbp"] += 1
-            if n != no or not np.array_equal(m, mo): fails.append(("sbp", s, n, no))
+            if n != no or not np.array_equal(m, mo): fails.append(("sbp", "case 5:%d" % (i5 - 1), s, n, no))
         elif which == 1:
             q = synth.pose_frame(s, n_obs=int(rng.integers(0, 1500)), mono_frac=float(rng.choice([0.0, 0.15, 1.0])), outlier_frac=float(rng.uniform(0, 0.4)),
                                  rot_deg=float(rng.uniform(0, 3)), trans=float(rng.uniform(0, 0.1)))
@@ -167,14 +189,14 @@ while time.time() - T1 < extra:
             nx["pose_iteration_counts_differ"] = nx.get("pose_iteration_counts_differ", 0) + (r["iterations_run"] != ro["iterations_run"])
             if not (np.array_equal(r["outlier"], ro["outlier"]) and r["n_inliers"] == ro["n_inliers"] and r["rounds_run"] == ro["rounds_run"]
                     and abs(r["iterations_run"] - ro["iterations_run"]) <= 4 and rel(r["q"], ro["q"]) < 1e-5 and rel(r["t"], ro["t"]) < 1e-5):
-                fails.append(("pose", s, q["n_obs"], r["n_inliers"], ro["n_inliers"], r["iterations_run"], ro["iterations_run"]))
+                fails.append(("pose", "case 5:%d" % (i5 - 1), s, q["n_obs"], r["n_inliers"], ro["n_inliers"], r["iterations_run"], ro["iterations_run"]))
         elif which == 2:
             nq, nt = int(rng.integers(0, 3000)), int(rng.integers(0, 3000))
             dq = rng.integers(0, 256, (nq, 32), dtype=np.uint8); dt = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
             if nq and nt and rng.integers(0, 2): dt[rng.integers(0, nt, nt // 3)] = dq[rng.integers(0, nq, nt // 3)]  # exact duplicates: distance ties
             ti, di = mt.match(dq, dt); to, do = O.bf_match(dq, dt)
             nx["match"] += 1
-            if not (np.array_equal(ti, to) and np.array_equal(di, do)): fails.append(("match", s, nq, nt))
+            if not (np.array_equal(ti, to) and np.array_equal(di, do)): fails.append(("match", "case 5:%d" % (i5 - 1), s, nq, nt))
         elif which == 3:
             fp = synth.frame_pair(s, 640, 480, 8)
             _, k0, _ = ext(fp["gray0"])
@@ -186,7 +208,7 @@ while time.time() - T1 < extra:
             g = trk.fbKltTracking(p0, p1, lvl, 15.0, 0.5, kps, pri); o = O.fb_klt_tracking(o0, o1, 640, 480, 35, lvl, 15.0, 0.5, kps, pri)
             nx["klt"] += 1
             if not (g[2] == o[2] and np.array_equal(g[1], o[1]) and np.array_equal(g[0].view(np.uint32), o[0].view(np.uint32))):
-                fails.append(("klt", s, lvl, g[2], o[2]))
+                fails.append(("klt", "case 5:%d" % (i5 - 1), s, lvl, g[2], o[2]))
         else:
             n = int(rng.integers(8, 1500))
             a, b, _, _ = synth.two_view_points(s, n, float(rng.uniform(0, 0.7)), float(rng.uniform(0, 1.0)))
@@ -194,9 +216,9 @@ while time.time() - T1 < extra:
             g = fm.findFundamentalMat(a, b, thr, conf); o = O.fundamental_ransac(a, b, thr, conf)
             nx["fmat"] += 1
             same_F = (g[1] is None) == (o[1] is None) and (g[1] is None or np.array_equal(g[1].view(np.uint64), o[1].view(np.uint64)))
-            if not (g[2] == o[2] and np.array_equal(g[0], o[0]) and same_F): fails.append(("fmat", s, n, thr, conf, g[2], o[2]))
+            if not (g[2] == o[2] and np.array_equal(g[0], o[0]) and same_F): fails.append(("fmat", "case 5:%d" % (i5 - 1), s, n, thr, conf, g[2], o[2]))
     except Exception as e:
-        fails.append(("next-exc", which, s, repr(e)[:200]))
+        fails.append(("next-exc", "case 5:%d" % (i5 - 1), which, s, repr(e)[:200]))
 print("next rows", nx, "fails", len(fails), flush=True)
 for f in fails[:40]: print("FAIL", f)
 sys.exit(1 if fails else 0)

@@ -136,6 +136,28 @@ def test_several_edges_between_one_pose_and_one_point(gpu_api, oracle, cfg):
         assert np.array_equal(rb[k], r[k]), k
 
 
+def test_lba_batch_with_degenerate_windows(gpu_api, oracle):
+    """A batch mixing ordinary windows with the degenerate ones: every pose fixed (only landmarks move), zero iterations (estimates
+    untouched), a single free pose, a tiny window — each equal, bit for bit, to the same window solved alone."""
+    base = synth.lba_window(4, n_free=3, n_fixed=2, n_points=50)
+    all_fixed = dict(base, pose_fixed=np.ones_like(base["pose_fixed"]))
+    zero_it = dict(base, iterations=0)
+    wins = [synth.lba_window(31, n_free=12, n_fixed=3, n_points=800), all_fixed, zero_it, synth.lba_window(32, n_free=1, n_fixed=2, n_points=40),
+            synth.lba_window(33, n_free=2, n_fixed=1, n_points=12), synth.lba_window(34, n_free=24, n_fixed=2, n_points=300)]
+    bat = gpu_api.BatchOptimizer(max_windows=len(wins), max_poses=32, max_points=1024, max_edges=32768)
+    got = bat.LocalBundleAdjustment(wins)
+    one = gpu_api.Optimizer(max_poses=32, max_points=1024, max_edges=32768)
+    for w, r in zip(wins, got):
+        r1 = one.LocalBundleAdjustment(w)
+        for k in ("pose_q", "pose_t", "points", "edge_chi2", "edge_depth_positive"):
+            assert np.array_equal(r[k], r1[k]), k
+        assert r["iterations_run"] == r1["iterations_run"]
+    assert got[2]["iterations_run"] == 0 and np.allclose(got[2]["points"], base["points"])
+    assert (got[1]["pose_t"] == base["pose_t"]).all()
+    of = oracle.lba_solve(all_fixed)
+    assert _rel(got[1]["points"], of["points"]) < 1e-5
+
+
 def test_lba_batched_windows_match_oracle_and_single(gpu_api, oracle):
     """gfs_lba_solve_batch: windows of different sizes (3 ... 20 free key-frames, 80 ... 3000 points, different iteration
     counts and numbers of rejected trials) solved together; every window against the oracle and, bit for bit, against the same
