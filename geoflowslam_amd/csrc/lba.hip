@@ -1613,11 +1613,23 @@ __global__ __launch_bounds__(kMk) void kb_lba_build_poses(const LbaDev* __restri
   GFS_LBAB_PROLOGUE(0, D.n_free)
   b_build_poses(D, blockIdx.x, need);
 }
-__global__ __launch_bounds__(kThreads) void kb_lba_begin(const LbaDev* __restrict__ DD) {
+__global__ __launch_bounds__(kThreads) void kb_lba_begin(const LbaDev* __restrict__ DD, int* __restrict__ n_done) {
   GFS_LBAB_PROLOGUE(0, 1)
   b_begin(D, blockIdx.x, need, D.S->it);
   __syncthreads();
-  if (threadIdx.x == 0) D.S->phase = 1;  // the build group is complete for this window: trials follow
+  if (threadIdx.x == 0) {
+    LbaState& S = *D.S;
+    if (D.iterations <= 0) {
+      // optimize(0): the errors have been evaluated, nothing else happens to this window (what gfs_lba_solve reports for it:
+      // the chi2 of the initial estimate, lambda 0, no iteration)
+      S.last_chi = S.current_chi;
+      S.lambda = 0;
+      S.phase = 2;
+      atomicAdd(n_done, 1);
+    } else {
+      S.phase = 1;  // the build group is complete for this window: trials follow
+    }
+  }
 }
 __global__ __launch_bounds__(kMk) void kb_lba_dinv(const LbaDev* __restrict__ DD) {
   GFS_LBAB_PROLOGUE(1, D.n_upd_blocks)
@@ -2327,14 +2339,13 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   const auto T2 = now();
   int rounds_run = 0;
   GFS_LAUNCH("kb_lba_init", kb_lba_init, dim3(64, n), dim3(kMk), 0, s, DD);
-  // windows with iterations <= 0 finish at once (optimize(0) leaves the estimate alone): handled by max_rounds = 0 below
-  const int max_rounds = max_iter > 0 ? max_iter * 11 + 1 : 0;
+  const int max_rounds = std::max(max_iter, 0) * 11 + 1;  // (windows with iterations <= 0 leave in the first round, after the errors)
   bool stopped = false;
   for (int round = 0; round < max_rounds; round++) {
     GFS_LAUNCH("kb_lba_errors", kb_lba_errors, dim3(max_err, n), dim3(kMk), 0, s, DD, 0);
     GFS_LAUNCH("kb_lba_build_landmarks", kb_lba_build_landmarks, dim3(max_lm, n), dim3(kMk), 0, s, DD);
     if (max_free > 0) GFS_LAUNCH("kb_lba_build_poses", kb_lba_build_poses, dim3(max_free, n), dim3(kMk), 0, s, DD);
-    GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD);
+    GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD, b->d_done.p);
     GFS_LAUNCH("kb_lba_dinv", kb_lba_dinv, dim3(max_upd, n), dim3(kMk), 0, s, DD);
     if (max_mfma_blocks > 0) {
       if (one_block)

@@ -151,8 +151,13 @@ def test_lba_batch_with_degenerate_windows(gpu_api, oracle):
         r1 = one.LocalBundleAdjustment(w)
         for k in ("pose_q", "pose_t", "points", "edge_chi2", "edge_depth_positive"):
             assert np.array_equal(r[k], r1[k]), k
-        assert r["iterations_run"] == r1["iterations_run"]
+        assert r["iterations_run"] == r1["iterations_run"] and r["final_chi2"] == r1["final_chi2"] and r["final_lambda"] == r1["final_lambda"]
     assert got[2]["iterations_run"] == 0 and np.allclose(got[2]["points"], base["points"])
+    # ... and a batch of nothing but zero-iteration windows still evaluates the errors
+    only0 = bat.LocalBundleAdjustment([zero_it, zero_it])
+    r1 = one.LocalBundleAdjustment(zero_it)
+    for r in only0:
+        assert r["iterations_run"] == 0 and np.array_equal(r["edge_chi2"], r1["edge_chi2"]) and r["final_chi2"] == r1["final_chi2"]
     assert (got[1]["pose_t"] == base["pose_t"]).all()
     of = oracle.lba_solve(all_fixed)
     assert _rel(got[1]["points"], of["points"]) < 1e-5
