@@ -96,6 +96,34 @@ def test_stop_flag_raised_while_solving(gpu_api, oracle):
         assert r["final_chi2"] <= chi0 * (1 + 1e-12)
 
 
+def test_stop_flag_raised_while_a_batch_is_solving(gpu_api, oracle):
+    """the same for gfs_lba_solve_batch: every window closes its running iteration and returns what it has"""
+    import threading
+    import time
+    wins = [synth.lba_window(60 + k, n_free=20, n_fixed=5, n_points=2500) for k in range(6)]
+    bat = gpu_api.BatchOptimizer(max_windows=len(wins), max_poses=32, max_points=4096, max_edges=65536)
+    full = bat.LocalBundleAdjustment(wins)
+    flag = np.zeros(1, np.int32)
+
+    def raiser():
+        time.sleep(0.002)
+        flag[0] = 1
+
+    t = threading.Thread(target=raiser)
+    t.start()
+    got = bat.LocalBundleAdjustment(wins, stop_flag=flag)
+    t.join()
+    for w, r, f in zip(wins, got, full):
+        assert 0 <= r["iterations_run"] <= f["iterations_run"]
+        assert np.isfinite(r["points"]).all() and np.isfinite(r["pose_t"]).all() and np.isfinite(r["pose_q"]).all()
+        if r["iterations_run"] < f["iterations_run"]:
+            assert r["final_chi2"] <= oracle.lba_linearize(w)["chi2"] * (1 + 1e-12)
+    # the handle is usable afterwards
+    again = bat.LocalBundleAdjustment(wins)
+    for a, f in zip(again, full):
+        assert np.array_equal(a["points"], f["points"]) and a["iterations_run"] == f["iterations_run"]
+
+
 def _with_second_camera_edges(w, seed, frac=0.15):
     """the window with a second edge between some (key-frame, point) pairs, the way a two-camera rig adds a right-camera
     observation of a point the left camera sees too (src/Optimizer.cc:1859-1925): a monocular observation ~0.7 px away"""
