@@ -1658,7 +1658,8 @@ __global__ __launch_bounds__(kMk) void kb_lba_schur_reduce_mfma(const LbaDev* __
 }
 template <bool kLds>
 __global__ __launch_bounds__(kThreads) void kb_lba_solve(const LbaDev* __restrict__ DD) {
-  GFS_LBAB_PROLOGUE(1, 1)
+  // every window takes the variant gfs_lba_solve would give it (the two differ in arithmetic), whatever else is in the batch
+  GFS_LBAB_PROLOGUE(1, (D.n_free <= kMaxFreeLds) == kLds ? 1 : 0)
   if (kLds)
     b_solve_lds(D);
   else
@@ -2332,9 +2333,17 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   GFS_HIP(hipMemcpyAsync(b->d_desc.p, b->h_desc.p, (size_t)n * sizeof(LbaDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(b->d_done.p, 0, sizeof(int), s));
   const int nmax = 6 * max_free;
-  const bool in_lds = max_free <= kMaxFreeLds;
-  const size_t lds = (in_lds ? (size_t)nmax * (nmax + 1) / 2 + 8 * nmax + 8 : (size_t)7 * nmax + 8) * sizeof(double);
-  GFS_REQUIRE(lds <= 160 * 1024, GFS_ERR_CAPACITY, "gfs_lba_solve_batch: %d free poses exceed the solver's workspace", max_free);
+  int free_small = 0, free_large = 0;  // largest window solved in LDS / in HBM
+  for (int w = 0; w < n; w++) {
+    const int f = b->h_desc.p[w].n_free;
+    if (f <= kMaxFreeLds)
+      free_small = std::max(free_small, f);
+    else
+      free_large = std::max(free_large, f);
+  }
+  const size_t lds_small = ((size_t)(6 * free_small) * (6 * free_small + 1) / 2 + 8 * (6 * free_small) + 8) * sizeof(double);
+  const size_t lds_large = ((size_t)7 * 6 * free_large + 8) * sizeof(double);
+  GFS_REQUIRE(lds_large <= 160 * 1024 - 1024, GFS_ERR_CAPACITY, "gfs_lba_solve_batch: %d free poses exceed the solver's workspace", max_free);
   const LbaDev* DD = b->d_desc.p;
   const auto T2 = now();
   int rounds_run = 0;
@@ -2359,10 +2368,10 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
       GFS_LAUNCH("kb_lba_schur_reduce", kb_lba_schur_reduce, dim3(gfs::div_up(nmax * (nmax + 1) / 2 + nmax, kMk), n), dim3(kMk), 0, s, DD);
     }
     if (max_pair_blocks > 0) GFS_LAUNCH("kb_lba_schur", kb_lba_schur, dim3(max_pair_blocks, n), dim3(kMk), 0, s, DD);
-    if (in_lds)
-      GFS_LAUNCH("kb_lba_solve", kb_lba_solve<true>, dim3(1, n), dim3(kThreads), lds, s, DD);
-    else
-      GFS_LAUNCH("kb_lba_solve", kb_lba_solve<false>, dim3(1, n), dim3(kThreads), lds, s, DD);
+    bool any_small = false;
+    for (int w = 0; w < n; w++) any_small = any_small || b->h_desc.p[w].n_free <= kMaxFreeLds;
+    if (any_small) GFS_LAUNCH("kb_lba_solve", kb_lba_solve<true>, dim3(1, n), dim3(kThreads), lds_small, s, DD);
+    if (free_large > 0) GFS_LAUNCH("kb_lba_solve", kb_lba_solve<false>, dim3(1, n), dim3(kThreads), lds_large, s, DD);
     GFS_LAUNCH("kb_lba_update", kb_lba_update, dim3(max_upd, n), dim3(kMk), 0, s, DD);
     GFS_LAUNCH("kb_lba_errors", kb_lba_errors, dim3(max_err, n), dim3(kMk), 0, s, DD, 1);
     const bool force_end = stop && *stop;  // setForceStopFlag: the running iteration is closed, nothing further starts

@@ -166,15 +166,17 @@ def test_several_edges_between_one_pose_and_one_point(gpu_api, oracle, cfg):
 
 def test_lba_batch_with_degenerate_windows(gpu_api, oracle):
     """A batch mixing ordinary windows with the degenerate ones: every pose fixed (only landmarks move), zero iterations (estimates
-    untouched), a single free pose, a tiny window — each equal, bit for bit, to the same window solved alone."""
+    untouched), a single free pose, a tiny window, a window too wide for the LDS solve — each equal, bit for bit, to the same window
+    solved alone."""
     base = synth.lba_window(4, n_free=3, n_fixed=2, n_points=50)
     all_fixed = dict(base, pose_fixed=np.ones_like(base["pose_fixed"]))
     zero_it = dict(base, iterations=0)
     wins = [synth.lba_window(31, n_free=12, n_fixed=3, n_points=800), all_fixed, zero_it, synth.lba_window(32, n_free=1, n_fixed=2, n_points=40),
-            synth.lba_window(33, n_free=2, n_fixed=1, n_points=12), synth.lba_window(34, n_free=24, n_fixed=2, n_points=300)]
-    bat = gpu_api.BatchOptimizer(max_windows=len(wins), max_poses=32, max_points=1024, max_edges=32768)
+            synth.lba_window(33, n_free=2, n_fixed=1, n_points=12), synth.lba_window(34, n_free=24, n_fixed=2, n_points=300),
+            synth.lba_window(35, n_free=40, n_fixed=3, n_points=500)]  # (> 30 free poses: reduced system factored in HBM, not LDS)
+    bat = gpu_api.BatchOptimizer(max_windows=len(wins), max_poses=48, max_points=1024, max_edges=65536)
     got = bat.LocalBundleAdjustment(wins)
-    one = gpu_api.Optimizer(max_poses=32, max_points=1024, max_edges=32768)
+    one = gpu_api.Optimizer(max_poses=48, max_points=1024, max_edges=65536)
     for w, r in zip(wins, got):
         r1 = one.LocalBundleAdjustment(w)
         for k in ("pose_q", "pose_t", "points", "edge_chi2", "edge_depth_positive"):
