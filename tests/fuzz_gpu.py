@@ -3,10 +3,10 @@
 voxel-sort permutations (random / tied / raster-like / adversarial keys, 1 .. 50 000 elements) bit-exact, GICP on random cloud
 pairs (sizes, truncations, motions) with equal iteration / inlier counts and the pose within the 1e-5 bar (the largest error is
 printed), ORB on odd image sizes / feature counts / level counts bit-exact, LocalBundleAdjustment windows of random size with
-and without second-camera edges.  Exit code 1 on any failure.  Round 2: 900 k sorts, 13 000 GICP pairs (without a tie at the 10th neighbour the pose agrees to
-1e-16; with one — noise-free raster clouds have one or two per cloud — 7 pairs over the 1e-5 bar), 364 ORB frames, 907 LBA windows, ~150 each of
-SearchByProjection / PoseOptimization / BF match / fbKltTracking / findFundamentalMat: no failure; the total LM iteration count of
-PoseOptimization differs by one in ~7 % of the frames (poses equal to 1e-10)."""
+and without second-camera edges, mixed LBA batches bit for bit against single solves.  Exit code 1 on any failure.  Round 2: 900 k sorts, 13 000 GICP pairs (without a tie at the 10th neighbour the pose agrees to
+1e-16; with one — noise-free raster clouds have one or two per cloud — 7 pairs over the 1e-5 bar), 2 200 ORB frames, 3 000 LBA windows, ~1 200 each of
+SearchByProjection / PoseOptimization / BF match / fbKltTracking / findFundamentalMat, 1 055 mixed LBA batches: no failure; the total
+LM iteration count of PoseOptimization differs by one in ~5 % of the frames (poses equal to 1e-10)."""
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -24,7 +24,7 @@ def case_rng(section, index):  # a case's draws depend on (seed, section, index)
     return np.random.default_rng([1234 + seed0, section, index])
 
 
-SECTIONS = [int(v) for v in os.environ.get("FUZZ_SECTIONS", "1,2,3,4,5").split(",")]  # e.g. FUZZ_SECTIONS=2: cloud pairs only
+SECTIONS = [int(v) for v in os.environ.get("FUZZ_SECTIONS", "1,2,3,4,5,6").split(",")]  # e.g. FUZZ_SECTIONS=2: cloud pairs only
 ONLY = None  # "section:index" as the third argument replays one case
 if len(sys.argv) > 3:
     ONLY = tuple(int(v) for v in sys.argv[3].split(":"))
@@ -221,5 +221,36 @@ while time.time() - T1 < extra and ONLY is None and 5 in SECTIONS:
     except Exception as e:
         fails.append(("next-exc", "case 5:%d" % (i5 - 1), which, s, repr(e)[:200]))
 print("next rows", nx, "fails", len(fails), flush=True)
+# ---- 6. mixed LBA batches against the same windows solved alone (bit for bit)
+T2 = time.time()
+nb6 = 0
+i6 = 0
+if 6 in SECTIONS and ONLY is None:
+    bat = api.BatchOptimizer(max_windows=8, max_poses=64, max_points=1024, max_edges=100000)
+    one = api.Optimizer(max_poses=64, max_points=1024, max_edges=100000)
+    while time.time() - T2 < budget * 0.15:
+        rng = case_rng(6, i6)
+        i6 += 1
+        wins = []
+        for _ in range(int(rng.integers(1, 9))):
+            w = synth.lba_window(int(rng.integers(0, 1 << 30)), n_free=int(rng.integers(1, 46)), n_fixed=int(rng.integers(1, 5)),
+                                 n_points=int(rng.integers(5, 800)), mono_frac=float(rng.choice([0.0, 0.1, 1.0])))
+            kind = int(rng.integers(0, 8))
+            if kind == 0: w = TL._with_second_camera_edges(w, int(rng.integers(0, 1000)), frac=float(rng.uniform(0.02, 0.3)))
+            if kind == 1: w["iterations"] = int(rng.integers(0, 4))
+            if kind == 2: w = dict(w, pose_fixed=np.ones_like(w["pose_fixed"]))
+            wins.append(w)
+        try:
+            got = bat.LocalBundleAdjustment(wins)
+            nb6 += 1
+            for k, (w, r) in enumerate(zip(wins, got)):
+                r1 = one.LocalBundleAdjustment(w)
+                okk = all(np.array_equal(r[key], r1[key]) for key in ("pose_q", "pose_t", "points", "edge_chi2", "edge_depth_positive"))
+                if not (okk and r["iterations_run"] == r1["iterations_run"] and r["final_chi2"] == r1["final_chi2"]):
+                    fails.append(("lba-batch", "case 6:%d" % (i6 - 1), k, len(wins), w["n_poses"], w["n_points"], w["n_edges"], w.get("iterations", 10),
+                                  r["iterations_run"], r1["iterations_run"]))
+        except Exception as e:
+            fails.append(("lba-batch-exc", "case 6:%d" % (i6 - 1), repr(e)[:200]))
+print("lba batches", nb6, "fails", len(fails), flush=True)
 for f in fails[:40]: print("FAIL", f)
 sys.exit(1 if fails else 0)
