@@ -3,9 +3,9 @@
 voxel-sort permutations (random / tied / raster-like / adversarial keys, 1 .. 50 000 elements) bit-exact, GICP on random cloud
 pairs (sizes, truncations, motions) with equal iteration / inlier counts and the pose within the 1e-5 bar (the largest error is
 printed), ORB on odd image sizes / feature counts / level counts bit-exact, LocalBundleAdjustment windows of random size with
-and without second-camera edges, mixed LBA batches bit for bit against single solves.  Exit code 1 on any failure.  Round 2: 900 k sorts, 13 000 GICP pairs (without a tie at the 10th neighbour the pose agrees to
+and without second-camera edges, mixed LBA batches and ragged GICP batches bit for bit against single calls.  Exit code 1 on any failure.  Round 2: 900 k sorts, 13 000 GICP pairs (without a tie at the 10th neighbour the pose agrees to
 1e-16; with one — noise-free raster clouds have one or two per cloud — 7 pairs over the 1e-5 bar), 2 200 ORB frames, 3 000 LBA windows, ~1 200 each of
-SearchByProjection / PoseOptimization / BF match / fbKltTracking / findFundamentalMat, 1 055 mixed LBA batches: no failure; the total
+SearchByProjection / PoseOptimization / BF match / fbKltTracking / findFundamentalMat, 1 055 mixed LBA batches and 2 966 ragged GICP batches (device entry) against single calls: no failure; the total
 LM iteration count of PoseOptimization differs by one in ~5 % of the frames (poses equal to 1e-10)."""
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +24,7 @@ def case_rng(section, index):  # a case's draws depend on (seed, section, index)
     return np.random.default_rng([1234 + seed0, section, index])
 
 
-SECTIONS = [int(v) for v in os.environ.get("FUZZ_SECTIONS", "1,2,3,4,5,6").split(",")]  # e.g. FUZZ_SECTIONS=2: cloud pairs only
+SECTIONS = [int(v) for v in os.environ.get("FUZZ_SECTIONS", "1,2,3,4,5,6,7").split(",")]  # e.g. FUZZ_SECTIONS=2: cloud pairs only
 ONLY = None  # "section:index" as the third argument replays one case
 if len(sys.argv) > 3:
     ONLY = tuple(int(v) for v in sys.argv[3].split(":"))
@@ -252,5 +252,50 @@ if 6 in SECTIONS and ONLY is None:
         except Exception as e:
             fails.append(("lba-batch-exc", "case 6:%d" % (i6 - 1), repr(e)[:200]))
 print("lba batches", nb6, "fails", len(fails), flush=True)
+# ---- 7. ragged GICP batches through the device entry against the same pairs one at a time (bit for bit)
+T3 = time.time()
+nb7 = 0
+i7 = 0
+if 7 in SECTIONS and ONLY is None:
+    from test_gpu_gms import _Hip
+    hip = _Hip()
+    single = api.RegistrationGICP(max_points=16384, max_batch=1)
+    while time.time() - T3 < budget * 0.15:
+        rng = case_rng(7, i7)
+        i7 += 1
+        B = int(rng.integers(2, 17))
+        triples = []
+        for b in range(B):
+            c0, c1, T01 = synth.cloud_pair(int(rng.integers(0, 1 << 30)), int(rng.choice([96, 128, 160])), int(rng.choice([72, 96])),
+                                           trans=float(rng.uniform(0, 0.3)), rot_deg=float(rng.uniform(0, 8)))
+            kind = int(rng.integers(0, 10))
+            if kind == 0: c0 = c0[:0]
+            if kind == 1: c1 = c1[:0]
+            if kind == 2: c0 = c0[:int(len(c0) * rng.uniform(0.05, 0.9))]
+            if kind == 3: c1 = c1[::int(rng.integers(2, 5))]
+            if kind == 4: c0, c1 = c0[:7], c1[:9]
+            init = T01 @ synth.random_motion(rng, 0.01, 0.5) if kind == 5 else np.eye(4)
+            triples.append((c0, c1, init))
+        SP = (max(max(len(a), len(b_)) for a, b_, _ in triples) + 1023) // 1024 * 1024
+        a0, a1 = np.zeros((B, SP, 4), np.float32), np.zeros((B, SP, 4), np.float32)
+        n0, n1, init = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4, 4))
+        for b, (a, s_, T0_) in enumerate(triples):
+            a0[b, :len(a)], a1[b, :len(s_)], n0[b], n1[b], init[b] = a, s_, len(a), len(s_), T0_
+        try:
+            regb = api.RegistrationGICP(max_points=SP, max_batch=B)
+            ptrs = [hip.to_device(x) for x in (a0, n0, a1, n1)]
+            got = regb.align_batch_device(ptrs[0], ptrs[1], ptrs[2], ptrs[3], B, SP, init_T=init)
+            nb7 += 1
+            for b, ((a, s_, T0_), r) in enumerate(zip(triples, got)):
+                r1 = single.RegisterPointClouds(a, s_, T0_)
+                if not (np.array_equal(r["T"], r1["T"]) and r["iterations"] == r1["iterations"] and r["num_inliers"] == r1["num_inliers"]
+                        and np.array_equal(r["H"], r1["H"]) and r["error"] == r1["error"]):
+                    fails.append(("gicp-batch", "case 7:%d" % (i7 - 1), b, B, len(a), len(s_), r["iterations"], r1["iterations"]))
+            regb.close() if hasattr(regb, "close") else None
+        except Exception as e:
+            fails.append(("gicp-batch-exc", "case 7:%d" % (i7 - 1), repr(e)[:200]))
+        hip.free()
+        hip = _Hip()
+print("gicp batches", nb7, "fails", len(fails), flush=True)
 for f in fails[:40]: print("FAIL", f)
 sys.exit(1 if fails else 0)
