@@ -539,7 +539,9 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
                                                         uint32_t* __restrict__ perm1, unsigned short* __restrict__ seg0,
                                                         unsigned short* __restrict__ seg1, const int* __restrict__ kept_off,
                                                         int kp_cap, uint32_t* __restrict__ kept, int* __restrict__ kept_cnt,
-                                                        int node_cap) {
+                                                        int node_cap, const CellDev* __restrict__ cells,
+                                                        const int* __restrict__ cell_cnt, int n_cells,
+                                                        const uint32_t* __restrict__ slab) {
   // node tables in dynamic LDS, node_cap entries each (the largest level's quota + slack, oct_lds_bytes): the kernel is a chain
   // of short dependent phases, so it is the number of workgroups a CU holds at once that sets its speed (97 B a node: 6
   // workgroups a CU for 1000 features; the fixed 768-entry tables allowed 2)
@@ -557,16 +559,58 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
   __shared__ int s_ctl[8];
   const int tid = threadIdx.x;
   const int l = blockIdx.x % nlevels, b = blockIdx.x / nlevels;
-  const int* off = cand_off + (size_t)b * (nlevels + 1);
-  const int n = off[l + 1] - off[l];
-  const uint32_t* c = cand + (size_t)b * cand_frame + off[l];
-  uint32_t* perm[2] = {perm0 + (size_t)b * cand_frame + off[l], perm1 + (size_t)b * cand_frame + off[l]};
-  unsigned short* seg[2] = {seg0 + (size_t)b * cand_frame + off[l], seg1 + (size_t)b * cand_frame + off[l]};
+  const LevelDev L = levels[l];
+  // cells != NULL: the level's candidates are taken straight from the per-cell slabs of k_fast_cells, in the order the reference
+  // feeds them to DistributeOctTree (cells row-major, raster order inside a cell) — what k_cand_pack would lay out; the working
+  // arrays of the level then live at the level's slab offset.  cells == NULL: a dense list (cand, cand_off) from the caller.
+  __shared__ int s_gscan[kOctThreads];
+  __shared__ int s_gbase;
+  size_t region = 0;
+  int n = 0;
+  if (cells) {
+    region = cells[L.cell_base].slab_off;
+  } else {
+    const int* off = cand_off + (size_t)b * (nlevels + 1);
+    n = off[l + 1] - off[l];
+    region = (size_t)off[l];
+  }
+  uint32_t* perm[2] = {perm0 + (size_t)b * cand_frame + region, perm1 + (size_t)b * cand_frame + region};
+  unsigned short* seg[2] = {seg0 + (size_t)b * cand_frame + region, seg1 + (size_t)b * cand_frame + region};
+  if (cells) {
+    const int* cnt = cell_cnt + (size_t)b * n_cells + L.cell_base;
+    const uint32_t* sl = slab + (size_t)b * cand_frame;
+    if (tid == 0) s_gbase = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < L.n_cells; c0 += kOctThreads) {
+      const int ci = c0 + tid;
+      const int my = ci < L.n_cells ? cnt[ci] : 0;
+      s_gscan[tid] = my;
+      __syncthreads();
+      for (int ofs = 1; ofs < kOctThreads; ofs <<= 1) {
+        const int v = tid >= ofs ? s_gscan[tid - ofs] : 0;
+        __syncthreads();
+        s_gscan[tid] += v;
+        __syncthreads();
+      }
+      const int base = s_gbase + s_gscan[tid] - my;
+      if (my > 0) {
+        const uint32_t* sp = sl + cells[L.cell_base + ci].slab_off;
+        for (int i = 0; i < my; i++) {
+          perm[0][base + i] = sp[i];
+          seg[0][base + i] = 0;
+        }
+      }
+      __syncthreads();
+      if (tid == kOctThreads - 1) s_gbase += s_gscan[kOctThreads - 1];
+      __syncthreads();
+    }
+    n = s_gbase;
+  }
+  const uint32_t* c = cells ? nullptr : cand + (size_t)b * cand_frame + region;
   if (n <= 0) {
     if (tid == 0) kept_cnt[(size_t)b * nlevels + l] = 0;
     return;
   }
-  const LevelDev L = levels[l];
   const int N = L.quota;
   const int width = L.max_bx - 16, height = L.max_by - 16;
   int nIni = (int)roundf((float)width / (float)height);  // :573
@@ -574,10 +618,11 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
   const float hX = (float)width / (float)nIni;
   const int chunk = (n + kOctThreads - 1) / kOctThreads;
   const int p0 = min(tid * chunk, n), p1 = min(p0 + chunk, n);
-  for (int p = p0; p < p1; p++) {
-    perm[0][p] = c[p];  // the permutation arrays carry the keys themselves: no gather through an index in the sweeps
-    seg[0][p] = 0;
-  }
+  if (c)
+    for (int p = p0; p < p1; p++) {
+      perm[0][p] = c[p];  // the permutation arrays carry the keys themselves: no gather through an index in the sweeps
+      seg[0][p] = 0;
+    }
   if (tid == 0) {
     ONode root;
     root.x0 = 0;
@@ -1265,6 +1310,7 @@ struct gfs_orb {
   gfs::DevBuf<unsigned short> d_seg0, d_seg1;
   gfs::DevBuf<int> d_kept_cnt, d_kept_off;
   int oct_node_cap = kOctMaxNodes;
+  bool cands_packed = false;  // d_cand / d_cand_off hold the last call's dense candidate list
   bool device_octree = true;   // DistributeOctTree on the GPU (k_octree); false = host quadtree (GFS_ORB_OCTREE=host)
   bool octree_supported = true;
   bool host_counts_valid = false, host_cands_valid = false;
@@ -1356,14 +1402,14 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   const size_t lds = 6 * (size_t)G.max_tile_w * G.max_tile_h + 8;  // tile + score map + corner list (u16) + compass-test list (u16)
   GFS_LAUNCH("k_fast_cells", k_fast_cells, dim3(n_cells, B), dim3(kFastThreads), lds, s, h->d_levels.p, h->d_cells.p, l0,
              h->d_pyr.p, cap_pyr, h->P.ini_th, h->P.min_th, n_cells, cap_slab, h->d_slab.p, h->d_cell_cnt.p);
-  GFS_LAUNCH("k_cand_pack", k_cand_pack, dim3(B), dim3(256), 0, s, h->d_levels.p, h->d_cells.p, nl, n_cells, cap_slab,
-             h->d_slab.p, h->d_cell_cnt.p, cap_slab, h->d_cand.p, h->d_cand_off.p);
   const int* tp = kBlurTaps[h->P.blur_variant ? 1 : 0];
   if (h->device_octree && h->octree_supported) {
-    // 3-6 (device): quadtree, slot assignment, blur, orientation + descriptors — no host round trip at all
-    GFS_LAUNCH("k_octree", k_octree, dim3(B * nl), dim3(kOctThreads), oct_lds_bytes(h->oct_node_cap), s, h->d_levels.p, nl, h->d_cand.p,
-               h->d_cand_off.p, cap_slab, h->d_perm0.p, h->d_perm1.p, h->d_seg0.p, h->d_seg1.p, h->d_kept_off.p, h->cap_kp, h->d_kept.p,
-               h->d_kept_cnt.p, h->oct_node_cap);
+    // 3-6 (device): quadtree (it takes its level's candidates straight from the cell slabs), slot assignment, blur, orientation +
+    // descriptors — no host round trip at all; the dense candidate list is only laid out when an introspection call asks for it
+    GFS_LAUNCH("k_octree", k_octree, dim3(B * nl), dim3(kOctThreads), oct_lds_bytes(h->oct_node_cap), s, h->d_levels.p, nl, nullptr,
+               nullptr, cap_slab, h->d_perm0.p, h->d_perm1.p, h->d_seg0.p, h->d_seg1.p, h->d_kept_off.p, h->cap_kp, h->d_kept.p,
+               h->d_kept_cnt.p, h->oct_node_cap, h->d_cells.p, h->d_cell_cnt.p, n_cells, h->d_slab.p);
+    h->cands_packed = false;
     GFS_LAUNCH("k_kp_finalize", k_kp_finalize, dim3(B), dim3(256), 0, s, h->d_levels.p, nl, h->d_kept.p, h->d_kept_cnt.p,
                h->d_kept_off.p, h->cap_kp, lap0, lap1, h->d_kpin.p, h->d_kp_count.p, h->d_mono.p);
     GFS_LAUNCH("k_blur7", k_blur7, dim3((unsigned)G.blur_tiles.size(), B), dim3(256), 0, s, h->d_levels.p, h->d_tiles.p, l0,
@@ -1377,6 +1423,9 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
     h->host_cands_valid = false;
     return GFS_OK;
   }
+  // host quadtree: the dense, ordered candidate list goes to the host
+  GFS_LAUNCH("k_cand_pack", k_cand_pack, dim3(B), dim3(256), 0, s, h->d_levels.p, h->d_cells.p, nl, n_cells, cap_slab, h->d_slab.p,
+             h->d_cell_cnt.p, cap_slab, h->d_cand.p, h->d_cand_off.p);
   GFS_HIP(hipMemcpyAsync(h->h_cand_off.p, h->d_cand_off.p, (size_t)B * (nl + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
   int max_total = 0;
@@ -1446,6 +1495,7 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   h->last_l0 = l0;
   h->host_counts_valid = true;
   h->host_cands_valid = true;
+  h->cands_packed = true;
   return GFS_OK;
 }
 
@@ -1458,6 +1508,13 @@ int sync_host_view(gfs_orb* h, bool want_candidates) {
   GFS_HIP(hipMemcpy(h->h_mono.p, h->d_mono.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
   h->host_counts_valid = true;
   if (want_candidates) {
+    if (!h->cands_packed) {  // the device quadtree read the slabs directly: lay the dense list out now (the slabs still hold the call)
+      const int n_cells = (int)h->G.cells.size();
+      GFS_LAUNCH("k_cand_pack", k_cand_pack, dim3(B), dim3(256), 0, h->stream, h->d_levels.p, h->d_cells.p, nl, n_cells, h->cap_slab,
+                 h->d_slab.p, h->d_cell_cnt.p, h->cap_slab, h->d_cand.p, h->d_cand_off.p);
+      GFS_HIP(hipDeviceSynchronize());
+      h->cands_packed = true;
+    }
     GFS_HIP(hipMemcpy(h->h_cand_off.p, h->d_cand_off.p, (size_t)B * (nl + 1) * sizeof(int), hipMemcpyDeviceToHost));
     GFS_HIP(hipMemcpy(h->h_cand.p, h->d_cand.p, (size_t)B * h->cap_slab * sizeof(uint32_t), hipMemcpyDeviceToHost));
     h->host_cands_valid = true;
@@ -1768,7 +1825,7 @@ int gfs_orb_octree_device(int device, const int32_t* x, const int32_t* y, const 
   const int node_cap = (n_features + 4 * nIni + 8 + 7) / 8 * 8;
   GFS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(kOctMaxNodes)));
   hipLaunchKernelGGL(k_octree, dim3(1), dim3(kOctThreads), oct_lds_bytes(node_cap), 0, dL.p, 1, dc.p, doff.p, c.size(), p0.p, p1.p, s0.p, s1.p,
-                     dko.p, kcap, dk.p, dcnt.p, node_cap);
+                     dko.p, kcap, dk.p, dcnt.p, node_cap, (const CellDev*)nullptr, (const int*)nullptr, 0, (const uint32_t*)nullptr);
   GFS_HIP(hipDeviceSynchronize());
   int cnt = 0;
   GFS_HIP(hipMemcpy(&cnt, dcnt.p, sizeof(int), hipMemcpyDeviceToHost));
