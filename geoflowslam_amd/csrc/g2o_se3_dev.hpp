@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "glibc_math.hpp"
+
 namespace gfs_se3 {
 
 __device__ __forceinline__ void quat_rotate(const double* q, const double* v, double* o) {  // Eigen _transformVector
@@ -71,7 +73,9 @@ __device__ inline void pose_oplus(const double* q_in, const double* t_in, const 
       V[i] = R[i];
     }
   } else {
-    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3.0);
+    // the reference's libm calls, with glibc's bits (glibc_math.hpp)
+    const double sn = gfs_glibc::sin(theta), cn = gfs_glibc::cos(theta);
+    const double a = sn / theta, b = (1 - cn) / (theta * theta), c = (theta - sn) / gfs_glibc::pow3(theta);
     for (int i = 0; i < 9; i++) {
       R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i];
       V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i];

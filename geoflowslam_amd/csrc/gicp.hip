@@ -18,6 +18,7 @@
 #include <memory>
 
 #include "gfs_common.hpp"
+#include "glibc_math.hpp"
 #include "voxel_qsort.hpp"
 #include "wave_reduce.hpp"
 
@@ -627,7 +628,7 @@ __device__ void eig3_direct(const double* cov6, double* V) {
     q = fmax(q, 0.0);
     const double rho = sqrt(a_over_3);
     const double theta = atan2(sqrt(q), half_b) * s_inv3;
-    const double cos_theta = cos(theta), sin_theta = sin(theta);
+    const double cos_theta = gfs_glibc::cos(theta), sin_theta = gfs_glibc::sin(theta);
     ev[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     ev[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
     ev[2] = c2_over_3 + 2.0 * rho * cos_theta;
@@ -1429,8 +1430,8 @@ __device__ void solve_and_propose(const double* H21, const double* b6, double la
     real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
   } else {
     const double ht = 0.5 * theta;
-    imag = sin(ht) / theta;
-    real = cos(ht);
+    imag = gfs_glibc::sin(ht) / theta;  // the reference's libm calls, with glibc's bits (glibc_math.hpp)
+    real = gfs_glibc::cos(ht);
   }
   const double qw = real, qx = imag * w0, qy = imag * w1, qz = imag * w2;
   double E[12];
@@ -1459,7 +1460,7 @@ __device__ void solve_and_propose(const double* H21, const double* b6, double la
     for (int c = 0; c < 3; c++)
 #pragma unroll
       for (int r = 0; r < 3; r++) O2[r + 3 * c] = O[r] * O[3 * c] + O[r + 3] * O[3 * c + 1] + O[r + 6] * O[3 * c + 2];
-    const double k1 = (1.0 - cos(theta)) / theta_sq, k2 = (theta - sin(theta)) / (theta_sq * theta);
+    const double k1 = (1.0 - gfs_glibc::cos(theta)) / theta_sq, k2 = (theta - gfs_glibc::sin(theta)) / (theta_sq * theta);
     double V[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + k1 * O[i] + k2 * O2[i];

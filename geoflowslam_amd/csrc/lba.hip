@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void k_lba(LbaDev D) {
       }
       rho = (current_chi - temp_chi) / (scale + 1e-3);
       if (rho > 0 && isfinite(temp_chi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3.0);
+        double alpha = 1. - gfs_glibc::pow3(2 * rho - 1);
         alpha = fmin(alpha, good_up);
         lambda *= fmax(good_lo, alpha);
         ni = 2;
@@ -1510,7 +1510,7 @@ __device__ __forceinline__ void b_decide(const LbaDev& D, const int bx, int forc
     S.temp_chi = temp_chi;
     S.rho = (S.current_chi - temp_chi) / (scale + 1e-3);
     if (S.rho > 0 && isfinite(temp_chi)) {
-      double alpha = 1. - pow((2 * S.rho - 1), 3.0);
+      double alpha = 1. - gfs_glibc::pow3(2 * S.rho - 1);
       alpha = fmin(alpha, 2. / 3.);
       S.lambda *= fmax(1. / 3., alpha);
       S.ni = 2;

@@ -6,8 +6,12 @@
 // edges (EdgeSE3ProjectXYZOnlyPose: src/OptimizableTypes.cpp:49-63; g2o::EdgeStereoSE3ProjectXYZOnlyPose:
 // Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:339-404), Huber kernels, a dense 6x6 system solved with Eigen::LDLT
 // semantics (solvers/linear_solver_dense.h:64-112), and the outlier re-classification between rounds (:972-1073).
-// Edges are spread over the threads; the 6x6 normal equations are summed with a fixed-order tree (wave shuffles, then
-// the four waves in order), the scalar LM bookkeeping runs on thread 0 and is broadcast through LDS.
+// Edges are spread over the threads, but every sum over the edges -- activeRobustChi2 (core/sparse_optimizer.cpp:104-122) and
+// the 21 + 6 entries of the normal equations (core/base_unary_edge.hpp:43-72, one edge after the other into the vertex's
+// block) -- is added in g2o's order, the edge order: the threads park their terms in an LDS slab and one lane per quantity
+// adds them up sequentially.  Together with glibc's sin / cos / pow (glibc_math.hpp) every double of the solve has the bits
+// the sequential CPU code produces; the sign of a gain ratio at a converged state (one more LM iteration or not) depends on
+// exactly that.  The scalar LM bookkeeping runs on thread 0 and is broadcast through LDS.
 // Quirks kept: every round restarts from the frame's pose, chi2 values are compared as floats, nGood is never reset,
 // the stereo projection uses a float 1/z, and the optimised pose is returned but meant to be discarded.
 #include <memory>
@@ -81,6 +85,29 @@ __device__ double block_sum256(double v, double* s4) {
   if (lane == 0) s4[wave] = v;
   __syncthreads();
   return ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
+
+// Ordered sums: kChunk edges per pass (one per thread) park their 27 terms in an LDS slab, row q = quantity q with an odd
+// row stride (the 27 summing lanes then read different banks); lane q adds its row to its running value in index order.
+constexpr int kChunk = kPoseThreads;
+constexpr int kSlabStride = kChunk + 1;
+constexpr int kSlabDoubles = kSys * kSlabStride;  // also the capacity of one pass of the chi2 sum
+
+__device__ __forceinline__ double ordered_sum(const double* __restrict__ v, int cnt, double s) {
+  int j = 0;
+  for (; j + 8 <= cnt; j += 8) {
+    const double a0 = v[j], a1 = v[j + 1], a2 = v[j + 2], a3 = v[j + 3], a4 = v[j + 4], a5 = v[j + 5], a6 = v[j + 6], a7 = v[j + 7];
+    s += a0;
+    s += a1;
+    s += a2;
+    s += a3;
+    s += a4;
+    s += a5;
+    s += a6;
+    s += a7;
+  }
+  for (; j < cnt; j++) s += v[j];
+  return s;
 }
 
 // Eigen::LDLT<MatrixXd>::compute + isPositive + solve on a 6x6 (see oracle/pose_oracle.cpp for the line-by-line restatement)
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
                                                            double* __restrict__ err_all, uint8_t* __restrict__ level_all,
                                                            PoseOut* __restrict__ outs) {
   __shared__ double s4[4];
-  __shared__ double s_many[(kPoseThreads / 64) * 32];
+  __shared__ double s_slab[kSlabDoubles];
   __shared__ double s_T[7], s_Tb[7];  // current estimate, backup (push / pop)
   __shared__ double s_sys[kSys];
   __shared__ double s_x[6];
@@ -210,29 +237,36 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     if (tid == 0) outs[f] = O;
     return;
   }
-  // errors + chi2 of the active edges at the current estimate; returns activeRobustChi2 (all threads)
+  // errors + chi2 of the active edges at the current estimate; returns activeRobustChi2, summed in edge order (thread 0 only)
   auto compute_active = [&](bool robust) {
     double T[7];
     for (int k = 0; k < 7; k++) T[k] = s_T[k];
-    double local = 0;
-    for (int e = tid; e < n; e += kPoseThreads) {
-      if (level[e]) continue;
-      double r[3];
-      pose_edge_error(F, E, e, T, T + 4, r);
-      const double c = pose_edge_chi2(E, e, r);
-      err[3 * e] = r[0];
-      err[3 * e + 1] = r[1];
-      err[3 * e + 2] = r[2];
-      chi2[e] = c;
-      if (robust) {
-        double r0, r1;
-        huber(c, E.stereo[e] ? dStereo : dMono, &r0, &r1);
-        local += r0;
-      } else {
-        local += c;
+    double chi = 0;
+    for (int base = 0; base < n; base += kSlabDoubles) {
+      const int cnt = min(kSlabDoubles, n - base);
+      for (int e = base + tid; e < base + cnt; e += kPoseThreads) {
+        double term = 0;  // an edge that is not active adds nothing (x + 0 = x)
+        if (!level[e]) {
+          double r[3];
+          pose_edge_error(F, E, e, T, T + 4, r);
+          const double c = pose_edge_chi2(E, e, r);
+          err[3 * e] = r[0];
+          err[3 * e + 1] = r[1];
+          err[3 * e + 2] = r[2];
+          chi2[e] = c;
+          term = c;
+          if (robust) {
+            double r1;
+            huber(c, E.stereo[e] ? dStereo : dMono, &term, &r1);
+          }
+        }
+        s_slab[e - base] = term;
       }
+      __syncthreads();
+      if (tid == 0) chi = ordered_sum(s_slab, cnt, chi);
+      __syncthreads();
     }
-    return block_sum256(local, s4);
+    return chi;
   };
   int nBad = 0, nGood = 0;
   for (int it = 0; it < F.n_rounds; it++) {
@@ -252,75 +286,79 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       {
         double T[7];
         for (int k = 0; k < 7; k++) T[k] = s_T[k];
-        double acc[kSys];
+        double run = 0;  // threads 0 .. 26: quantity tid, added up edge by edge
+        for (int base = 0; base < n; base += kChunk) {
+          const int e = base + tid;
+          double acc[kSys];
 #pragma unroll
-        for (int k = 0; k < kSys; k++) acc[k] = 0;
-        for (int e = tid; e < n; e += kPoseThreads) {
-          if (level[e]) continue;
-          double xc[3];
-          map3(T, T + 4, E.xw + 3 * e, xc);
-          const double x = xc[0], y = xc[1], z = xc[2];
-          double J[18];
-          int rows;
-          if (E.stereo[e]) {  // types_six_dof_expmap.cpp:375-404
-            rows = 3;
-            const double invz = 1.0 / z, invz_2 = invz * invz;
-            J[0] = x * y * invz_2 * F.fx;
-            J[1] = -(1 + (x * x * invz_2)) * F.fx;
-            J[2] = y * invz * F.fx;
-            J[3] = -invz * F.fx;
-            J[4] = 0;
-            J[5] = x * invz_2 * F.fx;
-            J[6] = (1 + y * y * invz_2) * F.fy;
-            J[7] = -x * y * invz_2 * F.fy;
-            J[8] = -x * invz * F.fy;
-            J[9] = 0;
-            J[10] = -invz * F.fy;
-            J[11] = y * invz_2 * F.fy;
-            J[12] = J[0] - F.bf * y * invz_2;
-            J[13] = J[1] + F.bf * x * invz_2;
-            J[14] = J[2];
-            J[15] = J[3];
-            J[16] = 0;
-            J[17] = J[5] - F.bf * invz_2;
-          } else {  // src/OptimizableTypes.cpp:49-63: -projectJac(xyz) * SE3deriv
-            rows = 2;
-            const double pj[6] = {F.fx / z, 0, -F.fx * x / (z * z), 0, F.fy / z, -F.fy * y / (z * z)};
-            const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
-            for (int r = 0; r < 2; r++)
-              for (int c = 0; c < 6; c++) J[6 * r + c] = -(pj[3 * r] * D[c] + pj[3 * r + 1] * D[6 + c] + pj[3 * r + 2] * D[12 + c]);
-            for (int c = 0; c < 6; c++) J[12 + c] = 0;
-          }
-          const double w = (double)E.w[e];
-          double rho1 = 1.0;
-          if (robust) {
-            double r0;
-            huber(chi2[e], E.stereo[e] ? dStereo : dMono, &r0, &rho1);
-          }
-          const double r[3] = {err[3 * e], err[3 * e + 1], err[3 * e + 2]};
-          int o = 0;
-          for (int a = 0; a < 6; a++) {
-            double sb = 0;
-            for (int k = 0; k < rows; k++) sb += J[6 * k + a] * (w * r[k]);
-            acc[21 + a] -= rho1 * sb;
-            for (int c = a; c < 6; c++) {
-              double hh = 0;
-              for (int k = 0; k < rows; k++) hh += J[6 * k + a] * ((rho1 * w) * J[6 * k + c]);
-              acc[o++] += hh;
+          for (int k = 0; k < kSys; k++) acc[k] = 0;
+          if (e < n && !level[e]) {
+            double xc[3];
+            map3(T, T + 4, E.xw + 3 * e, xc);
+            const double x = xc[0], y = xc[1], z = xc[2];
+            double J[18];
+            int rows;
+            if (E.stereo[e]) {  // types_six_dof_expmap.cpp:375-404
+              rows = 3;
+              const double invz = 1.0 / z, invz_2 = invz * invz;
+              J[0] = x * y * invz_2 * F.fx;
+              J[1] = -(1 + (x * x * invz_2)) * F.fx;
+              J[2] = y * invz * F.fx;
+              J[3] = -invz * F.fx;
+              J[4] = 0;
+              J[5] = x * invz_2 * F.fx;
+              J[6] = (1 + y * y * invz_2) * F.fy;
+              J[7] = -x * y * invz_2 * F.fy;
+              J[8] = -x * invz * F.fy;
+              J[9] = 0;
+              J[10] = -invz * F.fy;
+              J[11] = y * invz_2 * F.fy;
+              J[12] = J[0] - F.bf * y * invz_2;
+              J[13] = J[1] + F.bf * x * invz_2;
+              J[14] = J[2];
+              J[15] = J[3];
+              J[16] = 0;
+              J[17] = J[5] - F.bf * invz_2;
+            } else {  // src/OptimizableTypes.cpp:49-63: -projectJac(xyz) * SE3deriv
+              rows = 2;
+              const double pj[6] = {F.fx / z, 0, -F.fx * x / (z * z), 0, F.fy / z, -F.fy * y / (z * z)};
+              const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+              for (int r = 0; r < 2; r++)
+                for (int c = 0; c < 6; c++) J[6 * r + c] = -(pj[3 * r] * D[c] + pj[3 * r + 1] * D[6 + c] + pj[3 * r + 2] * D[12 + c]);
+              for (int c = 0; c < 6; c++) J[12 + c] = 0;
+            }
+            const double w = (double)E.w[e];
+            double rho1 = 1.0;
+            if (robust) {
+              double r0;
+              huber(chi2[e], E.stereo[e] ? dStereo : dMono, &r0, &rho1);
+            }
+            const double r[3] = {err[3 * e], err[3 * e + 1], err[3 * e + 2]};
+            // the lower triangle, row a / column c <= a: the entries Eigen's LDLT reads (packed a (a + 1) / 2 + c)
+            int o = 0;
+            for (int a = 0; a < 6; a++) {
+              double sb = 0;
+              for (int k = 0; k < rows; k++) sb += J[6 * k + a] * (w * r[k]);
+              acc[21 + a] = -(rho1 * sb);  // b -= rho1 J' W e
+              for (int c = 0; c <= a; c++) {
+                double hh = 0;
+                for (int k = 0; k < rows; k++) hh += J[6 * k + a] * ((rho1 * w) * J[6 * k + c]);
+                acc[o++] = hh;
+              }
             }
           }
+#pragma unroll
+          for (int k = 0; k < kSys; k++) s_slab[k * kSlabStride + tid] = acc[k];
+          __syncthreads();
+          if (tid < kSys) run = ordered_sum(s_slab + tid * kSlabStride, min(kChunk, n - base), run);
+          __syncthreads();
         }
-        const double v = gfs_red::block_sum_many<kSys, kPoseThreads / 64>(acc, s_many);
-        if (tid < kSys) s_sys[tid] = v;
+        if (tid < kSys) s_sys[tid] = run;
         __syncthreads();
       }
       if (tid == 0 && iteration == 0) {  // computeLambdaInit: tau * max |diag(H)|
         double maxDiagonal = 0;
-        int o = 0;
-        for (int a = 0; a < 6; a++) {
-          maxDiagonal = fmax(fabs(s_sys[o]), maxDiagonal);
-          o += 6 - a;
-        }
+        for (int a = 0; a < 6; a++) maxDiagonal = fmax(fabs(s_sys[a * (a + 1) / 2 + a]), maxDiagonal);
         currentLambda = 1e-5 * maxDiagonal;
         ni = 2;
         nBadLm = 0;
@@ -334,7 +372,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           double Hl[36], b[6], x[6];
           int o = 0;
           for (int a = 0; a < 6; a++)
-            for (int c = a; c < 6; c++) {
+            for (int c = 0; c <= a; c++) {
               Hl[6 * a + c] = s_sys[o];
               Hl[6 * c + a] = s_sys[o];
               o++;
@@ -365,7 +403,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           scale += 1e-3;
           rho /= scale;
           if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow((2 * rho - 1), 3.0);
+            double alpha = 1. - gfs_glibc::pow3(2 * rho - 1);
             alpha = fmin(alpha, 2. / 3.);
             const double scaleFactor = fmax(1. / 3., alpha);
             currentLambda *= scaleFactor;
@@ -446,6 +484,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     O.n_inliers = n - nBad;
     outs[f] = O;
   }
+}
+
+__global__ void k_test_glibc_math(const double* __restrict__ x, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = gfs_glibc::sin(x[i]);
+  out[n + i] = gfs_glibc::cos(x[i]);
+  out[2 * (size_t)n + i] = gfs_glibc::pow3(x[i]);
 }
 
 }  // namespace
@@ -576,6 +622,24 @@ int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_
     r.rounds_run = O.rounds_run;
     r.iterations_run = O.iterations_run;
   }
+  return GFS_OK;
+}
+
+// Test hook: the restated glibc functions evaluated on the device (tests/test_gpu_glibc_math.py).
+int gfs_test_glibc_math(int device, const double* x, int n, double* sin_out, double* cos_out, double* pow3_out) {
+  GFS_REQUIRE(x && sin_out && cos_out && pow3_out && n >= 0, GFS_ERR_INVALID_ARG, "gfs_test_glibc_math: invalid argument");
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  if (n == 0) return GFS_OK;
+  GFS_HIP(hipSetDevice(device));
+  gfs::DevBuf<double> d_x, d_o;
+  int rc = d_x.alloc(n);
+  if (!rc) rc = d_o.alloc((size_t)3 * n);
+  if (rc) return rc;
+  GFS_HIP(hipMemcpy(d_x.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+  GFS_LAUNCH("k_test_glibc_math", k_test_glibc_math, dim3(gfs::div_up(n, 256)), dim3(256), 0, (hipStream_t)0, d_x.p, n, d_o.p);
+  GFS_HIP(hipMemcpy(sin_out, d_o.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  GFS_HIP(hipMemcpy(cos_out, d_o.p + n, (size_t)n * 8, hipMemcpyDeviceToHost));
+  GFS_HIP(hipMemcpy(pow3_out, d_o.p + 2 * (size_t)n, (size_t)n * 8, hipMemcpyDeviceToHost));
   return GFS_OK;
 }
 

@@ -123,6 +123,11 @@ int gfs_orb_octree_device(int device, const int32_t* x, const int32_t* y, const 
 int gfs_test_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
 int gfs_test_heap_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
 
+/* GPU test hook: sin(x), cos(x), pow(x, 3.0) of n doubles evaluated on the device with the restated glibc 2.35 arithmetic
+ * (csrc/glibc_math.hpp) that the pose / window / registration optimizers use for SE3Quat::exp
+ * (Thirdparty/g2o/g2o/types/se3quat.h:223-257) and the Levenberg step control (core/optimization_algorithm_levenberg.cpp:127). */
+int gfs_test_glibc_math(int device, const double* x, int n, double* sin_out, double* cos_out, double* pow3_out);
+
 /* ============================================================================================
  * 2. Brute-force Hamming matching — replaces
  *      ORBmatcher::DescriptorDistance                       include/ORBmatcher.h:41, src/ORBmatcher.cc:2536-2550

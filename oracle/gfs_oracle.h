@@ -109,6 +109,7 @@ void gfso_gicp_set_stable_voxel_order(int on);
 /* quick_sort_omp (util/sort_omp.hpp:58-85) of (key, index) pairs by key, through libstdc++'s std::partition / std::sort:
  * idx_io holds the payload (0..n-1 on entry), both arrays are permuted in place */
 void gfso_quick_sort_pairs(uint64_t* keys_io, uint64_t* idx_io, int n);
+int gfso_knn_push_stream(int k, const uint64_t* index, const double* distance, int n, uint64_t* idx_out, double* dist_out);
 /* adversarial input for libstdc++'s std::sort (McIlroy's antiqsort): a permutation of 0..n-1 that reaches the heap-sort fallback */
 void gfso_antiqsort_keys(int n, int32_t* out);
 /* OpenMP threads for timing runs (the reference hard-codes 4, src/RegistrationGICP.cc:10); default 1 = deterministic */

@@ -663,6 +663,18 @@ void gfso_quick_sort_pairs(uint64_t* keys_io, uint64_t* idx_io, int n) {
     idx_io[i] = v[i].second;
   }
 }
+// a stream of pushes into the restated KnnResult (pinned against the reference's own container by tests/test_oracle_ref.py)
+int gfso_knn_push_stream(int k, const uint64_t* index, const double* distance, int n, uint64_t* idx_out, double* dist_out) {
+  std::vector<size_t> idx((size_t)k);
+  std::vector<double> d((size_t)k);
+  KnnResult r(idx.data(), d.data(), k);
+  for (int i = 0; i < n; i++) r.push((size_t)index[i], distance[i]);
+  for (int i = 0; i < k; i++) {
+    idx_out[i] = idx[i];
+    dist_out[i] = d[i];
+  }
+  return r.num_found;
+}
 void gfso_gicp_set_threads(int n) { g_omp_threads = n < 1 ? 1 : n; }
 
 void gfso_gicp_align(const float* target_xyzw, int nt, const float* source_xyzw, int ns, const double init_T[16],

@@ -279,6 +279,39 @@ def quick_sort_perm(keys):
     return idx.astype(np.int64), k
 
 
+_REF = False
+
+
+def ref_lib():
+    """oracle/_ref/libgfs_ref_small_gicp.so: the REFERENCE's own sort_omp.hpp / knn_result.hpp compiled from /root/reference by
+    oracle/ref_build.sh (the only hot-path sources that build without OpenCV / Eigen).  None when it has not been built."""
+    global _REF
+    if _REF is False:
+        path = os.path.join(_HERE, "_ref", "libgfs_ref_small_gicp.so")
+        _REF = C.CDLL(path) if os.path.exists(path) else None
+    return _REF
+
+
+def ref_quick_sort_perm(keys, num_threads=4):
+    """The reference's quick_sort_omp (util/sort_omp.hpp:58-103) as voxelgrid_sampling_omp calls it -> (permutation, sorted keys)."""
+    k = np.ascontiguousarray(keys, np.uint64).copy()
+    idx = np.arange(len(k), dtype=np.uint64)
+    ref_lib().gfsref_quick_sort_omp(_p(k), _p(idx), len(k), int(num_threads))
+    return idx.astype(np.int64), k
+
+
+def knn_push_stream(k, index, distance, ref=False, static_one=False):
+    """(index, distance) pushes into KnnResult of capacity k: the restated container, or the reference's (ref=True)."""
+    index = np.ascontiguousarray(index, np.uint64)
+    distance = np.ascontiguousarray(distance, np.float64)
+    io, do = np.zeros(k, np.uint64), np.zeros(k, np.float64)
+    if ref:
+        n = ref_lib().gfsref_knn_push_stream(k, int(static_one), _p(index), _p(distance), len(index), _p(io), _p(do))
+    else:
+        n = lib().gfso_knn_push_stream(k, _p(index), _p(distance), len(index), _p(io), _p(do))
+    return n, io, do
+
+
 def antiqsort_keys(n):
     out = np.zeros(n, np.int32)
     lib().gfso_antiqsort_keys(n, _p(out))

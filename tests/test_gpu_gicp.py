@@ -69,6 +69,19 @@ def test_voxel_sort_permutation_is_the_references(gpu_api, oracle):
         assert np.array_equal(got, want), (name, int((got != want).sum()), len(k))
 
 
+def test_voxel_sort_permutation_against_the_compiled_reference(gpu_api, oracle):
+    """The same, against the REFERENCE'S OWN quick_sort_omp (util/sort_omp.hpp compiled from /root/reference into oracle/_ref by
+    oracle/ref_build.sh; the prebuilt library travels to the GPU box) instead of the restatement."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    from test_oracle_ref import sort_cases
+    reg = gpu_api.RegistrationGICP(max_points=40960)
+    for name, k in sort_cases():
+        got = reg.voxel_sort_perm(k)
+        want, _ = oracle.ref_quick_sort_perm(k, 4)
+        assert np.array_equal(got, want), (name, int((got != want).sum()), len(k))
+
+
 def test_preprocess_stage_matches_oracle(gpu_api, oracle):
     """Voxel means bit-identical to the (unmodified, reference-order) oracle — same permutation of equal voxel keys, same
     1024-block splits, same summation order — and covariances equal to 1e-9."""

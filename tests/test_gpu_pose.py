@@ -70,3 +70,26 @@ def test_quirks_survive_on_the_gpu(gpu_api, oracle):
     p2 = synth.pose_frame(8, n_obs=120, outlier_frac=0.0)
     one, four = po.PoseOptimization([dict(p2, n_rounds=1), p2])
     assert four["avg_reproj_error"] < 0.5 * one["avg_reproj_error"]
+
+
+def test_random_frames_follow_the_oracle_bit_for_bit(gpu_api, oracle):
+    """1 200 random frames (drawn like tests/fuzz_gpu.py section 5: 0 ... 1 500 observations, mono / stereo / mixed, up to 40 % gross
+    outliers, up to 3 degrees / 0.1 m of initial error): every sum over the edges runs in g2o's edge order
+    (core/sparse_optimizer.cpp:104-122, core/base_unary_edge.hpp:43-72) and sin / cos / pow carry glibc's bits, so the LM
+    iteration counts -- decided at a converged state by the sign of a gain ratio that is rounding noise -- the poses and the
+    per-edge chi2 are the CPU restatement's, bit for bit."""
+    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1)
+    differ = []
+    for i in range(1200):
+        rng = np.random.default_rng([77, i])
+        p = synth.pose_frame(int(rng.integers(0, 1 << 30)), n_obs=int(rng.integers(0, 1500)), mono_frac=float(rng.choice([0.0, 0.15, 1.0])),
+                             outlier_frac=float(rng.uniform(0, 0.4)), rot_deg=float(rng.uniform(0, 3)), trans=float(rng.uniform(0, 0.1)))
+        r, ro = po.PoseOptimization(p), oracle.pose_optimization(p)
+        same = (r["iterations_run"] == ro["iterations_run"] and r["rounds_run"] == ro["rounds_run"] and r["n_inliers"] == ro["n_inliers"]
+                and np.array_equal(r["outlier"], ro["outlier"])
+                and np.array_equal(np.asarray(r["q"], np.float64).view(np.uint64), np.asarray(ro["q"], np.float64).view(np.uint64))
+                and np.array_equal(np.asarray(r["t"], np.float64).view(np.uint64), np.asarray(ro["t"], np.float64).view(np.uint64))
+                and np.array_equal(np.asarray(r["chi2"], np.float64).view(np.uint64), np.asarray(ro["chi2"], np.float64).view(np.uint64)))
+        if not same:
+            differ.append((i, p["n_obs"], r["iterations_run"], ro["iterations_run"], _rel(r["q"], ro["q"]), _rel(r["t"], ro["t"])))
+    assert not differ, differ[:10]
