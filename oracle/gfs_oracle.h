@@ -255,6 +255,8 @@ int gfso_gms_inlier_mask(const float* kp1_xy, int n1, int width1, int height1, c
 #define GFSO_KLT_USE_INITIAL_FLOW 4   /* cv::OPTFLOW_USE_INITIAL_FLOW */
 #define GFSO_KLT_GET_MIN_EIGENVALS 8  /* cv::OPTFLOW_LK_GET_MIN_EIGENVALS */
 /* Returns the number of levels buildOpticalFlowPyramid(…, maxLevel) produces; lw/lh [levels], off [levels + 1] (may be NULL). */
+/* 0: exact integer sums (default, what the HIP path implements); 1: OpenCV 4.5.4's scalar float loop; 2: four-lane float model */
+void gfso_klt_set_accumulation(int mode);
 int gfso_klt_layout(int w, int h, int win, int max_level, int32_t* lw, int32_t* lh, int64_t* off);
 int gfso_klt_build_pyramid(const uint8_t* img, int w, int h, int stride, int win, int max_level, uint8_t* pyr_img,
                            int16_t* pyr_deriv);

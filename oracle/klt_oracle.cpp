@@ -21,6 +21,14 @@
 // integers, so this restatement sums them EXACTLY (int64) and rounds once to float — the value every OpenCV build approximates
 // within its own rounding error.  It makes the result independent of summation order (so the GPU can be bit-exact against it)
 // at the price of ulp-level differences to any particular OpenCV binary; see DESIGN.md §2 (deviations) and §8.
+// So that the size of that difference is MEASURED and not asserted, gfso_klt_set_accumulation() switches the tracker to
+//   1: OpenCV 4.5.4's own scalar loop (the generic C++ path of LKTrackerInvoker, lkpyramid.cpp: `acctype iA11 = 0 ...
+//      iA11 += (itemtype)(ixval*ixval)` with acctype = itemtype = float, raster order; `ib1 += (itemtype)(diff*dIptr[0])`), or
+//   2: a four-lane model of the universal-intrinsics builds (lane k of a float32x4 accumulator takes the pixels x = 4i + k of
+//      every row, the row tail goes to the scalar accumulator, the lanes are combined as (l0 + l2) + (l1 + l3) at the end; for
+//      the mismatch vector two neighbouring integer products are added exactly before the conversion, as v_dotprod does).  A
+//      model of how vectorised binaries regroup the sum, not a transcription of one.
+// tests/test_klt_accumulation.py tracks the same points in all three modes and bounds the differences.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -40,6 +48,32 @@ inline int reflect101(int p, int len) {  // cv::borderInterpolate(p, len, BORDER
 inline int cv_round(float v) { return (int)std::lrintf(v); }  // cvRound: round half to even (default FP environment)
 inline int cv_floor(float v) { return (int)std::floor(v); }
 inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }  // CV_DESCALE
+
+int g_accum_mode = 0;  // 0 exact integer sums (what the HIP path implements), 1 OpenCV's scalar float loop, 2 four-lane float model
+
+// One of the tracker's five sums (A11, A12, A22, b1, b2).  add(v, x, vec_end): the integer summand of pixel x of a row whose
+// vectorised part ends at vec_end (mode 2).
+struct Acc {
+  int64_t s = 0;
+  float f = 0.f, lane[4] = {0.f, 0.f, 0.f, 0.f};
+  inline void add(int v, int x, int vec_end) {
+    if (g_accum_mode == 0) s += v;
+    else if (g_accum_mode == 1 || x >= vec_end) f += (float)v;
+    else lane[x & 3] += (float)v;
+  }
+  inline void add_pair(int v0, int v1, int x, int vec_end) {  // pixels x, x + 1 (x even) of the mismatch loop
+    if (g_accum_mode == 2 && x + 1 < vec_end) lane[(x >> 1) & 3] += (float)(v0 + v1);
+    else {
+      add(v0, x, 0);
+      add(v1, x + 1, 0);
+    }
+  }
+  inline float total() const {
+    if (g_accum_mode == 0) return (float)s;
+    if (g_accum_mode == 1) return f;
+    return f + ((lane[0] + lane[2]) + (lane[1] + lane[3]));
+  }
+};
 
 struct Layout {
   int n = 0;
@@ -124,7 +158,8 @@ void track_level(const LevelView& V, int win, int level, int max_level, int flag
 
   int16_t* Iw = buf.data();
   int16_t* dIw = buf.data() + (size_t)win * win;
-  int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+  Acc sA11, sA12, sA22;
+  const int vec4 = win & ~3, vec8 = win & ~7;
   for (int y = 0; y < win; y++) {
     const uint8_t* src = V.I + (int64_t)(y + ipy) * V.pitch + ipx;
     const int16_t* dsrc = V.dI + ((int64_t)(y + ipy) * V.pitch + ipx) * 2;
@@ -136,12 +171,12 @@ void track_level(const LevelView& V, int win, int level, int max_level, int flag
       Iw[y * win + x] = (int16_t)ival;
       dIw[(y * win + x) * 2] = (int16_t)ixval;
       dIw[(y * win + x) * 2 + 1] = (int16_t)iyval;
-      sA11 += (int64_t)ixval * ixval;
-      sA12 += (int64_t)ixval * iyval;
-      sA22 += (int64_t)iyval * iyval;
+      sA11.add(ixval * ixval, x, vec4);
+      sA12.add(ixval * iyval, x, vec4);
+      sA22.add(iyval * iyval, x, vec4);
     }
   }
-  float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+  float A11 = sA11.total() * FLT_SCALE, A12 = sA12.total() * FLT_SCALE, A22 = sA22.total() * FLT_SCALE;
   float D = A11 * A22 - A12 * A12;
   float min_eig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
   if (flags & GFSO_KLT_GET_MIN_EIGENVALS) *err = min_eig;
@@ -165,17 +200,30 @@ void track_level(const LevelView& V, int win, int level, int max_level, int flag
     iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
     iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
     iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-    int64_t sb1 = 0, sb2 = 0;
+    Acc sb1, sb2;
     for (int y = 0; y < win; y++) {
       const uint8_t* Jp = V.J + (int64_t)(y + iny) * V.pitch + inx;
+      int p1 = 0, p2 = 0;
       for (int x = 0; x < win; x++) {
         int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + V.pitch] * iw10 + Jp[x + V.pitch + 1] * iw11, W_BITS1 - 5) -
                    Iw[y * win + x];
-        sb1 += (int64_t)diff * dIw[(y * win + x) * 2];
-        sb2 += (int64_t)diff * dIw[(y * win + x) * 2 + 1];
+        const int q1 = diff * dIw[(y * win + x) * 2], q2 = diff * dIw[(y * win + x) * 2 + 1];
+        if (g_accum_mode != 2) {
+          sb1.add(q1, x, 0);
+          sb2.add(q2, x, 0);
+        } else if (x >= vec8) {
+          sb1.add(q1, x, 0);
+          sb2.add(q2, x, 0);
+        } else if (x & 1) {
+          sb1.add_pair(p1, q1, x - 1, vec8);
+          sb2.add_pair(p2, q2, x - 1, vec8);
+        } else {
+          p1 = q1;
+          p2 = q2;
+        }
       }
     }
-    float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+    float b1 = sb1.total() * FLT_SCALE, b2 = sb2.total() * FLT_SCALE;
     float dx = (float)((A12 * b2 - A22 * b1) * D), dy = (float)((A12 * b1 - A11 * b2) * D);
     nx += dx;
     ny += dy;
@@ -215,6 +263,8 @@ void track_level(const LevelView& V, int win, int level, int max_level, int flag
   }
 }
 }  // namespace
+
+extern "C" void gfso_klt_set_accumulation(int mode) { g_accum_mode = mode < 0 || mode > 2 ? 0 : mode; }
 
 extern "C" int gfso_klt_layout(int w, int h, int win, int max_level, int32_t* lw, int32_t* lh, int64_t* off) {
   Layout L = make_layout(w, h, win, max_level);

@@ -585,6 +585,11 @@ def stereo_from_rgbd(kps, depth, bf, kps_un_x=None):
 KLT_USE_INITIAL_FLOW, KLT_GET_MIN_EIGENVALS = 4, 8
 
 
+def klt_set_accumulation(mode):
+    """0 exact integer sums (default), 1 OpenCV's scalar float loop, 2 four-lane float model (oracle/klt_oracle.cpp header)."""
+    lib().gfso_klt_set_accumulation(int(mode))
+
+
 def klt_layout(width, height, win, max_level=3):
     """Level sizes and offsets of cv::buildOpticalFlowPyramid(img, pyr, Size(win, win), max_level) in the shared storage layout.
     Returns (lw, lh, off) with len(off) == levels + 1."""
