@@ -20,6 +20,12 @@
 // pivoting and the real roots of det(l*F1 + (1-l)*F2) = 0 by bracketing + bisection + Newton, all in +, -, *, /, sqrt: the CPU and
 // the GPU then produce the same bits.  The fundamental matrices agree with OpenCV's to rounding noise; their ORDER within one
 // subset (ascending l here) can differ, which matters only when two models of the same subset tie on the inlier count.
+// So that the effect of those two choices is MEASURED and not asserted, gfso_fmat_set_solver(1) switches seven_point() to OpenCV's own
+// internals, restated from the 4.5.4 sources: cv::SVDecomp(A, W, U, Vt, MODIFY_A | FULL_UV) on the 7 x 9 system = JacobiSVDImpl_
+// (core/src/lapack.cpp) on the rows of A -- one-sided Jacobi sweeps until no pair rotates, singular values sorted descending, and
+// the two null vectors produced the way FULL_UV completes the basis: a +-1/9 vector drawn from cv::RNG(0x12345678), projected
+// off the earlier rows twice and normalised --, then cv::solveCubic (core/src/mathfuncs.cpp: acos / cos for three real roots, pow
+// for one), roots in its order.  tests/test_fmat_solver_variants.py runs RANSAC both ways over many problems and compares masks.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -28,6 +34,169 @@
 #include "gfs_oracle.h"
 
 namespace gfs_fmat {
+
+int g_solver_mode = 0;  // 0: Gauss-Jordan null space + bisection (what the HIP path implements), 1: OpenCV's Jacobi SVD + solveCubic
+
+// cv::SVDecomp(A 7x9, FULL_UV): rows 7 and 8 of Vt.  `a` holds A on entry (rows 0 .. 6) and Vt on return (9 rows).
+void opencv_svd_null_space(double a[9][9]) {
+  const int m = 9, n = 7, n1 = 9;
+  const double minval = 2.2250738585072014e-308, eps = 2.220446049250313e-16 * 10;
+  double W[9];
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) sd += a[i][k] * a[i][k];
+    W[i] = sd;
+  }
+  const int max_iter = 30;  // std::max(m, 30)
+  for (int iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    for (int i = 0; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        double *Ai = a[i], *Aj = a[j];
+        double aa = W[i], p = 0, bb = W[j];
+        for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+        if (std::abs(p) <= eps * std::sqrt(aa * bb)) continue;
+        p *= 2;
+        const double beta = aa - bb, gamma = hypot(p, beta);
+        double c, sn;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          sn = std::sqrt(delta / gamma);
+          c = p / (gamma * sn * 2);
+        } else {
+          c = std::sqrt((gamma + beta) / (gamma * 2));
+          sn = p / (gamma * c * 2);
+        }
+        aa = bb = 0;
+        for (int k = 0; k < m; k++) {
+          const double t0 = c * Ai[k] + sn * Aj[k];
+          const double t1 = -sn * Ai[k] + c * Aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          aa += t0 * t0;
+          bb += t1 * t1;
+        }
+        W[i] = aa;
+        W[j] = bb;
+        changed = true;
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) sd += a[i][k] * a[i][k];
+    W[i] = std::sqrt(sd);
+  }
+  for (int i = 0; i < n - 1; i++) {
+    int j = i;
+    for (int k = i + 1; k < n; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      std::swap(W[i], W[j]);
+      for (int k = 0; k < m; k++) std::swap(a[i][k], a[j][k]);
+    }
+  }
+  uint64_t state = 0x12345678;  // RNG rng(0x12345678)
+  auto next = [&]() {
+    state = (uint64_t)(unsigned)state * 4164903690u + (unsigned)(state >> 32);
+    return (unsigned)state;
+  };
+  for (int i = 0; i < n1; i++) {
+    double sd = i < n ? W[i] : 0;
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+      const double val0 = 1. / m;
+      for (int k = 0; k < m; k++) a[i][k] = (next() & 256) != 0 ? val0 : -val0;
+      for (int iter = 0; iter < 2; iter++)
+        for (int j = 0; j < i; j++) {
+          sd = 0;
+          for (int k = 0; k < m; k++) sd += a[i][k] * a[j][k];
+          double asum = 0;
+          for (int k = 0; k < m; k++) {
+            const double t = a[i][k] - sd * a[j][k];
+            a[i][k] = t;
+            asum += std::abs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < m; k++) a[i][k] *= asum;
+        }
+      sd = 0;
+      for (int k = 0; k < m; k++) sd += a[i][k] * a[i][k];
+      sd = std::sqrt(sd);
+    }
+    const double sc = sd > minval ? 1 / sd : 0.;
+    for (int k = 0; k < m; k++) a[i][k] *= sc;
+  }
+}
+
+// cv::solveCubic(coeffs 1x4, roots): returns the number of roots, in OpenCV's order
+int opencv_solve_cubic(const double* cd, double* roots) {
+  double a0 = cd[0], a1 = cd[1], a2 = cd[2], a3 = cd[3];
+  double x0 = 0., x1 = 0., x2 = 0.;
+  int n = 0;
+  if (a0 == 0) {
+    if (a1 == 0) {
+      if (a2 == 0)
+        n = a3 == 0 ? -1 : 0;
+      else {
+        x0 = -a3 / a2;
+        n = 1;
+      }
+    } else {
+      double d = a2 * a2 - 4 * a1 * a3;
+      if (d >= 0) {
+        d = std::sqrt(d);
+        const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+        if (std::fabs(q1) > std::fabs(q2)) {
+          x0 = q1 / a1;
+          x1 = a3 / q1;
+        } else {
+          x0 = q2 / a1;
+          x1 = a3 / q2;
+        }
+        n = d > 0 ? 2 : 1;
+      }
+    }
+  } else {
+    a0 = 1. / a0;
+    a1 *= a0;
+    a2 *= a0;
+    a3 *= a0;
+    const double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+    const double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+    const double Qcubed = Q * Q * Q;
+    double d = Qcubed - R * R;
+    if (d > 0) {
+      const double theta = std::acos(R / std::sqrt(Qcubed));
+      const double sqrtQ = std::sqrt(Q);
+      const double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+      x0 = t0 * std::cos(t1) - t2;
+      x1 = t0 * std::cos(t1 + (2. * 3.1415926535897932384626433832795 / 3)) - t2;
+      x2 = t0 * std::cos(t1 + (4. * 3.1415926535897932384626433832795 / 3)) - t2;
+      n = 3;
+    } else if (d == 0) {
+      if (R >= 0) {
+        x0 = -2 * std::pow(R, 1. / 3) - a1 / 3;
+        x1 = std::pow(R, 1. / 3) - a1 / 3;
+      } else {
+        x0 = 2 * std::pow(-R, 1. / 3) - a1 / 3;
+        x1 = -std::pow(-R, 1. / 3) - a1 / 3;
+      }
+      x2 = 0;
+      n = x0 == x1 ? 1 : 2;
+      x1 = x0 == x1 ? 0 : x1;
+    } else {
+      d = std::sqrt(-d);
+      double e = std::pow(d + std::fabs(R), 1. / 3);
+      if (R > 0) e = -e;
+      x0 = (e + Q / e) - a1 * (1. / 3);
+      n = 1;
+    }
+  }
+  roots[0] = x0;
+  roots[1] = x1;
+  roots[2] = x2;
+  return n;
+}
 
 struct Rng {  // cv::RNG((uint64)-1)
   uint64_t state = 0xffffffffffffffffull;
@@ -163,50 +332,61 @@ int seven_point(const float* m1, const float* m2, const int* idx, double* Fm) {
     a[i][7] = y0;
     a[i][8] = 1;
   }
-  // null space of the 7 x 9 system: Gauss-Jordan with full pivoting; perm = column order, the last two columns stay free
-  int perm[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
-  for (int r = 0; r < 7; r++) {
-    int pi = r, pj = r;
-    double pv = -1;
-    for (int i = r; i < 7; i++)
-      for (int j = r; j < 9; j++)
-        if (std::fabs(a[i][j]) > pv) {
-          pv = std::fabs(a[i][j]);
-          pi = i;
-          pj = j;
-        }
-    if (!(pv > 0)) return 0;
-    for (int j = 0; j < 9; j++) {
-      const double tmp = a[r][j];
-      a[r][j] = a[pi][j];
-      a[pi][j] = tmp;
-    }
-    for (int i = 0; i < 7; i++) {
-      const double tmp = a[i][r];
-      a[i][r] = a[i][pj];
-      a[i][pj] = tmp;
-    }
-    {
-      const int tmp = perm[r];
-      perm[r] = perm[pj];
-      perm[pj] = tmp;
-    }
-    const double ip = 1. / a[r][r];
-    for (int j = 0; j < 9; j++) a[r][j] *= ip;
-    for (int i = 0; i < 7; i++) {
-      if (i == r) continue;
-      const double f = a[i][r];
-      for (int j = 0; j < 9; j++) a[i][j] -= f * a[r][j];
-    }
-  }
   double f1[9], f2[9];
-  for (int j = 0; j < 9; j++) f1[j] = f2[j] = 0;
-  for (int r = 0; r < 7; r++) {
-    f1[perm[r]] = -a[r][7];
-    f2[perm[r]] = -a[r][8];
+  if (g_solver_mode == 1) {  // OpenCV's own: SVDecomp(A, W, U, Vt, MODIFY_A | FULL_UV); f1 = Vt row 7, f2 = Vt row 8
+    double at[9][9];
+    for (int i = 0; i < 7; i++)
+      for (int j = 0; j < 9; j++) at[i][j] = a[i][j];
+    opencv_svd_null_space(at);
+    for (int j = 0; j < 9; j++) {
+      f1[j] = at[7][j];
+      f2[j] = at[8][j];
+    }
+  } else {
+    // null space of the 7 x 9 system: Gauss-Jordan with full pivoting; perm = column order, the last two columns stay free
+    int perm[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+    for (int r = 0; r < 7; r++) {
+      int pi = r, pj = r;
+      double pv = -1;
+      for (int i = r; i < 7; i++)
+        for (int j = r; j < 9; j++)
+          if (std::fabs(a[i][j]) > pv) {
+            pv = std::fabs(a[i][j]);
+            pi = i;
+            pj = j;
+          }
+      if (!(pv > 0)) return 0;
+      for (int j = 0; j < 9; j++) {
+        const double tmp = a[r][j];
+        a[r][j] = a[pi][j];
+        a[pi][j] = tmp;
+      }
+      for (int i = 0; i < 7; i++) {
+        const double tmp = a[i][r];
+        a[i][r] = a[i][pj];
+        a[i][pj] = tmp;
+      }
+      {
+        const int tmp = perm[r];
+        perm[r] = perm[pj];
+        perm[pj] = tmp;
+      }
+      const double ip = 1. / a[r][r];
+      for (int j = 0; j < 9; j++) a[r][j] *= ip;
+      for (int i = 0; i < 7; i++) {
+        if (i == r) continue;
+        const double f = a[i][r];
+        for (int j = 0; j < 9; j++) a[i][j] -= f * a[r][j];
+      }
+    }
+    for (int j = 0; j < 9; j++) f1[j] = f2[j] = 0;
+    for (int r = 0; r < 7; r++) {
+      f1[perm[r]] = -a[r][7];
+      f2[perm[r]] = -a[r][8];
+    }
+    f1[perm[7]] = 1;
+    f2[perm[8]] = 1;
   }
-  f1[perm[7]] = 1;
-  f2[perm[8]] = 1;
   // det(l * f1 + (1 - l) * f2) = 0 as in run7Point: f1 := f1 - f2, polynomial c[0] l^3 + c[1] l^2 + c[2] l + c[3]
   for (int i = 0; i < 9; i++) f1[i] -= f2[i];
   double c[4];
@@ -223,7 +403,8 @@ int seven_point(const float* m1, const float* m2, const int* idx, double* Fm) {
          f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
   c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
   double roots[3];
-  const int n = cubic_real_roots(c, roots);
+  const int n = g_solver_mode == 1 ? opencv_solve_cubic(c, roots) : cubic_real_roots(c, roots);
+  if (n < 1 || n > 3) return n < 0 ? 0 : n;
   for (int k = 0; k < n; k++) {
     double* F = Fm + 9 * k;
     double lambda = roots[k], mu = 1.;
@@ -283,6 +464,8 @@ int update_num_iters(double p, double ep, int max_iters) {  // RANSACUpdateNumIt
 }
 
 }  // namespace gfs_fmat
+
+extern "C" void gfso_fmat_set_solver(int mode) { gfs_fmat::g_solver_mode = mode == 1 ? 1 : 0; }
 
 extern "C" int gfso_fundamental_ransac(const float* pts1, const float* pts2, int n, double threshold, double confidence, int max_iters,
                                        uint8_t* mask, double* F_out, int* iterations_run) {

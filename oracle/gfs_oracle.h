@@ -274,6 +274,8 @@ int gfso_fb_klt_tracking(const uint8_t* prev_img, const int16_t* prev_deriv, con
  *      src/ORBmatcher.cc:236, 2399, 2463; src/Tracking.cc:1974): 7-point RANSAC with cv::RNG((uint64)-1).  See fmat_oracle.cpp for the
  *      two deliberate differences (null-space basis and cubic solver in basic arithmetic only).  pts: n x 2 floats.  Returns the
  *      inlier count of the best model (0 = no model, -2 = fewer than 15 points: OpenCV runs LMedS there, not restated). ---- */
+/* 0: Gauss-Jordan null space + bisection (default, what the HIP path implements); 1: OpenCV's Jacobi SVD + cv::solveCubic */
+void gfso_fmat_set_solver(int mode);
 int gfso_fundamental_ransac(const float* pts1, const float* pts2, int n, double threshold, double confidence, int max_iters,
                             uint8_t* mask, double* F_out, int* iterations_run);
 

@@ -653,6 +653,11 @@ def fb_klt_tracking(prev_pyr, cur_pyr, width, height, win, nbpyrlvl, ferr, fmax_
     return pri[:n].copy(), st[:n].astype(bool), int(good)
 
 
+def fmat_set_solver(mode):
+    """0 Gauss-Jordan null space + bisection (default), 1 OpenCV's Jacobi SVD + cv::solveCubic (oracle/fmat_oracle.cpp header)."""
+    lib().gfso_fmat_set_solver(int(mode))
+
+
 def fundamental_ransac(pts1, pts2, threshold=3.0, confidence=0.99, max_iters=1000):
     """cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, threshold, confidence, mask) restatement (oracle/fmat_oracle.cpp): RANSAC for n >= 15, LMedS for 8 <= n < 15 like the cv:: wrapper.
     Returns (mask bool [n], F [3, 3] or None, n_inliers, iterations_run)."""

@@ -42,4 +42,5 @@ def test_pow3_far_from_one(gpu_api):
     _, _, p = _device(gpu_api, x)
     with np.errstate(over="ignore", under="ignore"):
         want = np.array([math.pow(v, 3.0) if abs(v) < 1e103 else (math.copysign(math.inf, v)) for v in x])
-    assert np.array_equal(_bits(p), _bits(want))
+    bad = np.nonzero(_bits(p) != _bits(want))[0]
+    assert len(bad) == 0, [(float(x[i]).hex(), float(p[i]).hex(), float(want[i]).hex()) for i in bad[:8]]
