@@ -281,3 +281,56 @@ def test_streaming_batch_device(gpu_api):
     with pytest.raises(gpu_api.GfsError):
         chain.align_next_batch_device(d[0][0], d[0][1], B - 1, SP)           # batch size differs from the cached call
     hip.free()
+
+
+def _gicp_same(r, ro, bar=1e-5):
+    return (r["converged"] == ro["converged"] and r["iterations"] == ro["iterations"] and r["num_inliers"] == ro["num_inliers"]
+            and r["n_target_ds"] == ro["n_target_ds"] and r["n_source_ds"] == ro["n_source_ds"] and _rel(r["T"], ro["T"]) < bar)
+
+
+def test_random_pairs_meet_the_bar_or_have_a_proved_kth_distance_tie(gpu_api, oracle):
+    """2 000 random noise-free cloud pairs (drawn like tests/fuzz_gpu.py section 2: sizes, truncations, motions up to 0.15 m / 5 deg).
+    Every pair either agrees with the oracle -- converged flag, iteration count, inlier count, down-sampled sizes equal, pose within
+    the 1e-5 bar of BASELINE.json -- or the ONE documented cause is established for it and then removed: the voxel means are
+    bit-identical, some point has an EXACT distance tie between its 10th and 11th neighbour (ann/knn_result.hpp:80-101 keeps the first
+    one pushed, i.e. the KdTree's visiting order, which the reference itself does not reproduce between runs: DESIGN.md section 2),
+    and after moving the raw points behind every tied 11th neighbour by 20 micrometres the same pair agrees."""
+    reg = gpu_api.RegistrationGICP(max_points=65536)
+    ties, worst = [], 0.0
+    for ci in range(2000):
+        rng = np.random.default_rng([4321, 2, ci])
+        s = int(rng.integers(0, 1 << 30))
+        w, h = int(rng.choice([96, 128, 160, 200])), int(rng.choice([72, 96, 120, 150]))
+        c0, c1, _ = synth.cloud_pair(s, w, h, trans=float(rng.uniform(0.0, 0.15)), rot_deg=float(rng.uniform(0, 5)))
+        if rng.integers(0, 4) == 0:
+            c0 = c0[:int(len(c0) * rng.uniform(0.2, 1.0))]
+        if rng.integers(0, 4) == 0:
+            c1 = c1[::int(rng.integers(1, 4))]
+        r, ro = reg.RegisterPointClouds(c0, c1), oracle.gicp_align(c0, c1)
+        if _gicp_same(r, ro):
+            worst = max(worst, _rel(r["T"], ro["T"]))
+            continue
+        clouds = [c0.copy(), c1.copy()]
+        for attempt in range(3):  # breaking one tie can, rarely, create another
+            n_ties = 0
+            for which in (0, 1):
+                pts, _ = reg.preprocessed(0, which)
+                po, _, _ = oracle.gicp_preprocess(clouds[which])
+                ig, io = np.lexsort((pts[:, 2], pts[:, 1], pts[:, 0])), np.lexsort((po[:, 2], po[:, 1], po[:, 0]))
+                assert len(pts) == len(po) and (pts[ig] == po[io]).all(), ("voxel means differ", ci)
+                idx, sq = oracle.knn(po, po, 11)
+                for t in np.nonzero(sq[:, 9] == sq[:, 10])[0]:
+                    n_ties += 1
+                    key = np.floor(po[int(idx[t, 10]), :3] / 0.02).astype(np.int64)
+                    raw = clouds[which]
+                    sel = (np.floor(raw[:, :3].astype(np.float64) / 0.02).astype(np.int64) == key).all(1)
+                    raw[sel, 0] += np.float32(2e-5)
+            assert n_ties > 0, ("pair over the bar without a k-th-distance tie", ci, _rel(r["T"], ro["T"]), r["iterations"], ro["iterations"])
+            r2, ro2 = reg.RegisterPointClouds(clouds[0], clouds[1]), oracle.gicp_align(clouds[0], clouds[1])
+            if _gicp_same(r2, ro2):
+                break
+        else:
+            raise AssertionError(("still over the bar with every tie broken", ci))
+        ties.append((ci, _rel(r["T"], ro["T"]), n_ties))
+    assert len(ties) <= 40, ties  # round 2 measured 7 of 13 000
+    assert worst < 1e-5
