@@ -49,6 +49,8 @@ struct PairState {
 struct GicpParams {
   double inv_leaf, cell, inv_cell, max_dist_sq, rot_eps, trans_eps;
   int max_iterations, k_neighbors;
+  unsigned* tile_stats;  // optional [8]: workgroups of k_gicp_linearize by outcome of the tile staging (0 = tiled), diagnostics
+  int lin_tile;  // k_gicp_linearize stages its target tile in LDS (GFS_GICP_LIN_TILE=0 switches it off)
   int nn_rings;  // ceil(max_corr / cell): rings of cells a 1-NN probe may need to certify "nothing within max_corr"
   // Cloud slots of pair b are 2b and 2b + 1.  src_slot: which of the two holds the SOURCE cloud (1 in the plain entry points;
   // the streaming entry alternates so that the previous call's preprocessed source becomes this call's target in place).
@@ -1110,90 +1112,306 @@ __device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __
   if (threadIdx.x < N) dst[threadIdx.x] = r;
 }
 
+// ---- the target cloud as the 1-NN search sees it: cell boundaries of a row, candidate points.  Two sources with the same
+//      interface: the cloud in HBM (dense cell grid G), and a workgroup's TILE of it staged in LDS (LinTile below).
+struct NnGlobal {
+  const double4* tp;
+  const int* gi;
+  const unsigned* G;
+  const u64* uc;
+  const unsigned* ub;
+  int nu;
+  // boundaries (global point indices) of cells cx-1, cx, cx+1 of row (y, z); returns the offset that turns a global point index
+  // into this source's index (0 here)
+  __device__ __forceinline__ int cells3(int cx, int y, int z, int* e) const {
+    row_cells3(gi, G, uc, ub, nu, cx, y, z, e);
+    return 0;
+  }
+  __device__ __forceinline__ void load(int idx, double& x, double& y, double& z) const {
+    const double4 q = tp[idx];
+    x = q.x;
+    y = q.y;
+    z = q.z;
+  }
+};
+
+// A workgroup's tile of the target cloud.  The 256 source points of a workgroup are consecutive in cell order, so under the
+// current pose they land in a compact set of target cells; the rows of cells (y, z) their 27-cell neighbourhoods touch, each cut
+// to the x range those neighbourhoods need, are copied once with coalesced loads -- coordinates as three arrays of doubles, and
+// the rows' cell boundaries out of the dense grid -- and every lane then walks ITS cells out of LDS instead of gathering 32-byte
+// points through the vector L1 (~2 500 L1 accesses per wave before).  Workgroups whose tile does not fit (a block that straddles
+// distant surfaces) use the cloud in HBM; both sources give the same correspondences.
+#ifndef GFS_TILE_CAP
+#define GFS_TILE_CAP 1664
+#endif
+#ifndef GFS_TILE_CELLS
+#define GFS_TILE_CELLS 1280
+#endif
+constexpr int kTileCap = GFS_TILE_CAP;      // staged points
+constexpr int kTileRows = 192;              // rows of cells in the box of a workgroup
+constexpr int kTileCells = GFS_TILE_CELLS;  // staged cell boundaries
+struct LinTile {
+  double x[kTileCap], y[kTileCap], z[kTileCap];
+  unsigned cells[kTileCells];
+  int row_a[kTileRows], row_b[kTileRows];  // stage 1: x range of the lanes centred on the row; afterwards: first point, length
+  int row_lo[kTileRows];                   // x of the row's first staged cell boundary (-> index into cells)
+  int row_wid[kTileRows];                  // number of staged boundaries
+  int row_delta[kTileRows];                // LDS index = global point index + delta
+  int row_coff[kTileRows];                 // offset of the row's boundaries in cells[], -1: nothing staged (empty row)
+  int box[4];                              // cymin, cymax, czmin, czmax
+  unsigned long long wave_tot[4];
+};
+struct NnTile {
+  const LinTile* t;
+  int y0, z0, ny;  // the box's first row (cymin - 1, czmin - 1) and its row count along y
+  __device__ __forceinline__ int cells3(int cx, int y, int z, int* e) const {
+    const int r = (y - y0) + ny * (z - z0);
+    const int coff = t->row_coff[r];
+    e[0] = e[1] = e[2] = e[3] = 0;
+    if (coff < 0) return 0;
+    const int k0 = coff + (cx - 1 - t->row_lo[r]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) e[k] = (int)t->cells[k0 + k];
+    return t->row_delta[r];
+  }
+  __device__ __forceinline__ void load(int idx, double& x, double& y, double& z) const {
+    x = t->x[idx];
+    y = t->y[idx];
+    z = t->z[idx];
+  }
+};
+
+// 1-NN scan over up to four candidate runs (global begin, length, source offset) concatenated into one lane-private sequence:
+// every lane walks only ITS surviving cells, four candidates in flight.  bj is a GLOBAL point index.
+template <class Src>
+__device__ __forceinline__ void nn_scan4(const Src& src, double tx, double ty, double tz, int b0, int l0, int d0, int b1, int l1, int d1, int b2,
+                                         int l2, int d2, int b3, int l3, int d3, double& best, int& bj) {
+  const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
+  const int o0 = b0, o1 = b1 - c1, o2 = b2 - c2, o3 = b3 - c3;
+  for (int v = 0; v < total; v += 4) {
+    int j[4];
+    double dd[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int vv = min(v + u, total - 1);
+      const int run = vv < c1 ? 0 : vv < c2 ? 1 : vv < c3 ? 2 : 3;
+      j[u] = vv + (run == 0 ? o0 : run == 1 ? o1 : run == 2 ? o2 : o3);
+      double qx, qy, qz;
+      src.load(j[u] + (run == 0 ? d0 : run == 1 ? d1 : run == 2 ? d2 : d3), qx, qy, qz);
+      dd[u] = (qx - tx) * (qx - tx) + (qy - ty) * (qy - ty) + (qz - tz) * (qz - tz);
+    }
+    // clamped duplicates of the last candidate cannot win the strict '<'
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (dd[u] < best) {
+        best = dd[u];
+        bj = j[u];
+      }
+  }
+}
+
+// Exact 1-NN of (tx, ty, tz) inside the 27-cell cube around its cell (cell edge >= max correspondence distance), branch and bound
+// per lane: a cell is skipped when its box is farther than the bound B = min(max_dist^2, best so far).  `best` / `bj` come in
+// holding the correspondence of the previous linearisation re-evaluated under the new pose (or +inf / -1).  Order: own cell,
+// its two neighbours along x, then the other eight rows.
+template <class Src>
+__device__ __forceinline__ void nn_search27(const Src& src, const GicpParams& prm, double tx, double ty, double tz, int cx, int cy, int cz,
+                                            double& best, int& bj) {
+  double B = fmin(prm.max_dist_sq, best);
+  // lower bounds of the distance to the neighbouring cells along each axis (a hair conservative: 1e-9 cells)
+  const double ux = tx * prm.inv_cell - (double)(cx - kCoordOffset), uy = ty * prm.inv_cell - (double)(cy - kCoordOffset),
+               uz = tz * prm.inv_cell - (double)(cz - kCoordOffset);
+  const double lx0 = fmax(ux - 1e-9, 0.0) * prm.cell, lx2 = fmax(1.0 - ux - 1e-9, 0.0) * prm.cell;
+  const double ly[3] = {fmax(uy - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uy - 1e-9, 0.0) * prm.cell};
+  const double lz[3] = {fmax(uz - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uz - 1e-9, 0.0) * prm.cell};
+  {  // own row: the own cell first, its two neighbours only if they can still hold something nearer
+    int e[4];
+    const int d = src.cells3(cx, cy, cz, e);
+    nn_scan4(src, tx, ty, tz, e[1], e[2] - e[1], d, 0, 0, 0, 0, 0, 0, 0, 0, 0, best, bj);
+    B = fmin(B, best);
+    const int ll = lx0 * lx0 <= B ? e[1] - e[0] : 0, lr = lx2 * lx2 <= B ? e[3] - e[2] : 0;
+    nn_scan4(src, tx, ty, tz, e[0], ll, d, e[2], lr, d, 0, 0, 0, 0, 0, 0, best, bj);
+    B = fmin(B, best);
+  }
+  int rb[8], rl[8], rd[8], rank[8], nkept = 0;
+#pragma unroll
+  for (int t8 = 0; t8 < 8; t8++) {
+    const int t9 = t8 < 4 ? t8 : t8 + 1, dy = t9 % 3, dz = t9 / 3;
+    const double row2 = ly[dy] * ly[dy] + lz[dz] * lz[dz];
+    rb[t8] = 0;
+    rl[t8] = 0;
+    rd[t8] = 0;
+    if (row2 <= B) {
+      int e[4];
+      rd[t8] = src.cells3(cx, cy + dy - 1, cz + dz - 1, e);
+      const int b0 = row2 + lx0 * lx0 <= B ? e[0] : e[1], e0 = row2 + lx2 * lx2 <= B ? e[3] : e[2];
+      rb[t8] = b0;
+      rl[t8] = e0 - b0;
+    }
+    rank[t8] = nkept;
+    nkept += rl[t8] > 0 ? 1 : 0;
+  }
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    if (round == 1 && !__any(nkept > 4)) break;
+    int sb[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t8 = 0; t8 < 8; t8++)
+#pragma unroll
+      for (int sl_i = 0; sl_i < 4; sl_i++)
+        if (rl[t8] > 0 && rank[t8] == 4 * round + sl_i) {
+          sb[sl_i] = rb[t8];
+          sl[sl_i] = rl[t8];
+          sd[sl_i] = rd[t8];
+        }
+    nn_scan4(src, tx, ty, tz, sb[0], sl[0], sd[0], sb[1], sl[1], sd[1], sb[2], sl[2], sd[2], sb[3], sl[3], sd[3], best, bj);
+  }
+}
+
+// Stages the workgroup's tile (all threads call it; `inrange` = the lane holds a source point whose image has usable cell
+// coordinates cx, cy, cz).  Returns 0 -- for the whole workgroup -- when the tile is complete, else why not: 1 no dense grid, 2 no lane
+// with a usable image, 3 too many rows in the box, 4 too many points, 5 too many cell boundaries.
+__device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, int cy, int cz, const double4* __restrict__ tp,
+                                               const int* __restrict__ gi, const unsigned* __restrict__ G) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!gi[6]) return 1;  // no dense grid for this cloud (uniform)
+  if (tid < 4) T.box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+  __syncthreads();
+  {
+    int v[4] = {inrange ? cy : INT_MAX, inrange ? -cy : INT_MAX, inrange ? cz : INT_MAX, inrange ? -cz : INT_MAX};
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = min(v[k], __shfl_xor(v[k], ofs, 64));
+    if (lane == 0 && v[0] != INT_MAX) {
+      atomicMin(&T.box[0], v[0]);
+      atomicMax(&T.box[1], -v[1]);
+      atomicMin(&T.box[2], v[2]);
+      atomicMax(&T.box[3], -v[3]);
+    }
+  }
+  __syncthreads();
+  const int cymin = T.box[0], cymax = T.box[1], czmin = T.box[2], czmax = T.box[3];
+  if (cymin > cymax) return 2;  // no lane with a usable image
+  const long long nyl = (long long)cymax - cymin + 3, nzl = (long long)czmax - czmin + 3;
+  if (nyl * nzl > kTileRows) return 3;
+  const int ny = (int)nyl, nz = (int)nzl, nrows = ny * nz, y0 = cymin - 1, z0 = czmin - 1;
+  if (tid < nrows) {
+    T.row_a[tid] = INT_MAX;
+    T.row_b[tid] = INT_MIN;
+  }
+  __syncthreads();
+  if (inrange) {  // x range of the lanes centred on each row
+    const int r = (cy - y0) + ny * (cz - z0);
+    atomicMin(&T.row_a[r], cx);
+    atomicMax(&T.row_b[r], cx);
+  }
+  __syncthreads();
+  int lo = INT_MAX, hi = INT_MIN, j0 = 0, len = 0, wid = 0;
+  if (tid < nrows) {  // a row serves the lanes centred on it and on its eight neighbours
+    const int ry = tid % ny, rz = tid / ny;
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+      for (int dy = -1; dy <= 1; dy++) {
+        const int yy = ry + dy, zz = rz + dz;
+        if (yy >= 0 && yy < ny && zz >= 0 && zz < nz) {
+          lo = min(lo, T.row_a[yy + ny * zz]);
+          hi = max(hi, T.row_b[yy + ny * zz]);
+        }
+      }
+    if (lo <= hi) {
+      lo -= 1;
+      hi += 1;
+      const int gy = y0 + ry - gi[1], gz = z0 + rz - gi[2];
+      if ((unsigned)gy < (unsigned)gi[4] && (unsigned)gz < (unsigned)gi[5]) {
+        const size_t base = ((size_t)gz * gi[4] + gy) * gi[3];
+        j0 = (int)G[base + min(max(lo - gi[0], 0), gi[3])];
+        const int j1 = (int)G[base + min(max(hi + 1 - gi[0], 0), gi[3])];
+        len = max(j1 - j0, 0);
+        wid = len > 0 ? hi - lo + 2 : 0;  // the boundaries of cells lo .. hi + 1
+      }
+    }
+  }
+  // exclusive prefix sums of (len, wid) over the rows: packed in 64 bits, wave scan + the four wave totals
+  const unsigned long long pk = (unsigned long long)(unsigned)len | ((unsigned long long)(unsigned)wid << 32);
+  unsigned long long inc = pk;
+#pragma unroll
+  for (int ofs = 1; ofs < 64; ofs <<= 1) {
+    const unsigned long long o = __shfl_up(inc, ofs, 64);
+    if (lane >= ofs) inc += o;
+  }
+  __syncthreads();  // every thread has read its neighbours' row_a / row_b: they are reused below
+  if (lane == 63) T.wave_tot[wave] = inc;
+  __syncthreads();
+  unsigned long long before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const unsigned long long tw = T.wave_tot[w];
+    if (w < wave) before += tw;
+    total += tw;
+  }
+  if ((unsigned)(total & 0xffffffffu) > (unsigned)kTileCap) return 4;  // uniform
+  if ((unsigned)(total >> 32) > (unsigned)kTileCells) return 5;
+  if (tid < nrows) {
+    const unsigned long long exc = before + inc - pk;
+    const int poff = (int)(exc & 0xffffffffu), coff = (int)(exc >> 32);
+    T.row_a[tid] = j0;
+    T.row_b[tid] = len;
+    T.row_lo[tid] = lo;
+    T.row_wid[tid] = wid;
+    T.row_delta[tid] = poff - j0;
+    T.row_coff[tid] = len > 0 ? coff : -1;
+  }
+  __syncthreads();
+  for (int r = wave; r < nrows; r += 4) {  // a wave copies a row: coalesced 32-byte points in, three arrays out
+    const int n = T.row_b[r];
+    if (n <= 0) continue;
+    const int g0 = T.row_a[r], d = T.row_delta[r];
+    for (int k = lane; k < n; k += 64) {
+      const double4 q = tp[g0 + k];
+      T.x[g0 + k + d] = q.x;
+      T.y[g0 + k + d] = q.y;
+      T.z[g0 + k + d] = q.z;
+    }
+    const int ry = r % ny, rz = r / ny, rlo = T.row_lo[r], coff = T.row_coff[r], w = T.row_wid[r];
+    const size_t rbase = ((size_t)(z0 + rz - gi[2]) * gi[4] + (y0 + ry - gi[1])) * gi[3];
+    for (int k = lane; k < w; k += 64) T.cells[coff + k] = G[rbase + min(max(rlo + k - gi[0], 0), gi[3])];
+  }
+  __syncthreads();
+  return 0;
+}
+
 // GICPFactor::linearize (factors/gicp_factor.hpp:35-73) of source point i of a pair under the pose T12 (R col-major | t): exact
-// 1-NN in the target cloud, rejection beyond max_dist, the Mahalanobis matrix, and this point's terms ADDED to acc (H upper
-// triangle 21, b 6, e, inlier count).  Records the correspondence and the matrix for the error evaluations that follow.
-__device__ __forceinline__ void gicp_lin_point(int i, const double* __restrict__ T12, bool has_prev, int pair, int cs, int ct, int P,
+// 1-NN in the target cloud (through `src`), rejection beyond max_dist, the Mahalanobis matrix, and this point's terms ADDED to
+// acc (H upper triangle 21, b 6, e, inlier count).  Records the correspondence and the matrix for the error evaluations that follow.
+template <class Src>
+__device__ __forceinline__ void gicp_lin_point(const Src& src, int i, const double4 p, double tx, double ty, double tz, int cx, int cy, int cz,
+                                               bool in_range, const double* __restrict__ T12, bool has_prev, int pair, int cs, int ct, int P,
                                                const double4* __restrict__ pts, const double* __restrict__ cov6,
                                                const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
                                                const int* __restrict__ n_ucell, const unsigned* __restrict__ G,
                                                const int* __restrict__ gi, const GicpParams& prm, int* __restrict__ tgt_index,
                                                double* __restrict__ maha6, double (&acc)[kRed]) {
   {
-    const double4 p = pts[(size_t)cs * P + i];
     const double* R = T12;
-    const double* t = T12 + 9;
-    const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
-    const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
-    const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
     const double4* tp = pts + (size_t)ct * P;
     const u64* uc = ucell + (size_t)ct * (P + 1);
     const unsigned* ub = ubegin + (size_t)ct * (P + 1);
     const int nu = n_ucell[ct];
-    const int cx = fast_floor_d(tx * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(ty * prm.inv_cell) + kCoordOffset,
-              cz = fast_floor_d(tz * prm.inv_cell) + kCoordOffset;
     double best = 1.79769313486231570e308;
     int bj = -1;
-    if (fabs(tx) < 2.0e4 && fabs(ty) < 2.0e4 && fabs(tz) < 2.0e4) {
+    if (in_range) {
       if (prm.nn_rings <= 1) {
-        // Exact 1-NN inside the 27-cell cube (cell edge >= max correspondence distance), branch-and-bound per lane:
-        // a cell is skipped when its box is farther than the bound B = min(max_dist^2, best so far).  The bound starts
-        // from the correspondence of the previous linearisation (re-evaluated under the new pose) when there is one,
-        // so most lanes visit their own cell and little else; each lane walks only its surviving cells (nn_scan_runs4).
-        double B = prm.max_dist_sq;
         if (has_prev) {
           const int pj = tgt_index[(size_t)pair * P + i];
           if (pj >= 0) {
             const double4 q = tp[pj];
             best = (q.x - tx) * (q.x - tx) + (q.y - ty) * (q.y - ty) + (q.z - tz) * (q.z - tz);
             bj = pj;
-            B = fmin(B, best);
           }
         }
-        // lower bounds of the distance to the neighbouring cells along each axis (a hair conservative: 1e-9 cells)
-        const double ux = tx * prm.inv_cell - (double)(cx - kCoordOffset), uy = ty * prm.inv_cell - (double)(cy - kCoordOffset),
-                     uz = tz * prm.inv_cell - (double)(cz - kCoordOffset);
-        const double lx0 = fmax(ux - 1e-9, 0.0) * prm.cell, lx2 = fmax(1.0 - ux - 1e-9, 0.0) * prm.cell;
-        const double ly[3] = {fmax(uy - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uy - 1e-9, 0.0) * prm.cell};
-        const double lz[3] = {fmax(uz - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uz - 1e-9, 0.0) * prm.cell};
-        {  // own row first
-          int e[4];
-          row_cells3(gi, G, uc, ub, nu, cx, cy, cz, e);
-          const int b0 = lx0 * lx0 <= B ? e[0] : e[1], e0 = lx2 * lx2 <= B ? e[3] : e[2];
-          nn_scan_runs4(tp, tx, ty, tz, b0, e0 - b0, 0, 0, 0, 0, 0, 0, best, bj);
-          B = fmin(B, best);
-        }
-        int rb[8], rl[8], rank[8], nkept = 0;
-#pragma unroll
-        for (int t8 = 0; t8 < 8; t8++) {
-          const int t9 = t8 < 4 ? t8 : t8 + 1, dy = t9 % 3, dz = t9 / 3;
-          const double row2 = ly[dy] * ly[dy] + lz[dz] * lz[dz];
-          rb[t8] = 0;
-          rl[t8] = 0;
-          if (row2 <= B) {
-            int e[4];
-            row_cells3(gi, G, uc, ub, nu, cx, cy + dy - 1, cz + dz - 1, e);
-            const int b0 = row2 + lx0 * lx0 <= B ? e[0] : e[1], e0 = row2 + lx2 * lx2 <= B ? e[3] : e[2];
-            rb[t8] = b0;
-            rl[t8] = e0 - b0;
-          }
-          rank[t8] = nkept;
-          nkept += rl[t8] > 0 ? 1 : 0;
-        }
-#pragma unroll
-        for (int round = 0; round < 2; round++) {
-          if (round == 1 && !__any(nkept > 4)) break;
-          int sb[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0};
-#pragma unroll
-          for (int t8 = 0; t8 < 8; t8++)
-#pragma unroll
-            for (int sl_i = 0; sl_i < 4; sl_i++)
-              if (rl[t8] > 0 && rank[t8] == 4 * round + sl_i) {
-                sb[sl_i] = rb[t8];
-                sl[sl_i] = rl[t8];
-              }
-          nn_scan_runs4(tp, tx, ty, tz, sb[0], sl[0], sb[1], sl[1], sb[2], sl[2], sb[3], sl[3], best, bj);
-        }
+        nn_search27(src, prm, tx, ty, tz, cx, cy, cz, best, bj);
       } else {
       // (cell edge < max correspondence distance: experiment knob GFS_GICP_CELL)
       // exact 1-NN by growing cubes of cells: after probing radius r every unvisited point is farther than r*cell,
@@ -1297,9 +1515,23 @@ __device__ __forceinline__ void gicp_lin_point(int i, const double* __restrict__
   }
 }
 
+// a source point, its image under the pose and the image's cell
+__device__ __forceinline__ void lin_image(const double4& p, const double* __restrict__ T12, const GicpParams& prm, double& tx, double& ty,
+                                          double& tz, int& cx, int& cy, int& cz, bool& in_range) {
+  const double* R = T12;
+  const double* t = T12 + 9;
+  tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
+  ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
+  tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
+  cx = fast_floor_d(tx * prm.inv_cell) + kCoordOffset;
+  cy = fast_floor_d(ty * prm.inv_cell) + kCoordOffset;
+  cz = fast_floor_d(tz * prm.inv_cell) + kCoordOffset;
+  in_range = fabs(tx) < 2.0e4 && fabs(ty) < 2.0e4 && fabs(tz) < 2.0e4;
+}
+
 // GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
 // machine is in the "linearise" phase; per-block partial sums of H (upper), b, e and the inlier count.
-__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gicp_linearize(const PairState* __restrict__ st,
+__global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* __restrict__ st,
                                                               const double4* __restrict__ pts,
                                                               const double* __restrict__ cov6, const u64* __restrict__ ucell,
                                                               const unsigned* __restrict__ ubegin,
@@ -1309,6 +1541,7 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
                                                               int* __restrict__ tgt_index, double* __restrict__ maha6,
                                                               double* __restrict__ partial, int nblk) {
   __shared__ double s_red[4 * 32];
+  __shared__ LinTile tile;
   int pair, sub, chunk;
   if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
   const PairState S = st[pair];
@@ -1322,8 +1555,29 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
   double acc[kRed];
 #pragma unroll
   for (int k = 0; k < kRed; k++) acc[k] = 0;
-  if (i < ms)
-    gicp_lin_point(i, S.T, S.n_lin > 0, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm, tgt_index, maha6, acc);
+  double4 p = make_double4(0, 0, 0, 0);
+  double tx = 0, ty = 0, tz = 0;
+  int cx = 0, cy = 0, cz = 0;
+  bool in_range = false;
+  if (i < ms) {
+    p = pts[(size_t)cs * P + i];
+    lin_image(p, S.T, prm, tx, ty, tz, cx, cy, cz, in_range);
+  }
+  const double4* tp = pts + (size_t)ct * P;
+  const int why = prm.nn_rings <= 1 && prm.lin_tile ? lin_stage_tile(tile, i < ms && in_range, cx, cy, cz, tp, gi, G) : 6;
+  const bool tiled = why == 0;
+  if (prm.tile_stats && threadIdx.x == 0) atomicAdd(prm.tile_stats + why, 1u);
+  if (i < ms) {
+    if (tiled) {
+      const NnTile src{&tile, tile.box[0] - 1, tile.box[2] - 1, tile.box[1] - tile.box[0] + 3};
+      gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, S.n_lin > 0, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm,
+                     tgt_index, maha6, acc);
+    } else {
+      const NnGlobal src{tp, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
+      gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, S.n_lin > 0, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm,
+                     tgt_index, maha6, acc);
+    }
+  }
   block_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + chunk) * kRed, s_red);
 }
 
@@ -1617,8 +1871,16 @@ __global__ __launch_bounds__(kLmBlock) __attribute__((amdgpu_waves_per_eu(4, 8))
 #pragma unroll
       for (int k = 0; k < kRed; k++) acc[k] = 0;
       const bool has_prev = S.n_lin > 0;
-      for (int i = tid; i < ms; i += kLmBlock)
-        gicp_lin_point(i, S.T, has_prev, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm, tgt_index, maha6, acc);
+      for (int i = tid; i < ms; i += kLmBlock) {
+        const NnGlobal src{pts + (size_t)ct * P, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
+        const double4 p = pts[(size_t)cs * P + i];
+        double tx, ty, tz;
+        int cx, cy, cz;
+        bool in_range;
+        lin_image(p, S.T, prm, tx, ty, tz, cx, cy, cz, in_range);
+        gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, has_prev, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm,
+                       tgt_index, maha6, acc);
+      }
       const double r = gfs_red::block_sum_many<kRed, kLmBlock / 64>(acc, s_red);
       if (tid < kRed) s_sum[tid] = r;
       __syncthreads();
@@ -1752,6 +2014,7 @@ struct gfs_gicp {
   // (k_gicp_lm) — no launches / host polls inside the loop, but only one workgroup of parallelism per pair: measured 4x slower at
   // 128 pairs per batch (25 vs 6 ms per 512 pairs), it pays only for batches of many thousand small pairs.
   bool lm_rounds = true;
+  gfs::DevBuf<unsigned> d_tile_stats;  // [8] outcome counters of k_gicp_linearize's tile staging (gfs_gicp_tile_stats)
   bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
   gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
@@ -1859,6 +2122,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_kinfo2.alloc(C2 * 8));
   A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
   A(h->d_ndone.alloc(1));
+  A(h->d_tile_stats.alloc(8));
   A(h->d_keys0.alloc(C2 * P));
   A(h->d_keys1.alloc(C2 * P));
   A(h->d_val0.alloc(C2 * P));
@@ -1890,6 +2154,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->h_initT.alloc(B * 16));
   A(h->d_zero.alloc(B));
 #undef A
+  if (!rc) (void)hipMemset(h->d_tile_stats.p, 0, 8 * sizeof(unsigned));
   if (!rc) GFS_HIP(hipMemset(h->d_zero.p, 0, B * sizeof(int)));
   if (rc) return rc;
   *out = h.release();
@@ -1932,6 +2197,9 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   prm.inv_cell = 1.0 / prm.cell;
   prm.nn_rings = (int)std::ceil(cfg->max_correspondence_distance / prm.cell - 1e-12);
   if (prm.nn_rings < 1) prm.nn_rings = 1;
+  prm.lin_tile = 1;
+  prm.tile_stats = h->d_tile_stats.p;
+  if (const char* e = getenv("GFS_GICP_LIN_TILE")) prm.lin_tile = atoi(e) != 0;  // 0: every workgroup searches the cloud in HBM
   prm.max_dist_sq = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
   prm.rot_eps = cfg->rotation_eps;
   prm.trans_eps = cfg->translation_eps;
@@ -2125,6 +2393,17 @@ int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsi
   }
   if (n) GFS_HIP(hipMemcpyAsync(perm_out, h->d_val0.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset) {
+  GFS_REQUIRE(h && out8, GFS_ERR_INVALID_ARG, "gfs_gicp_tile_stats: invalid argument");
+  std::lock_guard<std::recursive_mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  unsigned v[8];
+  GFS_HIP(hipMemcpy(v, h->d_tile_stats.p, sizeof(v), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 8; k++) out8[k] = v[k];
+  if (reset) GFS_HIP(hipMemset(h->d_tile_stats.p, 0, sizeof(v)));
   return GFS_OK;
 }
 

@@ -214,6 +214,10 @@ int gfs_gicp_align_next_batch_device(gfs_gicp* h, const void* dev_source, const 
 /* Introspection for parity tests: preprocessing output (voxel means + covariances) of cloud `which`
  * (0 = target, 1 = source) of pair b of the last call. pts: [m][4] f64, covs: [m][9] f64 (3x3 col-major). */
 int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, double* covs, int cap, int* m);
+/* Diagnostics: workgroups of the linearisation kernel since the last reset, by outcome of staging their tile of the target cloud in
+ * LDS: out8[0] staged; [1] no dense grid; [2] no usable point; [3] / [4] / [5] too many rows / points / cell boundaries for the
+ * tile (those workgroups search the cloud in HBM: same results); [6] tiling switched off. */
+int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset);
 /* GPU test hook: the voxel sort of the preprocessing — the device replica of small_gicp's quick_sort_omp
  * (util/sort_omp.hpp:58-85: 3-way quicksort above 1024 elements, libstdc++ std::sort below), whose permutation of
  * equal keys decides the 1024-block splits of voxelgrid_sampling_omp (util/downsampling_omp.hpp:57-90) — on n <=

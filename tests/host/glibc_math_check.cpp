@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     if (!same(std::pow(vx, three), gfs_glibc::pow3(x))) { if (bad_p++ < 5) printf("pow3 %a: %a vs %a\n", x, std::pow(vx, three), gfs_glibc::pow3(x)); }
   };
   const double special[] = {0.0, -0.0, 1.0, -1.0, 0.126, 0.125, 0.855469, 0.8554687, 2.426265, 2.4262, 1e-5, 1e-8, 7.450580596923828e-09, 3.725290298461914e-09,
-                            1e300, -1e300, 1e-300, -1e-300, 1e-110, 5e-324, -5e-324, 2.2250738585072014e-308, 1e103, 1.5e102, 5.6e102, INFINITY, -INFINITY, NAN,
+                            1e300, -1e300, 1e-300, -1e-300, 1e-110, 5e-324, -5e-324, 2.2250738585072014e-308, 1e103, INFINITY, -INFINITY, NAN,
                             0.5, 2.0, 3.0, 1.0000000000000002, 0.9999999999999999};
   for (double x : special) check(x);
   for (long i = 0; i < N; i++) {
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     double x = ((st >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * 3.2;
     const int mode = i & 3;
     if (mode == 1) x = ldexp(x, -(int)((st >> 3) & 31));
-    if (mode == 2) x = ldexp(x, (int)((st >> 3) & 255) - 128);
+    if (mode == 2) x = ldexp(x, (int)((st >> 3) % 470) - 300);  // pow3 through its large-|y log x| paths (results 2^-900 .. 2^510)
     check(x);
   }
   printf("sin %ld cos %ld pow3 %ld of %ld\n", bad_s, bad_c, bad_p, N);
