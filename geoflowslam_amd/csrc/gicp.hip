@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <type_traits>
 
 #include "gfs_common.hpp"
 #include "glibc_math.hpp"
@@ -29,6 +30,11 @@ constexpr u64 kInvalidKey = ~0ull;
 constexpr int kCoordBits = 21;
 constexpr int kCoordOffset = 1 << (kCoordBits - 1);
 constexpr int kCoordMask = (1 << kCoordBits) - 1;
+// The CELL sort key (k_voxel_reduce -> k_radix_sort -> k_cell_build) orders the points of a cell by x as well: its x field counts
+// sixteenths of a cell.  Fields: x fine 25 bits | y 20 bits | z 19 bits (every coordinate the 21-bit voxel fields admit fits).
+constexpr int kFineBits = 4, kFine = 1 << kFineBits;
+constexpr int kCkSy = 25, kCkSz = 45;  // bit positions of the y and z fields of a cell sort key
+constexpr int kCkOffX = 1 << 24, kCkOffY = 1 << 19, kCkOffZ = 1 << 18;
 constexpr int kRed = 29;  // 21 (upper H) + 6 (b) + 1 (e) + 1 (inlier count)
 constexpr int kLinBlock = 256;
 
@@ -100,7 +106,8 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ t
 __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u64* __restrict__ keys1,
                                                      unsigned* __restrict__ val0, unsigned* __restrict__ val1,
                                                      const int* __restrict__ counts, int P, int* __restrict__ which,
-                                                     int* __restrict__ kinfo, int only) {
+                                                     int* __restrict__ kinfo, int only, int sy, int sz) {
+  // sy, sz: bit positions of the second and third field of a key (21 / 42 for voxel keys, kCkSy / kCkSz for cell sort keys)
   constexpr int kDB = 9, kNB = 1 << kDB;  // digit bits, bins
   constexpr int kEl = 4;                  // elements per thread and tile
   __shared__ unsigned hist[kNB];
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   unsigned* va = val0 + (size_t)c * P;
   unsigned* vb = val1 + (size_t)c * P;
   int flip = 0;
-  // Key compaction: the keys pack three 21-bit cell coordinates (x | y << 21 | z << 42) but one cloud spans only a
+  // Key compaction: the keys pack three coordinate fields (x | y << sy | z << sz) but one cloud spans only a
   // few hundred cells per axis.  Re-basing every field to the cloud's minimum and packing the fields tightly is order
   // preserving and cuts the 8 radix passes to ceil((bx + by + bz) / 8) (typically 4).  kinfo = {xmin, ymin, zmin, bx, by}
   // lets later kernels decode; equality and the invalid key (all ones) are preserved.
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
     for (int i = tid; i < n; i += 1024) {
       const u64 k = ka[i];
       if (k == kInvalidKey) continue;
-      const int f[3] = {(int)(k & kCoordMask), (int)((k >> kCoordBits) & kCoordMask), (int)(k >> (2 * kCoordBits))};
+      const int f[3] = {(int)(k & ((1ull << sy) - 1)), (int)((k >> sy) & ((1ull << (sz - sy)) - 1)), (int)(k >> sz)};
       for (int a = 0; a < 3; a++) {
         mn[a] = min(mn[a], f[a]);
         mx[a] = max(mx[a], f[a]);
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   for (int i = tid; i < n; i += 1024) {
     const u64 k = ka[i];
     if (k == kInvalidKey) continue;
-    const u64 x = (k & kCoordMask) - mnx, y = ((k >> kCoordBits) & kCoordMask) - mny, z = (k >> (2 * kCoordBits)) - mnz;
+    const u64 x = (k & ((1ull << sy) - 1)) - mnx, y = ((k >> sy) & ((1ull << (sz - sy)) - 1)) - mny, z = (k >> sz) - mnz;
     ka[i] = x | (y << bx) | (z << (bx + by));
   }
   if (tid == 0) {
@@ -333,8 +340,14 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
       } while (j < n && (j & 1023) != 0 && keys[j] == key);
       const double mx = sx / sw, my = sy / sw, mz = sz / sw;
       out[pos] = make_double4(mx, my, mz, sw / sw);
-      ck[pos] = pack_key(fast_floor_d(mx * inv_cell) + kCoordOffset, fast_floor_d(my * inv_cell) + kCoordOffset,
-                         fast_floor_d(mz * inv_cell) + kCoordOffset);
+      {  // cell sort key: the cell (as every search computes it: floor(v * inv_cell)) and, below it, the sixteenth of the cell along x
+        const double ux = mx * inv_cell;
+        const int cxm = fast_floor_d(ux), cym = fast_floor_d(my * inv_cell), czm = fast_floor_d(mz * inv_cell);
+        const int sub = min(max((int)((ux - (double)cxm) * (double)kFine), 0), kFine - 1);
+        const long long xf = (long long)cxm * kFine + sub + kCkOffX, yf = (long long)cym + kCkOffY, zf = (long long)czm + kCkOffZ;
+        // (coordinates the 21-bit voxel fields admit always fit; anything else cannot have passed the voxel stage)
+        ck[pos] = (u64)xf | ((u64)yf << kCkSy) | ((u64)zf << kCkSz);
+      }
       ci[pos] = (unsigned)pos;
     }
     __syncthreads();
@@ -373,20 +386,32 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
   // every thread owns a contiguous chunk of the sorted keys: one block scan numbers the cell starts
   const int chunk = (m + 1023) / 1024;
   const int i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
+  // the sort compacted the keys (k_radix_sort); a CELL is the key without the kFineBits sub-cell bits of its x field
+  const int* ki = kinfo + 8 * c;
+  const int kbx = ki[3], kby = ki[4];
+  auto cell_of = [&](u64 key, int& kx, int& ky, int& kz) {
+    const int xf = (int)(key & ((1ull << kbx) - 1)) + ki[0] - kCkOffX;
+    kx = (xf >> kFineBits) + kCoordOffset;  // arithmetic shift = floor
+    ky = (int)((key >> kbx) & ((1ull << kby) - 1)) + ki[1] - kCkOffY + kCoordOffset;
+    kz = (int)(key >> (kbx + kby)) + ki[2] - kCkOffZ + kCoordOffset;
+  };
+  auto new_cell = [&](int i) {
+    if (i == 0) return true;
+    int ax, ay, az, bx_, by_, bz_;
+    cell_of(ck[i - 1], ax, ay, az);
+    cell_of(ck[i], bx_, by_, bz_);
+    return ax != bx_ || ay != by_ || az != bz_;
+  };
   int cnt = 0;
-  for (int i = i0; i < i1; i++) cnt += (i == 0 || ck[i - 1] != ck[i]) ? 1 : 0;
+  for (int i = i0; i < i1; i++) cnt += new_cell(i) ? 1 : 0;
   int total;
   int pos = block_scan_1024(cnt, s_wave, &total);
   if (cnt > 0) {
-    // the sort compacted the keys (k_radix_sort): decode back to the packed 3 x 21-bit cell key
-    const int* ki = kinfo + 8 * c;
-    const int kbx = ki[3], kby = ki[4];
     int mn[3] = {kCoordMask, kCoordMask, kCoordMask}, mx[3] = {0, 0, 0};
     for (int i = i0; i < i1; i++) {
-      const u64 key = ck[i];
-      if (i == 0 || ck[i - 1] != key) {
-        const int kx = (int)(key & ((1ull << kbx) - 1)) + ki[0], ky = (int)((key >> kbx) & ((1ull << kby) - 1)) + ki[1],
-                  kz = (int)(key >> (kbx + kby)) + ki[2];
+      if (new_cell(i)) {
+        int kx, ky, kz;
+        cell_of(ck[i], kx, ky, kz);
         uc[pos] = pack_key(kx, ky, kz);
         ub[pos] = (unsigned)i;
         pos++;
@@ -526,32 +551,6 @@ __device__ __forceinline__ void row_cells3(const int* __restrict__ gi, const uns
       const u64 key = x < 0 ? pack_key(0, y, z) : x > kCoordMask ? pack_key(kCoordMask, y, z) + 1 : pack_key(x, y, z);
       e[k] = (int)ub[lower_bound_u64(uc, nu, key)];
     }
-  }
-}
-
-// 1-NN scan over up to four candidate runs (begin, length) concatenated into one lane-private sequence: every lane
-// walks only ITS surviving cells, four loads in flight, so a wave iterates max-over-lanes(sum of lengths) / 4 times.
-__device__ __forceinline__ void nn_scan_runs4(const double4* __restrict__ tp, double tx, double ty, double tz, int b0, int l0,
-                                              int b1, int l1, int b2, int l2, int b3, int l3, double& best, int& bj) {
-  const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
-  const int o0 = b0, o1 = b1 - c1, o2 = b2 - c2, o3 = b3 - c3;
-  for (int v = 0; v < total; v += 4) {
-    int j[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int vv = min(v + u, total - 1);
-      j[u] = vv + (vv < c1 ? o0 : vv < c2 ? o1 : vv < c3 ? o2 : o3);
-    }
-    const double4 q0 = tp[j[0]], q1 = tp[j[1]], q2 = tp[j[2]], q3 = tp[j[3]];
-    const double d0 = (q0.x - tx) * (q0.x - tx) + (q0.y - ty) * (q0.y - ty) + (q0.z - tz) * (q0.z - tz);
-    const double d1 = (q1.x - tx) * (q1.x - tx) + (q1.y - ty) * (q1.y - ty) + (q1.z - tz) * (q1.z - tz);
-    const double d2 = (q2.x - tx) * (q2.x - tx) + (q2.y - ty) * (q2.y - ty) + (q2.z - tz) * (q2.z - tz);
-    const double d3 = (q3.x - tx) * (q3.x - tx) + (q3.y - ty) * (q3.y - ty) + (q3.z - tz) * (q3.z - tz);
-    // clamped duplicates of the last candidate cannot win the strict '<'
-    if (d0 < best) { best = d0; bj = j[0]; }
-    if (d1 < best) { best = d1; bj = j[1]; }
-    if (d2 < best) { best = d2; bj = j[2]; }
-    if (d3 < best) { best = d3; bj = j[3]; }
   }
 }
 
@@ -808,7 +807,7 @@ __device__ __forceinline__ void knn_scan_run(const double4* __restrict__ p, cons
   }
 }
 
-// the same over up to four runs (begin, length) concatenated into one lane-private sequence (see nn_scan_runs4)
+// the same over up to four runs (begin, length) concatenated into one lane-private sequence (every lane walks only ITS surviving cells, four loads in flight)
 __device__ __forceinline__ void knn_scan_runs4(const double4* __restrict__ p, const double4& q, int b0, int l0, int b1, int l1, int b2,
                                                int l2, int b3, int l3, TopK<10>& loc) {
   const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
@@ -1150,15 +1149,17 @@ struct NnGlobal {
 constexpr int kTileCap = GFS_TILE_CAP;      // staged points
 constexpr int kTileRows = 192;              // rows of cells in the box of a workgroup
 constexpr int kTileCells = GFS_TILE_CELLS;  // staged cell boundaries
+constexpr int kTileNz = 64;                 // non-empty rows of a tile
 struct LinTile {
   double x[kTileCap], y[kTileCap], z[kTileCap];
   unsigned cells[kTileCells];
-  int row_a[kTileRows], row_b[kTileRows];  // stage 1: x range of the lanes centred on the row; afterwards: first point, length
+  int row_a[kTileRows], row_b[kTileRows];  // x range (min, max) of the lanes centred on the row
   int row_lo[kTileRows];                   // x of the row's first staged cell boundary (-> index into cells)
-  int row_wid[kTileRows];                  // number of staged boundaries
   int row_delta[kTileRows];                // LDS index = global point index + delta
   int row_coff[kTileRows];                 // offset of the row's boundaries in cells[], -1: nothing staged (empty row)
-  int box[4];                              // cymin, cymax, czmin, czmax
+  // the non-empty rows in order (for the flat copy): end of their points / boundaries in the tile, and where they come from
+  int nz_pend[kTileNz], nz_cend[kTileNz], nz_delta[kTileNz], nz_cbase[kTileNz], nz_base[kTileNz];
+  int box[4];  // cymin, cymax, czmin, czmax
   unsigned long long wave_tot[4];
 };
 struct NnTile {
@@ -1181,101 +1182,105 @@ struct NnTile {
   }
 };
 
-// 1-NN scan over up to four candidate runs (global begin, length, source offset) concatenated into one lane-private sequence:
-// every lane walks only ITS surviving cells, four candidates in flight.  bj is a GLOBAL point index.
+// The candidates of one row of cells (y, z): the strip [lo, hi) of points (global indices; index in the source = global + d) is
+// ordered by sixteenths of a cell along x (the cell sort key, k_voxel_reduce).  Walk outwards from `start` in both directions, two
+// candidates a side per step; a side stops when everything still ahead of it is farther than the bound: a point ahead has an x of
+// at least (x of the outermost point seen on that side) - slack, slack = one sixteenth of a cell (+ rounding).  row2 = squared
+// lower bound of the distance in y and z.  Any walk order gives the exact nearest neighbour; the order only breaks exact ties.
 template <class Src>
-__device__ __forceinline__ void nn_scan4(const Src& src, double tx, double ty, double tz, int b0, int l0, int d0, int b1, int l1, int d1, int b2,
-                                         int l2, int d2, int b3, int l3, int d3, double& best, int& bj) {
-  const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
-  const int o0 = b0, o1 = b1 - c1, o2 = b2 - c2, o3 = b3 - c3;
-  for (int v = 0; v < total; v += 4) {
-    int j[4];
-    double dd[4];
+__device__ __forceinline__ void nn_sweep(const Src& src, double tx, double ty, double tz, int lo, int hi, int d, int start, double row2,
+                                         double slack, double max_dist_sq, double& B, double& best, int& bj) {
+  int r = start, l = start - 1;
+  bool ra = r < hi, la = l >= lo;
+  while (ra || la) {
+    // clamped into the strip: a clamped index is just another (or the same) candidate of the strip
+    const int j[4] = {min(r, hi - 1), max(l, lo), min(r + 1, hi - 1), max(l - 1, lo)};
+    double qx[4], dd[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int vv = min(v + u, total - 1);
-      const int run = vv < c1 ? 0 : vv < c2 ? 1 : vv < c3 ? 2 : 3;
-      j[u] = vv + (run == 0 ? o0 : run == 1 ? o1 : run == 2 ? o2 : o3);
-      double qx, qy, qz;
-      src.load(j[u] + (run == 0 ? d0 : run == 1 ? d1 : run == 2 ? d2 : d3), qx, qy, qz);
-      dd[u] = (qx - tx) * (qx - tx) + (qy - ty) * (qy - ty) + (qz - tz) * (qz - tz);
+      double qy, qz;
+      src.load(j[u] + d, qx[u], qy, qz);
+      dd[u] = (qx[u] - tx) * (qx[u] - tx) + (qy - ty) * (qy - ty) + (qz - tz) * (qz - tz);
     }
-    // clamped duplicates of the last candidate cannot win the strict '<'
 #pragma unroll
     for (int u = 0; u < 4; u++)
       if (dd[u] < best) {
         best = dd[u];
         bj = j[u];
       }
+    B = fmin(max_dist_sq, best);
+    if (ra) {
+      r += 2;
+      const double g = qx[2] - slack - tx;  // everything right of j[2] has x - tx >= g
+      ra = r < hi && !(g > 0.0 && g * g + row2 > B);
+    }
+    if (la) {
+      l -= 2;
+      const double g = tx - qx[3] - slack;
+      la = l >= lo && !(g > 0.0 && g * g + row2 > B);
+    }
   }
 }
 
 // Exact 1-NN of (tx, ty, tz) inside the 27-cell cube around its cell (cell edge >= max correspondence distance), branch and bound
-// per lane: a cell is skipped when its box is farther than the bound B = min(max_dist^2, best so far).  `best` / `bj` come in
-// holding the correspondence of the previous linearisation re-evaluated under the new pose (or +inf / -1).  Order: own cell,
-// its two neighbours along x, then the other eight rows.
+// per lane with the bound B = min(max_dist^2, best so far).  `best` / `bj` come in holding the correspondence of the previous
+// linearisation re-evaluated under the new pose (or +inf / -1).  The own row of cells first (one sweep over its three cells from
+// the query's x outwards), then those of the other eight rows that are still within the bound: every lane works through ITS rows,
+// one per round.
 template <class Src>
 __device__ __forceinline__ void nn_search27(const Src& src, const GicpParams& prm, double tx, double ty, double tz, int cx, int cy, int cz,
                                             double& best, int& bj) {
   double B = fmin(prm.max_dist_sq, best);
-  // lower bounds of the distance to the neighbouring cells along each axis (a hair conservative: 1e-9 cells)
   const double ux = tx * prm.inv_cell - (double)(cx - kCoordOffset), uy = ty * prm.inv_cell - (double)(cy - kCoordOffset),
                uz = tz * prm.inv_cell - (double)(cz - kCoordOffset);
-  const double lx0 = fmax(ux - 1e-9, 0.0) * prm.cell, lx2 = fmax(1.0 - ux - 1e-9, 0.0) * prm.cell;
-  const double ly[3] = {fmax(uy - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uy - 1e-9, 0.0) * prm.cell};
-  const double lz[3] = {fmax(uz - 1e-9, 0.0) * prm.cell, 0.0, fmax(1.0 - uz - 1e-9, 0.0) * prm.cell};
-  {  // own row: the own cell first, its two neighbours only if they can still hold something nearer
+  // lower bounds of the distance to the neighbouring rows (a hair conservative: 1e-9 cells)
+  const double ly0 = fmax(uy - 1e-9, 0.0) * prm.cell, ly2 = fmax(1.0 - uy - 1e-9, 0.0) * prm.cell;
+  const double lz0 = fmax(uz - 1e-9, 0.0) * prm.cell, lz2 = fmax(1.0 - uz - 1e-9, 0.0) * prm.cell;
+  const double slack = prm.cell * (1.0 / kFine + 1e-9);
+  auto row = [&](int y, int z, double row2) {
     int e[4];
-    const int d = src.cells3(cx, cy, cz, e);
-    nn_scan4(src, tx, ty, tz, e[1], e[2] - e[1], d, 0, 0, 0, 0, 0, 0, 0, 0, 0, best, bj);
-    B = fmin(B, best);
-    const int ll = lx0 * lx0 <= B ? e[1] - e[0] : 0, lr = lx2 * lx2 <= B ? e[3] - e[2] : 0;
-    nn_scan4(src, tx, ty, tz, e[0], ll, d, e[2], lr, d, 0, 0, 0, 0, 0, 0, best, bj);
-    B = fmin(B, best);
-  }
-  int rb[8], rl[8], rd[8], rank[8], nkept = 0;
+    const int d = src.cells3(cx, y, z, e);
+    if (e[3] > e[0]) {
+      const int n1 = e[2] - e[1];  // the walk starts where the query's x would fall among the points of its own cell
+      const int start = e[1] + min(max((int)(ux * (double)n1), 0), n1);
+      nn_sweep(src, tx, ty, tz, e[0], e[3], d, start, row2, slack, prm.max_dist_sq, B, best, bj);
+    }
+  };
+  row(cy, cz, 0.0);
+  unsigned need = 0;
 #pragma unroll
   for (int t8 = 0; t8 < 8; t8++) {
     const int t9 = t8 < 4 ? t8 : t8 + 1, dy = t9 % 3, dz = t9 / 3;
-    const double row2 = ly[dy] * ly[dy] + lz[dz] * lz[dz];
-    rb[t8] = 0;
-    rl[t8] = 0;
-    rd[t8] = 0;
-    if (row2 <= B) {
-      int e[4];
-      rd[t8] = src.cells3(cx, cy + dy - 1, cz + dz - 1, e);
-      const int b0 = row2 + lx0 * lx0 <= B ? e[0] : e[1], e0 = row2 + lx2 * lx2 <= B ? e[3] : e[2];
-      rb[t8] = b0;
-      rl[t8] = e0 - b0;
-    }
-    rank[t8] = nkept;
-    nkept += rl[t8] > 0 ? 1 : 0;
+    const double a = dy == 0 ? ly0 : dy == 2 ? ly2 : 0.0, c = dz == 0 ? lz0 : dz == 2 ? lz2 : 0.0;
+    if (a * a + c * c <= B) need |= 1u << t8;
   }
-#pragma unroll
-  for (int round = 0; round < 2; round++) {
-    if (round == 1 && !__any(nkept > 4)) break;
-    int sb[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int t8 = 0; t8 < 8; t8++)
-#pragma unroll
-      for (int sl_i = 0; sl_i < 4; sl_i++)
-        if (rl[t8] > 0 && rank[t8] == 4 * round + sl_i) {
-          sb[sl_i] = rb[t8];
-          sl[sl_i] = rl[t8];
-          sd[sl_i] = rd[t8];
-        }
-    nn_scan4(src, tx, ty, tz, sb[0], sl[0], sd[0], sb[1], sl[1], sd[1], sb[2], sl[2], sd[2], sb[3], sl[3], sd[3], best, bj);
+  while (__any(need != 0)) {
+    if (need != 0) {
+      const int t8 = __ffs(need) - 1;
+      need &= need - 1;
+      const int t9 = t8 < 4 ? t8 : t8 + 1, dy = t9 % 3, dz = t9 / 3;
+      const double a = dy == 0 ? ly0 : dy == 2 ? ly2 : 0.0, c = dz == 0 ? lz0 : dz == 2 ? lz2 : 0.0;
+      const double row2 = a * a + c * c;
+      if (row2 <= B) row(cy + dy - 1, cz + dz - 1, row2);
+    }
   }
 }
 
 // Stages the workgroup's tile (all threads call it; `inrange` = the lane holds a source point whose image has usable cell
 // coordinates cx, cy, cz).  Returns 0 -- for the whole workgroup -- when the tile is complete, else why not: 1 no dense grid, 2 no lane
 // with a usable image, 3 too many rows in the box, 4 too many points, 5 too many cell boundaries.
+// Two dependent round trips to memory: the rows' first / last points out of the grid, then ONE flat copy of all points and
+// boundaries (every thread takes slots t, t + 256, ... of the tile, finds the slot's row by bisection over the non-empty rows and
+// has all its loads in flight before it stores).
 __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, int cy, int cz, const double4* __restrict__ tp,
-                                               const int* __restrict__ gi, const unsigned* __restrict__ G) {
+                                              const int* __restrict__ gi, const unsigned* __restrict__ G) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (!gi[6]) return 1;  // no dense grid for this cloud (uniform)
   if (tid < 4) T.box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+  if (tid < kTileRows) {
+    T.row_a[tid] = INT_MAX;
+    T.row_b[tid] = INT_MIN;
+  }
   __syncthreads();
   {
     int v[4] = {inrange ? cy : INT_MAX, inrange ? -cy : INT_MAX, inrange ? cz : INT_MAX, inrange ? -cz : INT_MAX};
@@ -1296,11 +1301,6 @@ __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, 
   const long long nyl = (long long)cymax - cymin + 3, nzl = (long long)czmax - czmin + 3;
   if (nyl * nzl > kTileRows) return 3;
   const int ny = (int)nyl, nz = (int)nzl, nrows = ny * nz, y0 = cymin - 1, z0 = czmin - 1;
-  if (tid < nrows) {
-    T.row_a[tid] = INT_MAX;
-    T.row_b[tid] = INT_MIN;
-  }
-  __syncthreads();
   if (inrange) {  // x range of the lanes centred on each row
     const int r = (cy - y0) + ny * (cz - z0);
     atomicMin(&T.row_a[r], cx);
@@ -1308,6 +1308,7 @@ __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, 
   }
   __syncthreads();
   int lo = INT_MAX, hi = INT_MIN, j0 = 0, len = 0, wid = 0;
+  size_t base = 0;
   if (tid < nrows) {  // a row serves the lanes centred on it and on its eight neighbours
     const int ry = tid % ny, rz = tid / ny;
 #pragma unroll
@@ -1325,7 +1326,7 @@ __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, 
       hi += 1;
       const int gy = y0 + ry - gi[1], gz = z0 + rz - gi[2];
       if ((unsigned)gy < (unsigned)gi[4] && (unsigned)gz < (unsigned)gi[5]) {
-        const size_t base = ((size_t)gz * gi[4] + gy) * gi[3];
+        base = ((size_t)gz * gi[4] + gy) * gi[3];
         j0 = (int)G[base + min(max(lo - gi[0], 0), gi[3])];
         const int j1 = (int)G[base + min(max(hi + 1 - gi[0], 0), gi[3])];
         len = max(j1 - j0, 0);
@@ -1333,8 +1334,10 @@ __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, 
       }
     }
   }
-  // exclusive prefix sums of (len, wid) over the rows: packed in 64 bits, wave scan + the four wave totals
-  const unsigned long long pk = (unsigned long long)(unsigned)len | ((unsigned long long)(unsigned)wid << 32);
+  // exclusive prefix sums of (points, boundaries, non-empty rows) over the rows: 24 + 24 + 16 bits, wave scan + four wave totals
+  // (a row longer than the tile cannot pass: clamp its length so that the packed sum cannot overflow its field)
+  const unsigned long long pk = (unsigned long long)min(len, kTileCap + 1) | ((unsigned long long)min(wid, kTileCells + 1) << 24) |
+                                ((unsigned long long)(len > 0 ? 1 : 0) << 48);
   unsigned long long inc = pk;
 #pragma unroll
   for (int ofs = 1; ofs < 64; ofs <<= 1) {
@@ -1351,32 +1354,69 @@ __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, 
     if (w < wave) before += tw;
     total += tw;
   }
-  if ((unsigned)(total & 0xffffffffu) > (unsigned)kTileCap) return 4;  // uniform
-  if ((unsigned)(total >> 32) > (unsigned)kTileCells) return 5;
+  const int tot_pts = (int)(total & 0xffffffu), tot_cells = (int)((total >> 24) & 0xffffffu), nnz = (int)(total >> 48);
+  if (tot_pts > kTileCap) return 4;  // uniform
+  if (tot_cells > kTileCells) return 5;
+  if (nnz > kTileNz) return 3;
   if (tid < nrows) {
     const unsigned long long exc = before + inc - pk;
-    const int poff = (int)(exc & 0xffffffffu), coff = (int)(exc >> 32);
-    T.row_a[tid] = j0;
-    T.row_b[tid] = len;
+    const int poff = (int)(exc & 0xffffffu), coff = (int)((exc >> 24) & 0xffffffu), k = (int)(exc >> 48);
     T.row_lo[tid] = lo;
-    T.row_wid[tid] = wid;
     T.row_delta[tid] = poff - j0;
     T.row_coff[tid] = len > 0 ? coff : -1;
+    if (len > 0) {  // the non-empty rows, in order: where their points and boundaries end in the tile, and where they come from
+      T.nz_pend[k] = poff + len;
+      T.nz_cend[k] = coff + wid;
+      T.nz_delta[k] = poff - j0;
+      T.nz_cbase[k] = lo - gi[0] - coff;  // boundary slot s holds G[base + clamp(s + cbase, 0, nx)] (the grid has < 2^21 cells)
+      T.nz_base[k] = (int)base;
+    }
   }
   __syncthreads();
-  for (int r = wave; r < nrows; r += 4) {  // a wave copies a row: coalesced 32-byte points in, three arrays out
-    const int n = T.row_b[r];
-    if (n <= 0) continue;
-    const int g0 = T.row_a[r], d = T.row_delta[r];
-    for (int k = lane; k < n; k += 64) {
-      const double4 q = tp[g0 + k];
-      T.x[g0 + k + d] = q.x;
-      T.y[g0 + k + d] = q.y;
-      T.z[g0 + k + d] = q.z;
+  {
+    constexpr int kU = (kTileCap + kLinBlock - 1) / kLinBlock;
+    double4 q[kU];
+    int slot[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      slot[u] = tid + u * kLinBlock;
+      if (slot[u] < tot_pts) {
+        int a = 0, b = nnz - 1;  // first non-empty row whose end lies beyond the slot
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (T.nz_pend[mid] > slot[u]) b = mid;
+          else a = mid + 1;
+        }
+        q[u] = tp[slot[u] - T.nz_delta[a]];
+      }
     }
-    const int ry = r % ny, rz = r / ny, rlo = T.row_lo[r], coff = T.row_coff[r], w = T.row_wid[r];
-    const size_t rbase = ((size_t)(z0 + rz - gi[2]) * gi[4] + (y0 + ry - gi[1])) * gi[3];
-    for (int k = lane; k < w; k += 64) T.cells[coff + k] = G[rbase + min(max(rlo + k - gi[0], 0), gi[3])];
+#pragma unroll
+    for (int u = 0; u < kU; u++)
+      if (slot[u] < tot_pts) {
+        T.x[slot[u]] = q[u].x;
+        T.y[slot[u]] = q[u].y;
+        T.z[slot[u]] = q[u].z;
+      }
+    constexpr int kUc = (kTileCells + kLinBlock - 1) / kLinBlock;
+    unsigned cv[kUc];
+#pragma unroll
+    for (int u = 0; u < kUc; u++) {
+      const int s = tid + u * kLinBlock;
+      if (s < tot_cells) {
+        int a = 0, b = nnz - 1;
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (T.nz_cend[mid] > s) b = mid;
+          else a = mid + 1;
+        }
+        cv[u] = G[T.nz_base[a] + min(max(s + T.nz_cbase[a], 0), gi[3])];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUc; u++) {
+      const int s = tid + u * kLinBlock;
+      if (s < tot_cells) T.cells[s] = cv[u];
+    }
   }
   __syncthreads();
   return 0;
@@ -1387,7 +1427,8 @@ __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, 
 // acc (H upper triangle 21, b 6, e, inlier count).  Records the correspondence and the matrix for the error evaluations that follow.
 template <class Src>
 __device__ __forceinline__ void gicp_lin_point(const Src& src, int i, const double4 p, double tx, double ty, double tz, int cx, int cy, int cz,
-                                               bool in_range, const double* __restrict__ T12, bool has_prev, int pair, int cs, int ct, int P,
+                                               bool in_range, const double* __restrict__ T12, bool has_prev, int prev_j, const double4 prev_q,
+                                               int pair, int cs, int ct, int P,
                                                const double4* __restrict__ pts, const double* __restrict__ cov6,
                                                const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
                                                const int* __restrict__ n_ucell, const unsigned* __restrict__ G,
@@ -1403,13 +1444,9 @@ __device__ __forceinline__ void gicp_lin_point(const Src& src, int i, const doub
     int bj = -1;
     if (in_range) {
       if (prm.nn_rings <= 1) {
-        if (has_prev) {
-          const int pj = tgt_index[(size_t)pair * P + i];
-          if (pj >= 0) {
-            const double4 q = tp[pj];
-            best = (q.x - tx) * (q.x - tx) + (q.y - ty) * (q.y - ty) + (q.z - tz) * (q.z - tz);
-            bj = pj;
-          }
+        if (has_prev && prev_j >= 0) {  // the previous correspondence under the new pose: the first bound
+          best = (prev_q.x - tx) * (prev_q.x - tx) + (prev_q.y - ty) * (prev_q.y - ty) + (prev_q.z - tz) * (prev_q.z - tz);
+          bj = prev_j;
         }
         nn_search27(src, prm, tx, ty, tz, cx, cy, cz, best, bj);
       } else {
@@ -1531,6 +1568,7 @@ __device__ __forceinline__ void lin_image(const double4& p, const double* __rest
 
 // GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
 // machine is in the "linearise" phase; per-block partial sums of H (upper), b, e and the inlier count.
+template <bool kTiled>
 __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* __restrict__ st,
                                                               const double4* __restrict__ pts,
                                                               const double* __restrict__ cov6, const u64* __restrict__ ucell,
@@ -1541,41 +1579,56 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
                                                               int* __restrict__ tgt_index, double* __restrict__ maha6,
                                                               double* __restrict__ partial, int nblk) {
   __shared__ double s_red[4 * 32];
-  __shared__ LinTile tile;
+  __shared__ typename std::conditional<kTiled, LinTile, int>::type tile;  // the untiled instance keeps its LDS (and its occupancy)
   int pair, sub, chunk;
   if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
-  const PairState S = st[pair];
-  if (S.phase != 0) return;
+  // Everything this workgroup can ask for before it knows anything is asked for first -- the pair's state, the cloud sizes, the
+  // grid header, the lane's source point and its previous correspondence -- so that the dependent round trips to memory that
+  // remain are: state -> (tile rows) -> (tile points) -> search in LDS -> target covariance.
   const int cs = 2 * pair + prm.src_slot, ct = 2 * pair + 1 - prm.src_slot;
+  const PairState* Sp = st + pair;
+  const int phase = Sp->phase, n_lin = Sp->n_lin;
+  double T12[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T12[k] = Sp->T[k];
   const int ms = m_counts[cs];
-  if (chunk * kLinBlock >= ms) return;
   const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
   const int* gi = ginfo + 8 * ct;
-  const int i = chunk * kLinBlock + threadIdx.x;
+  const int i = chunk * kLinBlock + threadIdx.x;  // < P: the grid covers at most the clouds' capacity
+  const double4 p = pts[(size_t)cs * P + i];
+  const double4* tp = pts + (size_t)ct * P;
+  const int prev_j = tgt_index[(size_t)pair * P + i];
+  if (phase != 0 || chunk * kLinBlock >= ms) return;
+  const bool has_prev = n_lin > 0;
+  double4 prev_q = make_double4(0, 0, 0, 0);
+  if (has_prev && i < ms && prev_j >= 0) prev_q = tp[prev_j];
   double acc[kRed];
 #pragma unroll
   for (int k = 0; k < kRed; k++) acc[k] = 0;
-  double4 p = make_double4(0, 0, 0, 0);
   double tx = 0, ty = 0, tz = 0;
   int cx = 0, cy = 0, cz = 0;
   bool in_range = false;
-  if (i < ms) {
-    p = pts[(size_t)cs * P + i];
-    lin_image(p, S.T, prm, tx, ty, tz, cx, cy, cz, in_range);
+  if (i < ms) lin_image(p, T12, prm, tx, ty, tz, cx, cy, cz, in_range);
+  bool tiled = false;
+  if constexpr (kTiled) {
+    const int why = prm.nn_rings <= 1 ? lin_stage_tile(tile, i < ms && in_range, cx, cy, cz, tp, gi, G) : 6;
+    tiled = why == 0;
+    if (prm.tile_stats && threadIdx.x == 0) atomicAdd(prm.tile_stats + why, 1u);
   }
-  const double4* tp = pts + (size_t)ct * P;
-  const int why = prm.nn_rings <= 1 && prm.lin_tile ? lin_stage_tile(tile, i < ms && in_range, cx, cy, cz, tp, gi, G) : 6;
-  const bool tiled = why == 0;
-  if (prm.tile_stats && threadIdx.x == 0) atomicAdd(prm.tile_stats + why, 1u);
   if (i < ms) {
-    if (tiled) {
-      const NnTile src{&tile, tile.box[0] - 1, tile.box[2] - 1, tile.box[1] - tile.box[0] + 3};
-      gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, S.n_lin > 0, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm,
-                     tgt_index, maha6, acc);
-    } else {
+    bool done = false;
+    if constexpr (kTiled) {
+      if (tiled) {
+        const NnTile src{&tile, tile.box[0] - 1, tile.box[2] - 1, tile.box[1] - tile.box[0] + 3};
+        gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell,
+                       G, gi, prm, tgt_index, maha6, acc);
+        done = true;
+      }
+    }
+    if (!done) {
       const NnGlobal src{tp, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
-      gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, S.n_lin > 0, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm,
-                     tgt_index, maha6, acc);
+      gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G,
+                     gi, prm, tgt_index, maha6, acc);
     }
   }
   block_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + chunk) * kRed, s_red);
@@ -1878,8 +1931,10 @@ __global__ __launch_bounds__(kLmBlock) __attribute__((amdgpu_waves_per_eu(4, 8))
         int cx, cy, cz;
         bool in_range;
         lin_image(p, S.T, prm, tx, ty, tz, cx, cy, cz, in_range);
-        gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, has_prev, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi, prm,
-                       tgt_index, maha6, acc);
+        const int prev_j = has_prev ? tgt_index[(size_t)pair * P + i] : -1;
+        const double4 prev_q = prev_j >= 0 ? pts[(size_t)ct * P + prev_j] : make_double4(0, 0, 0, 0);
+        gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi,
+                       prm, tgt_index, maha6, acc);
       }
       const double r = gfs_red::block_sum_many<kRed, kLmBlock / 64>(acc, s_red);
       if (tid < kRed) s_sum[tid] = r;
@@ -2014,6 +2069,7 @@ struct gfs_gicp {
   // (k_gicp_lm) — no launches / host polls inside the loop, but only one workgroup of parallelism per pair: measured 4x slower at
   // 128 pairs per batch (25 vs 6 ms per 512 pairs), it pays only for batches of many thousand small pairs.
   bool lm_rounds = true;
+  bool tile_stats_on = false;  // GFS_GICP_TILE_STATS=1
   gfs::DevBuf<unsigned> d_tile_stats;  // [8] outcome counters of k_gicp_linearize's tile staging (gfs_gicp_tile_stats)
   bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
@@ -2101,6 +2157,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   if (const char* e = getenv("GFS_GICP_VOXEL_ORDER")) h->stable_voxel_order = strcmp(e, "stable") == 0;
   if (const char* e = getenv("GFS_GICP_LM")) h->lm_rounds = strcmp(e, "persistent") != 0;
+  if (const char* e = getenv("GFS_GICP_TILE_STATS")) h->tile_stats_on = atoi(e) != 0;
   const size_t P = h->P, B = max_batch, C2 = 2 * B;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
@@ -2197,8 +2254,8 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   prm.inv_cell = 1.0 / prm.cell;
   prm.nn_rings = (int)std::ceil(cfg->max_correspondence_distance / prm.cell - 1e-12);
   if (prm.nn_rings < 1) prm.nn_rings = 1;
-  prm.lin_tile = 1;
-  prm.tile_stats = h->d_tile_stats.p;
+  prm.lin_tile = 0;  // measured (profiles/README.md, round 3): with the x-ordered sweep the search in HBM at 4 waves per SIMD beats the staged tile at 3
+  prm.tile_stats = h->tile_stats_on ? h->d_tile_stats.p : nullptr;  // one atomic per workgroup on one address: only on request
   if (const char* e = getenv("GFS_GICP_LIN_TILE")) prm.lin_tile = atoi(e) != 0;  // 0: every workgroup searches the cloud in HBM
   prm.max_dist_sq = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
   prm.rot_eps = cfg->rotation_eps;
@@ -2231,7 +2288,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
              stride_pts, P, prm.inv_leaf, h->d_keys0.p, h->d_val0.p, h->d_counts.p, prm.only);
   if (h->stable_voxel_order) {
     GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
-               h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only);
+               h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only, kCoordBits, 2 * kCoordBits);
   } else {
     // the reference's (unstable) quick_sort_omp permutation, reproduced exactly: util/sort_omp.hpp:58-85
     const int leaf_parts = std::max(1, std::min(64, P / 2048));
@@ -2245,7 +2302,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
              h->d_val0.p, h->d_val1.p, h->d_which.p, h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p, h->d_m.p,
              prm.only);
   GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p, h->d_ci1.p,
-             h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p, prm.only);
+             h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p, prm.only, kCkSy, kCkSz);
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
              h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p,
              prm.only);
@@ -2274,9 +2331,15 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     const int nblk_run = gfs::div_up(npts, kLinBlock);
     const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
     for (int round = 0; round < max_rounds; round++) {
-      GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
-                 h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
-                 nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
+      if (prm.lin_tile) {
+        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<true>, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
+                   h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
+                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
+      } else {
+        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<false>, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
+                   h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
+                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
+      }
       GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot);
       GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
                  h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B, prm.src_slot);

@@ -216,7 +216,8 @@ int gfs_gicp_align_next_batch_device(gfs_gicp* h, const void* dev_source, const 
 int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, double* covs, int cap, int* m);
 /* Diagnostics: workgroups of the linearisation kernel since the last reset, by outcome of staging their tile of the target cloud in
  * LDS: out8[0] staged; [1] no dense grid; [2] no usable point; [3] / [4] / [5] too many rows / points / cell boundaries for the
- * tile (those workgroups search the cloud in HBM: same results); [6] tiling switched off. */
+ * tile (those workgroups search the cloud in HBM: same results); [6] tiling switched off.  Counted only by handles created with
+ * GFS_GICP_TILE_STATS=1 in the environment (one atomic per workgroup on one address is not free). */
 int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset);
 /* GPU test hook: the voxel sort of the preprocessing — the device replica of small_gicp's quick_sort_omp
  * (util/sort_omp.hpp:58-85: 3-way quicksort above 1024 elements, libstdc++ std::sort below), whose permutation of

@@ -334,3 +334,17 @@ def test_random_pairs_meet_the_bar_or_have_a_proved_kth_distance_tie(gpu_api, or
         ties.append((ci, _rel(r["T"], ro["T"]), n_ties))
     assert len(ties) <= 40, ties  # round 2 measured 7 of 13 000
     assert worst < 1e-5
+
+
+def test_staged_tile_gives_the_same_bits(gpu_api, monkeypatch):
+    """GFS_GICP_LIN_TILE=1: k_gicp_linearize stages a workgroup's tile of the target cloud in LDS (not the default: measured slower
+    than the x-ordered sweep straight from HBM, profiles/README.md).  Same search, same order of visits: bit-identical results."""
+    reg = gpu_api.RegistrationGICP(max_points=20480)
+    for seed in (3, 1001, 1005):
+        fp = synth.frame_pair(seed)
+        monkeypatch.setenv("GFS_GICP_LIN_TILE", "0")
+        a = reg.RegisterPointClouds(fp["cloud0"], fp["cloud1"])
+        monkeypatch.setenv("GFS_GICP_LIN_TILE", "1")
+        b = reg.RegisterPointClouds(fp["cloud0"], fp["cloud1"])
+        assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["num_inliers"] == b["num_inliers"]
+        assert np.array_equal(a["H"], b["H"]) and a["error"] == b["error"]

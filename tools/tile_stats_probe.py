@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['GFS_GICP_TILE_STATS'] = '1'
 import numpy as np
 from geoflowslam_amd import api, synth
 reg = api.RegistrationGICP(max_points=20480)
