@@ -185,7 +185,7 @@ ABI_SYMBOLS = [
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
     "gfs_gicp_fetch_preprocessed", "gfs_gicp_tile_stats", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort",
-    "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_linearize", "gfs_lba_batch_create", "gfs_lba_batch_destroy",
+    "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_solve_bool", "gfs_lba_linearize", "gfs_lba_batch_create", "gfs_lba_batch_destroy",
     "gfs_lba_solve_batch",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_depth_convert_u16_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
@@ -248,6 +248,7 @@ def lib():
             L.gfs_lba_create.argtypes = [i, i, i, i, C.POINTER(vp)]
             L.gfs_lba_destroy.argtypes = [vp]
             L.gfs_lba_solve.argtypes = [vp, C.POINTER(LbaProblem), C.POINTER(LbaSolution), vp]
+            L.gfs_lba_solve_bool.argtypes = [vp, C.POINTER(LbaProblem), C.POINTER(LbaSolution), vp]
             L.gfs_lba_linearize.argtypes = [vp, C.POINTER(LbaProblem), vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
             L.gfs_lba_batch_create.argtypes = [i, i, i, i, i, C.POINTER(vp)]
             L.gfs_lba_batch_destroy.argtypes = [vp]

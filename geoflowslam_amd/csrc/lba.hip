@@ -1649,7 +1649,9 @@ __global__ __launch_bounds__(kMk) void kb_lba_schur_reduce(const LbaDev* __restr
 }
 template <bool kOneBlock>
 __global__ __launch_bounds__(kMk, kOneBlock ? 2 : 1) void kb_lba_schur_mfma(const LbaDev* __restrict__ DD) {
-  GFS_LBAB_PROLOGUE(1, D.schur_mfma ? D.n_schur_chunks * D.n_pair_tiles : 0)
+  // every window takes the instance gfs_lba_solve would launch for it (one 128 x 128 block of pose pairs or several), whatever
+  // else is in the batch: the host launches both instances when the batch mixes the two kinds
+  GFS_LBAB_PROLOGUE(1, D.schur_mfma && (D.n_pair_tiles == 1) == kOneBlock ? D.n_schur_chunks * D.n_pair_tiles : 0)
   b_schur_mfma<kOneBlock>(D, blockIdx.x);
 }
 __global__ __launch_bounds__(kMk) void kb_lba_schur_reduce_mfma(const LbaDev* __restrict__ DD) {
@@ -1983,7 +1985,16 @@ int lba_raise_lds_limits(int device) {
   return GFS_OK;
 }
 
-int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, volatile const int* stop) {
+// The caller's force-stop flag, read LIVE every time the host loop looks at it: an int (gfs_lba_solve) or the C++ bool the
+// reference hands in (Optimizer::LocalBundleAdjustment's pbStopFlag = &mbAbortBA, one byte: gfs_lba_solve_bool).
+struct StopFlag {
+  volatile const int* i = nullptr;
+  volatile const unsigned char* b = nullptr;
+  explicit operator bool() const { return i || b; }
+  bool operator*() const { return (i && *i) || (b && *b); }
+};
+
+int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, StopFlag stop) {
   hipStream_t s = h->stream;
   const int E = p->n_edges;
   LbaDev D;
@@ -2184,7 +2195,7 @@ static void lba_fetch_finish(const gfs_lba_problem* p, const HostPrep& P, const 
   sol->final_lambda = stats[1];
 }
 
-int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, volatile const int* stop) {
+static int lba_solve_impl(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, StopFlag stop) {
   GFS_REQUIRE(h && p && sol, GFS_ERR_INVALID_ARG, "gfs_lba_solve: NULL argument");
   if (stop && *stop) {  // if (pbStopFlag) if (*pbStopFlag) return;  (src/Optimizer.cc:1955-1956)
     gfs::set_error("gfs_lba_solve: stop flag raised before optimisation");
@@ -2240,16 +2251,23 @@ int gfs_lba_batch_create(int device, int max_windows, int max_poses, int max_poi
     gfs_lba* h = nullptr;
     const int rc = gfs_lba_create(device, max_poses, max_points, max_edges, &h);
     if (rc) {
-      for (gfs_lba* x : b->win) gfs_lba_destroy(x);
+      gfs_lba_batch_destroy(b.release());
       return rc;
     }
     b->win.push_back(h);
   }
   int rc = 0;
   if ((rc = b->d_desc.alloc(max_windows)) || (rc = b->h_desc.alloc(max_windows)) || (rc = b->d_flags.alloc(4 * (size_t)max_windows)) ||
-      (rc = b->d_done.alloc(1)) || (rc = b->h_cur.alloc(max_windows)))
+      (rc = b->d_done.alloc(1)) || (rc = b->h_cur.alloc(max_windows))) {
+    gfs_lba_batch_destroy(b.release());  // the windows (tens of MB of HBM and pinned arenas each) and the stream go with it
     return rc;
-  GFS_HIP(hipHostMalloc((void**)&b->h_done, 2 * sizeof(int), hipHostMallocDefault));
+  }
+  if (hipHostMalloc((void**)&b->h_done, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    b->h_done = nullptr;
+    gfs::set_error("gfs_lba_batch_create: hipHostMalloc failed");
+    gfs_lba_batch_destroy(b.release());
+    return GFS_ERR_HIP;
+  }
   b->prep.resize(max_windows);
   *out = b.release();
   return GFS_OK;
@@ -2267,8 +2285,7 @@ void gfs_lba_batch_destroy(gfs_lba_batch* b) {
 
 // n independent windows (replicas of the single-window solve: "LBA of one map does not shard") solved
 // together: per window exactly the arithmetic of gfs_lba_solve, the launches shared by all of them.
-int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_lba_solution* solutions, int n,
-                        volatile const int* stop) {
+static int lba_solve_batch_impl(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_lba_solution* solutions, int n, StopFlag stop) {
   GFS_REQUIRE(b && problems && solutions && n > 0, GFS_ERR_INVALID_ARG, "gfs_lba_solve_batch: invalid argument");
   GFS_REQUIRE(n <= b->max_windows, GFS_ERR_CAPACITY, "gfs_lba_solve_batch: %d windows exceed the handle's %d", n, b->max_windows);
   if (stop && *stop) {
@@ -2286,6 +2303,7 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
   const auto T0 = now();
   // ---- host preparation of every window (edge re-ordering, CSR tables), on a few threads
   std::vector<int> rcs((size_t)n, 0);
+  std::vector<std::string> msgs((size_t)n);  // gfs_last_error() is per thread: a worker's message is carried back to the caller's
   {
     static const int cap = getenv("GFS_LBA_THREADS") ? atoi(getenv("GFS_LBA_THREADS")) : 32;
     const int nthreads = std::max(1, std::min(n, std::min(cap, (int)std::thread::hardware_concurrency())));
@@ -2296,17 +2314,21 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
         for (int w = t; w < n; w += nthreads) {
           rcs[w] = prepare(b->win[w], &problems[w], b->prep[w]);
           if (!rcs[w]) rcs[w] = upload(b->win[w], b->prep[w], s);  // the copy leaves as soon as the window is ready
+          if (rcs[w]) msgs[w] = gfs_last_error();
         }
       });
     for (auto& x : th) x.join();
   }
   for (int w = 0; w < n; w++)
-    if (rcs[w]) return rcs[w];
+    if (rcs[w]) {
+      gfs::set_error("gfs_lba_solve_batch: window %d: %s", w, msgs[w].c_str());
+      return rcs[w];
+    }
   const auto T1 = now();
   int max_free = 0, max_err = 1, max_upd = 1, max_lm = 1, max_iter = 0, max_chunk_blocks = 0, max_pair_blocks = 0;
   size_t schur_lds = 0, mfma_lds = 0;
   int max_mfma_blocks = 0;
-  bool one_block = true;
+  bool any_one_block = false, any_multi_block = false;
   for (int w = 0; w < n; w++) {
     LbaDev D;
     const int rc = upload_and_fill(b->win[w], &problems[w], b->prep[w], 0, s, D, false);
@@ -2321,7 +2343,8 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     max_iter = std::max(max_iter, problems[w].iterations);
     if (D.schur_mfma) {
       max_mfma_blocks = std::max(max_mfma_blocks, D.n_schur_chunks * D.n_pair_tiles);
-      one_block = one_block && D.n_pair_tiles == 1;
+      any_one_block = any_one_block || D.n_pair_tiles == 1;
+      any_multi_block = any_multi_block || D.n_pair_tiles != 1;
       mfma_lds = std::max(mfma_lds, schur_mfma_lds_bytes(D));
     } else if (D.schur_sub) {
       max_chunk_blocks = std::max(max_chunk_blocks, D.n_schur_chunks * D.n_pair_tiles);
@@ -2357,10 +2380,8 @@ int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_l
     GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD, b->d_done.p);
     GFS_LAUNCH("kb_lba_dinv", kb_lba_dinv, dim3(max_upd, n), dim3(kMk), 0, s, DD);
     if (max_mfma_blocks > 0) {
-      if (one_block)
-        GFS_LAUNCH("kb_lba_schur_mfma", kb_lba_schur_mfma<true>, dim3(max_mfma_blocks, n), dim3(kMk), mfma_lds, s, DD);
-      else
-        GFS_LAUNCH("kb_lba_schur_mfma", kb_lba_schur_mfma<false>, dim3(max_mfma_blocks, n), dim3(kMk), mfma_lds, s, DD);
+      if (any_one_block) GFS_LAUNCH("kb_lba_schur_mfma", kb_lba_schur_mfma<true>, dim3(max_mfma_blocks, n), dim3(kMk), mfma_lds, s, DD);
+      if (any_multi_block) GFS_LAUNCH("kb_lba_schur_mfma", kb_lba_schur_mfma<false>, dim3(max_mfma_blocks, n), dim3(kMk), mfma_lds, s, DD);
       GFS_LAUNCH("kb_lba_schur_reduce", kb_lba_schur_reduce_mfma, dim3(gfs::div_up(nmax * (nmax + 1) / 2 + nmax, kMk), n), dim3(kMk), 0, s, DD);
     }
     if (max_chunk_blocks > 0) {
@@ -2420,7 +2441,7 @@ int gfs_lba_linearize(gfs_lba* h, const gfs_lba_problem* p, double* Hpp, double*
   HostPrep& P = tl_prep;
   int rc = prepare(h, p, P);
   if (rc) return rc;
-  rc = run(h, p, P, 1, nullptr);
+  rc = run(h, p, P, 1, StopFlag{});
   if (rc) return rc;
   const int E = p->n_edges, NP = p->n_points, F = P.n_free;
   std::vector<double> hpp((size_t)F * 21), hll((size_t)NP * 6), hpl((size_t)E * 18), chi(E);
@@ -2462,6 +2483,22 @@ int gfs_lba_linearize(gfs_lba* h, const gfs_lba_problem* p, double* Hpp, double*
         for (int c = 0; c < 3; c++) Hpl[18 * (size_t)e + a + 6 * c] = hpl[18 * (size_t)k + 3 * a + c];
   }
   return GFS_OK;
+}
+
+int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, volatile const int* stop) {
+  StopFlag f;
+  f.i = stop;
+  return lba_solve_impl(h, p, sol, f);
+}
+int gfs_lba_solve_bool(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* sol, const volatile unsigned char* stop) {
+  StopFlag f;
+  f.b = stop;
+  return lba_solve_impl(h, p, sol, f);
+}
+int gfs_lba_solve_batch(gfs_lba_batch* b, const gfs_lba_problem* problems, gfs_lba_solution* solutions, int n, volatile const int* stop) {
+  StopFlag f;
+  f.i = stop;
+  return lba_solve_batch_impl(b, problems, solutions, n, f);
 }
 
 }  // extern "C"

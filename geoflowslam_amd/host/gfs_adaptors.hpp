@@ -152,8 +152,10 @@ class LocalBundleAdjuster {
   ~LocalBundleAdjuster() { gfs_lba_destroy(h_); }
   // returns false when *pbStopFlag was already set (the reference returns early, src/Optimizer.cc:1955-1956)
   bool solve(const gfs_lba_problem& p, gfs_lba_solution& s, const bool* pbStopFlag) {
-    volatile int stop = (pbStopFlag && *pbStopFlag) ? 1 : 0;
-    const int rc = gfs_lba_solve(h_, &p, &s, pbStopFlag ? &stop : nullptr);
+    // the caller's flag itself goes down (a C++ bool is one byte): the solver reads it live, at the top of every iteration and
+    // after every trial step, so an mbAbortBA raised by the tracking thread WHILE the adjustment runs ends it (setForceStopFlag)
+    static_assert(sizeof(bool) == 1, "gfs_lba_solve_bool reads the flag as one byte");
+    const int rc = gfs_lba_solve_bool(h_, &p, &s, reinterpret_cast<const volatile unsigned char*>(pbStopFlag));
     if (rc == GFS_ERR_STOPPED) return false;
     check(rc, "gfs_lba_solve");
     return true;
@@ -624,7 +626,12 @@ inline int SearchByProjectionWithOF(KltTracker& klt, FundamentalMatcher& fmat, c
         if (!status[i]) vkpstatus[(size_t)index[i]] = 0;
     }
   };
-  auto is_nearby = [&](float x, float y) { return mask[(size_t)(int)y * W + (int)x] == 255; };  // cv::Point(pt.x, pt.y): truncation
+  // cv::Point(pt.x, pt.y): truncation.  A track that left the image cannot sit next to a key point of the mask: it is not "nearby"
+  // (the reference reads mask.at<uchar>() unchecked behind cv's own in-image filtering; here nothing is read outside the buffer).
+  auto is_nearby = [&](float x, float y) {
+    const int xi = (int)x, yi = (int)y;
+    return xi >= 0 && xi < W && yi >= 0 && yi < H && mask[(size_t)yi * W + xi] == 255;
+  };
   if (!v3dkpids.empty()) {  // 1st: key points with a map point, prior = projection (3 pyramid levels)
     std::vector<uint8_t> vkpstatus;
     track_and_check(3, v3dkps, v3dpriors, F_THRESHOLD, vkpstatus);

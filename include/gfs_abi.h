@@ -263,6 +263,10 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
 void gfs_lba_destroy(gfs_lba* h);
 /* optimizer.optimize(iterations) with the stop flag polled like setForceStopFlag (src/Optimizer.cc:1679). */
 int gfs_lba_solve(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* s, volatile const int* stop);
+/* The same with the reference's own flag type: `stop` points at a C++ bool (one byte), e.g. pbStopFlag = &mbAbortBA of
+ * LocalMapping (src/LocalMapping.cc: mbAbortBA is raised by the tracking thread while the adjustment runs).  It is read live,
+ * at the top of every iteration and after every trial step, like g2o's setForceStopFlag (src/Optimizer.cc:1679). */
+int gfs_lba_solve_bool(gfs_lba* h, const gfs_lba_problem* p, gfs_lba_solution* s, const volatile unsigned char* stop);
 /* One BlockSolver::buildSystem (core/block_solver.hpp:502-558): Hpp [n_free][36] (col-major 6x6 diagonal blocks,
  * free poses in ascending index order), Hll [n_points][9], Hpl per edge [n_edges][18] (6x3 col-major, zero for
  * edges on fixed poses), bp [n_free][6], bl [n_points][3], edge_chi2 [n_edges]. Returns robust chi2 in *chi2. */

@@ -4,7 +4,9 @@
 // back; the caller inspects the stand-ins.  Built by tests/test_lba_adaptor.py with g++.
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <memory>
 
 #include "../../geoflowslam_amd/host/gfs_adaptors.hpp"
@@ -125,7 +127,8 @@ extern "C" int lba_adaptor_test(const char* solver_lib, int n_poses, int n_point
       k.mvpMapPoints.push_back(&mps[edge_point[e]]);
       mps[edge_point[e]].obs[&k] = std::make_tuple(kp, -1);
     }
-    bool stop = stop_flag != 0;
+    bool stop = stop_flag == 1;  // 1: raised before the call; >= 2: raised by another thread that many microseconds into the solve
+    int solver_iterations = -1;
     int num_fixedKF = -1, num_OptKF = -1, num_MPs = -7, num_edges = -1;
     gfs_lba_problem seen{};
     std::vector<double> seen_is2, seen_obs;
@@ -156,7 +159,16 @@ extern "C" int lba_adaptor_test(const char* solver_lib, int n_poses, int n_point
       gfs_host::LocalBundleAdjustment<MockAccess, MockKeyFrame, MockMapPoint, MockMap>(
           [&](const gfs_lba_problem& p, gfs_lba_solution& s, const bool* st) {
             record(p);
-            return lba.solve(p, s, st);
+            std::thread raiser;
+            if (stop_flag >= 2)
+              raiser = std::thread([&] {
+                std::this_thread::sleep_for(std::chrono::microseconds(stop_flag));
+                stop = true;  // the tracking thread's mbAbortBA = true, while the adjustment runs
+              });
+            const bool ok = lba.solve(p, s, st);
+            if (raiser.joinable()) raiser.join();
+            solver_iterations = s.iterations_run;
+            return ok;
           },
           &kfs[pkf], stop_flag >= 0 ? &stop : nullptr, &map, num_fixedKF, num_OptKF, num_MPs, num_edges);
     }
@@ -187,6 +199,7 @@ extern "C" int lba_adaptor_test(const char* solver_lib, int n_poses, int n_point
     counts[7] = num_MPs;
     hubers[0] = seen.huber_mono;
     hubers[1] = seen.huber_stereo;
+    if (stop_flag >= 2) hubers[1] = (double)solver_iterations;  // (the raised-while-running test reads the iteration count here)
     for (int e = 0; e < seen.n_edges; e++) {
       flat_inv_sigma2[e] = seen_is2[e];
       for (int c = 0; c < 3; c++) flat_obs[3 * e + c] = seen_obs[3 * e + c];

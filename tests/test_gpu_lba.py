@@ -220,3 +220,19 @@ def test_lba_batched_windows_match_oracle_and_single(gpu_api, oracle):
     # the stop flag raised before the call: nothing is optimised (src/Optimizer.cc:1955-1956)
     with pytest.raises(gpu_api.GfsError):
         bat.LocalBundleAdjustment(wins[:2], stop_flag=np.ones(1, np.int32))
+
+
+def test_batch_mixing_one_block_and_several_block_schur_windows(gpu_api):
+    """A batch that mixes windows whose reduced system is one 128 x 128 block of pose pairs (<= 21 free poses) with wider ones
+    (several blocks): each window must be solved by the Schur-product instance gfs_lba_solve launches for it alone
+    (k_lba_schur_mfma<true> / <false>), so the batch stays bit-identical to the single solves."""
+    wins = [synth.lba_window(70 + i, n_free=nf, n_fixed=3, n_points=npt) for i, (nf, npt) in
+            enumerate([(4, 300), (40, 900), (20, 800), (26, 700), (21, 500), (22, 500), (60, 1200), (3, 200)])]
+    bat = gpu_api.BatchOptimizer(max_windows=8, max_poses=80, max_points=2048, max_edges=200000)
+    opt = gpu_api.Optimizer(max_poses=80, max_points=2048, max_edges=200000)
+    got = bat.LocalBundleAdjustment(wins)
+    for w, r in zip(wins, got):
+        r1 = opt.LocalBundleAdjustment(w)
+        assert r["iterations_run"] == r1["iterations_run"]
+        for key in ("pose_q", "pose_t", "points", "edge_chi2", "edge_depth_positive"):
+            assert np.array_equal(r[key], r1[key]), (w["n_poses"], key)

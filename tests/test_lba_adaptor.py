@@ -21,7 +21,7 @@ def harness(api):
     hdr = os.path.join(ROOT, "geoflowslam_amd", "host", "gfs_adaptors.hpp")
     if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         libdir = os.path.join(ROOT, "geoflowslam_amd")
-        subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-o", _SO, src, "-L" + libdir, "-lgfs_hip", "-ldl",
+        subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-o", _SO, src, "-L" + libdir, "-lgfs_hip", "-ldl", "-lpthread",
                         "-Wl,-rpath," + libdir], check=True)
     L = C.CDLL(_SO)
     L.lba_adaptor_test.argtypes = ([C.c_char_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_double] * 5 + [C.c_int] * 3
@@ -186,3 +186,16 @@ def test_adaptor_end_to_end_on_gpu(harness, gpu_api, oracle):
     out = _run(harness, w, None)
     _check(out, w2, ro)
     assert out["counts"][3] == 1
+
+
+@pytest.mark.gpu
+def test_adaptor_stop_flag_raised_while_the_adjustment_runs(harness, gpu_api, oracle):
+    """mbAbortBA raised by another thread DURING LocalBundleAdjustment: the solver reads the caller's bool live (top of every
+    iteration and after every trial step, g2o's setForceStopFlag, src/Optimizer.cc:1679), stops early, and -- like the reference, which
+    checks the flag only before optimize() (:1955-1956) -- the state reached so far is classified and written back."""
+    w = _window32(11, n_free=20, n_fixed=5, n_points=3000)
+    full = _run(harness, w, None, stop_flag=10_000_000)   # raised far too late: the complete optimisation
+    assert full["rc"] > 0 and full["hubers"][1] >= 3
+    early = _run(harness, w, None, stop_flag=150)          # raised 150 us in: a window of this size needs ~2 ms
+    assert early["rc"] > 0 and early["counts"][3] == 1     # written back all the same
+    assert 0 <= early["hubers"][1] < full["hubers"][1], (early["hubers"][1], full["hubers"][1])
