@@ -1,17 +1,17 @@
 // C++ host-side mirror of the reference's four seams on top of the C ABI (include/gfs_abi.h).
 //
-// The reference is C++17 (OpenCV / Eigen types in its signatures).  Neither library exists in this image, so
-// this header offers TWO layers:
-//   1. namespace gfs_host: the same classes with plain std:: containers (always compiled; used by the examples
-//      and by anything that does not want OpenCV / Eigen);
-//   2. namespace ORB_SLAM3 (guarded by GFS_WITH_OPENCV / GFS_WITH_EIGEN): drop-in classes with the reference's
-//      EXACT signatures —
-//        ORBextractor::operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&, cv::OutputArray,
-//                                 std::vector<int>&)                      include/ORBextractor.h:61-64
-//        ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)   include/ORBmatcher.h:41
-//        bf_match(d1, d2, std::vector<cv::DMatch>&)                       src/ORBmatcher.cc:755-756
-//        RegistrationGICP::RegisterPointClouds(...)                       include/RegistrationGICP.h:25-28
-//      INTEGRATION.md shows where they are swapped in.
+// The reference is C++17 (OpenCV / Eigen types in its signatures).  Neither library exists in this image, so there are TWO layers:
+//   1. this header, namespace gfs_host: the same classes with plain std:: containers (always compiled; used by the examples, the
+//      tests and by anything that does not want OpenCV / Eigen);
+//   2. gfs_reference_dropins.hpp beside it, namespace gfs_dropin: the code a maintainer adds to the reference tree, written against
+//      the reference's own types --
+//        GfsORBextractor : ORB_SLAM3::ORBextractor, operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&,
+//                                                              cv::OutputArray, std::vector<int>&)   include/ORBextractor.h:61-64
+//        bf_match(d1, d2, std::vector<cv::DMatch>&), gms_inlier_mask(...)                            src/ORBmatcher.cc:755-762
+//        RegisterPointClouds(...) -> small_gicp::RegistrationResult                                  include/RegistrationGICP.h:25-28
+//        LbaAccess<KeyFrame, MapPoint> for gfs_host::LocalBundleAdjustment                           src/Optimizer.cc:1588-2040
+//      compile-checked against the reference's real headers over declaration-only OpenCV / Eigen / Sophus stand-ins
+//      (tests/test_host_logic.py::test_reference_dropins_compile).  INTEGRATION.md shows where they are swapped in.
 // Error behaviour follows the reference: operator() returns -1 on an empty image, asserts CV_8UC1; GICP never throws.
 // Anything the GPU library reports as an error is raised as std::runtime_error (there is no CPU fallback).
 #pragma once
@@ -705,45 +705,6 @@ class PoseOptimizer {
 
 }  // namespace gfs_host
 
-#if defined(GFS_WITH_OPENCV)
-#include <opencv2/core/core.hpp>
-#include <opencv2/features2d/features2d.hpp>
-#include <cassert>
-namespace ORB_SLAM3 {
-// Drop-in for the reference class (same name, same virtual operator()): see INTEGRATION.md §1.
-class ORBextractor {
- public:
-  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
-  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
-      : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) {}
-  virtual ~ORBextractor() {}
-  virtual int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
-                         cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
-    if (_image.empty()) return -1;
-    cv::Mat image = _image.getMat();
-    assert(image.type() == CV_8UC1);
-    std::vector<gfs_keypoint> k;
-    std::vector<uint8_t> d;
-    const int mono = impl_(image.data, image.rows, image.cols, (int)image.step, k, d, vLappingArea);
-    static_assert(sizeof(cv::KeyPoint) == sizeof(gfs_keypoint), "cv::KeyPoint layout");
-    _keypoints.resize(k.size());
-    if (!k.empty()) memcpy((void*)_keypoints.data(), k.data(), k.size() * sizeof(gfs_keypoint));
-    if (k.empty())
-      _descriptors.release();
-    else {
-      _descriptors.create((int)k.size(), 32, CV_8U);
-      memcpy(_descriptors.getMat().data, d.data(), d.size());
-    }
-    return mono;
-  }
-  int GetLevels() { return impl_.GetLevels(); }
-  std::vector<float> GetScaleFactors() { return impl_.GetScaleFactors(); }
-  std::vector<float> GetInverseScaleFactors() { return impl_.GetInverseScaleFactors(); }
-  std::vector<float> GetScaleSigmaSquares() { return impl_.GetScaleSigmaSquares(); }
-  std::vector<float> GetInverseScaleSigmaSquares() { return impl_.GetInverseScaleSigmaSquares(); }
+// The drop-ins written against the reference's own types (cv::Mat, cv::KeyPoint, Eigen, Sophus, ORB_SLAM3::ORBextractor as a base
+// class, small_gicp::RegistrationResult) are in gfs_reference_dropins.hpp beside this file.
 
- private:
-  gfs_host::ORBextractor impl_;
-};
-}  // namespace ORB_SLAM3
-#endif

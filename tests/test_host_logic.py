@@ -69,3 +69,22 @@ def test_std_sort_replica_matches_libstdcxx(api, oracle):
             s, x = np.sort(rng.integers(2, 30, n))[::-1].copy(), rng.integers(0, 3, n)
         assert _sort_pair(P.gfs_test_sort_replica, O.gfso_std_sort_pairs, s, x)
         assert _sort_pair(P.gfs_test_heap_sort_replica, O.gfso_std_partial_sort_pairs, s, x)
+
+
+def test_reference_dropins_compile():
+    """geoflowslam_amd/host/gfs_reference_dropins.hpp -- the code INTEGRATION.md tells a maintainer to add to the reference tree --
+    goes through a compiler: against the reference's real include/ORBextractor.h and small_gicp registration_result.hpp when
+    /root/reference is on this machine (a reduced declaration of the two otherwise), over declaration-only OpenCV / Eigen / Sophus
+    stand-ins (tests/host/stubs/).  Syntax, override signatures and struct layouts only: nothing is linked or run."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "host", "stubs")]
+    ref = "/root/reference"
+    variants = [[]]
+    if os.path.exists(os.path.join(ref, "include", "ORBextractor.h")):
+        variants.append(["-DGFS_HAVE_REFERENCE_TREE", "-I" + os.path.join(ref, "include"),
+                         "-I" + os.path.join(ref, "Thirdparty", "small_gicp", "include")])
+    for extra in variants:
+        out = subprocess.run(cmd + extra + [os.path.join(root, "tests", "host", "reference_dropins_check.cpp")], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-3000:]
