@@ -111,11 +111,10 @@ __device__ __forceinline__ double ordered_sum(const double* __restrict__ v, int 
 }
 
 // Eigen::LDLT<MatrixXd>::compute + isPositive + solve on a 6x6 (see oracle/pose_oracle.cpp for the line-by-line restatement)
-__device__ bool ldlt6_solve_positive(const double* H /*row-major symmetric*/, const double* b, double* x) {
-  double A[6][6];
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 6; j++) A[i][j] = H[6 * i + j];
-  int tr[6];
+// The pivot search and the symmetric transpositions index the matrix at run time: private arrays would live in scratch memory (a
+// round trip to the L1 per access, on the one lane everybody waits for), so the caller hands in LDS: A 6x6 (holds H on entry),
+// y 6, tr 6.
+__device__ __forceinline__ bool ldlt6_solve_positive(double (*A)[6], const double* b, double* x, double* y, int* tr) {
   int sign = 0;
   for (int k = 0; k < 6; k++) {
     int p = k;
@@ -149,7 +148,7 @@ __device__ bool ldlt6_solve_positive(const double* H /*row-major symmetric*/, co
       }
     }
     if (k > 0) {
-      double temp[6];
+      double* temp = y;  // (y is not in use yet)
       for (int j = 0; j < k; j++) temp[j] = A[j][j] * A[k][j];
       double acc = 0;
       for (int j = 0; j < k; j++) acc += A[k][j] * temp[j];
@@ -173,7 +172,6 @@ __device__ bool ldlt6_solve_positive(const double* H /*row-major symmetric*/, co
     }
   }
   if (sign != 1) return false;
-  double y[6];
   for (int i = 0; i < 6; i++) y[i] = b[i];
   for (int k = 0; k < 6; k++) {
     const double tmp = y[k];
@@ -205,6 +203,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
   __shared__ double s_T[7], s_Tb[7];  // current estimate, backup (push / pop)
   __shared__ double s_sys[kSys];
   __shared__ double s_x[6];
+  __shared__ double s_A[6][6], s_y[6];
+  __shared__ int s_tr[6];
   __shared__ int s_flag[2];
   const int f = blockIdx.x, tid = threadIdx.x;
   const PoseFrame F = frames[f];
@@ -335,15 +335,25 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
             }
             const double r[3] = {err[3 * e], err[3 * e + 1], err[3 * e + 2]};
             // the lower triangle, row a / column c <= a: the entries Eigen's LDLT reads (packed a (a + 1) / 2 + c)
+            // (every index below is a compile-time constant: arrays indexed at run time would live in scratch memory.  The third
+            //  row is added by a select, not as a zero term, so that a mono edge sums exactly its two terms)
+            const bool three = rows == 3;
             int o = 0;
+#pragma unroll
             for (int a = 0; a < 6; a++) {
               double sb = 0;
-              for (int k = 0; k < rows; k++) sb += J[6 * k + a] * (w * r[k]);
+              sb += J[a] * (w * r[0]);
+              sb += J[6 + a] * (w * r[1]);
+              const double sb3 = sb + J[12 + a] * (w * r[2]);
+              sb = three ? sb3 : sb;
               acc[21 + a] = -(rho1 * sb);  // b -= rho1 J' W e
+#pragma unroll
               for (int c = 0; c <= a; c++) {
                 double hh = 0;
-                for (int k = 0; k < rows; k++) hh += J[6 * k + a] * ((rho1 * w) * J[6 * k + c]);
-                acc[o++] = hh;
+                hh += J[a] * ((rho1 * w) * J[c]);
+                hh += J[6 + a] * ((rho1 * w) * J[6 + c]);
+                const double hh3 = hh + J[12 + a] * ((rho1 * w) * J[12 + c]);
+                acc[o++] = three ? hh3 : hh;
               }
             }
           }
@@ -369,19 +379,16 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       while (again) {
         if (tid == 0) {
           for (int k = 0; k < 7; k++) s_Tb[k] = s_T[k];  // push()
-          double Hl[36], b[6], x[6];
+          double x[6];
           int o = 0;
           for (int a = 0; a < 6; a++)
             for (int c = 0; c <= a; c++) {
-              Hl[6 * a + c] = s_sys[o];
-              Hl[6 * c + a] = s_sys[o];
+              s_A[a][c] = s_sys[o];
+              s_A[c][a] = s_sys[o];
               o++;
             }
-          for (int a = 0; a < 6; a++) {
-            Hl[7 * a] += currentLambda;
-            b[a] = s_sys[21 + a];
-          }
-          const bool ok2 = ldlt6_solve_positive(Hl, b, x);
+          for (int a = 0; a < 6; a++) s_A[a][a] += currentLambda;
+          const bool ok2 = ldlt6_solve_positive(s_A, s_sys + 21, x, s_y, s_tr);
           if (ok2) {
             double qn[4], tn[3];
             pose_oplus(s_T, s_T + 4, x, qn, tn);
@@ -453,27 +460,56 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
         }
     }
     __syncthreads();
-    if (tid == 0) {
-      nBad = 0;
-      float avg = 0.0f;
+    {
+      // every edge is classified by its own thread; what is order dependent -- the float sum of the inliers' chi2, mono list first,
+      // then the stereo list, each in creation order (:972-1060) -- is added up by one lane from terms parked in LDS (an edge that
+      // is not an inlier of the list at hand parks +0, which changes nothing)
+      float* s_term = reinterpret_cast<float*>(s_slab);
+      constexpr int kTerms = 2 * kSlabDoubles;
+      int bad_local = 0, good_local = 0;
+      float avg = 0.0f;  // thread 0
       for (int pass = 0; pass < 2; pass++)
-        for (int e = 0; e < n; e++) {
-          if ((E.stereo[e] != 0) != (pass == 1)) continue;
-          const float c = (float)chi2[e];
-          if (c > (pass ? 7.815f : 5.991f)) {
-            outlier[e] = 1;
-            level[e] = 1;
-            nBad++;
-          } else {
-            avg += c;
-            outlier[e] = 0;
-            level[e] = 0;
-            nGood++;
+        for (int base = 0; base < n; base += kTerms) {
+          const int cnt = min(kTerms, n - base);
+          for (int e = base + tid; e < base + cnt; e += kPoseThreads) {
+            float term = 0.0f;
+            if ((E.stereo[e] != 0) == (pass == 1)) {
+              const float c = (float)chi2[e];
+              const bool out = c > (pass ? 7.815f : 5.991f);
+              outlier[e] = out ? 1 : 0;
+              level[e] = out ? 1 : 0;
+              bad_local += out ? 1 : 0;
+              good_local += out ? 0 : 1;
+              if (!out) term = c;
+            }
+            s_term[e - base] = term;
           }
+          __syncthreads();
+          if (tid == 0) {
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+              const float a0 = s_term[j], a1 = s_term[j + 1], a2 = s_term[j + 2], a3 = s_term[j + 3], a4 = s_term[j + 4], a5 = s_term[j + 5],
+                          a6 = s_term[j + 6], a7 = s_term[j + 7];
+              avg += a0;
+              avg += a1;
+              avg += a2;
+              avg += a3;
+              avg += a4;
+              avg += a5;
+              avg += a6;
+              avg += a7;
+            }
+            for (; j < cnt; j++) avg += s_term[j];
+          }
+          __syncthreads();
         }
-      avg /= (float)nGood;  // nGood is never reset between the rounds
-      O.avg = avg;
-      O.rounds_run = it + 1;
+      nBad = (int)block_sum256((double)bad_local, s4);
+      nGood += (int)block_sum256((double)good_local, s4);  // nGood is never reset between the rounds
+      if (tid == 0) {
+        avg /= (float)nGood;
+        O.avg = avg;
+        O.rounds_run = it + 1;
+      }
     }
     __syncthreads();
     if (n < 10) break;  // optimizer.edges().size() < 10 (:1073)

@@ -17,6 +17,7 @@
 // Results are bit-exact integer work; the float decisions (image bounds, window membership, level ranges, histogram bins)
 // use the reference's float expressions (the library is built with -ffp-contract=off).
 #include <memory>
+#include <type_traits>
 #include <mutex>
 
 #include "gfs_common.hpp"
@@ -25,10 +26,11 @@ namespace {
 
 constexpr int kGridCols = 64, kGridRows = 48, kCells = kGridCols * kGridRows;
 constexpr int kHisto = 30, kThHigh = 100;
-constexpr int kSbpThreads = 256;
+constexpr int kSbpThreads = 1024;  // a thread per map point while their candidates are enumerated (dependent gathers: parallelism hides them)
 constexpr int kSbpMaxCur = 4096;   // key-points of the current frame (LDS tables)
 constexpr int kSbpMaxLast = 8192;  // map points of the last frame
 constexpr int kCand = 64;          // candidates kept per map point (more: the assignment pass re-enumerates them)
+constexpr int kChunk = 32;         // map points per step of the assignment pass (their candidate lists are prefetched into LDS)
 
 struct SbpPair {
   int n_last, n_cur, n_levels, mono, check_orientation;
@@ -127,34 +129,88 @@ __device__ __forceinline__ Proj sbp_project(const SbpPair& P, const SbpView& V, 
 
 // GetFeaturesInArea + the static filters of the candidate loop, in the reference's visiting order (ix, iy, cell order).
 // f(i2, dist) is called for every candidate that survives them; returns whether vIndices2 was non-empty.
+// The items of the window's cells are walked as one sequence, four at a time: the four key-points are fetched together, then the
+// descriptors of the survivors together -- two round trips to memory per four items instead of two per item.
 template <class F>
 __device__ __forceinline__ bool sbp_candidates(const SbpPair& P, const SbpView& V, const Proj& R, int l,
                                                const unsigned short* s_start, const unsigned short* s_items, F&& f) {
   const bool bCheckLevels = (R.minLevel > 0) || (R.maxLevel >= 0);
   bool any = false;
-  for (int ix = R.x0; ix <= R.x1; ix++)
-    for (int iy = R.y0; iy <= R.y1; iy++) {
-      const int cell = ix * kGridRows + iy;
-      for (int k = s_start[cell]; k < s_start[cell + 1]; k++) {
-        const int i2 = s_items[k];
-        const gfs_keypoint kp = V.cur_kp[i2];
-        if (bCheckLevels) {
-          if (kp.octave < R.minLevel) continue;
-          if (R.maxLevel >= 0 && kp.octave > R.maxLevel) continue;
+  const uint4* dl = reinterpret_cast<const uint4*>(V.last_desc + 32 * (size_t)l);
+  const uint4 a0 = dl[0], a1 = dl[1];
+  int ix = R.x0, iy = R.y0;
+  int k = s_start[ix * kGridRows + iy], kend = s_start[ix * kGridRows + iy + 1];
+  bool more = true;
+  auto next_item = [&]() {  // the next key-point index of the window in visiting order, or -1
+    while (more && k >= kend) {
+      if (++iy > R.y1) {
+        iy = R.y0;
+        if (++ix > R.x1) {
+          more = false;
+          break;
         }
-        const float distx = kp.x - R.u, disty = kp.y - R.v;
-        if (!(fabsf(distx) < R.radius && fabsf(disty) < R.radius)) continue;
-        any = true;
-        if (V.cur_has_obs[i2]) continue;  // a map point with observations was there on entry: never replaced
-        const float ur2 = V.cur_ur[i2];
-        if (ur2 > 0) {
-          const float er = fabsf(R.ur - ur2);
-          if (er > R.ur_gate) continue;
-        }
-        f(i2, hamming256(V.last_desc + 32 * (size_t)l, V.cur_desc + 32 * (size_t)i2));
       }
+      k = s_start[ix * kGridRows + iy];
+      kend = s_start[ix * kGridRows + iy + 1];
     }
+    return more ? (int)s_items[k++] : -1;
+  };
+  while (more) {
+    int i2[4];
+    gfs_keypoint kp[4];
+    float ur2[4];
+    uint8_t ho[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      i2[u] = next_item();
+      const int j = max(i2[u], 0);
+      kp[u] = V.cur_kp[j];
+      ur2[u] = V.cur_ur[j];
+      ho[u] = V.cur_has_obs[j];
+    }
+    bool pass[4];
+    uint4 b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      pass[u] = false;
+      if (i2[u] < 0) continue;
+      if (bCheckLevels) {
+        if (kp[u].octave < R.minLevel) continue;
+        if (R.maxLevel >= 0 && kp[u].octave > R.maxLevel) continue;
+      }
+      const float distx = kp[u].x - R.u, disty = kp[u].y - R.v;
+      if (!(fabsf(distx) < R.radius && fabsf(disty) < R.radius)) continue;
+      any = true;
+      if (ho[u]) continue;  // a map point with observations was there on entry: never replaced
+      if (ur2[u] > 0) {
+        const float er = fabsf(R.ur - ur2[u]);
+        if (er > R.ur_gate) continue;
+      }
+      pass[u] = true;
+      const uint4* dc = reinterpret_cast<const uint4*>(V.cur_desc + 32 * (size_t)i2[u]);
+      b0[u] = dc[0];
+      b1[u] = dc[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (pass[u])
+        f(i2[u], __popc(a0.x ^ b0[u].x) + __popc(a0.y ^ b0[u].y) + __popc(a0.z ^ b0[u].z) + __popc(a0.w ^ b0[u].w) + __popc(a1.x ^ b1[u].x) +
+                     __popc(a1.y ^ b1[u].y) + __popc(a1.z ^ b1[u].z) + __popc(a1.w ^ b1[u].w));
+  }
   return any;
+}
+
+// minimum of an unsigned value over the wave's 64 lanes, in every lane: quad permutes and row rotations (DPP) inside the rows of 16,
+// the four row results through scalar registers
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {
+  auto dpp = [](unsigned x, auto ctrl) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, decltype(ctrl)::value, 0xf, 0xf, true); };
+  v = min(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // lane ^ 1
+  v = min(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // lane ^ 2
+  v = min(v, dpp(v, std::integral_constant<int, 0x124>{}));  // row_ror:4
+  v = min(v, dpp(v, std::integral_constant<int, 0x128>{}));  // row_ror:8
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                 r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(r0, r1), min(r2, r3));
 }
 
 __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__ pairs, const float* __restrict__ last_xw,
@@ -168,12 +224,23 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
   __shared__ unsigned short s_start[kCells + 1];
   __shared__ unsigned short s_items[kSbpMaxCur];
   __shared__ short s_state[kSbpMaxCur];  // -1 untouched, -2 reset to NULL, >= 0 map point of last entry l
-  __shared__ int s_cnt[kCells];
+  // 16 KB used twice: the cell counters of the grid build, then the two candidate buffers of the assignment pass
+  __shared__ unsigned s_pool[2 * kChunk * kCand];
+  int* s_cnt = reinterpret_cast<int*>(s_pool);
+  static_assert(2 * kChunk * kCand >= kCells, "the pool must hold the cell counters");
+  __shared__ int s_ccnt[2][kChunk];
+  __shared__ uint8_t s_hasobs[kSbpMaxLast];  // Observations() > 0 of the last frame's map points
+  __shared__ uint8_t s_oct[kSbpMaxCur];      // octave of the current key-points (the ratio test of the map-point overload)
   __shared__ int s_scan[kSbpThreads];
   __shared__ int s_hist[kHisto];
   __shared__ int s_ctl[4];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const SbpPair P = pairs[f];
+  // the pair's header lives in LDS: its scale table is indexed by the octave, and a private copy indexed at run time is a copy in
+  // scratch memory -- every field access a round trip to the L1
+  __shared__ SbpPair s_P;
+  if (tid == 0) s_P = pairs[f];
+  __syncthreads();
+  const SbpPair& P = s_P;
   const SbpView V{last_xw + (size_t)f * SL * 3, last_desc + (size_t)f * SL * 32, last_octave + (size_t)f * SL,
                   last_angle + (size_t)f * SL, last_has_obs + (size_t)f * SL, cur_kp + (size_t)f * SC,
                   cur_ur + (size_t)f * SC, cur_desc + (size_t)f * SC * 32, cur_has_obs + (size_t)f * SC};
@@ -191,6 +258,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
     const bool in = px >= 0 && px < kGridCols && py >= 0 && py < kGridRows;
     s_cell[i] = in ? (unsigned short)(px * kGridRows + py) : (unsigned short)0xffff;
     s_state[i] = -1;
+    s_oct[i] = (uint8_t)kp.octave;
     if (in) atomicAdd(&s_cnt[px * kGridRows + py], 1);
   }
   __syncthreads();
@@ -236,6 +304,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
   __syncthreads();
   // ---- A. candidates of every map point (parallel)
   for (int l = tid; l < NL; l += kSbpThreads) {
+    s_hasobs[l] = V.last_has_obs[l];
     const Proj R = sbp_project(P, V, l, bForward, bBackward);
     int n = 0;
     bool any = false;
@@ -247,103 +316,125 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
     ccnt[l] = any ? n : -1;  // -1: vIndices2.empty() -> continue
   }
   __syncthreads();
-  // ---- B. assignment in map-point order (one wave)
-  if (tid < 64) {
-    int nm = 0;
-    for (int l = 0; l < NL; l++) {
-      const int n = ccnt[l];
-      sel[l] = -1;
-      if (n < 0) continue;
-      unsigned key = 0xffffffffu;  // dist << 16 | visiting order: the first minimum wins
-      unsigned idx = 0;
-      unsigned key2 = 0xffffffffu, idx2 = 0;  // second best (mode 1, re-enumeration path)
-      if (n <= kCand) {
-        if (lane < n) {
-          const unsigned e = cnd[(size_t)l * kCand + lane];
-          const int i2 = (int)(e & 0xffffu);
-          const int st = s_state[i2];
-          if (!(st >= 0 && V.last_has_obs[st])) {  // mvpMapPoints[i2] && Observations() > 0 -> skip (:1914-1915)
-            key = ((e >> 16) << 16) | (unsigned)lane;
-            idx = (unsigned)i2;
-          }
+  // ---- B. assignment in map-point order: one wave walks the map points, everything it looks at is in LDS -- the other three waves
+  //         fetch the candidate lists of the next kChunk map points meanwhile (a map point's step used to be two dependent round
+  //         trips to HBM: 1.3 us x 900 map points; now ~0.2 us)
+  auto fetch = [&](int c0, int buf, int t, int nt) {
+    for (int k = t; k < kChunk * kCand; k += nt) {
+      const int l = c0 + k / kCand;
+      s_pool[buf * kChunk * kCand + k] = l < NL ? cnd[(size_t)l * kCand + (k % kCand)] : 0u;
+    }
+    for (int k = t; k < kChunk; k += nt) s_ccnt[buf][k] = c0 + k < NL ? ccnt[c0 + k] : -1;
+  };
+  fetch(0, 0, tid, kSbpThreads);
+  __syncthreads();
+  int nm = 0;
+  for (int c0 = 0; c0 < NL; c0 += kChunk) {
+    const int buf = (c0 / kChunk) & 1;
+    if (tid >= 64) {
+      if (c0 + kChunk < NL) fetch(c0 + kChunk, buf ^ 1, tid - 64, kSbpThreads - 64);
+    } else {
+      const int lend = min(c0 + kChunk, NL);
+      // (the list entry and the count of the NEXT map point are read while this one is decided: they do not depend on it)
+      int n_next = s_ccnt[buf][0];
+      unsigned e_next = s_pool[buf * kChunk * kCand + lane];
+      for (int l = c0; l < lend; l++) {
+        const int n = n_next;
+        const unsigned e = e_next;
+        if (l + 1 < lend) {
+          n_next = s_ccnt[buf][l + 1 - c0];
+          e_next = s_pool[buf * kChunk * kCand + (l + 1 - c0) * kCand + lane];
         }
-      } else if (lane == 0) {  // more candidates than the list holds: enumerate them again (rare)
-        const Proj R = sbp_project(P, V, l, bForward, bBackward);
-        int order = 0;
-        int bestDist = 256;
-        int bestDist2 = 256;
-        sbp_candidates(P, V, R, l, s_start, s_items, [&](int i2, int dist) {
-          const int st = s_state[i2];
-          if (!(st >= 0 && V.last_has_obs[st])) {
-            const unsigned kk = ((unsigned)dist << 16) | (unsigned)min(order, 0xffff);
-            if (dist < bestDist) {
-              bestDist2 = bestDist;
-              key2 = key;
-              idx2 = idx;
-              bestDist = dist;
-              idx = (unsigned)i2;
-              key = kk;
-            } else if (dist < bestDist2) {
-              bestDist2 = dist;
-              key2 = kk;
-              idx2 = (unsigned)i2;
+        int sel_l = -1;
+        if (n >= 0) {
+          unsigned key = 0xffffffffu;  // dist << 16 | visiting order: the first minimum wins
+          unsigned idx = 0;
+          unsigned key2 = 0xffffffffu, idx2 = 0;  // second best (mode 1, re-enumeration path)
+          if (n <= kCand) {
+            if (lane < n) {
+              const int i2 = (int)(e & 0xffffu);
+              const int st = s_state[i2];
+              if (!(st >= 0 && s_hasobs[st])) {  // mvpMapPoints[i2] && Observations() > 0 -> skip (:1914-1915)
+                key = ((e >> 16) << 16) | (unsigned)lane;
+                idx = (unsigned)i2;
+              }
             }
+          } else if (lane == 0) {  // more candidates than the list holds: enumerate them again (rare)
+            const Proj R = sbp_project(P, V, l, bForward, bBackward);
+            int order = 0;
+            int bestDist = 256;
+            int bestDist2 = 256;
+            sbp_candidates(P, V, R, l, s_start, s_items, [&](int i2, int dist) {
+              const int st = s_state[i2];
+              if (!(st >= 0 && s_hasobs[st])) {
+                const unsigned kk = ((unsigned)dist << 16) | (unsigned)min(order, 0xffff);
+                if (dist < bestDist) {
+                  bestDist2 = bestDist;
+                  key2 = key;
+                  idx2 = idx;
+                  bestDist = dist;
+                  idx = (unsigned)i2;
+                  key = kk;
+                } else if (dist < bestDist2) {
+                  bestDist2 = dist;
+                  key2 = kk;
+                  idx2 = (unsigned)i2;
+                }
+              }
+              order++;
+            });
           }
-          order++;
-        });
-      }
-      const unsigned mykey = key, myidx = idx;
-#pragma unroll
-      for (int ofs = 32; ofs > 0; ofs >>= 1) {
-        const unsigned ok = __shfl_xor(key, ofs, 64), oi = __shfl_xor(idx, ofs, 64);
-        if (ok < key) {
-          key = ok;
-          idx = oi;
-        }
-      }
-      const int bestDist = key == 0xffffffffu ? 256 : (int)(key >> 16);
-      if (P.mode == 1) {
-        // second best = the smallest (distance, visiting order) among the others: what the sequential best / second-best
-        // bookkeeping of :96-113 ends with.  (The re-enumeration path has filled key2 / idx2 on lane 0.)
-        unsigned k2 = (n <= kCand) ? (mykey == key ? 0xffffffffu : mykey) : key2, i2b = (n <= kCand) ? myidx : idx2;
-#pragma unroll
-        for (int ofs = 32; ofs > 0; ofs >>= 1) {
-          const unsigned ok = __shfl_xor(k2, ofs, 64), oi = __shfl_xor(i2b, ofs, 64);
-          if (ok < k2) {
-            k2 = ok;
-            i2b = oi;
-          }
-        }
-        if (bestDist <= kThHigh) {
-          const int best = (int)idx;
-          const int bestDist2 = k2 == 0xffffffffu ? 256 : (int)(k2 >> 16);
-          const int bestLevel = V.cur_kp[best].octave, bestLevel2 = k2 == 0xffffffffu ? -1 : V.cur_kp[i2b].octave;
-          const bool reject = bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2;
-          if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= P.nn_ratio * (float)bestDist2)) {
+          // the keys are distinct (their low half is the visiting order = the lane, or sits on lane 0 alone): the smallest key names
+          // its lane, whose index is then read directly
+          const unsigned mykey = key, myidx = idx;
+          key = wave_umin(mykey);
+          const int from = n <= kCand ? (int)(key & 63u) : 0;
+          idx = (unsigned)__builtin_amdgcn_readlane((int)myidx, __builtin_amdgcn_readfirstlane(from));
+          const int bestDist = key == 0xffffffffu ? 256 : (int)(key >> 16);
+          if (P.mode == 1) {
+            // second best = the smallest (distance, visiting order) among the others: what the sequential best / second-best
+            // bookkeeping of :96-113 ends with.  (The re-enumeration path has filled key2 / idx2 on lane 0.)
+            const unsigned myk2 = (n <= kCand) ? (mykey == key ? 0xffffffffu : mykey) : key2, myi2b = (n <= kCand) ? myidx : idx2;
+            const unsigned k2 = wave_umin(myk2);
+            const int from2 = n <= kCand ? (int)(k2 & 63u) : 0;
+            const unsigned i2b = (unsigned)__builtin_amdgcn_readlane((int)myi2b, __builtin_amdgcn_readfirstlane(from2));
+            if (bestDist <= kThHigh) {
+              const int best = (int)idx;
+              const int bestDist2 = k2 == 0xffffffffu ? 256 : (int)(k2 >> 16);
+              const int bestLevel = s_oct[best], bestLevel2 = k2 == 0xffffffffu ? -1 : (int)s_oct[i2b];
+              const bool reject = bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2;
+              if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= P.nn_ratio * (float)bestDist2)) {
+                nm++;
+                if (lane == 0) s_state[best] = (short)l;
+              }
+            }
+          } else if (bestDist <= kThHigh) {
             nm++;
-            if (lane == 0) s_state[best] = (short)l;
+            if (lane == 0) s_state[(int)idx] = (short)l;
+            sel_l = (int)idx;
           }
         }
-        continue;
-      }
-      if (bestDist <= kThHigh) {
-        const int best = (int)idx;
-        nm++;
-        if (lane == 0) {
-          s_state[best] = (short)l;
-          int bin = -1;
-          if (P.check_orientation) {
-            float rot = V.last_angle[l] - V.cur_kp[best].angle;
-            if (rot < 0.0) rot += 360.0f;
-            bin = (int)roundf(rot * (1.0f / kHisto));
-            if (bin == kHisto) bin = 0;
-            s_hist[bin]++;
-          }
-          sel[l] = best | (bin << 16);
-        }
+        if (lane == 0) sel[l] = sel_l;  // mode 0: the key-point this map point took (its histogram bin follows below)
       }
     }
-    if (lane == 0) s_ctl[0] = nm;
+    __syncthreads();
+  }
+  if (tid == 0) s_ctl[0] = nm;
+  __syncthreads();
+  if (P.mode == 0) {  // rotHist[bin].push_back(bestIdx2) of every assignment (:1935-1944), all map points at once
+    for (int l = tid; l < NL; l += kSbpThreads) {
+      const int best = sel[l];
+      if (best < 0) continue;
+      int bin = -1;
+      if (P.check_orientation) {
+        float rot = V.last_angle[l] - V.cur_kp[best].angle;
+        if (rot < 0.0) rot += 360.0f;
+        bin = (int)roundf(rot * (1.0f / kHisto));
+        if (bin == kHisto) bin = 0;
+        atomicAdd(&s_hist[bin], 1);
+      }
+      sel[l] = best | (bin << 16);
+    }
   }
   __syncthreads();
   // ---- C. rotation consistency
