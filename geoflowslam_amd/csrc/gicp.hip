@@ -2117,7 +2117,8 @@ static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only) 
 }
 
 // std::sort of the < 1024-element ranges (both key widths), then the heap-sort fallbacks they deferred
-static int voxel_qsort_leaves(gfs_gicp* h, int C2, int leaf_parts, hipStream_t s, int only) {
+static int voxel_qsort_leaves(gfs_gicp* h, int C2, int leaf_parts, hipStream_t s, int only, const float4* in_even = nullptr,
+                              const float4* in_odd = nullptr, int stride_pts = 0) {
   const int P = h->P;
   GFS_LAUNCH("k_voxel_qsort_leaf", vqs::k_voxel_qsort_leaf<unsigned>, dim3(leaf_parts, C2), dim3(256), 0, s, h->d_keys0.p,
              h->d_val0.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, P, only, h->d_heap.p, h->d_nheap.p, h->heap_cap);
@@ -2125,9 +2126,9 @@ static int voxel_qsort_leaves(gfs_gicp* h, int C2, int leaf_parts, hipStream_t s
              h->d_val0.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, P, only, h->d_heap.p, h->d_nheap.p, h->heap_cap);
   const int heap_parts = std::max(1, std::min(16, P / 4096));
   GFS_LAUNCH("k_voxel_qsort_heap", vqs::k_voxel_qsort_heap<unsigned>, dim3(heap_parts, C2), dim3(256), 0, s, h->d_keys0.p,
-             h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only);
+             h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only, in_even, in_odd, stride_pts);
   GFS_LAUNCH("k_voxel_qsort_heap64", vqs::k_voxel_qsort_heap<u64>, dim3(heap_parts, C2), dim3(256), 0, s, h->d_keys0.p,
-             h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only);
+             h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only, in_even, in_odd, stride_pts);
   return GFS_OK;
 }
 
@@ -2295,7 +2296,9 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     int rc_leaf = 0;
     GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, (size_t)C2 * sizeof(int), s));
     GFS_HIP(voxel_qsort_top(h, C2, s, prm.only));
-    rc_leaf = voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only);
+    // (GFS_GICP_VOXEL_TIES=exact: the reference's permutation even where it cannot change a voxel mean)
+    static const bool exact_ties = getenv("GFS_GICP_VOXEL_TIES") && strcmp(getenv("GFS_GICP_VOXEL_TIES"), "exact") == 0;
+    rc_leaf = exact_ties ? voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only) : voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, in_even, in_odd, stride_pts);
     if (rc_leaf) return rc_leaf;
   }
   GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, in_even, in_odd, stride_pts, h->d_keys0.p, h->d_keys1.p,

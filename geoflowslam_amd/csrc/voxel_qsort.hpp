@@ -1179,7 +1179,10 @@ struct HeapLds {
 template <typename KT>
 __global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigned* vals_all, const int* __restrict__ kinfo,
                                                           const unsigned* __restrict__ heap_all, const int* __restrict__ nheap,
-                                                          int heap_cap, int P, int only) {
+                                                          int heap_cap, int P, int only, const float4* __restrict__ pts_even,
+                                                          const float4* __restrict__ pts_odd, int stride_pts) {
+  // pts_even / pts_odd: the input clouds of the even / odd slots as k_voxel_reduce reads them (null: no shortcut, the exact
+  // permutation in every case -- the test hook)
   constexpr bool kNarrow = sizeof(KT) == 4;
   __shared__ HeapLds<KT> S;
   const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1203,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigne
     // of a depth image where nearly every voxel holds one point.  When all keys of the range are distinct the result of ANY
     // correct sort is the reference's: rank every element by counting smaller keys (all lanes in parallel), and replay
     // libstdc++'s heap sort only if two elements collide on a rank (equal keys: their order is the heap's).
-    bool replay = false;
+    bool replay = false, partial = false;
     int keep = 1;
     unsigned short* Rk = S.Rk[wave];
     {
@@ -1247,7 +1250,95 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigne
 #pragma unroll
         for (int r = 0; r < 16; r++)
           if (r * 64 + lane < n) K[rank[r]] = mykey[r];
-      } else {
+      }
+      if (replay && (pts_even || pts_odd)) {
+        // Equal keys exist (voxels with several points).  What their order decides downstream (k_voxel_reduce,
+        // util/downsampling_omp.hpp:63-90) is (a) which points of a voxel fall on either side of a 1024-element block cut and (b) the
+        // order in which a voxel's coordinates are added up in double precision.  If no tied voxel of this range straddles a cut,
+        // and the sums are exact whatever the order -- the coordinates are floats: a sum of up to 64 of them is exact in a double
+        // as long as their binary exponents span less than 23 -- every order gives the reference's means bit for bit, and the serial
+        // replay of the heap (~0.5 ms on one wave, with the rest of the chip waiting) is not needed: ties are ordered by position.
+        const float4* in = ((c & 1) ? pts_odd : pts_even);
+        int eqb[16], le[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) eqb[r] = le[r] = 0;
+        for (int j = 0; j < n8; j += 8) {
+          KT kj[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) kj[u] = K[j + u];
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (r < rows) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                le[r] += kj[u] <= mykey[r] ? 1 : 0;
+                eqb[r] += (kj[u] == mykey[r] && j + u < r * 64 + lane) ? 1 : 0;
+              }
+            }
+        }
+        bool bad = in == nullptr;
+        int below_bad = n;  // smallest rank among the voxels whose order does matter (they straddle a block cut)
+        int emin = 0x7fffffff, emax = -0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (r * 64 + lane < n) {
+            const int g = le[r] - rank[r];  // points of this element's voxel in the range (the padding keys are larger than any key)
+            if (g > 1) {
+              const int first = b + rank[r];
+              const bool matters = g > 64 || (first >> 10) != ((first + g - 1) >> 10);
+              bad = bad || matters;
+              if (matters) below_bad = min(below_bad, rank[r]);
+              if (in) {
+                const float4 pt = in[(size_t)(c >> 1) * stride_pts + va[b + r * 64 + lane]];
+                const float co[3] = {pt.x, pt.y, pt.z};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                  const unsigned bits = __float_as_uint(co[a]) & 0x7fffffffu;
+                  if (bits == 0) continue;                     // zeros add exactly
+                  if (bits >= 0x7f800000u) bad = true;          // inf / nan: leave it to the replay
+                  const int e = max((int)(bits >> 23), 1);      // (subnormals share the smallest exponent)
+                  emin = min(emin, e);
+                  emax = max(emax, e);
+                }
+              }
+            }
+          }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+          emin = min(emin, __shfl_xor(emin, ofs, 64));
+          emax = max(emax, __shfl_xor(emax, ofs, 64));
+          below_bad = min(below_bad, __shfl_xor(below_bad, ofs, 64));
+        }
+        // (one exponent window for all three coordinates and all tied voxels of the range: coarser than needed, and still passed
+        // by every depth-camera cloud -- |x|, |y| >= half a pixel's footprint, z >= the sensor's near limit)
+        const bool exact_sums = in != nullptr && (emax < emin || emax - emin < 23);
+        const bool harmless = __ballot(bad) == 0ull && exact_sums;
+        if (!harmless && exact_sums && below_bad < n) {
+          // Some tied voxel does straddle a cut: its order is the heap's, and so is the order of everything popped before it (the
+          // pops come out in descending key order).  But the replay can stop once that voxel has been popped: the ties left in the
+          // heap are of the harmless kind and take the places rank + position among their equals.
+          partial = true;
+          keep = below_bad;
+          VQS_WAVE_SYNC();
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (r * 64 + lane < n) Rk[r * 64 + lane] = (unsigned short)(rank[r] + eqb[r]);
+          for (int p = lane; p < n; p += 64) Pm[p] = (unsigned short)p;
+          VQS_WAVE_SYNC();
+        }
+        if (harmless) {
+          VQS_WAVE_SYNC();
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (r * 64 + lane < n) {
+              K[rank[r] + eqb[r]] = mykey[r];
+              slot[rank[r] + eqb[r]] = (unsigned short)(r * 64 + lane);
+            }
+          replay = false;
+          VQS_WAVE_SYNC();
+        }
+      }
+      if (replay && !partial) {
         // Equal keys exist: their order is the heap's.  The pops come out in descending key order, so once every key >= the
         // smallest tied key has been popped, what is left in the heap are distinct keys whose places are their ranks: only the
         // first n - (number of keys below the smallest tied key) pops are replayed.
