@@ -388,10 +388,14 @@ def main():
         if pmc_all.get("_batch_pairs") == B and args.workload == "c2":
             t = pmc_all.get(name)
             if t:  # HBM-side bytes per STEP measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)
-                traffic = int((t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
-                traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, same batch, 1 lane, serial), KB*1024, "
-                                "per step / launches per step; FETCH_SIZE left uncorrected (gather pattern uncalibrated, "
-                                "MI355X_MICROARCH.md §HBM)")
+                # calibration (profiles/r03_calibration.json, kernels with known byte counts): FETCH_SIZE reports HALF the bytes of
+                # wide streaming reads (0.500), the full 64-byte line for a 32-byte gather that misses the caches (2.02 x the 32 bytes
+                # asked for), nothing for gathers served by the L2; WRITE_SIZE is exact (1.000)
+                traffic = int((2.0 * t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
+                traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, same batch, 1 lane, serial), "
+                                "(2 x FETCH_SIZE + WRITE_SIZE) KB*1024 per step / launches per step; the factor 2 is the measured under-count of "
+                                "streaming reads (profiles/r03_calibration.json) and over-counts the share of cache-missing gathers, which the counter "
+                                "reports in full: an upper bound of the HBM-side bytes")
         roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 2) if ach else None, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 5) if ach else None, traffic=traffic, traffic_note=traffic_note,
                         avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=lps,

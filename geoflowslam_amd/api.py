@@ -180,7 +180,7 @@ ABI_SYMBOLS = [
     "gfs_orb_default_config", "gfs_orb_create", "gfs_orb_destroy", "gfs_orb_get_tables", "gfs_orb_max_keypoints",
     "gfs_orb_extract", "gfs_orb_extract_batch", "gfs_orb_extract_batch_device", "gfs_orb_device_results",
     "gfs_orb_fetch", "gfs_orb_level_size", "gfs_orb_fetch_level", "gfs_orb_fetch_candidates", "gfs_orb_octree_host",
-    "gfs_orb_octree_device", "gfs_test_sort_replica", "gfs_test_heap_sort_replica", "gfs_test_glibc_math",
+    "gfs_orb_octree_device", "gfs_test_sort_replica", "gfs_test_heap_sort_replica", "gfs_test_glibc_math", "gfs_test_traffic",
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
@@ -228,6 +228,7 @@ def lib():
         L.gfs_orb_octree_host.argtypes = [vp, vp, vp, i, i, i, i, i, i, vp, i]
         L.gfs_orb_octree_device.argtypes = [i, vp, vp, vp, i, i, i, i, i, i, vp, vp, vp, i]
         L.gfs_test_glibc_math.argtypes = [i, vp, i, vp, vp, vp]
+        L.gfs_test_traffic.argtypes = [i, i, C.c_longlong, C.c_longlong, i, C.POINTER(C.c_longlong)]
         L.gfs_hamming256.argtypes = [vp, vp]
         L.gfs_matcher_create.argtypes = [i, i, i, i, C.POINTER(vp)]
         L.gfs_matcher_destroy.argtypes = [vp]

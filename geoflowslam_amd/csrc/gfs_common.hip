@@ -1,6 +1,7 @@
 // Error reporting, device probing, timers and the per-kernel profiler of libgfs_hip.so.
 #include "gfs_common.hpp"
 
+#include <algorithm>
 #include <map>
 
 namespace gfs {
@@ -95,6 +96,34 @@ struct gfs_timer {
   hipEvent_t e0, e1;
 };
 
+namespace {
+__global__ void k_cal_stream_read(const double4* __restrict__ a, long long n, double* __restrict__ sink) {
+  double acc = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double4 v = a[i];
+    acc += v.x + v.y + v.z + v.w;
+  }
+  if (acc == 12345.678) sink[threadIdx.x] = acc;  // never true: keeps the loads
+}
+__global__ void k_cal_gather32(const double4* __restrict__ a, long long n, long long table, int per_thread, double* __restrict__ sink) {
+  double acc = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned long long h = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
+    for (int k = 0; k < per_thread; k++) {
+      h ^= h >> 29;
+      h *= 0xBF58476D1CE4E5B9ull;
+      const double4 v = a[(long long)(h % (unsigned long long)table)];
+      acc += v.x + v.y + v.z + v.w;
+    }
+  }
+  if (acc == 12345.678) sink[threadIdx.x] = acc;
+}
+__global__ void k_cal_stream_write(double4* __restrict__ a, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    a[i] = make_double4((double)i, 1.0, 2.0, 3.0);
+}
+}  // namespace
+
 extern "C" {
 
 int gfs_abi_version(void) { return GFS_ABI_VERSION; }
@@ -169,6 +198,38 @@ int gfs_profile_report(char (*names)[64], double* total_ms, int64_t* launches, i
     i++;
   }
   return i;
+}
+
+// Test hook for calibrating the HBM counters (profiles/calibrate.sh): kernels with KNOWN byte counts in the access patterns of the
+// hot kernels.  mode 0: streaming read of n 32-byte records (k_cal_stream_read); mode 1: every thread gathers `per_thread` 32-byte
+// records at pseudo-random indices of a table of `table` records (k_cal_gather32: the per-lane point gathers of the k-NN / 1-NN
+// searches); mode 2: streaming write of n 32-byte records (k_cal_stream_write).  Returns the bytes the kernel asked for.
+int gfs_test_traffic(int device, int mode, long long n, long long table, int per_thread, long long* bytes_out) {
+  GFS_REQUIRE(bytes_out && n > 0 && mode >= 0 && mode <= 2, GFS_ERR_INVALID_ARG, "gfs_test_traffic: invalid argument");
+  if (!gfs::device_ok(device)) return GFS_ERR_NO_DEVICE;
+  GFS_HIP(hipSetDevice(device));
+  gfs::DevBuf<double4> d_a;
+  gfs::DevBuf<double> d_sink;
+  const long long alloc = mode == 1 ? table : n;
+  int rc = d_a.alloc((size_t)alloc);
+  if (!rc) rc = d_sink.alloc(1 << 20);
+  if (rc) return rc;
+  GFS_HIP(hipMemset(d_a.p, 0, (size_t)alloc * sizeof(double4)));
+  GFS_HIP(hipMemset(d_sink.p, 0, (size_t)(1 << 20) * sizeof(double)));
+  GFS_HIP(hipDeviceSynchronize());
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 1 << 20);
+  if (mode == 0) {
+    GFS_LAUNCH("k_cal_stream_read", k_cal_stream_read, dim3(blocks), dim3(256), 0, (hipStream_t)0, d_a.p, n, d_sink.p);
+    *bytes_out = n * 32;
+  } else if (mode == 1) {
+    GFS_LAUNCH("k_cal_gather32", k_cal_gather32, dim3(blocks), dim3(256), 0, (hipStream_t)0, d_a.p, n, table, per_thread, d_sink.p);
+    *bytes_out = n * per_thread * 32;
+  } else {
+    GFS_LAUNCH("k_cal_stream_write", k_cal_stream_write, dim3(blocks), dim3(256), 0, (hipStream_t)0, d_a.p, n);
+    *bytes_out = n * 32;
+  }
+  GFS_HIP(hipDeviceSynchronize());
+  return GFS_OK;
 }
 
 }  // extern "C"

@@ -127,6 +127,10 @@ int gfs_test_heap_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* paylo
  * (csrc/glibc_math.hpp) that the pose / window / registration optimizers use for SE3Quat::exp
  * (Thirdparty/g2o/g2o/types/se3quat.h:223-257) and the Levenberg step control (core/optimization_algorithm_levenberg.cpp:127). */
 int gfs_test_glibc_math(int device, const double* x, int n, double* sin_out, double* cos_out, double* pow3_out);
+/* GPU test hook for calibrating the HBM counters (profiles/calibrate.sh): a kernel with a KNOWN byte count -- mode 0 streaming read,
+ * 1 per-lane gathers of 32-byte records out of a table of `table` records, 2 streaming write; n records (mode 1: n threads x per_thread
+ * gathers).  *bytes_out = the bytes the kernel asked for. */
+int gfs_test_traffic(int device, int mode, long long n, long long table, int per_thread, long long* bytes_out);
 
 /* ============================================================================================
  * 2. Brute-force Hamming matching — replaces
