@@ -1577,11 +1577,19 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
                                                               const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
                                                               int nchunks, int npairs, int P, GicpParams prm,
                                                               int* __restrict__ tgt_index, double* __restrict__ maha6,
-                                                              double* __restrict__ partial, int nblk) {
+                                                              double* __restrict__ partial, int nblk, const int* __restrict__ act,
+                                                              const int* __restrict__ n_act) {
   __shared__ double s_red[4 * 32];
   __shared__ typename std::conditional<kTiled, LinTile, int>::type tile;  // the untiled instance keeps its LDS (and its occupancy)
   int pair, sub, chunk;
-  if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
+  if (act) {  // a late round: only the pairs on the list (the grid covers an upper bound of their number)
+    const int slot = blockIdx.x / nchunks;
+    if (slot >= *n_act) return;
+    pair = act[slot];
+    chunk = blockIdx.x - slot * nchunks;
+  } else if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) {
+    return;
+  }
   // Everything this workgroup can ask for before it knows anything is asked for first -- the pair's state, the cloud sizes, the
   // grid header, the lane's source point and its previous correspondence -- so that the dependent round trips to memory that
   // remain are: state -> (tile rows) -> (tile points) -> search in LDS -> target covariance.
@@ -1638,10 +1646,18 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
 __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __restrict__ st, const double4* __restrict__ pts,
                                                            const int* __restrict__ m_counts, int P,
                                                            const int* __restrict__ tgt_index, const double* __restrict__ maha6,
-                                                           double* __restrict__ epartial, int nblk, int nchunks, int npairs, int src_slot) {
+                                                           double* __restrict__ epartial, int nblk, int nchunks, int npairs, int src_slot,
+                                                           const int* __restrict__ act, const int* __restrict__ n_act) {
   __shared__ double s_red[4 * 32];
   int pair, sub, chunk;
-  if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) return;
+  if (act) {  // a late round: only the pairs on the list
+    const int slot = blockIdx.x / nchunks;
+    if (slot >= *n_act) return;
+    pair = act[slot];
+    chunk = blockIdx.x - slot * nchunks;
+  } else if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) {
+    return;
+  }
   const PairState& S = st[pair];
   if (S.phase != 1) return;
   const int cs = 2 * pair + src_slot, ct = 2 * pair + 1 - src_slot;
@@ -1804,9 +1820,11 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
 
 // after a linearise pass: fold the per-block partial sums (fixed order), first damped solve
 __global__ __launch_bounds__(256) void k_gicp_solve(PairState* __restrict__ st, const double* __restrict__ partial,
-                                                    const int* __restrict__ m_counts, int nblk_max, int src_slot) {
+                                                    const int* __restrict__ m_counts, int nblk_max, int src_slot,
+                                                    int* __restrict__ n_act_next) {
   __shared__ double s_part[8 * 32], s_sum[32];
   const int pair = blockIdx.x;
+  if (pair == 0 && threadIdx.x == 0) *n_act_next = 0;  // k_gicp_decide of this round fills the list of the next one
   if (st[pair].phase != 0) return;
   const int ms = m_counts[2 * pair + src_slot];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
@@ -1840,9 +1858,21 @@ __global__ __launch_bounds__(256) void k_gicp_solve(PairState* __restrict__ st, 
 // after an error pass: accept / reject the trial (registration/optimizer.hpp:115-141)
 __global__ __launch_bounds__(256) void k_gicp_decide(PairState* __restrict__ st, const double* __restrict__ epartial,
                                                      const int* __restrict__ m_counts, int nblk_max, GicpParams prm,
-                                                     int* __restrict__ n_done) {
+                                                     int* __restrict__ n_done, int* __restrict__ act_next, int* __restrict__ n_act_next) {
+  // act_next / n_act_next: the pairs that are not done after this round, for the grids of the next one (filled by GicpActive's
+  // destructor on every path out of the bookkeeping below; the order is whatever the atomics give -- pairs are independent)
   __shared__ double s_part[8 * 32], s_sum[32];
   const int pair = blockIdx.x;
+  struct GicpActive {
+    const PairState* st;
+    int pair;
+    int* list;
+    int* n;
+    bool lead;
+    __device__ ~GicpActive() {
+      if (lead && st[pair].phase != 2) list[atomicAdd(n, 1)] = pair;
+    }
+  } note{st, pair, act_next, n_act_next, threadIdx.x == 0};
   if (st[pair].phase != 1) return;
   const int ms = m_counts[2 * pair + prm.src_slot];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
@@ -2068,6 +2098,7 @@ struct gfs_gicp {
   // one launch per step of the LM state machine (default).  GFS_GICP_LM=persistent: the whole loop of a pair in one workgroup
   // (k_gicp_lm) — no launches / host polls inside the loop, but only one workgroup of parallelism per pair: measured 4x slower at
   // 128 pairs per batch (25 vs 6 ms per 512 pairs), it pays only for batches of many thousand small pairs.
+  gfs::DevBuf<int> d_active, d_nactive;  // [2][B] pairs still iterating (written by k_gicp_decide for the next round), [2] their number
   bool lm_rounds = true;
   bool tile_stats_on = false;  // GFS_GICP_TILE_STATS=1
   gfs::DevBuf<unsigned> d_tile_stats;  // [8] outcome counters of k_gicp_linearize's tile staging (gfs_gicp_tile_stats)
@@ -2180,6 +2211,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_kinfo2.alloc(C2 * 8));
   A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
   A(h->d_ndone.alloc(1));
+  A(h->d_active.alloc(2 * (size_t)B));
+  A(h->d_nactive.alloc(2));
   A(h->d_tile_stats.alloc(8));
   A(h->d_keys0.alloc(C2 * P));
   A(h->d_keys1.alloc(C2 * P));
@@ -2333,28 +2366,41 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   } else {
     const int nblk_run = gfs::div_up(npts, kLinBlock);
     const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
+    int known_done = 0;  // pairs known to be done: the count polled one round behind
     for (int round = 0; round < max_rounds; round++) {
+      // Late rounds run for a handful of pairs: their grids are cut to the pairs still iterating.  The host knows an upper bound
+      // (the done counter it polled for round - 2); the list itself is written on the device by the previous round's
+      // k_gicp_decide.  While most pairs are active the full grid with its XCD-aware pair -> block map is kept.
+      const int ub = B - known_done;
+      const bool listed = round >= 2 && 4 * ub <= B;
+      const int* act = listed ? h->d_active.p + (size_t)(round & 1) * B : nullptr;
+      const int* n_act = h->d_nactive.p + (round & 1);
+      int* act_next = h->d_active.p + (size_t)((round + 1) & 1) * B;
+      int* n_act_next = h->d_nactive.p + ((round + 1) & 1);
+      const dim3 grid_pts(listed ? std::max(ub, 1) * nblk_run : xcd_grid(nblk_run, B, 1));
       if (prm.lin_tile) {
-        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<true>, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
+        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<true>, grid_pts, dim3(kLinBlock), 0, s, h->d_state.p,
                    h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
-                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
+                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk, act, n_act);
       } else {
-        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<false>, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p,
+        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<false>, grid_pts, dim3(kLinBlock), 0, s, h->d_state.p,
                    h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
-                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk);
+                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk, act, n_act);
       }
-      GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot);
-      GFS_LAUNCH("k_gicp_error", k_gicp_error, dim3(xcd_grid(nblk_run, B, 1)), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
-                 h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B, prm.src_slot);
+      GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot,
+                 n_act_next);
+      GFS_LAUNCH("k_gicp_error", k_gicp_error, grid_pts, dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
+                 h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B, prm.src_slot, act, n_act);
       GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
-                 h->d_ndone.p);
+                 h->d_ndone.p, act_next, n_act_next);
       // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
       // speculative round after convergence finds every pair in phase 2 and its blocks exit at once.
       GFS_HIP(hipMemcpyAsync(h->h_ndone.p + (round & 1), h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
       GFS_HIP(hipEventRecord(h->ev_round[round & 1], s));
       if (round >= 1) {
         GFS_HIP(hipEventSynchronize(h->ev_round[(round - 1) & 1]));
-        if (h->h_ndone.p[(round - 1) & 1] >= B) break;
+        known_done = h->h_ndone.p[(round - 1) & 1];
+        if (known_done >= B) break;
       }
     }
   }
