@@ -125,7 +125,9 @@ extern "C" int lba_adaptor_test(const char* solver_lib, int n_poses, int n_point
       if ((int)k.mvInvLevelSigma2.size() <= kp) k.mvInvLevelSigma2.resize((size_t)kp + 1);
       k.mvInvLevelSigma2[kp] = (float)edge_inv_sigma2[e];
       k.mvpMapPoints.push_back(&mps[edge_point[e]]);
-      mps[edge_point[e]].obs[&k] = std::make_tuple(kp, -1);
+      // init_kf_pose == -2: a rig with a second camera whose right image also saw the point (the adaptor must refuse it)
+      mps[edge_point[e]].obs[&k] = std::make_tuple(kp, init_kf_pose == -2 && e == 0 ? 0 : -1);
+      if (init_kf_pose == -2 && e == 0) k.mpCamera2 = &k;
     }
     bool stop = stop_flag == 1;  // 1: raised before the call; >= 2: raised by another thread that many microseconds into the solve
     int solver_iterations = -1;

@@ -179,6 +179,16 @@ def test_adaptor_stop_flag_and_no_fixed_keyframe(harness, oracle):
     assert out["rc"] == 0 and out["counts"][0] == 0 and out["counts"][3] == 0
 
 
+def test_adaptor_refuses_second_camera_observations(harness, oracle):
+    """A key-frame of a two-camera rig (mpCamera2 != nullptr) whose RIGHT image observed a map point would need
+    EdgeSE3ProjectXYZToBody (src/Optimizer.cc:1906-1949): not implemented -- the adaptor must refuse the window loudly (an exception,
+    -1 from the harness) before anything is optimised or written back, not drop the observation."""
+    w = _window32(6, n_free=3, n_fixed=2, n_points=60)
+    out = _run(harness, w, os.path.join(ROOT, "oracle", "libgfs_oracle.so"), init_kf_pose=-2)
+    assert out["rc"] == -1
+    assert not out["points"].any() and not out["pose_t"].any()  # the outputs were never filled
+
+
 @pytest.mark.gpu
 def test_adaptor_end_to_end_on_gpu(harness, gpu_api, oracle):
     w = _window32(7, n_free=6, n_fixed=3, n_points=500)
