@@ -324,7 +324,7 @@ def main():
         s0_, s1_ = shard_range(args.batch, rank, world)
         nb_ = s1_ - s0_  # this rank's block of the global batch (it takes the block from its own scene set: the blocks are independent)
         if nb_ > 0:
-            nl_s = max(1, min(args.lanes, nb_))
+            nl_s = max(1, min(args.lanes, nb_ // 32))  # >= 32 pairs per lane: c4_shard measured 2 lanes of 32 ahead of 4 of 16
             lanes_s = [Lane(*shard_range(nb_, l, nl_s)) for l in range(nl_s)]
             run_steps(max(2, args.prime // 2), lanes_s)
             barrier()
