@@ -5,9 +5,11 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker / timed CPU baseline.
  * Nothing under geoflowslam_amd/ may include, link or call anything declared here.
  *
- * PARITY UNPINNED: the reference (HorizonRobotics/GeoFlowSlam) ships no tests, golden vectors or
- * fixtures for this path and cannot be compiled here (OpenCV / Eigen / PCL are
- * absent), so this restatement is pinned only by (a) the reference sources it cites line by line,
+ * PARITY UNPINNED, with one exception: the reference (HorizonRobotics/GeoFlowSlam) ships no tests, golden vectors or
+ * fixtures for this path and cannot be compiled here (OpenCV / Eigen / PCL are absent) -- except
+ * small_gicp's util/sort_omp.hpp (quick_sort_omp, the voxel sort) and ann/knn_result.hpp (KnnResult), which build from their own
+ * sources: oracle/ref_build.sh compiles them from /root/reference into oracle/_ref/, and tests/test_oracle_ref.py pins the
+ * restatement of those two pieces against them.  Everything else of this restatement is pinned only by (a) the reference sources it cites line by line,
  * (b) hand-derived known-answer tests (tests/test_oracle_*.py) and (c) the documented semantics of
  * the third-party primitives it restates:
  *     OpenCV 4.5.4 (Ubuntu 22.04 libopencv-dev; reference says ">=3.0", CMakeLists.txt:65)

@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE — NOT PRODUCT CODE (see gfs_oracle.h header). PARITY UNPINNED.
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE (see gfs_oracle.h header). PARITY UNPINNED, except quick_sort_impl and KnnResult below:
+// pinned against the reference's own util/sort_omp.hpp and ann/knn_result.hpp compiled into oracle/_ref (tests/test_oracle_ref.py).
 //
 // CPU restatement of RegistrationGICP::RegisterPointClouds (reference src/RegistrationGICP.cc:5-20) and of the
 // small_gicp code it reaches (Thirdparty/small_gicp/include/small_gicp/..., cited per function), all in double,

@@ -1,7 +1,8 @@
 """ctypes binding of the CPU oracle (oracle/libgfs_oracle.so).
 
 TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg may import this module (see oracle/gfs_oracle.h).  PARITY UNPINNED.
+cpu_baseline leg may import this module (see oracle/gfs_oracle.h).  PARITY UNPINNED, except the voxel sort and the k-NN result
+container, which tests/test_oracle_ref.py pins against the reference's own headers compiled into oracle/_ref (ref_lib()).
 """
 import ctypes as C
 import os
