@@ -48,7 +48,7 @@ class GfsORBextractor : public ORB_SLAM3::ORBextractor {  // keeps the getters a
     int n = 0;
     const int mono = gfs_orb_extract(h_, image.data, image.rows, image.cols, (int)(size_t)image.step, vLappingArea[0], vLappingArea[1],
                                      reinterpret_cast<gfs_keypoint*>(_keypoints.data()), desc.data, cap_, &n);
-    if (mono < -1) throw std::runtime_error(gfs_last_error());
+    if (GFS_ORB_EXTRACT_FAILED(mono)) throw std::runtime_error(gfs_last_error());
     _keypoints.resize((size_t)n);
     if (n == 0)
       _descriptors.release();

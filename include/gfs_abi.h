@@ -85,7 +85,10 @@ int gfs_orb_max_keypoints(const gfs_orb* h);
  * bytes per row) -> kps[cap], desc[cap*32], *n = number of keypoints.
  * RETURNS monoIndex (>= 0; == *n on the RGB-D path where lapping = {0,0}), -1 for an empty image
  * (src/ORBextractor.cc:1150), or a gfs_status < -1 ... NOTE: to keep -1 unambiguous, errors are
- * reported as (GFS_ERR_* - 100). */
+ * reported as (GFS_ERR_* - 100).  Do NOT test the return value with `< 0` (-1 is the reference's own answer for an empty image): use
+ * the two macros below. */
+#define GFS_ORB_EXTRACT_FAILED(rc) ((rc) < -1)                            /* an error of the library, not the reference's -1 */
+#define GFS_ORB_EXTRACT_STATUS(rc) ((rc) < -1 ? (rc) + 100 : GFS_OK)      /* the gfs_status behind a failed call */
 int gfs_orb_extract(gfs_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
                     gfs_keypoint* kps, uint8_t* desc, int cap, int* n);
 
