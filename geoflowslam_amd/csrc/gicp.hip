@@ -2102,6 +2102,7 @@ struct gfs_gicp {
   bool lm_rounds = true;
   bool tile_stats_on = false;  // GFS_GICP_TILE_STATS=1
   gfs::DevBuf<unsigned> d_tile_stats;  // [8] outcome counters of k_gicp_linearize's tile staging (gfs_gicp_tile_stats)
+  bool vqs_lds = true;  // GFS_GICP_VQS_LDS=0: without k_voxel_qsort_top_lds
   bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
   gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
@@ -2119,26 +2120,36 @@ struct gfs_gicp {
   gfs::DevBuf<int> d_zero;  // [Bmax] zeros: the point counts of the slot that is not re-read in a streaming call
 };
 
-// The n >= 1024 levels of the voxel sort: the register-cached kernel for clouds whose keys compact to 31 bits (it flags the
-// others), then the general kernel for the flagged ones.
+// The n >= 1024 levels of the voxel sort: the LDS-resident kernel for clouds of at most kVqsLdsE * 1024 points whose keys compact to
+// 31 bits, the register-cached kernel for larger ones of that key width, the general kernel for the rest (each flags what it leaves).
+constexpr int kVqsLdsE = 19;
 static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only) {
   const int P = h->P;
-  int flagged_only = 1;
+  int flagged_only = 0;
+  if (h->vqs_lds) {
+    const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top_lds", s) : -1;
+    hipLaunchKernelGGL(vqs::k_voxel_qsort_top_lds<kVqsLdsE>, dim3(C2), dim3(1024), kVqsLdsE * 1024 * 8, s, h->d_keys0.p, h->d_val0.p,
+                       h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only);
+    if (_pid >= 0) ::gfs::profile_end(_pid, s);
+    flagged_only = 1;
+  }
 #define VQS_TOP_REG(E)                                                                                                         \
   do {                                                                                                                         \
     const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top_reg", s) : -1;                              \
     hipLaunchKernelGGL(vqs::k_voxel_qsort_top_reg<E>, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_val0.p, h->d_keys1.p,     \
-                       h->d_val1.p, h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only);           \
+                       h->d_val1.p, h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only,            \
+                       flagged_only);                                                                                          \
     if (_pid >= 0) ::gfs::profile_end(_pid, s);                                                                                \
   } while (0)
-  if (P <= 1024 * 20)
-    VQS_TOP_REG(20);
-  else if (P <= 1024 * 40)
+  if (P <= 1024 * 20) {
+    if (!(h->vqs_lds && P <= 1024 * kVqsLdsE)) VQS_TOP_REG(20);  // (no cloud can be left over when P fits the LDS kernel ...
+    flagged_only = 1;
+  } else if (P <= 1024 * 40) {
     VQS_TOP_REG(40);
-  else
-    flagged_only = 0;
+    flagged_only = 1;
+  }
 #undef VQS_TOP_REG
-  {
+  {  // ... except for key width: the general kernel always looks)
     const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top", s) : -1;
     hipLaunchKernelGGL(vqs::k_voxel_qsort_top, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_val0.p, h->d_keys1.p, h->d_val1.p,
                        h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only, flagged_only);
@@ -2188,6 +2199,9 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   h->nblk = gfs::div_up(h->P, kLinBlock);
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   if (const char* e = getenv("GFS_GICP_VOXEL_ORDER")) h->stable_voxel_order = strcmp(e, "stable") == 0;
+  if (const char* e = getenv("GFS_GICP_VQS_LDS")) h->vqs_lds = atoi(e) != 0;
+  GFS_HIP(hipFuncSetAttribute((const void*)vqs::k_voxel_qsort_top_lds<kVqsLdsE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kVqsLdsE * 1024 * 8));
   if (const char* e = getenv("GFS_GICP_LM")) h->lm_rounds = strcmp(e, "persistent") != 0;
   if (const char* e = getenv("GFS_GICP_TILE_STATS")) h->tile_stats_on = atoi(e) != 0;
   const size_t P = h->P, B = max_batch, C2 = 2 * B;

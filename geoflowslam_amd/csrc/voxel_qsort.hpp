@@ -341,7 +341,7 @@ template <int EMAX>
 __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, unsigned* vals_all, u64* side_all, unsigned* kscr_all,
                                                               const int* __restrict__ counts, int P, int* __restrict__ which,
                                                               int* __restrict__ kinfo, unsigned* __restrict__ leaf_all,
-                                                              int* __restrict__ nleaf, int only) {
+                                                              int* __restrict__ nleaf, int only, int only_flagged) {
   constexpr u64 kInvalid = ~0ull;
   constexpr int kCB = 21, kCM = (1 << kCB) - 1;
   constexpr int kSeg = EMAX + 1, kEq = 32;
@@ -354,6 +354,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   __shared__ int s_mn[3], s_mx[3];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
   if (only >= 0 && (c & 1) != only) return;
+  if (only_flagged && kinfo[8 * c + 6] == 0) return;  // k_voxel_qsort_top_lds took this cloud
   const int n = __builtin_amdgcn_readfirstlane(counts[c]);
   u64* ka = keys_all + (size_t)c * P;
   unsigned* va = vals_all + (size_t)c * P;
@@ -651,6 +652,351 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
       const unsigned v = vc[i];
       ka[i] = k == 0xffffffffu ? kInvalid : (u64)k;
       if (cur) va[i] = v;
+    }
+  }
+  if (tid == 0) nleaf[c] = s_nleaf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_voxel_qsort_top_lds<EMAX>: k_voxel_qsort_top_reg with the cloud RESIDENT IN LDS for all levels (clouds of at most 1024 * EMAX
+// points whose keys compact to <= 31 bits; EMAX = 19 covers a VGA depth image sampled with stride 4): 4-byte keys, 2-byte point
+// indices (they are < n) and the 2-byte rendezvous array = 8 bytes an element = 152 KB of the 160.  The partition of a level works
+// IN PLACE: std::partition only swaps pairs -- the k-th misplaced element of the front part (from the left) with the k-th misplaced
+// element of the back part (from the right) -- so after the back elements have announced their positions, the thread that owns
+// the FRONT element of a pair exchanges the two; no element is touched by two threads, nothing has to be copied aside, and the
+// 2.4 GB per 1024 clouds that the global ping-pong buffers of k_voxel_qsort_top_reg move through HBM stay on the CU.
+// Clouds that do not qualify are flagged kinfo[8c + 6] = 2 for k_voxel_qsort_top_reg (which flags 1 for k_voxel_qsort_top).
+// ------------------------------------------------------------------------------------------------
+template <int EMAX>
+__global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, unsigned* vals_all,
+                                                              const int* __restrict__ counts, int P, int* __restrict__ which,
+                                                              int* __restrict__ kinfo, unsigned* __restrict__ leaf_all,
+                                                              int* __restrict__ nleaf, int only) {
+  constexpr u64 kInvalid = ~0ull;
+  constexpr int kCB = 21, kCM = (1 << kCB) - 1;
+  constexpr int kSeg = EMAX + 1, kEq = 32;
+  __shared__ int seg_b[kSeg], seg_e[kSeg], seg_base[kSeg + 1], seg_m1[kSeg], seg_m2[kSeg], eq_cnt[kSeg], eq_pos[kSeg][kEq];
+  __shared__ int seg_local[kSeg], seg_wave[kSeg];  // flagged count before a range's first element inside its wave's chunk; that wave
+  __shared__ unsigned seg_pv[kSeg];
+  __shared__ int seg_K[kSeg];  // pairs a range's partition exchanges
+  __shared__ int s_wave[16], s_wbase[17];
+  extern __shared__ __align__(16) unsigned char vq_lds[];
+  unsigned* s_key = reinterpret_cast<unsigned*>(vq_lds);                                  // [1024 * EMAX] compacted keys
+  unsigned short* s_val = reinterpret_cast<unsigned short*>(s_key + 1024 * EMAX);          // [1024 * EMAX] point indices (< n)
+  unsigned short* side_pos = s_val + 1024 * EMAX;  // rendezvous of a partition sweep: slot (rank from the front) -> position of the back element
+  __shared__ int s_nseg, s_nleaf, s_over;
+  __shared__ int s_mn[3], s_mx[3];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
+  if (only >= 0 && (c & 1) != only) return;
+  const int n = __builtin_amdgcn_readfirstlane(counts[c]);
+  u64* ka = keys_all + (size_t)c * P;
+  unsigned* va = vals_all + (size_t)c * P;
+  unsigned* leaf = leaf_all + (size_t)c * P;
+  if (tid < 3) {
+    s_mn[tid] = 0x7fffffff;
+    s_mx[tid] = -1;
+  }
+  __syncthreads();
+  {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+    for (int i = tid; i < n; i += 1024) {
+      const u64 k = ka[i];
+      if (k == kInvalid) continue;
+      const int f[3] = {(int)(k & kCM), (int)((k >> kCB) & kCM), (int)(k >> (2 * kCB))};
+      for (int a = 0; a < 3; a++) {
+        mn[a] = min(mn[a], f[a]);
+        mx[a] = max(mx[a], f[a]);
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      if (mx[a] >= 0) {
+        atomicMin(&s_mn[a], mn[a]);
+        atomicMax(&s_mx[a], mx[a]);
+      }
+    }
+  }
+  __syncthreads();
+  const bool any_valid = s_mx[0] >= 0;
+  const int mnx = any_valid ? s_mn[0] : 0, mny = any_valid ? s_mn[1] : 0, mnz = any_valid ? s_mn[2] : 0;
+  auto nbits = [](int range) {
+    int b = 1;
+    while ((1 << b) <= range) b++;
+    return b;
+  };
+  const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
+            bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
+  if (bx + by + bz > 31 || n > 1024 * EMAX) {  // uniform: left to the kernels that work through HBM
+    if (tid == 0) kinfo[8 * c + 6] = 2;
+    return;
+  }
+  for (int i = tid; i < n; i += 1024) {
+    const u64 k = ka[i];
+    unsigned kk = 0xffffffffu;
+    if (k != kInvalid) kk = (unsigned)((k & kCM) - mnx) | ((unsigned)(((k >> kCB) & kCM) - mny) << bx) | ((unsigned)((k >> (2 * kCB)) - mnz) << (bx + by));
+    s_key[i] = kk;
+    s_val[i] = (unsigned short)va[i];
+  }
+  if (tid == 0) {
+    int* ki = kinfo + 8 * c;
+    ki[0] = mnx;
+    ki[1] = mny;
+    ki[2] = mnz;
+    ki[3] = bx;
+    ki[4] = by;
+    ki[5] = bx + by + bz;
+    ki[6] = 0;
+    which[c] = 0;
+    s_nleaf = 0;
+    s_nseg = 0;
+    if (n >= kLeafThreshold) {
+      seg_b[0] = 0;
+      seg_e[0] = n;
+      s_nseg = 1;
+    } else if (n >= 2) {
+      leaf[0] = 0u;
+      leaf[1] = (unsigned)n;
+      s_nleaf = 1;
+    }
+  }
+  __syncthreads();
+  const int E = (n + 1023) / 1024;
+  const u64 ltm = lanemask_lt();
+  while (true) {
+    const int nseg = __builtin_amdgcn_readfirstlane(s_nseg);
+    if (nseg == 0) break;
+    if (tid < nseg) {
+      const int b = seg_b[tid], len = seg_e[tid] - b, off = len / 8;  // sort_omp.hpp:70-75
+      const unsigned* f = s_key + b;
+      auto m3 = [](unsigned x, unsigned y, unsigned z) { return x < y ? (y < z ? y : (x < z ? z : x)) : (x < z ? x : (y < z ? z : y)); };
+      const unsigned m1 = m3(f[0], f[off], f[off * 2]), m2 = m3(f[off * 3], f[off * 4], f[off * 5]),
+                     mm = m3(f[off * 6], f[off * 7], f[len - 1]);
+      seg_pv[tid] = m3(m1, m2, mm);
+      eq_cnt[tid] = 0;
+    }
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    struct SegP {
+      int b, e, first, base, m;
+      unsigned pv;
+    };
+    // std::partition only swaps pairs: the k-th misplaced element of the front part (from the left) with the k-th misplaced
+    // element of the back part (from the right).  (B) both announce their positions -- the back one in slot first + k, the
+    // front one in slot last - 1 - k -- and (C) the thread that owns slot first + k exchanges the two.  K = the number of pairs.
+    auto partition_sweep = [&](int mode) {
+      auto load_seg = [&](int sidx, bool with_counts) {
+        SegP q;
+        q.b = q.e = q.first = 0x7fffffff;
+        q.base = q.m = 0;
+        q.pv = 0;
+        if (sidx < nseg) {  // wave-uniform: kept in scalar registers
+          q.b = __builtin_amdgcn_readfirstlane(seg_b[sidx]);
+          q.e = __builtin_amdgcn_readfirstlane(seg_e[sidx]);
+          q.first = mode == 0 ? q.b : __builtin_amdgcn_readfirstlane(seg_m1[sidx]);
+          q.pv = (unsigned)__builtin_amdgcn_readfirstlane((int)seg_pv[sidx]);
+          if (with_counts) {
+            q.base = __builtin_amdgcn_readfirstlane(seg_base[sidx]);
+            q.m = __builtin_amdgcn_readfirstlane(seg_base[sidx + 1]) - q.base;
+          }
+        }
+        return q;
+      };
+#define VQS_ROW_BEGIN(with_counts)                                       \
+  const int row0 = (wave * E + r) * 64, i = row0 + lane;                 \
+  while (row0 >= A.e && sA < nseg) {                                     \
+    A = B;                                                               \
+    sA++;                                                                \
+    B = load_seg(sA + 1, with_counts);                                   \
+  }                                                                      \
+  const bool inB = i >= B.b, in = inB || (i >= A.b && i < A.e);          \
+  const unsigned pv = inB ? B.pv : A.pv;                                 \
+  const int first = inB ? B.first : A.first;                             \
+  const unsigned key_r = key_nx;                                         \
+  {                                                                      \
+    const int i_nx = i + 64;  /* next row of this wave, fetched while this one is processed */ \
+    key_nx = (r + 1 < E && i_nx < n) ? s_key[i_nx] : 0u;                 \
+  }                                                                      \
+  const bool flag = in && (mode == 0 ? key_r < pv : (i >= first && !(pv < key_r)));
+      {  // (A) flagged elements per wave, and before every range start inside its wave
+        int cnt = 0, sA = 0;
+        SegP A = load_seg(0, false), B = load_seg(1, false);
+        unsigned key_nx = (wave * E * 64 + lane) < n ? s_key[wave * E * 64 + lane] : 0u;
+#pragma unroll 1
+        for (int r = 0; r < E; r++) {
+          VQS_ROW_BEGIN(false)
+          const u64 bl = __ballot(flag);
+          if (in && i == (inB ? B.b : A.b)) {
+            const int sidx = inB ? sA + 1 : sA;
+            seg_local[sidx] = cnt + __popcll(bl & ltm);
+            seg_wave[sidx] = wave;
+          }
+          cnt += __popcll(bl);
+          __builtin_amdgcn_sched_barrier(0);  // rows one after the other: interleaving them only costs registers
+        }
+        if (lane == 0) s_wave[wave] = cnt;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 16; w++) {
+          s_wbase[w] = acc;
+          acc += s_wave[w];
+        }
+        s_wbase[16] = acc;
+      }
+      __syncthreads();
+      if (tid < nseg) {
+        seg_base[tid] = s_wbase[seg_wave[tid]] + seg_local[tid];
+        seg_K[tid] = 0;
+      }
+      if (tid == 0) seg_base[nseg] = s_wbase[16];
+      const int wave_base = __builtin_amdgcn_readfirstlane(s_wbase[wave]);
+      __syncthreads();
+      {  // (B) announce
+        int run = wave_base, sA = 0;
+        SegP A = load_seg(0, true), B = load_seg(1, true);
+        unsigned key_nx = (wave * E * 64 + lane) < n ? s_key[wave * E * 64 + lane] : 0u;
+#pragma unroll 1
+        for (int r = 0; r < E; r++) {
+          VQS_ROW_BEGIN(true)
+          const u64 bl = __ballot(flag);
+          const int pre = run + __popcll(bl & ltm);
+          run += __popcll(bl);
+          if (in) {
+            const int lr = i - first, last = inB ? B.e : A.e, sidx = inB ? sA + 1 : sA;
+            bool stays = true;
+            if (lr >= 0) {
+              const int m = inB ? B.m : A.m, rk = pre - (inB ? B.base : A.base);  // flagged elements of the range before this one
+              if (lr < m && !flag) {  // k-th misplaced element of the front part, from the left
+                side_pos[last - 1 - (lr - rk)] = (unsigned short)i;
+                stays = false;
+              } else if (lr >= m && flag) {  // k-th misplaced element of the back part, from the right
+                side_pos[first + (m - rk - 1)] = (unsigned short)i;
+              }
+              if (lr == m - 1) seg_K[sidx] = m - rk - (flag ? 1 : 0);  // the front part's elements that are not flagged
+            }
+            // after the first partition: where the keys equal to the pivot sit (all of them in [middle1, last) then)
+            if (mode == 0 && stays && key_r == pv) {
+              const int slot = atomicAdd(&eq_cnt[sidx], 1);
+              if (slot < kEq) eq_pos[sidx][slot] = i;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      {  // (C) exchange the pairs: slot first + k belongs to the thread of that position
+        int sA = 0;
+        SegP A = load_seg(0, false), B = load_seg(1, false);
+        int KA = sA < nseg ? __builtin_amdgcn_readfirstlane(seg_K[0]) : 0, KB = 1 < nseg ? __builtin_amdgcn_readfirstlane(seg_K[1]) : 0;
+#pragma unroll 1
+        for (int r = 0; r < E; r++) {
+          const int row0 = (wave * E + r) * 64, i = row0 + lane;
+          while (row0 >= A.e && sA < nseg) {
+            A = B;
+            KA = KB;
+            sA++;
+            B = load_seg(sA + 1, false);
+            KB = sA + 1 < nseg ? __builtin_amdgcn_readfirstlane(seg_K[sA + 1]) : 0;
+          }
+          const bool inB = i >= B.b;
+          const int first = inB ? B.first : A.first, last = inB ? B.e : A.e, k = i - first;
+          if (k >= 0 && k < (inB ? KB : KA) && i < last) {
+            const int jb = side_pos[i], jf = side_pos[last - 1 - k];
+            const unsigned kf = s_key[jf], kb = s_key[jb];
+            const unsigned short vf = s_val[jf], vb = s_val[jb];
+            s_key[jf] = kb;
+            s_val[jf] = vb;
+            s_key[jb] = kf;
+            s_val[jb] = vf;
+            if (mode == 0 && kf == (inB ? B.pv : A.pv)) {
+              const int sidx = inB ? sA + 1 : sA;
+              const int slot = atomicAdd(&eq_cnt[sidx], 1);
+              if (slot < kEq) eq_pos[sidx][slot] = jb;
+            }
+          }
+        }
+      }
+      __syncthreads();
+#undef VQS_ROW_BEGIN
+    };
+    partition_sweep(0);
+    if (tid < nseg) {  // second partition by replaying its few swaps
+      const int m = eq_cnt[tid], m1 = seg_b[tid] + (seg_base[tid + 1] - seg_base[tid]);
+      seg_m1[tid] = m1;
+      seg_m2[tid] = m1 + m;
+      if (m > kEq) {
+        s_over = 1;
+      } else {
+        int* q = eq_pos[tid];  // sorted in place (ascending positions)
+#pragma unroll 1
+        for (int a = 1; a < m; a++) {
+          const int v = q[a];
+          int bpos = a;
+          while (bpos > 0 && q[bpos - 1] > v) {
+            q[bpos] = q[bpos - 1];
+            bpos--;
+          }
+          q[bpos] = v;
+        }
+        // k-th position of [m1, m1 + m) not holding a pivot key (from the left) <-> k-th pivot key beyond (from the right)
+        int a = 0, t = m - 1;
+#pragma unroll 1
+        for (int j = m1; j < m1 + m; j++) {
+          if (a < m && q[a] == j) {
+            a++;
+            continue;
+          }
+          const int jt = q[t--];  // >= m1 + m by counting
+          const unsigned kj = s_key[j];
+          const unsigned short vj = s_val[j];
+          s_key[j] = s_key[jt];
+          s_val[j] = s_val[jt];
+          s_key[jt] = kj;
+          s_val[jt] = vj;
+        }
+      }
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(s_over)) {  // a voxel with more than kEq points: the general sweep
+      partition_sweep(1);
+      if (tid < nseg) seg_m2[tid] = seg_m1[tid] + (seg_base[tid + 1] - seg_base[tid]);
+      __syncthreads();
+    }
+    // children [first, middle1) and [middle2, last)
+    int child_b[2] = {0, 0}, child_e[2] = {0, 0}, nact = 0;
+    if (tid < nseg) {
+      child_b[0] = seg_b[tid];
+      child_e[0] = seg_m1[tid];
+      child_b[1] = seg_m2[tid];
+      child_e[1] = seg_e[tid];
+      for (int k = 0; k < 2; k++) nact += (child_e[k] - child_b[k] >= kLeafThreshold) ? 1 : 0;
+    }
+    int tot_act;
+    int pos = scan_1024(nact, s_wave, &tot_act);
+    __syncthreads();
+    if (tid < nseg) {
+      for (int k = 0; k < 2; k++) {
+        const int len = child_e[k] - child_b[k];
+        if (len >= kLeafThreshold) {
+          seg_b[pos] = child_b[k];
+          seg_e[pos] = child_e[k];
+          pos++;
+        } else if (len >= 2) {
+          const int slot = atomicAdd(&s_nleaf, 1);
+          leaf[2 * slot] = (unsigned)child_b[k];
+          leaf[2 * slot + 1] = (unsigned)child_e[k];
+        }
+      }
+    }
+    if (tid == 0) s_nseg = tot_act;
+    __syncthreads();
+  }
+  // the keys go back as 64-bit compacted keys (k_voxel_qsort_leaf, k_voxel_reduce)
+  {
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned k = s_key[i];
+      ka[i] = k == 0xffffffffu ? kInvalid : (u64)k;
+      va[i] = (unsigned)s_val[i];
     }
   }
   if (tid == 0) nleaf[c] = s_nleaf;
