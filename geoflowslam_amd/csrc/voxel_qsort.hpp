@@ -667,6 +667,15 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
 // 2.4 GB per 1024 clouds that the global ping-pong buffers of k_voxel_qsort_top_reg move through HBM stay on the CU.
 // Clouds that do not qualify are flagged kinfo[8c + 6] = 2 for k_voxel_qsort_top_reg (which flags 1 for k_voxel_qsort_top).
 // ------------------------------------------------------------------------------------------------
+#ifdef GFS_VQS_TIMING
+#define VQS_T_INIT long long vt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, vt_last = clock64(); int vt_lv = 0;
+#define VQS_T(k) { if (k == 1) vt_lv++; const long long _n = clock64(); vt_acc[k] += _n - vt_last; vt_last = _n; }
+#define VQS_T_END if (threadIdx.x == 0 && blockIdx.x < 4) printf("VQST c=%d n=%d lv=%d load=%lld pivot=%lld A=%lld scan=%lld B=%lld C=%lld replay=%lld child=%lld store=%lld Aset=%lld Aloop=%lld Bset=%lld Bloop=%lld\n", (int)blockIdx.x, n, vt_lv, vt_acc[0], vt_acc[1], vt_acc[2], vt_acc[3], vt_acc[4], vt_acc[5], vt_acc[6], vt_acc[7], vt_acc[8], vt_acc[9], vt_acc[10], vt_acc[11], vt_acc[12]);
+#else
+#define VQS_T_INIT
+#define VQS_T(k)
+#define VQS_T_END
+#endif
 template <int EMAX>
 __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, unsigned* vals_all,
                                                               const int* __restrict__ counts, int P, int* __restrict__ which,
@@ -681,6 +690,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
   __shared__ int seg_K[kSeg];  // pairs a range's partition exchanges
   __shared__ int s_wave[16], s_wbase[17];
   extern __shared__ __align__(16) unsigned char vq_lds[];
+  VQS_T_INIT
   unsigned* s_key = reinterpret_cast<unsigned*>(vq_lds);                                  // [1024 * EMAX] compacted keys
   unsigned short* s_val = reinterpret_cast<unsigned short*>(s_key + 1024 * EMAX);          // [1024 * EMAX] point indices (< n)
   unsigned short* side_pos = s_val + 1024 * EMAX;  // rendezvous of a partition sweep: slot (rank from the front) -> position of the back element
@@ -697,10 +707,14 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
     s_mx[tid] = -1;
   }
   __syncthreads();
+  u64 kreg[EMAX];  // the thread's keys: all loads in flight at once (one workgroup a CU: nothing else hides their latency)
+#pragma unroll
+  for (int r = 0; r < EMAX; r++) kreg[r] = r * 1024 + tid < n ? ka[r * 1024 + tid] : kInvalid;
   {
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
-    for (int i = tid; i < n; i += 1024) {
-      const u64 k = ka[i];
+#pragma unroll
+    for (int r = 0; r < EMAX; r++) {
+      const u64 k = kreg[r];
       if (k == kInvalid) continue;
       const int f[3] = {(int)(k & kCM), (int)((k >> kCB) & kCM), (int)(k >> (2 * kCB))};
       for (int a = 0; a < 3; a++) {
@@ -708,8 +722,12 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
         mx[a] = max(mx[a], f[a]);
       }
     }
-    for (int a = 0; a < 3; a++) {
-      if (mx[a] >= 0) {
+    for (int a = 0; a < 3; a++) {  // one LDS atomic a wave, not one a thread
+      for (int o = 32; o >= 1; o >>= 1) {
+        mn[a] = min(mn[a], __shfl_xor(mn[a], o));
+        mx[a] = max(mx[a], __shfl_xor(mx[a], o));
+      }
+      if (lane == 0 && mx[a] >= 0) {
         atomicMin(&s_mn[a], mn[a]);
         atomicMax(&s_mx[a], mx[a]);
       }
@@ -729,12 +747,16 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
     if (tid == 0) kinfo[8 * c + 6] = 2;
     return;
   }
-  for (int i = tid; i < n; i += 1024) {
-    const u64 k = ka[i];
+#pragma unroll
+  for (int r = 0; r < EMAX; r++) {
+    const int i = r * 1024 + tid;
+    const u64 k = kreg[r];
     unsigned kk = 0xffffffffu;
     if (k != kInvalid) kk = (unsigned)((k & kCM) - mnx) | ((unsigned)(((k >> kCB) & kCM) - mny) << bx) | ((unsigned)((k >> (2 * kCB)) - mnz) << (bx + by));
-    s_key[i] = kk;
-    s_val[i] = (unsigned short)va[i];
+    if (i < n) {
+      s_key[i] = kk;
+      s_val[i] = (unsigned short)i;  // the point indices enter as the identity (k_voxel_keys, gfs_test_voxel_sort)
+    }
   }
   if (tid == 0) {
     int* ki = kinfo + 8 * c;
@@ -758,8 +780,8 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
       s_nleaf = 1;
     }
   }
-  __syncthreads();
-  const int E = (n + 1023) / 1024;
+  __syncthreads();  VQS_T(0)
+  const int E4 = (n + 4095) / 4096, chunk = E4 * 256;  // rows of 256 elements a wave; its part of the array
   const u64 ltm = lanemask_lt();
   while (true) {
     const int nseg = __builtin_amdgcn_readfirstlane(s_nseg);
@@ -774,14 +796,16 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
       eq_cnt[tid] = 0;
     }
     if (tid == 0) s_over = 0;
-    __syncthreads();
+    __syncthreads();  VQS_T(1)
     struct SegP {
       int b, e, first, base, m;
       unsigned pv;
     };
     // std::partition only swaps pairs: the k-th misplaced element of the front part (from the left) with the k-th misplaced
-    // element of the back part (from the right).  (B) both announce their positions -- the back one in slot first + k, the
-    // front one in slot last - 1 - k -- and (C) the thread that owns slot first + k exchanges the two.  K = the number of pairs.
+    // element of the back part (from the right).  (A) counts, (B) both announce their positions -- the back one in slot
+    // first + k, the front one in slot last - 1 - k -- and (C) exchanges the pairs, K of them a range.
+    // (A) and (B) walk the array in rows of 256 elements (four consecutive ones a lane, one 16-byte LDS read): wave w owns
+    // [w * chunk, (w + 1) * chunk).  A row lies inside one range almost always; then everything about the range is scalar.
     auto partition_sweep = [&](int mode) {
       auto load_seg = [&](int sidx, bool with_counts) {
         SegP q;
@@ -800,41 +824,63 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
         }
         return q;
       };
-#define VQS_ROW_BEGIN(with_counts)                                       \
-  const int row0 = (wave * E + r) * 64, i = row0 + lane;                 \
-  while (row0 >= A.e && sA < nseg) {                                     \
-    A = B;                                                               \
-    sA++;                                                                \
-    B = load_seg(sA + 1, with_counts);                                   \
-  }                                                                      \
-  const bool inB = i >= B.b, in = inB || (i >= A.b && i < A.e);          \
-  const unsigned pv = inB ? B.pv : A.pv;                                 \
-  const int first = inB ? B.first : A.first;                             \
-  const unsigned key_r = key_nx;                                         \
-  {                                                                      \
-    const int i_nx = i + 64;  /* next row of this wave, fetched while this one is processed */ \
-    key_nx = (r + 1 < E && i_nx < n) ? s_key[i_nx] : 0u;                 \
-  }                                                                      \
-  const bool flag = in && (mode == 0 ? key_r < pv : (i >= first && !(pv < key_r)));
+#define VQS_ROW_BEGIN(with_counts)                                                   \
+  const int row0 = wave * chunk + r * 256;                                           \
+  if (row0 >= n) break;                                                              \
+  while (row0 >= A.e && sA < nseg) {                                                 \
+    A = B;                                                                           \
+    sA++;                                                                            \
+    B = load_seg(sA + 1, with_counts);                                               \
+  }                                                                                  \
+  const uint4 k4 = k4_nx;                                                            \
+  if (r + 1 < E4) k4_nx = *reinterpret_cast<const uint4*>(s_key + row0 + 256 + 4 * lane); /* fetched while this row is processed */ \
+  const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};                                   \
+  const bool whole = mode == 0 && row0 >= A.b && row0 + 256 <= A.e;  /* scalar */
       {  // (A) flagged elements per wave, and before every range start inside its wave
         int cnt = 0, sA = 0;
+        uint4 k4_nx = *reinterpret_cast<const uint4*>(s_key + wave * chunk + 4 * lane);
         SegP A = load_seg(0, false), B = load_seg(1, false);
-        unsigned key_nx = (wave * E * 64 + lane) < n ? s_key[wave * E * 64 + lane] : 0u;
+        VQS_T(9)
 #pragma unroll 1
-        for (int r = 0; r < E; r++) {
+        for (int r = 0; r < E4; r++) {
           VQS_ROW_BEGIN(false)
-          const u64 bl = __ballot(flag);
-          if (in && i == (inB ? B.b : A.b)) {
-            const int sidx = inB ? sA + 1 : sA;
-            seg_local[sidx] = cnt + __popcll(bl & ltm);
-            seg_wave[sidx] = wave;
+          u64 mk[4];
+          if (whole) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) mk[j] = __ballot(kk[j] < A.pv);
+            if (row0 == A.b && lane == 0) {
+              seg_local[sA] = cnt;
+              seg_wave[sA] = wave;
+            }
+          } else {
+            bool f[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int i = row0 + 4 * lane + j;
+              const bool inB = i >= B.b, in = inB || (i >= A.b && i < A.e);
+              const unsigned pv = inB ? B.pv : A.pv;
+              const int first = inB ? B.first : A.first;
+              f[j] = in && (mode == 0 ? kk[j] < pv : (i >= first && !(pv < kk[j])));
+              mk[j] = __ballot(f[j]);
+            }
+            int before = cnt + __popcll(mk[0] & ltm) + __popcll(mk[1] & ltm) + __popcll(mk[2] & ltm) + __popcll(mk[3] & ltm);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int i = row0 + 4 * lane + j;
+              if (i == A.b || i == B.b) {
+                const int sidx = i == B.b ? sA + 1 : sA;
+                seg_local[sidx] = before;
+                seg_wave[sidx] = wave;
+              }
+              before += f[j] ? 1 : 0;
+            }
           }
-          cnt += __popcll(bl);
-          __builtin_amdgcn_sched_barrier(0);  // rows one after the other: interleaving them only costs registers
+          cnt += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
         }
         if (lane == 0) s_wave[wave] = cnt;
+        VQS_T(10)
       }
-      __syncthreads();
+      __syncthreads();  VQS_T(2)
       if (tid == 0) {
         int acc = 0;
         for (int w = 0; w < 16; w++) {
@@ -850,73 +896,106 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
       }
       if (tid == 0) seg_base[nseg] = s_wbase[16];
       const int wave_base = __builtin_amdgcn_readfirstlane(s_wbase[wave]);
-      __syncthreads();
+      __syncthreads();  VQS_T(3)
       {  // (B) announce
         int run = wave_base, sA = 0;
+        uint4 k4_nx = *reinterpret_cast<const uint4*>(s_key + wave * chunk + 4 * lane);
         SegP A = load_seg(0, true), B = load_seg(1, true);
-        unsigned key_nx = (wave * E * 64 + lane) < n ? s_key[wave * E * 64 + lane] : 0u;
-#pragma unroll 1
-        for (int r = 0; r < E; r++) {
-          VQS_ROW_BEGIN(true)
-          const u64 bl = __ballot(flag);
-          const int pre = run + __popcll(bl & ltm);
-          run += __popcll(bl);
-          if (in) {
-            const int lr = i - first, last = inB ? B.e : A.e, sidx = inB ? sA + 1 : sA;
-            bool stays = true;
-            if (lr >= 0) {
-              const int m = inB ? B.m : A.m, rk = pre - (inB ? B.base : A.base);  // flagged elements of the range before this one
-              if (lr < m && !flag) {  // k-th misplaced element of the front part, from the left
-                side_pos[last - 1 - (lr - rk)] = (unsigned short)i;
-                stays = false;
-              } else if (lr >= m && flag) {  // k-th misplaced element of the back part, from the right
-                side_pos[first + (m - rk - 1)] = (unsigned short)i;
+        auto row_body = [&](auto whole_c, int row0, const unsigned* kk) {
+          constexpr bool kWhole = decltype(whole_c)::value;
+          bool f[4], in[4], inB[4];
+          u64 mk[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int i = row0 + 4 * lane + j;
+            inB[j] = kWhole ? false : i >= B.b;
+            in[j] = kWhole ? true : (inB[j] || (i >= A.b && i < A.e));
+            const unsigned pv = inB[j] ? B.pv : A.pv;
+            const int first = inB[j] ? B.first : A.first;
+            f[j] = in[j] && (mode == 0 ? kk[j] < pv : (i >= first && !(pv < kk[j])));
+            mk[j] = __ballot(f[j]);
+          }
+          int pre = run + __popcll(mk[0] & ltm) + __popcll(mk[1] & ltm) + __popcll(mk[2] & ltm) + __popcll(mk[3] & ltm);
+          bool eq[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int i = row0 + 4 * lane + j;
+            const int first = inB[j] ? B.first : A.first, last = inB[j] ? B.e : A.e;
+            const int m = inB[j] ? B.m : A.m, rk = pre - (inB[j] ? B.base : A.base);  // flagged elements of the range before this one
+            const int lr = i - first;
+            // the k-th misplaced element of the front part (from the left: not flagged, k = lr - rk) announces itself in slot
+            // last - 1 - k, the k-th misplaced element of the back part (from the right: flagged, k = m - rk - 1) in slot first + k
+            const bool moves = in[j] && lr >= 0 && (f[j] ? lr >= m : lr < m);
+            const int slot = f[j] ? first + (m - rk - 1) : last - 1 - (lr - rk);
+            if (moves) side_pos[slot] = (unsigned short)i;
+            // after the first partition: where the keys equal to the pivot sit (all of them in [middle1, last) then); the ones
+            // that move are recorded by (C)
+            eq[j] = mode == 0 && in[j] && !f[j] && lr >= m && kk[j] == (inB[j] ? B.pv : A.pv);
+            pre += f[j] ? 1 : 0;
+          }
+          if (__ballot(eq[0] || eq[1] || eq[2] || eq[3])) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (eq[j]) {
+                const int sidx = inB[j] ? sA + 1 : sA;
+                const int slot = atomicAdd(&eq_cnt[sidx], 1);
+                if (slot < kEq) eq_pos[sidx][slot] = row0 + 4 * lane + j;
               }
-              if (lr == m - 1) seg_K[sidx] = m - rk - (flag ? 1 : 0);  // the front part's elements that are not flagged
-            }
-            // after the first partition: where the keys equal to the pivot sit (all of them in [middle1, last) then)
-            if (mode == 0 && stays && key_r == pv) {
-              const int slot = atomicAdd(&eq_cnt[sidx], 1);
-              if (slot < kEq) eq_pos[sidx][slot] = i;
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      __syncthreads();
-      {  // (C) exchange the pairs: slot first + k belongs to the thread of that position
-        int sA = 0;
-        SegP A = load_seg(0, false), B = load_seg(1, false);
-        int KA = sA < nseg ? __builtin_amdgcn_readfirstlane(seg_K[0]) : 0, KB = 1 < nseg ? __builtin_amdgcn_readfirstlane(seg_K[1]) : 0;
+          {  // K = the front part's elements that are not flagged: known to the thread of the front part's last element
+            const int xa = A.first + A.m - 1, xb = B.first + B.m - 1;  // scalar
+            if ((A.m > 0 && xa >= row0 && xa < row0 + 256) || (!kWhole && B.m > 0 && xb >= row0 && xb < row0 + 256)) {
+              int pre2 = run + __popcll(mk[0] & ltm) + __popcll(mk[1] & ltm) + __popcll(mk[2] & ltm) + __popcll(mk[3] & ltm);
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const int i = row0 + 4 * lane + j;
+                if (in[j]) {
+                  const int first = inB[j] ? B.first : A.first, m = inB[j] ? B.m : A.m, rk = pre2 - (inB[j] ? B.base : A.base);
+                  if (i - first == m - 1) seg_K[inB[j] ? sA + 1 : sA] = m - rk - (f[j] ? 1 : 0);
+                }
+                pre2 += f[j] ? 1 : 0;
+              }
+            }
+          }
+          run += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
+        };
+        VQS_T(11)
 #pragma unroll 1
-        for (int r = 0; r < E; r++) {
-          const int row0 = (wave * E + r) * 64, i = row0 + lane;
-          while (row0 >= A.e && sA < nseg) {
-            A = B;
-            KA = KB;
-            sA++;
-            B = load_seg(sA + 1, false);
-            KB = sA + 1 < nseg ? __builtin_amdgcn_readfirstlane(seg_K[sA + 1]) : 0;
+        for (int r = 0; r < E4; r++) {
+          VQS_ROW_BEGIN(true)
+          if (whole)
+            row_body(std::true_type{}, row0, kk);
+          else
+            row_body(std::false_type{}, row0, kk);
+        }
+        VQS_T(12)
+      }
+      __syncthreads();  VQS_T(4)
+      {  // (C) exchange the pairs, all ranges' pairs numbered through: thread t takes pairs t, t + 1024, ...
+        int sg = 0, off = 0, Ks = nseg > 0 ? seg_K[0] : 0;
+        for (int t = tid;; t += 1024) {
+          while (sg < nseg && t >= off + Ks) {
+            off += Ks;
+            sg++;
+            Ks = sg < nseg ? seg_K[sg] : 0;
           }
-          const bool inB = i >= B.b;
-          const int first = inB ? B.first : A.first, last = inB ? B.e : A.e, k = i - first;
-          if (k >= 0 && k < (inB ? KB : KA) && i < last) {
-            const int jb = side_pos[i], jf = side_pos[last - 1 - k];
-            const unsigned kf = s_key[jf], kb = s_key[jb];
-            const unsigned short vf = s_val[jf], vb = s_val[jb];
-            s_key[jf] = kb;
-            s_val[jf] = vb;
-            s_key[jb] = kf;
-            s_val[jb] = vf;
-            if (mode == 0 && kf == (inB ? B.pv : A.pv)) {
-              const int sidx = inB ? sA + 1 : sA;
-              const int slot = atomicAdd(&eq_cnt[sidx], 1);
-              if (slot < kEq) eq_pos[sidx][slot] = jb;
-            }
+          if (sg >= nseg) break;
+          const int k = t - off, first = mode == 0 ? seg_b[sg] : seg_m1[sg], last = seg_e[sg];
+          const int jb = side_pos[first + k], jf = side_pos[last - 1 - k];
+          const unsigned kf = s_key[jf], kb = s_key[jb];
+          const unsigned short vf = s_val[jf], vb = s_val[jb];
+          s_key[jf] = kb;
+          s_val[jf] = vb;
+          s_key[jb] = kf;
+          s_val[jb] = vf;
+          if (mode == 0 && kf == seg_pv[sg]) {
+            const int slot = atomicAdd(&eq_cnt[sg], 1);
+            if (slot < kEq) eq_pos[sg][slot] = jb;
           }
         }
       }
-      __syncthreads();
+      __syncthreads();  VQS_T(5)
 #undef VQS_ROW_BEGIN
     };
     partition_sweep(0);
@@ -956,7 +1035,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
         }
       }
     }
-    __syncthreads();
+    __syncthreads();  VQS_T(6)
     if (__builtin_amdgcn_readfirstlane(s_over)) {  // a voxel with more than kEq points: the general sweep
       partition_sweep(1);
       if (tid < nseg) seg_m2[tid] = seg_m1[tid] + (seg_base[tid + 1] - seg_base[tid]);
@@ -989,7 +1068,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
       }
     }
     if (tid == 0) s_nseg = tot_act;
-    __syncthreads();
+    __syncthreads();  VQS_T(7)
   }
   // the keys go back as 64-bit compacted keys (k_voxel_qsort_leaf, k_voxel_reduce)
   {
@@ -999,6 +1078,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
       va[i] = (unsigned)s_val[i];
     }
   }
+  VQS_T(8) VQS_T_END
   if (tid == 0) nleaf[c] = s_nleaf;
 }
 
