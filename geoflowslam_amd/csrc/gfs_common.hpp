@@ -98,6 +98,19 @@ void profile_end(int id, hipStream_t s);
   } while (0)
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+#if defined(__HIPCC__)
+// min / max over the 64 lanes of a wave (all lanes must be active); every lane gets the result.  Used in front of LDS atomics that a
+// whole workgroup would otherwise aim at one address (they serialise: ~35 cycles each).
+__device__ __forceinline__ int wave_min_i32(int v) {
+  for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+#endif
+
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 }  // namespace gfs

@@ -144,8 +144,10 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
         mx[a] = max(mx[a], f[a]);
       }
     }
-    for (int a = 0; a < 3; a++) {
-      if (mx[a] >= 0) {
+    for (int a = 0; a < 3; a++) {  // one LDS atomic a wave
+      mn[a] = gfs::wave_min_i32(mn[a]);
+      mx[a] = gfs::wave_max_i32(mx[a]);
+      if ((tid & 63) == 0 && mx[a] >= 0) {
         atomicMin(&s_mn[a], mn[a]);
         atomicMax(&s_mx[a], mx[a]);
       }
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
   for (int i = i0; i < i1; i++) cnt += new_cell(i) ? 1 : 0;
   int total;
   int pos = block_scan_1024(cnt, s_wave, &total);
-  if (cnt > 0) {
+  {
     int mn[3] = {kCoordMask, kCoordMask, kCoordMask}, mx[3] = {0, 0, 0};
     for (int i = i0; i < i1; i++) {
       if (new_cell(i)) {
@@ -423,9 +425,13 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
         mx[2] = max(mx[2], kz);
       }
     }
-    for (int a = 0; a < 3; a++) {
-      atomicMin(&s_bb[a], mn[a]);
-      atomicMax(&s_bb[3 + a], mx[a]);
+    for (int a = 0; a < 3; a++) {  // one LDS atomic a wave (threads without a cell hold the neutral values)
+      mn[a] = gfs::wave_min_i32(mn[a]);
+      mx[a] = gfs::wave_max_i32(mx[a]);
+      if ((tid & 63) == 0) {
+        atomicMin(&s_bb[a], mn[a]);
+        atomicMax(&s_bb[3 + a], mx[a]);
+      }
     }
   }
   __syncthreads();

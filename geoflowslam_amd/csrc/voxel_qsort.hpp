@@ -132,8 +132,10 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top(u64* keys_all, unsigne
         mx[a] = max(mx[a], f[a]);
       }
     }
-    for (int a = 0; a < 3; a++) {
-      if (mx[a] >= 0) {
+    for (int a = 0; a < 3; a++) {  // one LDS atomic a wave
+      mn[a] = gfs::wave_min_i32(mn[a]);
+      mx[a] = gfs::wave_max_i32(mx[a]);
+      if (lane == 0 && mx[a] >= 0) {
         atomicMin(&s_mn[a], mn[a]);
         atomicMax(&s_mx[a], mx[a]);
       }
@@ -381,8 +383,10 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
         mx[a] = max(mx[a], f[a]);
       }
     }
-    for (int a = 0; a < 3; a++) {
-      if (mx[a] >= 0) {
+    for (int a = 0; a < 3; a++) {  // one LDS atomic a wave
+      mn[a] = gfs::wave_min_i32(mn[a]);
+      mx[a] = gfs::wave_max_i32(mx[a]);
+      if (lane == 0 && mx[a] >= 0) {
         atomicMin(&s_mn[a], mn[a]);
         atomicMax(&s_mx[a], mx[a]);
       }
@@ -723,10 +727,8 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
       }
     }
     for (int a = 0; a < 3; a++) {  // one LDS atomic a wave, not one a thread
-      for (int o = 32; o >= 1; o >>= 1) {
-        mn[a] = min(mn[a], __shfl_xor(mn[a], o));
-        mx[a] = max(mx[a], __shfl_xor(mx[a], o));
-      }
+      mn[a] = gfs::wave_min_i32(mn[a]);
+      mx[a] = gfs::wave_max_i32(mx[a]);
       if (lane == 0 && mx[a] >= 0) {
         atomicMin(&s_mn[a], mn[a]);
         atomicMax(&s_mx[a], mx[a]);
