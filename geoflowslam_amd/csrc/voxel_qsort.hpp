@@ -1787,6 +1787,9 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_heap(u64* keys_all, unsigne
       }
       VQS_WAVE_SYNC();
     }
+#ifdef GFS_VQS_HEAP_STATS
+    if (lane == 0 && replay) printf("VQSH c=%d l=%d nh=%d b=%d n=%d replay=%d partial=%d keep=%d\n", c, l, nh, b, n, (int)replay, (int)partial, keep);
+#endif
     if (replay) {
       heap_sort_wave<KT>(K, Pm, 0, n, keep);
       if (keep > 1) {  // the `keep` smallest keys (all distinct) are still in heap order in [0, keep): each to its rank
