@@ -259,14 +259,29 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
     if (tid == 0) cell_cnt[(size_t)b * n_cells + cell_id] = 0;
     return;
   }
-  uint8_t* tile = smem;             // [h][w]
-  uint8_t* sc = smem + (size_t)w * h;  // [h][w] arc score - 1 (0 = not a corner at the low threshold)
-  unsigned short* clist = reinterpret_cast<unsigned short*>(smem + (((size_t)2 * w * h + 3) & ~(size_t)3));  // corner offsets
-  __shared__ int s_ncorner, s_nquick;
   int sp;
   const uint8_t* src = level_ptr(L, C.level, b, l0, pyr, pyr_frame, &sp);
   src += (size_t)C.y0 * sp + C.x0;
-  {
+  // The tile is staged with aligned 4-byte loads when every row of the cell starts at the same offset `al` inside its word
+  // (all pyramid planes: pitch and plane offsets are multiples of 64; a caller's level 0 whenever its pitch is a multiple of
+  // 4): row y of the cell then sits at tile0 + y * wp, wp = the row's words.  Otherwise byte by byte (wp = w).
+  const bool words = (sp & 3) == 0;
+  const int al = words ? (int)(reinterpret_cast<uintptr_t>(src) & 3) : 0;
+  const int wp = words ? (al + w + 3) & ~3 : w;
+  uint8_t* tile = smem;                    // [h][wp]
+  uint8_t* sc = smem + (size_t)wp * h;     // [h][wp] arc score - 1 (0 = not a corner at the low threshold)
+  unsigned short* clist = reinterpret_cast<unsigned short*>(smem + (size_t)2 * wp * h);  // corner offsets (wp * h is a multiple of 4 or ...
+  if (!words) clist = reinterpret_cast<unsigned short*>(smem + (((size_t)2 * w * h + 3) & ~(size_t)3));  // ... rounded up here)
+  __shared__ int s_ncorner, s_nquick;
+  if (words) {
+    const int wpr = wp >> 2, total = wpr * h;
+    const uint8_t* src_al = src - al;
+    for (int i = tid; i < total; i += kFastThreads) {
+      const int y = i / wpr, x = i - y * wpr;
+      reinterpret_cast<uint32_t*>(tile)[i] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)y * sp + 4 * x);
+      reinterpret_cast<uint32_t*>(sc)[i] = 0u;
+    }
+  } else {
     const int sy = kFastThreads / w, sx = kFastThreads - sy * w;  // raster step of one workgroup stride
     int x = tid % w;
     size_t g = (size_t)(tid / w) * sp + x;
@@ -281,6 +296,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
       }
     }
   }
+  tile += al;  // pixel (x, y) of the cell: tile[y * wp + x], and its score sc[y * wp + x]
+  sc += al;
   if (tid == 0) {
     s_count = 0;
     s_ncorner = 0;
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
   __syncthreads();
   const int th_hi = min(max(ini_th, 0), 255), th_lo = min(max(min_th, 0), 255);
   unsigned short* qlist = clist + (size_t)w * h;
-  unsigned short* klist = reinterpret_cast<unsigned short*>(tile);  // phase 3's output overwrites the tile (when there is any)
+  unsigned short* klist = reinterpret_cast<unsigned short*>(smem);  // phase 3's output overwrites the tile (when there is any)
   int nk = 0;
   // FAST with iniThFAST and, only if the cell produced nothing, again with minThFAST (src/ORBextractor.cc:815-827): at the low
   // threshold several times as many pixels are corners, and nearly every cell is settled by the first pass
@@ -308,14 +325,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
     // compacted, wave by wave, into a list ...
     {
       const int sy = kFastThreads / dw, sx = kFastThreads - sy * dw;  // raster step of one workgroup stride
-      int xx = tid % dw, o = (tid / dw + 3) * w + xx + 3;
+      int xx = tid % dw, o = (tid / dw + 3) * wp + xx + 3;
       const int total = dw * dh, lane = tid & 63;
       for (int base = 0; base < total; base += kFastThreads) {
         bool ok = false;
         if (base + tid < total) {
           const uint8_t* c = tile + o;
           const int v = c[0], lo = v - th, hi = v + th;
-          const int a = c[3 * w], b4 = c[3], e = c[-3 * w], f = c[-3];
+          const int a = c[3 * wp], b4 = c[3], e = c[-3 * wp], f = c[-3];
           const int nd = (a < lo) + (b4 < lo) + (e < lo) + (f < lo), nb = (a > hi) + (b4 > hi) + (e > hi) + (f > hi);
           ok = nd >= 2 || nb >= 2;
         }
@@ -327,10 +344,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
           if (ok) qlist[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)o;
         }
         xx += sx;
-        o += sy * w + sx;
+        o += sy * wp + sx;
         if (xx >= dw) {
           xx -= dw;
-          o += w - dw;
+          o += wp - dw;
         }
       }
     }
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
       const int nq = s_nquick;
       for (int k = tid; k < nq; k += kFastThreads) {
         const int o = qlist[k];
-        if (arc_is_corner(tile + o, w, th)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
+        if (arc_is_corner(tile + o, wp, th)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
       }
     }
     __syncthreads();
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
     const int ncorner = s_ncorner;
     for (int k = tid; k < ncorner; k += kFastThreads) {
       const int o = clist[k];
-      sc[o] = (uint8_t)(arc_score_full(tile + o, w) - 1);  // corner at th => S > th >= 0
+      sc[o] = (uint8_t)(arc_score_full(tile + o, wp) - 1);  // corner at th => S > th >= 0
     }
     __syncthreads();
     // phase 3: 3x3 non-maximum suppression (scores below the threshold count as 0 outside the corner set, and the cell
@@ -361,8 +378,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
       const int s = sc[o];
       if (s < T) continue;
 #define NB(off) ((int)sc[o + (off)] >= T ? (int)sc[o + (off)] : 0)
-      const bool keep = s > NB(-1) && s > NB(1) && s > NB(-w - 1) && s > NB(-w) && s > NB(-w + 1) && s > NB(w - 1) &&
-                        s > NB(w) && s > NB(w + 1);
+      const bool keep = s > NB(-1) && s > NB(1) && s > NB(-wp - 1) && s > NB(-wp) && s > NB(-wp + 1) && s > NB(wp - 1) &&
+                        s > NB(wp) && s > NB(wp + 1);
 #undef NB
       if (keep) klist[atomicAdd(&s_count, 1)] = (unsigned short)o;
     }
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
     const int o = klist[k];
     int r = 0;
     for (int j = 0; j < nk; j++) r += klist[j] < o ? 1 : 0;
-    const int y = o / w, x = o - y * w;
+    const int y = o / wp, x = o - y * wp;
     out[r] = (uint32_t)(x + offx) | ((uint32_t)(y + offy) << 12) | ((uint32_t)sc[o] << 24);
   }
   if (tid == 0) cell_cnt[(size_t)b * n_cells + cell_id] = nk;
@@ -1399,7 +1416,8 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                h->d_yt_alpha.p);
   }
   // 2. FAST cells of all levels, all frames in one launch
-  const size_t lds = 6 * (size_t)G.max_tile_w * G.max_tile_h + 8;  // tile + score map + corner list (u16) + compass-test list (u16)
+  // tile + score map (rows padded to whole words: k_fast_cells) + corner list (u16) + compass-test list (u16)
+  const size_t lds = 2 * (size_t)(G.max_tile_w + 6) * G.max_tile_h + 4 * (size_t)G.max_tile_w * G.max_tile_h + 8;
   GFS_LAUNCH("k_fast_cells", k_fast_cells, dim3(n_cells, B), dim3(kFastThreads), lds, s, h->d_levels.p, h->d_cells.p, l0,
              h->d_pyr.p, cap_pyr, h->P.ini_th, h->P.min_th, n_cells, cap_slab, h->d_slab.p, h->d_cell_cnt.p);
   const int* tp = kBlurTaps[h->P.blur_variant ? 1 : 0];
