@@ -550,7 +550,18 @@ __device__ __forceinline__ ONode oct_child(const ONode& nd, int q) {
   return c;
 }
 
-__global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restrict__ levels, int nlevels,
+#ifdef GFS_OCT_TIMING
+#define OCT_T_INIT long long ot_acc[6] = {0, 0, 0, 0, 0, 0}, ot_last = clock64(); int ot_cnt[2] = {0, 0};
+#define OCT_T(k) { const long long _n = clock64(); ot_acc[k] += _n - ot_last; ot_last = _n; }
+#define OCT_CNT(k) ot_cnt[k]++;
+#define OCT_T_END if (threadIdx.x == 0 && blockIdx.x < 16) printf("OCTT blk=%d n=%d nn=%d gather=%lld init=%lld sweeps=%lld(%d) sort=%lld(%d) loopB=%lld emit=%lld\n", (int)blockIdx.x, n, nn, ot_acc[0], ot_acc[1], ot_acc[2], ot_cnt[0], ot_acc[3], ot_cnt[1], ot_acc[4], ot_acc[5]);
+#else
+#define OCT_T_INIT
+#define OCT_T(k)
+#define OCT_CNT(k)
+#define OCT_T_END
+#endif
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_octree(const LevelDev* __restrict__ levels, int nlevels,
                                                         const uint32_t* __restrict__ cand, const int* __restrict__ cand_off,
                                                         size_t cand_frame, uint32_t* __restrict__ perm0,
                                                         uint32_t* __restrict__ perm1, unsigned short* __restrict__ seg0,
@@ -575,6 +586,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
   __shared__ unsigned long long s_w64[4];
   __shared__ int s_ctl[8];
   const int tid = threadIdx.x;
+  OCT_T_INIT
   const int l = blockIdx.x % nlevels, b = blockIdx.x / nlevels;
   const LevelDev L = levels[l];
   // cells != NULL: the level's candidates are taken straight from the per-cell slabs of k_fast_cells, in the order the reference
@@ -612,9 +624,16 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
       const int base = s_gbase + s_gscan[tid] - my;
       if (my > 0) {
         const uint32_t* sp = sl + cells[L.cell_base + ci].slab_off;
-        for (int i = 0; i < my; i++) {
-          perm[0][base + i] = sp[i];
-          seg[0][base + i] = 0;
+        for (int i0 = 0; i0 < my; i0 += 8) {  // eight loads in flight (a load behind every store would be a chain of round trips)
+          uint32_t t[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) t[u] = i0 + u < my ? sp[i0 + u] : 0u;
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (i0 + u < my) {
+              perm[0][base + i0 + u] = t[u];
+              seg[0][base + i0 + u] = 0;
+            }
         }
       }
       __syncthreads();
@@ -623,6 +642,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
     }
     n = s_gbase;
   }
+  OCT_T(0)
   const uint32_t* c = cells ? nullptr : cand + (size_t)b * cand_frame + region;
   if (n <= 0) {
     if (tid == 0) kept_cnt[(size_t)b * nlevels + l] = 0;
@@ -656,33 +676,92 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
 
   // One split sweep over the whole list.  init = true: the virtual root is cut into the nIni initial nodes
   // (push_back order, :586-604); otherwise every node with > 1 keys is divided (push_front order).
+  // walks keys[kb, ke) in order with eight loads in flight (f must not write what it is still to read)
+  auto for_keys = [&](const uint32_t* keys, int kb, int ke, auto&& f) {
+    for (int p = kb; p < ke; p += 8) {
+      uint32_t t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = p + u < ke ? keys[p + u] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (p + u < ke) f(p + u, t[u]);
+    }
+  };
+  // (kOctChunk keys a thread or fewer, i.e. n <= 4096: the thread's keys and node indices are loaded ONCE per sweep, all loads in
+  // flight together, and the three passes over them run from registers — a global round trip per key and pass made a sweep a
+  // chain of ~30 of them, ~2 us each)
+  constexpr int kOctChunk = 16;
+  const bool cached = chunk <= kOctChunk;
   auto sweep = [&](bool init) {
     const ONode* nodes = s_nodes[cur];
     ONode* nxt = s_nodes[cur ^ 1];
     const uint32_t* pa = perm[pc];
     const unsigned short* sa = seg[pc];
+    uint32_t kreg[kOctChunk];
+    int nreg[kOctChunk];
+    unsigned qbits = 0, abits = 0;  // per cached key: its quadrant (2 bits), and whether its node is being divided
+    if (cached) {  // (unconditional: one base address, immediate offsets; the arrays are padded by a chunk, what lies beyond p1 is not used)
+      const uint32_t* pa0 = pa + p0;
+      const unsigned short* sa0 = sa + p0;
+#pragma unroll
+      for (int j = 0; j < kOctChunk; j++) {
+        kreg[j] = pa0[j];
+        nreg[j] = (int)sa0[j];
+      }
+    }
     // 1. per-key quadrant counters, exclusive block scan
     U128 local{0, 0};
-    for (int p = p0; p < p1; p++) {
-      const ONode nd = nodes[sa[p]];
-      if (!init && nd.ke - nd.kb <= 1) continue;
-      const uint32_t key = pa[p];
-      const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
-      local = u128_add(local, u128_one(q));
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < kOctChunk; j++) {
+        if (p0 + j < p1) {
+          const ONode nd = nodes[nreg[j]];
+          if (init || nd.ke - nd.kb > 1) {
+            const int q = init ? min((int)((float)(kreg[j] & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, kreg[j]);
+            local = u128_add(local, u128_one(q));
+            qbits |= (unsigned)q << (2 * j);
+            abits |= 1u << j;
+          }
+        }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four keys' node reads in flight, not sixteen (registers)
+      }
+    } else {
+      for (int p = p0; p < p1; p++) {
+        const ONode nd = nodes[sa[p]];
+        if (!init && nd.ke - nd.kb <= 1) continue;
+        const uint32_t key = pa[p];
+        const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
+        local = u128_add(local, u128_one(q));
+      }
     }
     U128 total;
     const U128 base = oct_scan_u128(local, s_w128, &total);
     U128 run = base;
-    for (int p = p0; p < p1; p++) {
-      const int ni = sa[p];
-      const ONode nd = nodes[ni];
-      if (p == nd.kb) s_start[ni] = run;
-      if (init || nd.ke - nd.kb > 1) {
-        const uint32_t key = pa[p];
-        const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
-        run = u128_add(run, u128_one(q));
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < kOctChunk; j++) {
+        const int p = p0 + j;
+        if (p < p1) {
+          const int ni = nreg[j];
+          const int kb = nodes[ni].kb, ke = nodes[ni].ke;
+          if (p == kb) s_start[ni] = run;
+          if ((abits >> j) & 1u) run = u128_add(run, u128_one((int)((qbits >> (2 * j)) & 3u)));
+          if (p + 1 == ke) s_end[ni] = run;
+        }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-      if (p + 1 == nd.ke) s_end[ni] = run;
+    } else {
+      for (int p = p0; p < p1; p++) {
+        const int ni = sa[p];
+        const ONode nd = nodes[ni];
+        if (p == nd.kb) s_start[ni] = run;
+        if (init || nd.ke - nd.kb > 1) {
+          const uint32_t key = pa[p];
+          const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
+          run = u128_add(run, u128_one(q));
+        }
+        if (p + 1 == nd.ke) s_end[ni] = run;
+      }
     }
     __syncthreads();
     // 2. per-node child counts -> packed (children, multi, single) and its exclusive scan over the list
@@ -757,21 +836,45 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
     uint32_t* pb = perm[pc ^ 1];
     unsigned short* sb = seg[pc ^ 1];
     run = base;
-    for (int p = p0; p < p1; p++) {
-      const int ni = sa[p];
-      const ONode nd = nodes[ni];
-      if (init || nd.ke - nd.kb > 1) {
-        const uint32_t key = pa[p];
-        const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
-        unsigned ofs = 0;
-        for (int qq = 0; qq < q; qq++) ofs += u128_field(s_end[ni], qq) - u128_field(s_start[ni], qq);
-        const int dst = nd.kb + (int)ofs + (int)(u128_field(run, q) - u128_field(s_start[ni], q));
-        pb[dst] = pa[p];
-        sb[dst] = s_newidx[ni][q];
-        run = u128_add(run, u128_one(q));
-      } else {
-        pb[p] = pa[p];
-        sb[p] = s_newidx[ni][0];
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < kOctChunk; j++) {
+        const int p = p0 + j;
+        if (p < p1) {
+          const int ni = nreg[j];
+          if ((abits >> j) & 1u) {
+            const int q = (int)((qbits >> (2 * j)) & 3u);
+            const U128 st = s_start[ni], en = s_end[ni];
+            unsigned ofs = 0;
+            for (int qq = 0; qq < q; qq++) ofs += u128_field(en, qq) - u128_field(st, qq);
+            const int dst = nodes[ni].kb + (int)ofs + (int)(u128_field(run, q) - u128_field(st, q));
+            pb[dst] = kreg[j];
+            sb[dst] = s_newidx[ni][q];
+            run = u128_add(run, u128_one(q));
+          } else {
+            pb[p] = kreg[j];
+            sb[p] = s_newidx[ni][0];
+          }
+        }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      for (int p = p0; p < p1; p++) {
+        const int ni = sa[p];
+        const ONode nd = nodes[ni];
+        if (init || nd.ke - nd.kb > 1) {
+          const uint32_t key = pa[p];
+          const int q = init ? min((int)((float)(key & 0xfff) / hX), nIni - 1) : oct_quadrant(nd, key);
+          unsigned ofs = 0;
+          for (int qq = 0; qq < q; qq++) ofs += u128_field(s_end[ni], qq) - u128_field(s_start[ni], qq);
+          const int dst = nd.kb + (int)ofs + (int)(u128_field(run, q) - u128_field(s_start[ni], q));
+          pb[dst] = pa[p];
+          sb[dst] = s_newidx[ni][q];
+          run = u128_add(run, u128_one(q));
+        } else {
+          pb[p] = pa[p];
+          sb[p] = s_newidx[ni][0];
+        }
       }
     }
     __syncthreads();
@@ -782,11 +885,13 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
   };
 
   sweep(true);
+  OCT_T(1)
   bool finish = false;
   while (!finish) {
     const int prev = nn;
     vcur ^= 1;  // vSizeAndPointerToNode.clear(): entries are rebuilt by the sweep into the other buffer
     sweep(false);
+    OCT_T(2) OCT_CNT(0)
     if (nn >= N || nn == prev) {
       finish = true;
     } else if (nn + nvs * 3 > N) {
@@ -803,15 +908,29 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
           }, s_stack, 32);
         for (int i = tid; i < nn; i += kOctThreads) s_proc[i] = 0;
         __syncthreads();
+        OCT_T(3) OCT_CNT(1)
         // candidate splits of every entry; processing order k = 0.. is j = V-1-k (from the back)
         const int vchunk = (V + kOctThreads - 1) / kOctThreads;
         const int k0 = min(tid * vchunk, V), k1 = min(k0 + vchunk, V);
         unsigned long long lsum = 0;
+        // (a thread with one entry whose node has at most kOctChunk keys — the rule — loads them once, all loads in flight, and
+        // both the evaluation here and the partition below run from registers)
+        uint32_t nkey[kOctChunk];
+        bool have = false;
         for (int k = k0; k < k1; k++) {
           const int j = V - 1 - k;
           const ONode nd = nodes[vs[j].node];
           unsigned long long pk = 0;  // four 16-bit quadrant counters (an indexed private array would live in scratch memory)
-          for (int p = nd.kb; p < nd.ke; p++) pk += 1ull << (16 * oct_quadrant(nd, perm[pc][p]));
+          if (k1 - k0 == 1 && nd.ke - nd.kb <= kOctChunk) {
+            have = true;
+#pragma unroll
+            for (int u = 0; u < kOctChunk; u++) nkey[u] = nd.kb + u < nd.ke ? perm[pc][nd.kb + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < kOctChunk; u++)
+              if (nd.kb + u < nd.ke) pk += 1ull << (16 * oct_quadrant(nd, nkey[u]));
+          } else {
+            for_keys(perm[pc], nd.kb, nd.ke, [&](int, uint32_t key) { pk += 1ull << (16 * oct_quadrant(nd, key)); });
+          }
           int cc = 0, mm = 0;
           for (int q = 0; q < 4; q++) {
             const int cq = (int)((pk >> (16 * q)) & 0xffff);
@@ -859,16 +978,32 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
           uint32_t* pa = perm[pc];  // partitioned through the other buffer and copied back: pc does not flip here
           uint32_t* pb = perm[pc ^ 1];
           unsigned long long pk = 0;  // four 16-bit quadrant counters, then the four running positions
-          for (int p = nd.kb; p < nd.ke; p++) pk += 1ull << (16 * oct_quadrant(nd, pa[p]));
+          if (have) {
+#pragma unroll
+            for (int u = 0; u < kOctChunk; u++)
+              if (nd.kb + u < nd.ke) pk += 1ull << (16 * oct_quadrant(nd, nkey[u]));
+          } else {
+            for_keys(pa, nd.kb, nd.ke, [&](int, uint32_t key) { pk += 1ull << (16 * oct_quadrant(nd, key)); });
+          }
           const int cnt[4] = {(int)(pk & 0xffff), (int)((pk >> 16) & 0xffff), (int)((pk >> 32) & 0xffff), (int)(pk >> 48)};
           unsigned long long pos = (unsigned long long)cnt[0] << 16 | (unsigned long long)(cnt[0] + cnt[1]) << 32 |
                                    (unsigned long long)(cnt[0] + cnt[1] + cnt[2]) << 48;  // offsets from nd.kb
-          for (int p = nd.kb; p < nd.ke; p++) {
-            const int sh = 16 * oct_quadrant(nd, pa[p]);
-            pb[nd.kb + (int)((pos >> sh) & 0xffff)] = pa[p];
-            pos += 1ull << sh;
+          if (have) {  // all keys are in registers: partitioned in place
+#pragma unroll
+            for (int u = 0; u < kOctChunk; u++)
+              if (nd.kb + u < nd.ke) {
+                const int sh = 16 * oct_quadrant(nd, nkey[u]);
+                pa[nd.kb + (int)((pos >> sh) & 0xffff)] = nkey[u];
+                pos += 1ull << sh;
+              }
+          } else {
+            for_keys(pa, nd.kb, nd.ke, [&](int, uint32_t key) {
+              const int sh = 16 * oct_quadrant(nd, key);
+              pb[nd.kb + (int)((pos >> sh) & 0xffff)] = key;
+              pos += 1ull << sh;
+            });
+            for_keys(pb, nd.kb, nd.ke, [&](int p, uint32_t key) { pa[p] = key; });
           }
-          for (int p = nd.kb; p < nd.ke; p++) pa[p] = pb[p];
           int kb = nd.kb, before = 0, mrank = 0;
           for (int q = 0; q < 4; q++) {
             if (cnt[q] == 0) continue;
@@ -903,6 +1038,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
         vcur ^= 1;
         nn = T + (int)stot;
         nvs = Mtot;
+        OCT_T(4)
         if (nn >= N || nn == prev2) finish = true;
       }
     }
@@ -913,12 +1049,18 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelDev* __restri
   for (int i = tid; i < nn; i += kOctThreads) {
     const ONode nd = nodes[i];
     uint32_t best = perm[pc][nd.kb];
-    for (int p = nd.kb + 1; p < nd.ke; p++) {
-      const uint32_t k2 = perm[pc][p];
-      if ((k2 >> 24) > (best >> 24)) best = k2;
+    for (int pb_ = nd.kb + 1; pb_ < nd.ke; pb_ += 8) {  // eight loads in flight
+      uint32_t t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = pb_ + u < nd.ke ? perm[pc][pb_ + u] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (pb_ + u < nd.ke && (t[u] >> 24) > (best >> 24)) best = t[u];
     }
     out[i] = best;
   }
+  OCT_T(5)
+  OCT_T_END
   if (tid == 0) kept_cnt[(size_t)b * nlevels + l] = nn;
 }
 
@@ -1607,10 +1749,10 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   A(h->d_slab.alloc(B * h->cap_slab));
   A(h->d_cand.alloc(B * h->cap_slab));
   A(h->d_kpin.alloc(B * h->cap_kp));
-  A(h->d_perm0.alloc(B * h->cap_slab));
-  A(h->d_perm1.alloc(B * h->cap_slab));
-  A(h->d_seg0.alloc(B * h->cap_slab));
-  A(h->d_seg1.alloc(B * h->cap_slab));
+  A(h->d_perm0.alloc(B * h->cap_slab + 64));  // + 64: k_octree's cached sweeps read a whole chunk unconditionally
+  A(h->d_perm1.alloc(B * h->cap_slab + 64));  // + 64: k_octree's cached sweeps read a whole chunk unconditionally
+  A(h->d_seg0.alloc(B * h->cap_slab + 64));  // + 64: k_octree's cached sweeps read a whole chunk unconditionally
+  A(h->d_seg1.alloc(B * h->cap_slab + 64));  // + 64: k_octree's cached sweeps read a whole chunk unconditionally
   A(h->d_kept.alloc(B * h->cap_kp));
   A(h->d_kept_cnt.alloc(B * nl));
   A(h->d_kept_off.alloc(nl));
@@ -1831,8 +1973,8 @@ int gfs_orb_octree_device(int device, const int32_t* x, const int32_t* y, const 
   gfs::DevBuf<unsigned short> s0, s1;
   gfs::DevBuf<int> doff, dko, dcnt;
   int rc = 0;
-  if ((rc = dL.alloc(1)) || (rc = dc.alloc(c.size())) || (rc = p0.alloc(c.size())) || (rc = p1.alloc(c.size())) ||
-      (rc = s0.alloc(c.size())) || (rc = s1.alloc(c.size())) || (rc = dk.alloc(kcap)) || (rc = doff.alloc(2)) ||
+  if ((rc = dL.alloc(1)) || (rc = dc.alloc(c.size())) || (rc = p0.alloc(c.size() + 64)) || (rc = p1.alloc(c.size() + 64)) ||
+      (rc = s0.alloc(c.size() + 64)) || (rc = s1.alloc(c.size() + 64)) || (rc = dk.alloc(kcap)) || (rc = doff.alloc(2)) ||
       (rc = dko.alloc(1)) || (rc = dcnt.alloc(1)))
     return rc;
   const int off[2] = {0, n}, ko = 0;
