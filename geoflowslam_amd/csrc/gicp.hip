@@ -2109,6 +2109,7 @@ struct gfs_gicp {
   bool tile_stats_on = false;  // GFS_GICP_TILE_STATS=1
   gfs::DevBuf<unsigned> d_tile_stats;  // [8] outcome counters of k_gicp_linearize's tile staging (gfs_gicp_tile_stats)
   bool vqs_lds = true;  // GFS_GICP_VQS_LDS=0: without k_voxel_qsort_top_lds
+  bool sort_all_kernels = false;  // set for the second run of a call whose first run found a cloud the LDS sort kernel could not take
   bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
   gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
@@ -2128,16 +2129,23 @@ struct gfs_gicp {
 
 // The n >= 1024 levels of the voxel sort: the LDS-resident kernel for clouds of at most kVqsLdsE * 1024 points whose keys compact to
 // 31 bits, the register-cached kernel for larger ones of that key width, the general kernel for the rest (each flags what it leaves).
+// n_left != nullptr (only when every cloud fits the LDS kernel by size): the other two kernels are NOT launched and the LDS kernel
+// counts the clouds it left in *n_left -- the caller has to look at it and come back with n_left = nullptr if it is not zero.  (A
+// launch of the general kernel that finds nothing to do is not free: its 1024-thread workgroups need a CU to themselves, and with
+// other lanes' kernels in flight it waits ~0.3 ms for one.)
 constexpr int kVqsLdsE = 19;
-static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only) {
+static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only, int* n_left) {
   const int P = h->P;
   int flagged_only = 0;
+  const bool lds_covers_sizes = h->vqs_lds && P <= 1024 * kVqsLdsE;
+  if (!lds_covers_sizes) n_left = nullptr;
   if (h->vqs_lds) {
     const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top_lds", s) : -1;
     hipLaunchKernelGGL(vqs::k_voxel_qsort_top_lds<kVqsLdsE>, dim3(C2), dim3(1024), kVqsLdsE * 1024 * 8, s, h->d_keys0.p, h->d_val0.p,
-                       h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only);
+                       h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only, n_left);
     if (_pid >= 0) ::gfs::profile_end(_pid, s);
     flagged_only = 1;
+    if (n_left) return hipGetLastError();
   }
 #define VQS_TOP_REG(E)                                                                                                         \
   do {                                                                                                                         \
@@ -2148,14 +2156,14 @@ static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only) 
     if (_pid >= 0) ::gfs::profile_end(_pid, s);                                                                                \
   } while (0)
   if (P <= 1024 * 20) {
-    if (!(h->vqs_lds && P <= 1024 * kVqsLdsE)) VQS_TOP_REG(20);  // (no cloud can be left over when P fits the LDS kernel ...
+    if (!lds_covers_sizes) VQS_TOP_REG(20);  // (when P fits the LDS kernel only key width can leave a cloud over: the general kernel)
     flagged_only = 1;
   } else if (P <= 1024 * 40) {
     VQS_TOP_REG(40);
     flagged_only = 1;
   }
 #undef VQS_TOP_REG
-  {  // ... except for key width: the general kernel always looks)
+  {
     const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top", s) : -1;
     hipLaunchKernelGGL(vqs::k_voxel_qsort_top, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_val0.p, h->d_keys1.p, h->d_val1.p,
                        h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only, flagged_only);
@@ -2230,7 +2238,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_kinfo1.alloc(C2 * 8));
   A(h->d_kinfo2.alloc(C2 * 8));
   A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
-  A(h->d_ndone.alloc(1));
+  A(h->d_ndone.alloc(2));  // [0] pairs done, [1] clouds the LDS sort kernel left to the kernels that were not launched
   A(h->d_active.alloc(2 * (size_t)B));
   A(h->d_nactive.alloc(2));
   A(h->d_tile_stats.alloc(8));
@@ -2259,7 +2267,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_initT.alloc(B * 16));
   A(h->d_state.alloc(B));
   A(h->h_state.alloc(B));
-  A(h->h_ndone.alloc(2));
+  A(h->h_ndone.alloc(4));
   for (int k = 0; k < 2; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_round[k], hipEventDisableTiming));
   A(h->h_m.alloc(C2));
   A(h->h_initT.alloc(B * 16));
@@ -2298,6 +2306,8 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   GFS_HIP(hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const int P = h->P, C2 = 2 * B;
+  // (the round loop below looks at the count the LDS sort kernel leaves; the persistent LM kernel has no such look)
+  const bool optimistic_sort = h->lm_rounds && !h->sort_all_kernels;
   GicpParams prm;
   prm.inv_leaf = 1.0 / cfg->downsampling_resolution;
   // cell edge = max correspondence distance: one ring of cells certifies every 1-NN probe and (for voxel-sized
@@ -2335,7 +2345,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   for (int b = 0; b < B; b++)
     for (int k = 0; k < 16; k++) h->h_initT.p[16 * b + k] = init_T ? init_T[16 * b + k] : (k % 5 == 0 ? 1.0 : 0.0);
   GFS_HIP(hipMemcpyAsync(h->d_initT.p, h->h_initT.p, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, sizeof(int), s));
+  GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, 2 * sizeof(int), s));
   const int npts = std::min(stride_pts, P);
   // ---- preprocess_points x 2B (registration_helper.cpp:22-34)
   GFS_LAUNCH("k_voxel_keys", k_voxel_keys, dim3(gfs::div_up(npts, 256), C2), dim3(256), 0, s, in_even, in_odd, n_even, n_odd,
@@ -2348,7 +2358,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     const int leaf_parts = std::max(1, std::min(64, P / 2048));
     int rc_leaf = 0;
     GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, (size_t)C2 * sizeof(int), s));
-    GFS_HIP(voxel_qsort_top(h, C2, s, prm.only));
+    GFS_HIP(voxel_qsort_top(h, C2, s, prm.only, optimistic_sort ? h->d_ndone.p + 1 : nullptr));
     // (GFS_GICP_VOXEL_TIES=exact: the reference's permutation even where it cannot change a voxel mean)
     static const bool exact_ties = getenv("GFS_GICP_VOXEL_TIES") && strcmp(getenv("GFS_GICP_VOXEL_TIES"), "exact") == 0;
     rc_leaf = exact_ties ? voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only) : voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, in_even, in_odd, stride_pts);
@@ -2415,11 +2425,19 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
                  h->d_ndone.p, act_next, n_act_next);
       // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
       // speculative round after convergence finds every pair in phase 2 and its blocks exit at once.
-      GFS_HIP(hipMemcpyAsync(h->h_ndone.p + (round & 1), h->d_ndone.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      GFS_HIP(hipMemcpyAsync(h->h_ndone.p + 2 * (round & 1), h->d_ndone.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
       GFS_HIP(hipEventRecord(h->ev_round[round & 1], s));
       if (round >= 1) {
         GFS_HIP(hipEventSynchronize(h->ev_round[(round - 1) & 1]));
-        known_done = h->h_ndone.p[(round - 1) & 1];
+        if (optimistic_sort && h->h_ndone.p[2 * ((round - 1) & 1) + 1] > 0) {
+          // a cloud needed the voxel-sort kernels that were not launched (keys wider than 31 bits): everything again, with them
+          GFS_HIP(hipStreamSynchronize(s));
+          h->sort_all_kernels = true;
+          const int rc_again = gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
+          h->sort_all_kernels = false;
+          return rc_again;
+        }
+        known_done = h->h_ndone.p[2 * ((round - 1) & 1)];
         if (known_done >= B) break;
       }
     }
@@ -2518,7 +2536,7 @@ int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsi
   if (n) GFS_HIP(hipMemcpyAsync(h->d_val0.p, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
   const int leaf_parts = std::max(1, std::min(64, P / 2048));
   GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, 2 * sizeof(int), s));
-  GFS_HIP(voxel_qsort_top(h, 2, s, -1));
+  GFS_HIP(voxel_qsort_top(h, 2, s, -1, nullptr));
   {
     const int rc_leaf = voxel_qsort_leaves(h, 2, leaf_parts, s, -1);
     if (rc_leaf) return rc_leaf;

@@ -669,7 +669,8 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
 // element of the back part (from the right) -- so after the back elements have announced their positions, the thread that owns
 // the FRONT element of a pair exchanges the two; no element is touched by two threads, nothing has to be copied aside, and the
 // 2.4 GB per 1024 clouds that the global ping-pong buffers of k_voxel_qsort_top_reg move through HBM stay on the CU.
-// Clouds that do not qualify are flagged kinfo[8c + 6] = 2 for k_voxel_qsort_top_reg (which flags 1 for k_voxel_qsort_top).
+// Clouds that do not qualify are flagged kinfo[8c + 6] = 2 for k_voxel_qsort_top_reg (which flags 1 for k_voxel_qsort_top) and
+// counted in *n_left.
 // ------------------------------------------------------------------------------------------------
 #ifdef GFS_VQS_TIMING
 #define VQS_T_INIT long long vt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, vt_last = clock64(); int vt_lv = 0;
@@ -684,7 +685,7 @@ template <int EMAX>
 __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, unsigned* vals_all,
                                                               const int* __restrict__ counts, int P, int* __restrict__ which,
                                                               int* __restrict__ kinfo, unsigned* __restrict__ leaf_all,
-                                                              int* __restrict__ nleaf, int only) {
+                                                              int* __restrict__ nleaf, int only, int* __restrict__ n_left) {
   constexpr u64 kInvalid = ~0ull;
   constexpr int kCB = 21, kCM = (1 << kCB) - 1;
   constexpr int kSeg = EMAX + 1, kEq = 32;
@@ -746,7 +747,14 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
   const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
             bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
   if (bx + by + bz > 31 || n > 1024 * EMAX) {  // uniform: left to the kernels that work through HBM
-    if (tid == 0) kinfo[8 * c + 6] = 2;
+    if (tid == 0) {
+      kinfo[8 * c + 6] = 2;
+      if (n_left) {  // the host launches those kernels only when a cloud asked for them (gicp_run); until then the cloud stays
+        atomicAdd(n_left, 1);  // unsorted and the leaf kernels must find nothing to do in it
+        nleaf[c] = 0;
+        which[c] = 0;
+      }
+    }
     return;
   }
 #pragma unroll

@@ -174,6 +174,31 @@ def test_gicp_edge_cases(gpu_api, oracle):
     assert re["num_inliers"] == 0 and np.allclose(re["T"], np.eye(4))
 
 
+def test_wide_extent_cloud_on_an_lds_sized_handle(gpu_api, oracle):
+    """A handle whose capacity fits the LDS-resident voxel-sort kernel does not launch the other two sort kernels up front
+    (csrc/gicp.hip voxel_qsort_top): a cloud whose voxel keys do not compact to 31 bits is counted by the LDS kernel, gicp_run
+    sees the count at its first poll and runs the call again with all kernels.  The result must be the oracle's either way."""
+    fp = synth.frame_pair(9, 320, 240, 4)
+    rng = np.random.default_rng(3)
+    far = np.zeros((60, 4), np.float32)  # a few isolated returns far out: 80 m x 40 m x 20 m of 2 cm voxels = 12 + 11 + 10 bits
+    far[:, 0] = rng.uniform(-40, 40, 60)
+    far[:, 1] = rng.uniform(-20, 20, 60)
+    far[:, 2] = rng.uniform(0.5, 20, 60)
+    far[:, 3] = 1
+    c0 = np.concatenate([fp["cloud0"], far]).astype(np.float32)
+    c1 = np.concatenate([fp["cloud1"], far[::-1]]).astype(np.float32)
+    reg = gpu_api.RegistrationGICP(max_points=19200)
+    ro = oracle.gicp_align(c0, c1)
+    for _ in range(2):  # (the second call starts from the state the redo left behind)
+        r = reg.RegisterPointClouds(c0, c1)
+        assert _rel(r["T"], ro["T"]) < TOL and r["converged"] == ro["converged"] and r["iterations"] == ro["iterations"]
+        assert r["num_inliers"] == ro["num_inliers"] and r["n_source_ds"] == ro["n_source_ds"] and r["n_target_ds"] == ro["n_target_ds"]
+    # ... and a compact pair on the same handle afterwards (no redo) is still right
+    r = reg.RegisterPointClouds(fp["cloud0"], fp["cloud1"])
+    rn = oracle.gicp_align(fp["cloud0"], fp["cloud1"])
+    assert _rel(r["T"], rn["T"]) < TOL and r["iterations"] == rn["iterations"] and r["n_source_ds"] == rn["n_source_ds"]
+
+
 def test_gicp_720p_cloud(gpu_api, oracle):
     fp = synth.frame_pair(12, 1280, 720, 5)
     assert len(fp["cloud0"]) > 30000
