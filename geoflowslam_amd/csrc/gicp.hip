@@ -2173,18 +2173,21 @@ static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only, 
 }
 
 // std::sort of the < 1024-element ranges (both key widths), then the heap-sort fallbacks they deferred
-static int voxel_qsort_leaves(gfs_gicp* h, int C2, int leaf_parts, hipStream_t s, int only, const float4* in_even = nullptr,
-                              const float4* in_odd = nullptr, int stride_pts = 0) {
+static int voxel_qsort_leaves(gfs_gicp* h, int C2, int leaf_parts, hipStream_t s, int only, bool narrow_only,
+                              const float4* in_even = nullptr, const float4* in_odd = nullptr, int stride_pts = 0) {
   const int P = h->P;
   GFS_LAUNCH("k_voxel_qsort_leaf", vqs::k_voxel_qsort_leaf<unsigned>, dim3(leaf_parts, C2), dim3(256), 0, s, h->d_keys0.p,
              h->d_val0.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, P, only, h->d_heap.p, h->d_nheap.p, h->heap_cap);
-  GFS_LAUNCH("k_voxel_qsort_leaf64", vqs::k_voxel_qsort_leaf<u64>, dim3(leaf_parts, C2), dim3(256), 0, s, h->d_keys0.p,
-             h->d_val0.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, P, only, h->d_heap.p, h->d_nheap.p, h->heap_cap);
+  // (narrow_only: the caller knows, or will find out and come back, that no cloud has keys wider than 31 bits)
+  if (!narrow_only)
+    GFS_LAUNCH("k_voxel_qsort_leaf64", vqs::k_voxel_qsort_leaf<u64>, dim3(leaf_parts, C2), dim3(256), 0, s, h->d_keys0.p,
+               h->d_val0.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, P, only, h->d_heap.p, h->d_nheap.p, h->heap_cap);
   const int heap_parts = std::max(1, std::min(16, P / 4096));
   GFS_LAUNCH("k_voxel_qsort_heap", vqs::k_voxel_qsort_heap<unsigned>, dim3(heap_parts, C2), dim3(256), 0, s, h->d_keys0.p,
              h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only, in_even, in_odd, stride_pts);
-  GFS_LAUNCH("k_voxel_qsort_heap64", vqs::k_voxel_qsort_heap<u64>, dim3(heap_parts, C2), dim3(256), 0, s, h->d_keys0.p,
-             h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only, in_even, in_odd, stride_pts);
+  if (!narrow_only)
+    GFS_LAUNCH("k_voxel_qsort_heap64", vqs::k_voxel_qsort_heap<u64>, dim3(heap_parts, C2), dim3(256), 0, s, h->d_keys0.p,
+               h->d_val0.p, h->d_kinfo1.p, h->d_heap.p, h->d_nheap.p, h->heap_cap, P, only, in_even, in_odd, stride_pts);
   return GFS_OK;
 }
 
@@ -2361,7 +2364,9 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     GFS_HIP(voxel_qsort_top(h, C2, s, prm.only, optimistic_sort ? h->d_ndone.p + 1 : nullptr));
     // (GFS_GICP_VOXEL_TIES=exact: the reference's permutation even where it cannot change a voxel mean)
     static const bool exact_ties = getenv("GFS_GICP_VOXEL_TIES") && strcmp(getenv("GFS_GICP_VOXEL_TIES"), "exact") == 0;
-    rc_leaf = exact_ties ? voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only) : voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, in_even, in_odd, stride_pts);
+    const bool narrow_only = optimistic_sort && h->vqs_lds && P <= 1024 * kVqsLdsE;  // (what voxel_qsort_top counts in d_ndone[1])
+    rc_leaf = exact_ties ? voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, narrow_only)
+                         : voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, narrow_only, in_even, in_odd, stride_pts);
     if (rc_leaf) return rc_leaf;
   }
   GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, in_even, in_odd, stride_pts, h->d_keys0.p, h->d_keys1.p,
@@ -2538,7 +2543,7 @@ int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsi
   GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, 2 * sizeof(int), s));
   GFS_HIP(voxel_qsort_top(h, 2, s, -1, nullptr));
   {
-    const int rc_leaf = voxel_qsort_leaves(h, 2, leaf_parts, s, -1);
+    const int rc_leaf = voxel_qsort_leaves(h, 2, leaf_parts, s, -1, false);
     if (rc_leaf) return rc_leaf;
   }
   if (n) GFS_HIP(hipMemcpyAsync(perm_out, h->d_val0.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
