@@ -24,6 +24,7 @@
 #include "gfs_common.hpp"
 #include "orb_host.hpp"
 #include "std_sort_replica.hpp"
+#include "wave_std_sort.hpp"
 
 using gfs::BlurTileDev;
 using gfs::CellDev;
@@ -550,6 +551,12 @@ __device__ __forceinline__ ONode oct_child(const ONode& nd, int q) {
   return c;
 }
 
+// (out of line: the sort's own register arrays are then not part of k_octree's live state around the call)
+__device__ __attribute__((noinline)) void oct_sort_wave(unsigned* K, unsigned short* Pm, unsigned short* l0, unsigned short* l1,
+                                                        unsigned short* cl, unsigned short* st, int n) {
+  vqs::wave_std_sort<unsigned>(K, Pm, l0, l1, cl, st, n);
+}
+
 #ifdef GFS_OCT_TIMING
 #define OCT_T_INIT long long ot_acc[6] = {0, 0, 0, 0, 0, 0}, ot_last = clock64(); int ot_cnt[2] = {0, 0};
 #define OCT_T(k) { const long long _n = clock64(); ot_acc[k] += _n - ot_last; ot_last = _n; }
@@ -900,12 +907,35 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
         OVs* vs = s_vs[vcur];
         const int V = nvs;
         ONode* nodes = s_nodes[cur];
-        if (tid == 0)
-          gfs::replica_std_sort_on(vs, vs + V, [](const OVs& a, const OVs& e) {  // compareNodes :552-565
+        // sort(vSizeAndPointerToNode) :697-698 with compareNodes :552-565 (size, then UL.x: many entries are equivalent, so the
+        // result is libstdc++'s own sequence of moves).  One wave replays std::sort on the packed keys (size << 12 | x), the
+        // entries follow their keys; its LDS scratch is the sweeps' s_start / s_end, idle here.
+        if (V <= 1024 && (size_t)V * 12 + 256 <= (size_t)node_cap * 32) {
+          unsigned* sk = (unsigned*)s_start;
+          unsigned short* spm = (unsigned short*)(sk + V);
+          unsigned short *sl0 = spm + V, *sl1 = sl0 + V, *scl = sl1 + V, *sst = scl + V;
+          for (int i = tid; i < V; i += kOctThreads) {
+            sk[i] = ((unsigned)vs[i].size << 12) | (unsigned)vs[i].x0;  // x0 in [0, 4096), size <= n < 2^20
+            spm[i] = (unsigned short)i;
+          }
+          __syncthreads();
+          if (tid < 64) oct_sort_wave(sk, spm, sl0, sl1, scl, sst, V);
+          __syncthreads();
+          OVs mine[4];  // V <= 1024 = 4 x 256
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (tid + u * kOctThreads < V) mine[u] = vs[spm[tid + u * kOctThreads]];
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (tid + u * kOctThreads < V) vs[tid + u * kOctThreads] = mine[u];
+        } else if (tid == 0) {
+          gfs::replica_std_sort_on(vs, vs + V, [](const OVs& a, const OVs& e) {
             if (a.size < e.size) return true;
             if (a.size > e.size) return false;
             return a.x0 < e.x0;
           }, s_stack, 32);
+        }
         for (int i = tid; i < nn; i += kOctThreads) s_proc[i] = 0;
         __syncthreads();
         OCT_T(3) OCT_CNT(1)

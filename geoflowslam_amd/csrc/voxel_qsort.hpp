@@ -24,6 +24,8 @@
 // tests/test_gpu_gicp.py compares the permutation with the oracle's (which calls libstdc++'s std::partition / std::sort).
 #pragma once
 
+#include "wave_std_sort.hpp"
+
 namespace vqs {
 
 typedef unsigned long long u64;
@@ -1103,202 +1105,6 @@ struct LeafLds {
   unsigned short Pm[4][1024], l0[4][1024], l1[4][1024], cl[4][1024];
   unsigned short st[4][3 * 40];
 };
-
-template <typename KT>
-__device__ __forceinline__ void heap_adjust_soa(KT* K, unsigned short* Pm, int first, int hole, int len, KT vk,
-                                                unsigned short vp) {  // libstdc++ __adjust_heap + __push_heap
-  const int top = hole;
-  int child = hole;
-  while (child < (len - 1) / 2) {
-    child = 2 * (child + 1);
-    if (K[first + child] < K[first + child - 1]) child--;
-    K[first + hole] = K[first + child];
-    Pm[first + hole] = Pm[first + child];
-    hole = child;
-  }
-  if ((len & 1) == 0 && child == (len - 2) / 2) {
-    child = 2 * (child + 1);
-    K[first + hole] = K[first + child - 1];
-    Pm[first + hole] = Pm[first + child - 1];
-    hole = child - 1;
-  }
-  int parent = (hole - 1) / 2;
-  while (hole > top && K[first + parent] < vk) {
-    K[first + hole] = K[first + parent];
-    Pm[first + hole] = Pm[first + parent];
-    hole = parent;
-    parent = (hole - 1) / 2;
-  }
-  K[first + hole] = vk;
-  Pm[first + hole] = vp;
-}
-
-template <typename KT>
-__device__ void heap_sort_soa(KT* K, unsigned short* Pm, int lo, int hi) {  // __partial_sort(first, last, last), one lane
-  const int len = hi - lo;
-  if (len >= 2) {
-    int parent = (len - 2) / 2;
-    while (true) {
-      heap_adjust_soa<KT>(K, Pm, lo, parent, len, K[lo + parent], Pm[lo + parent]);
-      if (parent == 0) break;
-      parent--;
-    }
-  }
-  int last = hi;
-  while (last - lo > 1) {
-    --last;
-    const KT vk = K[last];
-    const unsigned short vp = Pm[last];
-    K[last] = K[lo];
-    Pm[last] = Pm[lo];
-    heap_adjust_soa<KT>(K, Pm, lo, 0, last - lo, vk, vp);
-  }
-}
-
-#define VQS_WAVE_SYNC()                                  \
-  do {                                                   \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-    __builtin_amdgcn_wave_barrier();                     \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-  } while (0)
-
-// Wave-cooperative __partial_sort(first, last, last) (= __make_heap + __sort_heap) on K / Pm [lo, hi) in LDS: the same
-// comparisons and moves as libstdc++'s serial code, arranged so that a pop costs a few LDS round trips instead of ~3 per
-// heap level.  __make_heap sifts the nodes in decreasing index order; nodes of one depth have disjoint subtrees, so a whole
-// depth is done at once (one lane per node, each running the serial __adjust_heap).  A pop walks the hole from the root to a
-// leaf along the larger children (bottom-up variant: no comparison with the value on the way down): the 63 lanes read the
-// child pairs of the next SIX levels below the hole at once, the walk through them is scalar bit arithmetic on two ballots,
-// and the lanes on the path write the chosen children up; __push_heap then climbs (rarely more than a level).
-template <typename KT>
-__device__ void heap_sort_wave(KT* K, unsigned short* Pm, int lo, int hi, int stop_len = 1) {
-  const int lane = threadIdx.x & 63;
-  const int len = hi - lo;
-  KT* H = K + lo;
-  unsigned short* Q = Pm + lo;
-  if (len < 2) return;
-  {
-    const int last_parent = (len - 2) / 2;
-    for (int d = 31 - __clz(last_parent + 1); d >= 0; d--) {
-      const int first_node = (1 << d) - 1, end_node = min((2 << d) - 2, last_parent);
-      for (int base = first_node; base <= end_node; base += 64) {
-        const int node = base + lane;
-        if (node <= end_node) heap_adjust_soa<KT>(K, Pm, lo, node, len, H[node], Q[node]);
-      }
-      VQS_WAVE_SYNC();
-    }
-  }
-  const int t = lane + 1, dt = 31 - __clz(t), tofs = t - (1 << dt);  // local node t (1-based) of the 6-level subtree below the hole
-  auto bcast = [](KT v, int from) {  // value of lane `from` (wave-uniform index)
-    if constexpr (sizeof(KT) == 4) {
-      return (KT)__builtin_amdgcn_readlane((int)v, from);
-    } else {
-      const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, from);
-      const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), from);
-      return (KT)(((u64)hi32 << 32) | lo32);
-    }
-  };
-#ifdef VQS_NO_POPS
-  return;
-#endif
-  // (stop_len > 1: only the pops down to a heap of stop_len elements are replayed — see k_voxel_qsort_heap)
-  for (int L = len - 1; L >= max(1, stop_len); L--) {  // __pop_heap(first, first + L, first + L): value = H[L], H[L] = H[0], sift in [0, L)
-    // (the popped value and the old root are not needed by the descent: no wait on these reads until the end of the pop)
-    const KT vk = H[L], rk = H[0];
-    const unsigned short vp = Q[L], rp = Q[0];
-    const int half = (L - 1) / 2;  // nodes below `half` have two children
-    int hole = 0;
-    KT upk = 0;  // the key just moved into the parent of the hole: __push_heap's first comparison needs no LDS read
-    unsigned short upp = 0;
-    bool moved = false;
-    while (hole < half) {
-      const int g = ((hole + 1) << dt) + tofs - 1;
-      const bool valid = lane < 63 && g < half;
-      KT kl = 0, kr = 0;
-      unsigned short pl = 0, pr = 0;
-      if (valid) {
-        kl = H[2 * g + 1];
-        kr = H[2 * g + 2];
-        pl = Q[2 * g + 1];
-        pr = Q[2 * g + 2];
-      }
-      const bool left = valid && kr < kl;  // __adjust_heap: the second child unless it is smaller than the first
-      // the walk through the six levels: scalar bit arithmetic on the two ballots, branch free (a finished walk idles)
-      const u64 bv = __ballot(valid), bl = __ballot(left);
-      int tt = 1, last_t = 1, alive = 1;
-      u64 pathmask = 0;
-#pragma unroll
-      for (int lev = 0; lev < 6; lev++) {
-        const int idx = tt - 1;
-        const int ok = alive & (int)((bv >> idx) & 1ull);
-        const int lf = (int)((bl >> idx) & 1ull);
-        pathmask |= (u64)ok << idx;
-        last_t = ok ? tt : last_t;
-        tt = ok ? 2 * tt + 1 - lf : tt;
-        alive = ok;
-      }
-      const KT ck = left ? kl : kr;
-      const unsigned short cp = left ? pl : pr;
-      if ((pathmask >> lane) & 1ull) {
-        H[g] = ck;
-        Q[g] = cp;
-      }
-      if (pathmask) {
-        upk = bcast(ck, last_t - 1);
-        upp = (unsigned short)__builtin_amdgcn_readlane((int)cp, last_t - 1);
-        moved = true;
-      }
-      const int dtt = 31 - __clz(tt);
-      hole = ((hole + 1) << dtt) + (tt - (1 << dtt)) - 1;
-      VQS_WAVE_SYNC();
-    }
-    if ((L & 1) == 0 && hole == (L - 2) / 2) {  // a last node with a single child
-      const int child = 2 * (hole + 1) - 1;
-      const KT ck = H[child];
-      const unsigned short cp = Q[child];
-      VQS_WAVE_SYNC();
-      if (lane == 0) {
-        H[hole] = ck;
-        Q[hole] = cp;
-      }
-      upk = ck;
-      upp = cp;
-      moved = true;
-      hole = child;
-      VQS_WAVE_SYNC();
-    }
-    if (lane == 0) {  // H[L] = H[0] of __pop_heap (node L is outside the sifted heap [0, L))
-      H[L] = rk;
-      Q[L] = rp;
-    }
-    bool first = moved;
-    while (hole > 0) {  // __push_heap
-      const int parent = (hole - 1) / 2;
-      KT pk;
-      unsigned short pp;
-      if (first) {
-        pk = upk;
-        pp = upp;
-        first = false;
-      } else {
-        pk = H[parent];
-        pp = Q[parent];
-      }
-      if (!(pk < vk)) break;
-      VQS_WAVE_SYNC();
-      if (lane == 0) {
-        H[hole] = pk;
-        Q[hole] = pp;
-      }
-      hole = parent;
-      VQS_WAVE_SYNC();
-    }
-    if (lane == 0) {
-      H[hole] = vk;
-      Q[hole] = vp;
-    }
-    VQS_WAVE_SYNC();
-  }
-}
 
 template <typename KT>
 __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigned* vals_all,
