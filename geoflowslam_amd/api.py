@@ -184,7 +184,7 @@ ABI_SYMBOLS = [
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
-    "gfs_gicp_fetch_preprocessed", "gfs_gicp_tile_stats", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort",
+    "gfs_gicp_fetch_preprocessed", "gfs_gicp_tile_stats", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort", "gfs_test_wave_std_sort",
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_solve_bool", "gfs_lba_linearize", "gfs_lba_batch_create", "gfs_lba_batch_destroy",
     "gfs_lba_solve_batch",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_depth_convert_u16_batch_device", "gfs_stereo_from_rgbd",
@@ -243,6 +243,7 @@ def lib():
             L.gfs_gicp_fetch_preprocessed.argtypes = [vp, i, i, vp, vp, i, ip]
             L.gfs_gicp_tile_stats.argtypes = [vp, vp, i]
             L.gfs_test_voxel_sort.argtypes = [vp, vp, i, vp]
+            L.gfs_test_wave_std_sort.argtypes = [i, vp, i, vp]
             L.gfs_gicp_align_next.argtypes = [vp, vp, i, vp, C.POINTER(GicpConfig), C.POINTER(GicpResult)]
             L.gfs_gicp_align_next_batch_device.argtypes = [vp, vp, vp, i, i, vp, C.POINTER(GicpConfig), vp, vp]
         if hasattr(L, "gfs_lba_create"):
@@ -418,6 +419,14 @@ class ORBextractor:
         x, y, s = (np.zeros(max(n, 1), np.int32) for _ in range(3))
         lib().gfs_orb_fetch_candidates(self.h, b, l, _p(x), _p(y), _p(s), n)
         return x[:n], y[:n], s[:n]
+
+
+def wave_std_sort_perm(keys, device=0):
+    """csrc/wave_std_sort.hpp on the GPU: the permutation std::sort leaves (test hook)."""
+    k = np.ascontiguousarray(keys, np.uint32)
+    perm = np.zeros(max(len(k), 1), np.uint16)
+    _check(lib().gfs_test_wave_std_sort(device, _p(k), len(k), _p(perm)), "gfs_test_wave_std_sort")
+    return perm[:len(k)].astype(np.int64)
 
 
 def octree_host(x, y, score, min_x, max_x, min_y, max_y, n_features):

@@ -2527,6 +2527,35 @@ int gfs_gicp_align(gfs_gicp* h, const float* target_xyzw, int nt, const float* s
 
 // Test hook (tests/test_gpu_gicp.py): runs the voxel sort of the preprocessing (voxel_qsort.hpp) on n caller-supplied 64-bit
 // keys laid out like voxel keys (3 x 21 bits, or all ones = invalid) and returns the permutation.
+// GPU test hook: vqs::wave_std_sort (csrc/wave_std_sort.hpp) on caller keys, n <= 1024; perm_out[i] = original index of the element
+// that std::sort leaves at position i.
+__global__ __launch_bounds__(64) void k_test_wave_std_sort(const unsigned* __restrict__ keys, int n, unsigned short* __restrict__ perm) {
+  __shared__ unsigned K[1024];
+  __shared__ unsigned short Pm[1024], l0[1024], l1[1024], cl[1024], st[3 * 40];
+  for (int i = threadIdx.x; i < n; i += 64) {
+    K[i] = keys[i];
+    Pm[i] = (unsigned short)i;
+  }
+  VQS_WAVE_SYNC();
+  vqs::wave_std_sort<unsigned>(K, Pm, l0, l1, cl, st, n);
+  for (int i = threadIdx.x; i < n; i += 64) perm[i] = Pm[i];
+}
+
+int gfs_test_wave_std_sort(int device, const unsigned* keys, int n, unsigned short* perm_out) {
+  GFS_REQUIRE(keys && perm_out && n >= 0 && n <= 1024, GFS_ERR_INVALID_ARG, "gfs_test_wave_std_sort: invalid argument");
+  GFS_HIP(hipSetDevice(device));
+  gfs::DevBuf<unsigned> dk;
+  gfs::DevBuf<unsigned short> dp;
+  int rc;
+  if ((rc = dk.alloc((size_t)std::max(n, 1))) || (rc = dp.alloc((size_t)std::max(n, 1)))) return rc;
+  if (n) GFS_HIP(hipMemcpy(dk.p, keys, (size_t)n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_test_wave_std_sort, dim3(1), dim3(64), 0, 0, dk.p, n, dp.p);
+  GFS_HIP(hipGetLastError());
+  GFS_HIP(hipDeviceSynchronize());
+  if (n) GFS_HIP(hipMemcpy(perm_out, dp.p, (size_t)n * 2, hipMemcpyDeviceToHost));
+  return GFS_OK;
+}
+
 int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsigned* perm_out) {
   GFS_REQUIRE(h && keys && perm_out && n >= 0 && n <= h->P, GFS_ERR_INVALID_ARG, "gfs_test_voxel_sort: invalid argument");
   std::lock_guard<std::recursive_mutex> lk(h->mu);

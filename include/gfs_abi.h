@@ -232,6 +232,9 @@ int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset);
  * max_points caller keys (3 x 21-bit voxel fields, or all ones = invalid).  perm_out[i] = input index of the i-th
  * element of the sorted sequence. */
 int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsigned* perm_out);
+/* GPU test hook: the one-wave std::sort replica (csrc/wave_std_sort.hpp: the voxel sort's leaves, sort_omp.hpp:61, and the quadtree's
+ * (size, x) list, ORBextractor.cc:697-698) on n <= 1024 caller keys; perm_out[i] = original index of the element left at position i. */
+int gfs_test_wave_std_sort(int device, const unsigned* keys, int n, unsigned short* perm_out);
 
 /* ============================================================================================
  * 4. Local bundle adjustment — replaces the numeric core of Optimizer::LocalBundleAdjustment

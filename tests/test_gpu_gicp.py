@@ -82,6 +82,32 @@ def test_voxel_sort_permutation_against_the_compiled_reference(gpu_api, oracle):
         assert np.array_equal(got, want), (name, int((got != want).sum()), len(k))
 
 
+def test_wave_std_sort_is_libstdcxx_std_sort(gpu_api, oracle):
+    """csrc/wave_std_sort.hpp (one wave, LDS) against std::sort itself — the oracle's quick_sort_omp hands ranges below 1024
+    elements to std::sort (util/sort_omp.hpp:61) —: the permutation, not just the order, on keys with many ties, sorted / reversed
+    input, and McIlroy's adversary (depth limit -> heap sort)."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (0, 1, 2, 3, 15, 16, 17, 18, 33, 64, 65, 100, 127, 128, 129, 255, 300, 511, 700, 1000, 1023):
+        cases.append(rng.integers(0, 1 << 30, n))            # distinct
+        cases.append(rng.integers(0, max(n // 4, 1), n))     # ties
+        cases.append(rng.integers(0, 3, n))                  # heavy ties
+        cases.append(np.sort(rng.integers(0, max(n // 2, 1), n)))
+        cases.append(np.sort(rng.integers(0, max(n // 2, 1), n))[::-1])
+        cases.append(np.full(n, 5))
+    for n in (100, 500, 1000, 1023):
+        a = oracle.antiqsort_keys(n).astype(np.int64)
+        cases += [a, a // 2, a // 5]
+    for _ in range(200):  # the quadtree's lists: (size << 12 | x) with small sizes and a dozen x values
+        n = int(rng.integers(2, 400))
+        cases.append((rng.integers(2, 12, n) << 12) | (rng.integers(0, 10, n) * 37))
+    for k in cases:
+        k = np.asarray(k, np.uint32)
+        got = gpu_api.wave_std_sort_perm(k)
+        want, _ = oracle.quick_sort_perm(k.astype(np.uint64))
+        assert np.array_equal(got, np.asarray(want, np.int64)), (len(k), int((got != want).sum()))
+
+
 def test_preprocess_stage_matches_oracle(gpu_api, oracle):
     """Voxel means bit-identical to the (unmodified, reference-order) oracle — same permutation of equal voxel keys, same
     1024-block splits, same summation order — and covariances equal to 1e-9."""
