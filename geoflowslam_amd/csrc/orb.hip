@@ -581,12 +581,16 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
   // of short dependent phases, so it is the number of workgroups a CU holds at once that sets its speed (97 B a node: 6
   // workgroups a CU for 1000 features; the fixed 768-entry tables allowed 2)
   extern __shared__ __align__(16) unsigned char oct_lds[];
-  ONode* s_nodes[2] = {(ONode*)oct_lds, (ONode*)oct_lds + node_cap};
-  U128* s_start = (U128*)(s_nodes[1] + node_cap);
+  // (the two node buffers and the two list buffers are addressed as base + index * node_cap: a run-time pick between two
+  // pointers kept in an array would turn every access into a FLAT one — 64-bit addresses, no LDS offsets)
+  ONode* const s_nodes0 = (ONode*)oct_lds;
+  auto s_nodes = [&](int w) { return s_nodes0 + (size_t)w * node_cap; };
+  U128* s_start = (U128*)(s_nodes0 + 2 * (size_t)node_cap);
   U128* s_end = s_start + node_cap;
   unsigned long long* s_npre = (unsigned long long*)(s_end + node_cap);  // per node: exclusive prefix of (children | multi << 20 | single << 40)
-  OVs* s_vs[2] = {(OVs*)(s_npre + node_cap), (OVs*)(s_npre + node_cap) + node_cap};
-  unsigned short(*s_newidx)[4] = (unsigned short(*)[4])(s_vs[1] + node_cap);
+  OVs* const s_vs0 = (OVs*)(s_npre + node_cap);
+  auto s_vs = [&](int w) { return s_vs0 + (size_t)w * node_cap; };
+  unsigned short(*s_newidx)[4] = (unsigned short(*)[4])(s_vs0 + 2 * (size_t)node_cap);
   unsigned char* s_proc = (unsigned char*)(s_newidx + node_cap);
   __shared__ U128 s_w128[4];
   __shared__ gfs::SortFrame s_stack[32];  // 2 lg(768) + 1 = 19 pending parts at most
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
     root.y1 = (short)height;
     root.kb = 0;
     root.ke = n;
-    s_nodes[0][0] = root;
+    s_nodes(0)[0] = root;
   }
   __syncthreads();
   int cur = 0, pc = 0, nn = 1;  // node-buffer index, permutation-buffer index, number of nodes in the list
@@ -700,8 +704,8 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
   constexpr int kOctChunk = 16;
   const bool cached = chunk <= kOctChunk;
   auto sweep = [&](bool init) {
-    const ONode* nodes = s_nodes[cur];
-    ONode* nxt = s_nodes[cur ^ 1];
+    const ONode* nodes = s_nodes(cur);
+    ONode* nxt = s_nodes(cur ^ 1);
     const uint32_t* pa = perm[pc];
     const unsigned short* sa = seg[pc];
     uint32_t kreg[kOctChunk];
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
           nxt[pos] = ch;
           s_newidx[i][q] = (unsigned short)pos;
           if (cnt[q] > 1) {
-            s_vs[vcur][Mx + mrank] = OVs{(int)cnt[q], ch.x0, (short)pos};
+            s_vs(vcur)[Mx + mrank] = OVs{(int)cnt[q], ch.x0, (short)pos};
             mrank++;
           }
           kb += (int)cnt[q];
@@ -904,9 +908,9 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
     } else if (nn + nvs * 3 > N) {
       while (!finish) {  // :690-744
         const int prev2 = nn;
-        OVs* vs = s_vs[vcur];
+        OVs* vs = s_vs(vcur);
         const int V = nvs;
-        ONode* nodes = s_nodes[cur];
+        ONode* nodes = s_nodes(cur);
         // sort(vSizeAndPointerToNode) :697-698 with compareNodes :552-565 (size, then UL.x: many entries are equivalent, so the
         // result is libstdc++'s own sequence of moves).  One wave replays std::sort on the packed keys (size << 12 | x), the
         // entries follow their keys; its LDS scratch is the sweeps' s_start / s_end, idle here.
@@ -992,8 +996,8 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
         unsigned long long ptot;
         unsigned long long pbase = oct_scan_u64(lsum2, s_w64, &ptot);
         const int T = (int)(ptot & 0xfffff), Mtot = (int)((ptot >> 20) & 0xfffff);
-        ONode* nxt = s_nodes[cur ^ 1];
-        OVs* vnew = s_vs[vcur ^ 1];
+        ONode* nxt = s_nodes(cur ^ 1);
+        OVs* vnew = s_vs(vcur ^ 1);
         for (int k = k0; k < k1; k++) {
           if (k >= t) break;
           const int j = V - 1 - k;
@@ -1074,7 +1078,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
     }
   }
   // retain the best point of each node, first maximum wins (:751-765)
-  const ONode* nodes = s_nodes[cur];
+  const ONode* nodes = s_nodes(cur);
   uint32_t* out = kept + (size_t)b * kp_cap + kept_off[l];
   for (int i = tid; i < nn; i += kOctThreads) {
     const ONode nd = nodes[i];
