@@ -614,8 +614,13 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
     n = off[l + 1] - off[l];
     region = (size_t)off[l];
   }
-  uint32_t* perm[2] = {perm0 + (size_t)b * cand_frame + region, perm1 + (size_t)b * cand_frame + region};
-  unsigned short* seg[2] = {seg0 + (size_t)b * cand_frame + region, seg1 + (size_t)b * cand_frame + region};
+  // (a pick between two pointers, not an array of them: the loads stay GLOBAL instructions)
+  uint32_t* const perm_a = perm0 + (size_t)b * cand_frame + region;
+  uint32_t* const perm_b = perm1 + (size_t)b * cand_frame + region;
+  unsigned short* const seg_a = seg0 + (size_t)b * cand_frame + region;
+  unsigned short* const seg_b = seg1 + (size_t)b * cand_frame + region;
+  auto perm = [&](int w) { return w ? perm_b : perm_a; };
+  auto seg = [&](int w) { return w ? seg_b : seg_a; };
   if (cells) {
     const int* cnt = cell_cnt + (size_t)b * n_cells + L.cell_base;
     const uint32_t* sl = slab + (size_t)b * cand_frame;
@@ -642,8 +647,8 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
 #pragma unroll
           for (int u = 0; u < 8; u++)
             if (i0 + u < my) {
-              perm[0][base + i0 + u] = t[u];
-              seg[0][base + i0 + u] = 0;
+              perm(0)[base + i0 + u] = t[u];
+              seg(0)[base + i0 + u] = 0;
             }
         }
       }
@@ -668,8 +673,8 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
   const int p0 = min(tid * chunk, n), p1 = min(p0 + chunk, n);
   if (c)
     for (int p = p0; p < p1; p++) {
-      perm[0][p] = c[p];  // the permutation arrays carry the keys themselves: no gather through an index in the sweeps
-      seg[0][p] = 0;
+      perm(0)[p] = c[p];  // the permutation arrays carry the keys themselves: no gather through an index in the sweeps
+      seg(0)[p] = 0;
     }
   if (tid == 0) {
     ONode root;
@@ -706,8 +711,8 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
   auto sweep = [&](bool init) {
     const ONode* nodes = s_nodes(cur);
     ONode* nxt = s_nodes(cur ^ 1);
-    const uint32_t* pa = perm[pc];
-    const unsigned short* sa = seg[pc];
+    const uint32_t* pa = perm(pc);
+    const unsigned short* sa = seg(pc);
     uint32_t kreg[kOctChunk];
     int nreg[kOctChunk];
     unsigned qbits = 0, abits = 0;  // per cached key: its quadrant (2 bits), and whether its node is being divided
@@ -844,8 +849,8 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
     }
     __syncthreads();
     // 4. stable scatter of the keys into their child ranges
-    uint32_t* pb = perm[pc ^ 1];
-    unsigned short* sb = seg[pc ^ 1];
+    uint32_t* pb = perm(pc ^ 1);
+    unsigned short* sb = seg(pc ^ 1);
     run = base;
     if (cached) {
 #pragma unroll
@@ -958,12 +963,12 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
           if (k1 - k0 == 1 && nd.ke - nd.kb <= kOctChunk) {
             have = true;
 #pragma unroll
-            for (int u = 0; u < kOctChunk; u++) nkey[u] = nd.kb + u < nd.ke ? perm[pc][nd.kb + u] : 0u;
+            for (int u = 0; u < kOctChunk; u++) nkey[u] = nd.kb + u < nd.ke ? perm(pc)[nd.kb + u] : 0u;
 #pragma unroll
             for (int u = 0; u < kOctChunk; u++)
               if (nd.kb + u < nd.ke) pk += 1ull << (16 * oct_quadrant(nd, nkey[u]));
           } else {
-            for_keys(perm[pc], nd.kb, nd.ke, [&](int, uint32_t key) { pk += 1ull << (16 * oct_quadrant(nd, key)); });
+            for_keys(perm(pc), nd.kb, nd.ke, [&](int, uint32_t key) { pk += 1ull << (16 * oct_quadrant(nd, key)); });
           }
           int cc = 0, mm = 0;
           for (int q = 0; q < 4; q++) {
@@ -1009,8 +1014,8 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
           pbase += v;
           const int ci = (int)(v & 0xfffff);
           // stable 4-way partition of this node's keys (through the other permutation buffer, then back)
-          uint32_t* pa = perm[pc];  // partitioned through the other buffer and copied back: pc does not flip here
-          uint32_t* pb = perm[pc ^ 1];
+          uint32_t* pa = perm(pc);  // partitioned through the other buffer and copied back: pc does not flip here
+          uint32_t* pb = perm(pc ^ 1);
           unsigned long long pk = 0;  // four 16-bit quadrant counters, then the four running positions
           if (have) {
 #pragma unroll
@@ -1082,11 +1087,11 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
   uint32_t* out = kept + (size_t)b * kp_cap + kept_off[l];
   for (int i = tid; i < nn; i += kOctThreads) {
     const ONode nd = nodes[i];
-    uint32_t best = perm[pc][nd.kb];
+    uint32_t best = perm(pc)[nd.kb];
     for (int pb_ = nd.kb + 1; pb_ < nd.ke; pb_ += 8) {  // eight loads in flight
       uint32_t t[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) t[u] = pb_ + u < nd.ke ? perm[pc][pb_ + u] : 0u;
+      for (int u = 0; u < 8; u++) t[u] = pb_ + u < nd.ke ? perm(pc)[pb_ + u] : 0u;
 #pragma unroll
       for (int u = 0; u < 8; u++)
         if (pb_ + u < nd.ke && (t[u] >> 24) > (best >> 24)) best = t[u];
