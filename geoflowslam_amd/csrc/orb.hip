@@ -551,10 +551,16 @@ __device__ __forceinline__ ONode oct_child(const ONode& nd, int q) {
   return c;
 }
 
-// (out of line: the sort's own register arrays are then not part of k_octree's live state around the call)
-__device__ __attribute__((noinline)) void oct_sort_wave(unsigned* K, unsigned short* Pm, unsigned short* l0, unsigned short* l1,
-                                                        unsigned short* cl, unsigned short* st, int n) {
-  vqs::wave_std_sort<unsigned>(K, Pm, l0, l1, cl, st, n);
+// k_octree's dynamic LDS (declared here for oct_sort_wave)
+extern __shared__ __align__(16) unsigned char oct_lds[];
+
+// (out of line: the sort's own register arrays are then not part of k_octree's live state around the call.  Its work arrays are
+// named by their offset in oct_lds, not by pointers: pointer arguments would arrive as GENERIC ones and every access of the sort
+// would be a FLAT instruction)
+__device__ __attribute__((noinline)) void oct_sort_wave(unsigned lds_off, int n) {
+  unsigned* K = reinterpret_cast<unsigned*>(oct_lds + lds_off);
+  unsigned short* Pm = reinterpret_cast<unsigned short*>(K + n);
+  vqs::wave_std_sort<unsigned>(K, Pm, Pm + n, Pm + 2 * n, Pm + 3 * n, Pm + 4 * n, n);
 }
 
 #ifdef GFS_OCT_TIMING
@@ -580,7 +586,6 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
   // node tables in dynamic LDS, node_cap entries each (the largest level's quota + slack, oct_lds_bytes): the kernel is a chain
   // of short dependent phases, so it is the number of workgroups a CU holds at once that sets its speed (97 B a node: 6
   // workgroups a CU for 1000 features; the fixed 768-entry tables allowed 2)
-  extern __shared__ __align__(16) unsigned char oct_lds[];
   // (the two node buffers and the two list buffers are addressed as base + index * node_cap: a run-time pick between two
   // pointers kept in an array would turn every access into a FLAT one — 64-bit addresses, no LDS offsets)
   ONode* const s_nodes0 = (ONode*)oct_lds;
@@ -922,13 +927,12 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
         if (V <= 1024 && (size_t)V * 12 + 256 <= (size_t)node_cap * 32) {
           unsigned* sk = (unsigned*)s_start;
           unsigned short* spm = (unsigned short*)(sk + V);
-          unsigned short *sl0 = spm + V, *sl1 = sl0 + V, *scl = sl1 + V, *sst = scl + V;
           for (int i = tid; i < V; i += kOctThreads) {
             sk[i] = ((unsigned)vs[i].size << 12) | (unsigned)vs[i].x0;  // x0 in [0, 4096), size <= n < 2^20
             spm[i] = (unsigned short)i;
           }
           __syncthreads();
-          if (tid < 64) oct_sort_wave(sk, spm, sl0, sl1, scl, sst, V);
+          if (tid < 64) oct_sort_wave((unsigned)((unsigned char*)s_start - oct_lds), V);  // K, Pm, l0, l1, cl, st laid out as above
           __syncthreads();
           OVs mine[4];  // V <= 1024 = 4 x 256
 #pragma unroll
