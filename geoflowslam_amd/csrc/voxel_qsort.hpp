@@ -365,8 +365,13 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   // Two copies of (key, point index): a partition sweep reads one and writes the other (elements are re-read in every step of a
   // sweep, coalesced and from L2, rather than held in registers: it keeps the kernel at 2 workgroups per compute unit)
   unsigned* kscr = kscr_all + (size_t)c * P;
-  unsigned* kbuf[2] = {kscr, (unsigned*)(side_all + (size_t)c * P)};
-  unsigned* vbuf[2] = {va, (unsigned*)(side_all + (size_t)c * P) + P};
+  // (picked by a select, not kept in an array of pointers: the accesses stay GLOBAL instructions instead of FLAT ones)
+  unsigned* const kbuf0 = kscr;
+  unsigned* const kbuf1 = (unsigned*)(side_all + (size_t)c * P);
+  unsigned* const vbuf0 = va;
+  unsigned* const vbuf1 = (unsigned*)(side_all + (size_t)c * P) + P;
+  auto kbuf = [&](int w) { return w ? kbuf1 : kbuf0; };
+  auto vbuf = [&](int w) { return w ? vbuf1 : vbuf0; };
   int cur = 0;
   unsigned* leaf = leaf_all + (size_t)c * P;
   if (tid < 3) {
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
     if (nseg == 0) break;
     if (tid < nseg) {
       const int b = seg_b[tid], len = seg_e[tid] - b, off = len / 8;  // sort_omp.hpp:70-75
-      const unsigned* f = kbuf[cur] + b;
+      const unsigned* f = kbuf(cur) + b;
       auto m3 = [](unsigned x, unsigned y, unsigned z) { return x < y ? (y < z ? y : (x < z ? z : x)) : (x < z ? x : (y < z ? z : y)); };
       const unsigned m1 = m3(f[0], f[off], f[off * 2]), m2 = m3(f[off * 3], f[off * 4], f[off * 5]),
                      mm = m3(f[off * 6], f[off * 7], f[len - 1]);
@@ -461,10 +466,10 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
     // left) and the k-th misplaced element of the back part (from the right) announce their positions in side_pos and take
     // each other's place; everything else stays.  (All elements are in registers, so the scatter is in place.)
     auto partition_sweep = [&](int mode) {
-      const unsigned* kin = kbuf[cur];
-      const unsigned* vin = vbuf[cur];
-      unsigned* kout = kbuf[cur ^ 1];
-      unsigned* vout = vbuf[cur ^ 1];
+      const unsigned* kin = kbuf(cur);
+      const unsigned* vin = vbuf(cur);
+      unsigned* kout = kbuf(cur ^ 1);
+      unsigned* vout = vbuf(cur ^ 1);
       auto load_seg = [&](int sidx, bool with_counts) {
         SegP q;
         q.b = q.e = q.first = 0x7fffffff;
@@ -604,8 +609,8 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
             continue;
           }
           const int jt = q[t--];  // >= m1 + m by counting
-          unsigned* kc = kbuf[cur];
-          unsigned* vc = vbuf[cur];
+          unsigned* kc = kbuf(cur);
+          unsigned* vc = vbuf(cur);
           const unsigned kj = kc[j], vj = vc[j];
           kc[j] = kc[jt];
           vc[j] = vc[jt];
@@ -651,8 +656,8 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
   }
   // the keys go back as 64-bit compacted keys (k_voxel_qsort_leaf, k_voxel_reduce)
   {
-    const unsigned* kc = kbuf[cur];
-    const unsigned* vc = vbuf[cur];
+    const unsigned* kc = kbuf(cur);
+    const unsigned* vc = vbuf(cur);
     for (int i = tid; i < n; i += 1024) {
       const unsigned k = kc[i];
       const unsigned v = vc[i];
