@@ -43,60 +43,69 @@ struct LbaState {
   int phase, it;                 // batched entry: 0 = build next, 1 = trial next, 2 = done; index of the running LM iteration
 };
 
+// The descriptor's pointers carry the GLOBAL address space in device code: the batched kernels read their descriptor from an array
+// in memory, and pointers that come out of memory are otherwise GENERIC — every access through them a FLAT instruction (64-bit
+// VGPR addresses, both wait counters).  Host code (and the host functions as the device pass parses them) sees plain pointers and
+// assigns through a cast to the member's type.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GFS_GLOBAL __attribute__((address_space(1)))
+#else
+#define GFS_GLOBAL
+#endif
 struct LbaDev {
   // problem (edges landmark-major)
   int n_poses, n_points, n_edges, n_free;
-  const double* pose_q0;  // [n_poses][4]
-  const double* pose_t0;  // [n_poses][3]
-  const int* free_index;  // [n_poses] -> free slot or -1
-  const int* free_pose;   // [n_free]  -> pose
-  const double* points0;  // [n_points][3]
-  const int* e_pose;
-  const int* e_point;
-  const double* e_obs;  // [n_edges][3]
-  const double* e_w;    // inv_sigma2
-  const unsigned char* e_stereo;
-  const int* pt_begin;     // [n_points+1]
-  const int* pose_begin;   // [n_free+1]
-  const int* pose_edges;   // edge ids (landmark-major numbering), ascending, per free pose
-  const int* edge_of;      // [n_free][n_points] edge id or -1 (the FIRST edge of a (pose, landmark) pair)
-  const int* lm_wg;        // [n_lm_wg + 1] landmark ranges of the workgroups of b_build_landmarks (<= kMk edges each, or one landmark)
+  const GFS_GLOBAL double* pose_q0;  // [n_poses][4]
+  const GFS_GLOBAL double* pose_t0;  // [n_poses][3]
+  const GFS_GLOBAL int* free_index;  // [n_poses] -> free slot or -1
+  const GFS_GLOBAL int* free_pose;   // [n_free]  -> pose
+  const GFS_GLOBAL double* points0;  // [n_points][3]
+  const GFS_GLOBAL int* e_pose;
+  const GFS_GLOBAL int* e_point;
+  const GFS_GLOBAL double* e_obs;  // [n_edges][3]
+  const GFS_GLOBAL double* e_w;    // inv_sigma2
+  const GFS_GLOBAL unsigned char* e_stereo;
+  const GFS_GLOBAL int* pt_begin;     // [n_points+1]
+  const GFS_GLOBAL int* pose_begin;   // [n_free+1]
+  const GFS_GLOBAL int* pose_edges;   // edge ids (landmark-major numbering), ascending, per free pose
+  const GFS_GLOBAL int* edge_of;      // [n_free][n_points] edge id or -1 (the FIRST edge of a (pose, landmark) pair)
+  const GFS_GLOBAL int* lm_wg;        // [n_lm_wg + 1] landmark ranges of the workgroups of b_build_landmarks (<= kMk edges each, or one landmark)
   int n_lm_wg;
-  const int* e_dup;        // [n_edges] first edge of the same (pose, landmark) pair, -1 for a first edge; NULL: no duplicates
+  const GFS_GLOBAL int* e_dup;        // [n_edges] first edge of the same (pose, landmark) pair, -1 for a first edge; NULL: no duplicates
   double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
   int iterations;
   // state / workspace
-  double* q;    // [n_poses][4] current
-  double* t;    // [n_poses][3]
-  double* X;    // [n_points][3]
-  double* q_try;
-  double* t_try;
-  double* X_try;
-  double* chi2;   // [n_edges] last computeActiveErrors
-  double* err;    // [n_edges][3]
-  double* Hpl;    // [n_edges][18] row-major (6 pose rows x 3 point cols)
-  double* Hll;    // [n_points][6] symmetric (xx,xy,xz,yy,yz,zz)
-  double* bl;     // [n_points][3]
-  double* Dinv;   // [n_points][6]
-  double* Hpp;    // [n_free][21] upper triangle row-major
-  double* bp;     // [n_free][6]
-  double* xl;     // [n_points][3]
-  double* xp;     // [n_free*6]
-  volatile int* stop;  // host-mapped force-stop flag
-  int* out_info;       // [0]=iterations_run [1]=failed flag
-  double* out_stats;   // [0]=final chi2 [1]=final lambda
+  GFS_GLOBAL double* q;    // [n_poses][4] current
+  GFS_GLOBAL double* t;    // [n_poses][3]
+  GFS_GLOBAL double* X;    // [n_points][3]
+  GFS_GLOBAL double* q_try;
+  GFS_GLOBAL double* t_try;
+  GFS_GLOBAL double* X_try;
+  GFS_GLOBAL double* chi2;   // [n_edges] last computeActiveErrors
+  GFS_GLOBAL double* err;    // [n_edges][3]
+  GFS_GLOBAL double* Hpl;    // [n_edges][18] row-major (6 pose rows x 3 point cols)
+  GFS_GLOBAL double* Hll;    // [n_points][6] symmetric (xx,xy,xz,yy,yz,zz)
+  GFS_GLOBAL double* bl;     // [n_points][3]
+  GFS_GLOBAL double* Dinv;   // [n_points][6]
+  GFS_GLOBAL double* Hpp;    // [n_free][21] upper triangle row-major
+  GFS_GLOBAL double* bp;     // [n_free][6]
+  GFS_GLOBAL double* xl;     // [n_points][3]
+  GFS_GLOBAL double* xp;     // [n_free*6]
+  volatile GFS_GLOBAL int* stop;  // host-mapped force-stop flag
+  GFS_GLOBAL int* out_info;       // [0]=iterations_run [1]=failed flag
+  GFS_GLOBAL double* out_stats;   // [0]=final chi2 [1]=final lambda
   int mode;            // 0 = full solve, 1 = linearise only
   // multi-kernel path (one launch per phase, all CUs): LM state, per-block partial sums, the reduced system in HBM
-  struct LbaState* S;
-  double* part_chi;    // [n_err_blocks] robust chi2 partial sums of the last k_lba_errors
-  double* part_scale;  // [n_upd_blocks] computeScale partial sums of the last k_lba_update
-  double* Hs;          // packed lower triangle of the Schur complement (6 n_free)^2 / 2
-  double* bs;          // [6 n_free]
+  GFS_GLOBAL struct LbaState* S;
+  GFS_GLOBAL double* part_chi;    // [n_err_blocks] robust chi2 partial sums of the last k_lba_errors
+  GFS_GLOBAL double* part_scale;  // [n_upd_blocks] computeScale partial sums of the last k_lba_update
+  GFS_GLOBAL double* Hs;          // packed lower triangle of the Schur complement (6 n_free)^2 / 2
+  GFS_GLOBAL double* bs;          // [6 n_free]
   int n_err_blocks, n_upd_blocks;
-  double* out_pack;  // results in one block: chi2 [n_edges], q [n_poses][4], t [n_poses][3], X [n_points][3], chi2 / lambda, iterations / buffer
+  GFS_GLOBAL double* out_pack;  // results in one block: chi2 [n_edges], q [n_poses][4], t [n_poses][3], X [n_points][3], chi2 / lambda, iterations / buffer
   // Schur products by landmark chunks: partial blocks [chunk][pose pair][36] and right-hand sides [chunk][free pose][6]
-  double* schur_part;
-  double* schur_part_b;
+  GFS_GLOBAL double* schur_part;
+  GFS_GLOBAL double* schur_part_b;
   int n_schur_chunks, n_pair_tiles, schur_sub;  // chunks of kSchurPts landmarks; tiles of kMk pose pairs; landmarks staged at a time
   int schur_mfma;  // 1: b_schur_mfma (n_schur_chunks chunks of kSchurMPts landmarks, n_pair_tiles = 128 x 128 blocks of the lower triangle)
 };
@@ -1857,22 +1866,22 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
   if (do_upload && (rc = upload(h, P, s))) return rc;
   D = LbaDev{};
   auto dev = [&](const void* host) { return (const void*)(h->d_in.p + ((const unsigned char*)host - h->h_stage.p)); };
-  D.pose_q0 = (const double*)dev(P.q0);
-  D.pose_t0 = (const double*)dev(P.t0);
-  D.points0 = (const double*)dev(P.X0);
-  D.free_index = (const int*)dev(P.free_index);
-  D.free_pose = (const int*)dev(P.free_pose);
-  D.e_pose = (const int*)dev(P.e_pose);
-  D.e_point = (const int*)dev(P.e_point);
-  D.e_obs = (const double*)dev(P.obs);
-  D.e_w = (const double*)dev(P.w);
-  D.pt_begin = (const int*)dev(P.pt_begin);
-  D.pose_begin = (const int*)dev(P.pose_begin);
-  D.pose_edges = (const int*)dev(P.pose_edges);
-  D.edge_of = (const int*)dev(P.edge_of);
-  D.e_stereo = (const unsigned char*)dev(P.stereo);
-  D.e_dup = P.e_dup ? (const int*)dev(P.e_dup) : nullptr;
-  D.lm_wg = (const int*)dev(P.lm_wg);
+  D.pose_q0 = (decltype(D.pose_q0))((const double*)dev(P.q0));
+  D.pose_t0 = (decltype(D.pose_t0))((const double*)dev(P.t0));
+  D.points0 = (decltype(D.points0))((const double*)dev(P.X0));
+  D.free_index = (decltype(D.free_index))((const int*)dev(P.free_index));
+  D.free_pose = (decltype(D.free_pose))((const int*)dev(P.free_pose));
+  D.e_pose = (decltype(D.e_pose))((const int*)dev(P.e_pose));
+  D.e_point = (decltype(D.e_point))((const int*)dev(P.e_point));
+  D.e_obs = (decltype(D.e_obs))((const double*)dev(P.obs));
+  D.e_w = (decltype(D.e_w))((const double*)dev(P.w));
+  D.pt_begin = (decltype(D.pt_begin))((const int*)dev(P.pt_begin));
+  D.pose_begin = (decltype(D.pose_begin))((const int*)dev(P.pose_begin));
+  D.pose_edges = (decltype(D.pose_edges))((const int*)dev(P.pose_edges));
+  D.edge_of = (decltype(D.edge_of))((const int*)dev(P.edge_of));
+  D.e_stereo = (decltype(D.e_stereo))((const unsigned char*)dev(P.stereo));
+  D.e_dup = (decltype(D.e_dup))(P.e_dup ? (const int*)dev(P.e_dup) : nullptr);
+  D.lm_wg = (decltype(D.lm_wg))((const int*)dev(P.lm_wg));
   D.n_lm_wg = P.n_lm_wg;
   D.n_poses = p->n_poses;
   D.n_points = NP;
@@ -1886,35 +1895,35 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
   D.huber_mono = p->huber_mono;
   D.huber_stereo = p->huber_stereo;
   D.iterations = p->iterations;
-  D.q = h->d_q.p;
-  D.t = h->d_t.p;
-  D.X = h->d_X.p;
-  D.q_try = h->d_qt.p;
-  D.t_try = h->d_tt.p;
-  D.X_try = h->d_Xt.p;
-  D.chi2 = h->d_chi2.p;
-  D.err = h->d_err.p;
-  D.Hpl = h->d_Hpl.p;
-  D.Hll = h->d_Hll.p;
-  D.bl = h->d_bl.p;
-  D.Dinv = h->d_Dinv.p;
-  D.Hpp = h->d_Hpp.p;
-  D.bp = h->d_bp.p;
-  D.xl = h->d_xl.p;
-  D.xp = h->d_xp.p;
+  D.q = (decltype(D.q))(h->d_q.p);
+  D.t = (decltype(D.t))(h->d_t.p);
+  D.X = (decltype(D.X))(h->d_X.p);
+  D.q_try = (decltype(D.q_try))(h->d_qt.p);
+  D.t_try = (decltype(D.t_try))(h->d_tt.p);
+  D.X_try = (decltype(D.X_try))(h->d_Xt.p);
+  D.chi2 = (decltype(D.chi2))(h->d_chi2.p);
+  D.err = (decltype(D.err))(h->d_err.p);
+  D.Hpl = (decltype(D.Hpl))(h->d_Hpl.p);
+  D.Hll = (decltype(D.Hll))(h->d_Hll.p);
+  D.bl = (decltype(D.bl))(h->d_bl.p);
+  D.Dinv = (decltype(D.Dinv))(h->d_Dinv.p);
+  D.Hpp = (decltype(D.Hpp))(h->d_Hpp.p);
+  D.bp = (decltype(D.bp))(h->d_bp.p);
+  D.xl = (decltype(D.xl))(h->d_xl.p);
+  D.xp = (decltype(D.xp))(h->d_xp.p);
   int* d_stop = nullptr;
   GFS_HIP(hipHostGetDevicePointer((void**)&d_stop, h->h_stop, 0));
   *h->h_stop = 0;
-  D.stop = d_stop;
-  D.out_info = h->d_info.p;
-  D.out_stats = h->d_stats.p;
-  D.out_pack = h->d_out.p;
+  D.stop = (decltype(D.stop))(d_stop);
+  D.out_info = (decltype(D.out_info))(h->d_info.p);
+  D.out_stats = (decltype(D.out_stats))(h->d_stats.p);
+  D.out_pack = (decltype(D.out_pack))(h->d_out.p);
   D.mode = mode;
-  D.S = h->d_state.p;
-  D.part_chi = h->d_part_chi.p;
-  D.part_scale = h->d_part_scale.p;
-  D.Hs = h->d_Hs.p;
-  D.bs = h->d_bs.p;
+  D.S = (decltype(D.S))(h->d_state.p);
+  D.part_chi = (decltype(D.part_chi))(h->d_part_chi.p);
+  D.part_scale = (decltype(D.part_scale))(h->d_part_scale.p);
+  D.Hs = (decltype(D.Hs))(h->d_Hs.p);
+  D.bs = (decltype(D.bs))(h->d_bs.p);
   D.n_err_blocks = gfs::div_up(std::max(E, 1), kMk);
   D.n_upd_blocks = gfs::div_up(std::max(NP, 1), kMk);
   // Schur products: on the matrix cores by landmark chunks (b_schur_mfma), GFS_LBA_SCHUR=chunks | pairs select the vector kernels
@@ -1954,8 +1963,8 @@ int upload_and_fill(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int
         GFS_HIP(hipStreamSynchronize(s));
         if ((rc = h->d_schur_part_b.alloc(need_b + need_b / 4))) return rc;
       }
-      D.schur_part = h->d_schur_part.p;
-      D.schur_part_b = h->d_schur_part_b.p;
+      D.schur_part = (decltype(D.schur_part))(h->d_schur_part.p);
+      D.schur_part_b = (decltype(D.schur_part_b))(h->d_schur_part_b.p);
     }
   }
   return GFS_OK;
@@ -2333,7 +2342,11 @@ static int lba_solve_batch_impl(gfs_lba_batch* b, const gfs_lba_problem* problem
     LbaDev D;
     const int rc = upload_and_fill(b->win[w], &problems[w], b->prep[w], 0, s, D, false);
     if (rc) return rc;
-    GFS_HIP(hipHostGetDevicePointer((void**)&D.stop, b->win[w]->h_stop, 0));
+    {
+      void* dstop = nullptr;
+      GFS_HIP(hipHostGetDevicePointer(&dstop, b->win[w]->h_stop, 0));
+      D.stop = (decltype(D.stop))dstop;
+    }
     *b->win[w]->h_stop = 0;
     b->h_desc.p[w] = D;
     max_free = std::max(max_free, D.n_free);
