@@ -120,7 +120,21 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area(const LevelDev* __rest
     uint8_t* dst = pyr + (size_t)b * pyr_frame + L.plane_off;
     // thread <-> (column, row phase): the column's taps (start, count, four weights) stay in registers down the strip, the
     // row's taps are the same for (nearly) every lane of a wave; per pixel that leaves the source bytes and the arithmetic
-    const int ncolt = min(L.cols, kPyrThreads), rows_par = kPyrThreads / ncolt;
+    // (ncolt columns x rows_par row phases <= 1024 threads, a thread walks q = ceil(cols / ncolt) columns: with one column a
+    // thread, a 533-column level — level 1 of a VGA frame, a third of all pixels — kept 491 of the 1024 threads idle; q is chosen
+    // for the most pixels per sweep of the workgroup)
+    int ncolt = min(L.cols, kPyrThreads), rows_par = kPyrThreads / ncolt;
+    {
+      int best = rows_par * L.cols;  // q = 1
+      for (int q = 2; q <= 8; q++) {
+        const int c = (L.cols + q - 1) / q, r = kPyrThreads / c;
+        if (c >= 64 && r * L.cols > best * q) {  // r * cols / q > best / 1
+          best = r * L.cols / q;
+          ncolt = c;
+          rows_par = r;
+        }
+      }
+    }
     const int cxi = tid % ncolt, ry = tid / ncolt;
     if (ry < rows_par) {
       for (int dx = cxi; dx < L.cols; dx += ncolt) {
@@ -133,16 +147,41 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area(const LevelDev* __rest
           const float4 ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)yi);
           const float ays[4] = {ay.x, ay.y, ay.z, ay.w};
           float sum = 0.f;
+          if constexpr (LDS) {
+            // Branch-free: the weights beyond a pixel's nx / ny taps are 0 in the tables, every term is >= 0, so the extra
+            // products add +0.0 and the sum is OpenCV's bit for bit; the extra bytes are read from the LDS strip (or beyond it:
+            // whatever comes back is a finite byte).  One wait for all reads of a pixel instead of one per tap behind its own
+            // branch.  The fourth tap / row only exists for scale factors above 2: skipped when no lane of the wave has one.
+            const bool any_x4 = __ballot(nx > 3) != 0ull, any_y4 = __ballot(ny > 3) != 0ull;
+            // (the four bytes of a row are cut out of two ALIGNED words: left to itself the compiler fuses the byte reads into
+            // 16-bit reads at odd addresses, and the kernel ran 1.8x slower)
+            const int off0 = (int)((src + (size_t)sy0 * sp + sx0) - smem);
+            const uint32_t* smem32 = reinterpret_cast<const uint32_t*>(smem);
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (j < ny) {
-              const uint8_t* row = src + (size_t)(sy0 + j) * sp + sx0;
-              float buf = __fadd_rn(0.f, __fmul_rn((float)row[0], ax.x));
-              if (nx > 1) buf = __fadd_rn(buf, __fmul_rn((float)row[1], ax.y));
-              if (nx > 2) buf = __fadd_rn(buf, __fmul_rn((float)row[2], ax.z));
-              if (nx > 3) buf = __fadd_rn(buf, __fmul_rn((float)row[3], ax.w));
-              const float t = __fmul_rn(ays[j], buf);
-              sum = (j == 0) ? t : __fadd_rn(sum, t);
+            for (int j = 0; j < 4; j++) {
+              if (j < 3 || any_y4) {
+                const int o = off0 + j * sp;
+                const uint32_t v = __builtin_amdgcn_alignbit(smem32[(o >> 2) + 1], smem32[o >> 2], (o & 3) * 8);
+                float buf = __fadd_rn(0.f, __fmul_rn((float)(v & 0xffu), ax.x));
+                buf = __fadd_rn(buf, __fmul_rn((float)((v >> 8) & 0xffu), ax.y));
+                buf = __fadd_rn(buf, __fmul_rn((float)((v >> 16) & 0xffu), ax.z));
+                if (any_x4) buf = __fadd_rn(buf, __fmul_rn((float)(v >> 24), ax.w));
+                const float t = __fmul_rn(ays[j], buf);
+                sum = (j == 0) ? t : __fadd_rn(sum, t);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (j < ny) {
+                const uint8_t* row = src + (size_t)(sy0 + j) * sp + sx0;
+                float buf = __fadd_rn(0.f, __fmul_rn((float)row[0], ax.x));
+                if (nx > 1) buf = __fadd_rn(buf, __fmul_rn((float)row[1], ax.y));
+                if (nx > 2) buf = __fadd_rn(buf, __fmul_rn((float)row[2], ax.z));
+                if (nx > 3) buf = __fadd_rn(buf, __fmul_rn((float)row[3], ax.w));
+                const float t = __fmul_rn(ays[j], buf);
+                sum = (j == 0) ? t : __fadd_rn(sum, t);
+              }
             }
           }
           const int r = __float2int_rn(sum);  // cvRound: round-half-even
