@@ -937,8 +937,10 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
 // Two passes: <16, 2, true> takes k_knn_cov's list (front of hard_list, counter ginfo[7]) with one r = 2 probe and
 // defers the really isolated points (~1 % of the list, but thousands of candidates each) to <64, 4, false>
 // (back of hard_list, counter far2_count) so that they do not hold up the other queries of their workgroup.
+// (three waves a SIMD: left alone the kernel takes 205 VGPRs = two waves, and it waits on dependent cell lookups — 1.24 -> 0.99 ms
+// per 1 024 clouds with the cap, a 124-byte spill included; four waves: no further gain)
 template <int LANES, int R0, bool DEFER>
-__global__ __launch_bounds__(256) void k_knn_cov_far(const double4* __restrict__ pts, const u64* __restrict__ ucell,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_knn_cov_far(const double4* __restrict__ pts, const u64* __restrict__ ucell,
                                                      const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
                                                      const int* __restrict__ m_counts, const int* __restrict__ bbox,
                                                      const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
