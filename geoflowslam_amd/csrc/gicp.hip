@@ -466,9 +466,9 @@ __device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n,
 // ginfo = {gx0, gy0, gz0, nx, ny, nz, ok}.  Clouds whose box exceeds kGridCap cells keep the binary-search path.
 // ------------------------------------------------------------------------------------------------
 constexpr int kGridCap = 1 << 21;
-constexpr int kGridFillParts = 16;  // workgroups per cloud in k_grid_fill
+constexpr int kGridFillParts = 64;  // workgroups (of 256 threads: no LDS, no barrier — small ones find a CU sooner when other lanes' kernels are in flight) per cloud in k_grid_fill
 
-__global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
+__global__ __launch_bounds__(256) void k_grid_fill(const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
                                                     const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
                                                     const int* __restrict__ bbox, int P, unsigned* __restrict__ grid,
                                                     int* __restrict__ ginfo, int* __restrict__ far2_count, int only) {
@@ -501,17 +501,17 @@ __global__ __launch_bounds__(1024) void k_grid_fill(const u64* __restrict__ ucel
     return ((z - gz0) * (int)ny + (y - gy0)) * (int)nx + (x - gx0);
   };
   // every occupied cell fills the gap back to the previous occupied cell (lanes write contiguous entries); the cells
-  // are dealt to kGridFillParts x 16 waves
-  const int nwaves = 16 * kGridFillParts;
+  // are dealt to kGridFillParts x 4 waves
+  const int nwaves = 4 * kGridFillParts;
   const int per_wave = (nu + nwaves - 1) / nwaves;
-  const int u_begin = (part * 16 + wave) * per_wave, u_end = min(u_begin + per_wave, nu);
+  const int u_begin = (part * 4 + wave) * per_wave, u_end = min(u_begin + per_wave, nu);
   for (int u = u_begin; u < u_end; u++) {
     const int hi = lin(uc[u]), lo = u > 0 ? lin(uc[u - 1]) + 1 : 0;
     const unsigned v = ub[u];
     for (int k = lo + lane; k <= hi; k += 64) G[k] = v;
   }
   const int last = lin(uc[nu - 1]);
-  for (int k = last + 1 + part * 1024 + tid; k <= ncell; k += 1024 * kGridFillParts) G[k] = (unsigned)m;
+  for (int k = last + 1 + part * 256 + tid; k <= ncell; k += 256 * kGridFillParts) G[k] = (unsigned)m;
 }
 
 // points of row (y, z) whose cell x lies in [xlo, xhi] -> [*j0, *j1)
@@ -2379,7 +2379,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
              h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p,
              prm.only);
-  GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(kGridFillParts, C2), dim3(1024), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
+  GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(kGridFillParts, C2), dim3(256), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
              h->d_bbox.p, P, h->d_grid.p, h->d_ginfo.p, h->d_far2.p, prm.only);
   const int knn_chunks = gfs::div_up(npts, 128);
   GFS_LAUNCH("k_knn_cov", k_knn_cov, dim3(xcd_grid(knn_chunks, B, 2)), dim3(128), 0, s, h->d_pts.p, h->d_ucell.p,
