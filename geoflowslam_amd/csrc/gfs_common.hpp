@@ -109,6 +109,20 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
 }
+// Walks p[i0], p[i0 + stride], ... (index < n) with U loads in flight and hands every element to f(index, value) in index order.
+// A plain grid-stride loop over global memory is compiled into load - wait - use per trip: with the 17-odd trips a thread of a
+// one-workgroup-per-cloud kernel makes, that is 17 dependent round trips of ~1.5 us where two or three would do.
+template <int U, class T, class F>
+__device__ __forceinline__ void strided_batch(const T* p, int i0, int stride, int n, F&& f) {
+  for (int i = i0; i < n; i += U * stride) {
+    T t[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) t[u] = p[min(i + u * stride, n - 1)];  // (clamped: no branch in front of a load)
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (i + u * stride < n) f(i + u * stride, t[u]);
+  }
+}
 #endif
 
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

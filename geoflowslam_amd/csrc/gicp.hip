@@ -135,15 +135,14 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   __syncthreads();
   {
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
-    for (int i = tid; i < n; i += 1024) {
-      const u64 k = ka[i];
-      if (k == kInvalidKey) continue;
+    gfs::strided_batch<8>(ka, tid, 1024, n, [&](int, u64 k) {
+      if (k == kInvalidKey) return;
       const int f[3] = {(int)(k & ((1ull << sy) - 1)), (int)((k >> sy) & ((1ull << (sz - sy)) - 1)), (int)(k >> sz)};
       for (int a = 0; a < 3; a++) {
         mn[a] = min(mn[a], f[a]);
         mx[a] = max(mx[a], f[a]);
       }
-    }
+    });
     for (int a = 0; a < 3; a++) {  // one LDS atomic a wave
       mn[a] = gfs::wave_min_i32(mn[a]);
       mx[a] = gfs::wave_max_i32(mx[a]);
@@ -163,12 +162,11 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   };
   const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
             bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
-  for (int i = tid; i < n; i += 1024) {
-    const u64 k = ka[i];
-    if (k == kInvalidKey) continue;
+  gfs::strided_batch<8>(ka, tid, 1024, n, [&](int i, u64 k) {
+    if (k == kInvalidKey) return;
     const u64 x = (k & ((1ull << sy) - 1)) - mnx, y = ((k >> sy) & ((1ull << (sz - sy)) - 1)) - mny, z = (k >> sz) - mnz;
     ka[i] = x | (y << bx) | (z << (bx + by));
-  }
+  });
   if (tid == 0) {
     int* ki = kinfo + 8 * c;
     ki[0] = mnx;
@@ -186,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
     for (int k = tid; k < kNB; k += 1024) hist[k] = 0;
     if (tid == 0) s_uniform = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[(unsigned)(ka[i] >> shift) & (kNB - 1)], 1u);
+    gfs::strided_batch<8>(ka, tid, 1024, n, [&](int, u64 k) { atomicAdd(&hist[(unsigned)(k >> shift) & (kNB - 1)], 1u); });
     __syncthreads();
     if (tid < kNB && hist[tid] == (unsigned)n) s_uniform = 1;
     __syncthreads();
@@ -384,7 +382,17 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
   u64* uc = ucell + (size_t)c * (P + 1);
   unsigned* ub = ubegin + (size_t)c * (P + 1);
   __syncthreads();
-  for (int i = tid; i < m; i += 1024) out[i] = tp[ci[i]];  // independent gathers, all in flight
+  for (int i = tid; i < m; i += 4 * 1024) {  // independent gathers, four in flight (a plain loop waits for every one of them)
+    unsigned ix[4];
+    double4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) ix[u] = ci[min(i + u * 1024, m - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = tp[ix[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + u * 1024 < m) out[i + u * 1024] = v[u];
+  }
   // every thread owns a contiguous chunk of the sorted keys: one block scan numbers the cell starts
   const int chunk = (m + 1023) / 1024;
   const int i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
@@ -404,26 +412,60 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
     cell_of(ck[i], bx_, by_, bz_);
     return ax != bx_ || ay != by_ || az != bz_;
   };
+  // (a chunk of at most kCbChunk keys — clouds of up to 20 480 points — is loaded once, all loads in flight, with the key in front
+  // of it; the two walks below then run from registers.  Larger chunks take the loops over global memory.)
+  constexpr int kCbChunk = 20;
+  const bool cached = chunk <= kCbChunk;
+  u64 kc[kCbChunk + 1];  // kc[j] = key i0 - 1 + j
+  unsigned newbits = 0;  // bit j: key i0 + j starts a cell
+  if (cached) {
+#pragma unroll
+    for (int j = 0; j <= kCbChunk; j++) kc[j] = ck[min(max(i0 - 1 + j, 0), max(m - 1, 0))];
+  }
   int cnt = 0;
-  for (int i = i0; i < i1; i++) cnt += new_cell(i) ? 1 : 0;
+  if (cached) {
+    int px, py, pz;
+    cell_of(kc[0], px, py, pz);
+#pragma unroll
+    for (int j = 0; j < kCbChunk; j++) {
+      if (i0 + j < i1) {
+        int qx, qy, qz;
+        cell_of(kc[j + 1], qx, qy, qz);
+        const bool nw = i0 + j == 0 || px != qx || py != qy || pz != qz;
+        newbits |= (nw ? 1u : 0u) << j;
+        px = qx;
+        py = qy;
+        pz = qz;
+      }
+    }
+    cnt = __popc(newbits);
+  } else {
+    for (int i = i0; i < i1; i++) cnt += new_cell(i) ? 1 : 0;
+  }
   int total;
   int pos = block_scan_1024(cnt, s_wave, &total);
   {
     int mn[3] = {kCoordMask, kCoordMask, kCoordMask}, mx[3] = {0, 0, 0};
-    for (int i = i0; i < i1; i++) {
-      if (new_cell(i)) {
-        int kx, ky, kz;
-        cell_of(ck[i], kx, ky, kz);
-        uc[pos] = pack_key(kx, ky, kz);
-        ub[pos] = (unsigned)i;
-        pos++;
-        mn[0] = min(mn[0], kx);
-        mn[1] = min(mn[1], ky);
-        mn[2] = min(mn[2], kz);
-        mx[0] = max(mx[0], kx);
-        mx[1] = max(mx[1], ky);
-        mx[2] = max(mx[2], kz);
-      }
+    auto emit = [&](int i, u64 key) {
+      int kx, ky, kz;
+      cell_of(key, kx, ky, kz);
+      uc[pos] = pack_key(kx, ky, kz);
+      ub[pos] = (unsigned)i;
+      pos++;
+      mn[0] = min(mn[0], kx);
+      mn[1] = min(mn[1], ky);
+      mn[2] = min(mn[2], kz);
+      mx[0] = max(mx[0], kx);
+      mx[1] = max(mx[1], ky);
+      mx[2] = max(mx[2], kz);
+    };
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < kCbChunk; j++)
+        if ((newbits >> j) & 1u) emit(i0 + j, kc[j + 1]);
+    } else {
+      for (int i = i0; i < i1; i++)
+        if (new_cell(i)) emit(i, ck[i]);
     }
     for (int a = 0; a < 3; a++) {  // one LDS atomic a wave (threads without a cell hold the neutral values)
       mn[a] = gfs::wave_min_i32(mn[a]);
