@@ -1104,11 +1104,13 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
 // cloud's compacted keys fit 31 bits (kinfo[5] <= 31; the invalid key becomes 0xffffffff), else u64; clouds of the
 // other width are skipped (both instantiations are launched).
 // ------------------------------------------------------------------------------------------------
+// (l0 / l1, the stopper lists of a partition: only their first K + 1 <= 512 entries are ever read — pair k is swapped while
+// L_k < R_k, and 512 disjoint pairs do not fit a range of < 1024 elements.  The stack of pending parts lives in a register, entry k
+// in lane k.  With 4-byte keys that is 40 KB a workgroup: four workgroups a CU instead of three.)
 template <typename KT>
 struct LeafLds {
   KT K[4][1024];
-  unsigned short Pm[4][1024], l0[4][1024], l1[4][1024], cl[4][1024];
-  unsigned short st[4][3 * 40];
+  unsigned short Pm[4][1024], l0[4][512], l1[4][512], cl[4][1024];
 };
 
 template <typename KT>
@@ -1131,7 +1133,9 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigne
   unsigned short* l0 = S.l0[wave];
   unsigned short* l1 = S.l1[wave];
   unsigned short* cl = S.cl[wave];
-  unsigned short* st = S.st[wave];
+  // stack of pending [lo, hi) parts with their depth budget: entry k = lane k's stk (lo | hi << 10 | depth << 21)
+  unsigned stk = 0;
+  auto stk_pack = [](int lo, int hi, int depth) { return (unsigned)lo | ((unsigned)hi << 10) | ((unsigned)depth << 21); };
   const u64 lt = lanemask_lt();
   for (int l = blockIdx.x * 4 + wave; l < nl; l += gridDim.x * 4) {
     const int b = __builtin_amdgcn_readfirstlane((int)leaf[2 * l]), n = __builtin_amdgcn_readfirstlane((int)leaf[2 * l + 1]) - b;
@@ -1143,17 +1147,13 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigne
     int lg = 0;
     for (int v = n; v > 1; v >>= 1) lg++;
     int sp = 0;
-    if (lane == 0) {
-      st[0] = 0;
-      st[1] = (unsigned short)n;
-      st[2] = (unsigned short)(2 * lg);
-    }
+    if (lane == 0) stk = stk_pack(0, n, 2 * lg);
     sp = 1;
     VQS_WAVE_SYNC();
     while (sp > 0) {  // __introsort_loop, the recursion on [cut, last) through a stack
       sp--;
-      int lo = __builtin_amdgcn_readfirstlane((int)st[3 * sp]), hi = __builtin_amdgcn_readfirstlane((int)st[3 * sp + 1]),
-          depth = __builtin_amdgcn_readfirstlane((int)st[3 * sp + 2]);
+      const unsigned top = (unsigned)__builtin_amdgcn_readlane((int)stk, __builtin_amdgcn_readfirstlane(sp));
+      int lo = (int)(top & 1023u), hi = (int)((top >> 10) & 2047u), depth = (int)(top >> 21);
       bool heaped = false;
       while (hi - lo > kIntroThreshold) {
         if constexpr (kNarrow) {
@@ -1176,9 +1176,8 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigne
               }
               total += len;
               if (sp == 0) break;
-              const int tlo = __builtin_amdgcn_readfirstlane((int)st[3 * (sp - 1)]),
-                        thi = __builtin_amdgcn_readfirstlane((int)st[3 * (sp - 1) + 1]),
-                        td = __builtin_amdgcn_readfirstlane((int)st[3 * (sp - 1) + 2]);
+              const unsigned nxt = (unsigned)__builtin_amdgcn_readlane((int)stk, __builtin_amdgcn_readfirstlane(sp - 1));
+              const int tlo = (int)(nxt & 1023u), thi = (int)((nxt >> 10) & 2047u), td = (int)(nxt >> 21);
               if (thi - tlo > 64 - total || (td == 0 && thi - tlo > kIntroThreshold)) break;
               sp--;
               blo = tlo;
@@ -1265,11 +1264,10 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigne
               const bool mgr = valid && lane == mylo && (myhi - mylo > kIntroThreshold);
               const u64 bm = __ballot(mgr);
               const int slot = sp + __popcll(bm & ltm);
-              if (mgr) {
-                st[3 * slot] = (unsigned short)(mypos0 + (mylo - myS));
-                st[3 * slot + 1] = (unsigned short)(mypos0 + (myhi - myS));
-                st[3 * slot + 2] = (unsigned short)mydepth;
-              }
+              // the managers push their entries to the lanes [sp, sp + count) (everybody else to lane 63: the stack is < 40 deep)
+              const int got = __builtin_amdgcn_ds_permute((mgr ? slot : 63) << 2,
+                                                          (int)stk_pack(mypos0 + (mylo - myS), mypos0 + (myhi - myS), mydepth));
+              if (lane >= sp && lane < sp + (int)__popcll(bm)) stk = (unsigned)got;
               sp += __popcll(bm);
             }
             VQS_WAVE_SYNC();
@@ -1330,8 +1328,8 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigne
           const bool geL = valid && !(K[valid ? iL : lo] < pv);
           const bool leR = valid && !(pv < K[valid ? iR : lo]);
           const u64 bL = __ballot(geL), bR = __ballot(leR);
-          if (geL) l0[cntL + __popcll(bL & lt)] = (unsigned short)iL;
-          if (leR) l1[cntR + __popcll(bR & lt)] = (unsigned short)iR;
+          if (geL && cntL + (int)__popcll(bL & lt) < 512) l0[cntL + __popcll(bL & lt)] = (unsigned short)iL;
+          if (leR && cntR + (int)__popcll(bR & lt) < 512) l1[cntR + __popcll(bR & lt)] = (unsigned short)iR;
           cntL += __popcll(bL);
           cntR += __popcll(bR);
         }
@@ -1362,11 +1360,7 @@ __global__ __launch_bounds__(256) void k_voxel_qsort_leaf(u64* keys_all, unsigne
           }
         }
         VQS_WAVE_SYNC();
-        if (lane == 0) {
-          st[3 * sp] = (unsigned short)cut;
-          st[3 * sp + 1] = (unsigned short)hi;
-          st[3 * sp + 2] = (unsigned short)depth;
-        }
+        if (lane == sp) stk = stk_pack(cut, hi, depth);
         sp++;
         VQS_WAVE_SYNC();
         hi = cut;
