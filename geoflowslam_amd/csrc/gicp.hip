@@ -488,7 +488,9 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
 // ------------------------------------------------------------------------------------------------
 // cell-grid helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n, u64 key) {
+// (out of line: the path of clouds whose bounding box exceeds the dense grid — dozens of inlined copies of this loop made the search
+// kernels a third longer than what they execute)
+__device__ __attribute__((noinline)) int lower_bound_u64(const u64* __restrict__ a, int n, u64 key) {
   int lo = 0, hi = n;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
