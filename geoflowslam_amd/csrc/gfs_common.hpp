@@ -112,8 +112,10 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // Walks p[i0], p[i0 + stride], ... (index < n) with U loads in flight and hands every element to f(index, value) in index order.
 // A plain grid-stride loop over global memory is compiled into load - wait - use per trip: with the 17-odd trips a thread of a
 // one-workgroup-per-cloud kernel makes, that is 17 dependent round trips of ~1.5 us where two or three would do.
-template <int U, class T, class F>
-__device__ __forceinline__ void strided_batch(const T* p, int i0, int stride, int n, F&& f) {
+// (P: any pointer type — an address-space-qualified one keeps its address space; decltype(+p[0]) is the plain element type)
+template <int U, class P, class F>
+__device__ __forceinline__ void strided_batch(P p, int i0, int stride, int n, F&& f) {
+  using T = decltype(+p[0]);
   for (int i = i0; i < n; i += U * stride) {
     T t[U];
 #pragma unroll

@@ -1203,7 +1203,8 @@ __device__ __forceinline__ void b_solve_lds(const LbaDev& D) {
   double* bs = Hs + (size_t)n * (n + 1) / 2;      // [n]
   double* invd = bs + n;                          // [n] 1 / d
   double* pan = invd + n;                         // [n][6] P = L D of the current block column
-  for (int k = threadIdx.x; k < n * (n + 1) / 2; k += kThreads) Hs[k] = D.Hs[k];
+  // (eight loads in flight: as a plain loop the 7 trips of a 120-row system are 7 dependent round trips)
+  gfs::strided_batch<8>(D.Hs, (int)threadIdx.x, kThreads, n * (n + 1) / 2, [&](int k, double v) { Hs[k] = v; });
   for (int k = threadIdx.x; k < n; k += kThreads) bs[k] = D.bs[k];
   if (threadIdx.x == 0) s_flag = 0;
   __syncthreads();
@@ -1323,8 +1324,7 @@ __device__ __forceinline__ void b_solve(const LbaDev& D) {
   double* Hs = kLds ? lds : D.Hs;
   double* bs = kLds ? lds + (size_t)n * (n + 1) / 2 : lds;
   double* pan = lds + n;  // !kLds only: panel rows [n][6] followed by the 6 pivots
-  if (kLds)
-    for (int k = threadIdx.x; k < n * (n + 1) / 2; k += kThreads) Hs[k] = D.Hs[k];
+  if (kLds) gfs::strided_batch<8>(D.Hs, (int)threadIdx.x, kThreads, n * (n + 1) / 2, [&](int k, double v) { Hs[k] = v; });
   for (int k = threadIdx.x; k < n; k += kThreads) bs[k] = D.bs[k];
   if (threadIdx.x == 0) s_flag = 0;
   __syncthreads();
