@@ -1382,6 +1382,8 @@ __device__ __forceinline__ int round_half_away(float x) {  // std::round(float) 
   return (int)r;
 }
 
+constexpr int kObGroup = 16;                    // lanes per key point
+constexpr int kObPerWg = 256 / kObGroup;        // key points per workgroup
 __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict__ levels, Lvl0 l0,
                                                       const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                       const uint8_t* __restrict__ blur, size_t blur_frame,
@@ -1390,10 +1392,14 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
                                                       const int8_t* __restrict__ ic_dv, int ic_n,
                                                       const int8_t* __restrict__ pattern, gfs_keypoint* __restrict__ kps,
                                                       uint8_t* __restrict__ desc) {
-  const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int b = blockIdx.y;
-  if (k >= kp_count[b]) return;
+  // Sixteen lanes per key point, four key points per wave: the per-key-point scalar work (fastAtan2, glibc's sincosf) is done for four
+  // of them at once instead of on 64 lanes for one; the pixel sums and the 256 tests are the same work either way.
+  const int sl = threadIdx.x & (kObGroup - 1);
+  const int b = blockIdx.y, n_kp = kp_count[b];
+  const int k_raw = blockIdx.x * kObPerWg + (threadIdx.x / kObGroup);
+  if ((int)(blockIdx.x * kObPerWg + (threadIdx.x >> 6) * (64 / kObGroup)) >= n_kp) return;  // the wave's first key point: wave-uniform
+  const bool live = k_raw < n_kp;
+  const int k = live ? k_raw : n_kp - 1;  // a group past the end repeats the last key point and stores nothing
   const KpIn in = kpin[(size_t)b * kp_cap + k];
   const LevelDev L = levels[in.level];
   int sp;
@@ -1401,44 +1407,47 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
   const int cx = __float2int_rn(in.x), cy = __float2int_rn(in.y);  // cvRound(pt)
   const uint8_t* center = src + (size_t)cy * sp + cx;
   int m10 = 0, m01 = 0;
-  for (int i = lane; i < ic_n; i += 64) {
+  for (int i = sl; i < ic_n; i += kObGroup) {
     const int du = ic_du[i], dv = ic_dv[i];
     const int val = center[dv * sp + du];
     m10 += du * val;
     m01 += dv * val;
   }
 #pragma unroll
-  for (int ofs = 32; ofs > 0; ofs >>= 1) {
-    m10 += __shfl_xor(m10, ofs, 64);
-    m01 += __shfl_xor(m01, ofs, 64);
+  for (int ofs = kObGroup / 2; ofs > 0; ofs >>= 1) {
+    m10 += __shfl_xor(m10, ofs, kObGroup);
+    m01 += __shfl_xor(m01, ofs, kObGroup);
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   float a, bb;
   glibc_sincosf(__fmul_rn(angle, factorPI), &bb, &a);  // a = cos, b = sin
-  // descriptor on the blurred level
+  // descriptor on the blurred level: lane sl takes the tests 16 sl .. 16 sl + 15 = descriptor bytes 2 sl, 2 sl + 1
   const uint8_t* bl = blur + (size_t)b * blur_frame + L.blur_off;
   const int bx = round_half_away(in.x), by = round_half_away(in.y);
   const uint8_t* bc = bl + (size_t)by * L.pitch + bx;
-  const int4 pw = *reinterpret_cast<const int4*>(pattern + 16 * lane);  // tests 4*lane .. 4*lane+3
-  const int words[4] = {pw.x, pw.y, pw.z, pw.w};
-  unsigned nib = 0;
+  unsigned bits = 0;
 #pragma unroll
-  for (int t = 0; t < 4; t++) {
-    const int wv = words[t];
-    const float x0 = (float)(int8_t)(wv & 0xff), y0 = (float)(int8_t)((wv >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((wv >> 16) & 0xff), y1 = (float)(int8_t)((wv >> 24) & 0xff);
-    const int r0 = round_half_away(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
-    const int c0 = round_half_away(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
-    const int r1 = round_half_away(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
-    const int c1 = round_half_away(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
-    const int v0 = bc[r0 * L.pitch + c0], v1 = bc[r1 * L.pitch + c1];
-    nib |= (unsigned)(v0 < v1) << t;
+  for (int q = 0; q < 4; q++) {
+    const int4 pw = *reinterpret_cast<const int4*>(pattern + 64 * sl + 16 * q);  // tests 16 sl + 4 q .. + 3
+    const int words[4] = {pw.x, pw.y, pw.z, pw.w};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int wv = words[t];
+      const float x0 = (float)(int8_t)(wv & 0xff), y0 = (float)(int8_t)((wv >> 8) & 0xff);
+      const float x1 = (float)(int8_t)((wv >> 16) & 0xff), y1 = (float)(int8_t)((wv >> 24) & 0xff);
+      const int r0 = round_half_away(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
+      const int c0 = round_half_away(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
+      const int r1 = round_half_away(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
+      const int c1 = round_half_away(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
+      const int v0 = bc[r0 * L.pitch + c0], v1 = bc[r1 * L.pitch + c1];
+      bits |= (unsigned)(v0 < v1) << (4 * q + t);
+    }
   }
-  const unsigned other = __shfl_xor(nib, 1, 64);
+  if (!live) return;
   const size_t o = (size_t)b * kp_cap + in.slot;
-  if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
-  if (lane == 0) {
+  *reinterpret_cast<unsigned short*>(desc + o * 32 + 2 * sl) = (unsigned short)bits;  // (a descriptor is 32 bytes: aligned)
+  if (sl == 0) {
     gfs_keypoint kp;
     // keypoint->pt *= scale for level != 0 (src/ORBextractor.cc:1204-1207)
     kp.x = in.level ? __fmul_rn(in.x, L.scale) : in.x;
@@ -1656,7 +1665,7 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                h->d_kept_off.p, h->cap_kp, lap0, lap1, h->d_kpin.p, h->d_kp_count.p, h->d_mono.p);
     GFS_LAUNCH("k_blur7", k_blur7, dim3((unsigned)G.blur_tiles.size(), B), dim3(256), 0, s, h->d_levels.p, h->d_tiles.p, l0,
                h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, tp[0], tp[1], tp[2], tp[3]);
-    GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(h->cap_kp, 4), B), dim3(256), 0, s, h->d_levels.p, l0,
+    GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(h->cap_kp, kObPerWg), B), dim3(256), 0, s, h->d_levels.p, l0,
                h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_ic_du.p,
                h->d_ic_dv.p, h->ic_n, h->d_pattern.p, h->d_kps.p, h->d_desc.p);
     h->last_B = B;
@@ -1729,7 +1738,7 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
     GFS_HIP(hipMemcpy2DAsync(h->d_kpin.p, (size_t)h->cap_kp * sizeof(KpIn), h->h_kpin.p, (size_t)h->cap_kp * sizeof(KpIn),
                              (size_t)max_n * sizeof(KpIn), B, hipMemcpyHostToDevice, s));
     // 6. orientation + descriptors
-    GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(max_n, 4), B), dim3(256), 0, s, h->d_levels.p, l0,
+    GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(max_n, kObPerWg), B), dim3(256), 0, s, h->d_levels.p, l0,
                h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_ic_du.p,
                h->d_ic_dv.p, h->ic_n, h->d_pattern.p, h->d_kps.p, h->d_desc.p);
   }
