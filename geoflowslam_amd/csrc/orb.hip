@@ -1258,20 +1258,26 @@ __global__ __launch_bounds__(256) void k_blur7(const LevelDev* __restrict__ leve
   for (int i = tid; i < (kBlurTH + 6) * (kBlurTW / 4); i += 256) {
     const int r = i >> 4, g = i & 15;  // outputs 4g..4g+3 need source bytes 4g+1 .. 4g+10 of the padded row
     const uint32_t w0 = raw[r][g], w1 = raw[r][g + 1], w2 = raw[r][g + 2];
-    unsigned by[12];
+    // Two outputs at a time in packed 16-bit lanes: (byte i, byte i + 1) of the 12 source bytes, zero-extended, is one v_perm; the
+    // taps sum to 256 / 257, so t0 (a + b) + t1 (c + d) + t2 (e + f) + t3 g <= 65 535 never wraps (what OpenCV's saturating u16
+    // arithmetic computes).  28 instructions for four outputs instead of 12 byte extractions + 32.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto pair = [&](int i) -> us2 {  // (by[i], by[i + 1]), i <= 10 (compile-time after unrolling)
+      const uint32_t hi = i + 1 <= 7 ? w1 : w2, lo = i + 1 <= 7 ? w0 : w1;
+      const uint32_t j = i + 1 <= 7 ? i : i - 4;
+      const uint32_t v = __builtin_amdgcn_perm(hi, lo, j | (0x0cu << 8) | ((j + 1) << 16) | (0x0cu << 24));
+      return __builtin_bit_cast(us2, v);
+    };
+    const us2 T0 = {(unsigned short)t0, (unsigned short)t0}, T1 = {(unsigned short)t1, (unsigned short)t1},
+              T2 = {(unsigned short)t2, (unsigned short)t2}, T3 = {(unsigned short)t3, (unsigned short)t3};
+    uint32_t o2[2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      by[k] = (w0 >> (8 * k)) & 0xff;
-      by[4 + k] = (w1 >> (8 * k)) & 0xff;
-      by[8 + k] = (w2 >> (8 * k)) & 0xff;
+    for (int h2 = 0; h2 < 2; h2++) {  // outputs (0, 1) then (2, 3): taps at bytes 1 + 2 h2 + j
+      const int b0 = 1 + 2 * h2;
+      const us2 v = (pair(b0) + pair(b0 + 6)) * T0 + (pair(b0 + 1) + pair(b0 + 5)) * T1 + (pair(b0 + 2) + pair(b0 + 4)) * T2 + pair(b0 + 3) * T3;
+      o2[h2] = __builtin_bit_cast(uint32_t, v);
     }
-    unsigned o[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const unsigned v = t0 * (by[k + 1] + by[k + 7]) + t1 * (by[k + 2] + by[k + 6]) + t2 * (by[k + 3] + by[k + 5]) + t3 * by[k + 4];
-      o[k] = min(v, 0xffffu);
-    }
-    *reinterpret_cast<uint2*>(&hb[r][4 * g]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    *reinterpret_cast<uint2*>(&hb[r][4 * g]) = make_uint2(o2[0], o2[1]);
   }
   __syncthreads();
   uint8_t* dst = blur + (size_t)b * blur_frame + L.blur_off;
