@@ -1290,10 +1290,13 @@ __global__ __launch_bounds__(256) void k_blur7(const LevelDev* __restrict__ leve
 #pragma unroll
     for (int j = 0; j < 7; j++) {
       const uint2 h = *reinterpret_cast<const uint2*>(&hb[r + j][4 * g]);
-      acc[0] += taps[j] * (h.x & 0xffff);
-      acc[1] += taps[j] * (h.x >> 16);
-      acc[2] += taps[j] * (h.y & 0xffff);
-      acc[3] += taps[j] * (h.y >> 16);
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      const us2 hx = __builtin_bit_cast(us2, h.x), hy = __builtin_bit_cast(us2, h.y);  // (16 x 16 -> 32 bit multiply-adds on the halves)
+      const unsigned short tj = (unsigned short)taps[j];
+      acc[0] += (unsigned)hx.x * (unsigned)tj;
+      acc[1] += (unsigned)hx.y * (unsigned)tj;
+      acc[2] += (unsigned)hy.x * (unsigned)tj;
+      acc[3] += (unsigned)hy.y * (unsigned)tj;
     }
     uint32_t pk = 0;
 #pragma unroll
