@@ -381,6 +381,7 @@ def main():
         ab = ab_step / lps if ab_step else None
         ach = ab / avg_s / 1e9 if ab else None
         traffic = None
+        traffic_raw = None
         traffic_note = None
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_serial.json")))  # newest round last
@@ -392,12 +393,14 @@ def main():
                 # wide streaming reads (0.500), the full 64-byte line for a 32-byte gather that misses the caches (2.02 x the 32 bytes
                 # asked for), nothing for gathers served by the L2; WRITE_SIZE is exact (1.000)
                 traffic = int((2.0 * t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
+                traffic_raw = int((t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)  # the counters as rocprofv3 prints them
                 traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, same batch, 1 lane, serial), "
                                 "(2 x FETCH_SIZE + WRITE_SIZE) KB*1024 per step / launches per step; the factor 2 is the measured under-count of "
                                 "streaming reads (profiles/r03_calibration.json) and over-counts the share of cache-missing gathers, which the counter "
                                 "reports in full: an upper bound of the HBM-side bytes")
         roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 2) if ach else None, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5) if ach else None, traffic=traffic, traffic_note=traffic_note,
+                        frac=round(ach / HBM_PEAK_GBS, 5) if ach else None, traffic=traffic, traffic_is_upper_bound=traffic is not None,
+                        traffic_raw_counters=traffic_raw, traffic_note=traffic_note,
                         avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=lps,
                         algorithmic_bytes_per_launch=int(ab) if ab else None,
                         share_of_gpu_kernel_time=round(ms / tot, 3),

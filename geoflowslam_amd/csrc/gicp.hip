@@ -31,7 +31,7 @@ constexpr int kCoordBits = 21;
 constexpr int kCoordOffset = 1 << (kCoordBits - 1);
 constexpr int kCoordMask = (1 << kCoordBits) - 1;
 // The CELL sort key (k_voxel_reduce -> k_radix_sort -> k_cell_build) orders the points of a cell by x as well: its x field counts
-// sixteenths of a cell.  Fields: x fine 25 bits | y 20 bits | z 19 bits (every coordinate the 21-bit voxel fields admit fits).
+// sixteenths of a cell.  Fields: x fine 25 bits | y 20 bits | z 19 bits (|cell coordinate| < 2^18: k_voxel_keys' max_vox sees to it).
 constexpr int kFineBits = 4, kFine = 1 << kFineBits;
 constexpr int kCkSy = 25, kCkSz = 45;  // bit positions of the y and z fields of a cell sort key
 constexpr int kCkOffX = 1 << 24, kCkOffY = 1 << 19, kCkOffZ = 1 << 18;
@@ -77,7 +77,7 @@ __device__ __forceinline__ u64 pack_key(int cx, int cy, int cz) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ tgt, const float4* __restrict__ src,
                                                     const int* __restrict__ nt, const int* __restrict__ ns,
-                                                    int stride_pts, int P, double inv_leaf, u64* __restrict__ keys,
+                                                    int stride_pts, int P, double inv_leaf, double max_vox, u64* __restrict__ keys,
                                                     unsigned* __restrict__ idx, int* __restrict__ counts, int only) {
   const int c = blockIdx.y, pair = c >> 1, which = c & 1;
   if (only >= 0 && which != only) return;
@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ t
   const float4 p = in[i];
   const double x = (double)p.x * inv_leaf, y = (double)p.y * inv_leaf, z = (double)p.z * inv_leaf;
   u64 key = kInvalidKey;
-  if (fabs(x) < 1.0e6 && fabs(y) < 1.0e6 && fabs(z) < 1.0e6) {  // also rejects NaN / inf
+  // max_vox: 1e6 voxels (inside the 21-bit fields), less when the cell is so small against the leaf that a coordinate the voxel
+  // fields admit would leave the fields of the CELL sort key (kCkOff*; gicp_run) -- such points are dropped like out-of-range ones
+  if (fabs(x) < max_vox && fabs(y) < max_vox && fabs(z) < max_vox) {  // also rejects NaN / inf
     const int cx = fast_floor_d(x) + kCoordOffset, cy = fast_floor_d(y) + kCoordOffset, cz = fast_floor_d(z) + kCoordOffset;
     if (cx >= 0 && cx <= kCoordMask && cy >= 0 && cy <= kCoordMask && cz >= 0 && cz <= kCoordMask) key = pack_key(cx, cy, cz);
   }
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
         const int cxm = fast_floor_d(ux), cym = fast_floor_d(my * inv_cell), czm = fast_floor_d(mz * inv_cell);
         const int sub = min(max((int)((ux - (double)cxm) * (double)kFine), 0), kFine - 1);
         const long long xf = (long long)cxm * kFine + sub + kCkOffX, yf = (long long)cym + kCkOffY, zf = (long long)czm + kCkOffZ;
-        // (coordinates the 21-bit voxel fields admit always fit; anything else cannot have passed the voxel stage)
+        // (|coordinate| < 2^18 cells: k_voxel_keys dropped everything else, and a mean lies inside its points' hull)
         ck[pos] = (u64)xf | ((u64)yf << kCkSy) | ((u64)zf << kCkSz);
       }
       ci[pos] = (unsigned)pos;
@@ -2396,9 +2398,13 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   GFS_HIP(hipMemcpyAsync(h->d_initT.p, h->h_initT.p, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, 2 * sizeof(int), s));
   const int npts = std::min(stride_pts, P);
+  // The cell sort key gives the cell z 19 bits, y 20 and x (in sixteenths) 25: every coordinate of a voxel mean fits while
+  // |coordinate| < 2^18 cells.  The voxel fields admit 10^6 leaves, which is less whenever cell >= 4 leaves (the reference's
+  // 0.1 / 0.02 m); for a smaller ratio the admitted range shrinks to what the cell key can hold (>= 13 km at 0.05 m).
+  const double max_vox = std::min(1.0e6, (double)((1 << 18) - 2) * prm.cell * prm.inv_leaf);
   // ---- preprocess_points x 2B (registration_helper.cpp:22-34)
   GFS_LAUNCH("k_voxel_keys", k_voxel_keys, dim3(gfs::div_up(npts, 256), C2), dim3(256), 0, s, in_even, in_odd, n_even, n_odd,
-             stride_pts, P, prm.inv_leaf, h->d_keys0.p, h->d_val0.p, h->d_counts.p, prm.only);
+             stride_pts, P, prm.inv_leaf, max_vox, h->d_keys0.p, h->d_val0.p, h->d_counts.p, prm.only);
   if (h->stable_voxel_order) {
     GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
                h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only, kCoordBits, 2 * kCoordBits);

@@ -301,11 +301,12 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
   }
   int sp;
   const uint8_t* src = level_ptr(L, C.level, b, l0, pyr, pyr_frame, &sp);
-  src += (size_t)C.y0 * sp + C.x0;
   // The tile is staged with aligned 4-byte loads when every row of the cell starts at the same offset `al` inside its word
   // (all pyramid planes: pitch and plane offsets are multiples of 64; a caller's level 0 whenever its pitch is a multiple of
-  // 4): row y of the cell then sits at tile0 + y * wp, wp = the row's words.  Otherwise byte by byte (wp = w).
-  const bool words = (sp & 3) == 0;
+  // 4 AND the plane itself starts on a word: the word loads reach back to the word boundary in front of a row, which lies
+  // inside the plane only then): row y of the cell then sits at tile0 + y * wp, wp = the row's words.  Otherwise byte by byte (wp = w).
+  const bool words = (sp & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+  src += (size_t)C.y0 * sp + C.x0;
   const int al = words ? (int)(reinterpret_cast<uintptr_t>(src) & 3) : 0;
   const int wp = words ? (al + w + 3) & ~3 : w;
   uint8_t* tile = smem;                    // [h][wp]

@@ -10,8 +10,10 @@
 // the 21 + 6 entries of the normal equations (core/base_unary_edge.hpp:43-72, one edge after the other into the vertex's
 // block) -- is added in g2o's order, the edge order: the threads park their terms in an LDS slab and one lane per quantity
 // adds them up sequentially.  Together with glibc's sin / cos / pow (glibc_math.hpp) every double of the solve has the bits
-// the sequential CPU code produces; the sign of a gain ratio at a converged state (one more LM iteration or not) depends on
-// exactly that.  The scalar LM bookkeeping runs on thread 0 and is broadcast through LDS.
+// the sequential CPU restatement (oracle/pose_oracle.cpp) produces; the sign of a gain ratio at a converged state (one more LM
+// iteration or not) depends on exactly that.  The 2- / 3-term products of an edge are associated the way Eigen evaluates
+// base_unary_edge.hpp:62-63 -- (A' weightedOmega) A and ((rho1 A') Omega) e, left to right -- but no Eigen / g2o build exists in
+// this image to pin that against: "bit-identical" is a statement about the restatement, the bar against the reference is 1e-5.  The scalar LM bookkeeping runs on thread 0 and is broadcast through LDS.
 // Quirks kept: every round restarts from the frame's pose, chi2 values are compared as floats, nGood is never reset,
 // the stereo projection uses a float 1/z, and the optimised pose is returned but meant to be discarded.
 #include <memory>
@@ -342,17 +344,17 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
 #pragma unroll
             for (int a = 0; a < 6; a++) {
               double sb = 0;
-              sb += J[a] * (w * r[0]);
-              sb += J[6 + a] * (w * r[1]);
-              const double sb3 = sb + J[12 + a] * (w * r[2]);
+              sb += ((rho1 * J[a]) * w) * r[0];
+              sb += ((rho1 * J[6 + a]) * w) * r[1];
+              const double sb3 = sb + ((rho1 * J[12 + a]) * w) * r[2];
               sb = three ? sb3 : sb;
-              acc[21 + a] = -(rho1 * sb);  // b -= rho1 J' W e
+              acc[21 + a] = -sb;  // b -= ((rho1 A') Omega) e, Eigen's left-to-right association of base_unary_edge.hpp:62
 #pragma unroll
               for (int c = 0; c <= a; c++) {
                 double hh = 0;
-                hh += J[a] * ((rho1 * w) * J[c]);
-                hh += J[6 + a] * ((rho1 * w) * J[6 + c]);
-                const double hh3 = hh + J[12 + a] * ((rho1 * w) * J[12 + c]);
+                hh += (J[a] * (rho1 * w)) * J[c];  // (A' weightedOmega) A: H(a, c) = sum_k (J_ka w') J_kc, base_unary_edge.hpp:63
+                hh += (J[6 + a] * (rho1 * w)) * J[6 + c];
+                const double hh3 = hh + (J[12 + a] * (rho1 * w)) * J[12 + c];
                 acc[o++] = three ? hh3 : hh;
               }
             }

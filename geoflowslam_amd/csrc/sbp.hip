@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
   }
   __syncthreads();
   {
-    constexpr int per = kCells / kSbpThreads;  // 12
+    constexpr int per = kCells / kSbpThreads;  // 3 (3072 cells over 1024 threads)
     int local = 0;
     for (int k = 0; k < per; k++) local += s_cnt[tid * per + k];
     s_scan[tid] = local;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
     ccnt[l] = any ? n : -1;  // -1: vIndices2.empty() -> continue
   }
   __syncthreads();
-  // ---- B. assignment in map-point order: one wave walks the map points, everything it looks at is in LDS -- the other three waves
+  // ---- B. assignment in map-point order: one wave walks the map points, everything it looks at is in LDS -- the other fifteen waves
   //         fetch the candidate lists of the next kChunk map points meanwhile (a map point's step used to be two dependent round
   //         trips to HBM: 1.3 us x 900 map points; now ~0.2 us)
   auto fetch = [&](int c0, int buf, int t, int nt) {

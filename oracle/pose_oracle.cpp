@@ -185,14 +185,17 @@ void build_system(const Ctx& C, double H[36], double b[6]) {
       huber(C.chi2[e], delta_of(C, e), &r0, &rho1);
     }
     const double* r = &C.err[3 * e];
-    // b -= rho1 * Jᵀ Ω e ; H += Jᵀ (rho1 Ω) J   (robustInformation = rho[1] * information, base_edge.h)
+    // b -= rho1 * Jᵀ Ω e ; H += Jᵀ (rho1 Ω) J   (robustInformation = rho[1] * information, base_edge.h), in the association
+    // Eigen gives the two expressions of base_unary_edge.hpp:62-63: ((rho1 Aᵀ) Ω) e and (Aᵀ weightedOmega) A, i.e.
+    // H(a, c) = Σ_k (J_ka w') J_kc (the lower triangle, which LDLT reads, is NOT the mirror of the upper one bit for bit).
+    // Whether a given Eigen release hoists the scalar rho1 out of the first product cannot be checked here (no Eigen): see header.
     for (int a = 0; a < 6; a++) {
       double s = 0;
-      for (int k = 0; k < rows; k++) s += J[6 * k + a] * (w * r[k]);
-      b[a] -= rho1 * s;
+      for (int k = 0; k < rows; k++) s += ((rho1 * J[6 * k + a]) * w) * r[k];
+      b[a] -= s;
       for (int c = 0; c < 6; c++) {
         double h = 0;
-        for (int k = 0; k < rows; k++) h += J[6 * k + a] * ((rho1 * w) * J[6 * k + c]);
+        for (int k = 0; k < rows; k++) h += (J[6 * k + a] * (rho1 * w)) * J[6 * k + c];
         H[6 * a + c] += h;
       }
     }
