@@ -23,6 +23,9 @@ namespace gfs_dropin {
 //      src/ORBextractor.cc:1253    case EXTRACTOR_TYPE::ORB_MI355X: return new gfs_dropin::GfsORBextractor(nfeatures, scaleFactor, ...);
 class GfsORBextractor : public ORB_SLAM3::ORBextractor {  // keeps the getters and mvImagePyramid of the base
  public:
+  // mvImagePyramid (include/ORBextractor.h:82, a public member) is read by the stereo matcher only (src/Frame.cc:1159-1256); an
+  // RGB-D / monocular frame never looks at it.  Set this to have operator() copy the un-blurred levels back after every call.
+  bool fill_image_pyramid = false;
   GfsORBextractor(int nf, float sf, int nl, int ini, int mn, int max_rows = 1080, int max_cols = 1920) : ORBextractor(nf, sf, nl, ini, mn) {
     gfs_orb_config c;
     gfs_orb_default_config(&c);
@@ -54,6 +57,15 @@ class GfsORBextractor : public ORB_SLAM3::ORBextractor {  // keeps the getters a
       _descriptors.release();
     else
       desc.rowRange(0, n).copyTo(_descriptors);  // :1168-1171
+    if (fill_image_pyramid) {  // ComputePyramid leaves the resized levels here (src/ORBextractor.cc:1227-1251); the blur works on clones
+      mvImagePyramid.resize((size_t)GetLevels());
+      for (int level = 0; level < GetLevels(); ++level) {
+        int rows = 0, cols = 0;
+        if (gfs_orb_level_size(h_, level, &rows, &cols) != GFS_OK) throw std::runtime_error(gfs_last_error());
+        mvImagePyramid[(size_t)level].create(rows, cols, CV_8UC1);  // continuous rows * cols bytes
+        if (gfs_orb_fetch_level(h_, 0, level, 0, mvImagePyramid[(size_t)level].data) != GFS_OK) throw std::runtime_error(gfs_last_error());
+      }
+    }
     return mono;
   }
 

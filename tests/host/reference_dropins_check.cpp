@@ -15,6 +15,11 @@ class ORBextractor {
   virtual ~ORBextractor() {}
   virtual int operator()(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors,
                          std::vector<int>& vLappingArea);
+  int inline GetLevels() { return nlevels; }
+  std::vector<cv::Mat> mvImagePyramid;
+
+ protected:
+  int nlevels;
 };
 }  // namespace ORB_SLAM3
 namespace small_gicp {
@@ -48,6 +53,7 @@ void instantiate_everything() {
   ORB_SLAM3::ORBextractor* base = &ext;  // the factory returns the base pointer (src/ORBextractor.cc:1253-1265)
   cv::Mat im, desc, d2;
   std::vector<cv::KeyPoint> kps, kps2;
+  ext.fill_image_pyramid = true;  // the stereo matcher reads mvImagePyramid (src/Frame.cc:1159-1256)
   (*base)(im, cv::Mat(), kps, desc, lap);  // Frame::ExtractORB, src/Frame.cc:768-777
   std::vector<cv::DMatch> matches;
   gfs_dropin::bf_match(desc, d2, matches);

@@ -22,6 +22,7 @@ class Mat {
   int type() const;
   bool empty() const;
   Mat rowRange(int start, int end) const;
+  void create(int rows, int cols, int type);
   void copyTo(const _OutputArray& dst) const;
   uchar* data;
   int rows, cols;
