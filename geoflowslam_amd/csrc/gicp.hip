@@ -2181,16 +2181,22 @@ struct gfs_gicp {
 // counts the clouds it left in *n_left -- the caller has to look at it and come back with n_left = nullptr if it is not zero.  (A
 // launch of the general kernel that finds nothing to do is not free: its 1024-thread workgroups need a CU to themselves, and with
 // other lanes' kernels in flight it waits ~0.3 ms for one.)
-constexpr int kVqsLdsE = 19;
+// kVqsLdsE: keys, point indices and the rendezvous array in LDS (8 bytes an element); kVqsLdsGvE: the keys only (4 bytes), the other
+// two in a global scratch block (d_keys1 is free while this kernel sorts) -- what a handle sized for 720p clouds gets.
+constexpr int kVqsLdsE = 19, kVqsLdsGvE = 37;
 static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only, int* n_left) {
   const int P = h->P;
   int flagged_only = 0;
-  const bool lds_covers_sizes = h->vqs_lds && P <= 1024 * kVqsLdsE;
+  const bool lds_covers_sizes = h->vqs_lds && P <= 1024 * kVqsLdsGvE;
   if (!lds_covers_sizes) n_left = nullptr;
   if (h->vqs_lds) {
     const int _pid = ::gfs::profile_on() ? ::gfs::profile_begin("k_voxel_qsort_top_lds", s) : -1;
-    hipLaunchKernelGGL(vqs::k_voxel_qsort_top_lds<kVqsLdsE>, dim3(C2), dim3(1024), kVqsLdsE * 1024 * 8, s, h->d_keys0.p, h->d_val0.p,
-                       h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only, n_left);
+    if (P <= 1024 * kVqsLdsE || P > 1024 * kVqsLdsGvE)
+      hipLaunchKernelGGL((vqs::k_voxel_qsort_top_lds<kVqsLdsE, false>), dim3(C2), dim3(1024), kVqsLdsE * 1024 * 8, s, h->d_keys0.p,
+                         h->d_val0.p, h->d_keys1.p, h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only, n_left);
+    else
+      hipLaunchKernelGGL((vqs::k_voxel_qsort_top_lds<kVqsLdsGvE, true>), dim3(C2), dim3(1024), kVqsLdsGvE * 1024 * 4, s, h->d_keys0.p,
+                         h->d_val0.p, h->d_keys1.p, h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, h->d_leaf.p, h->d_nleaf.p, only, n_left);
     if (_pid >= 0) ::gfs::profile_end(_pid, s);
     flagged_only = 1;
     if (n_left) return hipGetLastError();
@@ -2203,11 +2209,12 @@ static hipError_t voxel_qsort_top(gfs_gicp* h, int C2, hipStream_t s, int only, 
                        flagged_only);                                                                                          \
     if (_pid >= 0) ::gfs::profile_end(_pid, s);                                                                                \
   } while (0)
+  // (when P fits an LDS kernel only key width can leave a cloud over: the general kernel)
   if (P <= 1024 * 20) {
-    if (!lds_covers_sizes) VQS_TOP_REG(20);  // (when P fits the LDS kernel only key width can leave a cloud over: the general kernel)
+    if (!lds_covers_sizes) VQS_TOP_REG(20);
     flagged_only = 1;
   } else if (P <= 1024 * 40) {
-    VQS_TOP_REG(40);
+    if (!lds_covers_sizes) VQS_TOP_REG(40);
     flagged_only = 1;
   }
 #undef VQS_TOP_REG
@@ -2265,8 +2272,10 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   if (const char* e = getenv("GFS_GICP_VOXEL_ORDER")) h->stable_voxel_order = strcmp(e, "stable") == 0;
   if (const char* e = getenv("GFS_GICP_VQS_LDS")) h->vqs_lds = atoi(e) != 0;
-  GFS_HIP(hipFuncSetAttribute((const void*)vqs::k_voxel_qsort_top_lds<kVqsLdsE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  GFS_HIP(hipFuncSetAttribute((const void*)vqs::k_voxel_qsort_top_lds<kVqsLdsE, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kVqsLdsE * 1024 * 8));
+  GFS_HIP(hipFuncSetAttribute((const void*)vqs::k_voxel_qsort_top_lds<kVqsLdsGvE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kVqsLdsGvE * 1024 * 4));
   if (const char* e = getenv("GFS_GICP_LM")) h->lm_rounds = strcmp(e, "persistent") != 0;
   if (const char* e = getenv("GFS_GICP_TILE_STATS")) h->tile_stats_on = atoi(e) != 0;
   const size_t P = h->P, B = max_batch, C2 = 2 * B;
@@ -2416,7 +2425,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     GFS_HIP(voxel_qsort_top(h, C2, s, prm.only, optimistic_sort ? h->d_ndone.p + 1 : nullptr));
     // (GFS_GICP_VOXEL_TIES=exact: the reference's permutation even where it cannot change a voxel mean)
     static const bool exact_ties = getenv("GFS_GICP_VOXEL_TIES") && strcmp(getenv("GFS_GICP_VOXEL_TIES"), "exact") == 0;
-    const bool narrow_only = optimistic_sort && h->vqs_lds && P <= 1024 * kVqsLdsE;  // (what voxel_qsort_top counts in d_ndone[1])
+    const bool narrow_only = optimistic_sort && h->vqs_lds && P <= 1024 * kVqsLdsGvE;  // (what voxel_qsort_top counts in d_ndone[1])
     rc_leaf = exact_ties ? voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, narrow_only)
                          : voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, narrow_only, in_even, in_odd, stride_pts);
     if (rc_leaf) return rc_leaf;

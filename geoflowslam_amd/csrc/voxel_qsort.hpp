@@ -688,8 +688,14 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_reg(u64* keys_all, uns
 #define VQS_T(k)
 #define VQS_T_END
 #endif
-template <int EMAX>
-__global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, unsigned* vals_all,
+// kGV (clouds of up to 1024 * EMAX = 37 888 points: a 1280x720 depth image sampled with stride 5): only the KEYS stay in LDS (4 bytes
+// an element = 152 KB), the 2-byte point indices and the 2-byte rendezvous array live in a per-cloud scratch block in global memory
+// (side_all: 4 bytes an element, L2-resident).  The phases that walk the whole array -- (A) counting and (B) announcing -- read keys
+// only, i.e. LDS only; (B)'s scattered 2-byte stores and the K pair exchanges of (C) (index loads batched four pairs deep) are what
+// touches global memory: per level about n / 2 two-byte stores and n / 4 pairs, against three full passes of 8-byte loads and stores for
+// the ping-pong kernel (k_voxel_qsort_top_reg) these clouds used to fall back to.
+template <int EMAX, bool kGV = false>
+__global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, unsigned* vals_all, u64* side_all,
                                                               const int* __restrict__ counts, int P, int* __restrict__ which,
                                                               int* __restrict__ kinfo, unsigned* __restrict__ leaf_all,
                                                               int* __restrict__ nleaf, int only, int* __restrict__ n_left) {
@@ -700,16 +706,18 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
   __shared__ int seg_local[kSeg], seg_wave[kSeg];  // flagged count before a range's first element inside its wave's chunk; that wave
   __shared__ unsigned seg_pv[kSeg];
   __shared__ int seg_K[kSeg];  // pairs a range's partition exchanges
+  __shared__ unsigned short eq_j[kGV ? kSeg : 1][kEq];  // kGV: the front positions of the second partition's swaps
   __shared__ int s_wave[16], s_wbase[17];
   extern __shared__ __align__(16) unsigned char vq_lds[];
   VQS_T_INIT
   unsigned* s_key = reinterpret_cast<unsigned*>(vq_lds);                                  // [1024 * EMAX] compacted keys
-  unsigned short* s_val = reinterpret_cast<unsigned short*>(s_key + 1024 * EMAX);          // [1024 * EMAX] point indices (< n)
-  unsigned short* side_pos = s_val + 1024 * EMAX;  // rendezvous of a partition sweep: slot (rank from the front) -> position of the back element
   __shared__ int s_nseg, s_nleaf, s_over;
   __shared__ int s_mn[3], s_mx[3];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
   if (only >= 0 && (c & 1) != only) return;
+  // [1024 * EMAX] point indices (< n) and the rendezvous of a partition sweep: slot (rank from the front) -> position of the back element
+  unsigned short* s_val = kGV ? reinterpret_cast<unsigned short*>(side_all + (size_t)c * P) : reinterpret_cast<unsigned short*>(s_key + 1024 * EMAX);
+  unsigned short* side_pos = kGV ? s_val + P : s_val + 1024 * EMAX;
   const int n = __builtin_amdgcn_readfirstlane(counts[c]);
   u64* ka = keys_all + (size_t)c * P;
   unsigned* va = vals_all + (size_t)c * P;
@@ -719,19 +727,28 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
     s_mx[tid] = -1;
   }
   __syncthreads();
-  u64 kreg[EMAX];  // the thread's keys: all loads in flight at once (one workgroup a CU: nothing else hides their latency)
-#pragma unroll
-  for (int r = 0; r < EMAX; r++) kreg[r] = r * 1024 + tid < n ? ka[r * 1024 + tid] : kInvalid;
+  // the thread's keys: all loads of a chunk in flight at once (one workgroup a CU: nothing else hides their latency); up to 19 rows
+  // are ONE chunk that stays in registers for the compaction below, more rows are read twice, 19 at a time
+  constexpr int kRows = EMAX <= 19 ? EMAX : 19, kChunks = (EMAX + kRows - 1) / kRows;
+  u64 kreg[kRows];
   {
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
 #pragma unroll
-    for (int r = 0; r < EMAX; r++) {
-      const u64 k = kreg[r];
-      if (k == kInvalid) continue;
-      const int f[3] = {(int)(k & kCM), (int)((k >> kCB) & kCM), (int)(k >> (2 * kCB))};
-      for (int a = 0; a < 3; a++) {
-        mn[a] = min(mn[a], f[a]);
-        mx[a] = max(mx[a], f[a]);
+    for (int ch = 0; ch < kChunks; ch++) {
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        const int i = (ch * kRows + r) * 1024 + tid;
+        kreg[r] = (ch * kRows + r < EMAX && i < n) ? ka[i] : kInvalid;
+      }
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        const u64 k = kreg[r];
+        if (k == kInvalid) continue;
+        const int f[3] = {(int)(k & kCM), (int)((k >> kCB) & kCM), (int)(k >> (2 * kCB))};
+        for (int a = 0; a < 3; a++) {
+          mn[a] = min(mn[a], f[a]);
+          mx[a] = max(mx[a], f[a]);
+        }
       }
     }
     for (int a = 0; a < 3; a++) {  // one LDS atomic a wave, not one a thread
@@ -765,14 +782,24 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
     return;
   }
 #pragma unroll
-  for (int r = 0; r < EMAX; r++) {
-    const int i = r * 1024 + tid;
-    const u64 k = kreg[r];
-    unsigned kk = 0xffffffffu;
-    if (k != kInvalid) kk = (unsigned)((k & kCM) - mnx) | ((unsigned)(((k >> kCB) & kCM) - mny) << bx) | ((unsigned)((k >> (2 * kCB)) - mnz) << (bx + by));
-    if (i < n) {
-      s_key[i] = kk;
-      s_val[i] = (unsigned short)i;  // the point indices enter as the identity (k_voxel_keys, gfs_test_voxel_sort)
+  for (int ch = 0; ch < kChunks; ch++) {
+    if (kChunks > 1) {
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        const int i = (ch * kRows + r) * 1024 + tid;
+        kreg[r] = (ch * kRows + r < EMAX && i < n) ? ka[i] : kInvalid;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      const int i = (ch * kRows + r) * 1024 + tid;
+      const u64 k = kreg[r];
+      unsigned kk = 0xffffffffu;
+      if (k != kInvalid) kk = (unsigned)((k & kCM) - mnx) | ((unsigned)(((k >> kCB) & kCM) - mny) << bx) | ((unsigned)((k >> (2 * kCB)) - mnz) << (bx + by));
+      if (ch * kRows + r < EMAX && i < n) {
+        s_key[i] = kk;
+        s_val[i] = (unsigned short)i;  // the point indices enter as the identity (k_voxel_keys, gfs_test_voxel_sort)
+      }
     }
   }
   if (tid == 0) {
@@ -989,7 +1016,65 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
         VQS_T(12)
       }
       __syncthreads();  VQS_T(4)
-      {  // (C) exchange the pairs, all ranges' pairs numbered through: thread t takes pairs t, t + 1024, ...
+      if constexpr (kGV) {  // (C) with the point indices and the rendezvous array in global memory: four pairs a trip, their loads in flight together
+        __threadfence_block();  // (B)'s rendezvous stores, made by other waves of this workgroup
+        int sg = 0, off = 0, Ks = nseg > 0 ? seg_K[0] : 0, tbase_of_batch = 0;
+        bool more = true;
+        while (more) {
+          int jb_slot[4], jf_slot[4], sgv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            sgv[u] = -1;
+            jb_slot[u] = jf_slot[u] = 0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (!more) continue;
+            // (trip u of this batch: pair number tcur; the batches of a thread are 4096 pairs apart)
+            const int tcur = tid + 1024 * u + tbase_of_batch;
+            while (sg < nseg && tcur >= off + Ks) {
+              off += Ks;
+              sg++;
+              Ks = sg < nseg ? seg_K[sg] : 0;
+            }
+            if (sg >= nseg) {
+              more = false;
+              continue;
+            }
+            const int k = tcur - off, first = mode == 0 ? seg_b[sg] : seg_m1[sg], last = seg_e[sg];
+            sgv[u] = sg;
+            jb_slot[u] = first + k;
+            jf_slot[u] = last - 1 - k;
+          }
+          int jb[4], jf[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            jb[u] = sgv[u] >= 0 ? (int)side_pos[jb_slot[u]] : 0;
+            jf[u] = sgv[u] >= 0 ? (int)side_pos[jf_slot[u]] : 0;
+          }
+          unsigned short vf[4], vb[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            vf[u] = sgv[u] >= 0 ? s_val[jf[u]] : (unsigned short)0;
+            vb[u] = sgv[u] >= 0 ? s_val[jb[u]] : (unsigned short)0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (sgv[u] < 0) continue;
+            const unsigned kf = s_key[jf[u]], kb = s_key[jb[u]];
+            s_key[jf[u]] = kb;
+            s_key[jb[u]] = kf;
+            s_val[jf[u]] = vb[u];
+            s_val[jb[u]] = vf[u];
+            if (mode == 0 && kf == seg_pv[sgv[u]]) {
+              const int slot = atomicAdd(&eq_cnt[sgv[u]], 1);
+              if (slot < kEq) eq_pos[sgv[u]][slot] = jb[u];
+            }
+          }
+          tbase_of_batch += 4096;
+        }
+        __threadfence_block();
+      } else {  // (C) exchange the pairs, all ranges' pairs numbered through: thread t takes pairs t, t + 1024, ...
         int sg = 0, off = 0, Ks = nseg > 0 ? seg_K[0] : 0;
         for (int t = tid;; t += 1024) {
           while (sg < nseg && t >= off + Ks) {
@@ -1036,6 +1121,7 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
         }
         // k-th position of [m1, m1 + m) not holding a pivot key (from the left) <-> k-th pivot key beyond (from the right)
         int a = 0, t = m - 1;
+        [[maybe_unused]] int nsw = 0;
 #pragma unroll 1
         for (int j = m1; j < m1 + m; j++) {
           if (a < m && q[a] == j) {
@@ -1044,11 +1130,36 @@ __global__ __launch_bounds__(1024) void k_voxel_qsort_top_lds(u64* keys_all, uns
           }
           const int jt = q[t--];  // >= m1 + m by counting
           const unsigned kj = s_key[j];
-          const unsigned short vj = s_val[j];
           s_key[j] = s_key[jt];
-          s_val[j] = s_val[jt];
           s_key[jt] = kj;
-          s_val[jt] = vj;
+          if constexpr (kGV) {  // the point indices follow below, their loads batched (a global round trip per swap otherwise)
+            eq_j[tid][nsw++] = (unsigned short)j;
+          } else {
+            const unsigned short vj = s_val[j];
+            s_val[j] = s_val[jt];
+            s_val[jt] = vj;
+          }
+        }
+        if constexpr (kGV) {  // swap s of the loop above paired j = eq_j[s] with jt = q[m - 1 - s]; all positions are distinct
+#pragma unroll 1
+          for (int s0 = 0; s0 < nsw; s0 += 4) {
+            unsigned short va_[4], vb_[4];
+            int ja[4], jb_[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const bool on = s0 + u < nsw;
+              ja[u] = on ? (int)eq_j[tid][s0 + u] : 0;
+              jb_[u] = on ? q[m - 1 - (s0 + u)] : 0;
+              va_[u] = on ? s_val[ja[u]] : (unsigned short)0;
+              vb_[u] = on ? s_val[jb_[u]] : (unsigned short)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+              if (s0 + u < nsw) {
+                s_val[ja[u]] = vb_[u];
+                s_val[jb_[u]] = va_[u];
+              }
+          }
         }
       }
     }

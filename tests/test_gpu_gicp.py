@@ -21,7 +21,7 @@ def _voxel_keys(x, y, z):
 def _sort_cases():
     rng = np.random.default_rng(7)
     cases = []
-    for n in (0, 1, 2, 3, 16, 17, 18, 64, 65, 500, 1023, 1024, 1025, 2047, 2048, 5000, 19200, 40000):
+    for n in (0, 1, 2, 3, 16, 17, 18, 64, 65, 500, 1023, 1024, 1025, 2047, 2048, 5000, 19200, 36864, 40000):
         for mode in range(6):
             if mode == 0:      # depth-camera like: most voxels unique, ~10 % shared
                 x, y, z = rng.integers(0, 200, n), rng.integers(0, 150, n), rng.integers(0, 4, n)
@@ -46,12 +46,18 @@ def _sort_cases():
     return cases
 
 
-def test_voxel_sort_permutation_is_the_references(gpu_api, oracle):
+# handle capacities that select the three kernels of the n >= 1024 levels (csrc/gicp.hip voxel_qsort_top): the cloud resident in LDS,
+# the keys in LDS with the point indices in global memory (720p clouds), the ping-pong kernel through HBM
+SORT_CAPS = [19456, 37888, 40960]
+
+
+@pytest.mark.parametrize("cap", SORT_CAPS)
+def test_voxel_sort_permutation_is_the_references(gpu_api, oracle, cap):
     """The preprocessing's voxel sort must produce small_gicp quick_sort_omp's permutation (util/sort_omp.hpp:58-85; the sort is
     not stable and the 1024-block splits of voxelgrid_sampling_omp depend on it): 3-way quicksort levels, libstdc++ introsort
     leaves, final insertion sort — and the heap-sort fallback, reached with McIlroy's adversarial input for std::sort."""
-    reg = gpu_api.RegistrationGICP(max_points=40960)
-    cases = _sort_cases()
+    reg = gpu_api.RegistrationGICP(max_points=cap)
+    cases = [c for c in _sort_cases() if len(c[1]) <= cap]
     for n in (100, 700, 1000, 1023):
         a = oracle.antiqsort_keys(n).astype(np.int64)
         for div in (1, 2, 3):
@@ -64,19 +70,22 @@ def test_voxel_sort_permutation_is_the_references(gpu_api, oracle):
     cases.append(("antiqsort-embedded", _voxel_keys(mix[rng.permutation(len(mix))], np.full(len(mix), 2), np.full(len(mix), 2))))
     cases.append(("antiqsort-embedded-inorder", _voxel_keys(mix, np.full(len(mix), 2), np.full(len(mix), 2))))
     for name, k in cases:
+        if len(k) > cap:
+            continue
         got = reg.voxel_sort_perm(k)
         want, _ = oracle.quick_sort_perm(k)
         assert np.array_equal(got, want), (name, int((got != want).sum()), len(k))
 
 
-def test_voxel_sort_permutation_against_the_compiled_reference(gpu_api, oracle):
+@pytest.mark.parametrize("cap", SORT_CAPS)
+def test_voxel_sort_permutation_against_the_compiled_reference(gpu_api, oracle, cap):
     """The same, against the REFERENCE'S OWN quick_sort_omp (util/sort_omp.hpp compiled from /root/reference into oracle/_ref by
     oracle/ref_build.sh; the prebuilt library travels to the GPU box) instead of the restatement."""
     if oracle.ref_lib() is None:
         pytest.skip("oracle/_ref not built")
     from test_oracle_ref import sort_cases
-    reg = gpu_api.RegistrationGICP(max_points=40960)
-    for name, k in sort_cases():
+    reg = gpu_api.RegistrationGICP(max_points=cap)
+    for name, k in [c for c in sort_cases() if len(c[1]) <= cap]:
         got = reg.voxel_sort_perm(k)
         want, _ = oracle.ref_quick_sort_perm(k, 4)
         assert np.array_equal(got, want), (name, int((got != want).sum()), len(k))
@@ -225,10 +234,11 @@ def test_wide_extent_cloud_on_an_lds_sized_handle(gpu_api, oracle):
     assert _rel(r["T"], rn["T"]) < TOL and r["iterations"] == rn["iterations"] and r["n_source_ds"] == rn["n_source_ds"]
 
 
-def test_gicp_720p_cloud(gpu_api, oracle):
+@pytest.mark.parametrize("cap", [36864, 40960])
+def test_gicp_720p_cloud(gpu_api, oracle, cap):
     fp = synth.frame_pair(12, 1280, 720, 5)
     assert len(fp["cloud0"]) > 30000
-    reg = gpu_api.RegistrationGICP(max_points=40960)
+    reg = gpu_api.RegistrationGICP(max_points=cap)
     r = reg.RegisterPointClouds(fp["cloud0"], fp["cloud1"])
     ro = oracle.gicp_align(fp["cloud0"], fp["cloud1"])
     assert _rel(r["T"], ro["T"]) < TOL and r["converged"] == ro["converged"]

@@ -19,7 +19,7 @@ def _voxel_keys(x, y, z):
 def sort_cases():
     rng = np.random.default_rng(11)
     cases = []
-    for n in (0, 1, 2, 15, 16, 17, 100, 1023, 1024, 1025, 2047, 2048, 4097, 9000, 20000, 40000):
+    for n in (0, 1, 2, 15, 16, 17, 100, 1023, 1024, 1025, 2047, 2048, 4097, 9000, 20000, 36864, 40000):
         for mode in range(6):
             if mode == 0:    # few distinct voxels: heavy ties
                 x, y, z = rng.integers(0, 4, n), rng.integers(0, 3, n), rng.integers(0, 2, n)
