@@ -837,24 +837,26 @@ __device__ __forceinline__ void knn_write_cov(const TopK<10>& best, int kk, cons
 }
 
 // scans the run [j0, j1) of candidate points, four loads in flight
-__device__ __forceinline__ void knn_scan_run(const double4* __restrict__ p, const double4& q, int j0, int j1, TopK<10>& loc) {
+// (bound: candidates farther than that cannot belong to the result -- k nearer ones are known to exist -- and skip the insertion)
+__device__ __forceinline__ void knn_scan_run(const double4* __restrict__ p, const double4& q, int j0, int j1, TopK<10>& loc,
+                                             double bound = 1.79769313486231570e308) {
   for (int j = j0; j < j1; j += 4) {  // four loads in flight
     const double4 t0 = p[j], t1 = p[min(j + 1, j1 - 1)], t2 = p[min(j + 2, j1 - 1)], t3 = p[min(j + 3, j1 - 1)];
     {
-      const double ddx = t0.x - q.x, ddy = t0.y - q.y, ddz = t0.z - q.z;
-      loc.push(j, ddx * ddx + ddy * ddy + ddz * ddz);
+      const double ddx = t0.x - q.x, ddy = t0.y - q.y, ddz = t0.z - q.z, d = ddx * ddx + ddy * ddy + ddz * ddz;
+      if (d <= bound) loc.push(j, d);
     }
     if (j + 1 < j1) {
-      const double ddx = t1.x - q.x, ddy = t1.y - q.y, ddz = t1.z - q.z;
-      loc.push(j + 1, ddx * ddx + ddy * ddy + ddz * ddz);
+      const double ddx = t1.x - q.x, ddy = t1.y - q.y, ddz = t1.z - q.z, d = ddx * ddx + ddy * ddy + ddz * ddz;
+      if (d <= bound) loc.push(j + 1, d);
     }
     if (j + 2 < j1) {
-      const double ddx = t2.x - q.x, ddy = t2.y - q.y, ddz = t2.z - q.z;
-      loc.push(j + 2, ddx * ddx + ddy * ddy + ddz * ddz);
+      const double ddx = t2.x - q.x, ddy = t2.y - q.y, ddz = t2.z - q.z, d = ddx * ddx + ddy * ddy + ddz * ddz;
+      if (d <= bound) loc.push(j + 2, d);
     }
     if (j + 3 < j1) {
-      const double ddx = t3.x - q.x, ddy = t3.y - q.y, ddz = t3.z - q.z;
-      loc.push(j + 3, ddx * ddx + ddy * ddy + ddz * ddz);
+      const double ddx = t3.x - q.x, ddy = t3.y - q.y, ddz = t3.z - q.z, d = ddx * ddx + ddy * ddy + ddz * ddz;
+      if (d <= bound) loc.push(j + 3, d);
     }
   }
 }
@@ -958,7 +960,11 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
       }
       knn_scan_runs4(p, q, rb[0], rl[0], rb[1], rl[1], rb[2], rl[2], rb[3], rl[3], best);
     }
-    certified = best.found >= want && best.nth(max(want - 1, 0)) <= cell2;
+    // certified: nothing outside the 27-cell cube can be nearer than the k-th candidate.  The cube's faces are 1 + u and 2 - u
+    // cells away from the query along each axis (u = its position inside its own cell): at least one cell, up to 1.5
+    const double fx = fmin(ux + 1.0, 2.0 - ux), fy = fmin(uy + 1.0, 2.0 - uy), fz = fmin(uz + 1.0, 2.0 - uz);
+    const double reach = fmax(fmin(fx, fmin(fy, fz)) - 1e-9, 1.0) * prm.cell;
+    certified = best.found >= want && best.nth(max(want - 1, 0)) <= fmax(reach * reach, cell2);
   }
   // Isolated point (k-th neighbour beyond one cell, ~2 % of a depth-camera cloud): it needs a (much) bigger probe.  Done
   // here it would stall the other 63 lanes of its wave (and ~70 % of the waves hold such a lane), so it is deferred.
@@ -1063,8 +1069,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
           int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0;
           if (usea) row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xa, upr == 1 ? x1 : x0 + xa, ya, za, &ja0, &ja1);
           if (useb) row_range(gi, G, uc, ub, nu, upr == 1 ? x0 : x0 + xb, upr == 1 ? x1 : x0 + xb, yb, zb, &jb0, &jb1);
-          knn_scan_run(p, q, ja0, ja1, loc);
-          knn_scan_run(p, q, jb0, jb1, loc);
+          knn_scan_run(p, q, ja0, ja1, loc, Dk);
+          knn_scan_run(p, q, jb0, jb1, loc, Dk);
         }
         best.init();
 #pragma unroll
@@ -1131,6 +1137,234 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       knn_write_cov(res, kk, p, cov6 + ((size_t)c * P + s_query[threadIdx.x]) * 6);
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_knn_cov_far_wg: the really isolated queries (back of hard_list, counter far2_count: a handful per depth-camera cloud, each
+// with a probe of hundreds of rows), one 256-thread WORKGROUP per query.  The probe's rows are looked up once, all lanes at
+// once (one round trip to memory instead of a chain of them per lane), their candidate runs are numbered through and the threads
+// stride over that one sequence -- balanced whatever the rows hold, coalesced inside a row.  A query that knows k candidates
+// already (Dk: k_knn_cov / the r = 2 pass found k points within sqrt(Dk)) needs ONE probe of ceil(sqrt(Dk) / cell) rings and
+// only candidates with d <= Dk can belong to the result, so the sorted insertion runs for those alone.  Per thread a top-k in
+// visiting order = ascending point index (rows are walked in (z, y) order, points are sorted by (z, y, x)); the k winners come
+// out of wave arg-min rounds and a 4-list merge, ties to the lower point index: the same set the lane-group version
+// (k_knn_cov_far<64, 4, false>, the previous form of this pass) selects.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFarWgRows = 1024;  // rows of one chunk of the probe (begin, prefix) in LDS
+
+__global__ __launch_bounds__(256) void k_knn_cov_far_wg(const double4* __restrict__ pts, const u64* __restrict__ ucell,
+                                                        const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell,
+                                                        const int* __restrict__ m_counts, const int* __restrict__ bbox,
+                                                        const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
+                                                        const unsigned* __restrict__ hard_list, const double* __restrict__ hard_d,
+                                                        const int* __restrict__ far2_count, int nchunks, int npairs, int P,
+                                                        GicpParams prm, double* __restrict__ cov6) {
+  __shared__ int s_beg[kFarWgRows], s_pre[kFarWgRows + 1];
+  __shared__ int s_wave[4];
+  __shared__ double s_md[4][10];
+  __shared__ int s_mi[4][10];
+  int pair, which, chunk;
+  if (!xcd_pair_map(nchunks, npairs, 2, &pair, &which, &chunk)) return;
+  if (prm.only >= 0 && which != prm.only) return;
+  const int c = 2 * pair + which;
+  const int m = m_counts[c];
+  const unsigned* G = grid + (size_t)c * (kGridCap + 1);
+  const int* gi = ginfo + 8 * c;
+  const double4* p = pts + (size_t)c * P;
+  const u64* uc = ucell + (size_t)c * (P + 1);
+  const unsigned* ub = ubegin + (size_t)c * (P + 1);
+  const unsigned* list = hard_list + (size_t)c * P;
+  const double* list_d = hard_d + (size_t)c * P;
+  const int nu = n_ucell[c];
+  const int nhard = far2_count[c];
+  const int kk = min(prm.k_neighbors, 10);
+  const int want = min(kk, m);
+  const int bx0 = bbox[6 * c], by0 = bbox[6 * c + 1], bz0 = bbox[6 * c + 2], bx1 = bbox[6 * c + 3], by1 = bbox[6 * c + 4],
+            bz1 = bbox[6 * c + 5];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int h = chunk; h < nhard; h += nchunks) {  // uniform per workgroup
+    const int i = (int)list[P - 1 - h];
+    double Dk = list_d[P - 1 - h];
+    const double4 q = p[i];
+    const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
+              cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
+    const double uy = q.y * prm.inv_cell - (double)(cy - kCoordOffset), uz = q.z * prm.inv_cell - (double)(cz - kCoordOffset);
+    auto axis_lb = [&](int d, double u) {  // lower bound of the distance to the cells d steps away along one axis (a hair conservative)
+      const double v = d == 0 ? 0.0 : d > 0 ? (double)d - u : u - (double)(d + 1);
+      return fmax(v - 1e-9, 0.0) * prm.cell;
+    };
+    TopK<10> best;  // the merged result (thread 0)
+    int r = Dk < 1.0e300 ? max((int)ceil(sqrt(Dk) * prm.inv_cell), 2) : 4;  // (unbounded: r is not used, the scan takes everything)
+    while (true) {
+      const bool bounded = Dk < 1.0e300;
+      TopK<10> loc;
+      loc.init();
+      const int x0 = max(cx - r, bx0), x1 = min(cx + r, bx1), y0 = max(cy - r, by0), y1 = min(cy + r, by1), z0 = max(cz - r, bz0),
+                z1 = min(cz + r, bz1);
+      const int ny = y1 - y0 + 1, nrows = !bounded ? 1 : x0 <= x1 && y0 <= y1 && z0 <= z1 ? ny * (z1 - z0 + 1) : 0;
+      for (int row0 = 0; row0 < nrows; row0 += kFarWgRows) {
+        const int nr = min(kFarWgRows, nrows - row0);
+        // (a) the rows of the chunk: four a thread, their look-ups in flight together; rows (and x cells) beyond sqrt(Dk) are cut off
+        int len[4], beg[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int t = tid * 4 + u;  // a thread's rows are consecutive: one exclusive scan numbers the candidates
+          len[u] = 0;
+          beg[u] = 0;
+          if (t < nr && !bounded) {  // no k candidates known anywhere near: the whole cloud as one run (68 candidates a thread at VGA density)
+            len[u] = m;
+          } else if (t < nr) {
+            const int row = row0 + t, y = y0 + row % ny, z = z0 + row / ny;
+            int xa = x0, xb = x1;
+            bool use = true;
+            if (bounded) {
+              const double ly = axis_lb(y - cy, uy), lz = axis_lb(z - cz, uz), rest = Dk - ly * ly - lz * lz;
+              use = rest >= 0.0;
+              if (use) {  // x cells farther than sqrt(rest): an integer bound one cell on the safe side
+                const int rx = (int)ceil(sqrt(rest) * prm.inv_cell) + 1;
+                xa = max(xa, cx - rx);
+                xb = min(xb, cx + rx);
+              }
+            }
+            if (use && xa <= xb) {
+              int j0, j1;
+              row_range(gi, G, uc, ub, nu, xa, xb, y, z, &j0, &j1);
+              beg[u] = j0;
+              len[u] = j1 - j0;
+            }
+          }
+        }
+        const int mine = len[0] + len[1] + len[2] + len[3];
+        int incl = mine;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) {
+          const int v = __shfl_up(incl, ofs, 64);
+          if (lane >= ofs) incl += v;
+        }
+        __syncthreads();  // (the previous chunk's tables are no longer read)
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const int t = s_wave[w];
+          if (w < wave) base += t;
+          total += t;
+        }
+        int run = base + incl - mine;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int t = tid * 4 + u;
+          if (t < nr) {
+            s_beg[t] = beg[u];
+            s_pre[t] = run;
+          }
+          run += len[u];
+        }
+        if (tid == 0) s_pre[nr] = total;
+        __syncthreads();
+        // (b) the candidates of the chunk, numbered through: thread t takes v = t, t + 256, ...
+        int rr = 0, vend = s_pre[1];
+        constexpr int kFly = 8;  // loads in flight a thread (one workgroup a query: nothing else hides their latency)
+        for (int v = tid; v < total; v += kFly * 256) {
+          int j[kFly];
+          bool on[kFly];
+#pragma unroll
+          for (int u = 0; u < kFly; u++) {
+            const int vv = v + u * 256;
+            on[u] = vv < total;
+            j[u] = 0;
+            if (on[u]) {
+              while (vv >= vend) {
+                rr++;
+                vend = s_pre[rr + 1];
+              }
+              j[u] = s_beg[rr] + (vv - s_pre[rr]);
+            }
+          }
+          double4 t4[kFly];
+#pragma unroll
+          for (int u = 0; u < kFly; u++) t4[u] = p[j[u]];
+#pragma unroll
+          for (int u = 0; u < kFly; u++) {
+            const double ddx = t4[u].x - q.x, ddy = t4[u].y - q.y, ddz = t4[u].z - q.z;
+            const double d = ddx * ddx + ddy * ddy + ddz * ddz;
+            if (on[u] && d <= Dk) loc.push(j[u], d);
+          }
+        }
+      }
+      // (c) k winners of the workgroup: per wave by arg-min rounds over the lanes' list heads, then thread 0 merges the four lists
+#pragma unroll
+      for (int k = 0; k < 10; k++) {
+        const double hd = loc.d[0];
+        const int hj = loc.id[0];
+        double bd = hd;
+        int bj = hj;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+          const double od = __shfl_xor(bd, ofs, 64);
+          const int oj = __shfl_xor(bj, ofs, 64);
+          if (od < bd || (od == bd && (unsigned)oj < (unsigned)bj)) {
+            bd = od;
+            bj = oj;
+          }
+        }
+        if (lane == 0) {
+          s_md[wave][k] = bd;
+          s_mi[wave][k] = bj;
+        }
+        if (hj == bj && bj >= 0) {  // the owning lane pops its head
+#pragma unroll
+          for (int e = 0; e < 9; e++) {
+            loc.d[e] = loc.d[e + 1];
+            loc.id[e] = loc.id[e + 1];
+          }
+          loc.d[9] = 1.79769313486231570e308;
+          loc.id[9] = -1;
+        }
+      }
+      __syncthreads();
+      bool done = true;  // uniform: every thread evaluates the same merged list
+      {
+        best.init();
+        int hp[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          double bd = 1.79769313486231570e308;
+          int bj = -1, bw = -1;
+#pragma unroll
+          for (int w = 0; w < 4; w++) {
+            // (hp[w] is a run-time index into LDS, not into registers)
+            const double od = hp[w] < 10 ? s_md[w][hp[w]] : 1.79769313486231570e308;
+            const int oj = hp[w] < 10 ? s_mi[w][hp[w]] : -1;
+            if (oj >= 0 && (bj < 0 || od < bd || (od == bd && (unsigned)oj < (unsigned)bj))) {
+              bd = od;
+              bj = oj;
+              bw = w;
+            }
+          }
+          if (bj >= 0) {
+            best.d[k] = bd;
+            best.id[k] = bj;
+            best.found = k + 1;
+#pragma unroll
+            for (int w = 0; w < 4; w++) hp[w] += w == bw ? 1 : 0;
+          }
+        }
+        const double reach = (double)r * prm.cell;
+        const bool covers_all = !bounded || (cx - r <= bx0 && cx + r >= bx1 && cy - r <= by0 && cy + r >= by1 && cz - r <= bz0 && cz + r >= bz1);
+        const double kth = best.nth(max(want - 1, 0));
+        done = (best.found >= want && kth <= reach * reach) || covers_all || r > kCoordMask;
+        if (!done) {  // k candidates are known now: the next probe is the last one
+          if (best.found >= want) Dk = fmin(Dk, kth);
+          r = best.found >= want ? min(2 * r, (int)ceil(sqrt(kth) * prm.inv_cell)) : 2 * r;
+        }
+      }
+      __syncthreads();  // (s_md / s_mi are rewritten by the next probe or query)
+      if (done) break;
+    }
+    if (tid == 0) knn_write_cov(best, kk, p, cov6 + ((size_t)c * P + i) * 6);
   }
 }
 
@@ -2448,10 +2682,16 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   GFS_LAUNCH("k_knn_cov_far", (k_knn_cov_far<16, 2, true>), dim3(xcd_grid(far_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
              h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
              h->d_hard_d.p, h->d_far2.p, far_chunks, B, P, prm, h->d_cov6.p);
-  const int far2_chunks = std::max(1, std::min(4, knn_chunks));  // a handful of queries per cloud: few workgroups, grid-stride
-  GFS_LAUNCH("k_knn_cov_far2", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(far2_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p,
-             h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
-             h->d_hard_d.p, h->d_far2.p, far2_chunks, B, P, prm, h->d_cov6.p);
+  const int far2_chunks = std::max(1, std::min(32, knn_chunks));  // a handful of queries per cloud (a few dozen in the worst scenes), a workgroup each
+  static const bool far2_groups = getenv("GFS_GICP_FAR2") && strcmp(getenv("GFS_GICP_FAR2"), "groups") == 0;  // the lane-group form
+  if (far2_groups)
+    GFS_LAUNCH("k_knn_cov_far2", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(4, B, 2)), dim3(256), 0, s, h->d_pts.p,
+               h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
+               h->d_hard_d.p, h->d_far2.p, 4, B, P, prm, h->d_cov6.p);
+  else
+    GFS_LAUNCH("k_knn_cov_far2", k_knn_cov_far_wg, dim3(xcd_grid(far2_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p, h->d_ucell.p,
+               h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p, h->d_hard_d.p,
+               h->d_far2.p, far2_chunks, B, P, prm, h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
   GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
              prm.max_iterations, h->d_ndone.p);
@@ -2649,6 +2889,28 @@ int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset) {
   GFS_HIP(hipMemcpy(v, h->d_tile_stats.p, sizeof(v), hipMemcpyDeviceToHost));
   for (int k = 0; k < 8; k++) out8[k] = v[k];
   if (reset) GFS_HIP(hipMemset(h->d_tile_stats.p, 0, sizeof(v)));
+  return GFS_OK;
+}
+
+// Diagnostics: how many queries of cloud (b, which) of the last call went to the deferred k-NN passes, and the far ones' bounds.
+// out = {points, deferred to the r = 2 pass, deferred to the isolated-point pass}; dk (may be null): the latter's bounds (cap entries)
+int gfs_gicp_knn_stats(gfs_gicp* h, int b, int which, int out[3], double* dk, int cap) {
+  GFS_REQUIRE(h && b >= 0 && b < h->last_B && (which == 0 || which == 1) && out, GFS_ERR_INVALID_ARG, "gfs_gicp_knn_stats: invalid argument");
+  std::lock_guard<std::recursive_mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  GFS_HIP(hipDeviceSynchronize());
+  const int c = 2 * b + (which ? h->last_src_slot : 1 - h->last_src_slot);
+  int gi[8];
+  GFS_HIP(hipMemcpy(out, h->d_m.p + c, sizeof(int), hipMemcpyDeviceToHost));
+  GFS_HIP(hipMemcpy(gi, h->d_ginfo.p + 8 * c, sizeof(gi), hipMemcpyDeviceToHost));
+  out[1] = gi[7];
+  GFS_HIP(hipMemcpy(out + 2, h->d_far2.p + c, sizeof(int), hipMemcpyDeviceToHost));
+  const int n = std::min(out[2], cap);
+  if (dk && n > 0) {
+    std::vector<double> t((size_t)n);
+    GFS_HIP(hipMemcpy(t.data(), h->d_hard_d.p + (size_t)c * h->P + (h->P - n), (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; k++) dk[k] = t[(size_t)(n - 1 - k)];
+  }
   return GFS_OK;
 }
 

@@ -226,6 +226,9 @@ int gfs_gicp_fetch_preprocessed(gfs_gicp* h, int b, int which, double* pts, doub
  * tile (those workgroups search the cloud in HBM: same results); [6] tiling switched off.  Counted only by handles created with
  * GFS_GICP_TILE_STATS=1 in the environment (one atomic per workgroup on one address is not free). */
 int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset);
+/* Diagnostics (tools/knn_probe.py): out = {down-sampled points, queries deferred to the r = 2 pass, queries deferred to the
+ * isolated-point pass} of cloud (b, which) of the last call; dk (may be NULL): the squared-distance bounds of the latter. */
+int gfs_gicp_knn_stats(gfs_gicp* h, int b, int which, int out[3], double* dk, int cap);
 /* GPU test hook: the voxel sort of the preprocessing — the device replica of small_gicp's quick_sort_omp
  * (util/sort_omp.hpp:58-85: 3-way quicksort above 1024 elements, libstdc++ std::sort below), whose permutation of
  * equal keys decides the 1024-block splits of voxelgrid_sampling_omp (util/downsampling_omp.hpp:57-90) — on n <=
