@@ -307,24 +307,48 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
                                                        const unsigned* __restrict__ val1, const int* __restrict__ which,
                                                        const int* __restrict__ counts, int P, double inv_cell,
                                                        double4* __restrict__ tmp_pts, u64* __restrict__ cell_keys,
-                                                       unsigned* __restrict__ cell_idx, int* __restrict__ m_counts, int only) {
+                                                       unsigned* __restrict__ cell_idx, int* __restrict__ m_counts, int only,
+                                                       int tiles_per_part, int* __restrict__ bbox) {
+  // gridDim.y workgroups a cloud (small batches: one workgroup a cloud leaves the chip idle): part p takes the 1024-element tiles
+  // [p * tiles_per_part, (p + 1) * tiles_per_part) and first counts the means the tiles in front of it emit -- the same numbers,
+  // the same output positions as a single workgroup walking the whole array
   __shared__ int s_wave[16];
   __shared__ int s_carry;
-  const int c = blockIdx.x, pair = c >> 1, tid = threadIdx.x;
+  const int c = blockIdx.x, pair = c >> 1, tid = threadIdx.x, part = blockIdx.y;
   if (only >= 0 && (c & 1) != only) return;
   const int n = counts[c];
+  if (part == 0 && tid < 6) bbox[6 * c + tid] = tid < 3 ? kCoordMask : 0;  // k_cell_build's workgroups reduce into it
   const u64* keys = (which[c] ? keys1 : keys0) + (size_t)c * P;
   const unsigned* idx = (which[c] ? val1 : val0) + (size_t)c * P;
   const float4* in = ((c & 1) ? src : tgt) + (size_t)pair * stride_pts;
   double4* out = tmp_pts + (size_t)c * P;
   u64* ck = cell_keys + (size_t)c * P;
   unsigned* ci = cell_idx + (size_t)c * P;
-  if (tid == 0) s_carry = 0;
+  const int e0 = min(part * tiles_per_part * 1024, n), e1 = part + 1 == (int)gridDim.y ? n : min((part + 1) * tiles_per_part * 1024, n);
+  {
+    int before = 0;  // means emitted by [0, e0): a run start = a valid key that differs from its predecessor or sits on a 1024-cut
+    for (int i = tid; i < e0; i += 8 * 1024) {  // (thread 0 sits on the 1024-cuts: i & 1023 == tid; e0 is a multiple of 1024)
+      u64 k[8], kp[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int iu = min(i + u * 1024, e0 - 1);
+        k[u] = keys[iu];
+        kp[u] = keys[max(iu - 1, 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        before += (i + u * 1024 < e0 && k[u] != kInvalidKey && (tid == 0 || kp[u] != k[u])) ? 1 : 0;
+    }
+    int total;
+    (void)block_scan_1024(before, s_wave, &total);
+    __syncthreads();
+    if (tid == 0) s_carry = total;
+  }
   __syncthreads();
-  for (int t0 = 0; t0 < n; t0 += 1024) {
+  for (int t0 = e0; t0 < e1; t0 += 1024) {
     const int i = t0 + tid;
     u64 key = kInvalidKey;
-    if (i < n) key = keys[i];
+    if (i < e1) key = keys[i];
     const bool valid = key != kInvalidKey;
     const bool start = valid && (i == 0 || (i & 1023) == 0 || keys[i - 1] != key);
     int total;
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
     if (tid == 0) s_carry += total;
     __syncthreads();
   }
-  if (tid == 0) m_counts[c] = s_carry;
+  if (tid == 0 && part + 1 == (int)gridDim.y) m_counts[c] = s_carry;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -370,9 +394,11 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
                                                      u64* __restrict__ ucell, unsigned* __restrict__ ubegin,
                                                      int* __restrict__ n_ucell, int* __restrict__ bbox,
                                                      const int* __restrict__ kinfo, int only) {
+  // gridDim.y workgroups a cloud: part p takes the sorted elements [a0, a1) and first counts the cells that start in front of a0
+  // (bbox[6c ..] was reset by k_voxel_reduce; the parts reduce into it with atomics)
   __shared__ int s_wave[16];
   __shared__ int s_bb[6];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, tid = threadIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (only >= 0 && (c & 1) != only) return;
   if (tid < 3) s_bb[tid] = kCoordMask;
   else if (tid < 6) s_bb[tid] = 0;
@@ -384,20 +410,21 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
   u64* uc = ucell + (size_t)c * (P + 1);
   unsigned* ub = ubegin + (size_t)c * (P + 1);
   __syncthreads();
-  for (int i = tid; i < m; i += 4 * 1024) {  // independent gathers, four in flight (a plain loop waits for every one of them)
+  const int span = (m + nparts - 1) / nparts, a0 = min(part * span, m), a1 = min(a0 + span, m);
+  for (int i = a0 + tid; i < a1; i += 4 * 1024) {  // independent gathers, four in flight (a plain loop waits for every one of them)
     unsigned ix[4];
     double4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) ix[u] = ci[min(i + u * 1024, m - 1)];
+    for (int u = 0; u < 4; u++) ix[u] = ci[min(i + u * 1024, a1 - 1)];
 #pragma unroll
     for (int u = 0; u < 4; u++) v[u] = tp[ix[u]];
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (i + u * 1024 < m) out[i + u * 1024] = v[u];
+      if (i + u * 1024 < a1) out[i + u * 1024] = v[u];
   }
-  // every thread owns a contiguous chunk of the sorted keys: one block scan numbers the cell starts
-  const int chunk = (m + 1023) / 1024;
-  const int i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
+  // every thread owns a contiguous chunk of the part's sorted keys: one block scan numbers the cell starts
+  const int chunk = (a1 - a0 + 1023) / 1024;
+  const int i0 = min(a0 + tid * chunk, a1), i1 = min(i0 + chunk, a1);
   // the sort compacted the keys (k_radix_sort); a CELL is the key without the kFineBits sub-cell bits of its x field
   const int* ki = kinfo + 8 * c;
   const int kbx = ki[3], kby = ki[4];
@@ -444,8 +471,31 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
   } else {
     for (int i = i0; i < i1; i++) cnt += new_cell(i) ? 1 : 0;
   }
+  int carry = 0;  // cells that start in [0, a0)
+  if (a0 > 0) {
+    int before = 0;
+    for (int i = tid; i < a0; i += 8 * 1024) {
+      u64 k[8], kp[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int iu = min(i + u * 1024, a0 - 1);
+        k[u] = ck[iu];
+        kp[u] = ck[max(iu - 1, 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int ax, ay, az, bx_, by_, bz_;
+        cell_of(kp[u], ax, ay, az);
+        cell_of(k[u], bx_, by_, bz_);
+        before += (i + u * 1024 < a0 && (i + u * 1024 == 0 || ax != bx_ || ay != by_ || az != bz_)) ? 1 : 0;
+      }
+    }
+    (void)block_scan_1024(before, s_wave, &carry);
+    __syncthreads();
+  }
   int total;
-  int pos = block_scan_1024(cnt, s_wave, &total);
+  int pos = carry + block_scan_1024(cnt, s_wave, &total);
+  total += carry;
   {
     int mn[3] = {kCoordMask, kCoordMask, kCoordMask}, mx[3] = {0, 0, 0};
     auto emit = [&](int i, u64 key) {
@@ -479,12 +529,14 @@ __global__ __launch_bounds__(1024) void k_cell_build(const double4* __restrict__
     }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && part + 1 == nparts) {
     n_ucell[c] = total;
     ub[total] = (unsigned)m;
     uc[total] = kInvalidKey;
   }
-  if (tid < 6) bbox[6 * c + tid] = s_bb[tid];  // occupied-cell bounding box (x0,y0,z0,x1,y1,z1)
+  // occupied-cell bounding box (x0,y0,z0,x1,y1,z1), reduced over the parts (a part without a cell start holds the neutral values)
+  if (tid < 3) atomicMin(&bbox[6 * c + tid], s_bb[tid]);
+  else if (tid < 6) atomicMax(&bbox[6 * c + tid], s_bb[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2653,7 +2705,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
                h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only, kCoordBits, 2 * kCoordBits);
   } else {
     // the reference's (unstable) quick_sort_omp permutation, reproduced exactly: util/sort_omp.hpp:58-85
-    const int leaf_parts = std::max(1, std::min(64, P / 2048));
+    const int leaf_parts = std::max(1, std::min(64, P / 1024));  // x 4 waves: a wave per leaf for nearly every cloud (the longest leaf sets the time)
     int rc_leaf = 0;
     GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, (size_t)C2 * sizeof(int), s));
     GFS_HIP(voxel_qsort_top(h, C2, s, prm.only, optimistic_sort ? h->d_ndone.p + 1 : nullptr));
@@ -2664,12 +2716,15 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
                          : voxel_qsort_leaves(h, C2, leaf_parts, s, prm.only, narrow_only, in_even, in_odd, stride_pts);
     if (rc_leaf) return rc_leaf;
   }
-  GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2), dim3(1024), 0, s, in_even, in_odd, stride_pts, h->d_keys0.p, h->d_keys1.p,
-             h->d_val0.p, h->d_val1.p, h->d_which.p, h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p, h->d_m.p,
-             prm.only);
+  // small batches: several workgroups a cloud for the one-workgroup-per-cloud kernels (256 CUs; the clouds of a streaming call are C2 / 2)
+  const int tiles = P / 1024, wg_parts = std::max(1, std::min(std::min(8, tiles), 384 / std::max(1, prm.only >= 0 ? C2 / 2 : C2)));
+  const int tiles_per_part = gfs::div_up(tiles, wg_parts);
+  GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2, wg_parts), dim3(1024), 0, s, in_even, in_odd, stride_pts, h->d_keys0.p,
+             h->d_keys1.p, h->d_val0.p, h->d_val1.p, h->d_which.p, h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p,
+             h->d_m.p, prm.only, tiles_per_part, h->d_bbox.p);
   GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p, h->d_ci1.p,
              h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p, prm.only, kCkSy, kCkSz);
-  GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
+  GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2, wg_parts), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
              h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p,
              prm.only);
   GFS_LAUNCH("k_grid_fill", k_grid_fill, dim3(kGridFillParts, C2), dim3(256), 0, s, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p,
@@ -2869,7 +2924,7 @@ int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsi
   GFS_HIP(hipMemcpyAsync(h->d_counts.p, counts, sizeof(counts), hipMemcpyHostToDevice, s));
   if (n) GFS_HIP(hipMemcpyAsync(h->d_keys0.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, s));
   if (n) GFS_HIP(hipMemcpyAsync(h->d_val0.p, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-  const int leaf_parts = std::max(1, std::min(64, P / 2048));
+  const int leaf_parts = std::max(1, std::min(64, P / 1024));  // x 4 waves: a wave per leaf for nearly every cloud (the longest leaf sets the time)
   GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, 2 * sizeof(int), s));
   GFS_HIP(voxel_qsort_top(h, 2, s, -1, nullptr));
   {
