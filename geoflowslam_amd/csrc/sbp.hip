@@ -127,67 +127,69 @@ __device__ __forceinline__ Proj sbp_project(const SbpPair& P, const SbpView& V, 
   return R;
 }
 
+// The current frame's key-points as the candidate loop needs them, in LDS (filled with the grid): position, octave, mvuRight, and
+// whether a map point with observations sits there on entry.
+struct SbpCur {
+  const float* x;
+  const float* y;
+  const uint8_t* oct;
+  const float* ur;
+  const uint8_t* has_obs;
+};
+
 // GetFeaturesInArea + the static filters of the candidate loop, in the reference's visiting order (ix, iy, cell order).
 // f(i2, dist) is called for every candidate that survives them; returns whether vIndices2 was non-empty.
-// The items of the window's cells are walked as one sequence, four at a time: the four key-points are fetched together, then the
-// descriptors of the survivors together -- two round trips to memory per four items instead of two per item.
+// A cell is c = ix * kGridRows + iy and the items are stored by cell, so the cells iy = y0 .. y1 of one grid column are ONE
+// contiguous run of s_items: a window is x1 - x0 + 1 runs (<= 13 for the largest radius), not (x1 - x0 + 1) (y1 - y0 + 1) cells of
+// which two thirds are empty.  The items are walked four at a time: their fields come from LDS, the descriptors of the survivors
+// are fetched together -- one round trip to memory per four items, for the survivors only.
 template <class F>
-__device__ __forceinline__ bool sbp_candidates(const SbpPair& P, const SbpView& V, const Proj& R, int l,
+__device__ __forceinline__ bool sbp_candidates(const SbpPair& P, const SbpView& V, const SbpCur& C, const Proj& R, int l,
                                                const unsigned short* s_start, const unsigned short* s_items, F&& f) {
   const bool bCheckLevels = (R.minLevel > 0) || (R.maxLevel >= 0);
   bool any = false;
   const uint4* dl = reinterpret_cast<const uint4*>(V.last_desc + 32 * (size_t)l);
   const uint4 a0 = dl[0], a1 = dl[1];
-  int ix = R.x0, iy = R.y0;
-  int k = s_start[ix * kGridRows + iy], kend = s_start[ix * kGridRows + iy + 1];
+  int ix = R.x0;
+  int k = s_start[ix * kGridRows + R.y0], kend = s_start[ix * kGridRows + R.y1 + 1];
   bool more = true;
   auto next_item = [&]() {  // the next key-point index of the window in visiting order, or -1
     while (more && k >= kend) {
-      if (++iy > R.y1) {
-        iy = R.y0;
-        if (++ix > R.x1) {
-          more = false;
-          break;
-        }
+      if (++ix > R.x1) {
+        more = false;
+        break;
       }
-      k = s_start[ix * kGridRows + iy];
-      kend = s_start[ix * kGridRows + iy + 1];
+      k = s_start[ix * kGridRows + R.y0];
+      kend = s_start[ix * kGridRows + R.y1 + 1];
     }
     return more ? (int)s_items[k++] : -1;
   };
   while (more) {
     int i2[4];
-    gfs_keypoint kp[4];
-    float ur2[4];
-    uint8_t ho[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      i2[u] = next_item();
-      const int j = max(i2[u], 0);
-      kp[u] = V.cur_kp[j];
-      ur2[u] = V.cur_ur[j];
-      ho[u] = V.cur_has_obs[j];
-    }
     bool pass[4];
     uint4 b0[4], b1[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
+      i2[u] = next_item();
       pass[u] = false;
       if (i2[u] < 0) continue;
+      const int j = i2[u];
       if (bCheckLevels) {
-        if (kp[u].octave < R.minLevel) continue;
-        if (R.maxLevel >= 0 && kp[u].octave > R.maxLevel) continue;
+        const int oct = C.oct[j];
+        if (oct < R.minLevel) continue;
+        if (R.maxLevel >= 0 && oct > R.maxLevel) continue;
       }
-      const float distx = kp[u].x - R.u, disty = kp[u].y - R.v;
+      const float distx = C.x[j] - R.u, disty = C.y[j] - R.v;
       if (!(fabsf(distx) < R.radius && fabsf(disty) < R.radius)) continue;
       any = true;
-      if (ho[u]) continue;  // a map point with observations was there on entry: never replaced
-      if (ur2[u] > 0) {
-        const float er = fabsf(R.ur - ur2[u]);
+      if (C.has_obs[j]) continue;  // a map point with observations was there on entry: never replaced
+      const float ur2 = C.ur[j];
+      if (ur2 > 0) {
+        const float er = fabsf(R.ur - ur2);
         if (er > R.ur_gate) continue;
       }
       pass[u] = true;
-      const uint4* dc = reinterpret_cast<const uint4*>(V.cur_desc + 32 * (size_t)i2[u]);
+      const uint4* dc = reinterpret_cast<const uint4*>(V.cur_desc + 32 * (size_t)j);
       b0[u] = dc[0];
       b1[u] = dc[1];
     }
@@ -213,6 +215,11 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
   return min(min(r0, r1), min(r2, r3));
 }
 
+#ifdef GFS_SBP_TIMING
+#define SBP_T(k) { const long long _n = clock64(); if (threadIdx.x == 0) sbp_t[k] = _n; }
+#else
+#define SBP_T(k)
+#endif
 __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__ pairs, const float* __restrict__ last_xw,
                                                      const uint8_t* __restrict__ last_desc, const int* __restrict__ last_octave,
                                                      const float* __restrict__ last_angle, const uint8_t* __restrict__ last_has_obs,
@@ -228,13 +235,19 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
   __shared__ unsigned s_pool[2 * kChunk * kCand];
   int* s_cnt = reinterpret_cast<int*>(s_pool);
   static_assert(2 * kChunk * kCand >= kCells, "the pool must hold the cell counters");
-  __shared__ int s_ccnt[2][kChunk];
+  __shared__ int s_hold[kSbpMaxCur];  // last taker of a key-point (assignment pass)
   __shared__ uint8_t s_hasobs[kSbpMaxLast];  // Observations() > 0 of the last frame's map points
   __shared__ uint8_t s_oct[kSbpMaxCur];      // octave of the current key-points (the ratio test of the map-point overload)
-  __shared__ int s_scan[kSbpThreads];
+  __shared__ int s_scan[16];
+  __shared__ float s_kx[kSbpMaxCur], s_ky[kSbpMaxCur], s_ur[kSbpMaxCur];  // key-point position, mvuRight
+  __shared__ uint8_t s_ho[kSbpMaxCur];                                    // a map point with observations on entry
   __shared__ int s_hist[kHisto];
   __shared__ int s_ctl[4];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+#ifdef GFS_SBP_TIMING
+  __shared__ long long sbp_t[8];
+#endif
+  SBP_T(0)
   // the pair's header lives in LDS: its scale table is indexed by the octave, and a private copy indexed at run time is a copy in
   // scratch memory -- every field access a round trip to the L1
   __shared__ SbpPair s_P;
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
   int* ccnt = cand_cnt + (size_t)f * SL;
   int* sel = lsel + (size_t)f * SL;
   const int N = P.n_cur, NL = P.n_last;
-  // ---- 0. grid
+  // ---- 0. grid (Frame::AssignFeaturesToGrid: the key-points of a cell in index order) + the key-point fields the windows look at
   for (int c = tid; c < kCells; c += kSbpThreads) s_cnt[c] = 0;
   if (tid < kHisto) s_hist[tid] = 0;
   __syncthreads();
@@ -259,36 +272,59 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
     s_cell[i] = in ? (unsigned short)(px * kGridRows + py) : (unsigned short)0xffff;
     s_state[i] = -1;
     s_oct[i] = (uint8_t)kp.octave;
+    s_kx[i] = kp.x;
+    s_ky[i] = kp.y;
+    s_ur[i] = V.cur_ur[i];
+    s_ho[i] = V.cur_has_obs[i];
     if (in) atomicAdd(&s_cnt[px * kGridRows + py], 1);
   }
   __syncthreads();
   {
     constexpr int per = kCells / kSbpThreads;  // 3 (3072 cells over 1024 threads)
-    int local = 0;
-    for (int k = 0; k < per; k++) local += s_cnt[tid * per + k];
-    s_scan[tid] = local;
-    __syncthreads();
-    for (int ofs = 1; ofs < kSbpThreads; ofs <<= 1) {
-      const int v = tid >= ofs ? s_scan[tid - ofs] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
+    int cnt[per], local = 0;
+#pragma unroll
+    for (int k = 0; k < per; k++) {
+      cnt[k] = s_cnt[tid * per + k];
+      local += cnt[k];
     }
-    int run = s_scan[tid] - local;
+    int incl = local;  // exclusive scan over the threads: shuffles inside the wave, the sixteen wave totals through LDS
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+      const int v = __shfl_up(incl, ofs, 64);
+      if (lane >= ofs) incl += v;
+    }
+    if (lane == 63) s_scan[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < (tid >> 6); w++) run += s_scan[w];
+#pragma unroll
     for (int k = 0; k < per; k++) {
       s_start[tid * per + k] = (unsigned short)run;
-      run += s_cnt[tid * per + k];
+      s_cnt[tid * per + k] = 0;  // now the fill counter of the cell
+      run += cnt[k];
     }
     if (tid == kSbpThreads - 1) s_start[kCells] = (unsigned short)run;
   }
   __syncthreads();
-  for (int i = tid; i < N; i += kSbpThreads) {  // position inside the cell = number of earlier key-points of that cell
+  for (int i = tid; i < N; i += kSbpThreads) {  // into the cell in arrival order ...
     const unsigned short c = s_cell[i];
     if (c == 0xffff) continue;
-    int r = 0;
-    for (int j = 0; j < i; j++) r += s_cell[j] == c ? 1 : 0;
-    s_items[s_start[c] + r] = (unsigned short)i;
+    s_items[s_start[c] + atomicAdd(&s_cnt[c], 1)] = (unsigned short)i;
   }
+  __syncthreads();
+  for (int c = tid; c < kCells; c += kSbpThreads) {  // ... then every cell in index order (a handful of items: insertion sort)
+    const int b = s_start[c], e = s_start[c + 1];
+    for (int a = b + 1; a < e; a++) {
+      const unsigned short v = s_items[a];
+      int q = a;
+      while (q > b && s_items[q - 1] > v) {
+        s_items[q] = s_items[q - 1];
+        q--;
+      }
+      s_items[q] = v;
+    }
+  }
+  const SbpCur Cur{s_kx, s_ky, s_oct, s_ur, s_ho};
   // twc = Tcw.inverse().translation(); tlc = Tlw * twc  (se3.hpp:208-211; the SO3 constructor re-normalises the conjugate)
   float qi[4] = {-P.Tcw_q[0], -P.Tcw_q[1], -P.Tcw_q[2], P.Tcw_q[3]};
   {
@@ -302,6 +338,7 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
   for (int k = 0; k < 3; k++) tlc[k] += P.Tlw_t[k];
   const bool bForward = tlc[2] > P.b && !P.mono, bBackward = -tlc[2] > P.b && !P.mono;
   __syncthreads();
+  SBP_T(1)
   // ---- A. candidates of every map point (parallel)
   for (int l = tid; l < NL; l += kSbpThreads) {
     s_hasobs[l] = V.last_has_obs[l];
@@ -309,117 +346,114 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
     int n = 0;
     bool any = false;
     if (R.ok)
-      any = sbp_candidates(P, V, R, l, s_start, s_items, [&](int i2, int dist) {
+      any = sbp_candidates(P, V, Cur, R, l, s_start, s_items, [&](int i2, int dist) {
         if (n < kCand) cnd[(size_t)l * kCand + n] = (unsigned)i2 | ((unsigned)dist << 16);
         n++;
       });
     ccnt[l] = any ? n : -1;  // -1: vIndices2.empty() -> continue
   }
   __syncthreads();
-  // ---- B. assignment in map-point order: one wave walks the map points, everything it looks at is in LDS -- the other fifteen waves
-  //         fetch the candidate lists of the next kChunk map points meanwhile (a map point's step used to be two dependent round
-  //         trips to HBM: 1.3 us x 900 map points; now ~0.2 us)
-  auto fetch = [&](int c0, int buf, int t, int nt) {
-    for (int k = t; k < kChunk * kCand; k += nt) {
-      const int l = c0 + k / kCand;
-      s_pool[buf * kChunk * kCand + k] = l < NL ? cnd[(size_t)l * kCand + (k % kCand)] : 0u;
-    }
-    for (int k = t; k < kChunk; k += nt) s_ccnt[buf][k] = c0 + k < NL ? ccnt[c0 + k] : -1;
-  };
-  fetch(0, 0, tid, kSbpThreads);
   __syncthreads();
-  int nm = 0;
-  for (int c0 = 0; c0 < NL; c0 += kChunk) {
-    const int buf = (c0 / kChunk) & 1;
-    if (tid >= 64) {
-      if (c0 + kChunk < NL) fetch(c0 + kChunk, buf ^ 1, tid - 64, kSbpThreads - 64);
-    } else {
-      const int lend = min(c0 + kChunk, NL);
-      // (the list entry and the count of the NEXT map point are read while this one is decided: they do not depend on it)
-      int n_next = s_ccnt[buf][0];
-      unsigned e_next = s_pool[buf * kChunk * kCand + lane];
-      for (int l = c0; l < lend; l++) {
-        const int n = n_next;
-        const unsigned e = e_next;
-        if (l + 1 < lend) {
-          n_next = s_ccnt[buf][l + 1 - c0];
-          e_next = s_pool[buf * kChunk * kCand + (l + 1 - c0) * kCand + lane];
-        }
-        int sel_l = -1;
-        if (n >= 0) {
-          unsigned key = 0xffffffffu;  // dist << 16 | visiting order: the first minimum wins
-          unsigned idx = 0;
-          unsigned key2 = 0xffffffffu, idx2 = 0;  // second best (mode 1, re-enumeration path)
-          if (n <= kCand) {
-            if (lane < n) {
-              const int i2 = (int)(e & 0xffffu);
-              const int st = s_state[i2];
-              if (!(st >= 0 && s_hasobs[st])) {  // mvpMapPoints[i2] && Observations() > 0 -> skip (:1914-1915)
-                key = ((e >> 16) << 16) | (unsigned)lane;
-                idx = (unsigned)i2;
-              }
-            }
-          } else if (lane == 0) {  // more candidates than the list holds: enumerate them again (rare)
-            const Proj R = sbp_project(P, V, l, bForward, bBackward);
-            int order = 0;
-            int bestDist = 256;
-            int bestDist2 = 256;
-            sbp_candidates(P, V, R, l, s_start, s_items, [&](int i2, int dist) {
-              const int st = s_state[i2];
-              if (!(st >= 0 && s_hasobs[st])) {
-                const unsigned kk = ((unsigned)dist << 16) | (unsigned)min(order, 0xffff);
-                if (dist < bestDist) {
-                  bestDist2 = bestDist;
-                  key2 = key;
-                  idx2 = idx;
-                  bestDist = dist;
-                  idx = (unsigned)i2;
-                  key = kk;
-                } else if (dist < bestDist2) {
-                  bestDist2 = dist;
-                  key2 = kk;
-                  idx2 = (unsigned)i2;
-                }
-              }
-              order++;
-            });
-          }
-          // the keys are distinct (their low half is the visiting order = the lane, or sits on lane 0 alone): the smallest key names
-          // its lane, whose index is then read directly
-          const unsigned mykey = key, myidx = idx;
-          key = wave_umin(mykey);
-          const int from = n <= kCand ? (int)(key & 63u) : 0;
-          idx = (unsigned)__builtin_amdgcn_readlane((int)myidx, __builtin_amdgcn_readfirstlane(from));
-          const int bestDist = key == 0xffffffffu ? 256 : (int)(key >> 16);
-          if (P.mode == 1) {
-            // second best = the smallest (distance, visiting order) among the others: what the sequential best / second-best
-            // bookkeeping of :96-113 ends with.  (The re-enumeration path has filled key2 / idx2 on lane 0.)
-            const unsigned myk2 = (n <= kCand) ? (mykey == key ? 0xffffffffu : mykey) : key2, myi2b = (n <= kCand) ? myidx : idx2;
-            const unsigned k2 = wave_umin(myk2);
-            const int from2 = n <= kCand ? (int)(k2 & 63u) : 0;
-            const unsigned i2b = (unsigned)__builtin_amdgcn_readlane((int)myi2b, __builtin_amdgcn_readfirstlane(from2));
-            if (bestDist <= kThHigh) {
-              const int best = (int)idx;
-              const int bestDist2 = k2 == 0xffffffffu ? 256 : (int)(k2 >> 16);
-              const int bestLevel = s_oct[best], bestLevel2 = k2 == 0xffffffffu ? -1 : (int)s_oct[i2b];
-              const bool reject = bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2;
-              if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= P.nn_ratio * (float)bestDist2)) {
-                nm++;
-                if (lane == 0) s_state[best] = (short)l;
-              }
-            }
-          } else if (bestDist <= kThHigh) {
-            nm++;
-            if (lane == 0) s_state[(int)idx] = (short)l;
-            sel_l = (int)idx;
-          }
-        }
-        if (lane == 0) sel[l] = sel_l;  // mode 0: the key-point this map point took (its histogram bin follows below)
+  SBP_T(2)
+  // ---- B. assignment.  The reference walks the map points in index order; each takes its nearest candidate (first minimum in
+  //         visiting order) among the key-points that do not hold a map point with observations yet (:1914-1915), i.e. that no
+  //         EARLIER map point with Observations() > 0 has taken.  That is a serial dictatorship, and with one common priority order
+  //         (the index) its outcome is the fixed point of deferred acceptance: every map point proposes to its best key-point
+  //         that is not held by a lower-index blocker, every key-point keeps the lowest-index blocking proposer, the displaced
+  //         ones propose again.  A key-point's holder index only ever decreases, so a map point's options only shrink and a
+  //         handful of fully parallel rounds (the longest displacement chain) replace the walk over ~1000 map points on one wave.
+  //         s_block[i2] = lowest index of a proposer with Observations() > 0 (a map point without observations takes a
+  //         key-point without blocking it: later ones overwrite it, and every take counts -- :1929-1933).
+  int* s_block = reinterpret_cast<int*>(s_pool);  // [kSbpMaxCur] (the cell counters are no longer needed)
+  static_assert(2 * kChunk * kCand >= kSbpMaxCur, "the pool must hold the blocker table");
+  for (int i = tid; i < N; i += kSbpThreads) {
+    s_block[i] = 0x7fffffff;
+    s_hold[i] = -1;
+  }
+  // best available candidate of map point l (everything the sequential code decides for it, given who blocks what): -1 = none
+  auto decide = [&](int l) {
+    const int n = ccnt[l];
+    if (n < 0) return -1;
+    unsigned key = 0xffffffffu, key2 = 0xffffffffu;  // dist << 16 | visiting order: the first minimum wins; the second best (mode 1)
+    int idx = -1, idx2 = -1;
+    auto offer = [&](int i2, int dist, int order) {
+      if (s_block[i2] < l) return;  // mvpMapPoints[i2] && Observations() > 0 -> skip (:1914-1915)
+      const unsigned kk = ((unsigned)dist << 16) | (unsigned)min(order, 0xffff);
+      if (kk < key) {
+        key2 = key;
+        idx2 = idx;
+        key = kk;
+        idx = i2;
+      } else if (kk < key2) {
+        key2 = kk;
+        idx2 = i2;
       }
+    };
+    if (n <= kCand) {
+      for (int j = 0; j < n; j += 4) {  // (a row of the list is 256 bytes: four entries a load)
+        const uint4 e4 = *reinterpret_cast<const uint4*>(cnd + (size_t)l * kCand + j);
+        const unsigned e[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (j + u < n) offer((int)(e[u] & 0xffffu), (int)(e[u] >> 16), j + u);
+      }
+    } else {  // more candidates than the list holds: enumerate them again (rare)
+      const Proj R = sbp_project(P, V, l, bForward, bBackward);
+      int order = 0;
+      sbp_candidates(P, V, Cur, R, l, s_start, s_items, [&](int i2, int dist) { offer(i2, dist, order++); });
     }
+    const int bestDist = idx < 0 ? 256 : (int)(key >> 16);
+    if (bestDist > kThHigh) return -1;
+    if (P.mode == 1) {  // best / second-best ratio test when both sit on one pyramid level (:96-113)
+      const int bestDist2 = idx2 < 0 ? 256 : (int)(key2 >> 16);
+      const int bestLevel = s_oct[idx], bestLevel2 = idx2 < 0 ? -1 : (int)s_oct[idx2];
+      if (bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2) return -1;
+    }
+    return idx;
+  };
+  __syncthreads();
+  for (int round = 0;; round++) {
+    if (tid == 0) s_ctl[0] = 0;
+    __syncthreads();
+    bool changed = false;
+    for (int l = tid; l < NL; l += kSbpThreads) {
+      const int cur = round == 0 ? -3 : sel[l];
+      // mode 0: a proposal stands until a lower-index blocker takes its key-point, "nothing" stands for good (options only shrink);
+      // mode 1: the ratio test looks at the second best as well, so every round decides again
+      if (round > 0 && P.mode == 0 && (cur < 0 || s_block[cur] >= l)) continue;
+      const int now = decide(l);
+      if (now != cur) {
+        sel[l] = now;
+        changed = true;
+      }
+      if (now >= 0 && s_hasobs[l] && atomicMin(&s_block[now], l) > l) changed = true;
+    }
+    if (changed) s_ctl[0] = 1;
+    __syncthreads();
+    const bool again = s_ctl[0] != 0;
+    __syncthreads();
+    if (!again) break;
+  }
+  SBP_T(3)
+  // takes: every map point with a proposal (an overwritten take counts like the reference counts it); the key-point ends up with the
+  // LAST taker in index order = its blocker if it has one (nobody above a blocker can take it), else the highest-index taker
+  int nm = 0;
+  for (int l = tid; l < NL; l += kSbpThreads) {
+    const int i2 = sel[l];
+    if (i2 < 0) continue;
+    nm++;
+    atomicMax(&s_hold[i2], l);
+    if (P.mode == 1) sel[l] = -1;  // (the rotation histogram below belongs to the frame-to-frame overload)
+  }
+  {
+    for (int ofs = 32; ofs > 0; ofs >>= 1) nm += __shfl_down(nm, ofs, 64);
+    if (tid == 0) s_ctl[0] = 0;
+    __syncthreads();
+    if (lane == 0 && nm) atomicAdd(&s_ctl[0], nm);
     __syncthreads();
   }
-  if (tid == 0) s_ctl[0] = nm;
+  for (int i = tid; i < N; i += kSbpThreads)
+    if (s_hold[i] >= 0) s_state[i] = (short)s_hold[i];
   __syncthreads();
   if (P.mode == 0) {  // rotHist[bin].push_back(bestIdx2) of every assignment (:1935-1944), all map points at once
     for (int l = tid; l < NL; l += kSbpThreads) {
@@ -484,6 +518,11 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
     }
     __syncthreads();
   }
+  SBP_T(4)
+#ifdef GFS_SBP_TIMING
+  __syncthreads();
+  if (tid == 0 && f == 0) printf("SBPT grid=%lld A=%lld B=%lld C=%lld N=%d NL=%d\n", sbp_t[1] - sbp_t[0], sbp_t[2] - sbp_t[1], sbp_t[3] - sbp_t[2], sbp_t[4] - sbp_t[3], N, NL);
+#endif
   for (int i = tid; i < N; i += kSbpThreads) cur_match[(size_t)f * SC + i] = s_state[i];
   if (tid == 0) nmatches[f] = s_ctl[0];
 }
