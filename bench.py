@@ -728,8 +728,9 @@ def main():
             gbe = bs.GpuBackend(api, W, H, NF, NL, SP, device=local_rank)
             lat_g, st_g, states_g = bs.run_stream(gbe, frames_s, Kc, W, H, STRIDE, 120, warm=6)
             ss = bs.summarize(lat_g, st_g)
-            ss.update(metric="single-stream front-end latency per frame (B = 1, sequential): ORB + stereo-from-RGBD + depth->cloud + GICP (streaming entry) "
-                             "+ SearchByProjection + PoseOptimization, host pointers in, results out, every copy and sync included",
+            ss.update(metric="single-stream front-end latency per frame (B = 1, sequential): ORB + the RGB-D tail of the Frame constructor (stereo-from-RGBD + depth->cloud: "
+                             "gfs_frame_rgbd, the cloud stays on the device) + GICP (streaming entry) + SearchByProjection + PoseOptimization, host pointers in, "
+                             "results out, every copy and sync included",
                       matches_per_frame=int(np.median([s_["matches"] for s_ in states_g])), pose_inliers_per_frame=int(np.median([s_["inliers"] for s_ in states_g])))
             if not args.no_cpu_baseline:
                 from oracle import oracle as O

@@ -2,8 +2,8 @@
 System::TrackRGBD (reference src/System.cc:600) -> Tracking::GrabImageRGBD -> Frame::Frame -> Tracking::Track drives the path:
 
     ORB extraction of the new image                      Frame::ExtractORB            src/Frame.cc:ORBextractor::operator()
- -> mvuRight / mvDepth from the depth map                Frame::ComputeStereoFromRGBD src/Frame.cc:1314-1332
- -> depth map -> point cloud                             Frame::ConvertDepthToPointCloud src/Frame.cc:590-623
+ -> mvuRight / mvDepth from the depth map                Frame::ComputeStereoFromRGBD src/Frame.cc:1314-1332   } one stage: the RGB-D tail
+ -> depth map -> point cloud                             Frame::ConvertDepthToPointCloud src/Frame.cc:590-623  } of the Frame constructor
  -> GICP of the new cloud against the previous one       RegistrationGICP::RegisterPointClouds src/RegistrationGICP.cc:5-20
  -> windowed matching against the last frame's points    ORBmatcher::SearchByProjection(Frame&, const Frame&, th = 15, false) src/ORBmatcher.cc:1853-2063
  -> motion-only bundle adjustment                        Optimizer::PoseOptimization  src/Optimizer.cc:763-1098
@@ -41,17 +41,18 @@ class GpuBackend:
         _, k, d = self.ext(gray)
         return k, d
 
-    def stereo(self, kps, depth):
-        return self.frm.ComputeStereoFromRGBD(kps, depth, BF)
-
-    def cloud(self, depth, ds, K):
-        return self.frm.ConvertDepthToPointCloud(depth, ds, *K)
+    def frame_rgbd(self, kps, depth, ds, K):
+        # the RGB-D tail of the Frame constructor as ONE call: the depth map crosses PCIe once, the cloud stays on the device
+        # (a host copy only until the registration has its first target)
+        ur, zd, cloud, dev = self.frm.FrameRGBD(kps, depth, BF, ds, *K, host_cloud=not self.have_target)
+        return ur, zd, (cloud if cloud is not None else dev)
 
     def gicp(self, prev_cloud, cloud):
         if not self.have_target:  # first pair of the stream: both clouds; afterwards only the new one is preprocessed
             self.have_target = True
             return self.reg.RegisterPointClouds(prev_cloud, cloud)["T"]
-        return self.reg.RegisterNext(cloud)["T"]
+        d_cloud, d_n, stride, _ = cloud  # the device-resident cloud of frame_rgbd
+        return self.reg.align_next_batch_device(d_cloud, d_n, 1, stride)[0]["T"]
 
     def sbp(self, prob):
         return self.pm.SearchByProjection(prob)
@@ -79,11 +80,9 @@ class OracleBackend:
         _, k, d = self.orbx.extract(gray)
         return k, d
 
-    def stereo(self, kps, depth):
-        return self.O.stereo_from_rgbd(kps, depth, BF)
-
-    def cloud(self, depth, ds, K):
-        return self.O.depth_to_cloud(depth, ds, *K)
+    def frame_rgbd(self, kps, depth, ds, K):
+        ur, zd = self.O.stereo_from_rgbd(kps, depth, BF)
+        return ur, zd, self.O.depth_to_cloud(depth, ds, *K)
 
     def gicp(self, prev_cloud, cloud):
         return self.O.gicp_align(prev_cloud, cloud)["T"]
@@ -101,10 +100,8 @@ def track_frame(be, last, gray, depth, K, W, H, ds, stages):
     t = time.perf_counter()
     kps, desc = be.orb(gray)
     t = _lap(stages, "orb", t)
-    ur, zd = be.stereo(kps, depth)
-    t = _lap(stages, "stereo_from_rgbd", t)
-    cloud = be.cloud(depth, ds, K)
-    t = _lap(stages, "depth_to_cloud", t)
+    ur, zd, cloud = be.frame_rgbd(kps, depth, ds, K)
+    t = _lap(stages, "frame_rgbd", t)
     cur = dict(kps=kps, desc=desc, ur=np.asarray(ur, np.float32), z=np.asarray(zd, np.float32), cloud=cloud, matches=0, inliers=0, T=np.eye(4))
     if last is None:
         return cur

@@ -184,7 +184,7 @@ ABI_SYMBOLS = [
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
-    "gfs_gicp_fetch_preprocessed", "gfs_gicp_tile_stats", "gfs_gicp_knn_stats", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort", "gfs_test_wave_std_sort",
+    "gfs_gicp_fetch_preprocessed", "gfs_gicp_tile_stats", "gfs_gicp_knn_stats", "gfs_frame_rgbd", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort", "gfs_test_wave_std_sort",
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_solve_bool", "gfs_lba_linearize", "gfs_lba_batch_create", "gfs_lba_batch_destroy",
     "gfs_lba_solve_batch",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_depth_convert_u16_batch_device", "gfs_stereo_from_rgbd",
@@ -264,6 +264,7 @@ def lib():
             L.gfs_depth_to_cloud_batch_device.argtypes = [vp, vp, i, i, i, i, f, f, f, f, vp, i, vp, vp]
             L.gfs_depth_convert_u16_batch_device.argtypes = [vp, vp, i, i, i, f, vp, vp]
             L.gfs_stereo_from_rgbd.argtypes = [vp, vp, vp, i, vp, i, i, i, f, vp, vp]
+            L.gfs_frame_rgbd.argtypes = [vp, vp, vp, i, vp, i, i, i, f, i, f, f, f, f, vp, vp, vp, i, ip, vp, vp, ip]
             L.gfs_stereo_from_rgbd_batch_device.argtypes = [vp, vp, vp, vp, i, i, vp, i, i, f, vp, vp, vp]
         if hasattr(L, "gfs_klt_create"):
             f, d = C.c_float, C.c_double
@@ -1065,6 +1066,24 @@ class Frame:
         _check(lib().gfs_stereo_from_rgbd(self.h, _p(kps), _p(unx), n, _p(depth), depth.shape[0], depth.shape[1], depth.shape[1],
                                           bf, _p(ur), _p(vd)), "gfs_stereo_from_rgbd")
         return ur[:n], vd[:n]
+
+    def FrameRGBD(self, kps, depth, bf, downSample, fx, fy, cx, cy, kps_un_x=None, host_cloud=True):
+        """The RGB-D tail of the Frame constructor (ComputeStereoFromRGBD + ConvertDepthToPointCloud, src/Frame.cc:1314-1332,
+        590-623) in one call: gfs_frame_rgbd.  Returns (mvuRight, mvDepth, cloud or None, (dev_cloud, dev_count, stride, n))."""
+        depth = np.ascontiguousarray(depth, np.float32)
+        kps = np.ascontiguousarray(kps)
+        n = len(kps)
+        rows, cols = depth.shape
+        ur = np.empty(max(n, 1), np.float32)
+        vd = np.empty(max(n, 1), np.float32)
+        unx = np.ascontiguousarray(kps_un_x, np.float32) if kps_un_x is not None else None
+        out = np.empty((rows * cols // (downSample * downSample) + rows + cols, 4), np.float32) if host_cloud else None
+        nc, stride = C.c_int(), C.c_int()
+        dc, dn = C.c_void_p(), C.c_void_p()
+        _check(lib().gfs_frame_rgbd(self.h, _p(kps), _p(unx), n, _p(depth), rows, cols, cols, bf, downSample, fx, fy, cx, cy, _p(ur),
+                                    _p(vd), _p(out), len(out) if out is not None else 0, C.byref(nc), C.byref(dc), C.byref(dn),
+                                    C.byref(stride)), "gfs_frame_rgbd")
+        return ur[:n], vd[:n], (out[:nc.value] if out is not None else None), (dc.value, dn.value, stride.value, nc.value)
 
     def depth_convert_u16_batch_device(self, d_u16, B, rows, cols, factor, d_f32, stream=None):
         """imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) for CV_16U depth maps already in HBM (src/Tracking.cc:1622-1623)"""

@@ -122,7 +122,7 @@ int gfs_frame_create(int device, int max_rows, int max_cols, int max_keypoints, 
   A(h->d_unx.alloc(max_keypoints));
   A(h->d_ur.alloc(max_keypoints));
   A(h->d_vd.alloc(max_keypoints));
-  A(h->d_n.alloc(1));
+  A(h->d_n.alloc(2));  // [0] cloud points, [1] key-points of a gfs_frame_rgbd call
 #undef A
   if (rc) return rc;
   *out = h.release();
@@ -223,6 +223,51 @@ int gfs_stereo_from_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps
   GFS_HIP(hipMemcpyAsync(u_right, h->d_ur.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(depth_out, h->d_vd.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
+  return GFS_OK;
+}
+
+// The RGB-D tail of the Frame constructor in one call (src/Frame.cc: ComputeStereoFromRGBD(imDepth) :1314-1332, then
+// ConvertDepthToPointCloud :590-623): the depth map crosses PCIe ONCE, both kernels run behind it, one synchronisation.  The cloud
+// stays on the device for the registration (dev_cloud / dev_count are what gfs_gicp_align[_next]_batch_device take, stride
+// *cloud_stride points); out_xyzw may be NULL when the caller does not need a host copy.
+int gfs_frame_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x, int n, const float* depth, int rows, int cols,
+                   int stride_elems, float bf, int downsample, float fx, float fy, float cx, float cy, float* u_right,
+                   float* depth_out, float* out_xyzw, int cap, int* n_cloud, void** dev_cloud, void** dev_count, int* cloud_stride) {
+  GFS_REQUIRE(h && n >= 0 && n_cloud, GFS_ERR_INVALID_ARG, "gfs_frame_rgbd: invalid argument");
+  *n_cloud = 0;
+  GFS_REQUIRE(depth && rows > 0 && cols > 0 && downsample > 0 && stride_elems >= cols && rows <= h->max_rows && cols <= h->max_cols &&
+                  n <= h->max_kp && (n == 0 || (kps && u_right && depth_out)),
+              GFS_ERR_INVALID_ARG, "gfs_frame_rgbd: invalid argument or capacity");
+  std::lock_guard<std::mutex> lk(h->mu);
+  GFS_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  GFS_HIP(hipMemcpy2DAsync(h->d_depth.p, (size_t)cols * 4, depth, (size_t)stride_elems * 4, (size_t)cols * 4, rows,
+                           hipMemcpyHostToDevice, s));
+  if (n) {
+    GFS_HIP(hipMemcpyAsync(h->d_kps.p, kps, (size_t)n * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
+    if (kps_un_x) GFS_HIP(hipMemcpyAsync(h->d_unx.p, kps_un_x, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    GFS_HIP(hipMemcpyAsync(h->d_n.p + 1, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    const int rc = gfs_stereo_from_rgbd_batch_device(h, h->d_kps.p, kps_un_x ? h->d_unx.p : nullptr, h->d_n.p + 1, 1, h->max_kp,
+                                                     h->d_depth.p, rows, cols, bf, h->d_ur.p, h->d_vd.p, s);
+    if (rc) return rc;
+    GFS_HIP(hipMemcpyAsync(u_right, h->d_ur.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    GFS_HIP(hipMemcpyAsync(depth_out, h->d_vd.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  }
+  const int maxpts = (int)h->d_cloud.n;
+  const int rc = gfs_depth_to_cloud_batch_device(h, h->d_depth.p, 1, rows, cols, downsample, fx, fy, cx, cy, h->d_cloud.p, maxpts,
+                                                 h->d_n.p, s);
+  if (rc) return rc;
+  int cnt = 0;
+  GFS_HIP(hipMemcpyAsync(&cnt, h->d_n.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipStreamSynchronize(s));
+  *n_cloud = cnt;
+  if (dev_cloud) *dev_cloud = h->d_cloud.p;
+  if (dev_count) *dev_count = h->d_n.p;
+  if (cloud_stride) *cloud_stride = maxpts;
+  if (out_xyzw) {
+    GFS_REQUIRE(cnt <= cap, GFS_ERR_CAPACITY, "gfs_frame_rgbd: %d points exceed caller capacity %d", cnt, cap);
+    if (cnt) GFS_HIP(hipMemcpy(out_xyzw, h->d_cloud.p, (size_t)cnt * 16, hipMemcpyDeviceToHost));
+  }
   return GFS_OK;
 }
 

@@ -2675,10 +2675,11 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   prm.src_slot = 1;
   prm.only = -1;
   if (streaming) {
-    GFS_REQUIRE(h->last_B == B && h->last_stride == stride_pts && h->last_leaf == cfg->downsampling_resolution &&
-                    h->last_cell == prm.cell && h->last_k == cfg->num_neighbors,
+    // (the stride is that of THIS call's source buffer: the target slot is not read from any input buffer again)
+    GFS_REQUIRE(h->last_B == B && h->last_leaf == cfg->downsampling_resolution && h->last_cell == prm.cell &&
+                    h->last_k == cfg->num_neighbors,
                 GFS_ERR_INVALID_ARG,
-                "gfs_gicp_align_next: needs a previous call on this handle with the same batch size, stride and preprocessing "
+                "gfs_gicp_align_next: needs a previous call on this handle with the same batch size and preprocessing "
                 "parameters (its source clouds are this call's targets)");
     prm.src_slot = 1 - h->last_src_slot;
     prm.only = prm.src_slot;

@@ -55,29 +55,30 @@ __device__ __forceinline__ void map3(const double* q, const double* t, const dou
   o[2] += t[2];
 }
 
-// computeError of edge e at pose (q, t)
-__device__ __forceinline__ void pose_edge_error(const PoseFrame& F, const EdgeView& E, int e, const double* q, const double* t,
-                                                double* r) {
+// computeError of an edge at pose (q, t) and its chi2
+// An edge as its thread keeps it: the inputs (read once) and the state g2o keeps per edge (error vector, chi2, level) plus mvbOutlier.
+struct EdgeReg {
+  double xw[3], obs[3], err[3], chi2, w;
+  int stereo, level, outlier;
+};
+__device__ __forceinline__ void pose_edge_error(const PoseFrame& F, const EdgeReg& R, const double* q, const double* t, double* r) {
   double xc[3];
-  map3(q, t, E.xw + 3 * e, xc);
-  const double* obs = E.obs + 3 * e;
-  if (E.stereo[e]) {  // cam_project (types_six_dof_expmap.cpp:339-346): float invz, double bf
+  map3(q, t, R.xw, xc);
+  if (R.stereo) {  // cam_project (types_six_dof_expmap.cpp:339-346): float invz, double bf
     const float invz = (float)(1.0 / xc[2]);
     const double u = xc[0] * (double)invz * F.fx + F.cx, v = xc[1] * (double)invz * F.fy + F.cy;
-    r[0] = obs[0] - u;
-    r[1] = obs[1] - v;
-    r[2] = obs[2] - (u - F.bf * (double)invz);
+    r[0] = R.obs[0] - u;
+    r[1] = R.obs[1] - v;
+    r[2] = R.obs[2] - (u - F.bf * (double)invz);
   } else {  // Pinhole::project(Vector3d), src/CameraModels/Pinhole.cpp:35-41
-    r[0] = obs[0] - (F.fx * xc[0] / xc[2] + F.cx);
-    r[1] = obs[1] - (F.fy * xc[1] / xc[2] + F.cy);
+    r[0] = R.obs[0] - (F.fx * xc[0] / xc[2] + F.cx);
+    r[1] = R.obs[1] - (F.fy * xc[1] / xc[2] + F.cy);
     r[2] = 0;
   }
 }
-__device__ __forceinline__ double pose_edge_chi2(const EdgeView& E, int e, const double* r) {
-  const double w = (double)E.w[e];
-  return E.stereo[e] ? (r[0] * w * r[0] + r[1] * w * r[1] + r[2] * w * r[2]) : (r[0] * w * r[0] + r[1] * w * r[1]);
+__device__ __forceinline__ double pose_edge_chi2(const EdgeReg& R, const double* r) {
+  return R.stereo ? (r[0] * R.w * r[0] + r[1] * R.w * r[1] + r[2] * R.w * r[2]) : (r[0] * R.w * r[0] + r[1] * R.w * r[1]);
 }
-
 // deterministic block sum (256 threads): wave shuffle tree, then the four waves in order; result in every thread
 __device__ double block_sum256(double v, double* s4) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -95,101 +96,167 @@ constexpr int kChunk = kPoseThreads;
 constexpr int kSlabStride = kChunk + 1;
 constexpr int kSlabDoubles = kSys * kSlabStride;  // also the capacity of one pass of the chi2 sum
 
-__device__ __forceinline__ double ordered_sum(const double* __restrict__ v, int cnt, double s) {
+template <typename T>
+__device__ __forceinline__ T ordered_sum(const T* __restrict__ v, int cnt, T s) {
+  // one dependent chain of cnt additions; the terms of the NEXT batch are fetched from LDS while this batch is added (a plain loop
+  // waits for its eight reads, adds, and only then asks for the next eight: 250 cycles a batch instead of the 80 the adds take)
+  constexpr int kB = 8;
+  T a[kB];
   int j = 0;
-  for (; j + 8 <= cnt; j += 8) {
-    const double a0 = v[j], a1 = v[j + 1], a2 = v[j + 2], a3 = v[j + 3], a4 = v[j + 4], a5 = v[j + 5], a6 = v[j + 6], a7 = v[j + 7];
-    s += a0;
-    s += a1;
-    s += a2;
-    s += a3;
-    s += a4;
-    s += a5;
-    s += a6;
-    s += a7;
+  if (cnt >= kB) {
+#pragma unroll
+    for (int u = 0; u < kB; u++) a[u] = v[u];
+    for (; j + 2 * kB <= cnt; j += kB) {
+      T b[kB];
+#pragma unroll
+      for (int u = 0; u < kB; u++) b[u] = v[j + kB + u];
+#pragma unroll
+      for (int u = 0; u < kB; u++) s += a[u];
+#pragma unroll
+      for (int u = 0; u < kB; u++) a[u] = b[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kB; u++) s += a[u];
+    j += kB;
   }
   for (; j < cnt; j++) s += v[j];
   return s;
 }
 
-// Eigen::LDLT<MatrixXd>::compute + isPositive + solve on a 6x6 (see oracle/pose_oracle.cpp for the line-by-line restatement)
-// The pivot search and the symmetric transpositions index the matrix at run time: private arrays would live in scratch memory (a
-// round trip to the L1 per access, on the one lane everybody waits for), so the caller hands in LDS: A 6x6 (holds H on entry),
-// y 6, tr 6.
-__device__ __forceinline__ bool ldlt6_solve_positive(double (*A)[6], const double* b, double* x, double* y, int* tr) {
-  int sign = 0;
-  for (int k = 0; k < 6; k++) {
-    int p = k;
-    double best = fabs(A[k][k]);
-    for (int i = k + 1; i < 6; i++)
-      if (fabs(A[i][i]) > best) {
-        best = fabs(A[i][i]);
-        p = i;
-      }
-    tr[k] = p;
-    if (p != k) {
-      for (int j = 0; j < k; j++) {
-        const double tmp = A[k][j];
-        A[k][j] = A[p][j];
-        A[p][j] = tmp;
-      }
-      for (int i = p + 1; i < 6; i++) {
-        const double tmp = A[i][k];
-        A[i][k] = A[i][p];
-        A[i][p] = tmp;
-      }
-      {
-        const double tmp = A[k][k];
-        A[k][k] = A[p][p];
-        A[p][p] = tmp;
-      }
-      for (int i = k + 1; i < p; i++) {
-        const double tmp = A[i][k];
-        A[i][k] = A[p][i];
-        A[p][i] = tmp;
-      }
+// Eigen::LDLT<MatrixXd>::compute + isPositive + solve on a 6x6 (see oracle/pose_oracle.cpp for the line-by-line restatement).
+// The pivot search and the symmetric transpositions index the matrix at run time.  A private array indexed at run time lives in
+// scratch memory, an LDS copy costs a round trip per access on the one lane everybody waits for (6.5 us a solve, a fifth of the
+// kernel): here every index is a compile-time constant -- the loops over k, i, j are unrolled and the run-time pivot p is matched
+// against its (at most five) possible values, each with its own statically indexed swaps -- so the 21 entries of the lower
+// triangle, y and the transpositions stay in registers.  The arithmetic, operation for operation, is the restatement's.
+template <int K, int PC>
+__device__ __forceinline__ void ldlt6_transpose(double (&A)[6][6]) {  // symmetric transposition k <-> p restricted to the lower triangle
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    const double tmp = A[K][j];
+    A[K][j] = A[PC][j];
+    A[PC][j] = tmp;
+  }
+#pragma unroll
+  for (int i = PC + 1; i < 6; i++) {
+    const double tmp = A[i][K];
+    A[i][K] = A[i][PC];
+    A[i][PC] = tmp;
+  }
+  {
+    const double tmp = A[K][K];
+    A[K][K] = A[PC][PC];
+    A[PC][PC] = tmp;
+  }
+#pragma unroll
+  for (int i = K + 1; i < PC; i++) {
+    const double tmp = A[i][K];
+    A[i][K] = A[PC][i];
+    A[PC][i] = tmp;
+  }
+}
+template <int K>
+__device__ __forceinline__ void ldlt6_step(double (&A)[6][6], int (&tr)[6], int& sign) {
+  int p = K;
+  double best = fabs(A[K][K]);
+#pragma unroll
+  for (int i = K + 1; i < 6; i++)
+    if (fabs(A[i][i]) > best) {
+      best = fabs(A[i][i]);
+      p = i;
     }
-    if (k > 0) {
-      double* temp = y;  // (y is not in use yet)
-      for (int j = 0; j < k; j++) temp[j] = A[j][j] * A[k][j];
-      double acc = 0;
-      for (int j = 0; j < k; j++) acc += A[k][j] * temp[j];
-      A[k][k] -= acc;
-      for (int i = k + 1; i < 6; i++) {
-        double a2 = 0;
-        for (int j = 0; j < k; j++) a2 += A[i][j] * temp[j];
-        A[i][k] -= a2;
-      }
-    }
-    const double akk = A[k][k];
-    if (fabs(akk) > 0)
-      for (int i = k + 1; i < 6; i++) A[i][k] /= akk;
-    if (sign == 1) {
-      if (akk < 0) sign = 2;
-    } else if (sign == -1) {
-      if (akk > 0) sign = 2;
-    } else if (sign == 0) {
-      if (akk > 0) sign = 1;
-      else if (akk < 0) sign = -1;
+  tr[K] = p;
+  if constexpr (K + 1 < 6) { if (p == K + 1) ldlt6_transpose<K, K + 1 < 6 ? K + 1 : 5>(A); }
+  if constexpr (K + 2 < 6) { if (p == K + 2) ldlt6_transpose<K, K + 2 < 6 ? K + 2 : 5>(A); }
+  if constexpr (K + 3 < 6) { if (p == K + 3) ldlt6_transpose<K, K + 3 < 6 ? K + 3 : 5>(A); }
+  if constexpr (K + 4 < 6) { if (p == K + 4) ldlt6_transpose<K, K + 4 < 6 ? K + 4 : 5>(A); }
+  if constexpr (K + 5 < 6) { if (p == K + 5) ldlt6_transpose<K, K + 5 < 6 ? K + 5 : 5>(A); }
+  if constexpr (K > 0) {
+    double temp[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) temp[j] = A[j][j] * A[K][j];
+    double acc = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) acc += A[K][j] * temp[j];
+    A[K][K] -= acc;
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) {
+      double a2 = 0;
+#pragma unroll
+      for (int j = 0; j < K; j++) a2 += A[i][j] * temp[j];
+      A[i][K] -= a2;
     }
   }
+  const double akk = A[K][K];
+  if (fabs(akk) > 0) {
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) A[i][K] /= akk;
+  }
+  if (sign == 1) {
+    if (akk < 0) sign = 2;
+  } else if (sign == -1) {
+    if (akk > 0) sign = 2;
+  } else if (sign == 0) {
+    if (akk > 0) sign = 1;
+    else if (akk < 0) sign = -1;
+  }
+}
+template <int K>
+__device__ __forceinline__ void ldlt6_swap_y(double (&y)[6], int p) {  // y[K] <-> y[p], p >= K
+  if constexpr (K + 1 < 6) { if (p == K + 1) { const double t = y[K]; y[K] = y[K + 1 < 6 ? K + 1 : 5]; y[K + 1 < 6 ? K + 1 : 5] = t; } }
+  if constexpr (K + 2 < 6) { if (p == K + 2) { const double t = y[K]; y[K] = y[K + 2 < 6 ? K + 2 : 5]; y[K + 2 < 6 ? K + 2 : 5] = t; } }
+  if constexpr (K + 3 < 6) { if (p == K + 3) { const double t = y[K]; y[K] = y[K + 3 < 6 ? K + 3 : 5]; y[K + 3 < 6 ? K + 3 : 5] = t; } }
+  if constexpr (K + 4 < 6) { if (p == K + 4) { const double t = y[K]; y[K] = y[K + 4 < 6 ? K + 4 : 5]; y[K + 4 < 6 ? K + 4 : 5] = t; } }
+  if constexpr (K + 5 < 6) { if (p == K + 5) { const double t = y[K]; y[K] = y[K + 5 < 6 ? K + 5 : 5]; y[K + 5 < 6 ? K + 5 : 5] = t; } }
+}
+// H: the 21 entries of the lower triangle, packed a (a + 1) / 2 + c; lambda is added to the diagonal
+__device__ __forceinline__ bool ldlt6_solve_positive(const double* H21, double lambda, const double* b, double* x) {
+  double A[6][6];
+  {
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c <= a; c++) {
+        A[a][c] = H21[o];
+        A[c][a] = H21[o];
+        o++;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; a++) A[a][a] += lambda;
+  int tr[6], sign = 0;
+  ldlt6_step<0>(A, tr, sign);
+  ldlt6_step<1>(A, tr, sign);
+  ldlt6_step<2>(A, tr, sign);
+  ldlt6_step<3>(A, tr, sign);
+  ldlt6_step<4>(A, tr, sign);
+  ldlt6_step<5>(A, tr, sign);
   if (sign != 1) return false;
+  double y[6];
+#pragma unroll
   for (int i = 0; i < 6; i++) y[i] = b[i];
-  for (int k = 0; k < 6; k++) {
-    const double tmp = y[k];
-    y[k] = y[tr[k]];
-    y[tr[k]] = tmp;
-  }
+  ldlt6_swap_y<0>(y, tr[0]);
+  ldlt6_swap_y<1>(y, tr[1]);
+  ldlt6_swap_y<2>(y, tr[2]);
+  ldlt6_swap_y<3>(y, tr[3]);
+  ldlt6_swap_y<4>(y, tr[4]);
+#pragma unroll
   for (int i = 0; i < 6; i++)
+#pragma unroll
     for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+#pragma unroll
   for (int i = 0; i < 6; i++) y[i] = fabs(A[i][i]) > 2.2250738585072014e-308 ? y[i] / A[i][i] : 0.0;
+#pragma unroll
   for (int i = 5; i >= 0; i--)
+#pragma unroll
     for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
-  for (int k = 5; k >= 0; k--) {
-    const double tmp = y[k];
-    y[k] = y[tr[k]];
-    y[tr[k]] = tmp;
-  }
+  ldlt6_swap_y<4>(y, tr[4]);
+  ldlt6_swap_y<3>(y, tr[3]);
+  ldlt6_swap_y<2>(y, tr[2]);
+  ldlt6_swap_y<1>(y, tr[1]);
+  ldlt6_swap_y<0>(y, tr[0]);
+#pragma unroll
   for (int i = 0; i < 6; i++) x[i] = y[i];
   return true;
 }
@@ -205,9 +272,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
   __shared__ double s_T[7], s_Tb[7];  // current estimate, backup (push / pop)
   __shared__ double s_sys[kSys];
   __shared__ double s_x[6];
-  __shared__ double s_A[6][6], s_y[6];
-  __shared__ int s_tr[6];
-  __shared__ int s_flag[2];
+  __shared__ int s_flag[3];
   const int f = blockIdx.x, tid = threadIdx.x;
   const PoseFrame F = frames[f];
   const int n = F.n_obs;
@@ -220,7 +285,44 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
   const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);  // deltaMono / deltaStereo are floats (:807-808)
   double q0[4] = {F.q[0], F.q[1], F.q[2], F.q[3]};
   normalize_rotation(q0);  // SE3Quat(q, t) constructor
-  for (int e = tid; e < n; e += kPoseThreads) {
+  // Edge e belongs to thread e % 256 in every pass of the kernel.  The thread's first two edges (frames of up to 512 observations:
+  // the usual case) live in registers for the whole solve -- inputs, error vector, chi2, level, outlier flag; without that every one
+  // of the ~50 passes over the edges starts with a round trip to memory for 56 bytes an edge and ends with another for the state.
+  // Edges beyond them go through global memory (load, pass body, store).
+  auto load_edge = [&](int e, bool with_state) {
+    EdgeReg R;
+    for (int k = 0; k < 3; k++) {
+      R.xw[k] = E.xw[3 * e + k];
+      R.obs[k] = E.obs[3 * e + k];
+      R.err[k] = with_state ? err[3 * e + k] : 0.0;
+    }
+    R.w = (double)E.w[e];
+    R.stereo = E.stereo[e];
+    R.chi2 = with_state ? chi2[e] : 0.0;
+    R.level = with_state ? level[e] : 0;
+    R.outlier = with_state ? outlier[e] : 0;
+    return R;
+  };
+  auto store_edge = [&](int e, const EdgeReg& R) {
+    for (int k = 0; k < 3; k++) err[3 * e + k] = R.err[k];
+    chi2[e] = R.chi2;
+    level[e] = (uint8_t)R.level;
+    outlier[e] = (uint8_t)R.outlier;
+  };
+  EdgeReg R0 = load_edge(min(tid, n - 1 < 0 ? 0 : n - 1), false), R1 = load_edge(min(tid + kPoseThreads, n - 1 < 0 ? 0 : n - 1), false);
+  auto with_edge = [&](int e, auto&& body) {  // e = tid + 256 k: k is the same in every thread of a pass
+    const int k = (e - tid) / kPoseThreads;
+    if (k == 0) {
+      body(R0);
+    } else if (k == 1) {
+      body(R1);
+    } else {
+      EdgeReg R = load_edge(e, true);
+      body(R);
+      store_edge(e, R);
+    }
+  };
+  for (int e = tid + 2 * kPoseThreads; e < n; e += kPoseThreads) {
     outlier[e] = 0;
     level[e] = 0;
     chi2[e] = 0;
@@ -236,6 +338,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
   O.rounds_run = 0;
   O.iterations_run = 0;
   if (n < 3) {  // nInitialCorrespondences < 3 -> return 0 (:958)
+    if (tid < n) {
+      outlier[tid] = 0;
+      chi2[tid] = 0;
+    }
     if (tid == 0) outs[f] = O;
     return;
   }
@@ -248,20 +354,22 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       const int cnt = min(kSlabDoubles, n - base);
       for (int e = base + tid; e < base + cnt; e += kPoseThreads) {
         double term = 0;  // an edge that is not active adds nothing (x + 0 = x)
-        if (!level[e]) {
-          double r[3];
-          pose_edge_error(F, E, e, T, T + 4, r);
-          const double c = pose_edge_chi2(E, e, r);
-          err[3 * e] = r[0];
-          err[3 * e + 1] = r[1];
-          err[3 * e + 2] = r[2];
-          chi2[e] = c;
-          term = c;
-          if (robust) {
-            double r1;
-            huber(c, E.stereo[e] ? dStereo : dMono, &term, &r1);
+        with_edge(e, [&](EdgeReg& R) {
+          if (!R.level) {
+            double r[3];
+            pose_edge_error(F, R, T, T + 4, r);
+            const double c = pose_edge_chi2(R, r);
+            R.err[0] = r[0];
+            R.err[1] = r[1];
+            R.err[2] = r[2];
+            R.chi2 = c;
+            term = c;
+            if (robust) {
+              double r1;
+              huber(c, R.stereo ? dStereo : dMono, &term, &r1);
+            }
           }
-        }
+        });
         s_slab[e - base] = term;
       }
       __syncthreads();
@@ -276,13 +384,18 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     if (tid < 4) s_T[tid] = q0[tid];  // setEstimate(pFrame->GetPose()): the frame pose never changes
     if (tid < 3) s_T[4 + tid] = F.t[tid];
     int local_active = 0;
-    for (int e = tid; e < n; e += kPoseThreads) local_active += level[e] == 0;
+    for (int e = tid; e < n; e += kPoseThreads) with_edge(e, [&](EdgeReg& R) { local_active += R.level == 0; });
     __syncthreads();
     const int n_active = (int)block_sum256((double)local_active, s4);
     double currentLambda = -1, ni = 2;  // thread 0 only
     int nBadLm = 0;
+    // g2o computes the active errors at the top of every iteration; after an ACCEPTED trial they are what that trial has just left
+    // in the edges, at the same estimate -- same values, same sum -- so the pass is run only after a rejected one (pop(): estimate
+    // restored, the edges keep the trial's errors) and at the start of a round
+    bool fresh = false;       // uniform
+    double currentChi = 0;    // thread 0
     for (int iteration = 0; iteration < F.its && n_active > 0; iteration++) {
-      double currentChi = compute_active(robust);
+      if (!fresh) currentChi = compute_active(robust);
       const double iniChi = currentChi;
       // ---- buildSystem: linearizeOplus + constructQuadraticForm, summed over the threads' edges
       {
@@ -294,13 +407,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           double acc[kSys];
 #pragma unroll
           for (int k = 0; k < kSys; k++) acc[k] = 0;
-          if (e < n && !level[e]) {
+          if (e < n) with_edge(e, [&](EdgeReg& R) {
+            if (R.level) return;
             double xc[3];
-            map3(T, T + 4, E.xw + 3 * e, xc);
+            map3(T, T + 4, R.xw, xc);
             const double x = xc[0], y = xc[1], z = xc[2];
             double J[18];
             int rows;
-            if (E.stereo[e]) {  // types_six_dof_expmap.cpp:375-404
+            if (R.stereo) {  // types_six_dof_expmap.cpp:375-404
               rows = 3;
               const double invz = 1.0 / z, invz_2 = invz * invz;
               J[0] = x * y * invz_2 * F.fx;
@@ -329,13 +443,13 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
                 for (int c = 0; c < 6; c++) J[6 * r + c] = -(pj[3 * r] * D[c] + pj[3 * r + 1] * D[6 + c] + pj[3 * r + 2] * D[12 + c]);
               for (int c = 0; c < 6; c++) J[12 + c] = 0;
             }
-            const double w = (double)E.w[e];
+            const double w = R.w;
             double rho1 = 1.0;
             if (robust) {
               double r0;
-              huber(chi2[e], E.stereo[e] ? dStereo : dMono, &r0, &rho1);
+              huber(R.chi2, R.stereo ? dStereo : dMono, &r0, &rho1);
             }
-            const double r[3] = {err[3 * e], err[3 * e + 1], err[3 * e + 2]};
+            const double r[3] = {R.err[0], R.err[1], R.err[2]};
             // the lower triangle, row a / column c <= a: the entries Eigen's LDLT reads (packed a (a + 1) / 2 + c)
             // (every index below is a compile-time constant: arrays indexed at run time would live in scratch memory.  The third
             //  row is added by a select, not as a zero term, so that a mono edge sums exactly its two terms)
@@ -358,7 +472,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
                 acc[o++] = three ? hh3 : hh;
               }
             }
-          }
+          });
 #pragma unroll
           for (int k = 0; k < kSys; k++) s_slab[k * kSlabStride + tid] = acc[k];
           __syncthreads();
@@ -381,16 +495,12 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       while (again) {
         if (tid == 0) {
           for (int k = 0; k < 7; k++) s_Tb[k] = s_T[k];  // push()
-          double x[6];
-          int o = 0;
-          for (int a = 0; a < 6; a++)
-            for (int c = 0; c <= a; c++) {
-              s_A[a][c] = s_sys[o];
-              s_A[c][a] = s_sys[o];
-              o++;
-            }
-          for (int a = 0; a < 6; a++) s_A[a][a] += currentLambda;
-          const bool ok2 = ldlt6_solve_positive(s_A, s_sys + 21, x, s_y, s_tr);
+          double x[6], H21[21], b6[6];
+#pragma unroll
+          for (int k = 0; k < 21; k++) H21[k] = s_sys[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) b6[k] = s_sys[21 + k];
+          const bool ok2 = ldlt6_solve_positive(H21, currentLambda, b6, x);
           if (ok2) {
             double qn[4], tn[3];
             pose_oplus(s_T, s_T + 4, x, qn, tn);
@@ -425,9 +535,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           }
           qmax++;
           s_flag[1] = (rho < 0 && qmax < 10) ? 1 : 0;
+          s_flag[2] = (rho > 0 && isfinite(tempChi)) ? 1 : 0;  // the trial was accepted
         }
         __syncthreads();
         again = s_flag[1] != 0;
+        fresh = s_flag[2] != 0;
         __syncthreads();
       }
       if (tid == 0) {
@@ -452,14 +564,15 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       double T[7];
       for (int k = 0; k < 7; k++) T[k] = s_T[k];
       for (int e = tid; e < n; e += kPoseThreads)
-        if (outlier[e]) {
+        with_edge(e, [&](EdgeReg& R) {
+          if (!R.outlier) return;
           double r[3];
-          pose_edge_error(F, E, e, T, T + 4, r);
-          err[3 * e] = r[0];
-          err[3 * e + 1] = r[1];
-          err[3 * e + 2] = r[2];
-          chi2[e] = pose_edge_chi2(E, e, r);
-        }
+          pose_edge_error(F, R, T, T + 4, r);
+          R.err[0] = r[0];
+          R.err[1] = r[1];
+          R.err[2] = r[2];
+          R.chi2 = pose_edge_chi2(R, r);
+        });
     }
     __syncthreads();
     {
@@ -475,34 +588,21 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           const int cnt = min(kTerms, n - base);
           for (int e = base + tid; e < base + cnt; e += kPoseThreads) {
             float term = 0.0f;
-            if ((E.stereo[e] != 0) == (pass == 1)) {
-              const float c = (float)chi2[e];
-              const bool out = c > (pass ? 7.815f : 5.991f);
-              outlier[e] = out ? 1 : 0;
-              level[e] = out ? 1 : 0;
-              bad_local += out ? 1 : 0;
-              good_local += out ? 0 : 1;
-              if (!out) term = c;
-            }
+            with_edge(e, [&](EdgeReg& R) {
+              if ((R.stereo != 0) == (pass == 1)) {
+                const float c = (float)R.chi2;
+                const bool out = c > (pass ? 7.815f : 5.991f);
+                R.outlier = out ? 1 : 0;
+                R.level = out ? 1 : 0;
+                bad_local += out ? 1 : 0;
+                good_local += out ? 0 : 1;
+                if (!out) term = c;
+              }
+            });
             s_term[e - base] = term;
           }
           __syncthreads();
-          if (tid == 0) {
-            int j = 0;
-            for (; j + 8 <= cnt; j += 8) {
-              const float a0 = s_term[j], a1 = s_term[j + 1], a2 = s_term[j + 2], a3 = s_term[j + 3], a4 = s_term[j + 4], a5 = s_term[j + 5],
-                          a6 = s_term[j + 6], a7 = s_term[j + 7];
-              avg += a0;
-              avg += a1;
-              avg += a2;
-              avg += a3;
-              avg += a4;
-              avg += a5;
-              avg += a6;
-              avg += a7;
-            }
-            for (; j < cnt; j++) avg += s_term[j];
-          }
+          if (tid == 0) avg = ordered_sum(s_term, cnt, avg);
           __syncthreads();
         }
       nBad = (int)block_sum256((double)bad_local, s4);
@@ -516,6 +616,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     __syncthreads();
     if (n < 10) break;  // optimizer.edges().size() < 10 (:1073)
   }
+  if (tid < n) store_edge(tid, R0);  // what the host reads back: mvbOutlier and the per-edge chi2
+  if (tid + kPoseThreads < n) store_edge(tid + kPoseThreads, R1);
   if (tid == 0) {
     for (int k = 0; k < 4; k++) O.q[k] = s_T[k];
     for (int k = 0; k < 3; k++) O.t[k] = s_T[4 + k];
@@ -538,16 +640,31 @@ struct gfs_pose {
   int device, max_obs, max_batch;
   hipStream_t stream;
   std::mutex mu;
-  gfs::DevBuf<PoseFrame> d_frames;
-  gfs::DevBuf<PoseOut> d_out;
-  gfs::DevBuf<double> d_xw, d_obs, d_chi2, d_err;
-  gfs::DevBuf<float> d_w;
-  gfs::DevBuf<uint8_t> d_stereo, d_outlier, d_level;
-  gfs::PinBuf<PoseFrame> h_frames;
-  gfs::PinBuf<PoseOut> h_out;
-  gfs::PinBuf<double> h_xw, h_obs, h_chi2;
-  gfs::PinBuf<float> h_w;
-  gfs::PinBuf<uint8_t> h_stereo, h_outlier;
+  // One pinned arena that mirrors one device block for the inputs (frames | xw | obs | w | stereo) and one for the outputs
+  // (out | chi2 | outlier): a call is ONE copy in, the kernel, ONE copy out (five + three copies before: ~10 us of host time and a
+  // copy-engine round trip each, more than the kernel's share of a single frame).
+  gfs::DevBuf<uint8_t> d_in, d_res;
+  gfs::PinBuf<uint8_t> h_in, h_res;
+  // layout of a call with B frames, arrays strided by `stride` (the call's largest observation count, rounded up) per frame
+  struct Layout {
+    size_t o_xw, o_obs, o_w, o_st, in_bytes, r_chi, r_outl, res_bytes;
+  };
+  Layout layout(size_t B, size_t stride) const {
+    auto up = [](size_t v) { return gfs::align_up(v, 256); };
+    const size_t E = stride * B;
+    Layout L;
+    L.o_xw = up(B * sizeof(PoseFrame));
+    L.o_obs = L.o_xw + up(E * 24);
+    L.o_w = L.o_obs + up(E * 24);
+    L.o_st = L.o_w + up(E * 4);
+    L.in_bytes = L.o_st + up(E);
+    L.r_chi = up(B * sizeof(PoseOut));
+    L.r_outl = L.r_chi + up(E * 8);
+    L.res_bytes = L.r_outl + up(E);
+    return L;
+  }
+  gfs::DevBuf<double> d_err;
+  gfs::DevBuf<uint8_t> d_level;
 };
 
 extern "C" {
@@ -561,27 +678,16 @@ int gfs_pose_create(int device, int max_obs, int max_batch, gfs_pose** out) {
   h->max_obs = max_obs;
   h->max_batch = max_batch;
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  const size_t E = (size_t)max_obs * max_batch, B = max_batch;
+  const size_t Smax = gfs::align_up((size_t)max_obs, 64), E = Smax * max_batch, B = max_batch;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
-  A(h->d_frames.alloc(B));
-  A(h->d_out.alloc(B));
-  A(h->d_xw.alloc(E * 3));
-  A(h->d_obs.alloc(E * 3));
-  A(h->d_chi2.alloc(E));
+  const gfs_pose::Layout L = h->layout(B, Smax);
+  A(h->d_in.alloc(L.in_bytes));
+  A(h->h_in.alloc(L.in_bytes));
+  A(h->d_res.alloc(L.res_bytes));
+  A(h->h_res.alloc(L.res_bytes));
   A(h->d_err.alloc(E * 3));
-  A(h->d_w.alloc(E));
-  A(h->d_stereo.alloc(E));
-  A(h->d_outlier.alloc(E));
   A(h->d_level.alloc(E));
-  A(h->h_frames.alloc(B));
-  A(h->h_out.alloc(B));
-  A(h->h_xw.alloc(E * 3));
-  A(h->h_obs.alloc(E * 3));
-  A(h->h_chi2.alloc(E));
-  A(h->h_w.alloc(E));
-  A(h->h_stereo.alloc(E));
-  A(h->h_outlier.alloc(E));
 #undef A
   if (rc) {
     (void)hipStreamDestroy(h->stream);
@@ -604,16 +710,29 @@ int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_
   GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_pose_optimize: batch %d exceeds capacity %d", B, h->max_batch);
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
-  const int S = h->max_obs;
+  int S = 64;  // stride of the per-frame arrays in this call
+  for (int f = 0; f < B; f++) {
+    GFS_REQUIRE(problems[f].n_obs >= 0 && problems[f].n_obs <= h->max_obs, GFS_ERR_CAPACITY,
+                "gfs_pose_optimize: frame %d has %d observations (capacity %d)", f, problems[f].n_obs, h->max_obs);
+    S = std::max(S, (int)gfs::align_up((size_t)problems[f].n_obs, 64));
+  }
+  S = std::min(S, (int)gfs::align_up((size_t)h->max_obs, 64));
+  const gfs_pose::Layout L = h->layout((size_t)B, (size_t)S);
+  PoseFrame* h_frames = reinterpret_cast<PoseFrame*>(h->h_in.p);
+  double* h_xw = reinterpret_cast<double*>(h->h_in.p + L.o_xw);
+  double* h_obs = reinterpret_cast<double*>(h->h_in.p + L.o_obs);
+  float* h_w = reinterpret_cast<float*>(h->h_in.p + L.o_w);
+  uint8_t* h_stereo = h->h_in.p + L.o_st;
+  const PoseOut* h_out = reinterpret_cast<const PoseOut*>(h->h_res.p);
+  const double* h_chi2 = reinterpret_cast<const double*>(h->h_res.p + L.r_chi);
+  const uint8_t* h_outlier = h->h_res.p + L.r_outl;
   for (int f = 0; f < B; f++) {
     const gfs_pose_problem& p = problems[f];
-    GFS_REQUIRE(p.n_obs >= 0 && p.n_obs <= S, GFS_ERR_CAPACITY, "gfs_pose_optimize: frame %d has %d observations (capacity %d)", f,
-                p.n_obs, S);
     GFS_REQUIRE(p.n_obs == 0 || (p.xw && p.obs && p.inv_sigma2 && p.stereo), GFS_ERR_INVALID_ARG,
                 "gfs_pose_optimize: frame %d has NULL observation arrays", f);
     GFS_REQUIRE(p.n_obs == 0 || (solutions[f].outlier && solutions[f].chi2), GFS_ERR_INVALID_ARG,
                 "gfs_pose_optimize: frame %d has NULL output arrays", f);
-    PoseFrame& F = h->h_frames.p[f];
+    PoseFrame& F = h_frames[f];
     for (int k = 0; k < 4; k++) F.q[k] = p.q[k];
     for (int k = 0; k < 3; k++) F.t[k] = p.t[k];
     F.fx = p.fx;
@@ -626,32 +745,27 @@ int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_
     F.its = p.its;
     F.pad = 0;
     if (p.n_obs > 0) {
-      memcpy(h->h_xw.p + (size_t)f * S * 3, p.xw, (size_t)p.n_obs * 24);
-      memcpy(h->h_obs.p + (size_t)f * S * 3, p.obs, (size_t)p.n_obs * 24);
-      memcpy(h->h_w.p + (size_t)f * S, p.inv_sigma2, (size_t)p.n_obs * 4);
-      memcpy(h->h_stereo.p + (size_t)f * S, p.stereo, (size_t)p.n_obs);
+      memcpy(h_xw + (size_t)f * S * 3, p.xw, (size_t)p.n_obs * 24);
+      memcpy(h_obs + (size_t)f * S * 3, p.obs, (size_t)p.n_obs * 24);
+      memcpy(h_w + (size_t)f * S, p.inv_sigma2, (size_t)p.n_obs * 4);
+      memcpy(h_stereo + (size_t)f * S, p.stereo, (size_t)p.n_obs);
     }
   }
   hipStream_t s = h->stream;
-  const size_t E = (size_t)S * B;
-  GFS_HIP(hipMemcpyAsync(h->d_frames.p, h->h_frames.p, B * sizeof(PoseFrame), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_xw.p, h->h_xw.p, E * 24, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_obs.p, h->h_obs.p, E * 24, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_w.p, h->h_w.p, E * 4, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_stereo.p, h->h_stereo.p, E, hipMemcpyHostToDevice, s));
-  GFS_LAUNCH("k_pose_opt", k_pose_opt, dim3(B), dim3(kPoseThreads), 0, s, h->d_frames.p, h->d_xw.p, h->d_obs.p, h->d_w.p,
-             h->d_stereo.p, S, h->d_outlier.p, h->d_chi2.p, h->d_err.p, h->d_level.p, h->d_out.p);
-  GFS_HIP(hipMemcpyAsync(h->h_out.p, h->d_out.p, B * sizeof(PoseOut), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(h->h_outlier.p, h->d_outlier.p, E, hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(h->h_chi2.p, h->d_chi2.p, E * 8, hipMemcpyDeviceToHost, s));
+  GFS_HIP(hipMemcpyAsync(h->d_in.p, h->h_in.p, L.in_bytes, hipMemcpyHostToDevice, s));
+  GFS_LAUNCH("k_pose_opt", k_pose_opt, dim3(B), dim3(kPoseThreads), 0, s, reinterpret_cast<const PoseFrame*>(h->d_in.p),
+             reinterpret_cast<const double*>(h->d_in.p + L.o_xw), reinterpret_cast<const double*>(h->d_in.p + L.o_obs),
+             reinterpret_cast<const float*>(h->d_in.p + L.o_w), (const uint8_t*)(h->d_in.p + L.o_st), S, h->d_res.p + L.r_outl,
+             reinterpret_cast<double*>(h->d_res.p + L.r_chi), h->d_err.p, h->d_level.p, reinterpret_cast<PoseOut*>(h->d_res.p));
+  GFS_HIP(hipMemcpyAsync(h->h_res.p, h->d_res.p, L.res_bytes, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
   for (int f = 0; f < B; f++) {
-    const PoseOut& O = h->h_out.p[f];
+    const PoseOut& O = h_out[f];
     gfs_pose_solution& r = solutions[f];
     const int n = problems[f].n_obs;
     if (n > 0) {
-      memcpy(r.outlier, h->h_outlier.p + (size_t)f * S, n);
-      memcpy(r.chi2, h->h_chi2.p + (size_t)f * S, (size_t)n * 8);
+      memcpy(r.outlier, h_outlier + (size_t)f * S, n);
+      memcpy(r.chi2, h_chi2 + (size_t)f * S, (size_t)n * 8);
     }
     for (int k = 0; k < 4; k++) r.q[k] = O.q[k];
     for (int k = 0; k < 3; k++) r.t[k] = O.t[k];

@@ -533,39 +533,66 @@ struct gfs_sbp {
   int device, max_last, max_cur, max_batch;
   hipStream_t stream;
   std::mutex mu;
-  gfs::DevBuf<SbpPair> d_pairs;
-  gfs::DevBuf<float> d_last_xw, d_last_angle, d_cur_ur;
-  gfs::DevBuf<uint8_t> d_last_desc, d_last_has_obs, d_cur_desc, d_cur_has_obs;
-  gfs::DevBuf<int> d_last_octave, d_cand_cnt, d_lsel, d_cur_match, d_nmatches;
-  gfs::DevBuf<gfs_keypoint> d_cur_kp;
+  // One pinned arena that mirrors one device block for the inputs, one for the results: a call is ONE copy in, the kernel, ONE copy
+  // out (ten + two copies before -- ~10 us of host time and a copy-engine round trip each, twice the kernel's time for one frame).
+  // The per-frame arrays are strided by the CALL's largest counts (rounded up to 64), not by the handle's capacity.
+  gfs::DevBuf<uint8_t> d_in, d_res;
+  gfs::PinBuf<uint8_t> h_in, h_res;
+  gfs::DevBuf<int> d_cand_cnt, d_lsel;
   gfs::DevBuf<unsigned> d_cand;
-  gfs::PinBuf<SbpPair> h_pairs;
-  gfs::PinBuf<float> h_last_xw, h_last_angle, h_cur_ur;
-  gfs::PinBuf<uint8_t> h_last_desc, h_last_has_obs, h_cur_desc, h_cur_has_obs;
-  gfs::PinBuf<int> h_last_octave, h_cur_match, h_nmatches;
-  gfs::PinBuf<gfs_keypoint> h_cur_kp;
+  struct Layout {
+    int SL, SC;
+    size_t o_xw, o_desc, o_oct, o_ang, o_lobs, o_kp, o_ur, o_cdesc, o_cobs, in_bytes, r_nm, res_bytes;
+  };
+  Layout layout(size_t B, int SL, int SC) const {
+    auto up = [](size_t v) { return gfs::align_up(v, 256); };
+    const size_t L = (size_t)SL * B, Cn = (size_t)SC * B;
+    Layout Y;
+    Y.SL = SL;
+    Y.SC = SC;
+    Y.o_xw = up(B * sizeof(SbpPair));
+    Y.o_desc = Y.o_xw + up(L * 12);
+    Y.o_oct = Y.o_desc + up(L * 32);
+    Y.o_ang = Y.o_oct + up(L * 4);
+    Y.o_lobs = Y.o_ang + up(L * 4);
+    Y.o_kp = Y.o_lobs + up(L);
+    Y.o_ur = Y.o_kp + up(Cn * sizeof(gfs_keypoint));
+    Y.o_cdesc = Y.o_ur + up(Cn * 4);
+    Y.o_cobs = Y.o_cdesc + up(Cn * 32);
+    Y.in_bytes = Y.o_cobs + up(Cn);
+    Y.r_nm = up(Cn * 4);
+    Y.res_bytes = Y.r_nm + up(B * 4);
+    return Y;
+  }
+  // the staging views of a call (host side of the arena)
+  struct Stage {
+    SbpPair* pairs;
+    float *last_xw, *last_angle, *cur_ur;
+    uint8_t *last_desc, *last_has_obs, *cur_desc, *cur_has_obs;
+    int* last_octave;
+    gfs_keypoint* cur_kp;
+    const int *cur_match, *nmatches;
+  };
+  Stage stage(const Layout& Y) const {
+    uint8_t* b = h_in.p;
+    return Stage{reinterpret_cast<SbpPair*>(b), reinterpret_cast<float*>(b + Y.o_xw), reinterpret_cast<float*>(b + Y.o_ang),
+                 reinterpret_cast<float*>(b + Y.o_ur), b + Y.o_desc, b + Y.o_lobs, b + Y.o_cdesc, b + Y.o_cobs,
+                 reinterpret_cast<int*>(b + Y.o_oct), reinterpret_cast<gfs_keypoint*>(b + Y.o_kp),
+                 reinterpret_cast<const int*>(h_res.p), reinterpret_cast<const int*>(h_res.p + Y.r_nm)};
+  }
 };
 
-// uploads the staged batch, runs k_sbp, downloads cur_match / nmatches into the pinned buffers
-static int sbp_run(gfs_sbp* h, int B) {
-  const int SL = h->max_last, SC = h->max_cur;
+// uploads the staged batch, runs k_sbp, downloads cur_match / nmatches into the pinned result block
+static int sbp_run(gfs_sbp* h, int B, const gfs_sbp::Layout& Y) {
   hipStream_t s = h->stream;
-  const size_t L = (size_t)SL * B, Cn = (size_t)SC * B;
-  GFS_HIP(hipMemcpyAsync(h->d_pairs.p, h->h_pairs.p, B * sizeof(SbpPair), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_xw.p, h->h_last_xw.p, L * 12, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_desc.p, h->h_last_desc.p, L * 32, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_octave.p, h->h_last_octave.p, L * 4, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_angle.p, h->h_last_angle.p, L * 4, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_last_has_obs.p, h->h_last_has_obs.p, L, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_kp.p, h->h_cur_kp.p, Cn * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_ur.p, h->h_cur_ur.p, Cn * 4, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_desc.p, h->h_cur_desc.p, Cn * 32, hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemcpyAsync(h->d_cur_has_obs.p, h->h_cur_has_obs.p, Cn, hipMemcpyHostToDevice, s));
-  GFS_LAUNCH("k_sbp", k_sbp, dim3(B), dim3(kSbpThreads), 0, s, h->d_pairs.p, h->d_last_xw.p, h->d_last_desc.p, h->d_last_octave.p,
-             h->d_last_angle.p, h->d_last_has_obs.p, h->d_cur_kp.p, h->d_cur_ur.p, h->d_cur_desc.p, h->d_cur_has_obs.p, SL, SC,
-             h->d_cand.p, h->d_cand_cnt.p, h->d_lsel.p, h->d_cur_match.p, h->d_nmatches.p);
-  GFS_HIP(hipMemcpyAsync(h->h_cur_match.p, h->d_cur_match.p, Cn * 4, hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(h->h_nmatches.p, h->d_nmatches.p, B * 4, hipMemcpyDeviceToHost, s));
+  uint8_t* d = h->d_in.p;
+  GFS_HIP(hipMemcpyAsync(d, h->h_in.p, Y.in_bytes, hipMemcpyHostToDevice, s));
+  GFS_LAUNCH("k_sbp", k_sbp, dim3(B), dim3(kSbpThreads), 0, s, reinterpret_cast<const SbpPair*>(d), reinterpret_cast<const float*>(d + Y.o_xw),
+             (const uint8_t*)(d + Y.o_desc), reinterpret_cast<const int*>(d + Y.o_oct), reinterpret_cast<const float*>(d + Y.o_ang),
+             (const uint8_t*)(d + Y.o_lobs), reinterpret_cast<const gfs_keypoint*>(d + Y.o_kp), reinterpret_cast<const float*>(d + Y.o_ur),
+             (const uint8_t*)(d + Y.o_cdesc), (const uint8_t*)(d + Y.o_cobs), Y.SL, Y.SC, h->d_cand.p, h->d_cand_cnt.p, h->d_lsel.p,
+             reinterpret_cast<int*>(h->d_res.p), reinterpret_cast<int*>(h->d_res.p + Y.r_nm));
+  GFS_HIP(hipMemcpyAsync(h->h_res.p, h->d_res.p, Y.res_bytes, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
   return GFS_OK;
 }
@@ -584,36 +611,18 @@ int gfs_sbp_create(int device, int max_last, int max_cur, int max_batch, gfs_sbp
   h->max_cur = max_cur;
   h->max_batch = max_batch;
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  const size_t L = (size_t)max_last * max_batch, Cn = (size_t)max_cur * max_batch, B = max_batch;
+  const int SLmax = (int)gfs::align_up((size_t)max_last, 64), SCmax = (int)gfs::align_up((size_t)max_cur, 64);
+  const size_t L = (size_t)SLmax * max_batch, B = max_batch;
+  const gfs_sbp::Layout Y = h->layout(B, SLmax, SCmax);
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
-  A(h->d_pairs.alloc(B));
-  A(h->d_last_xw.alloc(L * 3));
-  A(h->d_last_desc.alloc(L * 32));
-  A(h->d_last_octave.alloc(L));
-  A(h->d_last_angle.alloc(L));
-  A(h->d_last_has_obs.alloc(L));
-  A(h->d_cur_kp.alloc(Cn));
-  A(h->d_cur_ur.alloc(Cn));
-  A(h->d_cur_desc.alloc(Cn * 32));
-  A(h->d_cur_has_obs.alloc(Cn));
+  A(h->d_in.alloc(Y.in_bytes));
+  A(h->h_in.alloc(Y.in_bytes));
+  A(h->d_res.alloc(Y.res_bytes));
+  A(h->h_res.alloc(Y.res_bytes));
   A(h->d_cand.alloc(L * kCand));
   A(h->d_cand_cnt.alloc(L));
   A(h->d_lsel.alloc(L));
-  A(h->d_cur_match.alloc(Cn));
-  A(h->d_nmatches.alloc(B));
-  A(h->h_pairs.alloc(B));
-  A(h->h_last_xw.alloc(L * 3));
-  A(h->h_last_desc.alloc(L * 32));
-  A(h->h_last_octave.alloc(L));
-  A(h->h_last_angle.alloc(L));
-  A(h->h_last_has_obs.alloc(L));
-  A(h->h_cur_kp.alloc(Cn));
-  A(h->h_cur_ur.alloc(Cn));
-  A(h->h_cur_desc.alloc(Cn * 32));
-  A(h->h_cur_has_obs.alloc(Cn));
-  A(h->h_cur_match.alloc(Cn));
-  A(h->h_nmatches.alloc(B));
 #undef A
   if (rc) {
     (void)hipStreamDestroy(h->stream);
@@ -636,11 +645,20 @@ int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B,
   GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_search_by_projection: batch %d exceeds capacity %d", B, h->max_batch);
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
-  const int SL = h->max_last, SC = h->max_cur;
+  const int capL = h->max_last, capC = h->max_cur;
+  int SL = 64, SC = 64;  // strides of the per-frame arrays in this call
+  for (int f = 0; f < B; f++) {
+    SL = std::max(SL, (int)gfs::align_up((size_t)std::max(problems[f].n_last, 0), 64));
+    SC = std::max(SC, (int)gfs::align_up((size_t)std::max(problems[f].n_cur, 0), 64));
+  }
+  SL = std::min(SL, (int)gfs::align_up((size_t)capL, 64));
+  SC = std::min(SC, (int)gfs::align_up((size_t)capC, 64));
+  const gfs_sbp::Layout Y = h->layout((size_t)B, SL, SC);
+  const gfs_sbp::Stage G = h->stage(Y);
   for (int f = 0; f < B; f++) {
     const gfs_sbp_problem& p = problems[f];
-    GFS_REQUIRE(p.n_last >= 0 && p.n_last <= SL && p.n_cur >= 0 && p.n_cur <= SC, GFS_ERR_CAPACITY,
-                "gfs_search_by_projection: pair %d has %d map points / %d key-points (capacity %d / %d)", f, p.n_last, p.n_cur, SL, SC);
+    GFS_REQUIRE(p.n_last >= 0 && p.n_last <= capL && p.n_cur >= 0 && p.n_cur <= capC, GFS_ERR_CAPACITY,
+                "gfs_search_by_projection: pair %d has %d map points / %d key-points (capacity %d / %d)", f, p.n_last, p.n_cur, capL, capC);
     GFS_REQUIRE(p.n_levels > 0 && p.n_levels <= 16 && p.scale_factors, GFS_ERR_INVALID_ARG,
                 "gfs_search_by_projection: pair %d needs 1..16 scale factors", f);
     GFS_REQUIRE(p.n_cur == 0 || cur_match[f], GFS_ERR_INVALID_ARG, "gfs_search_by_projection: cur_match[%d] is NULL", f);
@@ -651,7 +669,7 @@ int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B,
     for (int l = 0; l < p.n_last; l++)
       GFS_REQUIRE(p.last_octave[l] >= 0 && p.last_octave[l] < p.n_levels, GFS_ERR_INVALID_ARG,
                   "gfs_search_by_projection: pair %d map point %d has octave %d outside [0, %d)", f, l, p.last_octave[l], p.n_levels);
-    SbpPair& S = h->h_pairs.p[f];
+    SbpPair& S = G.pairs[f];
     S.n_last = p.n_last;
     S.n_cur = p.n_cur;
     S.n_levels = p.n_levels;
@@ -682,24 +700,24 @@ int gfs_search_by_projection(gfs_sbp* h, const gfs_sbp_problem* problems, int B,
     S.th = p.th;
     for (int k = 0; k < 16; k++) S.scale[k] = k < p.n_levels ? p.scale_factors[k] : 0.f;
     if (p.n_last > 0) {
-      memcpy(h->h_last_xw.p + (size_t)f * SL * 3, p.last_xw, (size_t)p.n_last * 12);
-      memcpy(h->h_last_desc.p + (size_t)f * SL * 32, p.last_desc, (size_t)p.n_last * 32);
-      memcpy(h->h_last_octave.p + (size_t)f * SL, p.last_octave, (size_t)p.n_last * 4);
-      memcpy(h->h_last_angle.p + (size_t)f * SL, p.last_angle, (size_t)p.n_last * 4);
-      memcpy(h->h_last_has_obs.p + (size_t)f * SL, p.last_mp_has_obs, (size_t)p.n_last);
+      memcpy(G.last_xw + (size_t)f * SL * 3, p.last_xw, (size_t)p.n_last * 12);
+      memcpy(G.last_desc + (size_t)f * SL * 32, p.last_desc, (size_t)p.n_last * 32);
+      memcpy(G.last_octave + (size_t)f * SL, p.last_octave, (size_t)p.n_last * 4);
+      memcpy(G.last_angle + (size_t)f * SL, p.last_angle, (size_t)p.n_last * 4);
+      memcpy(G.last_has_obs + (size_t)f * SL, p.last_mp_has_obs, (size_t)p.n_last);
     }
     if (p.n_cur > 0) {
-      memcpy(h->h_cur_kp.p + (size_t)f * SC, p.cur_kps_un, (size_t)p.n_cur * sizeof(gfs_keypoint));
-      memcpy(h->h_cur_ur.p + (size_t)f * SC, p.cur_u_right, (size_t)p.n_cur * 4);
-      memcpy(h->h_cur_desc.p + (size_t)f * SC * 32, p.cur_desc, (size_t)p.n_cur * 32);
-      memcpy(h->h_cur_has_obs.p + (size_t)f * SC, p.cur_has_mp_obs, (size_t)p.n_cur);
+      memcpy(G.cur_kp + (size_t)f * SC, p.cur_kps_un, (size_t)p.n_cur * sizeof(gfs_keypoint));
+      memcpy(G.cur_ur + (size_t)f * SC, p.cur_u_right, (size_t)p.n_cur * 4);
+      memcpy(G.cur_desc + (size_t)f * SC * 32, p.cur_desc, (size_t)p.n_cur * 32);
+      memcpy(G.cur_has_obs + (size_t)f * SC, p.cur_has_mp_obs, (size_t)p.n_cur);
     }
   }
-  const int rc = sbp_run(h, B);
+  const int rc = sbp_run(h, B, Y);
   if (rc != GFS_OK) return rc;
   for (int f = 0; f < B; f++) {
-    if (problems[f].n_cur > 0) memcpy(cur_match[f], h->h_cur_match.p + (size_t)f * SC, (size_t)problems[f].n_cur * 4);
-    nmatches[f] = h->h_nmatches.p[f];
+    if (problems[f].n_cur > 0) memcpy(cur_match[f], G.cur_match + (size_t)f * SC, (size_t)problems[f].n_cur * 4);
+    nmatches[f] = G.nmatches[f];
   }
   return GFS_OK;
 }
@@ -709,11 +727,20 @@ int gfs_search_by_projection_map(gfs_sbp* h, const gfs_sbp_map_problem* problems
   GFS_REQUIRE(B <= h->max_batch, GFS_ERR_CAPACITY, "gfs_search_by_projection_map: batch %d exceeds capacity %d", B, h->max_batch);
   std::lock_guard<std::mutex> lk(h->mu);
   GFS_HIP(hipSetDevice(h->device));
-  const int SL = h->max_last, SC = h->max_cur;
+  const int capL = h->max_last, capC = h->max_cur;
+  int SL = 64, SC = 64;  // strides of the per-frame arrays in this call
+  for (int f = 0; f < B; f++) {
+    SL = std::max(SL, (int)gfs::align_up((size_t)std::max(problems[f].n_mp, 0), 64));
+    SC = std::max(SC, (int)gfs::align_up((size_t)std::max(problems[f].n_cur, 0), 64));
+  }
+  SL = std::min(SL, (int)gfs::align_up((size_t)capL, 64));
+  SC = std::min(SC, (int)gfs::align_up((size_t)capC, 64));
+  const gfs_sbp::Layout Y = h->layout((size_t)B, SL, SC);
+  const gfs_sbp::Stage G = h->stage(Y);
   for (int f = 0; f < B; f++) {
     const gfs_sbp_map_problem& p = problems[f];
-    GFS_REQUIRE(p.n_mp >= 0 && p.n_mp <= SL && p.n_cur >= 0 && p.n_cur <= SC, GFS_ERR_CAPACITY,
-                "gfs_search_by_projection_map: frame %d has %d map points / %d key-points (capacity %d / %d)", f, p.n_mp, p.n_cur, SL, SC);
+    GFS_REQUIRE(p.n_mp >= 0 && p.n_mp <= capL && p.n_cur >= 0 && p.n_cur <= capC, GFS_ERR_CAPACITY,
+                "gfs_search_by_projection_map: frame %d has %d map points / %d key-points (capacity %d / %d)", f, p.n_mp, p.n_cur, capL, capC);
     GFS_REQUIRE(p.n_levels > 0 && p.n_levels <= 16 && p.scale_factors, GFS_ERR_INVALID_ARG,
                 "gfs_search_by_projection_map: frame %d needs 1..16 scale factors", f);
     GFS_REQUIRE(p.n_cur == 0 || cur_match[f], GFS_ERR_INVALID_ARG, "gfs_search_by_projection_map: cur_match[%d] is NULL", f);
@@ -724,7 +751,7 @@ int gfs_search_by_projection_map(gfs_sbp* h, const gfs_sbp_map_problem* problems
     for (int l = 0; l < p.n_mp; l++)
       GFS_REQUIRE(p.mp_level[l] >= 0 && p.mp_level[l] < p.n_levels, GFS_ERR_INVALID_ARG,
                   "gfs_search_by_projection_map: frame %d map point %d has level %d outside [0, %d)", f, l, p.mp_level[l], p.n_levels);
-    SbpPair& S = h->h_pairs.p[f];
+    SbpPair& S = G.pairs[f];
     memset(&S, 0, sizeof(S));
     S.n_last = p.n_mp;
     S.n_cur = p.n_cur;
@@ -738,24 +765,24 @@ int gfs_search_by_projection_map(gfs_sbp* h, const gfs_sbp_map_problem* problems
     S.th = p.th;
     for (int k = 0; k < 16; k++) S.scale[k] = k < p.n_levels ? p.scale_factors[k] : 0.f;
     if (p.n_mp > 0) {
-      memcpy(h->h_last_xw.p + (size_t)f * SL * 3, p.mp_proj, (size_t)p.n_mp * 12);
-      memcpy(h->h_last_desc.p + (size_t)f * SL * 32, p.mp_desc, (size_t)p.n_mp * 32);
-      memcpy(h->h_last_octave.p + (size_t)f * SL, p.mp_level, (size_t)p.n_mp * 4);
-      memcpy(h->h_last_angle.p + (size_t)f * SL, p.mp_view_cos, (size_t)p.n_mp * 4);
-      memcpy(h->h_last_has_obs.p + (size_t)f * SL, p.mp_has_obs, (size_t)p.n_mp);
+      memcpy(G.last_xw + (size_t)f * SL * 3, p.mp_proj, (size_t)p.n_mp * 12);
+      memcpy(G.last_desc + (size_t)f * SL * 32, p.mp_desc, (size_t)p.n_mp * 32);
+      memcpy(G.last_octave + (size_t)f * SL, p.mp_level, (size_t)p.n_mp * 4);
+      memcpy(G.last_angle + (size_t)f * SL, p.mp_view_cos, (size_t)p.n_mp * 4);
+      memcpy(G.last_has_obs + (size_t)f * SL, p.mp_has_obs, (size_t)p.n_mp);
     }
     if (p.n_cur > 0) {
-      memcpy(h->h_cur_kp.p + (size_t)f * SC, p.cur_kps_un, (size_t)p.n_cur * sizeof(gfs_keypoint));
-      memcpy(h->h_cur_ur.p + (size_t)f * SC, p.cur_u_right, (size_t)p.n_cur * 4);
-      memcpy(h->h_cur_desc.p + (size_t)f * SC * 32, p.cur_desc, (size_t)p.n_cur * 32);
-      memcpy(h->h_cur_has_obs.p + (size_t)f * SC, p.cur_has_mp_obs, (size_t)p.n_cur);
+      memcpy(G.cur_kp + (size_t)f * SC, p.cur_kps_un, (size_t)p.n_cur * sizeof(gfs_keypoint));
+      memcpy(G.cur_ur + (size_t)f * SC, p.cur_u_right, (size_t)p.n_cur * 4);
+      memcpy(G.cur_desc + (size_t)f * SC * 32, p.cur_desc, (size_t)p.n_cur * 32);
+      memcpy(G.cur_has_obs + (size_t)f * SC, p.cur_has_mp_obs, (size_t)p.n_cur);
     }
   }
-  const int rc = sbp_run(h, B);
+  const int rc = sbp_run(h, B, Y);
   if (rc != GFS_OK) return rc;
   for (int f = 0; f < B; f++) {
-    if (problems[f].n_cur > 0) memcpy(cur_match[f], h->h_cur_match.p + (size_t)f * SC, (size_t)problems[f].n_cur * 4);
-    nmatches[f] = h->h_nmatches.p[f];
+    if (problems[f].n_cur > 0) memcpy(cur_match[f], G.cur_match + (size_t)f * SC, (size_t)problems[f].n_cur * 4);
+    nmatches[f] = G.nmatches[f];
   }
   return GFS_OK;
 }

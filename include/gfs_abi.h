@@ -325,6 +325,13 @@ int gfs_stereo_from_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps
 int gfs_stereo_from_rgbd_batch_device(gfs_frame* h, const void* dev_kps, const void* dev_kps_un_x, const void* dev_counts,
                                       int B, int kp_stride, const void* dev_depth, int rows, int cols, float bf,
                                       void* dev_u_right, void* dev_depth_out, void* stream);
+/* The RGB-D tail of the Frame constructor in one call: ComputeStereoFromRGBD(imDepth) (src/Frame.cc:1314-1332) followed by
+ * ConvertDepthToPointCloud (:590-623).  The depth map is uploaded once and the cloud stays on the device: *dev_cloud /
+ * *dev_count / *cloud_stride are the arguments gfs_gicp_align_batch_device / gfs_gicp_align_next_batch_device take (valid until
+ * the next call on this handle).  out_xyzw may be NULL (no host copy of the cloud); *n_cloud receives the point count. */
+int gfs_frame_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x, int n, const float* depth, int rows, int cols,
+                   int stride_elems, float bf, int downsample, float fx, float fy, float cx, float cy, float* u_right,
+                   float* depth_out, float* out_xyzw, int cap, int* n_cloud, void** dev_cloud, void** dev_count, int* cloud_stride);
 
 /* ============================================================================================
  * 6. Optimizer::PoseOptimization — motion-only bundle adjustment of a frame
