@@ -274,6 +274,209 @@ __global__ __launch_bounds__(1024) void k_radix_sort(u64* __restrict__ keys0, u6
   if (tid == 0) which[c] = flip;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_cell_sort_lds: the CELL sort of a cloud of at most kCsE * 1024 means (a VGA depth image sampled with stride 4) with the
+// cloud RESIDENT IN LDS for all passes: 4-byte compacted keys (the three fields re-based to the cloud's extent, like
+// k_radix_sort) + 2-byte indices = 6 bytes an element, 120 KB, + the sixteen per-wave digit histograms (32 KB).  Same stable LSD
+// radix (9-bit digits), same permutation as k_radix_sort; the four passes through HBM of that kernel (2.1 GB moved for 0.42 GB of
+// keys per 1 024 clouds, r03f_pmc_traffic) become one read and one write.  A pass works in place: every thread first takes ITS
+// elements into registers -- wave w owns the contiguous chunk [w * chunk, (w + 1) * chunk) and walks it in rows of 64 lanes, so
+// the stable order is (wave, row, lane) --, the waves count their digits (wave ballots, one histogram row a wave), one scan over
+// (digit, wave) turns the counts into start positions, and the second walk over the same registers ranks and scatters.  Three
+// barriers a pass, none inside the walks.  Clouds it cannot take (keys wider than 32 bits, more than kCsE * 1024 means) are
+// counted in *n_left: the caller comes back with k_radix_sort (gicp_run, like the voxel sort's optimistic launch).
+// ------------------------------------------------------------------------------------------------
+constexpr int kCsE = 20, kCsRows = kCsE * 1024 / (16 * 64);  // rows of 64 elements per wave chunk: 20
+constexpr int kCsLdsBytes = kCsE * 1024 * 6 + 16 * 512 * 4;
+
+__global__ __launch_bounds__(1024) void k_cell_sort_lds(u64* __restrict__ keys0, unsigned* __restrict__ val0,
+                                                        const int* __restrict__ counts, int P, int* __restrict__ which,
+                                                        int* __restrict__ kinfo, int only, int* __restrict__ n_left) {
+  constexpr int kDB = 9, kNB = 1 << kDB;
+  extern __shared__ __align__(16) unsigned char cs_lds[];
+  unsigned* s_key = reinterpret_cast<unsigned*>(cs_lds);                               // [kCsE * 1024]
+  unsigned short* s_val = reinterpret_cast<unsigned short*>(s_key + kCsE * 1024);      // [kCsE * 1024]
+  unsigned* s_hist = reinterpret_cast<unsigned*>(s_val + kCsE * 1024);                 // [16][kNB]
+  __shared__ int s_mn[3], s_mx[3];
+  __shared__ unsigned s_wtot[8];
+  __shared__ int s_uniform;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (only >= 0 && (c & 1) != only) return;
+  const int n = __builtin_amdgcn_readfirstlane(counts[c]);
+  u64* ka = keys0 + (size_t)c * P;
+  unsigned* va = val0 + (size_t)c * P;
+  if (tid < 3) {
+    s_mn[tid] = 0x7fffffff;
+    s_mx[tid] = -1;
+  }
+  __syncthreads();
+  // wave w owns [w * chunk, (w + 1) * chunk), chunk a multiple of 64; its row r is elements w * chunk + 64 r + lane
+  const int chunk = ((n + 16 * 64 - 1) / (16 * 64)) * 64, rows = chunk >> 6;
+  const int base = wave * chunk;
+  u64 kreg[kCsRows];
+#pragma unroll
+  for (int r = 0; r < kCsRows; r++) {
+    const int i = base + 64 * r + lane;
+    kreg[r] = (r < rows && i < n) ? ka[i] : kInvalidKey;
+  }
+  {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+#pragma unroll
+    for (int r = 0; r < kCsRows; r++) {
+      const u64 k = kreg[r];
+      if (k == kInvalidKey) continue;
+      const int f[3] = {(int)(k & ((1ull << kCkSy) - 1)), (int)((k >> kCkSy) & ((1ull << (kCkSz - kCkSy)) - 1)), (int)(k >> kCkSz)};
+      for (int a = 0; a < 3; a++) {
+        mn[a] = min(mn[a], f[a]);
+        mx[a] = max(mx[a], f[a]);
+      }
+    }
+    for (int a = 0; a < 3; a++) {  // one LDS atomic a wave
+      mn[a] = gfs::wave_min_i32(mn[a]);
+      mx[a] = gfs::wave_max_i32(mx[a]);
+      if (lane == 0 && mx[a] >= 0) {
+        atomicMin(&s_mn[a], mn[a]);
+        atomicMax(&s_mx[a], mx[a]);
+      }
+    }
+  }
+  __syncthreads();
+  const bool any_valid = s_mx[0] >= 0;
+  const int mnx = any_valid ? s_mn[0] : 0, mny = any_valid ? s_mn[1] : 0, mnz = any_valid ? s_mn[2] : 0;
+  auto nbits = [](int range) {
+    int b = 1;
+    while ((1 << b) <= range) b++;
+    return b;
+  };
+  const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
+            bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
+  if (bx + by + bz > 32 || n > kCsE * 1024) {  // uniform: left to k_radix_sort (the caller launches it when the count says so)
+    if (tid == 0) {
+      atomicAdd(n_left, 1);
+      which[c] = 0;
+    }
+    return;
+  }
+  unsigned key[kCsRows];
+  unsigned short val[kCsRows];
+#pragma unroll
+  for (int r = 0; r < kCsRows; r++) {
+    const u64 k = kreg[r];
+    key[r] = 0xffffffffu;  // (a cell key is never the invalid key: every mean is a valid point)
+    if (k != kInvalidKey)
+      key[r] = (unsigned)((k & ((1ull << kCkSy) - 1)) - mnx) | ((unsigned)(((k >> kCkSy) & ((1ull << (kCkSz - kCkSy)) - 1)) - mny) << bx) |
+               ((unsigned)((k >> kCkSz) - mnz) << (bx + by));
+    val[r] = (unsigned short)(base + 64 * r + lane);  // the indices enter as the identity (k_voxel_reduce)
+  }
+  if (tid == 0) {
+    int* ki = kinfo + 8 * c;
+    ki[0] = mnx;
+    ki[1] = mny;
+    ki[2] = mnz;
+    ki[3] = bx;
+    ki[4] = by;
+    which[c] = 0;  // the sorted keys go back to buffer 0
+  }
+  const int npass = (bx + by + bz + kDB - 1) / kDB;
+  unsigned* myhist = s_hist + wave * kNB;
+  const u64 ltm = (1ull << lane) - 1ull;
+  for (int pass = 0; pass < npass && n > 0; pass++) {
+    const int shift = kDB * pass;
+    if (pass > 0) {  // (pass 0 works on the registers of the load)
+#pragma unroll
+      for (int r = 0; r < kCsRows; r++) {
+        const int i = base + 64 * r + lane;
+        if (r < rows && i < n) {
+          key[r] = s_key[i];
+          val[r] = s_val[i];
+        }
+      }
+    }
+    for (int k = lane; k < kNB; k += 64) myhist[k] = 0;
+    if (tid == 0) s_uniform = 0;
+    // (A) digits of the wave's chunk: per row the lanes with one digit find each other by ballots, their first lane counts them
+    auto same_digit = [&](bool valid, unsigned digit) {  // the valid lanes of the row that hold this lane's digit
+      u64 mask = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < kDB; bit++) {
+        const bool b1 = (digit >> bit) & 1u;
+        const u64 bm = __ballot(b1);
+        mask &= b1 ? bm : ~bm;
+      }
+      return mask;
+    };
+#pragma unroll
+    for (int r = 0; r < kCsRows; r++) {
+      if (r >= rows) continue;
+      const bool valid = base + 64 * r + lane < n;
+      const unsigned digit = (key[r] >> shift) & (kNB - 1);
+      const u64 mask = same_digit(valid, digit);
+      if (valid && (mask & ltm) == 0) myhist[digit] += (unsigned)__popcll(mask);  // one lane per distinct digit of the row
+    }
+    __syncthreads();
+    // (B) start position of (digit, wave): exclusive scan over the digits of the totals, then over the waves inside a digit
+    unsigned own = 0;
+    if (tid < kNB) {
+      for (int w = 0; w < 16; w++) own += s_hist[w * kNB + tid];
+      if (own == (unsigned)n) s_uniform = 1;
+    }
+    unsigned incl = own;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+      const unsigned v = __shfl_up(incl, ofs, 64);
+      if (lane >= ofs) incl += v;
+    }
+    if (tid < kNB && lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    if (s_uniform) {  // every key has this digit: nothing moves (block-uniform); the keys stay where they are
+      if (pass == 0) {
+#pragma unroll
+        for (int r = 0; r < kCsRows; r++) {
+          const int i = base + 64 * r + lane;
+          if (r < rows && i < n) {
+            s_key[i] = key[r];
+            s_val[i] = val[r];
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if (tid < kNB) {
+      unsigned acc = incl - own;
+      for (int w = 0; w < wave; w++) acc += s_wtot[w];
+      for (int w = 0; w < 16; w++) {
+        const unsigned t = s_hist[w * kNB + tid];
+        s_hist[w * kNB + tid] = acc;
+        acc += t;
+      }
+    }
+    __syncthreads();
+    // (C) rank and scatter: the wave walks its chunk again, its histogram row is now the running position of every digit
+#pragma unroll
+    for (int r = 0; r < kCsRows; r++) {
+      if (r >= rows) continue;
+      const bool valid = base + 64 * r + lane < n;
+      const unsigned digit = (key[r] >> shift) & (kNB - 1);
+      const u64 mask = same_digit(valid, digit);
+      const unsigned before = valid ? myhist[digit] : 0u;
+      const unsigned lane_rank = (unsigned)__popcll(mask & ltm);
+      if (valid) {
+        const unsigned pos = before + lane_rank;
+        s_key[pos] = key[r];
+        s_val[pos] = val[r];
+        if (lane_rank == 0) myhist[digit] = before + (unsigned)__popcll(mask);
+      }
+    }
+    __syncthreads();
+  }
+  // back to HBM as 64-bit compacted keys + 32-bit indices (k_cell_build)
+  for (int i = tid; i < n; i += 1024) {
+    ka[i] = (u64)s_key[i];
+    va[i] = (unsigned)s_val[i];
+  }
+}
+
 // block-wide exclusive scan of one int per thread (1024 threads); returns exclusive prefix, total in *total
 __device__ __forceinline__ int block_scan_1024(int v, int* s_wave /*16*/, int* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2562,6 +2765,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
                               kVqsLdsE * 1024 * 8));
   GFS_HIP(hipFuncSetAttribute((const void*)vqs::k_voxel_qsort_top_lds<kVqsLdsGvE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kVqsLdsGvE * 1024 * 4));
+  GFS_HIP(hipFuncSetAttribute((const void*)k_cell_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kCsLdsBytes));
   if (const char* e = getenv("GFS_GICP_LM")) h->lm_rounds = strcmp(e, "persistent") != 0;
   if (const char* e = getenv("GFS_GICP_TILE_STATS")) h->tile_stats_on = atoi(e) != 0;
   const size_t P = h->P, B = max_batch, C2 = 2 * B;
@@ -2723,8 +2927,15 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   GFS_LAUNCH("k_voxel_reduce", k_voxel_reduce, dim3(C2, wg_parts), dim3(1024), 0, s, in_even, in_odd, stride_pts, h->d_keys0.p,
              h->d_keys1.p, h->d_val0.p, h->d_val1.p, h->d_which.p, h->d_counts.p, P, prm.inv_cell, h->d_tmp.p, h->d_ck0.p, h->d_ci0.p,
              h->d_m.p, prm.only, tiles_per_part, h->d_bbox.p);
-  GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p, h->d_ci1.p,
-             h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p, prm.only, kCkSy, kCkSz);
+  // the cell sort: resident in LDS when the handle's clouds fit (it counts the clouds it cannot take in d_ndone[1], which the LM
+  // loop's first poll looks at -- the call is then run again with k_radix_sort, like the voxel sort's optimistic launch)
+  if (optimistic_sort && h->vqs_lds && P <= 1024 * kCsE) {
+    GFS_LAUNCH("k_cell_sort_lds", k_cell_sort_lds, dim3(C2), dim3(1024), kCsLdsBytes, s, h->d_ck0.p, h->d_ci0.p, h->d_m.p, P,
+               h->d_which2.p, h->d_kinfo2.p, prm.only, h->d_ndone.p + 1);
+  } else {
+    GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p, h->d_ci1.p,
+               h->d_m.p, P, h->d_which2.p, h->d_kinfo2.p, prm.only, kCkSy, kCkSz);
+  }
   GFS_LAUNCH("k_cell_build", k_cell_build, dim3(C2, wg_parts), dim3(1024), 0, s, h->d_tmp.p, h->d_ck0.p, h->d_ck1.p, h->d_ci0.p,
              h->d_ci1.p, h->d_which2.p, h->d_m.p, P, h->d_pts.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_bbox.p, h->d_kinfo2.p,
              prm.only);
