@@ -1041,6 +1041,120 @@ struct TopK {
   }
 };
 
+// The main 10-NN pass keeps its candidates as KEYS: the squared distance (a non-negative double, whose bit pattern orders like the
+// value) with the low 20 mantissa bits replaced by the point index (clouds hold at most 2^20 points).  A key is still a double, so
+// a compare-exchange of two candidates is v_min_f64 + v_max_f64 -- two instructions that carry the index along -- instead of the
+// five per slot of the sorted insertion (compare, two selects for the index, max, min): four candidates are sorted (5 exchanges)
+// and merged into the ascending list of ELEVEN keys by a pruned bitonic merge (27 exchanges), 16 instructions a candidate against
+// 50.  The kernel is bound by exactly these instructions (95 % VALU, profiles/r03f_pmc_sq.json).
+// Exactness: a key is the distance to within 2^-32; keys are compared, so two candidates whose distances agree in all but the last
+// 20 bits are ordered by index instead.  That can only matter at the boundary between the k-th and the (k+1)-th candidate -- the
+// reason for the eleventh slot: if those two keys share their high bits the query is handed to the deferred pass (exact sorted
+// insertion), otherwise every candidate outside the list is strictly farther than the k-th, as with exact comparisons.  Bounds
+// derived from a key use its upper end (low bits all ones).
+struct TopKey11 {
+  static constexpr double kNone = 1.79769313486231570e308;  // above every key (distances are far below 1e300)
+  double k[11];
+  __device__ void init() {
+#pragma unroll
+    for (int i = 0; i < 11; i++) k[i] = kNone;
+  }
+  static __device__ __forceinline__ double key(double dist, int index) {
+    const u64 b = (u64)__double_as_longlong(dist);
+    return __longlong_as_double((long long)((b & ~0xfffffull) | (u64)(unsigned)index));
+  }
+  static __device__ __forceinline__ void cx(double& a, double& b) {  // a <- min, b <- max
+    const double lo = min_f64(a, b), hi = max_f64(a, b);
+    a = lo;
+    b = hi;
+  }
+  // merges four keys (kNone = no candidate) into the list
+  __device__ __forceinline__ void push4(double c0, double c1, double c2, double c3) {
+    cx(c0, c1);
+    cx(c2, c3);
+    cx(c0, c2);
+    cx(c1, c3);
+    cx(c1, c2);  // c0 <= c1 <= c2 <= c3
+    // V[0..10] = k (ascending), V[11] = kNone, V[12..15] = c3, c2, c1, c0 (descending): bitonic; merge, keep V[0..10]
+    double v11 = kNone, v12 = c3, v13 = c2, v14 = c1, v15 = c0;
+    cx(k[0], k[8]);
+    cx(k[1], k[9]);
+    cx(k[2], k[10]);
+    cx(k[4], v12);
+    cx(k[5], v13);
+    cx(k[6], v14);
+    cx(k[7], v15);  // (k[3] against v11 = kNone: nothing moves)
+    // lower half: the eight smallest, bitonic -> sorted
+    cx(k[0], k[4]);
+    cx(k[1], k[5]);
+    cx(k[2], k[6]);
+    cx(k[3], k[7]);
+    cx(k[0], k[2]);
+    cx(k[1], k[3]);
+    cx(k[4], k[6]);
+    cx(k[5], k[7]);
+    cx(k[0], k[1]);
+    cx(k[2], k[3]);
+    cx(k[4], k[5]);
+    cx(k[6], k[7]);
+    // upper half: its three smallest, sorted, into k[8..10]
+    cx(k[8], v12);
+    cx(k[9], v13);
+    cx(k[10], v14);
+    v11 = min_f64(v11, v15);
+    cx(k[8], k[10]);
+    cx(k[9], v11);
+    cx(k[8], k[9]);
+    k[10] = min_f64(k[10], v11);
+  }
+  __device__ __forceinline__ double at(int n) const {
+    // k[n] without dynamic register indexing -- and without a chain of selects, which the optimiser turns back into an indexed
+    // load from a scratch copy of the array: the bits are blended with integer masks
+    u64 bits = 0;
+#pragma unroll
+    for (int i = 0; i < 11; i++) bits |= (u64)__double_as_longlong(k[i]) & (u64)(-(long long)(i == n));
+    return __longlong_as_double((long long)bits);
+  }
+  // upper end of the distance a key stands for
+  static __device__ __forceinline__ double upper(double key) { return __longlong_as_double(__double_as_longlong(key) | 0xfffffll); }
+  static __device__ __forceinline__ int index(double key) { return (int)((unsigned)__double_as_longlong(key) & 0xfffffu); }
+  static __device__ __forceinline__ bool same_high_bits(double a, double b) {
+    return ((u64)__double_as_longlong(a) >> 20) == ((u64)__double_as_longlong(b) >> 20);
+  }
+};
+
+// (no arrays of double4 below: they end up in scratch memory behind FLAT instructions)
+__device__ __forceinline__ double knn_key(const double4& t, const double4& q, int j, bool on) {
+  const double ddx = t.x - q.x, ddy = t.y - q.y, ddz = t.z - q.z;
+  return on ? TopKey11::key(ddx * ddx + ddy * ddy + ddz * ddz, j) : TopKey11::kNone;
+}
+// the run [j0, j1) of candidate points into the key list, four loads in flight
+__device__ __forceinline__ void knn_scan_run_keys(const double4* __restrict__ p, const double4& q, int j0, int j1, TopKey11& loc) {
+  for (int j = j0; j < j1; j += 4) {
+    const double4 t0 = p[j], t1 = p[min(j + 1, j1 - 1)], t2 = p[min(j + 2, j1 - 1)], t3 = p[min(j + 3, j1 - 1)];
+    loc.push4(knn_key(t0, q, j, true), knn_key(t1, q, j + 1, j + 1 < j1), knn_key(t2, q, j + 2, j + 2 < j1),
+              knn_key(t3, q, j + 3, j + 3 < j1));
+  }
+}
+// the same over up to four runs (begin, length) concatenated into one lane-private sequence
+__device__ __forceinline__ void knn_scan_runs4_keys(const double4* __restrict__ p, const double4& q, int b0, int l0, int b1, int l1,
+                                                    int b2, int l2, int b3, int l3, TopKey11& loc) {
+  const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
+  const int o0 = b0, o1 = b1 - c1, o2 = b2 - c2, o3 = b3 - c3;
+  for (int v = 0; v < total; v += 4) {
+    int j[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int vv = min(v + u, total - 1);
+      j[u] = vv + (vv < c1 ? o0 : vv < c2 ? o1 : vv < c3 ? o2 : o3);
+    }
+    const int j0 = j[0], j1 = j[1], j2 = j[2], j3 = j[3];
+    const double4 t0 = p[j0], t1 = p[j1], t2 = p[j2], t3 = p[j3];
+    loc.push4(knn_key(t0, q, j0, true), knn_key(t1, q, j1, v + 1 < total), knn_key(t2, q, j2, v + 2 < total),
+              knn_key(t3, q, j3, v + 3 < total));
+  }
+}
+
 // covariance of the k nearest neighbours, regularised: cov := V diag(1e-3, 1, 1) V^T  (util/normal_estimation.hpp:66-92)
 __device__ __forceinline__ void knn_write_cov(const TopK<10>& best, int kk, const double4* __restrict__ p, double* __restrict__ out) {
   const int n = min(best.found, kk);
@@ -1171,7 +1285,7 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
   const double4 q = p[i];
   const int cx = fast_floor_d(q.x * prm.inv_cell) + kCoordOffset, cy = fast_floor_d(q.y * prm.inv_cell) + kCoordOffset,
             cz = fast_floor_d(q.z * prm.inv_cell) + kCoordOffset;
-  TopK<10> best;
+  TopKey11 best;
   const int kk = min(prm.k_neighbors, 10);
   const int want = min(kk, m);
   // The 27-cell cube, branch-and-bound per lane like the 1-NN search of k_gicp_linearize: the own row (3 cells) is scanned
@@ -1181,6 +1295,7 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
   // cells as one concatenated sequence, four loads in flight (a wave iterates max-over-lanes(candidates) / 4 times: ~65 instead
   // of ~105 candidates on a depth-camera cloud).
   bool certified = false;
+  double kth_for_deferred = TopKey11::kNone;
   {
     best.init();
     const double cell2 = prm.cell * prm.cell;
@@ -1192,12 +1307,17 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
     {
       int j0, j1;
       row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy, cz, &j0, &j1);
-      knn_scan_run(p, q, j0, j1, best);
+      knn_scan_run_keys(p, q, j0, j1, best);
     }
+    // k-th distance so far (its upper end), or "none yet"
+    auto kth_bound = [&]() {
+      const double kw = best.at(max(want - 1, 0));
+      return kw < TopKey11::kNone ? TopKey11::upper(kw) : TopKey11::kNone;
+    };
     constexpr int rows[2][4] = {{1, 3, 5, 7}, {0, 2, 6, 8}};  // (dy + 1) + 3 (dz + 1): faces, then diagonals
 #pragma unroll
     for (int round = 0; round < 2; round++) {
-      const double B = best.found >= want ? best.nth(max(want - 1, 0)) : 1.79769313486231570e308;
+      const double B = kth_bound();
       int rb[4], rl[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -1213,13 +1333,18 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
           rl[u] = e0 - b0;
         }
       }
-      knn_scan_runs4(p, q, rb[0], rl[0], rb[1], rl[1], rb[2], rl[2], rb[3], rl[3], best);
+      knn_scan_runs4_keys(p, q, rb[0], rl[0], rb[1], rl[1], rb[2], rl[2], rb[3], rl[3], best);
     }
     // certified: nothing outside the 27-cell cube can be nearer than the k-th candidate.  The cube's faces are 1 + u and 2 - u
     // cells away from the query along each axis (u = its position inside its own cell): at least one cell, up to 1.5
     const double fx = fmin(ux + 1.0, 2.0 - ux), fy = fmin(uy + 1.0, 2.0 - uy), fz = fmin(uz + 1.0, 2.0 - uz);
     const double reach = fmax(fmin(fx, fmin(fy, fz)) - 1e-9, 1.0) * prm.cell;
-    certified = best.found >= want && best.nth(max(want - 1, 0)) <= fmax(reach * reach, cell2);
+    // ... and the key list must name the k nearest beyond doubt: the (k+1)-th key differs from the k-th above the index bits
+    const double kw = best.at(max(want - 1, 0)), kn = best.at(want);
+    certified = want > 0 && kw < TopKey11::kNone && TopKey11::upper(kw) <= fmax(reach * reach, cell2) &&
+                !(kn < TopKey11::kNone && TopKey11::same_high_bits(kw, kn));
+    certified = certified || want == 0;
+    kth_for_deferred = kw < TopKey11::kNone ? TopKey11::upper(kw) : TopKey11::kNone;
   }
   // Isolated point (k-th neighbour beyond one cell, ~2 % of a depth-camera cloud): it needs a (much) bigger probe.  Done
   // here it would stall the other 63 lanes of its wave (and ~70 % of the waves hold such a lane), so it is deferred.
@@ -1227,10 +1352,17 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
     const int slot = atomicAdd(&ginfo_rw[8 * c + 7], 1);
     hard_list[(size_t)c * P + slot] = (unsigned)i;
     // k candidates already known: the true k nearest lie within this distance (bounds the follow-up probe)
-    hard_d[(size_t)c * P + slot] = best.found >= want ? best.nth(max(want - 1, 0)) : 1.79769313486231570e308;
+    hard_d[(size_t)c * P + slot] = kth_for_deferred;
     return;
   }
-  knn_write_cov(best, kk, p, cov6 + ((size_t)c * P + i) * 6);
+  TopK<10> res;  // the neighbours in key order (distance, then index)
+  res.found = 0;
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    res.id[k] = best.k[k] < TopKey11::kNone ? TopKey11::index(best.k[k]) : -1;
+    res.found += best.k[k] < TopKey11::kNone ? 1 : 0;
+  }
+  knn_write_cov(res, kk, p, cov6 + ((size_t)c * P + i) * 6);
 }
 
 // k_knn_cov_far<LANES, R0, DEFER>: the queries whose k-th neighbour is farther than one cell (sparse regions, a few %
