@@ -108,6 +108,7 @@ def track_frame(be, last, gray, depth, K, W, H, ds, stages):
     T = np.asarray(be.gicp(last["cloud"], cloud), np.float64).reshape(4, 4)  # x_last = T x_cur
     t = _lap(stages, "gicp", t)
     Tcl = np.linalg.inv(T)  # the current camera's pose with the last camera as the world
+    qcl = _quat_from_R(Tcl[:3, :3])
     # the last frame's map points: its key points with a depth, unprojected (Frame::UnprojectStereo), world = last camera
     lk, lz = last["kps"], last["z"]
     has = lz > 0
@@ -115,7 +116,7 @@ def track_frame(be, last, gray, depth, K, W, H, ds, stages):
     f32 = np.float32
     prob = dict(last_xw=xw, last_desc=last["desc"][has], last_octave=lk["octave"][has].astype(np.int32), last_angle=lk["angle"][has].astype(np.float32),
                 last_mp_has_obs=np.ones(int(has.sum()), np.uint8), cur_kps_un=kps, cur_u_right=cur["ur"], cur_desc=desc,
-                cur_has_mp_obs=np.zeros(len(kps), np.uint8), Tcw_q=_quat_from_R(Tcl[:3, :3]).astype(np.float32), Tcw_t=Tcl[:3, 3].astype(np.float32),
+                cur_has_mp_obs=np.zeros(len(kps), np.uint8), Tcw_q=qcl.astype(np.float32), Tcw_t=Tcl[:3, 3].astype(np.float32),
                 Tlw_q=np.array([0, 0, 0, 1], np.float32), Tlw_t=np.zeros(3, np.float32), fx=f32(fx), fy=f32(fy), cx=f32(cx), cy=f32(cy), bf=f32(BF),
                 b=f32(BF / fx), min_x=f32(0), max_x=f32(W), min_y=f32(0), max_y=f32(H), grid_w_inv=f32(64) / f32(W), grid_h_inv=f32(48) / f32(H),
                 scale_factors=be.scale, th=f32(TH_RGBD), mono=0, check_orientation=1)
@@ -124,7 +125,7 @@ def track_frame(be, last, gray, depth, K, W, H, ds, stages):
     sel = np.nonzero(match >= 0)[0]
     mp = match[sel]
     obs = np.stack([kps["x"][sel], kps["y"][sel], cur["ur"][sel]], 1).astype(np.float64)
-    pp = dict(q=_quat_from_R(Tcl[:3, :3]).astype(np.float64), t=Tcl[:3, 3].astype(np.float64), xw=xw[mp].astype(np.float64), obs=obs,
+    pp = dict(q=qcl.astype(np.float64), t=Tcl[:3, 3].astype(np.float64), xw=xw[mp].astype(np.float64), obs=obs,
               inv_sigma2=be.inv_sigma2[kps["octave"][sel]], stereo=(cur["ur"][sel] >= 0).astype(np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=BF)
     r = be.pose(pp)
     _lap(stages, "pose_optimization", t)

@@ -62,6 +62,7 @@ struct GicpParams {
   // the streaming entry alternates so that the previous call's preprocessed source becomes this call's target in place).
   // only: -1 = preprocess both slots, else only the slot of that parity.
   int src_slot, only;
+  int knn_exact;  // GFS_GICP_KNN_EXACT=1 (test knob): k_knn_cov certifies nothing, every query takes the exact deferred passes
 };
 
 __device__ __forceinline__ int fast_floor_d(double v) {  // util/fast_floor.hpp:12-15
@@ -1343,7 +1344,7 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
     const double kw = best.at(max(want - 1, 0)), kn = best.at(want);
     certified = want > 0 && kw < TopKey11::kNone && TopKey11::upper(kw) <= fmax(reach * reach, cell2) &&
                 !(kn < TopKey11::kNone && TopKey11::same_high_bits(kw, kn));
-    certified = certified || want == 0;
+    certified = (certified || want == 0) && !prm.knn_exact;
     kth_for_deferred = kw < TopKey11::kNone ? TopKey11::upper(kw) : TopKey11::kNone;
   }
   // Isolated point (k-th neighbour beyond one cell, ~2 % of a depth-camera cloud): it needs a (much) bigger probe.  Done
@@ -3010,6 +3011,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   prm.k_neighbors = cfg->num_neighbors;
   prm.src_slot = 1;
   prm.only = -1;
+  prm.knn_exact = getenv("GFS_GICP_KNN_EXACT") && atoi(getenv("GFS_GICP_KNN_EXACT")) != 0;
   if (streaming) {
     // (the stride is that of THIS call's source buffer: the target slot is not read from any input buffer again)
     GFS_REQUIRE(h->last_B == B && h->last_leaf == cfg->downsampling_resolution && h->last_cell == prm.cell &&

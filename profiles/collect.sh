@@ -25,13 +25,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- \
     python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_pmc_$c.log 2>&1
 done
-# 4. issue / wait mix of the hot kernels
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
-  --output-format csv -d $OUT/${TAG}_pmc_sq -- \
-  python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_pmc_sq.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE \
-  --output-format csv -d $OUT/${TAG}_pmc_sq2 -- \
-  python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_pmc_sq2.log 2>&1
+# 4. issue / wait mix of the hot kernels (at most four counters a pass: a seven-counter pass hung for its whole timeout in round 4)
+n=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+           "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE"; do
+  n=$((n+1)); d=pmc_sq$n; [ $n = 1 ] && d=pmc_sq
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/${TAG}_$d -- \
+    python $R/bench.py --steps 2 --warmup 1 --serial --lanes 1 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 0 > $OUT/${TAG}_$d.log 2>&1
+done
 
 python $R/profiles/summarize.py $OUT $TAG
 tail -c 600 $OUT/${TAG}_bench.json

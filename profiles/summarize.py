@@ -56,7 +56,7 @@ for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_traffic_serial.json"), "w"), indent=1)
 
 sq = {}
-for d in ("pmc_sq", "pmc_sq2"):
+for d in ("pmc_sq", "pmc_sq2", "pmc_sq3"):
     acc, n = counters(os.path.join(out, f"{tag}_{d}"))
     for k, v in acc.items():
         sq.setdefault(k, {}).update({a: round(b / len(n[k])) for a, b in v.items()})

@@ -79,3 +79,37 @@ def test_gpu_u16_depth_conversion_is_convert_to(gpu_api, oracle):
         assert n == len(co) and np.array_equal(hip.to_host(d_out, (cap, 4), np.float32)[:n].view(np.uint32), co.view(np.uint32))
     finally:
         hip.free()
+
+
+@pytest.mark.gpu
+def test_gpu_frame_rgbd_is_the_two_calls_and_feeds_the_registration(gpu_api, oracle):
+    """gfs_frame_rgbd = ComputeStereoFromRGBD + ConvertDepthToPointCloud behind ONE depth upload (the RGB-D tail of the Frame
+    constructor, src/Frame.cc:1314-1332, 590-623): mvuRight / mvDepth / cloud bit-exact against the oracle, with and without the host
+    copy of the cloud; the device-resident cloud it returns is what gfs_gicp_align_next_batch_device consumes (same pose, bit for bit,
+    as the host-pointer entry on the same clouds)."""
+    fp = synth.frame_pair(6)
+    fx, fy, cx, cy = (float(np.float32(v)) for v in synth.intrinsics(640, 480))
+    bf = float(np.float32(0.0745 * 607.0))
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7)
+    fr = gpu_api.Frame(max_rows=480, max_cols=640)
+    reg_a, reg_b = gpu_api.RegistrationGICP(max_points=20480, max_batch=1), gpu_api.RegistrationGICP(max_points=20480, max_batch=1)
+    clouds = []
+    for key_g, key_d in (("gray0", "depth0"), ("gray1", "depth1")):
+        _, kps, _ = ext(fp[key_g])
+        ur, vd, cloud, dev = fr.FrameRGBD(kps, fp[key_d], bf, 4, fx, fy, cx, cy, host_cloud=True)
+        uo, vo = oracle.stereo_from_rgbd(kps, fp[key_d], bf)
+        co = oracle.depth_to_cloud(fp[key_d], 4, fx, fy, cx, cy)
+        assert np.array_equal(ur.view(np.uint32), uo.view(np.uint32)) and np.array_equal(vd.view(np.uint32), vo.view(np.uint32))
+        assert cloud.shape == co.shape and np.array_equal(cloud.view(np.uint32), co.view(np.uint32)) and dev[3] == len(co)
+        ur2, vd2, none, dev2 = fr.FrameRGBD(kps, fp[key_d], bf, 4, fx, fy, cx, cy, host_cloud=False)
+        assert none is None and dev2[3] == len(co) and np.array_equal(ur2.view(np.uint32), uo.view(np.uint32))
+        clouds.append((co, dev2))
+    # frame 0 against itself seeds both handles; then frame 1 once through the device-resident cloud, once through host pointers
+    reg_a.RegisterPointClouds(clouds[0][0], clouds[0][0])
+    reg_b.RegisterPointClouds(clouds[0][0], clouds[0][0])
+    d_cloud, d_n, stride, _ = clouds[1][1]
+    ra = reg_a.align_next_batch_device(d_cloud, d_n, 1, stride)[0]
+    rb = reg_b.RegisterNext(clouds[1][0])
+    assert np.array_equal(ra["T"], rb["T"]) and ra["iterations"] == rb["iterations"] and ra["num_inliers"] == rb["num_inliers"]
+    ro = oracle.gicp_align(clouds[0][0], clouds[1][0])
+    assert np.linalg.norm(ra["T"] - ro["T"]) <= 1e-6 * np.linalg.norm(ro["T"])

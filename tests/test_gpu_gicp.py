@@ -409,3 +409,24 @@ def test_staged_tile_gives_the_same_bits(gpu_api, monkeypatch):
         b = reg.RegisterPointClouds(fp["cloud0"], fp["cloud1"])
         assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["num_inliers"] == b["num_inliers"]
         assert np.array_equal(a["H"], b["H"]) and a["error"] == b["error"]
+
+
+def test_key_merge_selects_what_the_exact_passes_select(gpu_api, monkeypatch):
+    """k_knn_cov keeps its candidates as (distance | point index) keys merged by a min / max network (csrc/gicp.hip TopKey11) and
+    hands a query to the exact deferred passes when the k-th and (k+1)-th key agree above the index bits.  GFS_GICP_KNN_EXACT=1
+    sends EVERY query through those exact passes: the covariances must be the same bits either way -- on depth-camera clouds and on a
+    lattice, where nearly every point has an exact four-way tie at its 10th neighbour (4 at d, 4 at sqrt(2) d, then 4 at 2 d)."""
+    clouds = [synth.frame_pair(s, 320, 240, 4)["cloud0"] for s in (3, 11)]
+    gx, gy = np.meshgrid(np.arange(70), np.arange(50))
+    lattice = np.stack([gx.ravel() * 0.02 - 0.69, gy.ravel() * 0.02 - 0.49, np.full(gx.size, 1.5) + 0.003 * (gx.ravel() % 3), np.ones(gx.size)], 1)
+    clouds.append(lattice.astype(np.float32))
+    reg = gpu_api.RegistrationGICP(max_points=20480)
+    for c in clouds:
+        monkeypatch.setenv("GFS_GICP_KNN_EXACT", "0")
+        reg.RegisterPointClouds(c, c)
+        pa, ca = reg.preprocessed(0, 0)
+        monkeypatch.setenv("GFS_GICP_KNN_EXACT", "1")
+        reg.RegisterPointClouds(c, c)
+        pb, cb = reg.preprocessed(0, 0)
+        assert np.array_equal(pa, pb) and len(pa) > 1000
+        assert np.array_equal(ca.view(np.uint64), cb.view(np.uint64)), int((ca != cb).any(axis=(1, 2)).sum())
