@@ -22,8 +22,21 @@ BF = 40.0       # baseline x fx of the TUM RGB-D settings files (Examples/RGB-D/
 
 
 def _quat_from_R(R):
-    from geoflowslam_amd import synth
-    return synth._quat_from_R(R)
+    """Unit quaternion (x, y, z, w), w >= 0, of a rotation matrix: the largest of (trace, diagonal) picks the branch (what
+    scipy's Rotation.from_matrix(...).as_quat() computes; written out because that call costs ~0.1 ms, a twentieth of a frame)."""
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = (float(v) for v in np.asarray(R, np.float64).reshape(9))
+    tr = m00 + m11 + m22
+    if tr >= m00 and tr >= m11 and tr >= m22:
+        q = [m21 - m12, m02 - m20, m10 - m01, 1.0 + tr]
+    elif m00 >= m11 and m00 >= m22:
+        q = [1.0 - tr + 2.0 * m00, m01 + m10, m02 + m20, m21 - m12]
+    elif m11 >= m22:
+        q = [m01 + m10, 1.0 - tr + 2.0 * m11, m12 + m21, m02 - m20]
+    else:
+        q = [m02 + m20, m12 + m21, 1.0 - tr + 2.0 * m22, m10 - m01]
+    n = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]) ** 0.5
+    s = (1.0 if q[3] >= 0 else -1.0) / n
+    return np.array([q[0] * s, q[1] * s, q[2] * s, q[3] * s])
 
 
 class GpuBackend:
@@ -112,10 +125,17 @@ def track_frame(be, last, gray, depth, K, W, H, ds, stages):
     # the last frame's map points: its key points with a depth, unprojected (Frame::UnprojectStereo), world = last camera
     lk, lz = last["kps"], last["z"]
     has = lz > 0
-    xw = np.stack([(lk["x"] - cx) * lz / fx, (lk["y"] - cy) * lz / fy, lz], 1).astype(np.float32)[has]
+    xw = np.empty((len(lz), 3), np.float32)  # (double-precision expressions rounded once, like np.stack(...).astype(float32))
+    xw[:, 0] = (lk["x"] - cx) * lz / fx
+    xw[:, 1] = (lk["y"] - cy) * lz / fy
+    xw[:, 2] = lz
+    if has.all():  # every key point of the last frame has a depth: nothing to compact
+        l_desc, l_oct, l_ang = last["desc"], lk["octave"].astype(np.int32), lk["angle"].astype(np.float32)
+    else:
+        xw, l_desc, l_oct, l_ang = xw[has], last["desc"][has], lk["octave"][has].astype(np.int32), lk["angle"][has].astype(np.float32)
     f32 = np.float32
-    prob = dict(last_xw=xw, last_desc=last["desc"][has], last_octave=lk["octave"][has].astype(np.int32), last_angle=lk["angle"][has].astype(np.float32),
-                last_mp_has_obs=np.ones(int(has.sum()), np.uint8), cur_kps_un=kps, cur_u_right=cur["ur"], cur_desc=desc,
+    prob = dict(last_xw=xw, last_desc=l_desc, last_octave=l_oct, last_angle=l_ang,
+                last_mp_has_obs=np.ones(len(xw), np.uint8), cur_kps_un=kps, cur_u_right=cur["ur"], cur_desc=desc,
                 cur_has_mp_obs=np.zeros(len(kps), np.uint8), Tcw_q=qcl.astype(np.float32), Tcw_t=Tcl[:3, 3].astype(np.float32),
                 Tlw_q=np.array([0, 0, 0, 1], np.float32), Tlw_t=np.zeros(3, np.float32), fx=f32(fx), fy=f32(fy), cx=f32(cx), cy=f32(cy), bf=f32(BF),
                 b=f32(BF / fx), min_x=f32(0), max_x=f32(W), min_y=f32(0), max_y=f32(H), grid_w_inv=f32(64) / f32(W), grid_h_inv=f32(48) / f32(H),

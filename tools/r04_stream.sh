@@ -1,5 +1,5 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-python tools/stream_overhead.py 2>&1 | tail -12
+python tools/stream_overhead.py 2>&1 | head -8
 python - <<'P'
 import sys; sys.path.insert(0,'.')
 import numpy as np
