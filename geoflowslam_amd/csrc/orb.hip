@@ -1564,7 +1564,7 @@ struct gfs_orb {
   gfs::DevBuf<LevelDev> d_levels;
   gfs::DevBuf<CellDev> d_cells;
   gfs::DevBuf<BlurTileDev> d_tiles;
-  gfs::DevBuf<int> d_strip_rows, d_xt_start, d_xt_n, d_yt_start, d_yt_n, d_cell_cnt, d_cand_off, d_kp_count, d_mono;
+  gfs::DevBuf<int> d_strip_rows, d_strip_rows_fine, d_xt_start, d_xt_n, d_yt_start, d_yt_n, d_cell_cnt, d_cand_off, d_kp_count, d_mono;
   gfs::DevBuf<float> d_xt_alpha, d_yt_alpha;
   gfs::DevBuf<uint32_t> d_slab, d_cand, d_perm0, d_perm1, d_kept;
   gfs::DevBuf<unsigned short> d_seg0, d_seg1;
@@ -1610,6 +1610,8 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
   GFS_HIP(hipMemcpyAsync(h->d_cells.p, G.cells.data(), G.cells.size() * sizeof(CellDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_tiles.p, G.blur_tiles.data(), G.blur_tiles.size() * sizeof(BlurTileDev), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_strip_rows.p, G.strip_rows.data(), G.strip_rows.size() * 4, hipMemcpyHostToDevice, s));
+  if (G.pyr_strips_fine > 0)
+    GFS_HIP(hipMemcpyAsync(h->d_strip_rows_fine.p, G.strip_rows_fine.data(), G.strip_rows_fine.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_xt_start.p, G.xt_start.data(), G.xt_start.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_xt_n.p, G.xt_n.data(), G.xt_n.size() * 4, hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_xt_alpha.p, G.xt_alpha.data(), G.xt_alpha.size() * 4, hipMemcpyHostToDevice, s));
@@ -1650,8 +1652,12 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   // 1. pyramid chain (level l depends on l-1): one launch, row strips with recomputed halos
   static const bool pyr_in_hbm = getenv("GFS_ORB_PYR_HBM") != nullptr;  // test knob: take the large-image path on any image
   if (G.pyr_lds_a + G.pyr_lds_b > 0 && !pyr_in_hbm) {
-    GFS_LAUNCH("k_pyr_area", (k_pyr_area<true>), dim3(G.pyr_strips, B), dim3(kPyrThreads), G.pyr_lds_a + G.pyr_lds_b, s, h->d_levels.p,
-               nl, l0, h->d_pyr.p, cap_pyr, h->d_strip_rows.p, (unsigned)G.pyr_lds_a, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p,
+    // a few frames: the finer cut, so that the launch has workgroups for the chip (a frame's strips are dependent chains of levels)
+    const bool fine = G.pyr_strips_fine > 0 && B * G.pyr_strips < 128;
+    const int S = fine ? G.pyr_strips_fine : G.pyr_strips;
+    const size_t la = fine ? G.pyr_lds_a_fine : G.pyr_lds_a, lb = fine ? G.pyr_lds_b_fine : G.pyr_lds_b;
+    GFS_LAUNCH("k_pyr_area", (k_pyr_area<true>), dim3(S, B), dim3(kPyrThreads), la + lb, s, h->d_levels.p, nl, l0, h->d_pyr.p, cap_pyr,
+               fine ? h->d_strip_rows_fine.p : h->d_strip_rows.p, (unsigned)la, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p,
                h->d_yt_start.p, h->d_yt_n.p, h->d_yt_alpha.p);
   } else {
     GFS_LAUNCH("k_pyr_area", (k_pyr_area<false>), dim3(G.pyr_strips, B), dim3(kPyrThreads), 0, s, h->d_levels.p, nl, l0, h->d_pyr.p,
@@ -1835,6 +1841,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   A(h->d_cells.alloc(h->cap_cells));
   A(h->d_tiles.alloc(G.blur_tiles.size() + 64));
   A(h->d_strip_rows.alloc((size_t)2 * gfs::OrbGeometry::kPyrMaxStrips * 16));
+  A(h->d_strip_rows_fine.alloc((size_t)2 * gfs::OrbGeometry::kPyrMaxStrips * 16));
   GFS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_area<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   GFS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(kOctMaxNodes)));
   A(h->d_xt_start.alloc(tab_x));

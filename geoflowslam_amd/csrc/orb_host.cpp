@@ -204,8 +204,9 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
   // without any inter-workgroup dependency it also computes, at every lower level, the rows its higher levels read
   // (INTER_AREA footprints from the y tables).  Neighbouring strips recompute a few identical halo rows.  S is the smallest
   // candidate whose level-0 and level-1 strips (the two LDS ping-pong buffers) fit the CU's LDS.
-  pyr_strips = 0;
-  pyr_lds_a = pyr_lds_b = 0;
+  pyr_strips = pyr_strips_fine = 0;
+  pyr_lds_a = pyr_lds_b = pyr_lds_a_fine = pyr_lds_b_fine = 0;
+  strip_rows_fine.clear();
   const int nl = p.nlevels;
   if (nl >= 2) {
     const int cand[] = {8, 12, 16, 24, 32, 48, 64};
@@ -239,13 +240,21 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
       }
       la = (la + 15) / 16 * 16;
       lb = (lb + 15) / 16 * 16;
-      if (la + lb <= 150 * 1024 || S == 64) {
-        strip_rows = tab;
-        pyr_strips = S;
-        if (la + lb <= 150 * 1024) {
-          pyr_lds_a = la;
-          pyr_lds_b = lb;
+      if (pyr_strips == 0) {
+        if (la + lb <= 150 * 1024 || S == 64) {
+          strip_rows = tab;
+          pyr_strips = S;
+          if (la + lb <= 150 * 1024) {
+            pyr_lds_a = la;
+            pyr_lds_b = lb;
+          }
+          if (pyr_lds_a + pyr_lds_b == 0) break;  // (the strips do not fit the LDS at all: the HBM path has one cut)
         }
+      } else if (S >= 4 * pyr_strips || S == 64) {
+        strip_rows_fine = tab;
+        pyr_strips_fine = S;
+        pyr_lds_a_fine = la;
+        pyr_lds_b_fine = lb;
         break;
       }
     }

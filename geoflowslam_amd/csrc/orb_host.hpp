@@ -64,6 +64,12 @@ struct OrbGeometry {
   std::vector<int> strip_rows;
   int pyr_strips = 0;
   size_t pyr_lds_a = 0, pyr_lds_b = 0;
+  // the same for a finer cut (about four times the strips): what a launch of a few frames uses -- with one frame the eight
+  // workgroups of the coarse cut each walk all levels of a tall strip one after the other on an otherwise idle chip.  Same rows, same
+  // arithmetic; the halo rows are recomputed by more workgroups.  pyr_strips_fine = 0: none (the coarse cut is already the finest).
+  std::vector<int> strip_rows_fine;
+  int pyr_strips_fine = 0;
+  size_t pyr_lds_a_fine = 0, pyr_lds_b_fine = 0;
   static constexpr int kPyrMaxStrips = 64;
   size_t pyr_bytes = 0, blur_bytes = 0;  // per frame
   size_t slab_entries = 0;               // per frame
