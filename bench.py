@@ -728,6 +728,13 @@ def main():
             gbe = bs.GpuBackend(api, W, H, NF, NL, SP, device=local_rank)
             lat_g, st_g, states_g = bs.run_stream(gbe, frames_s, Kc, W, H, STRIDE, 120, warm=6)
             ss = bs.summarize(lat_g, st_g)
+            # the same chain with the ORB extraction running BESIDE depth -> cloud -> GICP (they do not depend on each other): what a
+            # Tracking::GrabImageRGBD written for the device would do; same calls, same results, reported beside the sequential figure
+            lat_v, st_v, states_v = bs.run_stream(gbe, frames_s, Kc, W, H, STRIDE, 120, warm=6, overlap=True)
+            ov = bs.summarize(lat_v, st_v)
+            ov["same_results_as_sequential"] = bool(all(a_["matches"] == b_["matches"] and a_["inliers"] == b_["inliers"] and np.array_equal(a_["T"], b_["T"])
+                                                        and np.array_equal(a_["match"], b_["match"]) for a_, b_ in zip(states_g[-40:], states_v[-40:])))
+            ss["orb_beside_registration"] = ov
             ss.update(metric="single-stream front-end latency per frame (B = 1, sequential): ORB + the RGB-D tail of the Frame constructor (stereo-from-RGBD + depth->cloud: "
                              "gfs_frame_rgbd, the cloud stays on the device) + GICP (streaming entry) + SearchByProjection + PoseOptimization, host pointers in, "
                              "results out, every copy and sync included",

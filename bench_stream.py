@@ -49,6 +49,9 @@ class GpuBackend:
         t = self.ext.tables()
         self.scale, self.inv_sigma2 = np.asarray(t["scale"], np.float32), np.asarray(t["inv_sigma2"], np.float32)
         self.have_target = False
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(1)
+        self.no_kps = np.zeros(0, self.ext(np.zeros((H, W), np.uint8))[1].dtype)
 
     def orb(self, gray):
         _, k, d = self.ext(gray)
@@ -59,6 +62,18 @@ class GpuBackend:
         # (a host copy only until the registration has its first target)
         ur, zd, cloud, dev = self.frm.FrameRGBD(kps, depth, BF, ds, *K, host_cloud=not self.have_target)
         return ur, zd, (cloud if cloud is not None else dev)
+
+    def front_overlapped(self, gray, depth, ds, K):
+        """ORB extraction BESIDE depth -> cloud -> registration: the two do not depend on each other (the registration needs the
+        depth map only), so the extractor runs on a worker thread with its own handle and stream while this thread uploads the
+        depth map, builds the cloud and registers it; the stereo coordinates follow when the key-points are there, from the depth
+        map still on the device.  Same calls, same results as the sequential chain -- only the order on the time line differs."""
+        fut = self.pool.submit(self.orb, gray)
+        _, _, _, dev = self.frm.FrameRGBD(self.no_kps, depth, BF, ds, *K, host_cloud=False)
+        T = self.reg.align_next_batch_device(dev[0], dev[1], 1, dev[2])[0]["T"]
+        kps, desc = fut.result()
+        ur, zd, _, _ = self.frm.FrameRGBD(kps, None, BF, 0, *K, host_cloud=False, shape=depth.shape)
+        return kps, desc, ur, zd, dev, T
 
     def gicp(self, prev_cloud, cloud):
         if not self.have_target:  # first pair of the stream: both clouds; afterwards only the new one is preprocessed
@@ -107,19 +122,26 @@ class OracleBackend:
         return self.O.pose_optimization(prob)
 
 
-def track_frame(be, last, gray, depth, K, W, H, ds, stages):
-    """One frame through the chain.  `last` = the previous frame's state (None for the first frame).  Returns the new state."""
+def track_frame(be, last, gray, depth, K, W, H, ds, stages, overlap=False):
+    """One frame through the chain.  `last` = the previous frame's state (None for the first frame).  Returns the new state.
+    overlap: the extractor runs beside cloud + registration (GpuBackend.front_overlapped) once the registration has a target."""
     fx, fy, cx, cy = K
     t = time.perf_counter()
-    kps, desc = be.orb(gray)
-    t = _lap(stages, "orb", t)
-    ur, zd, cloud = be.frame_rgbd(kps, depth, ds, K)
-    t = _lap(stages, "frame_rgbd", t)
-    cur = dict(kps=kps, desc=desc, ur=np.asarray(ur, np.float32), z=np.asarray(zd, np.float32), cloud=cloud, matches=0, inliers=0, T=np.eye(4))
-    if last is None:
-        return cur
-    T = np.asarray(be.gicp(last["cloud"], cloud), np.float64).reshape(4, 4)  # x_last = T x_cur
-    t = _lap(stages, "gicp", t)
+    if overlap and last is not None and getattr(be, "have_target", False):
+        kps, desc, ur, zd, cloud, T = be.front_overlapped(gray, depth, ds, K)
+        T = np.asarray(T, np.float64).reshape(4, 4)
+        t = _lap(stages, "orb_beside_cloud_and_gicp", t)
+        cur = dict(kps=kps, desc=desc, ur=np.asarray(ur, np.float32), z=np.asarray(zd, np.float32), cloud=cloud, matches=0, inliers=0, T=np.eye(4))
+    else:
+        kps, desc = be.orb(gray)
+        t = _lap(stages, "orb", t)
+        ur, zd, cloud = be.frame_rgbd(kps, depth, ds, K)
+        t = _lap(stages, "frame_rgbd", t)
+        cur = dict(kps=kps, desc=desc, ur=np.asarray(ur, np.float32), z=np.asarray(zd, np.float32), cloud=cloud, matches=0, inliers=0, T=np.eye(4))
+        if last is None:
+            return cur
+        T = np.asarray(be.gicp(last["cloud"], cloud), np.float64).reshape(4, 4)  # x_last = T x_cur
+        t = _lap(stages, "gicp", t)
     Tcl = np.linalg.inv(T)  # the current camera's pose with the last camera as the world
     qcl = _quat_from_R(Tcl[:3, :3])
     # the last frame's map points: its key points with a depth, unprojected (Frame::UnprojectStereo), world = last camera
@@ -159,7 +181,7 @@ def _lap(stages, name, t0):
     return t1
 
 
-def run_stream(be, frames, K, W, H, ds, n_frames, warm=3):
+def run_stream(be, frames, K, W, H, ds, n_frames, warm=3, overlap=False):
     """frames: list of (gray, depth); the stream walks it back and forth.  Returns (per-frame seconds, per-stage seconds, states)."""
     seq = list(range(len(frames))) + list(range(len(frames) - 2, 0, -1)) if len(frames) > 2 else [0, 1]
     last, lat, stages, states = None, [], {}, []
@@ -167,7 +189,7 @@ def run_stream(be, frames, K, W, H, ds, n_frames, warm=3):
         gray, depth = frames[seq[i % len(seq)]]
         st = {}
         t0 = time.perf_counter()
-        last = track_frame(be, last, gray, depth, K, W, H, ds, st)
+        last = track_frame(be, last, gray, depth, K, W, H, ds, st, overlap)
         dt = time.perf_counter() - t0
         if i > warm:  # frame 0 has no predecessor; the next `warm` frames load code objects and ramp the clocks
             lat.append(dt)

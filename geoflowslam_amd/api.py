@@ -1067,17 +1067,22 @@ class Frame:
                                           bf, _p(ur), _p(vd)), "gfs_stereo_from_rgbd")
         return ur[:n], vd[:n]
 
-    def FrameRGBD(self, kps, depth, bf, downSample, fx, fy, cx, cy, kps_un_x=None, host_cloud=True):
+    def FrameRGBD(self, kps, depth, bf, downSample, fx, fy, cx, cy, kps_un_x=None, host_cloud=True, shape=None):
         """The RGB-D tail of the Frame constructor (ComputeStereoFromRGBD + ConvertDepthToPointCloud, src/Frame.cc:1314-1332,
-        590-623) in one call: gfs_frame_rgbd.  Returns (mvuRight, mvDepth, cloud or None, (dev_cloud, dev_count, stride, n))."""
-        depth = np.ascontiguousarray(depth, np.float32)
+        590-623) in one call: gfs_frame_rgbd.  Returns (mvuRight, mvDepth, cloud or None, (dev_cloud, dev_count, stride, n)).
+        depth=None (with shape=(rows, cols)): the depth map of the previous call, still on the device; downSample=0: no cloud."""
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.float32)
+            rows, cols = depth.shape
+        else:
+            rows, cols = shape
         kps = np.ascontiguousarray(kps)
         n = len(kps)
-        rows, cols = depth.shape
         ur = np.empty(max(n, 1), np.float32)
         vd = np.empty(max(n, 1), np.float32)
         unx = np.ascontiguousarray(kps_un_x, np.float32) if kps_un_x is not None else None
-        out = np.empty((rows * cols // (downSample * downSample) + rows + cols, 4), np.float32) if host_cloud else None
+        want_cloud = host_cloud and downSample > 0
+        out = np.empty((rows * cols // (downSample * downSample) + rows + cols, 4), np.float32) if want_cloud else None
         nc, stride = C.c_int(), C.c_int()
         dc, dn = C.c_void_p(), C.c_void_p()
         _check(lib().gfs_frame_rgbd(self.h, _p(kps), _p(unx), n, _p(depth), rows, cols, cols, bf, downSample, fx, fy, cx, cy, _p(ur),

@@ -100,6 +100,7 @@ struct gfs_frame {
   gfs::DevBuf<float4> d_cloud;
   gfs::DevBuf<gfs_keypoint> d_kps;
   gfs::DevBuf<int> d_n;
+  int res_rows = 0, res_cols = 0;  // size of the depth map resident in d_depth (gfs_frame_rgbd)
 };
 
 extern "C" {
@@ -165,6 +166,7 @@ int gfs_depth_convert_u16_batch_device(gfs_frame* h, const void* dev_depth_u16, 
 
 int gfs_depth_to_cloud(gfs_frame* h, const float* depth, int rows, int cols, int stride_elems, int downsample, float fx,
                        float fy, float cx, float cy, float* out_xyzw, int cap, int* n) {
+  if (h) h->res_rows = h->res_cols = 0;  // (d_depth is about to be overwritten or left stale)
   GFS_REQUIRE(h && n, GFS_ERR_INVALID_ARG, "gfs_depth_to_cloud: NULL argument");
   *n = 0;
   if (!depth || rows <= 0 || cols <= 0) return GFS_OK;  // "Depth image is empty": the reference returns without points
@@ -206,6 +208,7 @@ int gfs_stereo_from_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps
                          int cols, int stride_elems, float bf, float* u_right, float* depth_out) {
   GFS_REQUIRE(h && n >= 0, GFS_ERR_INVALID_ARG, "gfs_stereo_from_rgbd: invalid argument");
   if (n == 0) return GFS_OK;
+  h->res_rows = h->res_cols = 0;
   GFS_REQUIRE(kps && depth && u_right && depth_out && rows > 0 && cols > 0 && stride_elems >= cols && rows <= h->max_rows &&
                   cols <= h->max_cols && n <= h->max_kp,
               GFS_ERR_INVALID_ARG, "gfs_stereo_from_rgbd: invalid argument or capacity");
@@ -235,14 +238,23 @@ int gfs_frame_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x,
                    float* depth_out, float* out_xyzw, int cap, int* n_cloud, void** dev_cloud, void** dev_count, int* cloud_stride) {
   GFS_REQUIRE(h && n >= 0 && n_cloud, GFS_ERR_INVALID_ARG, "gfs_frame_rgbd: invalid argument");
   *n_cloud = 0;
-  GFS_REQUIRE(depth && rows > 0 && cols > 0 && downsample > 0 && stride_elems >= cols && rows <= h->max_rows && cols <= h->max_cols &&
+  // depth == NULL: the depth map of the previous call on this handle (same rows x cols) is still on the device -- a caller that
+  // overlaps the ORB extraction with the registration asks for the cloud first and for the stereo coordinates once the key-points
+  // exist; downsample <= 0: no cloud in this call.
+  GFS_REQUIRE(rows > 0 && cols > 0 && (depth == nullptr || stride_elems >= cols) && rows <= h->max_rows && cols <= h->max_cols &&
                   n <= h->max_kp && (n == 0 || (kps && u_right && depth_out)),
               GFS_ERR_INVALID_ARG, "gfs_frame_rgbd: invalid argument or capacity");
   std::lock_guard<std::mutex> lk(h->mu);
+  GFS_REQUIRE(depth != nullptr || (h->res_rows == rows && h->res_cols == cols), GFS_ERR_INVALID_ARG,
+              "gfs_frame_rgbd: no resident %dx%d depth map on this handle", cols, rows);
   GFS_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  GFS_HIP(hipMemcpy2DAsync(h->d_depth.p, (size_t)cols * 4, depth, (size_t)stride_elems * 4, (size_t)cols * 4, rows,
-                           hipMemcpyHostToDevice, s));
+  if (depth) {
+    GFS_HIP(hipMemcpy2DAsync(h->d_depth.p, (size_t)cols * 4, depth, (size_t)stride_elems * 4, (size_t)cols * 4, rows,
+                             hipMemcpyHostToDevice, s));
+    h->res_rows = rows;
+    h->res_cols = cols;
+  }
   if (n) {
     GFS_HIP(hipMemcpyAsync(h->d_kps.p, kps, (size_t)n * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
     if (kps_un_x) GFS_HIP(hipMemcpyAsync(h->d_unx.p, kps_un_x, (size_t)n * 4, hipMemcpyHostToDevice, s));
@@ -254,11 +266,13 @@ int gfs_frame_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x,
     GFS_HIP(hipMemcpyAsync(depth_out, h->d_vd.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   }
   const int maxpts = (int)h->d_cloud.n;
-  const int rc = gfs_depth_to_cloud_batch_device(h, h->d_depth.p, 1, rows, cols, downsample, fx, fy, cx, cy, h->d_cloud.p, maxpts,
-                                                 h->d_n.p, s);
-  if (rc) return rc;
   int cnt = 0;
-  GFS_HIP(hipMemcpyAsync(&cnt, h->d_n.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (downsample > 0) {
+    const int rc = gfs_depth_to_cloud_batch_device(h, h->d_depth.p, 1, rows, cols, downsample, fx, fy, cx, cy, h->d_cloud.p, maxpts,
+                                                   h->d_n.p, s);
+    if (rc) return rc;
+    GFS_HIP(hipMemcpyAsync(&cnt, h->d_n.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
   GFS_HIP(hipStreamSynchronize(s));
   *n_cloud = cnt;
   if (dev_cloud) *dev_cloud = h->d_cloud.p;

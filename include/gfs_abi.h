@@ -328,7 +328,10 @@ int gfs_stereo_from_rgbd_batch_device(gfs_frame* h, const void* dev_kps, const v
 /* The RGB-D tail of the Frame constructor in one call: ComputeStereoFromRGBD(imDepth) (src/Frame.cc:1314-1332) followed by
  * ConvertDepthToPointCloud (:590-623).  The depth map is uploaded once and the cloud stays on the device: *dev_cloud /
  * *dev_count / *cloud_stride are the arguments gfs_gicp_align_batch_device / gfs_gicp_align_next_batch_device take (valid until
- * the next call on this handle).  out_xyzw may be NULL (no host copy of the cloud); *n_cloud receives the point count. */
+ * the next call on this handle).  out_xyzw may be NULL (no host copy of the cloud); *n_cloud receives the point count.
+ * depth == NULL: use the depth map the previous gfs_frame_rgbd call on this handle uploaded (same rows x cols); downsample <= 0:
+ * no cloud in this call.  Together: the cloud first (n = 0), the registration, and the stereo coordinates when the key-points of
+ * an ORB extraction that ran beside the registration have arrived -- one depth upload either way. */
 int gfs_frame_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x, int n, const float* depth, int rows, int cols,
                    int stride_elems, float bf, int downsample, float fx, float fy, float cx, float cy, float* u_right,
                    float* depth_out, float* out_xyzw, int cap, int* n_cloud, void** dev_cloud, void** dev_count, int* cloud_stride);

@@ -103,11 +103,18 @@ def test_gpu_frame_rgbd_is_the_two_calls_and_feeds_the_registration(gpu_api, ora
         assert cloud.shape == co.shape and np.array_equal(cloud.view(np.uint32), co.view(np.uint32)) and dev[3] == len(co)
         ur2, vd2, none, dev2 = fr.FrameRGBD(kps, fp[key_d], bf, 4, fx, fy, cx, cy, host_cloud=False)
         assert none is None and dev2[3] == len(co) and np.array_equal(ur2.view(np.uint32), uo.view(np.uint32))
+        # the cloud first (no key-points yet), the stereo coordinates later from the depth map still on the device: what a caller does
+        # that runs the ORB extraction beside the registration (bench_stream.GpuBackend.front_overlapped)
+        e0, e1, none, dev3 = fr.FrameRGBD(kps[:0], fp[key_d], bf, 4, fx, fy, cx, cy, host_cloud=False)
+        assert len(e0) == 0 and dev3[3] == len(co)
+        ur3, vd3, none, dev4 = fr.FrameRGBD(kps, None, bf, 0, fx, fy, cx, cy, host_cloud=False, shape=fp[key_d].shape)
+        assert np.array_equal(ur3.view(np.uint32), uo.view(np.uint32)) and np.array_equal(vd3.view(np.uint32), vo.view(np.uint32)) and dev4[3] == 0
+        dev2 = dev3
         clouds.append((co, dev2))
     # frame 0 against itself seeds both handles; then frame 1 once through the device-resident cloud, once through host pointers
     reg_a.RegisterPointClouds(clouds[0][0], clouds[0][0])
     reg_b.RegisterPointClouds(clouds[0][0], clouds[0][0])
-    d_cloud, d_n, stride, _ = clouds[1][1]
+    d_cloud, d_n, stride, _ = clouds[1][1]  # (the stereo-only call after it left the cloud and its count where they were)
     ra = reg_a.align_next_batch_device(d_cloud, d_n, 1, stride)[0]
     rb = reg_b.RegisterNext(clouds[1][0])
     assert np.array_equal(ra["T"], rb["T"]) and ra["iterations"] == rb["iterations"] and ra["num_inliers"] == rb["num_inliers"]
