@@ -64,65 +64,298 @@ __device__ __forceinline__ const uint8_t* level_ptr(const LevelDev& L, int level
 // One launch for the whole chain: workgroup (k, b) produces, level after level, a horizontal strip of every level of
 // frame b (OrbGeometry::strip_rows: its share of the level plus the halo rows its own higher levels read), so a level
 // only ever reads rows the same workgroup produced.  Neighbouring strips recompute a few identical halo rows instead of
-// synchronising.  The strips live in LDS (two ping-pong buffers: level 0 strip staged with word loads, every level is
-// computed LDS -> LDS and streamed out to HBM once): the 16 byte taps per pixel are LDS reads, not 16 global byte loads
-// (the per-level kernel was bound by the texture-address rate of those loads: 0.32 ms / 64 VGA frames, this one 0.1x ms).
-// LDS = false: same schedule through HBM (a level re-reads the rows its own workgroup wrote: workgroup-scope fence +
-// barrier; an agent-scope fence would write back the XCD's L2 at every level, measured 4x slower) for images whose
-// strips do not fit the LDS.
-constexpr int kPyrThreads = 1024;
-template <bool LDS>
-__global__ __launch_bounds__(kPyrThreads) void k_pyr_area(const LevelDev* __restrict__ levels, int nlevels, Lvl0 l0,
-                                                          uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                          const int* __restrict__ strip_rows, unsigned lds_a,
-                                                          const int* __restrict__ xt_start, const int* __restrict__ xt_n,
-                                                          const float* __restrict__ xt_alpha, const int* __restrict__ yt_start,
-                                                          const int* __restrict__ yt_n, const float* __restrict__ yt_alpha) {
+// synchronising.
+//
+// k_pyr_area_lds: the strips live in LDS (two ping-pong buffers, rows of kPyrLdsPitch(cols) bytes: level 0 strip staged with
+// word loads, every level is computed LDS -> LDS and streamed out to HBM once).  A WAVE walks down a chunk of <= 128 columns,
+// lane <-> two neighbouring columns (their taps -- start, count, weights from the host-built tables -- in registers), the
+// rows one after the other:
+//  * the horizontal sum of a source row is the same number for every destination row that reads it (OpenCV recomputes `buf`
+//    per (dy, sy) entry of its y table from the same bytes), and at scale factors < 2 consecutive destination rows share their
+//    boundary source row: kept from one row to the next, ~1.2 horizontal sums per pixel instead of the 3 a thread per pixel
+//    spends;
+//  * the two columns of a lane go through v_pk_mul_f32 / v_pk_add_f32 (IEEE per component, no FMA: the same bits), and out
+//    as one 16-bit store;
+//  * a row's taps are wave-uniform: read from an LDS copy of the y tables (all levels of the strip, staged once beside the
+//    level-0 rows) into scalar registers, the tap count is a scalar branch; word-aligned LDS rows make a lane's byte shift a
+//    constant of the run, so a source row costs one address add per column;
+//  * the (chunk, row) units of a level are cut into sixteen contiguous runs, chunk-major, one per wave.
+// What it replaced (round 4, clock64 per level under -DGFS_PYR_TIMING): thread <-> pixel with 3 x 4 taps each, ~57 VALU
+// instructions a pixel, VALU-bound at one workgroup a CU, plus ~7 k cycles a level of table loads and set-up in front of the
+// first pixel: 1.17 ms per 512 VGA frames.
+//
+// k_pyr_area_hbm: same strips through HBM, thread <-> pixel (a level re-reads the rows its own workgroup wrote:
+// workgroup-scope fence + barrier; an agent-scope fence would write back the XCD's L2 at every level, measured 4x slower) for
+// images whose strips do not fit the LDS.
+constexpr int kPyrThreads = 1024, kPyrWaves = kPyrThreads / 64;
+constexpr int kPyrTabRows = gfs::OrbGeometry::kPyrTabRows, kPyrProgRows = gfs::OrbGeometry::kPyrProgRows;
+typedef float pyr_f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(kPyrThreads) void k_pyr_area_lds(const LevelDev* __restrict__ levels, int nlevels, Lvl0 l0,
+                                                              uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                              const int* __restrict__ strip_rows, unsigned lds_a,
+                                                              unsigned lds_x, int xt_total,
+                                                              const int* __restrict__ xt_start, const int* __restrict__ xt_n,
+                                                              const float* __restrict__ xt_alpha, const int* __restrict__ yt_start,
+                                                              const int* __restrict__ yt_n, const float* __restrict__ yt_alpha) {
   extern __shared__ __align__(16) uint8_t smem[];
+  // The y tables of the strip as a program over SOURCE rows (all levels, one entry per source row a level reads): the weight
+  // it carries into the destination row that is open there, the weight into the row that OPENS there when it is the boundary
+  // row of two (else 0), whether the open row ends there, whether a row opens there.  Built once from the tables in memory;
+  // s_first: the source row a destination row starts on (where a wave's run begins).
+  __shared__ float4 s_prog[kPyrProgRows + 1];
+  __shared__ int s_first[kPyrTabRows];
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int* rng = strip_rows + 2 * k * nlevels;
-  if (LDS) {  // stage the level-0 rows level 1 reads
+#ifdef GFS_PYR_TIMING
+  __shared__ long long pyr_t[12];
+  __shared__ int pyr_w[3][16];
+  { const long long _n = clock64(); if (tid == 0) pyr_t[0] = _n; }
+#endif
+  for (int i = tid; i < kPyrProgRows + 1; i += kPyrThreads) s_prog[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  {
+    int off = 0, pb = 0;  // first destination row / first program entry of the level
+    for (int level = 1; level < nlevels; level++) {
+      const int r0 = rng[2 * level], n = rng[2 * level + 1] - r0, yo = levels[level].ytab_off;
+      const int srow0 = rng[2 * (level - 1)];
+      const int i = tid - off;
+      if (i >= 0 && i < n) {  // one thread a destination row
+        const int d = r0 + i, sy0 = yt_start[yo + d], ny = yt_n[yo + d];
+        const float4 ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)(yo + d));
+        const float ays[4] = {ay.x, ay.y, ay.z, ay.w};
+        const int prev_last = d > 0 ? yt_start[yo + d - 1] + yt_n[yo + d - 1] - 1 : -1;
+        s_first[off + i] = sy0;
+        float* pr = reinterpret_cast<float*>(s_prog + pb + (sy0 - srow0));
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < ny) {
+            if (j == 0 && sy0 == prev_last) {  // the boundary row of d - 1 and d
+              pr[1] = ays[0];
+              pr[3] = __int_as_float(1);
+            } else {
+              pr[4 * j] = ays[j];
+            }
+            if (j == ny - 1) pr[4 * j + 2] = __int_as_float(1);
+          }
+      }
+      off += n;
+      pb += rng[2 * (level - 1) + 1] - srow0;
+    }
+  }
+  // the column taps of every level >= 1 (lds_x = their offset behind the two strip buffers; 0 = they stay in memory: a column
+  // somewhere has a fourth tap, or they do not fit): a run's taps are then two LDS reads instead of a round trip to the L2 in
+  // front of its first row (~1 500 cycles, twice for a wave whose run crosses a chunk boundary while the other waves wait)
+  float4* s_xt = reinterpret_cast<float4*>(smem + lds_x);
+  if (lds_x)
+    for (int i = tid; i < xt_total; i += kPyrThreads) {
+      const float4 a = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)i);
+      s_xt[i] = make_float4(a.x, a.y, a.z, __int_as_float(xt_start[i]));
+    }
+  {  // the level-0 rows level 1 reads
     const LevelDev S0 = levels[0];
-    int sp;
-    const uint8_t* src = level_ptr(S0, 0, b, l0, pyr, pyr_frame, &sp);
-    const int s0 = rng[0], s1 = rng[1], cols = S0.cols;
-    if (((cols | sp) & 3) == 0 && ((uintptr_t)src & 3) == 0) {
+    int gp;
+    const uint8_t* src = level_ptr(S0, 0, b, l0, pyr, pyr_frame, &gp);
+    const int s0 = rng[0], s1 = rng[1], cols = S0.cols, sp = gfs::OrbGeometry::kPyrLdsPitch(cols);
+    if (((cols | gp) & 15) == 0 && ((uintptr_t)src & 15) == 0) {
+      const int qpr = cols >> 4, total = (s1 - s0) * qpr;
+      for (int i = tid; i < total; i += kPyrThreads) {
+        const int y = i / qpr, x = i - y * qpr;
+        reinterpret_cast<uint4*>(smem)[i] = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + y) * gp + 16 * x);
+      }
+    } else if (((cols | gp) & 3) == 0 && ((uintptr_t)src & 3) == 0) {
       const int wpr = cols >> 2, total = (s1 - s0) * wpr;
       for (int i = tid; i < total; i += kPyrThreads) {
         const int y = i / wpr, x = i - y * wpr;
-        reinterpret_cast<uint32_t*>(smem)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(s0 + y) * sp + 4 * x);
+        reinterpret_cast<uint32_t*>(smem)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(s0 + y) * gp + 4 * x);
       }
     } else {
       const int total = (s1 - s0) * cols;
       for (int i = tid; i < total; i += kPyrThreads) {
         const int y = i / cols, x = i - y * cols;
-        smem[i] = src[(size_t)(s0 + y) * sp + x];
+        smem[y * sp + x] = src[(size_t)(s0 + y) * gp + x];
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
+#ifdef GFS_PYR_TIMING
+  { const long long _n = clock64(); if (tid == 0) pyr_t[8] = _n; }
+#endif
+  int tab0 = 0, pb = 0;  // first destination row / first program entry of the level
+  for (int level = 1; level < nlevels; level++) {
+#ifdef GFS_PYR_TIMING
+    long long ft0 = clock64(), ft1 = 0, ft2 = 0, ft3 = 0;
+#endif
+    const LevelDev L = levels[level];
+    const int scols = levels[level - 1].cols;
+    const int r0 = rng[2 * level], nrow = rng[2 * level + 1] - r0, srow0 = rng[2 * (level - 1)], nsrc = rng[2 * (level - 1) + 1] - srow0;
+    // source rows [srow0, ...) of level - 1 sit in the buffer of that level's parity, the rows produced here go to the other one
+    const int sp = gfs::OrbGeometry::kPyrLdsPitch(scols), kp = gfs::OrbGeometry::kPyrLdsPitch(L.cols);
+    const unsigned src_off = (level - 1) & 1 ? lds_a : 0u, keep_off = level & 1 ? lds_a : 0u;
+    const bool has_keep = level + 1 < nlevels;
+    uint8_t* dst = pyr + (size_t)b * pyr_frame + L.plane_off;
+    const bool dst_even = (((uintptr_t)dst | (unsigned)L.pitch) & 1) == 0;
+    const int nchunk = (L.cols + 127) >> 7, cw = (((L.cols + nchunk - 1) / nchunk) + 1) & ~1;  // columns of a chunk: even, <= 128
+    const int units = nchunk * nrow;
+    const int u1 = (int)((long long)(wave + 1) * units / kPyrWaves);
+    int u = (int)((long long)wave * units / kPyrWaves);
+#ifdef GFS_PYR_TIMING
+    asm volatile("" ::"s"(u), "s"(u1));
+    ft1 = clock64();
+#endif
+    while (u < u1) {
+      const int chunk = u / nrow, row_a = u - chunk * nrow, row_b = min(nrow, row_a + (u1 - u));
+      const int dx0 = chunk * cw + 2 * lane;
+      const bool on0 = 2 * lane < cw && dx0 < L.cols, on1 = on0 && dx0 + 1 < L.cols;
+      const int xa = L.xtab_off + min(dx0, L.cols - 1), xb = L.xtab_off + min(dx0 + 1, L.cols - 1);
+      int sxa, sxb;
+      float4 axa, axb;
+      bool x4 = false;  // a fourth tap only exists for scale factors above 2
+      if (lds_x) {
+        axa = s_xt[xa];
+        axb = s_xt[xb];
+        sxa = __float_as_int(axa.w);
+        sxb = __float_as_int(axb.w);
+      } else {
+        sxa = xt_start[xa];
+        sxb = xt_start[xb];
+        x4 = __ballot(xt_n[xa] > 3 || xt_n[xb] > 3) != 0ull;
+        axa = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)xa);
+        axb = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)xb);
+      }
+      const pyr_f2 a0 = {axa.x, axb.x}, a1 = {axa.y, axb.y}, a2 = {axa.z, axb.z}, a3 = {axa.w, axb.w};
+      // the aligned word a column's first byte lies in (+ the next one) and the shift that brings its four bytes down
+      const uint32_t* wa = reinterpret_cast<const uint32_t*>(smem + src_off + (sxa & ~3));
+      const uint32_t* wb = reinterpret_cast<const uint32_t*>(smem + src_off + (sxb & ~3));
+      const int sha = (sxa & 3) * 8, shb = (sxb & 3) * 8, spw = sp >> 2;
+      uint8_t* drow = dst + (size_t)(r0 + row_a) * L.pitch + dx0;
+      uint8_t* krow = smem + keep_off + (size_t)row_a * kp + dx0;
+#ifdef GFS_PYR_TIMING
+      asm volatile("" ::"v"(a0), "v"(a2), "v"(sha), "v"(shb));
+      if (ft2 == 0) ft2 = clock64();
+#endif
+      auto walk = [&](auto X4) {
+        constexpr bool kX4 = decltype(X4)::value;
+        // The run is a stream of SOURCE rows: every one is read once (its words and its program entry fetched an iteration
+        // ahead), its horizontal sums go with the entry's weight into the open destination row (0 + p = p, x + 0 = x: all terms
+        // are >= +0, so a sum that starts at +0 and source rows with weight 0 leave OpenCV's bits alone); when the row ends
+        // there it is rounded and stored and the next one starts with the boundary weight (or +0).
+        auto words = [&](int si, uint32_t(&w)[4]) {  // si: source row relative to the strip
+          const int o = si * spw;
+          w[0] = wa[o];
+          w[1] = wa[o + 1];
+          w[2] = wb[o];
+          w[3] = wb[o + 1];
+        };
+        // buf[dx] of a source row for the lane's two columns: b0 a0 + b1 a1 + ... in table order (weights beyond a column's
+        // taps are 0 in the tables and the bytes under them finite)
+        auto hsum = [&](const uint32_t(&w)[4]) {
+          const uint32_t va = __builtin_amdgcn_alignbit(w[1], w[0], sha), vb = __builtin_amdgcn_alignbit(w[3], w[2], shb);
+          const pyr_f2 c0 = {(float)(va & 0xffu), (float)(vb & 0xffu)}, c1 = {(float)((va >> 8) & 0xffu), (float)((vb >> 8) & 0xffu)},
+                       c2 = {(float)((va >> 16) & 0xffu), (float)((vb >> 16) & 0xffu)};
+          pyr_f2 buf = c0 * a0;
+          buf = buf + c1 * a1;
+          buf = buf + c2 * a2;
+          if constexpr (kX4) {
+            const pyr_f2 c3 = {(float)(va >> 24), (float)(vb >> 24)};
+            buf = buf + c3 * a3;
+          }
+          return buf;
+        };
+        auto emit = [&](pyr_f2 sum) {
+          const int ra = __float2int_rn(sum.x), rb = __float2int_rn(sum.y);  // cvRound: round-half-even
+          const unsigned v = (unsigned)min(max(ra, 0), 255) | ((unsigned)min(max(rb, 0), 255) << 8);
+          if (on0) {
+            if (on1 && dst_even) {
+              *reinterpret_cast<uint16_t*>(drow) = (uint16_t)v;
+            } else {
+              drow[0] = (uint8_t)v;
+              if (on1) drow[1] = (uint8_t)(v >> 8);
+            }
+            if (has_keep) *reinterpret_cast<uint16_t*>(krow) = (uint16_t)v;  // (kp is a multiple of 4, dx0 even: aligned; an odd
+                                                                             //  level's last column writes one pad byte)
+          }
+          drow += L.pitch;
+          krow += kp;
+        };
+        int si = __builtin_amdgcn_readfirstlane(s_first[tab0 + row_a]) - srow0, left = row_b - row_a;
+        uint32_t w[4];
+        words(si, w);
+        float4 P = s_prog[pb + si];
+        pyr_f2 sum;
+        {  // the first source row: the run's first row opens there (behind the row before it) or is the open one
+          const pyr_f2 h = hsum(w);
+          words(min(si + 1, nsrc - 1), w);
+          const float4 Pn = s_prog[pb + si + 1];
+          const bool opens = __builtin_amdgcn_readfirstlane(__float_as_int(P.w)) != 0;
+          sum = h * (opens ? P.y : P.x);
+          if (!opens && __builtin_amdgcn_readfirstlane(__float_as_int(P.z)) != 0) {  // (a row of one tap)
+            emit(sum);
+            sum = h * P.y;
+            left--;
+          }
+          P = Pn;
+          si++;
+        }
+        while (left > 0) {
+          const pyr_f2 h = hsum(w);
+          words(min(si + 1, nsrc - 1), w);
+          const float4 Pn = s_prog[pb + si + 1];
+          sum = sum + h * P.x;
+          if (__builtin_amdgcn_readfirstlane(__float_as_int(P.z)) != 0) {
+            emit(sum);
+            sum = h * P.y;
+            left--;
+          }
+          P = Pn;
+          si++;
+        }
+      };
+      if (x4) walk(std::true_type{});
+      else walk(std::false_type{});
+      u += row_b - row_a;
+    }
+    pb += nsrc;
+    tab0 += nrow;
+#ifdef GFS_PYR_TIMING
+    ft3 = clock64();
+    if (lane == 0) { pyr_w[0][wave] = (int)(ft2 - ft0); pyr_w[1][wave] = (int)(ft3 - ft2); pyr_w[2][wave] = (int)(ft3 - ft0); }
+#endif
+    __syncthreads();
+#ifdef GFS_PYR_TIMING
+    { const long long _n = clock64(); if (tid == 0) pyr_t[level] = _n;
+      if (tid == 0 && b == 7 && k == 0 && (level == 1 || level == 4 || level == 7))
+        { printf("PYRF l=%d meta=%lld xtap=%lld walk=%lld bar=%lld units=%d nchunk=%d\n", level, ft1 - ft0, ft2 - ft1, ft3 - ft2, _n - ft3, units, nchunk);
+          if (level == 1) for (int q = 0; q < 16; q++) printf("PYRW w=%d pre=%d walk=%d end=%d\n", q, pyr_w[0][q], pyr_w[1][q], pyr_w[2][q]); } }
+#endif
+  }
+#ifdef GFS_PYR_TIMING
+  if (tid == 0 && b == 7 && (k == 0 || k == 3))
+    printf("PYRT k=%d stage=%lld l1=%lld l2=%lld l3=%lld l4=%lld l5=%lld l6=%lld l7=%lld total=%lld\n", k, pyr_t[8] - pyr_t[0],
+           pyr_t[1] - pyr_t[8], pyr_t[2] - pyr_t[1], pyr_t[3] - pyr_t[2], pyr_t[4] - pyr_t[3], pyr_t[5] - pyr_t[4], pyr_t[6] - pyr_t[5],
+           pyr_t[7] - pyr_t[6], pyr_t[7] - pyr_t[0]);
+#endif
+}
+
+__global__ __launch_bounds__(kPyrThreads) void k_pyr_area_hbm(const LevelDev* __restrict__ levels, int nlevels, Lvl0 l0,
+                                                              uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                              const int* __restrict__ strip_rows,
+                                                              const int* __restrict__ xt_start, const int* __restrict__ xt_n,
+                                                              const float* __restrict__ xt_alpha, const int* __restrict__ yt_start,
+                                                              const int* __restrict__ yt_n, const float* __restrict__ yt_alpha) {
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int* rng = strip_rows + 2 * k * nlevels;
   for (int level = 1; level < nlevels; level++) {
     const LevelDev L = levels[level];
     const LevelDev S = levels[level - 1];
     const int r0 = rng[2 * level], r1 = rng[2 * level + 1];
     int sp;
-    const uint8_t* src;
-    uint8_t* keep = nullptr;  // LDS copy of the rows produced here (the next level's source)
-    if (LDS) {
-      // source rows [rng[2 (level-1)], ...) of level-1 sit in the buffer of that level's parity, pitch = its column count
-      const uint8_t* sbuf = smem + ((level - 1) & 1 ? lds_a : 0u);
-      sp = S.cols;
-      src = sbuf - (size_t)rng[2 * (level - 1)] * sp;
-      if (level + 1 < nlevels) keep = smem + (level & 1 ? lds_a : 0u);
-    } else {
-      src = level_ptr(S, level - 1, b, l0, pyr, pyr_frame, &sp);
-    }
+    const uint8_t* src = level_ptr(S, level - 1, b, l0, pyr, pyr_frame, &sp);
     uint8_t* dst = pyr + (size_t)b * pyr_frame + L.plane_off;
-    // thread <-> (column, row phase): the column's taps (start, count, four weights) stay in registers down the strip, the
-    // row's taps are the same for (nearly) every lane of a wave; per pixel that leaves the source bytes and the arithmetic
-    // (ncolt columns x rows_par row phases <= 1024 threads, a thread walks q = ceil(cols / ncolt) columns: with one column a
-    // thread, a 533-column level — level 1 of a VGA frame, a third of all pixels — kept 491 of the 1024 threads idle; q is chosen
-    // for the most pixels per sweep of the workgroup)
+    // thread <-> (column, row phase): the column's taps (start, count, four weights) stay in registers down the strip
+    // (ncolt columns x rows_par row phases <= 1024 threads, a thread walks q = ceil(cols / ncolt) columns; q is chosen for the
+    // most pixels per sweep of the workgroup)
     int ncolt = min(L.cols, kPyrThreads), rows_par = kPyrThreads / ncolt;
     {
       int best = rows_par * L.cols;  // q = 1
@@ -147,51 +380,24 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area(const LevelDev* __rest
           const float4 ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)yi);
           const float ays[4] = {ay.x, ay.y, ay.z, ay.w};
           float sum = 0.f;
-          if constexpr (LDS) {
-            // Branch-free: the weights beyond a pixel's nx / ny taps are 0 in the tables, every term is >= 0, so the extra
-            // products add +0.0 and the sum is OpenCV's bit for bit; the extra bytes are read from the LDS strip (or beyond it:
-            // whatever comes back is a finite byte).  One wait for all reads of a pixel instead of one per tap behind its own
-            // branch.  The fourth tap / row only exists for scale factors above 2: skipped when no lane of the wave has one.
-            const bool any_x4 = __ballot(nx > 3) != 0ull, any_y4 = __ballot(ny > 3) != 0ull;
-            // (the four bytes of a row are cut out of two ALIGNED words: left to itself the compiler fuses the byte reads into
-            // 16-bit reads at odd addresses, and the kernel ran 1.8x slower)
-            const int off0 = (int)((src + (size_t)sy0 * sp + sx0) - smem);
-            const uint32_t* smem32 = reinterpret_cast<const uint32_t*>(smem);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (j < 3 || any_y4) {
-                const int o = off0 + j * sp;
-                const uint32_t v = __builtin_amdgcn_alignbit(smem32[(o >> 2) + 1], smem32[o >> 2], (o & 3) * 8);
-                float buf = __fadd_rn(0.f, __fmul_rn((float)(v & 0xffu), ax.x));
-                buf = __fadd_rn(buf, __fmul_rn((float)((v >> 8) & 0xffu), ax.y));
-                buf = __fadd_rn(buf, __fmul_rn((float)((v >> 16) & 0xffu), ax.z));
-                if (any_x4) buf = __fadd_rn(buf, __fmul_rn((float)(v >> 24), ax.w));
-                const float t = __fmul_rn(ays[j], buf);
-                sum = (j == 0) ? t : __fadd_rn(sum, t);
-              }
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (j < ny) {
-                const uint8_t* row = src + (size_t)(sy0 + j) * sp + sx0;
-                float buf = __fadd_rn(0.f, __fmul_rn((float)row[0], ax.x));
-                if (nx > 1) buf = __fadd_rn(buf, __fmul_rn((float)row[1], ax.y));
-                if (nx > 2) buf = __fadd_rn(buf, __fmul_rn((float)row[2], ax.z));
-                if (nx > 3) buf = __fadd_rn(buf, __fmul_rn((float)row[3], ax.w));
-                const float t = __fmul_rn(ays[j], buf);
-                sum = (j == 0) ? t : __fadd_rn(sum, t);
-              }
+          for (int j = 0; j < 4; j++) {
+            if (j < ny) {
+              const uint8_t* row = src + (size_t)(sy0 + j) * sp + sx0;
+              float buf = __fadd_rn(0.f, __fmul_rn((float)row[0], ax.x));
+              if (nx > 1) buf = __fadd_rn(buf, __fmul_rn((float)row[1], ax.y));
+              if (nx > 2) buf = __fadd_rn(buf, __fmul_rn((float)row[2], ax.z));
+              if (nx > 3) buf = __fadd_rn(buf, __fmul_rn((float)row[3], ax.w));
+              const float t = __fmul_rn(ays[j], buf);
+              sum = (j == 0) ? t : __fadd_rn(sum, t);
             }
           }
           const int r = __float2int_rn(sum);  // cvRound: round-half-even
-          const uint8_t v = (uint8_t)min(max(r, 0), 255);
-          dst[(size_t)dy * L.pitch + dx] = v;
-          if (LDS && keep) keep[(dy - r0) * L.cols + dx] = v;
+          dst[(size_t)dy * L.pitch + dx] = (uint8_t)min(max(r, 0), 255);
         }
       }
     }
-    if (!LDS) __threadfence_block();
+    __threadfence_block();
     __syncthreads();
   }
 }
@@ -1656,12 +1862,14 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
     const bool fine = G.pyr_strips_fine > 0 && B * G.pyr_strips < 128;
     const int S = fine ? G.pyr_strips_fine : G.pyr_strips;
     const size_t la = fine ? G.pyr_lds_a_fine : G.pyr_lds_a, lb = fine ? G.pyr_lds_b_fine : G.pyr_lds_b;
-    GFS_LAUNCH("k_pyr_area", (k_pyr_area<true>), dim3(S, B), dim3(kPyrThreads), la + lb, s, h->d_levels.p, nl, l0, h->d_pyr.p, cap_pyr,
-               fine ? h->d_strip_rows_fine.p : h->d_strip_rows.p, (unsigned)la, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p,
+    const size_t lx = fine ? G.pyr_lds_x_fine : G.pyr_lds_x;
+    GFS_LAUNCH("k_pyr_area_lds", k_pyr_area_lds, dim3(S, B), dim3(kPyrThreads), la + lb + lx, s, h->d_levels.p, nl, l0, h->d_pyr.p, cap_pyr,
+               fine ? h->d_strip_rows_fine.p : h->d_strip_rows.p, (unsigned)la, lx ? (unsigned)(la + lb) : 0u, (int)G.xt_start.size(),
+               h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p,
                h->d_yt_start.p, h->d_yt_n.p, h->d_yt_alpha.p);
   } else {
-    GFS_LAUNCH("k_pyr_area", (k_pyr_area<false>), dim3(G.pyr_strips, B), dim3(kPyrThreads), 0, s, h->d_levels.p, nl, l0, h->d_pyr.p,
-               cap_pyr, h->d_strip_rows.p, 0u, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p, h->d_yt_start.p, h->d_yt_n.p,
+    GFS_LAUNCH("k_pyr_area_hbm", k_pyr_area_hbm, dim3(G.pyr_strips, B), dim3(kPyrThreads), 0, s, h->d_levels.p, nl, l0, h->d_pyr.p,
+               cap_pyr, h->d_strip_rows.p, h->d_xt_start.p, h->d_xt_n.p, h->d_xt_alpha.p, h->d_yt_start.p, h->d_yt_n.p,
                h->d_yt_alpha.p);
   }
   // 2. FAST cells of all levels, all frames in one launch
@@ -1842,7 +2050,8 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   A(h->d_tiles.alloc(G.blur_tiles.size() + 64));
   A(h->d_strip_rows.alloc((size_t)2 * gfs::OrbGeometry::kPyrMaxStrips * 16));
   A(h->d_strip_rows_fine.alloc((size_t)2 * gfs::OrbGeometry::kPyrMaxStrips * 16));
-  GFS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_area<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  GFS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_area_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)gfs::OrbGeometry::kPyrLdsBudget));
   GFS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(kOctMaxNodes)));
   A(h->d_xt_start.alloc(tab_x));
   A(h->d_xt_n.alloc(tab_x));

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 namespace gfs {
@@ -205,16 +206,24 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
   // (INTER_AREA footprints from the y tables).  Neighbouring strips recompute a few identical halo rows.  S is the smallest
   // candidate whose level-0 and level-1 strips (the two LDS ping-pong buffers) fit the CU's LDS.
   pyr_strips = pyr_strips_fine = 0;
-  pyr_lds_a = pyr_lds_b = pyr_lds_a_fine = pyr_lds_b_fine = 0;
+  pyr_lds_a = pyr_lds_b = pyr_lds_a_fine = pyr_lds_b_fine = pyr_lds_x = pyr_lds_x_fine = 0;
+  strip_rows.clear();
   strip_rows_fine.clear();
   const int nl = p.nlevels;
   if (nl >= 2) {
-    const int cand[] = {8, 12, 16, 24, 32, 48, 64};
-    for (int S : cand) {
-      std::vector<int> tab((size_t)2 * S * nl, 0);
+    struct Cut {
+      int S = 0;
+      std::vector<int> tab;
       size_t la = 0, lb = 0;
+      int tab_rows = 0;   // most rows of levels >= 1 one strip produces
+      int prog_rows = 0;  // most rows of levels < nl - 1 one strip reads
+    };
+    auto cut = [&](int S) {
+      Cut c;
+      c.S = S;
+      c.tab.assign((size_t)2 * S * nl, 0);
       for (int k = 0; k < S; k++) {
-        int a = 0, b = 0;
+        int a = 0, b = 0, rows = 0, srows = 0;
         for (int l = nl - 1; l >= 0; l--) {
           const int R = levels[l].rows;
           int oa = l >= 1 ? (int)((long long)k * R / S) : 0, ob = l >= 1 ? (int)((long long)(k + 1) * R / S) : 0;
@@ -231,32 +240,69 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
           }
           a = oa;
           b = ob;
-          tab[2 * ((size_t)k * nl + l)] = a;
-          tab[2 * ((size_t)k * nl + l) + 1] = b;
-          const size_t bytes = (size_t)(b - a) * levels[l].cols;
-          if (l % 2 == 0) la = std::max(la, bytes);
-          else lb = std::max(lb, bytes);
+          c.tab[2 * ((size_t)k * nl + l)] = a;
+          c.tab[2 * ((size_t)k * nl + l) + 1] = b;
+          const size_t bytes = (size_t)(b - a) * kPyrLdsPitch(levels[l].cols);
+          if (l % 2 == 0) c.la = std::max(c.la, bytes);
+          else c.lb = std::max(c.lb, bytes);
+          if (l >= 1) rows += b - a;
+          if (l < nl - 1) srows += b - a;
+        }
+        c.tab_rows = std::max(c.tab_rows, rows);
+        c.prog_rows = std::max(c.prog_rows, srows);
+      }
+      c.la = (c.la + 15) / 16 * 16;
+      c.lb = (c.lb + 15) / 16 * 16;
+      return c;
+    };
+    const int cand[] = {8, 12, 16, 24, 32, 48, 64};
+    size_t budget = kPyrLdsBudget;
+    if (const char* e = getenv("GFS_ORB_PYR_LDS_KB")) budget = (size_t)std::max(8, atoi(e)) * 1024;  // tuning knob
+    size_t xbytes = 16 * xt_start.size();
+    for (int n : xt_n)
+      if (n > 3) xbytes = 0;
+    if (getenv("GFS_ORB_PYR_XTAB_HBM")) xbytes = 0;  // test knob: the x tables stay in memory
+    std::vector<Cut> cuts;
+    for (int S : cand) cuts.push_back(cut(S));
+    // k_pyr_area_lds streams the source rows of a run once, in order: consecutive rows of a level may share their boundary
+    // source row, no more (true of INTER_AREA tables at scale factors >= 1; checked, not assumed)
+    bool streamable = true;
+    for (int l = 1; l < nl && streamable; l++)
+      for (int r = 0; r + 1 < levels[l].rows; r++) {
+        const int i = levels[l].ytab_off + r, last = yt_start[i] + yt_n[i] - 1;
+        if (yt_start[i + 1] < last || (yt_start[i + 1] == last && yt_n[i + 1] == 1)) {  // (two rows may not end on one source row)
+          streamable = false;
+          break;
         }
       }
-      la = (la + 15) / 16 * 16;
-      lb = (lb + 15) / 16 * 16;
-      if (pyr_strips == 0) {
-        if (la + lb <= 150 * 1024 || S == 64) {
-          strip_rows = tab;
-          pyr_strips = S;
-          if (la + lb <= 150 * 1024) {
-            pyr_lds_a = la;
-            pyr_lds_b = lb;
-          }
-          if (pyr_lds_a + pyr_lds_b == 0) break;  // (the strips do not fit the LDS at all: the HBM path has one cut)
-        }
-      } else if (S >= 4 * pyr_strips || S == 64) {
-        strip_rows_fine = tab;
-        pyr_strips_fine = S;
-        pyr_lds_a_fine = la;
-        pyr_lds_b_fine = lb;
+    int pick = -1;
+    for (size_t extra : {xbytes, (size_t)0}) {
+      for (size_t i = 0; i < cuts.size() && pick < 0 && streamable; i++)
+        if (cuts[i].la + cuts[i].lb + extra <= budget && cuts[i].tab_rows <= kPyrTabRows &&
+            cuts[i].prog_rows <= kPyrProgRows)
+          pick = (int)i;
+      if (pick >= 0) {
+        pyr_lds_x = extra;
         break;
       }
+    }
+    if (pick < 0) {  // the strips do not fit the LDS at all: the HBM path, finest cut
+      strip_rows = cuts.back().tab;
+      pyr_strips = cuts.back().S;
+    } else {
+      strip_rows = cuts[pick].tab;
+      pyr_strips = cuts[pick].S;
+      pyr_lds_a = cuts[pick].la;
+      pyr_lds_b = cuts[pick].lb;
+      for (size_t i = pick + 1; i < cuts.size(); i++)
+        if (cuts[i].S >= 4 * pyr_strips || i + 1 == cuts.size()) {
+          strip_rows_fine = cuts[i].tab;
+          pyr_strips_fine = cuts[i].S;
+          pyr_lds_a_fine = cuts[i].la;
+          pyr_lds_b_fine = cuts[i].lb;
+          pyr_lds_x_fine = cuts[i].la + cuts[i].lb + xbytes <= budget ? xbytes : 0;
+          break;
+        }
     }
   }
 }

@@ -60,7 +60,15 @@ struct OrbGeometry {
   std::vector<float> xt_alpha, yt_alpha;
   // fused pyramid kernel: rows [strip_rows[2*(k*nlevels+l)], strip_rows[2*(k*nlevels+l)+1]) of level l held by strip k: for
   // l >= 1 the rows it computes (its own share of the level plus the halo its higher levels read), for l = 0 the source rows
-  // level 1 reads.  pyr_lds_a / pyr_lds_b: bytes of the two LDS ping-pong buffers (even / odd levels); 0 = does not fit.
+  // level 1 reads.  pyr_lds_a / pyr_lds_b: bytes of the two LDS ping-pong buffers (even / odd levels; rows of kPyrLdsPitch(cols)
+  // bytes); 0 = does not fit.  pyr_lds_x: bytes of the x tables of all levels kept in LDS behind them (16 bytes a column: three
+  // weights + the first source column; only when no column has a fourth tap), 0 = read from memory.  A cut only counts as
+  // fitting when the rows a strip produces over all levels >= 1 also fit the kernel's table of row taps (kPyrTabRows).  The
+  // cut is the coarsest one that fits with the x tables, else the coarsest that fits without.
+  static constexpr int kPyrTabRows = 384, kPyrProgRows = 512;  // destination rows / source rows of a strip over all levels
+  static constexpr size_t kPyrLdsBudget = 150 * 1024;
+  static constexpr int kPyrLdsPitch(int cols) { return (cols + 3) & ~3; }
+  size_t pyr_lds_x = 0, pyr_lds_x_fine = 0;
   std::vector<int> strip_rows;
   int pyr_strips = 0;
   size_t pyr_lds_a = 0, pyr_lds_b = 0;
