@@ -110,65 +110,97 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area_lds(const LevelDev* __
   const int* rng = strip_rows + 2 * k * nlevels;
 #ifdef GFS_PYR_TIMING
   __shared__ long long pyr_t[12];
-  __shared__ int pyr_w[3][16];
   { const long long _n = clock64(); if (tid == 0) pyr_t[0] = _n; }
 #endif
+  // Staging: every load is asked for before the first one is waited for (four in flight per thread and table; one round trip
+  // per loop iteration made this part 17 k cycles of a workgroup's 87 k).
   for (int i = tid; i < kPyrProgRows + 1; i += kPyrThreads) s_prog[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
+  // (1) the y-table row of this thread (one thread a destination row of the strip, all levels), kept in registers for now
+  bool my_row = false;
+  int my_first = 0, my_ny = 0, my_prev_last = -1, my_slot = 0, my_prog = 0;
+  float4 my_ay = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     int off = 0, pb = 0;  // first destination row / first program entry of the level
     for (int level = 1; level < nlevels; level++) {
       const int r0 = rng[2 * level], n = rng[2 * level + 1] - r0, yo = levels[level].ytab_off;
       const int srow0 = rng[2 * (level - 1)];
       const int i = tid - off;
-      if (i >= 0 && i < n) {  // one thread a destination row
-        const int d = r0 + i, sy0 = yt_start[yo + d], ny = yt_n[yo + d];
-        const float4 ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)(yo + d));
-        const float ays[4] = {ay.x, ay.y, ay.z, ay.w};
-        const int prev_last = d > 0 ? yt_start[yo + d - 1] + yt_n[yo + d - 1] - 1 : -1;
-        s_first[off + i] = sy0;
-        float* pr = reinterpret_cast<float*>(s_prog + pb + (sy0 - srow0));
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (j < ny) {
-            if (j == 0 && sy0 == prev_last) {  // the boundary row of d - 1 and d
-              pr[1] = ays[0];
-              pr[3] = __int_as_float(1);
-            } else {
-              pr[4 * j] = ays[j];
-            }
-            if (j == ny - 1) pr[4 * j + 2] = __int_as_float(1);
-          }
+      if (i >= 0 && i < n) {
+        const int d = r0 + i;
+        my_row = true;
+        my_first = yt_start[yo + d];
+        my_ny = yt_n[yo + d];
+        my_ay = *reinterpret_cast<const float4*>(yt_alpha + 4 * (size_t)(yo + d));
+        if (d > 0) my_prev_last = yt_start[yo + d - 1] + yt_n[yo + d - 1] - 1;
+        my_slot = off + i;
+        my_prog = pb - srow0;
       }
       off += n;
       pb += rng[2 * (level - 1) + 1] - srow0;
     }
   }
-  // the column taps of every level >= 1 (lds_x = their offset behind the two strip buffers; 0 = they stay in memory: a column
-  // somewhere has a fourth tap, or they do not fit): a run's taps are then two LDS reads instead of a round trip to the L2 in
-  // front of its first row (~1 500 cycles, twice for a wave whose run crosses a chunk boundary while the other waves wait)
+  // (2) the column taps of every level >= 1 (lds_x = their offset behind the two strip buffers; 0 = they stay in memory: a
+  // column somewhere has a fourth tap, or they do not fit): a run's taps are then two LDS reads instead of a round trip to the
+  // L2 in front of its first row (~1 500 cycles, twice for a wave whose run crosses a chunk boundary while the others wait)
   float4* s_xt = reinterpret_cast<float4*>(smem + lds_x);
   if (lds_x)
-    for (int i = tid; i < xt_total; i += kPyrThreads) {
-      const float4 a = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)i);
-      s_xt[i] = make_float4(a.x, a.y, a.z, __int_as_float(xt_start[i]));
+    for (int i0 = tid; i0 < xt_total; i0 += 4 * kPyrThreads) {
+      float4 a[4];
+      int st[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = i0 + q * kPyrThreads;
+        if (i < xt_total) {
+          a[q] = *reinterpret_cast<const float4*>(xt_alpha + 4 * (size_t)i);
+          st[q] = xt_start[i];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = i0 + q * kPyrThreads;
+        if (i < xt_total) s_xt[i] = make_float4(a[q].x, a[q].y, a[q].z, __int_as_float(st[q]));
+      }
     }
-  {  // the level-0 rows level 1 reads
+  {  // (3) the level-0 rows level 1 reads
     const LevelDev S0 = levels[0];
     int gp;
     const uint8_t* src = level_ptr(S0, 0, b, l0, pyr, pyr_frame, &gp);
     const int s0 = rng[0], s1 = rng[1], cols = S0.cols, sp = gfs::OrbGeometry::kPyrLdsPitch(cols);
     if (((cols | gp) & 15) == 0 && ((uintptr_t)src & 15) == 0) {
       const int qpr = cols >> 4, total = (s1 - s0) * qpr;
-      for (int i = tid; i < total; i += kPyrThreads) {
-        const int y = i / qpr, x = i - y * qpr;
-        reinterpret_cast<uint4*>(smem)[i] = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + y) * gp + 16 * x);
+      for (int i0 = tid; i0 < total; i0 += 4 * kPyrThreads) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int i = i0 + q * kPyrThreads;
+          if (i < total) {
+            const int y = i / qpr, x = i - y * qpr;
+            v[q] = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + y) * gp + 16 * x);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int i = i0 + q * kPyrThreads;
+          if (i < total) reinterpret_cast<uint4*>(smem)[i] = v[q];
+        }
       }
     } else if (((cols | gp) & 3) == 0 && ((uintptr_t)src & 3) == 0) {
       const int wpr = cols >> 2, total = (s1 - s0) * wpr;
-      for (int i = tid; i < total; i += kPyrThreads) {
-        const int y = i / wpr, x = i - y * wpr;
-        reinterpret_cast<uint32_t*>(smem)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(s0 + y) * gp + 4 * x);
+      for (int i0 = tid; i0 < total; i0 += 4 * kPyrThreads) {
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int i = i0 + q * kPyrThreads;
+          if (i < total) {
+            const int y = i / wpr, x = i - y * wpr;
+            v[q] = *reinterpret_cast<const uint32_t*>(src + (size_t)(s0 + y) * gp + 4 * x);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int i = i0 + q * kPyrThreads;
+          if (i < total) reinterpret_cast<uint32_t*>(smem)[i] = v[q];
+        }
       }
     } else {
       const int total = (s1 - s0) * cols;
@@ -178,15 +210,29 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area_lds(const LevelDev* __
       }
     }
   }
+  __syncthreads();  // (the program is zeroed)
+  if (my_row) {     // (4) the thread's row into the program
+    const float ays[4] = {my_ay.x, my_ay.y, my_ay.z, my_ay.w};
+    s_first[my_slot] = my_first;
+    float* pr = reinterpret_cast<float*>(s_prog + my_prog + my_first);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (j < my_ny) {
+        if (j == 0 && my_first == my_prev_last) {  // the boundary row of d - 1 and d
+          pr[1] = ays[0];
+          pr[3] = __int_as_float(1);
+        } else {
+          pr[4 * j] = ays[j];
+        }
+        if (j == my_ny - 1) pr[4 * j + 2] = __int_as_float(1);
+      }
+  }
   __syncthreads();
 #ifdef GFS_PYR_TIMING
   { const long long _n = clock64(); if (tid == 0) pyr_t[8] = _n; }
 #endif
   int tab0 = 0, pb = 0;  // first destination row / first program entry of the level
   for (int level = 1; level < nlevels; level++) {
-#ifdef GFS_PYR_TIMING
-    long long ft0 = clock64(), ft1 = 0, ft2 = 0, ft3 = 0;
-#endif
     const LevelDev L = levels[level];
     const int scols = levels[level - 1].cols;
     const int r0 = rng[2 * level], nrow = rng[2 * level + 1] - r0, srow0 = rng[2 * (level - 1)], nsrc = rng[2 * (level - 1) + 1] - srow0;
@@ -200,10 +246,6 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area_lds(const LevelDev* __
     const int units = nchunk * nrow;
     const int u1 = (int)((long long)(wave + 1) * units / kPyrWaves);
     int u = (int)((long long)wave * units / kPyrWaves);
-#ifdef GFS_PYR_TIMING
-    asm volatile("" ::"s"(u), "s"(u1));
-    ft1 = clock64();
-#endif
     while (u < u1) {
       const int chunk = u / nrow, row_a = u - chunk * nrow, row_b = min(nrow, row_a + (u1 - u));
       const int dx0 = chunk * cw + 2 * lane;
@@ -231,10 +273,6 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area_lds(const LevelDev* __
       const int sha = (sxa & 3) * 8, shb = (sxb & 3) * 8, spw = sp >> 2;
       uint8_t* drow = dst + (size_t)(r0 + row_a) * L.pitch + dx0;
       uint8_t* krow = smem + keep_off + (size_t)row_a * kp + dx0;
-#ifdef GFS_PYR_TIMING
-      asm volatile("" ::"v"(a0), "v"(a2), "v"(sha), "v"(shb));
-      if (ft2 == 0) ft2 = clock64();
-#endif
       auto walk = [&](auto X4) {
         constexpr bool kX4 = decltype(X4)::value;
         // The run is a stream of SOURCE rows: every one is read once (its words and its program entry fetched an iteration
@@ -264,8 +302,9 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area_lds(const LevelDev* __
           return buf;
         };
         auto emit = [&](pyr_f2 sum) {
-          const int ra = __float2int_rn(sum.x), rb = __float2int_rn(sum.y);  // cvRound: round-half-even
-          const unsigned v = (unsigned)min(max(ra, 0), 255) | ((unsigned)min(max(rb, 0), 255) << 8);
+          // saturate_cast<uchar>(cvRound(sum)): v_cvt_pk_u8_f32 rounds half to even and clamps to 0..255 (checked against
+          // __float2int_rn + clamp over 16.7 M values with every tie and its neighbours: tools/probes/cvt_pk_u8_probe.hip)
+          const unsigned v = __builtin_amdgcn_cvt_pk_u8_f32(sum.y, 1u, __builtin_amdgcn_cvt_pk_u8_f32(sum.x, 0u, 0u));
           if (on0) {
             if (on1 && dst_even) {
               *reinterpret_cast<uint16_t*>(drow) = (uint16_t)v;
@@ -318,16 +357,9 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area_lds(const LevelDev* __
     }
     pb += nsrc;
     tab0 += nrow;
-#ifdef GFS_PYR_TIMING
-    ft3 = clock64();
-    if (lane == 0) { pyr_w[0][wave] = (int)(ft2 - ft0); pyr_w[1][wave] = (int)(ft3 - ft2); pyr_w[2][wave] = (int)(ft3 - ft0); }
-#endif
     __syncthreads();
 #ifdef GFS_PYR_TIMING
-    { const long long _n = clock64(); if (tid == 0) pyr_t[level] = _n;
-      if (tid == 0 && b == 7 && k == 0 && (level == 1 || level == 4 || level == 7))
-        { printf("PYRF l=%d meta=%lld xtap=%lld walk=%lld bar=%lld units=%d nchunk=%d\n", level, ft1 - ft0, ft2 - ft1, ft3 - ft2, _n - ft3, units, nchunk);
-          if (level == 1) for (int q = 0; q < 16; q++) printf("PYRW w=%d pre=%d walk=%d end=%d\n", q, pyr_w[0][q], pyr_w[1][q], pyr_w[2][q]); } }
+    { const long long _n = clock64(); if (tid == 0) pyr_t[level] = _n; }
 #endif
   }
 #ifdef GFS_PYR_TIMING
@@ -1778,6 +1810,7 @@ struct gfs_orb {
   int oct_node_cap = kOctMaxNodes;
   bool cands_packed = false;  // d_cand / d_cand_off hold the last call's dense candidate list
   bool device_octree = true;   // DistributeOctTree on the GPU (k_octree); false = host quadtree (GFS_ORB_OCTREE=host)
+  bool pyr_in_hbm = false;     // test knob GFS_ORB_PYR_HBM: take the large-image pyramid path on any image
   bool octree_supported = true;
   bool host_counts_valid = false, host_cands_valid = false;
   gfs::DevBuf<KpIn> d_kpin;
@@ -1856,8 +1889,7 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
   const int n_cells = (int)G.cells.size();
   const size_t cap_pyr = h->cap_pyr, cap_blur = h->cap_blur, cap_slab = h->cap_slab;
   // 1. pyramid chain (level l depends on l-1): one launch, row strips with recomputed halos
-  static const bool pyr_in_hbm = getenv("GFS_ORB_PYR_HBM") != nullptr;  // test knob: take the large-image path on any image
-  if (G.pyr_lds_a + G.pyr_lds_b > 0 && !pyr_in_hbm) {
+  if (G.pyr_lds_a + G.pyr_lds_b > 0 && !h->pyr_in_hbm) {
     // a few frames: the finer cut, so that the launch has workgroups for the chip (a frame's strips are dependent chains of levels)
     const bool fine = G.pyr_strips_fine > 0 && B * G.pyr_strips < 128;
     const int S = fine ? G.pyr_strips_fine : G.pyr_strips;
@@ -2096,6 +2128,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   if (const char* e = getenv("GFS_ORB_HOST_THREADS")) h->host_threads = std::max(1, atoi(e));
   h->pool.reset(new WorkerPool(h->host_threads));
   if (const char* e = getenv("GFS_ORB_OCTREE")) h->device_octree = strcmp(e, "host") != 0;
+  h->pyr_in_hbm = getenv("GFS_ORB_PYR_HBM") != nullptr;
   *out = h.release();
   return GFS_OK;
 }

@@ -255,7 +255,7 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
       c.lb = (c.lb + 15) / 16 * 16;
       return c;
     };
-    const int cand[] = {8, 12, 16, 24, 32, 48, 64};
+    const int cand[] = {4, 5, 6, 7, 8, 10, 12, 16, 24, 32, 48, 64};
     size_t budget = kPyrLdsBudget;
     if (const char* e = getenv("GFS_ORB_PYR_LDS_KB")) budget = (size_t)std::max(8, atoi(e)) * 1024;  // tuning knob
     size_t xbytes = 16 * xt_start.size();

@@ -142,3 +142,26 @@ def test_host_octree_path_still_matches(gpu_api, oracle, monkeypatch):
     ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7)
     orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
     _compare_full(ext, orc, synth.noise_image(3, 640, 480))
+
+
+@pytest.mark.parametrize("knob", [None, "GFS_ORB_PYR_XTAB_HBM", "GFS_ORB_PYR_HBM", ("GFS_ORB_PYR_LDS_KB", "60"), ("GFS_ORB_PYR_LDS_KB", "24")])
+def test_pyramid_kernel_paths_give_the_same_frames(gpu_api, oracle, knob, monkeypatch):
+    """k_pyr_area_lds with its x tables in LDS (default) / in memory, finer strip cuts, and k_pyr_area_hbm: one result.
+    The knobs are read when the extractor is created."""
+    if knob is not None:
+        name, value = knob if isinstance(knob, tuple) else (knob, "1")
+        monkeypatch.setenv(name, value)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    for w, h, seed in ((640, 480, 3), (577, 411, 4), (322, 242, 5)):
+        ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=h, max_cols=w)
+        _compare_full(ext, orc, synth.noise_image(seed, w, h))
+
+
+@pytest.mark.parametrize("scale,levels", [(1.1, 8), (1.3, 6), (1.5, 5), (1.9, 4), (2.5, 3)])
+def test_pyramid_scale_factors(gpu_api, oracle, scale, levels):
+    """INTER_AREA tables of other scale factors: two to four taps a pixel (above 2 a fourth tap: the x tables stay in memory).
+    (Integer factors take another cv::resize path and are refused by gfs_orb_create.)"""
+    orc = oracle.OrbOracle(800, scale, levels, 20, 7)
+    for w, h, seed in ((640, 480, 6), (801, 603, 7)):
+        ext = gpu_api.ORBextractor(800, scale, levels, 20, 7, max_rows=h, max_cols=w)
+        _compare_full(ext, orc, synth.noise_image(seed, w, h))
