@@ -275,16 +275,20 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
           break;
         }
       }
-    int pick = -1;
-    for (size_t extra : {xbytes, (size_t)0}) {
-      for (size_t i = 0; i < cuts.size() && pick < 0 && streamable; i++)
-        if (cuts[i].la + cuts[i].lb + extra <= budget && cuts[i].tab_rows <= kPyrTabRows &&
-            cuts[i].prog_rows <= kPyrProgRows)
-          pick = (int)i;
-      if (pick >= 0) {
-        pyr_lds_x = extra;
-        break;
-      }
+    // the coarsest cut that fits without the x tables, and with them; the tables only go to LDS when that does not cost much
+    // finer strips (every strip recomputes its halo at every level: a 720p frame fits as 16 strips without them, as 48 with
+    // them, and ran 184 us against 105 us per 32 frames)
+    auto first_fit = [&](size_t extra) {
+      for (size_t i = 0; i < cuts.size() && streamable; i++)
+        if (cuts[i].la + cuts[i].lb + extra <= budget && cuts[i].tab_rows <= kPyrTabRows && cuts[i].prog_rows <= kPyrProgRows)
+          return (int)i;
+      return -1;
+    };
+    const int pick0 = first_fit(0), pickx = xbytes ? first_fit(xbytes) : -1;
+    int pick = pick0;
+    if (pickx >= 0 && 2 * cuts[pickx].S <= 3 * cuts[pick0].S) {
+      pick = pickx;
+      pyr_lds_x = xbytes;
     }
     if (pick < 0) {  // the strips do not fit the LDS at all: the HBM path, finest cut
       strip_rows = cuts.back().tab;

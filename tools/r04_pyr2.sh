@@ -1,10 +1,4 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-python - <<'P'
-from geoflowslam_amd import api
-for sc, nl in ((2.0, 4), (2.5, 3), (1.5, 5)):
-    try:
-        api.ORBextractor(800, sc, nl, 20, 7, max_rows=480, max_cols=640); print(sc, "ok")
-    except Exception as e:
-        print(sc, "ERR", e)
-P
-timeout 1200 python -m pytest tests/test_gpu_orb_match.py -q -m gpu 2>&1 | tail -8
+timeout 1200 python -m pytest tests/test_gpu_orb_match.py tests/test_golden.py tests/test_gpu_host_mirror.py tests/test_frame_helpers.py tests/test_gpu_batched.py -q -m gpu 2>&1 | tail -3
+python tools/stream_probe.py 2>&1 | head -3
+timeout 600 python bench.py --workload c3 --batch 32 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-klt --verify 0 --prime 3 --lanes 2 2>&1 | tail -1 | cut -c1-200
