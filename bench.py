@@ -32,7 +32,8 @@ def algorithmic_bytes_per_step(kernel, ctx):
     B = ctx["B"]
     table = {
         "k_fast_cells": B * (P + 4 * ctx["cands"]),                 # P read + 4 B per packed candidate
-        "k_pyr_area": B * (P0 + (P - P0) + (P - ctx["p_last"])),    # P0 read + levels written + levels re-read
+        "k_pyr_area_lds": B * (P0 + (P - P0)),                      # P0 read + levels written (a level is re-read from LDS)
+        "k_pyr_area_hbm": B * (P0 + (P - P0) + (P - ctx["p_last"])),  # P0 read + levels written + levels re-read
         "k_blur7": B * 2 * P,
         "k_orient_brief": B * K * (31 * 31 + 37 * 37 + 60),         # K x (31x31 + 37x37) read + 60 B out
         "k_bf_hamming": B * (32 * 2 * K + 8 * K),
@@ -41,6 +42,7 @@ def algorithmic_bytes_per_step(kernel, ctx):
         "k_gicp_error": 136.0 * ctx["err_points"],
         "k_knn_cov": (10 * 32 + 160) * ctx["ds_points"],            # 10-NN gather + covariance write, both clouds
         "k_radix_sort": 2 * 12 * ctx["ds_points"],                    # the cell sort: (8 B key + 4 B index) read + written
+        "k_cell_sort_lds": 2 * 12 * ctx["ds_points"],
         "k_voxel_qsort_top_reg": 2 * 12 * ctx["in_points"],            # the voxel sort (quick_sort_omp replica): keys + indices in, out
         "k_voxel_qsort_top": 2 * 12 * ctx["in_points"],
         "k_voxel_qsort_leaf": 2 * 12 * ctx["in_points"],

@@ -1632,14 +1632,39 @@ __device__ __forceinline__ int round_half_away(float x) {  // std::round(float) 
 
 constexpr int kObGroup = 16;                    // lanes per key point
 constexpr int kObPerWg = 256 / kObGroup;        // key points per workgroup
+// The kernel was bound by the L1's line rate (~3 400 line requests per wave of four key points = the measured 0.77 ms per 512
+// frames; its ~1 540 VALU instructions per wave account for 0.3 ms): sixteen lanes read sixteen different rows of a patch in
+// one instruction.  Now both patches are read row by row:
+//  * IC_Angle: the 31 rows of the disc as 8 unaligned words each (u = -16 .. 15), eight lanes a row; a word's four pixels
+//    meet their weights (u + 16 inside the disc, else 0; and 1 / 0) in v_dot4_u32_u8: m10 = sum(W . I) - 16 sum(M . I),
+//    m01 = sum(v (M . I)).  Integer sums: any order gives the reference's numbers.
+//  * the 37 x 37 window of the blurred level the 256 steered tests read (pattern coordinates <= 13 in magnitude: rotated and
+//    rounded <= 18; checked when the extractor is created) goes to LDS as 37 rows of 10 aligned words; the tests read bytes
+//    there.
+constexpr int kObHalf = 18, kObRows = 2 * kObHalf + 1, kObRowWords = 10;
 __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict__ levels, Lvl0 l0,
                                                       const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                       const uint8_t* __restrict__ blur, size_t blur_frame,
                                                       const KpIn* __restrict__ kpin, const int* __restrict__ kp_count,
-                                                      int kp_cap, const int8_t* __restrict__ ic_du,
-                                                      const int8_t* __restrict__ ic_dv, int ic_n,
+                                                      int kp_cap, const int* __restrict__ umax,
                                                       const int8_t* __restrict__ pattern, gfs_keypoint* __restrict__ kps,
                                                       uint8_t* __restrict__ desc) {
+  __shared__ uint2 s_w[31 * 8];  // (W, M) of word j of disc row r
+  __shared__ uint32_t s_patch[kObPerWg][kObRows * kObRowWords];
+  if (threadIdx.x < 31 * 8) {
+    const int r = threadIdx.x >> 3, j = threadIdx.x & 7, v = r - 15, um = umax[v < 0 ? -v : v];
+    unsigned W = 0, M = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int u = -16 + 4 * j + q;
+      if (u >= -um && u <= um) {
+        W |= (unsigned)(u + 16) << (8 * q);
+        M |= 1u << (8 * q);
+      }
+    }
+    s_w[threadIdx.x] = make_uint2(W, M);
+  }
+  __syncthreads();
   // Sixteen lanes per key point, four key points per wave: the per-key-point scalar work (fastAtan2, glibc's sincosf) is done for four
   // of them at once instead of on 64 lanes for one; the pixel sums and the 256 tests are the same work either way.
   const int sl = threadIdx.x & (kObGroup - 1);
@@ -1653,13 +1678,47 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
   int sp;
   const uint8_t* src = level_ptr(L, in.level, b, l0, pyr, pyr_frame, &sp);
   const int cx = __float2int_rn(in.x), cy = __float2int_rn(in.y);  // cvRound(pt)
-  const uint8_t* center = src + (size_t)cy * sp + cx;
-  int m10 = 0, m01 = 0;
-  for (int i = sl; i < ic_n; i += kObGroup) {
-    const int du = ic_du[i], dv = ic_dv[i];
-    const int val = center[dv * sp + du];
-    m10 += du * val;
-    m01 += dv * val;
+  // descriptor window on the blurred level: asked for first, so that its rows travel while the angle is computed
+  const uint8_t* bl = blur + (size_t)b * blur_frame + L.blur_off;
+  const int bx = round_half_away(in.x), by = round_half_away(in.y);
+  const uint8_t* bc = bl + (size_t)by * L.pitch + bx;
+  const uint8_t* wcorner = bc - (size_t)kObHalf * L.pitch - kObHalf;
+  const int ax = (int)(reinterpret_cast<uintptr_t>(wcorner) & 3);  // (all rows alike: the planes' pitches are multiples of 64)
+  uint32_t* mp = s_patch[threadIdx.x / kObGroup];
+  {
+    const uint8_t* wbase = wcorner - ax;
+    constexpr int kIter = (kObRows * kObRowWords + kObGroup - 1) / kObGroup;
+    uint32_t wv[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; it++) {
+      const int idx = min(sl + it * kObGroup, kObRows * kObRowWords - 1);
+      const int row = idx / kObRowWords, j = idx - row * kObRowWords;
+      wv[it] = *reinterpret_cast<const uint32_t*>(wbase + (size_t)row * L.pitch + 4 * j);
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; it++) mp[min(sl + it * kObGroup, kObRows * kObRowWords - 1)] = wv[it];
+  }
+  int m10, m01;
+  {
+    const uint8_t* row0 = src + (size_t)(cy - 15) * sp + (cx - 16);
+    const int j = sl & 7;
+    unsigned sW = 0;
+    int sM = 0;
+    m01 = 0;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int r = 2 * it + (sl >> 3);
+      if (r < 31) {
+        uint32_t w;
+        __builtin_memcpy(&w, row0 + (size_t)r * sp + 4 * j, 4);
+        const uint2 wm = s_w[r * 8 + j];
+        const int dm = (int)__builtin_amdgcn_udot4(w, wm.y, 0u, false);
+        sW = __builtin_amdgcn_udot4(w, wm.x, sW, false);
+        sM += dm;
+        m01 += (r - 15) * dm;
+      }
+    }
+    m10 = (int)sW - 16 * sM;
   }
 #pragma unroll
   for (int ofs = kObGroup / 2; ofs > 0; ofs >>= 1) {
@@ -1670,10 +1729,11 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   float a, bb;
   glibc_sincosf(__fmul_rn(angle, factorPI), &bb, &a);  // a = cos, b = sin
-  // descriptor on the blurred level: lane sl takes the tests 16 sl .. 16 sl + 15 = descriptor bytes 2 sl, 2 sl + 1
-  const uint8_t* bl = blur + (size_t)b * blur_frame + L.blur_off;
-  const int bx = round_half_away(in.x), by = round_half_away(in.y);
-  const uint8_t* bc = bl + (size_t)by * L.pitch + bx;
+  // descriptor: lane sl takes the tests 16 sl .. 16 sl + 15 = descriptor bytes 2 sl, 2 sl + 1
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the window was written by this key point's own sixteen lanes
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint8_t* win = reinterpret_cast<const uint8_t*>(mp) + kObHalf * (4 * kObRowWords) + kObHalf + ax;  // (0, 0) of the window
   unsigned bits = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -1688,7 +1748,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
       const int c0 = round_half_away(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
       const int r1 = round_half_away(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
       const int c1 = round_half_away(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
-      const int v0 = bc[r0 * L.pitch + c0], v1 = bc[r1 * L.pitch + c1];
+      const int v0 = win[r0 * (4 * kObRowWords) + c0], v1 = win[r1 * (4 * kObRowWords) + c1];
       bits |= (unsigned)(v0 < v1) << (4 * q + t);
     }
   }
@@ -1816,8 +1876,8 @@ struct gfs_orb {
   gfs::DevBuf<KpIn> d_kpin;
   gfs::DevBuf<gfs_keypoint> d_kps;
   gfs::DevBuf<uint8_t> d_desc;
-  gfs::DevBuf<int8_t> d_ic_du, d_ic_dv, d_pattern;
-  int ic_n = 0;
+  gfs::DevBuf<int8_t> d_pattern;
+  gfs::DevBuf<int> d_umax;  // the IC_Angle disc: half-width of row |v|
   // pinned host
   gfs::PinBuf<int> h_cand_off, h_kp_count, h_mono;
   gfs::PinBuf<uint32_t> h_cand;
@@ -1922,8 +1982,8 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
     GFS_LAUNCH("k_blur7", k_blur7, dim3((unsigned)G.blur_tiles.size(), B), dim3(256), 0, s, h->d_levels.p, h->d_tiles.p, l0,
                h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, tp[0], tp[1], tp[2], tp[3]);
     GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(h->cap_kp, kObPerWg), B), dim3(256), 0, s, h->d_levels.p, l0,
-               h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_ic_du.p,
-               h->d_ic_dv.p, h->ic_n, h->d_pattern.p, h->d_kps.p, h->d_desc.p);
+               h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_umax.p,
+               h->d_pattern.p, h->d_kps.p, h->d_desc.p);
     h->last_B = B;
     h->last_l0 = l0;
     h->host_counts_valid = false;
@@ -1995,8 +2055,8 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                              (size_t)max_n * sizeof(KpIn), B, hipMemcpyHostToDevice, s));
     // 6. orientation + descriptors
     GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(max_n, kObPerWg), B), dim3(256), 0, s, h->d_levels.p, l0,
-               h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_ic_du.p,
-               h->d_ic_dv.p, h->ic_n, h->d_pattern.p, h->d_kps.p, h->d_desc.p);
+               h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_umax.p,
+               h->d_pattern.p, h->d_kps.p, h->d_desc.p);
   }
   h->last_B = B;
   h->last_l0 = l0;
@@ -2112,16 +2172,17 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   A(h->h_mono.alloc(B));
   A(h->h_cand.alloc(B * h->cap_slab));
   A(h->h_kpin.alloc(B * h->cap_kp));
-  std::vector<int8_t> du, dv;
-  gfs::ic_angle_offsets(h->P.umax, du, dv);
-  h->ic_n = (int)du.size();
-  A(h->d_ic_du.alloc(du.size()));
-  A(h->d_ic_dv.alloc(dv.size()));
+  A(h->d_umax.alloc(16));
   A(h->d_pattern.alloc(1024));
 #undef A
   if (rc) return rc;
-  GFS_HIP(hipMemcpy(h->d_ic_du.p, du.data(), du.size(), hipMemcpyHostToDevice));
-  GFS_HIP(hipMemcpy(h->d_ic_dv.p, dv.data(), dv.size(), hipMemcpyHostToDevice));
+  // k_orient_brief keeps the window the steered tests can reach in LDS: (x, y) rotated and rounded stays within hypot(x, y) + 0.5
+  for (int i = 0; i < 512; i++) {
+    const double x = (double)(int8_t)kPattern[2 * i], y = (double)(int8_t)kPattern[2 * i + 1];
+    GFS_REQUIRE(std::sqrt(x * x + y * y) + 0.5 < (double)(kObHalf + 1), GFS_ERR_UNSUPPORTED,
+                "a BRIEF test point lies outside the %d x %d window of k_orient_brief", kObRows, kObRows);
+  }
+  GFS_HIP(hipMemcpy(h->d_umax.p, h->P.umax, 16 * sizeof(int), hipMemcpyHostToDevice));
   GFS_HIP(hipMemcpy(h->d_pattern.p, kPattern, 1024, hipMemcpyHostToDevice));
   GFS_HIP(hipMemset(h->d_kp_count.p, 0, B * sizeof(int)));
   h->host_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
