@@ -1780,11 +1780,26 @@ __device__ __forceinline__ void inv3(const double* A, double* M) {
 }
 
 // per-wave shuffle reduction, then the 4 waves of the block are folded in fixed order: deterministic sums
-// per-block partial sums: wave totals by recursive halving (wave_reduce.hpp), then the 4 waves of the block in fixed order
+// per-WAVE partial sums (wave totals by recursive halving, wave_reduce.hpp), stored side by side per block: slot `wave` of the
+// block's kLinWaves slots.  The four waves of a block are added up, in the fixed order 0 + w0 + w1 + w2 + w3, by the kernel that
+// folds the partials (fold_partials): the same numbers as a block-wide sum in LDS, but a wave that has finished its points
+// leaves instead of waiting at two barriers for the slowest of its block (clock64 per section, -DGFS_LIN_TIMING in round 4: a
+// wave of k_gicp_linearize lived 55 - 74 k cycles, 7 - 23 k of them in the reduction, nearly all of that waiting).
+constexpr int kLinWaves = kLinBlock / 64;
 template <int N>
-__device__ __forceinline__ void block_reduce_store(double (&vals)[N], double* __restrict__ dst, double* s_red /*[4][32]*/) {
-  const double r = gfs_red::block_sum_many<N, kLinBlock / 64>(vals, s_red);
-  if (threadIdx.x < N) dst[threadIdx.x] = r;
+__device__ __forceinline__ void wave_reduce_store(double (&vals)[N], double* __restrict__ dst_block, int wave) {
+  const double tot = gfs_red::wave_sum_many<N>(vals);
+  const int lane = threadIdx.x & 63;
+  if (lane < N) dst_block[wave * N + lane] = tot;
+}
+// A 256-point chunk of a cloud is one workgroup of four waves, or -- the search kernels that need no LDS -- four workgroups of one
+// wave (a CU takes a new workgroup only when all its waves fit: one-wave workgroups fill the slots that finished waves leave).
+// `chunk` comes in as the launch block's index within the pair; returns the lane's point and its wave's slot of the chunk.
+__device__ __forceinline__ int lin_point_of(int& chunk, int* wave_slot) {
+  const int per = kLinBlock / (int)blockDim.x, part = chunk % per;
+  chunk /= per;
+  *wave_slot = part * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+  return chunk * kLinBlock + part * (int)blockDim.x + (int)threadIdx.x;
 }
 
 // ---- the target cloud as the 1-NN search sees it: cell boundaries of a row, candidate points.  Two sources with the same
@@ -2255,7 +2270,6 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
                                                               int* __restrict__ tgt_index, double* __restrict__ maha6,
                                                               double* __restrict__ partial, int nblk, const int* __restrict__ act,
                                                               const int* __restrict__ n_act) {
-  __shared__ double s_red[4 * 32];
   __shared__ typename std::conditional<kTiled, LinTile, int>::type tile;  // the untiled instance keeps its LDS (and its occupancy)
   int pair, sub, chunk;
   if (act) {  // a late round: only the pairs on the list (the grid covers an upper bound of their number)
@@ -2278,7 +2292,8 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
   const int ms = m_counts[cs];
   const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
   const int* gi = ginfo + 8 * ct;
-  const int i = chunk * kLinBlock + threadIdx.x;  // < P: the grid covers at most the clouds' capacity
+  int wave_slot;
+  const int i = lin_point_of(chunk, &wave_slot);  // < P: the grid covers at most the clouds' capacity
   const double4 p = pts[(size_t)cs * P + i];
   const double4* tp = pts + (size_t)ct * P;
   const int prev_j = tgt_index[(size_t)pair * P + i];
@@ -2315,7 +2330,7 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
                      gi, prm, tgt_index, maha6, acc);
     }
   }
-  block_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + chunk) * kRed, s_red);
+  wave_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + chunk) * kLinWaves * kRed, wave_slot);
 }
 
 // GICPFactor::error (factors/gicp_factor.hpp:76-86) with the frozen correspondences / Mahalanobis matrices.
@@ -2324,7 +2339,6 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __res
                                                            const int* __restrict__ tgt_index, const double* __restrict__ maha6,
                                                            double* __restrict__ epartial, int nblk, int nchunks, int npairs, int src_slot,
                                                            const int* __restrict__ act, const int* __restrict__ n_act) {
-  __shared__ double s_red[4 * 32];
   int pair, sub, chunk;
   if (act) {  // a late round: only the pairs on the list
     const int slot = blockIdx.x / nchunks;
@@ -2338,8 +2352,9 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __res
   if (S.phase != 1) return;
   const int cs = 2 * pair + src_slot, ct = 2 * pair + 1 - src_slot;
   const int ms = m_counts[cs];
+  int wave_slot;
+  const int i = lin_point_of(chunk, &wave_slot);
   if (chunk * kLinBlock >= ms) return;
-  const int i = chunk * kLinBlock + threadIdx.x;
   double e[1] = {0.0};
   if (i < ms) {
     const int ti = tgt_index[(size_t)pair * P + i];
@@ -2358,7 +2373,7 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __res
       e[0] = 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
     }
   }
-  block_reduce_store<1>(e, epartial + (size_t)pair * nblk + chunk, s_red);
+  wave_reduce_store<1>(e, epartial + ((size_t)pair * nblk + chunk) * kLinWaves, wave_slot);
 }
 
 // (H + lambda I) delta = -b, then new_T = T * se3_exp(delta) (registration/optimizer.hpp:109-112, util/lie.hpp:54-103).
@@ -2475,14 +2490,20 @@ __device__ void solve_and_propose(const double* H21, const double* b6, double la
   for (int i = 0; i < 3; i++) newT12[9 + i] = T12[i] * E[9] + T12[i + 3] * E[10] + T12[i + 6] * E[11] + T12[9 + i];
 }
 
-// fixed-order sum of `n` per-block partial vectors of `stride` doubles: 8 strided sub-sums per component, then 8 -> 1
+// fixed-order sum of `n` blocks' partial vectors (kLinWaves wave vectors of `stride` doubles each, wave_reduce_store): the waves of
+// a block first, then 8 strided sub-sums per component over the blocks, then 8 -> 1
 template <int NCOMP>
 __device__ __forceinline__ void fold_partials(const double* __restrict__ part, int n, int stride, double* s_part /*[8][32]*/,
                                               double* s_out /*[32]*/) {
   const int comp = threadIdx.x & 31, sub = threadIdx.x >> 5;  // 256 threads = 32 components x 8 sub-sums
   double a = 0;
   if (comp < NCOMP)
-    for (int k = sub; k < n; k += 8) a += part[(size_t)k * stride + comp];
+    for (int k = sub; k < n; k += 8) {
+      double blk = 0;  // the block's sum: its waves in order
+#pragma unroll
+      for (int w = 0; w < kLinWaves; w++) blk += part[((size_t)k * kLinWaves + w) * stride + comp];
+      a += blk;
+    }
   s_part[sub * 32 + comp] = a;
   __syncthreads();
   if (threadIdx.x < NCOMP) {
@@ -2504,7 +2525,7 @@ __global__ __launch_bounds__(256) void k_gicp_solve(PairState* __restrict__ st, 
   if (st[pair].phase != 0) return;
   const int ms = m_counts[2 * pair + src_slot];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
-  fold_partials<kRed>(partial + (size_t)pair * nblk_max * kRed, nblk, kRed, s_part, s_sum);
+  fold_partials<kRed>(partial + (size_t)pair * nblk_max * kLinWaves * kRed, nblk, kRed, s_part, s_sum);
   if (threadIdx.x == 0) {
     PairState& S = st[pair];
     double H[21], b[6], T[12], delta[6], newT[12];
@@ -2552,7 +2573,7 @@ __global__ __launch_bounds__(256) void k_gicp_decide(PairState* __restrict__ st,
   if (st[pair].phase != 1) return;
   const int ms = m_counts[2 * pair + prm.src_slot];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
-  fold_partials<1>(epartial + (size_t)pair * nblk_max, nblk, 1, s_part, s_sum);
+  fold_partials<1>(epartial + (size_t)pair * nblk_max * kLinWaves, nblk, 1, s_part, s_sum);
   if (threadIdx.x != 0) return;
   PairState& S = st[pair];
   const double new_e = s_sum[0];
@@ -2945,8 +2966,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_cov6.alloc(C2 * P * 6));
   A(h->d_maha6.alloc(B * P * 6));
   A(h->d_tgt_index.alloc(B * P));
-  A(h->d_partial.alloc(B * h->nblk * kRed));
-  A(h->d_epartial.alloc(B * h->nblk));
+  A(h->d_partial.alloc(B * h->nblk * kLinWaves * kRed));
+  A(h->d_epartial.alloc(B * h->nblk * kLinWaves));
   A(h->d_initT.alloc(B * 16));
   A(h->d_state.alloc(B));
   A(h->h_state.alloc(B));
@@ -3115,19 +3136,26 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
       int* act_next = h->d_active.p + (size_t)((round + 1) & 1) * B;
       int* n_act_next = h->d_nactive.p + ((round + 1) & 1);
       const dim3 grid_pts(listed ? std::max(ub, 1) * nblk_run : xcd_grid(nblk_run, B, 1));
+      // GFS_GICP_LIN_WG=64 / 128: the kernels without LDS as one- or two-wave workgroups, four or two to a chunk (lin_point_of).
+      // Measured in round 4: k_gicp_linearize alone 150 -> 137 us per launch of 512 pairs with one-wave workgroups (finished waves
+      // make room at once), the overlapped bench unchanged to slightly lower (37.2 against 37.3 k frames/s, the 64-pair block 28.8
+      // against 29.0 k: the other lanes' kernels already fill those gaps, and four times the workgroups go through the dispatcher)
+      static const int lin_wg = getenv("GFS_GICP_LIN_WG") ? std::max(64, std::min(256, atoi(getenv("GFS_GICP_LIN_WG")) / 64 * 64)) : 256;
+      const int per = kLinBlock / (lin_wg == 128 ? 128 : lin_wg == 256 ? 256 : 64), wg = kLinBlock / per;
+      const dim3 grid_w(listed ? std::max(ub, 1) * nblk_run * per : xcd_grid(nblk_run * per, B, 1));
       if (prm.lin_tile) {
         GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<true>, grid_pts, dim3(kLinBlock), 0, s, h->d_state.p,
                    h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
                    nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk, act, n_act);
       } else {
-        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<false>, grid_pts, dim3(kLinBlock), 0, s, h->d_state.p,
+        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<false>, grid_w, dim3(wg), 0, s, h->d_state.p,
                    h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
-                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk, act, n_act);
+                   nblk_run * per, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk, act, n_act);
       }
       GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot,
                  n_act_next);
-      GFS_LAUNCH("k_gicp_error", k_gicp_error, grid_pts, dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p,
-                 h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run, B, prm.src_slot, act, n_act);
+      GFS_LAUNCH("k_gicp_error", k_gicp_error, grid_w, dim3(wg), 0, s, h->d_state.p, h->d_pts.p,
+                 h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run * per, B, prm.src_slot, act, n_act);
       GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
                  h->d_ndone.p, act_next, n_act_next);
       // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
