@@ -529,7 +529,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
   __shared__ int s_count;
   const int cell_id = blockIdx.x, b = blockIdx.y;
   const CellDev C = cells[cell_id];
-  const LevelDev L = levels[C.level];
   const int w = C.w, h = C.h;
   const int tid = threadIdx.x;
   const int dw = w - 6, dh = h - 6;
@@ -537,8 +536,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
     if (tid == 0) cell_cnt[(size_t)b * n_cells + cell_id] = 0;
     return;
   }
-  int sp;
-  const uint8_t* src = level_ptr(L, C.level, b, l0, pyr, pyr_frame, &sp);
+  // (the level's pitch and plane come with the cell's descriptor: levels[C.level] would be a second dependent load)
+  const int sp = C.level == 0 ? l0.pitch : C.pitch;
+  const uint8_t* src = C.level == 0 ? l0.base + (size_t)b * l0.frame_stride : pyr + (size_t)b * pyr_frame + C.plane_off;
   // The tile is staged with aligned 4-byte loads when every row of the cell starts at the same offset `al` inside its word
   // (all pyramid planes: pitch and plane offsets are multiples of 64; a caller's level 0 whenever its pitch is a multiple of
   // 4 AND the plane itself starts on a word: the word loads reach back to the word boundary in front of a row, which lies
@@ -555,10 +555,24 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __r
   if (words) {
     const int wpr = wp >> 2, total = wpr * h;
     const uint8_t* src_al = src - al;
-    for (int i = tid; i < total; i += kFastThreads) {
-      const int y = i / wpr, x = i - y * wpr;
-      reinterpret_cast<uint32_t*>(tile)[i] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)y * sp + 4 * x);
-      reinterpret_cast<uint32_t*>(sc)[i] = 0u;
+    for (int i0 = tid; i0 < total; i0 += 4 * kFastThreads) {  // four loads in flight, then their stores
+      uint32_t v[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = i0 + q * kFastThreads;
+        if (i < total) {
+          const int y = i / wpr, x = i - y * wpr;
+          v[q] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)y * sp + 4 * x);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = i0 + q * kFastThreads;
+        if (i < total) {
+          reinterpret_cast<uint32_t*>(tile)[i] = v[q];
+          reinterpret_cast<uint32_t*>(sc)[i] = 0u;
+        }
+      }
     }
   } else {
     const int sy = kFastThreads / w, sx = kFastThreads - sy * w;  // raster step of one workgroup stride
@@ -1467,31 +1481,45 @@ __global__ __launch_bounds__(256) void k_blur7(const LevelDev* __restrict__ leve
                                                int t3) {
   __shared__ __align__(16) uint32_t raw[kBlurTH + 6][18];        // 72 bytes per row: [x0-4, x0+68)
   __shared__ __align__(16) uint16_t hb[kBlurTH + 6][kBlurTW];
-  const BlurTileDev T = tiles[blockIdx.x];
+  const BlurTileDev T = tiles[blockIdx.x];  // (carries the level's geometry: no second dependent load of levels[T.level])
   const int b = blockIdx.y;
-  const LevelDev L = levels[T.level];
-  int sp;
-  const uint8_t* src = level_ptr(L, T.level, b, l0, pyr, pyr_frame, &sp);
+  struct {
+    int rows, cols, pitch;
+    unsigned blur_off;
+  } L = {T.rows, T.cols, T.pitch, T.blur_off};
+  const int sp = T.level == 0 ? l0.pitch : T.pitch;
+  const uint8_t* src = T.level == 0 ? l0.base + (size_t)b * l0.frame_stride : pyr + (size_t)b * pyr_frame + T.plane_off;
   const int x0 = T.tx * kBlurTW, y0 = T.ty * kBlurTH;
   const int tid = threadIdx.x;
   const bool word_ok = ((sp & 3) == 0) && ((reinterpret_cast<size_t>(src) & 3) == 0);
-  for (int i = tid; i < (kBlurTH + 6) * 18; i += 256) {
-    const int r = i / 18, w = i - r * 18;
-    const int sy = reflect101(y0 + r - 3, L.rows);
-    const int xb = x0 - 4 + 4 * w;  // first source column of this word
-    uint32_t v;
-    if (word_ok && xb >= 0 && xb + 3 < L.cols) {
-      v = *reinterpret_cast<const uint32_t*>(src + (size_t)sy * sp + xb);
-    } else {
-      v = 0;
+  // all of a thread's words are asked for before the first one is stored (a load and its store per loop iteration made the
+  // staging three round trips to memory one after the other: 6.5 k of a workgroup's 10 k cycles, clock64 in round 4)
+  constexpr int kWords = (kBlurTH + 6) * 18, kIt = (kWords + 255) / 256;
+  uint32_t v[kIt];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int sx = reflect101(xb + k, L.cols);
-        const int sxc = min(max(sx, 0), L.cols - 1);  // columns far right of the image are never used
-        v |= (uint32_t)src[(size_t)sy * sp + sxc] << (8 * k);
+  for (int it = 0; it < kIt; it++) {
+    const int i = tid + it * 256;
+    v[it] = 0;
+    if (i < kWords) {
+      const int r = i / 18, w = i - r * 18;
+      const int sy = reflect101(y0 + r - 3, L.rows);
+      const int xb = x0 - 4 + 4 * w;  // first source column of this word
+      if (word_ok && xb >= 0 && xb + 3 < L.cols) {
+        v[it] = *reinterpret_cast<const uint32_t*>(src + (size_t)sy * sp + xb);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int sx = reflect101(xb + k, L.cols);
+          const int sxc = min(max(sx, 0), L.cols - 1);  // columns far right of the image are never used
+          v[it] |= (uint32_t)src[(size_t)sy * sp + sxc] << (8 * k);
+        }
       }
     }
-    raw[r][w] = v;
+  }
+#pragma unroll
+  for (int it = 0; it < kIt; it++) {
+    const int i = tid + it * 256;
+    if (i < kWords) (&raw[0][0])[i] = v[it];
   }
   __syncthreads();
   for (int i = tid; i < (kBlurTH + 6) * (kBlurTW / 4); i += 256) {

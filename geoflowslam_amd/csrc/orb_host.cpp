@@ -176,6 +176,8 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
         c.w = (short)((int)maxX - (int)iniX);
         c.h = (short)((int)maxY - (int)iniY);
         const int dw = std::max(c.w - 6, 0), dh = std::max(c.h - 6, 0);
+        c.pitch = L.pitch;
+        c.plane_off = L.plane_off;
         c.slab_off = (unsigned)slab;
         c.slab_cap = (unsigned)(((dw + 1) / 2) * ((dh + 1) / 2));  // 3x3 strict-max NMS keeps <= 1 per 2x2 block
         slab += c.slab_cap;
@@ -190,7 +192,7 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
     L.kp_cap = L.quota + 3 + 4 * nIni;
     kp_cap += L.kp_cap;
     for (int ty = 0; ty < (L.rows + 31) / 32; ty++)  // 64 x 32 tiles (k_blur7)
-      for (int tx = 0; tx < (L.cols + 63) / 64; tx++) blur_tiles.push_back(BlurTileDev{(short)l, (short)tx, (short)ty, 0});
+      for (int tx = 0; tx < (L.cols + 63) / 64; tx++) blur_tiles.push_back(BlurTileDev{(short)l, (short)tx, (short)ty, 0, L.rows, L.cols, L.pitch, L.plane_off, L.blur_off, 0u});
   }
   if (cols >= 4096 || rows >= 4096) {
     supported = false;

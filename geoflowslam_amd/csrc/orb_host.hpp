@@ -33,10 +33,18 @@ struct CellDev {
   short pad;
   unsigned slab_off;  // first candidate slot of this cell in one frame's slab buffer
   unsigned slab_cap;
+  // the level's plane (copies of LevelDev::pitch / plane_off: k_fast_cells reaches its pixels behind ONE descriptor load)
+  int pitch;
+  unsigned plane_off;
+  unsigned pad2;
 };
 
 struct BlurTileDev {
   short level, tx, ty, pad;
+  // the level (copies of LevelDev::rows / cols / pitch / plane_off / blur_off: one descriptor load in k_blur7)
+  int rows, cols, pitch;
+  unsigned plane_off, blur_off;
+  unsigned pad2;
 };
 
 struct OrbParams {
