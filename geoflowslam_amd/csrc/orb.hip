@@ -901,6 +901,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
   // feeds them to DistributeOctTree (cells row-major, raster order inside a cell) — what k_cand_pack would lay out; the working
   // arrays of the level then live at the level's slab offset.  cells == NULL: a dense list (cand, cand_off) from the caller.
   __shared__ int s_gscan[kOctThreads];
+  __shared__ unsigned s_coff[kOctThreads];
   __shared__ int s_gbase;
   size_t region = 0;
   int n = 0;
@@ -934,19 +935,38 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
         s_gscan[tid] += v;
         __syncthreads();
       }
-      const int base = s_gbase + s_gscan[tid] - my;
-      if (my > 0) {
-        const uint32_t* sp = sl + cells[L.cell_base + ci].slab_off;
-        for (int i0 = 0; i0 < my; i0 += 8) {  // eight loads in flight (a load behind every store would be a chain of round trips)
-          uint32_t t[8];
+      // the chunk's candidates as one flat range [0, tot): element e belongs to the first cell whose inclusive prefix exceeds e
+      // (a search over the scanned counts in LDS), so every thread copies the same number of elements, eight loads in flight,
+      // and neighbouring threads write neighbouring slots.  (A thread per cell copied its own cell's candidates one batch after
+      // the other: as many round trips as the fullest cell needs, 35 - 80 k of a workgroup's ~230 k cycles, clock64 in round 4.)
+      s_coff[tid] = ci < L.n_cells ? cells[L.cell_base + ci].slab_off : 0u;
+      __syncthreads();
+      const int tot = s_gscan[kOctThreads - 1];
+      for (int e0 = tid; e0 < tot; e0 += 8 * kOctThreads) {
+        uint32_t t[8];
 #pragma unroll
-          for (int u = 0; u < 8; u++) t[u] = i0 + u < my ? sp[i0 + u] : 0u;
+        for (int u = 0; u < 8; u++) {
+          const int e = e0 + u * kOctThreads;
+          t[u] = 0u;
+          if (e < tot) {
+            int lo = 0, hi = kOctThreads - 1;  // first cell with s_gscan[cell] > e
 #pragma unroll
-          for (int u = 0; u < 8; u++)
-            if (i0 + u < my) {
-              perm(0)[base + i0 + u] = t[u];
-              seg(0)[base + i0 + u] = 0;
+            for (int st = 0; st < 8; st++) {
+              const int mid = (lo + hi) >> 1;
+              if (s_gscan[mid] > e) hi = mid;
+              else lo = mid + 1;
             }
+            const int excl = lo > 0 ? s_gscan[lo - 1] : 0;
+            t[u] = sl[s_coff[lo] + (unsigned)(e - excl)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int e = e0 + u * kOctThreads;
+          if (e < tot) {
+            perm(0)[s_gbase + e] = t[u];
+            seg(0)[s_gbase + e] = 0;
+          }
         }
       }
       __syncthreads();
