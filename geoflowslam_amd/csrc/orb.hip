@@ -927,13 +927,10 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
     for (int c0 = 0; c0 < L.n_cells; c0 += kOctThreads) {
       const int ci = c0 + tid;
       const int my = ci < L.n_cells ? cnt[ci] : 0;
-      s_gscan[tid] = my;
-      __syncthreads();
-      for (int ofs = 1; ofs < kOctThreads; ofs <<= 1) {
-        const int v = tid >= ofs ? s_gscan[tid - ofs] : 0;
-        __syncthreads();
-        s_gscan[tid] += v;
-        __syncthreads();
+      {  // inclusive prefix of the cells' counts (wave shuffles + one exchange between the four waves)
+        unsigned long long tot64;
+        const unsigned long long excl = oct_scan_u64((unsigned long long)my, s_w64, &tot64);
+        s_gscan[tid] = (int)excl + my;
       }
       // the chunk's candidates as one flat range [0, tot): element e belongs to the first cell whose inclusive prefix exceeds e
       // (a search over the scanned counts in LDS), so every thread copies the same number of elements, eight loads in flight,
