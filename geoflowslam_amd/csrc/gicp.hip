@@ -518,6 +518,8 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
   // the same output positions as a single workgroup walking the whole array
   __shared__ int s_wave[16];
   __shared__ int s_carry;
+  __shared__ float s_px[1024], s_py[1024], s_pz[1024];
+  __shared__ unsigned char s_stop[1024];
   const int c = blockIdx.x, pair = c >> 1, tid = threadIdx.x, part = blockIdx.y;
   if (only >= 0 && (c & 1) != only) return;
   const int n = counts[c];
@@ -549,25 +551,57 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
     if (tid == 0) s_carry = total;
   }
   __syncthreads();
+  // A tile's points are fetched by all its threads at once (sorted index -> point: two round trips a tile) into LDS; the thread
+  // at a run's start then adds its run up from there, in the order of the sorted array as before (the same doubles).  Walking the
+  // run through memory -- index, point, next key: two dependent round trips per point, the wave waiting for its longest run --
+  // made a tile ~17 k cycles.
+  // ... and the loads run two tiles ahead of the sums: a tile's sorted indices are asked for two iterations early, its keys and
+  // (through the indices, which have arrived by then) its points one iteration early
+  auto load_keys = [&](int t0, u64& key, u64& prev) {
+    const int i = t0 + tid;
+    key = kInvalidKey;
+    prev = kInvalidKey;
+    if (i < e1) {
+      key = keys[i];
+      if (i > 0) prev = keys[i - 1];
+    }
+  };
+  auto load_idx = [&](int t0) { return t0 + tid < e1 ? idx[t0 + tid] : 0u; };
+  u64 key_n, prev_n;
+  load_keys(e0, key_n, prev_n);
+  unsigned ix_n = load_idx(e0), ix_nn = load_idx(e0 + 1024);
+  float4 p_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e0 + tid < e1) p_n = in[ix_n];
   for (int t0 = e0; t0 < e1; t0 += 1024) {
     const int i = t0 + tid;
-    u64 key = kInvalidKey;
-    if (i < e1) key = keys[i];
+    const u64 key = key_n, prevk = prev_n;
+    const float4 p = p_n;
+    // the next tile's keys and points, the indices of the one after it
+    load_keys(t0 + 1024, key_n, prev_n);
+    ix_n = ix_nn;
+    p_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t0 + 1024 + tid < e1) p_n = in[ix_n];
+    ix_nn = load_idx(t0 + 2048);
     const bool valid = key != kInvalidKey;
-    const bool start = valid && (i == 0 || (i & 1023) == 0 || keys[i - 1] != key);
+    const bool start = valid && (i == 0 || (i & 1023) == 0 || prevk != key);
+    if (valid) {
+      s_px[tid] = p.x;
+      s_py[tid] = p.y;
+      s_pz[tid] = p.z;
+    }
+    s_stop[tid] = (start || !valid) ? 1 : 0;  // a run ends in front of the next start, of the first invalid key, or with the tile
     int total;
-    const int pos = block_scan_1024(start ? 1 : 0, s_wave, &total) + s_carry;
+    const int pos = block_scan_1024(start ? 1 : 0, s_wave, &total) + s_carry;  // (its barriers publish the tile)
     if (start) {
       double sx = 0, sy = 0, sz = 0, sw = 0;
-      int j = i;
+      int j = tid;
       do {
-        const float4 p = in[idx[j]];
-        sx += (double)p.x;
-        sy += (double)p.y;
-        sz += (double)p.z;
+        sx += (double)s_px[j];
+        sy += (double)s_py[j];
+        sz += (double)s_pz[j];
         sw += 1.0;
         j++;
-      } while (j < n && (j & 1023) != 0 && keys[j] == key);
+      } while (j < 1024 && !s_stop[j]);
       const double mx = sx / sw, my = sy / sw, mz = sz / sw;
       out[pos] = make_double4(mx, my, mz, sw / sw);
       {  // cell sort key: the cell (as every search computes it: floor(v * inv_cell)) and, below it, the sixteenth of the cell along x
