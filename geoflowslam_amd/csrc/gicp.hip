@@ -841,10 +841,23 @@ __global__ __launch_bounds__(256) void k_grid_fill(const u64* __restrict__ ucell
   const int nwaves = 4 * kGridFillParts;
   const int per_wave = (nu + nwaves - 1) / nwaves;
   const int u_begin = (part * 4 + wave) * per_wave, u_end = min(u_begin + per_wave, nu);
-  for (int u = u_begin; u < u_end; u++) {
-    const int hi = lin(uc[u]), lo = u > 0 ? lin(uc[u - 1]) + 1 : 0;
-    const unsigned v = ub[u];
-    for (int k = lo + lane; k <= hi; k += 64) G[k] = v;
+  // (the wave's cells are fetched sixty-four at a time, a lane each, and handed round by v_readlane: a load per cell in front of
+  // its stores was a round trip to memory per cell, ~8 one after the other per wave)
+  for (int base = u_begin; base < u_end; base += 64) {
+    const int u = base + lane;
+    int hi = -1, lo = 0;
+    unsigned v = 0;
+    if (u < u_end) {
+      hi = lin(uc[u]);
+      lo = u > 0 ? lin(uc[u - 1]) + 1 : 0;
+      v = ub[u];
+    }
+    const int cnt = min(64, u_end - base);
+    for (int j = 0; j < cnt; j++) {
+      const int hj = __builtin_amdgcn_readlane(hi, j), lj = __builtin_amdgcn_readlane(lo, j);
+      const unsigned vj = (unsigned)__builtin_amdgcn_readlane((int)v, j);
+      for (int k = lj + lane; k <= hj; k += 64) G[k] = vj;
+    }
   }
   const int last = lin(uc[nu - 1]);
   for (int k = last + 1 + part * 256 + tid; k <= ncell; k += 256 * kGridFillParts) G[k] = (unsigned)m;
