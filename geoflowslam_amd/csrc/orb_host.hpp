@@ -3,6 +3,7 @@
 //   src/ORBextractor.cc:421-479 (ctor tables), :770-806 (cell grid), :1227-1251 (level sizes),
 //   :502-768 (DistributeOctTree), and OpenCV's computeResizeAreaTab (imgproc/src/resize.cpp).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 

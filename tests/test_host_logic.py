@@ -88,3 +88,21 @@ def test_reference_dropins_compile():
     for extra in variants:
         out = subprocess.run(cmd + extra + [os.path.join(root, "tests", "host", "reference_dropins_check.cpp")], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_pyramid_strip_geometry(tmp_path):
+    """The strip cuts k_pyr_area_lds is launched with (OrbGeometry::build, csrc/orb_host.cpp), over image sizes from 160 x 120 to
+    4000 x 3000, scale factors 1.1 ... 2.5 and 2 / 4 / 8 levels: every row of every level is produced by a strip, every row a strip
+    produces reads source rows the same strip holds, the strips fit their LDS buffers and the kernel's row tables, the y tables are
+    streamable, and the cell / blur-tile descriptors carry their level's geometry (tests/host/orb_geometry_check.cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "orb_geometry_check")
+    src = [os.path.join(root, "tests", "host", "orb_geometry_check.cpp"), os.path.join(root, "geoflowslam_amd", "csrc", "orb_host.cpp")]
+    inc = ["-I" + os.path.join(root, "geoflowslam_amd", "csrc"), "-I" + os.path.join(root, "include")]
+    out = subprocess.run(["g++", "-std=c++17", "-O1"] + inc + src + ["-o", exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0 and "violations: 0" in run.stdout, run.stdout[-3000:]
+    assert "640x480 sf=1.20 nl=8 cut: 6 strips" in run.stdout  # (the cut the bench runs with: the x tables in LDS)
