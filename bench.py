@@ -55,6 +55,92 @@ def algorithmic_bytes_per_step(kernel, ctx):
     return table.get(kernel)
 
 
+def select_committed_traffic(profiles_dir, kernel, launches_per_step, batch_pairs, workload="c2"):
+    """`roofline.traffic` from a COMMITTED rocprofv3 PMC summary (profiles/r*_pmc_traffic_serial.json; written on another box by
+    profiles/collect.sh + summarize.py).  It is not something this run measured, so it is optional by construction: the newest file
+    that (a) parses, (b) was collected at this batch size and (c) holds BOTH the FETCH_SIZE and the WRITE_SIZE pass for `kernel` is
+    used; anything else gives traffic = null with the reason in `note`.  Never raises."""
+    import glob
+    none = dict(traffic=None, traffic_raw_counters=None, source=None, note=None)
+    try:
+        if workload != "c2":
+            return dict(none, note="no committed PMC profile for this workload")
+        files = sorted(glob.glob(os.path.join(profiles_dir, "r*_pmc_traffic_serial.json")), reverse=True)  # newest round first
+        skipped = []
+        for f in files:
+            try:
+                allk = json.load(open(f))
+            except Exception as e:
+                skipped.append(f"{os.path.basename(f)}: unreadable ({type(e).__name__})")
+                continue
+            if not isinstance(allk, dict) or allk.get("_batch_pairs") != batch_pairs:
+                skipped.append(f"{os.path.basename(f)}: other batch size")
+                continue
+            t = allk.get(kernel)
+            if not isinstance(t, dict):
+                skipped.append(f"{os.path.basename(f)}: kernel not in file")
+                continue
+            fk, wk = t.get("fetch_kb_per_step"), t.get("write_kb_per_step")
+            if not isinstance(fk, (int, float)) or not isinstance(wk, (int, float)) or not launches_per_step:
+                skipped.append(f"{os.path.basename(f)}: incomplete (a PMC pass is missing)")
+                continue
+            # calibration (profiles/r03_calibration.json, kernels with known byte counts): FETCH_SIZE reports HALF the bytes of wide
+            # streaming reads (0.500), the full 64-byte line for a 32-byte gather that misses the caches (2.02 x the 32 bytes asked
+            # for), nothing for gathers served by the L2; WRITE_SIZE is exact (1.000)
+            return dict(traffic=int((2.0 * fk + wk) * 1024 / launches_per_step),
+                        traffic_raw_counters=int((fk + wk) * 1024 / launches_per_step),
+                        source=f"committed profiles/{os.path.basename(f)} (collected on another box by profiles/collect.sh), NOT measured by this run",
+                        note="rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, same batch, 1 lane, serial), (2 x FETCH_SIZE + WRITE_SIZE) "
+                             "KB*1024 per step / launches per step; the factor 2 is the measured under-count of streaming reads "
+                             "(profiles/r03_calibration.json) and over-counts the share of cache-missing gathers, which the counter reports in "
+                             "full: an upper bound of the HBM-side bytes" + (f"; skipped: {'; '.join(skipped)}" if skipped else ""))
+        return dict(none, note="no complete committed PMC profile for this kernel and batch size" + (f" ({'; '.join(skipped[:4])})" if skipped else ""))
+    except Exception as e:
+        return dict(none, note=f"traffic unavailable: {type(e).__name__}: {e}")
+
+
+def supervise(argv, deadline_s):
+    """N = 1 only: run the bench in a CHILD process that prints the JSON line again after every side leg, keep the newest one and
+    print exactly ONE line.  A side leg that crashes the process (GPU fault, segfault in a library) or hangs past the deadline then
+    costs its own object, not the measured headline; rc is 0 whenever the timed headline was produced."""
+    import subprocess
+    env = dict(os.environ, GFS_BENCH_CHILD="1")
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    last = [None]
+
+    def reader():
+        for ln in p.stdout:
+            ln = ln.strip()
+            if ln.startswith("{"):
+                last[0] = ln
+            elif ln:
+                print(ln, file=sys.stderr)
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    died = None
+    try:
+        rc = p.wait(timeout=deadline_s)
+        if rc != 0:
+            died = f"bench child exited with rc {rc} after the last completed leg"
+    except subprocess.TimeoutExpired:
+        p.kill()  # the exact PID this function started
+        p.wait()
+        died = f"bench child passed the {deadline_s:.0f} s deadline in a side leg and was stopped"
+    th.join(timeout=10)
+    if last[0] is None:
+        sys.exit(f"bench.py: no headline was produced ({died or 'child printed nothing'})")
+    if died:
+        try:
+            o = json.loads(last[0])
+            o["side_legs_incomplete"] = died
+            last[0] = json.dumps(o)
+        except Exception:
+            pass
+    print(last[0], flush=True)
+    sys.exit(0)
+
+
 def _gen_one(a):
     from geoflowslam_amd import synth
     seed, width, height, stride = a
@@ -133,9 +219,17 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
                     help="c2 = BASELINE.json configs[1] (640x480, 1000 features, ~19k-pt clouds; the metric's configuration); "
                          "c3 = configs[2] (1280x720, 2000 features, ~37k-pt clouds; use --batch 32)")
+    ap.add_argument("--leg-budget-s", type=float, default=420.0,
+                    help="side legs (everything after roofline + cpu_baseline) are skipped once the run is this old: the line must reach the driver")
+    ap.add_argument("--deadline-s", type=float, default=1500.0, help="N = 1: the supervising parent stops a hung child after this long and prints the newest line")
+    ap.add_argument("--no-supervisor", action="store_true", help="N = 1: run in this process (no child), side legs guarded by try/except only")
     args = ap.parse_args()
+    t_start = time.perf_counter()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)  # does not return
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_supervisor and "GFS_BENCH_CHILD" not in os.environ \
+            and "GFS_BENCH_NO_SUPERVISOR" not in os.environ:
+        supervise(sys.argv[1:], args.deadline_s)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -351,11 +445,94 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)  # everything the path holds in HBM (workspaces are sized once, at handle creation)
     hbm_used_gb = round((total_b - free_b) / 2**30, 1)
 
+    def assemble():
+        g = g_head
+        out = {
+            "metric": "front-end frames/sec (ORB+match+GICP) on 640x480 RGBD",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None, "dtype": "u8/int32 (ORB, match) + f64 (GICP)", "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[1]: 640x480 RGBD frame pair, ORB extract (1000 feats, 8 levels) "
+                                    "+ BF Hamming match + GMS filter + GICP on ~19k-pt clouds (stride-4 depth grid)") if args.workload == "c2" else
+                                   ("BASELINE.json configs[2] (NOT the metric's configuration): 1280x720 RGBD frame pair, ORB extract (2000 feats, "
+                                    "8 levels) + BF Hamming match + GMS filter + GICP on ~37k-pt clouds (stride-5 depth grid)"),
+                       "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "hbm_in_use_gb": hbm_used_gb,
+                       "passes": "joined after every pass" if (args.step_join or args.serial) else "K passes per lane chain, joined once", "distinct_scenes_per_gpu": nd, "scene_seeds": f"{seed0}..{seed0 + nd - 1} (rank 0)",
+                       "scene_render_s": round(t_gen, 1), "global_batch_pairs": total_pairs,
+                       "parallelism": (f"one global batch of {args.batch} pairs cut into contiguous blocks over {world} rank(s), no collective"
+                                       if args.strong else f"frames sharded x{world}, no collective"),
+                       "gicp_mean_outer_iterations": round(float(np.mean([r["n_linearize"] for r in g])), 2),
+                       "gicp_mean_error_evals": round(float(np.mean([r["n_error_evals"] for r in g])), 2),
+                       "gicp_converged_frac": round(float(np.mean([r["converged"] for r in g])), 3)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if args.gicp_stream:
+            out["config"]["workload"] += " [EXPERIMENT --gicp-stream: target preprocessing reused from the previous call]"
+        if verify:
+            out["verified_pairs"] = verify.get("verified_pairs")
+            out["verify"] = verify
+        if strong:
+            out["strong"] = strong
+        if h2d:
+            out["h2d_inclusive"] = h2d
+        if klt:
+            out["optical_flow"] = klt
+        out.update(extras)
+        if skipped_legs:
+            out["skipped_legs"] = dict(legs=list(skipped_legs), reason=f"run older than --leg-budget-s {args.leg_budget_s:.0f} s")
+        if cpu and "value" in cpu:
+            out["gpu_over_cpu"] = round(fps / cpu["value"], 2)
+            out["gpu_over_cpu_all_cores"] = round(fps / cpu["all_cores"]["value"], 2)
+        return out
+
+    # ---- from here on everything is a side leg around a headline that is already measured: every leg is guarded, the line is
+    #      (re)assembled by emit() after each one (the N = 1 supervisor keeps the newest), legs are skipped when the run is too old
+    cpu = klt = verify = h2d = None
+    extras = {}
+    skipped_legs = []
+    g_head = gicp_results() if rank == 0 else []
+
+    def over_budget(leg):
+        if time.perf_counter() - t_start > args.leg_budget_s:
+            skipped_legs.append(leg)
+            return True
+        return False
+
+    def emit(final=False):
+        if rank != 0 or not (final or "GFS_BENCH_CHILD" in os.environ):
+            return
+        try:
+            line = json.dumps(assemble(), default=str)
+        except Exception as e:  # even a bug in the assembly must not cost the measured headline
+            line = json.dumps({"metric": "front-end frames/sec (ORB+match+GICP) on 640x480 RGBD", "value": round(fps, 2), "unit": "frames/s",
+                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                               "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                               "dtype": "u8/int32 (ORB, match) + f64 (GICP)", "data": "synthetic", "roofline": None, "cpu_baseline": None,
+                               "assemble_error": f"{type(e).__name__}: {e}"})
+        print(line, flush=True)
+
     # ---- dominant-kernel roofline: per-kernel HIP-event timing on the launch stream (extra, untimed steps, run one
     #      module at a time so that a kernel's events do not include waiting for kernels of other streams)
     roofline = None
     kern = {}
-    if rank == 0:
+    emit()  # the headline alone, before any side leg
+
+    def guarded(leg):
+        """The headline was measured before any side leg runs: a failing leg is recorded as {"error": ...} in its own object and the
+        JSON line is still printed with rc 0."""
+        try:
+            return leg()
+        except Exception as e:
+            import traceback
+            return dict(error=f"{type(e).__name__}: {e}", where=traceback.format_exc(limit=3).strip().splitlines()[-3:])
+
+    def committed_traffic(name, lps):
+        """HBM-side bytes per launch of kernel `name` from the newest COMPLETE committed PMC profile (profiles/r*_pmc_traffic_serial.json, written on
+        another box by profiles/collect.sh): NOT measured by this run, optional, never allowed to cost the line."""
+        return select_committed_traffic(os.environ.get("GFS_BENCH_PROFILES_DIR", os.path.join(ROOT, "profiles")), name, lps, B, args.workload)
+
+    def roofline_leg():
+        nonlocal kern
         api.profile_reset()
         api.profile_enable(True)
         nprof = 2
@@ -382,35 +559,22 @@ def main():
         ab_step = algorithmic_bytes_per_step(name, ctx)
         ab = ab_step / lps if ab_step else None
         ach = ab / avg_s / 1e9 if ab else None
-        traffic = None
-        traffic_raw = None
-        traffic_note = None
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_serial.json")))  # newest round last
-        pmc_all = json.load(open(pmcs[-1])) if pmcs else {}
-        if pmc_all.get("_batch_pairs") == B and args.workload == "c2":
-            t = pmc_all.get(name)
-            if t:  # HBM-side bytes per STEP measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)
-                # calibration (profiles/r03_calibration.json, kernels with known byte counts): FETCH_SIZE reports HALF the bytes of
-                # wide streaming reads (0.500), the full 64-byte line for a 32-byte gather that misses the caches (2.02 x the 32 bytes
-                # asked for), nothing for gathers served by the L2; WRITE_SIZE is exact (1.000)
-                traffic = int((2.0 * t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)
-                traffic_raw = int((t["fetch_kb_per_step"] + t["write_kb_per_step"]) * 1024 / lps)  # the counters as rocprofv3 prints them
-                traffic_note = (os.path.basename(pmcs[-1]) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, same batch, 1 lane, serial), "
-                                "(2 x FETCH_SIZE + WRITE_SIZE) KB*1024 per step / launches per step; the factor 2 is the measured under-count of "
-                                "streaming reads (profiles/r03_calibration.json) and over-counts the share of cache-missing gathers, which the counter "
-                                "reports in full: an upper bound of the HBM-side bytes")
-        roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 2) if ach else None, peak=HBM_PEAK_GBS, unit="GB/s",
+        tr = committed_traffic(name, lps)
+        traffic, traffic_raw, traffic_note, traffic_source = tr["traffic"], tr["traffic_raw_counters"], tr["note"], tr["source"]
+        return dict(bound="hbm", kernel=name, achieved=round(ach, 2) if ach else None, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 5) if ach else None, traffic=traffic, traffic_is_upper_bound=traffic is not None,
-                        traffic_raw_counters=traffic_raw, traffic_note=traffic_note,
+                        traffic_raw_counters=traffic_raw, traffic_source=traffic_source, traffic_note=traffic_note,
                         avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=lps,
                         algorithmic_bytes_per_launch=int(ab) if ab else None,
                         share_of_gpu_kernel_time=round(ms / tot, 3),
                         kernels_ms_per_step={k: round(v[0] / nprof, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])})
 
+    if rank == 0:
+        roofline = guarded(roofline_leg)
+        emit()
+
     # ---- CPU baseline: the oracle (CPU restatement; the reference itself cannot be built: OpenCV/Eigen absent)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    def cpu_leg():
         from oracle import oracle as O
         O.lib()
         ncores = os.cpu_count() or 1
@@ -450,16 +614,19 @@ def main():
         with ThreadPoolExecutor(max_workers=ncores) as ex:
             list(ex.map(one, range(nall)))
         dt_all = time.perf_counter() - t1
-        cpu = dict(value=round(nseq / dt_ref, 3), unit="frames/s", cores=8, kind="port",
+        return dict(value=round(nseq / dt_ref, 3), unit="frames/s", cores=8, kind="port",
                    sample=f"{nseq} VGA frame pairs processed one at a time with the reference's threading: ORB 1000 feats "
                           f"(OpenMP over 8 levels) + BF match 1000x1000 + GMS + GICP ~19k-pt clouds (4 threads, as hard-coded)",
                    all_cores=dict(value=round(nall / dt_all, 3), cores=ncores,
                                   sample=f"{nall} pairs on {ncores} worker threads, single-threaded oracle per pair"),
                    note="CPU restatement of the reference algorithm (reference not buildable here: OpenCV/Eigen/PCL absent)")
 
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = guarded(cpu_leg)
+        emit()
+
     # ---- the optical-flow stream next to the path: reported beside the metric, never part of `value`
-    klt = None
-    if rank == 0 and world == 1 and not args.no_klt:
+    if rank == 0 and world == 1 and not args.no_klt and not over_budget("optical_flow"):
         try:
             WIN = 35
             cap = lanes[0].cap
@@ -540,8 +707,8 @@ def main():
             klt = dict(error=f"{type(e).__name__}: {e}")
 
     # ---- the other SURVEY.md 8(d) figures, beside the metric (rank 0, N = 1): ORB only (configs[0]) and LBA windows (configs[4])
-    extras = {}
-    if rank == 0 and world == 1 and not args.no_extras:
+    emit()
+    if rank == 0 and world == 1 and not args.no_extras and not over_budget("orb_only/lba/c3/c4_shard"):
         try:
             # all lanes' extractors at once, each on its own stream (the way the headline step runs them), and one lane alone
             def _orb_pass(lns, reps):
@@ -722,7 +889,8 @@ def main():
 
     # ---- ONE live stream, a frame at a time, as System::TrackRGBD (src/System.cc:600) drives the path: ORB -> stereo from RGB-D ->
     #      depth -> cloud -> GICP against the previous cloud (gfs_gicp_align_next) -> SearchByProjection -> PoseOptimization
-    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2":
+    emit()
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2" and not over_budget("single_stream"):
         try:
             import bench_stream as bs
             Kc = synth.intrinsics(W, H)
@@ -764,8 +932,7 @@ def main():
             extras["single_stream"] = dict(error=f"{type(e).__name__}: {e}")
 
     # ---- verification of the TIMED batch's outputs against the CPU oracle (a sample; after the timed region)
-    verify = None
-    if rank == 0 and args.verify > 0 and not args.no_cpu_baseline and not args.gicp_stream:
+    def verify_leg():
         from oracle import oracle as O
         O.lib()
         step_overlapped()  # the same pass as the timed ones, outputs left in HBM
@@ -802,14 +969,17 @@ def main():
         with ThreadPoolExecutor(max_workers=min(len(picks), 16)) as ex:
             res = list(ex.map(check, picks))
         bad = [dict(pair=b, orb=o, match=m, gms=gm_, gicp=gi_, gicp_rel_err=e) for b, o, m, gm_, gi_, e in res if not (o and m and gm_ and gi_)]
-        verify = dict(verified_pairs=len(res) - len(bad), checked_pairs=len(res),
+        return dict(verified_pairs=len(res) - len(bad), checked_pairs=len(res),
                       checks="ORB key points + descriptors, BF matches, GMS mask bit-exact; GICP pose <= 1e-5 rel. Frobenius, iterations and converged equal",
                       max_gicp_rel_err=max(e for *_, e in res), failures=bad)
 
+    if rank == 0 and args.verify > 0 and not args.no_cpu_baseline and not args.gicp_stream and not over_budget("verify"):
+        verify = guarded(verify_leg)
+        emit()
+
     # ---- PCIe-inclusive figure (N = 1): images and depth maps start in pinned HOST memory every pass, the clouds are built on the
     #      device (Frame::ConvertDepthToPointCloud), the per-pair results come back to pinned host memory
-    h2d = None
-    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2" and not args.gicp_stream:
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2" and not args.gicp_stream and not over_budget("h2d_inclusive"):
         try:
             fx, fy, cx_, cy_ = synth.intrinsics(W, H)
             h_gray = torch.from_numpy(np.stack([pairs[i]["gray1"] for i in sel])).pin_memory()
@@ -964,43 +1134,7 @@ def main():
                 del ln.dd0, ln.dd1, ln.gg, ln.cc0, ln.cc1
         except Exception as e:
             h2d = dict(error=f"{type(e).__name__}: {e}")
-    if rank == 0:
-        g = gicp_results()
-        out = {
-            "metric": "front-end frames/sec (ORB+match+GICP) on 640x480 RGBD",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
-            "vs_baseline": None, "dtype": "u8/int32 (ORB, match) + f64 (GICP)", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: 640x480 RGBD frame pair, ORB extract (1000 feats, 8 levels) "
-                                    "+ BF Hamming match + GMS filter + GICP on ~19k-pt clouds (stride-4 depth grid)") if args.workload == "c2" else
-                                   ("BASELINE.json configs[2] (NOT the metric's configuration): 1280x720 RGBD frame pair, ORB extract (2000 feats, "
-                                    "8 levels) + BF Hamming match + GMS filter + GICP on ~37k-pt clouds (stride-5 depth grid)"),
-                       "batch_pairs_per_gpu": B, "lanes_per_gpu": nlanes, "hbm_in_use_gb": hbm_used_gb,
-                       "passes": "joined after every pass" if (args.step_join or args.serial) else "K passes per lane chain, joined once", "distinct_scenes_per_gpu": nd, "scene_seeds": f"{seed0}..{seed0 + nd - 1} (rank 0)",
-                       "scene_render_s": round(t_gen, 1), "global_batch_pairs": total_pairs,
-                       "parallelism": (f"one global batch of {args.batch} pairs cut into contiguous blocks over {world} rank(s), no collective"
-                                       if args.strong else f"frames sharded x{world}, no collective"),
-                       "gicp_mean_outer_iterations": round(float(np.mean([r["n_linearize"] for r in g])), 2),
-                       "gicp_mean_error_evals": round(float(np.mean([r["n_error_evals"] for r in g])), 2),
-                       "gicp_converged_frac": round(float(np.mean([r["converged"] for r in g])), 3)},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        if args.gicp_stream:
-            out["config"]["workload"] += " [EXPERIMENT --gicp-stream: target preprocessing reused from the previous call]"
-        if verify:
-            out["verified_pairs"] = verify["verified_pairs"]
-            out["verify"] = verify
-        if strong:
-            out["strong"] = strong
-        if h2d:
-            out["h2d_inclusive"] = h2d
-        if klt:
-            out["optical_flow"] = klt
-        out.update(extras)
-        if cpu:
-            out["gpu_over_cpu"] = round(fps / cpu["value"], 2)
-            out["gpu_over_cpu_all_cores"] = round(fps / cpu["all_cores"]["value"], 2)
-        print(json.dumps(out))
+    emit(final=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC counters of one kernel, per dispatch, over one serial step (counters in their own passes, no trace domains):
 #   gpurun -- 'bash profiles/pmc_kernel.sh k_gicp_linearize tag "SQ_WAVES SQ_INSTS_VALU ..." ["second set" ...]'
+export GFS_BENCH_NO_SUPERVISOR=1  # the profiler must see the process that launches the kernels
 set -u
 K=$1; TAG=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}

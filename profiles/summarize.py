@@ -45,15 +45,30 @@ for suffix in ("stats", "stats_serial"):
         shutil.copy(f, os.path.join(out, f"{tag}_kernel_{suffix}.csv"))
 
 traffic = {"_batch_pairs": int(os.environ.get("GFS_BENCH_BATCH", "512"))}  # bench.py's default --batch (the PMC passes use it)
+passes_with_rows = 0
 for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     acc, n = counters(os.path.join(out, f"{tag}_pmc_{c}"))
+    passes_with_rows += bool(acc)
     for k, v in acc.items():
         t = traffic.setdefault(k, {})
         launches = len(n[k])
         t[f"{key}_kb_per_launch"] = round(v[c] / launches, 1)
         t["launches_per_step"] = round(launches / nsteps, 2)
         t[f"{key}_kb_per_step"] = round(v[c] / nsteps, 1)
-json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_traffic_serial.json"), "w"), indent=1)
+# a traffic file is only worth keeping when BOTH passes produced rows for every kernel in it (round 4 committed one whose WRITE_SIZE pass
+# had been killed; bench.py read it and died): incomplete kernels are dropped, an incomplete collection writes nothing
+incomplete = [k for k, t in traffic.items() if not k.startswith("_") and not ("fetch_kb_per_step" in t and "write_kb_per_step" in t)]
+for k in incomplete:
+    del traffic[k]
+tpath = os.path.join(out, f"{tag}_pmc_traffic_serial.json")
+if passes_with_rows == 2 and len(traffic) > 1:
+    json.dump(traffic, open(tpath, "w"), indent=1)
+    if incomplete:
+        print("summarize.py: kernels seen by only one PMC pass, dropped:", incomplete, file=sys.stderr)
+else:
+    if os.path.exists(tpath):
+        os.remove(tpath)
+    print(f"summarize.py: NOT writing {os.path.basename(tpath)}: {passes_with_rows} of the 2 PMC passes produced rows", file=sys.stderr)
 
 sq = {}
 for d in ("pmc_sq", "pmc_sq2", "pmc_sq3"):

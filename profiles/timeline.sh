@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel timeline of the overlapped headline step: wall span, time with >= 1 / >= 2 / ... kernels in flight, per-kernel totals.
 #   gpurun -- 'bash profiles/timeline.sh tag [bench args]'
+export GFS_BENCH_NO_SUPERVISOR=1  # the profiler must see the process that launches the kernels
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Per-launch durations of one kernel over one serial step (1 lane, the whole batch per launch):
 #   gpurun -- 'bash profiles/trace_kernel.sh k_gicp_linearize tag [ENV=VALUE ...]'
+export GFS_BENCH_NO_SUPERVISOR=1  # the profiler must see the process that launches the kernels
 set -u
 K=$1; TAG=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,4 +1,5 @@
 # per-kernel totals of one serial step for a list of GFS_GICP_CELL values:  gpurun -- 'bash tools/cell_probe.sh 0.1 0.07 0.05'
+export GFS_BENCH_NO_SUPERVISOR=1  # the profiler must see the process that launches the kernels
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for C in "$@"; do

@@ -1,3 +1,4 @@
+export GFS_BENCH_NO_SUPERVISOR=1  # the profiler must see the process that launches the kernels
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for B in 64 128 256 512; do
