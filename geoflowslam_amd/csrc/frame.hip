@@ -103,6 +103,17 @@ struct gfs_frame {
   int res_rows = 0, res_cols = 0;  // size of the depth map resident in d_depth (gfs_frame_rgbd)
 };
 
+// Error paths of the host-pointer entries must not return while asynchronous copies into the CALLER's buffers (or out of a
+// stack variable) are still in flight on the handle's stream: armed after the first asynchronous operation, disarmed by the
+// regular synchronisation.
+struct StreamDrain {
+  hipStream_t s;
+  bool armed = true;
+  ~StreamDrain() {
+    if (armed) (void)hipStreamSynchronize(s);
+  }
+};
+
 extern "C" {
 
 int gfs_frame_create(int device, int max_rows, int max_cols, int max_keypoints, gfs_frame** out) {
@@ -166,15 +177,16 @@ int gfs_depth_convert_u16_batch_device(gfs_frame* h, const void* dev_depth_u16, 
 
 int gfs_depth_to_cloud(gfs_frame* h, const float* depth, int rows, int cols, int stride_elems, int downsample, float fx,
                        float fy, float cx, float cy, float* out_xyzw, int cap, int* n) {
-  if (h) h->res_rows = h->res_cols = 0;  // (d_depth is about to be overwritten or left stale)
   GFS_REQUIRE(h && n, GFS_ERR_INVALID_ARG, "gfs_depth_to_cloud: NULL argument");
   *n = 0;
   if (!depth || rows <= 0 || cols <= 0) return GFS_OK;  // "Depth image is empty": the reference returns without points
   GFS_REQUIRE(downsample > 0 && stride_elems >= cols && rows <= h->max_rows && cols <= h->max_cols, GFS_ERR_INVALID_ARG,
               "gfs_depth_to_cloud: invalid geometry");
   std::lock_guard<std::mutex> lk(h->mu);
+  h->res_rows = h->res_cols = 0;  // d_depth is about to be overwritten (under the lock: gfs_frame_rgbd(depth = NULL) reads these)
   GFS_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
+  StreamDrain drain{s};
   GFS_HIP(hipMemcpy2DAsync(h->d_depth.p, (size_t)cols * 4, depth, (size_t)stride_elems * 4, (size_t)cols * 4, rows,
                            hipMemcpyHostToDevice, s));
   const int maxpts = (int)h->d_cloud.n;
@@ -184,6 +196,7 @@ int gfs_depth_to_cloud(gfs_frame* h, const float* depth, int rows, int cols, int
   int cnt = 0;
   GFS_HIP(hipMemcpyAsync(&cnt, h->d_n.p, sizeof(int), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
+  drain.armed = false;
   *n = cnt;
   GFS_REQUIRE(cnt <= cap, GFS_ERR_CAPACITY, "gfs_depth_to_cloud: %d points exceed caller capacity %d", cnt, cap);
   if (cnt && out_xyzw) GFS_HIP(hipMemcpy(out_xyzw, h->d_cloud.p, (size_t)cnt * 16, hipMemcpyDeviceToHost));
@@ -208,13 +221,14 @@ int gfs_stereo_from_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps
                          int cols, int stride_elems, float bf, float* u_right, float* depth_out) {
   GFS_REQUIRE(h && n >= 0, GFS_ERR_INVALID_ARG, "gfs_stereo_from_rgbd: invalid argument");
   if (n == 0) return GFS_OK;
-  h->res_rows = h->res_cols = 0;
   GFS_REQUIRE(kps && depth && u_right && depth_out && rows > 0 && cols > 0 && stride_elems >= cols && rows <= h->max_rows &&
                   cols <= h->max_cols && n <= h->max_kp,
               GFS_ERR_INVALID_ARG, "gfs_stereo_from_rgbd: invalid argument or capacity");
   std::lock_guard<std::mutex> lk(h->mu);
+  h->res_rows = h->res_cols = 0;  // (under the lock, as in gfs_depth_to_cloud)
   GFS_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
+  StreamDrain drain{s};
   GFS_HIP(hipMemcpy2DAsync(h->d_depth.p, (size_t)cols * 4, depth, (size_t)stride_elems * 4, (size_t)cols * 4, rows,
                            hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemcpyAsync(h->d_kps.p, kps, (size_t)n * sizeof(gfs_keypoint), hipMemcpyHostToDevice, s));
@@ -226,6 +240,7 @@ int gfs_stereo_from_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps
   GFS_HIP(hipMemcpyAsync(u_right, h->d_ur.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(depth_out, h->d_vd.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
+  drain.armed = false;
   return GFS_OK;
 }
 
@@ -249,7 +264,9 @@ int gfs_frame_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x,
               "gfs_frame_rgbd: no resident %dx%d depth map on this handle", cols, rows);
   GFS_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
+  StreamDrain drain{s};
   if (depth) {
+    h->res_rows = h->res_cols = 0;
     GFS_HIP(hipMemcpy2DAsync(h->d_depth.p, (size_t)cols * 4, depth, (size_t)stride_elems * 4, (size_t)cols * 4, rows,
                              hipMemcpyHostToDevice, s));
     h->res_rows = rows;
@@ -274,6 +291,7 @@ int gfs_frame_rgbd(gfs_frame* h, const gfs_keypoint* kps, const float* kps_un_x,
     GFS_HIP(hipMemcpyAsync(&cnt, h->d_n.p, sizeof(int), hipMemcpyDeviceToHost, s));
   }
   GFS_HIP(hipStreamSynchronize(s));
+  drain.armed = false;
   *n_cloud = cnt;
   if (dev_cloud) *dev_cloud = h->d_cloud.p;
   if (dev_count) *dev_count = h->d_n.p;

@@ -291,7 +291,7 @@ constexpr int kCsE = 20, kCsRows = kCsE * 1024 / (16 * 64);  // rows of 64 eleme
 constexpr int kCsLdsBytes = kCsE * 1024 * 6 + 16 * 512 * 4;
 
 __global__ __launch_bounds__(1024) void k_cell_sort_lds(u64* __restrict__ keys0, unsigned* __restrict__ val0,
-                                                        const int* __restrict__ counts, int P, int* __restrict__ which,
+                                                        int* __restrict__ counts, int P, int* __restrict__ which,
                                                         int* __restrict__ kinfo, int only, int* __restrict__ n_left) {
   constexpr int kDB = 9, kNB = 1 << kDB;
   extern __shared__ __align__(16) unsigned char cs_lds[];
@@ -352,9 +352,16 @@ __global__ __launch_bounds__(1024) void k_cell_sort_lds(u64* __restrict__ keys0,
   const int bx = any_valid ? nbits(s_mx[0] - mnx) : 1, by = any_valid ? nbits(s_mx[1] - mny) : 1,
             bz = any_valid ? nbits(s_mx[2] - mnz) : 1;
   if (bx + by + bz > 32 || n > kCsE * 1024) {  // uniform: left to k_radix_sort (the caller launches it when the count says so)
+    // The kernels queued behind this one (cell build, grid fill, k-NN, the first LM rounds) run before the host sees *n_left: they
+    // must not walk an UNSORTED key array with stale bit widths.  The cloud is emptied for them (an empty cloud is a regular input);
+    // the caller's rerun (gicp_run, sort_all_kernels) rebuilds everything from the input points, this count included.
     if (tid == 0) {
       atomicAdd(n_left, 1);
       which[c] = 0;
+      counts[c] = 0;
+      int* ki = kinfo + 8 * c;
+      ki[0] = ki[1] = ki[2] = 0;
+      ki[3] = ki[4] = 1;
     }
     return;
   }
@@ -1098,8 +1105,11 @@ struct TopK {
 // Exactness: a key is the distance to within 2^-32; keys are compared, so two candidates whose distances agree in all but the last
 // 20 bits are ordered by index instead.  That can only matter at the boundary between the k-th and the (k+1)-th candidate -- the
 // reason for the eleventh slot: if those two keys share their high bits the query is handed to the deferred pass (exact sorted
-// insertion), otherwise every candidate outside the list is strictly farther than the k-th, as with exact comparisons.  Bounds
-// derived from a key use its upper end (low bits all ones).
+// insertion), otherwise every candidate outside the list is strictly farther than the k-th, as with exact comparisons: the SET of
+// the k neighbours is exact.  Their ORDER inside the list is (distance to 2^-32, then index): two neighbours whose distances
+// differ only below that come out in index order, and the covariance -- a sum over the list -- is then folded in another order
+// than the exact passes (and the reference) fold it: a last-bit difference of the covariance (tests hold it to 1e-9, the pose to
+// 1e-5), not a different neighbour set.  Bounds derived from a key use its upper end (low bits all ones).
 struct TopKey11 {
   static constexpr double kNone = 1.79769313486231570e308;  // above every key (distances are far below 1e300)
   double k[11];
@@ -3226,7 +3236,14 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   }
   GFS_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, (size_t)B * sizeof(PairState), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_m.p, h->d_m.p, (size_t)C2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (optimistic_sort) GFS_HIP(hipMemcpyAsync(h->h_ndone.p, h->d_ndone.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
+  if (optimistic_sort && h->h_ndone.p[1] > 0) {  // (the polls inside the loop normally catch this after round 0; never return such a result)
+    h->sort_all_kernels = true;
+    const int rc_again = gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
+    h->sort_all_kernels = false;
+    return rc_again;
+  }
   for (int b = 0; b < B; b++) {
     const PairState& S = h->h_state.p[b];
     gfs_gicp_result& r = out[b];

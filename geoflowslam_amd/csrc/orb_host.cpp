@@ -259,7 +259,7 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
     };
     const int cand[] = {4, 5, 6, 7, 8, 10, 12, 16, 24, 32, 48, 64};
     size_t budget = kPyrLdsBudget;
-    if (const char* e = getenv("GFS_ORB_PYR_LDS_KB")) budget = (size_t)std::max(8, atoi(e)) * 1024;  // tuning knob
+    if (const char* e = getenv("GFS_ORB_PYR_LDS_KB")) budget = std::min(kPyrLdsBudget, (size_t)std::max(8, atoi(e)) * 1024);  // tuning knob, never above what the kernel may allocate
     size_t xbytes = 16 * xt_start.size();
     for (int n : xt_n)
       if (n > 3) xbytes = 0;

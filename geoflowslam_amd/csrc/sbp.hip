@@ -412,27 +412,60 @@ __global__ __launch_bounds__(kSbpThreads) void k_sbp(const SbpPair* __restrict__
     return idx;
   };
   __syncthreads();
-  for (int round = 0;; round++) {
-    if (tid == 0) s_ctl[0] = 0;
-    __syncthreads();
-    bool changed = false;
-    for (int l = tid; l < NL; l += kSbpThreads) {
-      const int cur = round == 0 ? -3 : sel[l];
-      // mode 0: a proposal stands until a lower-index blocker takes its key-point, "nothing" stands for good (options only shrink);
-      // mode 1: the ratio test looks at the second best as well, so every round decides again
-      if (round > 0 && P.mode == 0 && (cur < 0 || s_block[cur] >= l)) continue;
-      const int now = decide(l);
-      if (now != cur) {
-        sel[l] = now;
-        changed = true;
+  if (P.mode == 1) {
+    // The ratio test makes a map point's choice depend on its SECOND best too, so a proposal can be withdrawn when a lower-index
+    // blocker takes the second best away (or hands it back): the blocker table is not monotone and must not remember withdrawn
+    // proposals.  Jacobi rounds: every map point decides from the blocker table of the previous round (read-only in this phase),
+    // then the table is rebuilt from the current proposals.  sel[l] depends only on the proposals of map points below l, so after
+    // round t the first t map points hold the sequential walk's choice for good: the fixed point is the reference's result, reached
+    // in (longest dependency chain) rounds, and no thread reads the table while another writes it.
+    for (int round = 0;; round++) {
+      if (tid == 0) s_ctl[0] = 0;
+      __syncthreads();
+      bool changed = false;
+      for (int l = tid; l < NL; l += kSbpThreads) {
+        const int cur = round == 0 ? -3 : sel[l];
+        const int now = decide(l);
+        if (now != cur) {
+          sel[l] = now;
+          changed = true;
+        }
       }
-      if (now >= 0 && s_hasobs[l] && atomicMin(&s_block[now], l) > l) changed = true;
+      if (changed) s_ctl[0] = 1;
+      __syncthreads();
+      const bool again = s_ctl[0] != 0;
+      if (!again) break;  // (uniform: every thread read the same flag after the barrier)
+      for (int i = tid; i < N; i += kSbpThreads) s_block[i] = 0x7fffffff;
+      __syncthreads();
+      for (int l = tid; l < NL; l += kSbpThreads) {
+        const int now = sel[l];
+        if (now >= 0 && s_hasobs[l]) atomicMin(&s_block[now], l);
+      }
+      __syncthreads();
     }
-    if (changed) s_ctl[0] = 1;
-    __syncthreads();
-    const bool again = s_ctl[0] != 0;
-    __syncthreads();
-    if (!again) break;
+  } else {
+    for (int round = 0;; round++) {
+      if (tid == 0) s_ctl[0] = 0;
+      __syncthreads();
+      bool changed = false;
+      for (int l = tid; l < NL; l += kSbpThreads) {
+        const int cur = round == 0 ? -3 : sel[l];
+        // a proposal stands until a lower-index blocker takes its key-point, "nothing" stands for good (options only shrink: a
+        // key-point's blocker index only ever decreases, so the unique fixed point does not depend on the order of the updates)
+        if (round > 0 && (cur < 0 || s_block[cur] >= l)) continue;
+        const int now = decide(l);
+        if (now != cur) {
+          sel[l] = now;
+          changed = true;
+        }
+        if (now >= 0 && s_hasobs[l] && atomicMin(&s_block[now], l) > l) changed = true;
+      }
+      if (changed) s_ctl[0] = 1;
+      __syncthreads();
+      const bool again = s_ctl[0] != 0;
+      __syncthreads();
+      if (!again) break;
+    }
   }
   SBP_T(3)
   // takes: every map point with a proposal (an overwritten take counts like the reference counts it); the key-point ends up with the
