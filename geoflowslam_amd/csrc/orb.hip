@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_area_hbm(const LevelDev* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fast_cells: one workgroup per FAST cell (reference src/ORBextractor.cc:788-842 calling cv::FAST on the
+// k_fast_cells: one WAVE per FAST cell (reference src/ORBextractor.cc:788-842 calling cv::FAST on the
 // cell sub-image).  The (w x h) cell tile is staged in LDS; for every interior pixel the arc score
 //      S = max over the 16 arcs of 9 contiguous ring pixels of min(v - ring)  (and of min(ring - v))
 // is evaluated once; a pixel is a FAST corner at threshold t iff S > t and OpenCV's cornerScore is S - 1.
@@ -451,246 +451,310 @@ __device__ __forceinline__ unsigned has9(unsigned m) {  // any run of >= 9 set b
   return r & 0xffffu;
 }
 
-__device__ __forceinline__ void ring_diffs(const uint8_t* __restrict__ c, int p, int* d) {
+// One polarity only.  The antipodal-pair pre-test says which polarity a pixel can be a corner of (a corner with 9 darker ring pixels
+// passes the DARK pair test), and a pixel cannot be a corner of both: two 9-arcs of a 16-ring overlap.  For the same reason the
+// score of a dark corner is its dark arc score alone: every 9-arc holds a pixel of the dark arc, where ring - v < -t < 0, so the
+// bright term of max(A, -Bm) stays below -t.  pol = 0: darker (ring < v - t), 1: brighter (ring > v + t).
+#define GFS_RING16_(F)                                                                                                     \
+  F(rp3[0]) F(rp3[1]) F(rp2[2]) F(rp1[3]) F(c[3]) F(rm1[3]) F(rm2[2]) F(rm3[1]) F(rm3[0]) F(rm3[-1]) F(rm2[-2]) F(rm1[-3]) \
+  F(c[-3]) F(rp1[-3]) F(rp2[-2]) F(rp3[-1])
+__device__ __forceinline__ bool arc_is_corner_pol(const uint8_t* __restrict__ c, int p, int th, int pol) {
   const int v = c[0];
-  d[0] = v - c[3 * p];
-  d[1] = v - c[3 * p + 1];
-  d[2] = v - c[2 * p + 2];
-  d[3] = v - c[p + 3];
-  d[4] = v - c[3];
-  d[5] = v - c[-p + 3];
-  d[6] = v - c[-2 * p + 2];
-  d[7] = v - c[-3 * p + 1];
-  d[8] = v - c[-3 * p];
-  d[9] = v - c[-3 * p - 1];
-  d[10] = v - c[-2 * p - 2];
-  d[11] = v - c[-p - 3];
-  d[12] = v - c[-3];
-  d[13] = v - c[p - 3];
-  d[14] = v - c[2 * p - 2];
-  d[15] = v - c[3 * p - 1];
-}
-
-// cheap test: is the pixel a FAST-9/16 corner at threshold th_low (9 contiguous ring pixels all darker or all brighter)?
-// One subtraction + one funnel shift per ring pixel and polarity: the sign bit of (ring - (v - t)) resp. ((v + t) - ring)
-// is shifted into a 16-bit mask (ring order reversed, which the cyclic run test does not care about).
-__device__ __forceinline__ bool arc_is_corner(const uint8_t* __restrict__ c, int p, int th_low) {
-  const int v = c[0], lo = v - th_low, hi = v + th_low;
+  const int sgn = pol ? -1 : 1, off = pol ? v + th : th - v;  // sign bit of sgn * ring + off: ring < v - th resp. ring > v + th
   const uint8_t *rm3 = c - 3 * p, *rm2 = c - 2 * p, *rm1 = c - p, *rp1 = c + p, *rp2 = c + 2 * p, *rp3 = c + 3 * p;
-  unsigned md = 0, mb = 0;
-#define GFS_RING_(px)                                                     \
-  {                                                                       \
-    const int cv_ = (px);                                                 \
-    md = __builtin_amdgcn_alignbit(md, (unsigned)(cv_ - lo), 31);         \
-    mb = __builtin_amdgcn_alignbit(mb, (unsigned)(hi - cv_), 31);         \
-  }
-  GFS_RING_(rp3[0]) GFS_RING_(rp3[1]) GFS_RING_(rp2[2]) GFS_RING_(rp1[3]) GFS_RING_(c[3]) GFS_RING_(rm1[3]) GFS_RING_(rm2[2])
-  GFS_RING_(rm3[1]) GFS_RING_(rm3[0]) GFS_RING_(rm3[-1]) GFS_RING_(rm2[-2]) GFS_RING_(rm1[-3]) GFS_RING_(c[-3])
-  GFS_RING_(rp1[-3]) GFS_RING_(rp2[-2]) GFS_RING_(rp3[-1])
+  unsigned m = 0;
+#define GFS_RING_(px) m = __builtin_amdgcn_alignbit(m, (unsigned)((int)(px) * sgn + off), 31);
+  GFS_RING16_(GFS_RING_)
 #undef GFS_RING_
-  return (has9(md) | has9(mb)) != 0;
+  return has9(m & 0xffffu) != 0;
 }
-
-// exact arc score S (max over the 16 arcs of 9 of min(v - ring) and of min(ring - v)): only evaluated for corners
-__device__ __forceinline__ int arc_score_full(const uint8_t* __restrict__ c, int p) {
+// S = max over the 16 arcs of 9 of min(d), d = v - ring (dark) resp. ring - v (bright)
+__device__ __forceinline__ int arc_score_pol(const uint8_t* __restrict__ c, int p, int pol) {
+  const int v = c[0];
+  const int sgn = pol ? 1 : -1, off = pol ? -v : v;
+  const uint8_t *rm3 = c - 3 * p, *rm2 = c - 2 * p, *rm1 = c - p, *rp1 = c + p, *rp2 = c + 2 * p, *rp3 = c + 3 * p;
   int d[16];
-  ring_diffs(c, p, d);
-  // sliding min / max over 9 cyclic neighbours by doubling
-  int lo[16], hi[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    lo[k] = min(d[k], d[(k + 1) & 15]);
-    hi[k] = max(d[k], d[(k + 1) & 15]);
+  {
+    int k = 0;
+#define GFS_RING_(px) d[k++] = (int)(px) * sgn + off;
+    GFS_RING16_(GFS_RING_)
+#undef GFS_RING_
   }
-  int lo4[16], hi4[16];
+  int lo[16], lo4[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    lo4[k] = min(lo[k], lo[(k + 2) & 15]);
-    hi4[k] = max(hi[k], hi[(k + 2) & 15]);
-  }
-  int A = -256, Bm = 256;
+  for (int k = 0; k < 16; k++) lo[k] = min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int l9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-    const int h9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-    A = max(A, l9);
-    Bm = min(Bm, h9);
-  }
-  return max(A, -Bm);
+  for (int k = 0; k < 16; k++) lo4[k] = min(lo[k], lo[(k + 2) & 15]);
+  int A = -256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) A = max(A, min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]));
+  return A;
+}
+#undef GFS_RING16_
+
+// k_fast_cells, round 5: ONE WAVE per cell, kFcWaves independent cells per workgroup, no workgroup barrier and no LDS atomic
+// anywhere.  Round 4's counters (profiles/r04h_pmc_sq.json: 902 M VALU wave-instructions per launch of 512 VGA frames = 3 055 per
+// cell, x 4 cycles / 1 024 SIMDs = 1.47 of the 1.585 ms) say the kernel is bound by VALU issue, not by latency: four waves per cell
+// each paid the loop and address overhead of every phase, a byte at a time.  Now
+//   phase 0  the antipodal-pair pre-test (9 contiguous ring pixels contain one pixel of every antipodal pair, so a corner has
+//            top|bottom AND left|right darker than v - t, or brighter than v + t) runs on FOUR pixels a lane from aligned LDS
+//            words: the five words (rows y-3, y, y+3; left / right windows by v_alignbyte) are split into even / odd bytes and
+//            compared as packed 16-bit pairs (v_pk_min/max_u16, v_pk_add/sub_i16): ~13 instructions a pixel slot, was ~30 + 5 LDS
+//            byte reads.  A lane keeps the pass bits of its 4-pixel groups (one column group, every rstep-th row) in one register;
+//   compact  one wave scan (DPP) of the per-lane counts, then every lane writes its own pixels' offsets;
+//   phase 1  the exact 9-arc mask test on dense lanes over that list (two entries a lane in flight), corners compacted in place
+//            by wave ballot;
+//   phase 2  exact arc scores of the corners, phase 3 the 3x3 NMS over the corner list, phase 4 rank = raster order, emit.
+// The workgroup -> (frame, cell) map is XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8 picks the
+// XCD and all cells of a frame (or of a contiguous part of a frame when there are fewer than 8 frames) run on ONE XCD, neighbouring
+// cells back to back: the 6-pixel overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched from HBM by
+// several XCDs (round 4: FETCH_SIZE 1.99 x the pixels).
+constexpr int kFcWaves = 4;
+
+typedef unsigned short fc_us2 __attribute__((ext_vector_type(2)));
+typedef short fc_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned fc_min(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(fc_us2, a), __builtin_bit_cast(fc_us2, b)));
+}
+__device__ __forceinline__ unsigned fc_max(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fc_us2, a), __builtin_bit_cast(fc_us2, b)));
+}
+__device__ __forceinline__ unsigned fc_add(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, (fc_s2)(__builtin_bit_cast(fc_s2, a) + __builtin_bit_cast(fc_s2, b)));
+}
+__device__ __forceinline__ unsigned fc_sub(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, (fc_s2)(__builtin_bit_cast(fc_s2, a) - __builtin_bit_cast(fc_s2, b)));
+}
+// sign bits (15, 31) of *dark / *bright set where the pixel of the pair passes the antipodal-pair pre-test of that polarity at
+// threshold t2 = t | t << 16
+__device__ __forceinline__ void fc_pair_test(unsigned T, unsigned Bt, unsigned L, unsigned R, unsigned v, unsigned t2, unsigned* dark,
+                                             unsigned* bright) {
+  const unsigned md = fc_max(fc_min(T, Bt), fc_min(L, R));  // darker: max(min(T,B), min(L,R)) < v - t
+  const unsigned mb = fc_min(fc_max(T, Bt), fc_max(L, R));  // brighter: min(max(T,B), max(L,R)) > v + t
+  *dark = fc_sub(fc_add(md, t2), v);
+  *bright = fc_sub(fc_add(v, t2), mb);
+}
+// the four sign bits of an even (pixels 0, 2) and an odd (pixels 1, 3) pair as a nibble
+__device__ __forceinline__ unsigned fc_nibble(unsigned fe, unsigned fo) {
+  const unsigned tt = ((fe >> 15) & 0x00010001u) | ((fo >> 14) & 0x00020002u);  // bits 0, 1 (pixels 0, 1) and 16, 17 (pixels 2, 3)
+  return (tt | (tt >> 14)) & 0xfu;
+}
+// wave-wide inclusive scan of a small non-negative count (row_shr 1, 2, 4, 8 inside the 16-lane rows, then the row totals)
+__device__ __forceinline__ int fc_wave_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+  return x;
+}
+__device__ __forceinline__ int fc_mbcnt(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+// everything a lane wrote to LDS is visible to the other lanes of ITS wave behind this point (one wave runs in lock step and the
+// LDS serves its instructions in order: only the compiler has to be kept from moving accesses across)
+__device__ __forceinline__ void fc_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kFastThreads = 256;  // a cell is ~900 pixels and a chain of short phases: small workgroups, many of them per CU
-__global__ __launch_bounds__(kFastThreads) void k_fast_cells(const LevelDev* __restrict__ levels,
-                                                    const CellDev* __restrict__ cells, Lvl0 l0,
-                                                    const uint8_t* __restrict__ pyr, size_t pyr_frame, int ini_th,
-                                                    int min_th, int n_cells, size_t slab_frame,
-                                                    uint32_t* __restrict__ slab, int* __restrict__ cell_cnt) {
+struct FastMap {  // workgroup id -> (frame, cell): see fast_map()
+  int units, parts, cells_per_part, grid;
+};
+inline FastMap fast_map(int B, int n_cells) {
+  FastMap M;
+  M.parts = 1;
+  while (B * M.parts < 8 && M.parts < 8) M.parts *= 2;  // fewer than 8 frames: a frame's cells are cut into contiguous parts
+  M.cells_per_part = (n_cells + M.parts - 1) / M.parts;
+  M.units = B * M.parts;
+  const int units_per_xcd = (M.units + 7) / 8;
+  const int wgs_per_xcd = (units_per_xcd * M.cells_per_part + kFcWaves - 1) / kFcWaves;
+  M.grid = 8 * wgs_per_xcd;
+  return M;
+}
+
+__global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __restrict__ cells, Lvl0 l0,
+                                                             const uint8_t* __restrict__ pyr, size_t pyr_frame, int ini_th,
+                                                             int min_th, int n_cells, FastMap M, int lds_wave, size_t slab_frame,
+                                                             uint32_t* __restrict__ slab, int* __restrict__ cell_cnt) {
   extern __shared__ __align__(16) uint8_t smem[];
-  __shared__ int s_count;
-  const int cell_id = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int b, cell_id;
+  {
+    const int id = blockIdx.x, xcd = id & 7;
+    const int slot = (id >> 3) * kFcWaves + wave;
+    const int k = slot / M.cells_per_part, c = slot - k * M.cells_per_part;
+    const int unit = k * 8 + xcd;
+    if (unit >= M.units) return;
+    b = unit / M.parts;
+    cell_id = (unit - b * M.parts) * M.cells_per_part + c;
+    if (cell_id >= n_cells) return;
+  }
   const CellDev C = cells[cell_id];
   const int w = C.w, h = C.h;
-  const int tid = threadIdx.x;
   const int dw = w - 6, dh = h - 6;
   if (dw <= 0 || dh <= 0) {
-    if (tid == 0) cell_cnt[(size_t)b * n_cells + cell_id] = 0;
+    if (lane == 0) cell_cnt[(size_t)b * n_cells + cell_id] = 0;
     return;
   }
-  // (the level's pitch and plane come with the cell's descriptor: levels[C.level] would be a second dependent load)
   const int sp = C.level == 0 ? l0.pitch : C.pitch;
   const uint8_t* src = C.level == 0 ? l0.base + (size_t)b * l0.frame_stride : pyr + (size_t)b * pyr_frame + C.plane_off;
-  // The tile is staged with aligned 4-byte loads when every row of the cell starts at the same offset `al` inside its word
-  // (all pyramid planes: pitch and plane offsets are multiples of 64; a caller's level 0 whenever its pitch is a multiple of
-  // 4 AND the plane itself starts on a word: the word loads reach back to the word boundary in front of a row, which lies
-  // inside the plane only then): row y of the cell then sits at tile0 + y * wp, wp = the row's words.  Otherwise byte by byte (wp = w).
+  // Rows of the tile are whole words.  With a word-aligned plane (every pyramid level; a caller's level 0 whose pitch and base are
+  // multiples of 4) a row is staged by aligned 4-byte loads from the word boundary in front of the cell, and pixel x of the cell sits
+  // at byte al + x of its row; otherwise the tile is staged byte by byte with al = 0.
   const bool words = (sp & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
   src += (size_t)C.y0 * sp + C.x0;
   const int al = words ? (int)(reinterpret_cast<uintptr_t>(src) & 3) : 0;
-  const int wp = words ? (al + w + 3) & ~3 : w;
-  uint8_t* tile = smem;                    // [h][wp]
-  uint8_t* sc = smem + (size_t)wp * h;     // [h][wp] arc score - 1 (0 = not a corner at the low threshold)
-  unsigned short* clist = reinterpret_cast<unsigned short*>(smem + (size_t)2 * wp * h);  // corner offsets (wp * h is a multiple of 4 or ...
-  if (!words) clist = reinterpret_cast<unsigned short*>(smem + (((size_t)2 * w * h + 3) & ~(size_t)3));  // ... rounded up here)
-  __shared__ int s_ncorner, s_nquick;
-  if (words) {
-    const int wpr = wp >> 2, total = wpr * h;
-    const uint8_t* src_al = src - al;
-    for (int i0 = tid; i0 < total; i0 += 4 * kFastThreads) {  // four loads in flight, then their stores
-      uint32_t v[4];
+  const int wp = (al + w + 3) & ~3, wpr = wp >> 2;
+  uint8_t* tile = smem + (size_t)wave * lds_wave;             // [h][wp] (+ one word in front: the left window of word 0 is masked, not unread)
+  uint8_t* sc = tile + (size_t)wp * h + 16;                   // [h][wp] arc score - 1 (0 = not a corner)
+  unsigned short* list = reinterpret_cast<unsigned short*>(sc + (size_t)wp * h + 16);  // [dw * dh] offsets: pre-test list, corners, survivors
+  // ---- staging: lanes as (row phase, word of the row); all loads of up to four passes in flight
+  {
+    const int rp = 64 / wpr;  // rows per pass (wpr <= 64: the host refuses wider cells)
+    const int ry = lane / wpr, x = lane - ry * wpr;
+    const bool on = ry < rp;
+    uint32_t* tw = reinterpret_cast<uint32_t*>(tile);
+    uint32_t* sw = reinterpret_cast<uint32_t*>(sc);
+    if (words) {
+      const uint8_t* src_al = src - al + 4 * x;
+      for (int y0 = 0; y0 < h; y0 += 4 * rp) {
+        uint32_t v[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int i = i0 + q * kFastThreads;
-        if (i < total) {
-          const int y = i / wpr, x = i - y * wpr;
-          v[q] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)y * sp + 4 * x);
+        for (int q = 0; q < 4; q++) {
+          const int y = y0 + q * rp + ry;
+          if (on && y < h) v[q] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)__mul24(y, sp));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int y = y0 + q * rp + ry;
+          if (on && y < h) {
+            tw[__mul24(y, wpr) + x] = v[q];
+            sw[__mul24(y, wpr) + x] = 0u;
+          }
         }
       }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int i = i0 + q * kFastThreads;
-        if (i < total) {
-          reinterpret_cast<uint32_t*>(tile)[i] = v[q];
-          reinterpret_cast<uint32_t*>(sc)[i] = 0u;
-        }
-      }
-    }
-  } else {
-    const int sy = kFastThreads / w, sx = kFastThreads - sy * w;  // raster step of one workgroup stride
-    int x = tid % w;
-    size_t g = (size_t)(tid / w) * sp + x;
-    for (int i = tid; i < w * h; i += kFastThreads) {
-      tile[i] = src[g];
-      sc[i] = 0;
-      x += sx;
-      g += (size_t)sy * sp + sx;
-      if (x >= w) {
-        x -= w;
-        g += sp - w;
+    } else {
+      for (int y = ry; on && y < h; y += rp) sw[y * wpr + x] = 0u;
+      for (int i = lane; i < w * h; i += 64) {
+        const int y = i / w, xx = i - y * w;
+        tile[y * wp + xx] = src[(size_t)y * sp + xx];
       }
     }
   }
-  tile += al;  // pixel (x, y) of the cell: tile[y * wp + x], and its score sc[y * wp + x]
-  sc += al;
-  if (tid == 0) {
-    s_count = 0;
-    s_ncorner = 0;
-    s_nquick = 0;
-  }
-  __syncthreads();
+  fc_wave_sync();
+  // ---- lane geometry of phase 0: column group gl (4 pixels = one word), rows 3 + rl + it * rstep
+  const int ua = al + 3, ub = al + w - 4;            // first / last detection byte of a row
+  const int gw0 = ua >> 2, ng = (ub >> 2) - gw0 + 1;  // word columns that hold detection pixels
+  const int rstep = 64 / ng;
+  const int rl = lane / ng, gl = lane - rl * ng;
+  const bool lane_on = rl < rstep;
+  const int u0 = 4 * (gw0 + gl);
+  unsigned vmask = 0;  // which of the word's four pixels are detection pixels
+#pragma unroll
+  for (int j = 0; j < 4; j++) vmask |= (u0 + j >= ua && u0 + j <= ub) ? (1u << j) : 0u;
+  if (!lane_on) vmask = 0;
   const int th_hi = min(max(ini_th, 0), 255), th_lo = min(max(min_th, 0), 255);
-  unsigned short* qlist = clist + (size_t)w * h;
-  unsigned short* klist = reinterpret_cast<unsigned short*>(smem);  // phase 3's output overwrites the tile (when there is any)
+  const float inv_wp = 1.0f / (float)wp;
   int nk = 0;
-  // FAST with iniThFAST and, only if the cell produced nothing, again with minThFAST (src/ORBextractor.cc:815-827): at the low
-  // threshold several times as many pixels are corners, and nearly every cell is settled by the first pass
+  // FAST with iniThFAST and, only if the cell produced nothing, again with minThFAST (src/ORBextractor.cc:815-827)
   for (int pass = 0; pass < 2; pass++) {
     const int th = pass == 0 ? th_hi : th_lo;
     const int T = max(th, 1);
-    if (pass == 1) {
-      if (tid == 0) {
-        s_ncorner = 0;
-        s_nquick = 0;
+    const unsigned t2 = (unsigned)th * 0x00010001u;
+    // ---- phase 0 + compaction, 8 row steps (32 pass bits a lane) at a time
+    int nq = 0;
+    for (int row0 = 0; row0 < dh; row0 += 8 * rstep) {
+      const int nit = min(8, (dh - row0 + rstep - 1) / rstep);
+      unsigned flags = 0, flagsb = 0;  // pass bits of the dark / bright pre-test, a nibble a row step
+      for (int it = 0; it < nit; it++) {
+        const int y = 3 + row0 + rl + it * rstep;
+        const int yy = min(y, h - 4);  // (rows past the cell: computed on a valid row, masked below)
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(tile) + __mul24(yy, wpr) + (gw0 + gl);  // (v_mul_lo_u32 is quarter rate)
+        const unsigned Tw = rw[-3 * wpr], Bw = rw[3 * wpr], Cw = rw[0], Cp = rw[-1], Cn = rw[1];
+        const unsigned Lw = __builtin_amdgcn_alignbyte(Cw, Cp, 1);  // bytes u0 - 3 .. u0
+        const unsigned Rw = __builtin_amdgcn_alignbyte(Cn, Cw, 3);  // bytes u0 + 3 .. u0 + 6
+        const unsigned kE = 0x00ff00ffu;
+        unsigned de, be, dod, bod;
+        fc_pair_test(Tw & kE, Bw & kE, Lw & kE, Rw & kE, Cw & kE, t2, &de, &be);                                          // pixels 0, 2
+        fc_pair_test((Tw >> 8) & kE, (Bw >> 8) & kE, (Lw >> 8) & kE, (Rw >> 8) & kE, (Cw >> 8) & kE, t2, &dod, &bod);  // pixels 1, 3
+        const unsigned vm = y > h - 4 ? 0u : vmask;
+        flags |= (fc_nibble(de, dod) & vm) << (4 * it);
+        flagsb |= (fc_nibble(be, bod) & vm) << (4 * it);
       }
-      __syncthreads();
-    }
-    // phase 0: the four compass points of the ring.  Nine contiguous ring pixels always contain at least two of them, so a
-    // corner at threshold th has two compass points darker than v - th or two brighter than v + th; the pixels that pass are
-    // compacted, wave by wave, into a list ...
-    {
-      const int sy = kFastThreads / dw, sx = kFastThreads - sy * dw;  // raster step of one workgroup stride
-      int xx = tid % dw, o = (tid / dw + 3) * wp + xx + 3;
-      const int total = dw * dh, lane = tid & 63;
-      for (int base = 0; base < total; base += kFastThreads) {
-        bool ok = false;
-        if (base + tid < total) {
-          const uint8_t* c = tile + o;
-          const int v = c[0], lo = v - th, hi = v + th;
-          const int a = c[3 * wp], b4 = c[3], e = c[-3 * wp], f = c[-3];
-          const int nd = (a < lo) + (b4 < lo) + (e < lo) + (f < lo), nb = (a > hi) + (b4 > hi) + (e > hi) + (f > hi);
-          ok = nd >= 2 || nb >= 2;
-        }
-        const unsigned long long m = __ballot(ok);
-        if (m) {
-          int at = 0;
-          if (lane == 0) at = atomicAdd(&s_nquick, (int)__popcll(m));
-          at = __shfl(at, 0, 64);
-          if (ok) qlist[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)o;
-        }
-        xx += sx;
-        o += sy * wp + sx;
-        if (xx >= dw) {
-          xx -= dw;
-          o += wp - dw;
-        }
+      const int cnt = __builtin_popcount(flags) + __builtin_popcount(flagsb);
+      const int incl = fc_wave_scan(cnt);
+      int pos = nq + incl - cnt;
+      nq += __builtin_amdgcn_readlane(incl, 63);
+      const int obase = (3 + row0 + rl) * wp + u0, ostep = rstep * wp;
+      while (flags) {  // an entry: offset of the pixel in the tile | polarity << 15
+        const int j = __builtin_ctz(flags);
+        flags &= flags - 1;
+        list[pos++] = (unsigned short)(obase + (j >> 2) * ostep + (j & 3));
       }
-    }
-    __syncthreads();
-    // ... phase 1: the 9-arc test on dense lanes over that list; corners (a few %) are compacted into a second list ...
-    {
-      const int nq = s_nquick;
-      for (int k = tid; k < nq; k += kFastThreads) {
-        const int o = qlist[k];
-        if (arc_is_corner(tile + o, wp, th)) clist[atomicAdd(&s_ncorner, 1)] = (unsigned short)o;
+      while (flagsb) {
+        const int j = __builtin_ctz(flagsb);
+        flagsb &= flagsb - 1;
+        list[pos++] = (unsigned short)((obase + (j >> 2) * ostep + (j & 3)) | 0x8000);
       }
     }
-    __syncthreads();
-    // ... phase 2: the expensive exact score runs on dense lanes over the corner list only
-    const int ncorner = s_ncorner;
-    for (int k = tid; k < ncorner; k += kFastThreads) {
-      const int o = clist[k];
-      sc[o] = (uint8_t)(arc_score_full(tile + o, wp) - 1);  // corner at th => S > th >= 0
+    fc_wave_sync();
+    // ---- phase 1: the 9-arc test over the list, corners compacted in place (a wave reads its 128 entries before it writes any)
+    int nc = 0;
+    for (int k0 = 0; k0 < nq; k0 += 128) {
+      const int ka = k0 + lane, kb = k0 + 64 + lane;
+      const bool ona = ka < nq, onb = kb < nq;
+      const int oa = ona ? list[ka] : 3 * wp + ua, ob = onb ? list[kb] : 3 * wp + ua;
+      const bool ca = arc_is_corner_pol(tile + (oa & 0x7fff), wp, th, oa >> 15) && ona;
+      const bool cb = arc_is_corner_pol(tile + (ob & 0x7fff), wp, th, ob >> 15) && onb;
+      const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
+      if (ca) list[nc + fc_mbcnt(ma)] = (unsigned short)oa;
+      nc += (int)__popcll(ma);
+      if (cb) list[nc + fc_mbcnt(mb)] = (unsigned short)ob;
+      nc += (int)__popcll(mb);
     }
-    __syncthreads();
-    // phase 3: 3x3 non-maximum suppression (scores below the threshold count as 0 outside the corner set, and the cell
-    // border is outside the detection area: nonmaxSuppression of cv::FAST on the cell image) over the corner list only.
-    // Survivors are collected unordered; with a survivor the tile is no longer needed and is reused for their offsets (at
-    // most one survivor per 2x2 block -> w*h/4 entries of 2 bytes).  The decisions are taken before the first offset is
-    // written (the arc tests above read the tile, this phase does not).
-    for (int k = tid; k < ncorner; k += kFastThreads) {
-      const int o = clist[k];
-      const int s = sc[o];
-      if (s < T) continue;
+    fc_wave_sync();
+    // ---- phase 2: exact scores of the corners
+    for (int k = lane; k < nc; k += 64) {
+      const int e = list[k], o = e & 0x7fff;
+      sc[o] = (uint8_t)(arc_score_pol(tile + o, wp, e >> 15) - 1);  // corner at th => S > th >= 0
+    }
+    fc_wave_sync();
+    // ---- phase 3: 3x3 strict-maximum suppression (scores below the threshold count as 0, the cell border is outside the
+    //      detection area: nonmaxSuppression of cv::FAST on the cell image); survivors compacted in place
+    nk = 0;
+    for (int k0 = 0; k0 < nc; k0 += 64) {
+      const int k = k0 + lane;
+      bool keep = false;
+      int o = 0;
+      if (k < nc) {
+        o = list[k] & 0x7fff;
+        const int s = sc[o];
 #define NB(off) ((int)sc[o + (off)] >= T ? (int)sc[o + (off)] : 0)
-      const bool keep = s > NB(-1) && s > NB(1) && s > NB(-wp - 1) && s > NB(-wp) && s > NB(-wp + 1) && s > NB(wp - 1) &&
-                        s > NB(wp) && s > NB(wp + 1);
+        keep = s >= T && s > NB(-1) && s > NB(1) && s > NB(-wp - 1) && s > NB(-wp) && s > NB(-wp + 1) && s > NB(wp - 1) &&
+               s > NB(wp) && s > NB(wp + 1);
 #undef NB
-      if (keep) klist[atomicAdd(&s_count, 1)] = (unsigned short)o;
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) list[nk + fc_mbcnt(m)] = (unsigned short)o;
+      nk += (int)__popcll(m);
     }
-    __syncthreads();
-    nk = s_count;
+    fc_wave_sync();
     if (nk > 0) break;
   }
-  // phase 4: raster order = ascending tile offset; every survivor finds its rank among the (few) survivors
+  // ---- phase 4: raster order = ascending offset; every survivor finds its rank among the (few) survivors
   uint32_t* out = slab + (size_t)b * slab_frame + C.slab_off;
-  const int offx = C.x0 - 16, offy = C.y0 - 16;  // + j*wCell, + i*hCell (src/ORBextractor.cc:847-848)
-  for (int k = tid; k < nk; k += kFastThreads) {
-    const int o = klist[k];
+  const int offx = C.x0 - 16 - al, offy = C.y0 - 16;  // + j*wCell, + i*hCell (src/ORBextractor.cc:847-848)
+  for (int k = lane; k < nk; k += 64) {
+    const int o = list[k];
     int r = 0;
-    for (int j = 0; j < nk; j++) r += klist[j] < o ? 1 : 0;
-    const int y = o / wp, x = o - y * wp;
+    for (int j = 0; j < nk; j++) r += list[j] < o ? 1 : 0;
+    const int y = (int)(((float)o + 0.5f) * inv_wp), x = o - y * wp;
     out[r] = (uint32_t)(x + offx) | ((uint32_t)(y + offy) << 12) | ((uint32_t)sc[o] << 24);
   }
-  if (tid == 0) cell_cnt[(size_t)b * n_cells + cell_id] = nk;
+  if (lane == 0) cell_cnt[(size_t)b * n_cells + cell_id] = nk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1943,6 +2007,8 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
   gfs::OrbGeometry G;
   G.build(h->P, rows, cols);
   GFS_REQUIRE(G.supported, GFS_ERR_UNSUPPORTED, "ORB geometry for %dx%d unsupported: %s", cols, rows, G.why);
+  GFS_REQUIRE(kFcWaves * G.fast_lds_wave <= 160 * 1024 && G.max_tile_w + 6 <= 256 && (G.max_tile_w + 6) * G.max_tile_h < 32768,
+              GFS_ERR_UNSUPPORTED, "FAST cell tile of %dx%d too large for LDS", cols, rows);
   GFS_REQUIRE(G.pyr_bytes <= h->cap_pyr && G.blur_bytes <= h->cap_blur && G.slab_entries <= h->cap_slab &&
                   G.cells.size() <= h->cap_cells && G.kp_cap <= h->cap_kp,
               GFS_ERR_CAPACITY, "image %dx%d needs more workspace than the handle reserved", cols, rows);
@@ -2010,10 +2076,10 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                h->d_yt_alpha.p);
   }
   // 2. FAST cells of all levels, all frames in one launch
-  // tile + score map (rows padded to whole words: k_fast_cells) + corner list (u16) + compass-test list (u16)
-  const size_t lds = 2 * (size_t)(G.max_tile_w + 6) * G.max_tile_h + 4 * (size_t)G.max_tile_w * G.max_tile_h + 8;
-  GFS_LAUNCH("k_fast_cells", k_fast_cells, dim3(n_cells, B), dim3(kFastThreads), lds, s, h->d_levels.p, h->d_cells.p, l0,
-             h->d_pyr.p, cap_pyr, h->P.ini_th, h->P.min_th, n_cells, cap_slab, h->d_slab.p, h->d_cell_cnt.p);
+  // per wave (= per cell): tile + score map (rows padded to whole words) + one list of offsets (u16), see k_fast_cells
+  const FastMap fm = fast_map(B, n_cells);
+  GFS_LAUNCH("k_fast_cells", k_fast_cells, dim3(fm.grid), dim3(64 * kFcWaves), (size_t)kFcWaves * G.fast_lds_wave, s, h->d_cells.p, l0,
+             h->d_pyr.p, cap_pyr, h->P.ini_th, h->P.min_th, n_cells, fm, (int)G.fast_lds_wave, cap_slab, h->d_slab.p, h->d_cell_cnt.p);
   const int* tp = kBlurTaps[h->P.blur_variant ? 1 : 0];
   if (h->device_octree && h->octree_supported) {
     // 3-6 (device): quadtree (it takes its level's candidates straight from the cell slabs), slot assignment, blur, orientation +
@@ -2166,7 +2232,8 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   G.build(h->P, cfg->max_rows, cfg->max_cols);
   GFS_REQUIRE(G.supported, GFS_ERR_UNSUPPORTED, "ORB geometry for max size %dx%d unsupported: %s", cfg->max_cols,
               cfg->max_rows, G.why);
-  GFS_REQUIRE(6 * (size_t)G.max_tile_w * G.max_tile_h + 8 <= 64000, GFS_ERR_UNSUPPORTED, "FAST cell tile too large for LDS");
+  GFS_REQUIRE(kFcWaves * G.fast_lds_wave <= 160 * 1024 && G.max_tile_w + 6 <= 256 && (G.max_tile_w + 6) * G.max_tile_h < 32768, GFS_ERR_UNSUPPORTED,
+              "FAST cell tile too large for LDS");
   const size_t B = cfg->max_batch;
   h->cap_pyr = G.pyr_bytes + 4096;
   h->cap_blur = G.blur_bytes + 4096;
@@ -2190,6 +2257,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   GFS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_area_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)gfs::OrbGeometry::kPyrLdsBudget));
   GFS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(kOctMaxNodes)));
+  GFS_HIP(hipFuncSetAttribute((const void*)k_fast_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   A(h->d_xt_start.alloc(tab_x));
   A(h->d_xt_n.alloc(tab_x));
   A(h->d_xt_alpha.alloc(tab_x * 4));

@@ -112,6 +112,7 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
   size_t pyr = 0, blur = 0, slab = 0;
   kp_cap = 0;
   max_tile_w = max_tile_h = 0;
+  fast_lds_wave = 0;
   for (int l = 0; l < p.nlevels; l++) {
     LevelDev& L = levels[l];
     // ComputePyramid, src/ORBextractor.cc:1228-1231
@@ -183,6 +184,10 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
         slab += c.slab_cap;
         max_tile_w = std::max(max_tile_w, (int)c.w);
         max_tile_h = std::max(max_tile_h, (int)c.h);
+        {  // k_fast_cells: rows of (3 + w + 3) & ~3 bytes at most (word alignment of the cell's first pixel), two maps + 16 bytes each, the list
+          const size_t wp = (size_t)((c.w + 6) & ~3), need = 2 * (wp * c.h + 16) + 2 * (size_t)dw * dh + 16;
+          fast_lds_wave = std::max(fast_lds_wave, (need + 15) & ~(size_t)15);
+        }
         cells.push_back(c);
       }
     }

@@ -92,7 +92,8 @@ struct OrbGeometry {
   size_t slab_entries = 0;               // per frame
   size_t cand_cap = 0;                   // dense candidate list capacity per frame (== slab_entries)
   int kp_cap = 0;                        // keypoint capacity per frame
-  int max_tile_w = 0, max_tile_h = 0;    // FAST cell tile bounds (for the LDS allocation)
+  int max_tile_w = 0, max_tile_h = 0;    // FAST cell tile bounds
+  size_t fast_lds_wave = 0;              // LDS bytes of one cell in k_fast_cells (tile + score map + offset list), the largest cell's
   bool supported = true;
   const char* why = "";
   void build(const OrbParams& p, int rows, int cols);
