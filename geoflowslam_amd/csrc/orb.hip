@@ -509,7 +509,19 @@ __device__ __forceinline__ int arc_score_pol(const uint8_t* __restrict__ c, int 
 // XCD and all cells of a frame (or of a contiguous part of a frame when there are fewer than 8 frames) run on ONE XCD, neighbouring
 // cells back to back: the 6-pixel overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched from HBM by
 // several XCDs (round 4: FETCH_SIZE 1.99 x the pixels).
-constexpr int kFcWaves = 4;
+#ifndef GFS_FC_WAVES
+#define GFS_FC_WAVES 4
+#endif
+constexpr int kFcWaves = GFS_FC_WAVES;
+#ifdef GFS_FAST_TIMING
+#define FC_T_INIT long long fc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fc_last = clock64();
+#define FC_T(k) { const long long _n = clock64(); fc_acc[k] += _n - fc_last; fc_last = _n; }
+#define FC_T_END(nq_, nc_, nk_) if (lane == 0 && (blockIdx.x % 257) == 0 && wave == 0) printf("FASTT lvl=%d stage=%lld p0=%lld compact=%lld arc=%lld score=%lld nms=%lld emit=%lld nq=%d nc=%d nk=%d\n", (int)C.level, fc_acc[0], fc_acc[1], fc_acc[2], fc_acc[3], fc_acc[4], fc_acc[5], fc_acc[6], nq_, nc_, nk_);
+#else
+#define FC_T_INIT
+#define FC_T(k)
+#define FC_T_END(a, b, c)
+#endif
 
 typedef unsigned short fc_us2 __attribute__((ext_vector_type(2)));
 typedef short fc_s2 __attribute__((ext_vector_type(2)));
@@ -539,6 +551,9 @@ __device__ __forceinline__ unsigned fc_nibble(unsigned fe, unsigned fo) {
   const unsigned tt = ((fe >> 15) & 0x00010001u) | ((fo >> 14) & 0x00020002u);  // bits 0, 1 (pixels 0, 1) and 16, 17 (pixels 2, 3)
   return (tt | (tt >> 14)) & 0xfu;
 }
+// a / n for 0 <= a < 4096, 1 <= n <= 256, by one reciprocal: (a + 0.5) / n is at least 0.5 / n away from an integer, far more than the
+// error of v_rcp_f32 and the product (the integer division sequence is ~20 instructions)
+__device__ __forceinline__ int fc_div(int a, int n) { return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)n)); }
 // wave-wide inclusive scan of a small non-negative count (row_shr 1, 2, 4, 8 inside the 16-lane rows, then the row totals)
 __device__ __forceinline__ int fc_wave_scan(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -593,6 +608,7 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
     if (cell_id >= n_cells) return;
   }
   const CellDev C = cells[cell_id];
+  FC_T_INIT
   const int w = C.w, h = C.h;
   const int dw = w - 6, dh = h - 6;
   if (dw <= 0 || dh <= 0) {
@@ -614,43 +630,50 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
   // ---- staging: lanes as (row phase, word of the row); all loads of up to four passes in flight
   {
     const int rp = 64 / wpr;  // rows per pass (wpr <= 64: the host refuses wider cells)
-    const int ry = lane / wpr, x = lane - ry * wpr;
+    const int ry = fc_div(lane, wpr), x = lane - ry * wpr;
     const bool on = ry < rp;
     uint32_t* tw = reinterpret_cast<uint32_t*>(tile);
     uint32_t* sw = reinterpret_cast<uint32_t*>(sc);
     if (words) {
-      const uint8_t* src_al = src - al + 4 * x;
-      for (int y0 = 0; y0 < h; y0 += 4 * rp) {
-        uint32_t v[4];
+      const uint8_t* gp = src - al + 4 * x + (size_t)__mul24(ry, sp);  // row ry, then rp rows further per load
+      const size_t gstep = (size_t)__mul24(rp, sp);
+      int li = __mul24(ry, wpr) + x;
+      const int lstep = __mul24(rp, wpr);
+      constexpr int kInFlight = 12;  // every load of a typical cell (<= 60 rows of <= 12 words) before the first store: ONE round trip
+      for (int y0 = ry; y0 < h; y0 += kInFlight * rp) {
+        uint32_t v[kInFlight];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int y = y0 + q * rp + ry;
-          if (on && y < h) v[q] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)__mul24(y, sp));
+        for (int q = 0; q < kInFlight; q++) {
+          if (on && y0 + q * rp < h) v[q] = *reinterpret_cast<const uint32_t*>(gp);
+          gp += gstep;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int y = y0 + q * rp + ry;
-          if (on && y < h) {
-            tw[__mul24(y, wpr) + x] = v[q];
-            sw[__mul24(y, wpr) + x] = 0u;
+        for (int q = 0; q < kInFlight; q++) {
+          if (on && y0 + q * rp < h) {
+            tw[li] = v[q];
+            sw[li] = 0u;
           }
+          li += lstep;
         }
       }
     } else {
       for (int y = ry; on && y < h; y += rp) sw[y * wpr + x] = 0u;
       for (int i = lane; i < w * h; i += 64) {
-        const int y = i / w, xx = i - y * w;
+        const int y = fc_div(i, w), xx = i - y * w;
         tile[y * wp + xx] = src[(size_t)y * sp + xx];
       }
     }
   }
   fc_wave_sync();
+  FC_T(0)
   // ---- lane geometry of phase 0: column group gl (4 pixels = one word), rows 3 + rl + it * rstep
   const int ua = al + 3, ub = al + w - 4;            // first / last detection byte of a row
   const int gw0 = ua >> 2, ng = (ub >> 2) - gw0 + 1;  // word columns that hold detection pixels
   const int rstep = 64 / ng;
-  const int rl = lane / ng, gl = lane - rl * ng;
+  int rl = fc_div(lane, ng);
+  const int gl = lane - rl * ng;
   const bool lane_on = rl < rstep;
+  if (!lane_on) rl = 0;  // (idle lanes walk the rows of row phase 0, masked: every LDS address stays where the active lanes read)
   const int u0 = 4 * (gw0 + gl);
   unsigned vmask = 0;  // which of the word's four pixels are detection pixels
 #pragma unroll
@@ -659,6 +682,7 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
   const int th_hi = min(max(ini_th, 0), 255), th_lo = min(max(min_th, 0), 255);
   const float inv_wp = 1.0f / (float)wp;
   int nk = 0;
+  [[maybe_unused]] int fc_nq = 0, fc_nc = 0;
   // FAST with iniThFAST and, only if the cell produced nothing, again with minThFAST (src/ORBextractor.cc:815-827)
   for (int pass = 0; pass < 2; pass++) {
     const int th = pass == 0 ? th_hi : th_lo;
@@ -669,10 +693,11 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
     for (int row0 = 0; row0 < dh; row0 += 8 * rstep) {
       const int nit = min(8, (dh - row0 + rstep - 1) / rstep);
       unsigned flags = 0, flagsb = 0;  // pass bits of the dark / bright pre-test, a nibble a row step
-      for (int it = 0; it < nit; it++) {
-        const int y = 3 + row0 + rl + it * rstep;
-        const int yy = min(y, h - 4);  // (rows past the cell: computed on a valid row, masked below)
-        const uint32_t* rw = reinterpret_cast<const uint32_t*>(tile) + __mul24(yy, wpr) + (gw0 + gl);  // (v_mul_lo_u32 is quarter rate)
+      // (rows past the cell, reached by the lanes of the last row phases in the last step, are read from what lies behind the tile
+      // inside this wave's LDS -- at most rstep + 3 rows, OrbGeometry::fast_lds_wave covers them -- and masked)
+      const uint32_t* rw = reinterpret_cast<const uint32_t*>(tile) + __mul24(3 + row0 + rl, wpr) + (gw0 + gl);
+      int y = 3 + row0 + rl;
+      for (int it = 0; it < nit; it++, y += rstep, rw += rstep * wpr) {
         const unsigned Tw = rw[-3 * wpr], Bw = rw[3 * wpr], Cw = rw[0], Cp = rw[-1], Cn = rw[1];
         const unsigned Lw = __builtin_amdgcn_alignbyte(Cw, Cp, 1);  // bytes u0 - 3 .. u0
         const unsigned Rw = __builtin_amdgcn_alignbyte(Cn, Cw, 3);  // bytes u0 + 3 .. u0 + 6
@@ -684,6 +709,7 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
         flags |= (fc_nibble(de, dod) & vm) << (4 * it);
         flagsb |= (fc_nibble(be, bod) & vm) << (4 * it);
       }
+      FC_T(1)
       const int cnt = __builtin_popcount(flags) + __builtin_popcount(flagsb);
       const int incl = fc_wave_scan(cnt);
       int pos = nq + incl - cnt;
@@ -699,6 +725,7 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
         flagsb &= flagsb - 1;
         list[pos++] = (unsigned short)((obase + (j >> 2) * ostep + (j & 3)) | 0x8000);
       }
+      FC_T(2)
     }
     fc_wave_sync();
     // ---- phase 1: the 9-arc test over the list, corners compacted in place (a wave reads its 128 entries before it writes any)
@@ -716,12 +743,16 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
       nc += (int)__popcll(mb);
     }
     fc_wave_sync();
+    fc_nq = nq;
+    fc_nc = nc;
+    FC_T(3)
     // ---- phase 2: exact scores of the corners
     for (int k = lane; k < nc; k += 64) {
       const int e = list[k], o = e & 0x7fff;
       sc[o] = (uint8_t)(arc_score_pol(tile + o, wp, e >> 15) - 1);  // corner at th => S > th >= 0
     }
     fc_wave_sync();
+    FC_T(4)
     // ---- phase 3: 3x3 strict-maximum suppression (scores below the threshold count as 0, the cell border is outside the
     //      detection area: nonmaxSuppression of cv::FAST on the cell image); survivors compacted in place
     nk = 0;
@@ -731,30 +762,55 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
       int o = 0;
       if (k < nc) {
         o = list[k] & 0x7fff;
-        const int s = sc[o];
-#define NB(off) ((int)sc[o + (off)] >= T ? (int)sc[o + (off)] : 0)
-        keep = s >= T && s > NB(-1) && s > NB(1) && s > NB(-wp - 1) && s > NB(-wp) && s > NB(-wp + 1) && s > NB(wp - 1) &&
-               s > NB(wp) && s > NB(wp + 1);
-#undef NB
+        const uint8_t* q = sc + o;
+        const int s = q[0];
+        // a neighbour below the threshold counts as 0, and s >= T is above every such neighbour: "s > max of the eight" says the same
+        const int m8 = max(max(max((int)q[-1], (int)q[1]), max((int)q[-wp - 1], (int)q[-wp])),
+                           max(max((int)q[-wp + 1], (int)q[wp - 1]), max((int)q[wp], (int)q[wp + 1])));
+        keep = s >= T && s > m8;
       }
       const unsigned long long m = __ballot(keep);
       if (keep) list[nk + fc_mbcnt(m)] = (unsigned short)o;
       nk += (int)__popcll(m);
     }
     fc_wave_sync();
+    FC_T(5)
     if (nk > 0) break;
   }
-  // ---- phase 4: raster order = ascending offset; every survivor finds its rank among the (few) survivors
+  // ---- phase 4: raster order = ascending offset.  The survivors mark their offsets in a bitmap (the tile is no longer needed: the
+  //      bitmap and the words' prefix counts take its place); a survivor's rank = set bits below its own.
   uint32_t* out = slab + (size_t)b * slab_frame + C.slab_off;
   const int offx = C.x0 - 16 - al, offy = C.y0 - 16;  // + j*wCell, + i*hCell (src/ORBextractor.cc:847-848)
-  for (int k = lane; k < nk; k += 64) {
-    const int o = list[k];
-    int r = 0;
-    for (int j = 0; j < nk; j++) r += list[j] < o ? 1 : 0;
-    const int y = (int)(((float)o + 0.5f) * inv_wp), x = o - y * wp;
-    out[r] = (uint32_t)(x + offx) | ((uint32_t)(y + offy) << 12) | ((uint32_t)sc[o] << 24);
+  if (nk > 0) {
+    const int nbw = (wp * h + 31) >> 5;  // bitmap words
+    uint32_t* bm = reinterpret_cast<uint32_t*>(tile);
+    unsigned short* pre = reinterpret_cast<unsigned short*>(bm + nbw);  // (wp * h / 8 + wp * h / 16 bytes <= wp * h)
+    for (int i = lane; i < nbw; i += 64) bm[i] = 0u;
+    fc_wave_sync();
+    for (int k = lane; k < nk; k += 64) {
+      const int o = list[k];
+      atomicOr(&bm[o >> 5], 1u << (o & 31));
+    }
+    fc_wave_sync();
+    int run = 0;
+    for (int i0 = 0; i0 < nbw; i0 += 64) {
+      const int i = i0 + lane;
+      const int c = i < nbw ? __builtin_popcount(bm[i]) : 0;
+      const int incl = fc_wave_scan(c);
+      if (i < nbw) pre[i] = (unsigned short)(run + incl - c);
+      run += __builtin_amdgcn_readlane(incl, 63);
+    }
+    fc_wave_sync();
+    for (int k = lane; k < nk; k += 64) {
+      const int o = list[k];
+      const int r = pre[o >> 5] + __builtin_popcount(bm[o >> 5] & ((1u << (o & 31)) - 1u));
+      const int y = (int)(((float)o + 0.5f) * inv_wp), x = o - y * wp;
+      out[r] = (uint32_t)(x + offx) | ((uint32_t)(y + offy) << 12) | ((uint32_t)sc[o] << 24);
+    }
   }
   if (lane == 0) cell_cnt[(size_t)b * n_cells + cell_id] = nk;
+  FC_T(6)
+  FC_T_END(fc_nq, fc_nc, nk)
 }
 
 // ------------------------------------------------------------------------------------------------

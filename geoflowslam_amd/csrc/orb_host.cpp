@@ -184,8 +184,12 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
         slab += c.slab_cap;
         max_tile_w = std::max(max_tile_w, (int)c.w);
         max_tile_h = std::max(max_tile_h, (int)c.h);
-        {  // k_fast_cells: rows of (3 + w + 3) & ~3 bytes at most (word alignment of the cell's first pixel), two maps + 16 bytes each, the list
-          const size_t wp = (size_t)((c.w + 6) & ~3), need = 2 * (wp * c.h + 16) + 2 * (size_t)dw * dh + 16;
+        if (dw > 0 && dh > 0) {
+          // k_fast_cells: rows of (3 + w + 3) & ~3 bytes at most (word alignment of the cell's first pixel), two maps + 16 bytes each and
+          // the offset list; phase 0 reads up to rstep + 3 (masked) rows past the tile, which must stay inside the wave's region
+          const size_t wp = (size_t)((c.w + 6) & ~3);
+          const size_t ng_min = (size_t)std::max(1, dw / 4), past = wp * (c.h + 64 / ng_min + 3) + 16;
+          const size_t need = std::max(2 * (wp * c.h + 16) + 2 * (size_t)dw * dh + 16, past);
           fast_lds_wave = std::max(fast_lds_wave, (need + 15) & ~(size_t)15);
         }
         cells.push_back(c);
