@@ -189,7 +189,7 @@ ABI_SYMBOLS = [
     "gfs_lba_solve_batch",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_depth_convert_u16_batch_device", "gfs_stereo_from_rgbd",
     "gfs_stereo_from_rgbd_batch_device",
-    "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize",
+    "gfs_pose_create", "gfs_pose_destroy", "gfs_pose_optimize", "gfs_pose_set_sum_order",
     "gfs_gms_create", "gfs_gms_destroy", "gfs_gms_inlier_mask", "gfs_gms_inlier_mask_batch_device",
     "gfs_sbp_create", "gfs_sbp_destroy", "gfs_search_by_projection", "gfs_search_by_projection_map",
     "gfs_klt_create", "gfs_klt_destroy", "gfs_klt_layout", "gfs_klt_pyramid_create", "gfs_klt_pyramid_destroy",
@@ -1003,9 +1003,14 @@ class PoseOptimizer:
     """ORB_SLAM3::Optimizer::PoseOptimization (reference include/Optimizer.h, src/Optimizer.cc:763-1098), conventional-SLAM
     branch, on flattened frames (gfs_pose_problem in include/gfs_abi.h).  A batch of frames is one kernel launch."""
 
-    def __init__(self, max_obs=4096, max_batch=64, device=0):
+    SUMS_TREE, SUMS_EDGE_ORDER = 0, 1  # GFS_POSE_SUMS_* (include/gfs_abi.h)
+
+    def __init__(self, max_obs=4096, max_batch=64, device=0, sums="tree"):
+        """sums: "tree" (the library's default: sums over the edges by a fixed-shape tree) or "edge_order" (g2o's order on one lane: the
+        bits of the sequential code, about twice the latency of a single frame)."""
         self.h = C.c_void_p()
         _check(lib().gfs_pose_create(device, max_obs, max_batch, C.byref(self.h)), "gfs_pose_create")
+        _check(lib().gfs_pose_set_sum_order(self.h, {"tree": 0, "edge_order": 1}[sums]), "gfs_pose_set_sum_order")
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

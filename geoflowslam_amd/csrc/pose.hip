@@ -261,6 +261,14 @@ __device__ __forceinline__ bool ldlt6_solve_positive(const double* H21, double l
   return true;
 }
 
+// kTree = false: every sum over the edges in edge order on one lane (the bits of the sequential restatement; a chain of n dependent
+//   additions, 21 cycles each, three times an LM iteration).
+// kTree = true (the default of the handle): the same terms added by a tree of FIXED shape -- a thread adds its own edges (e = tid,
+//   tid + 256, ...) in index order, then the 256 partial sums are folded by the wave shuffle tree and the four waves in order.  The
+//   shape depends on nothing but the number of edges, so a frame gives the same bits alone or inside any batch; against the
+//   restatement the sums differ in their last bits (relative 1e-16), the bar on the pose is 1e-5, and an outlier flag can only
+//   differ where an edge's chi2 sits within rounding of its threshold (tests/test_gpu_pose.py proves that for every flip).
+template <bool kTree>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __restrict__ frames, const double* __restrict__ xw_all,
                                                            const double* __restrict__ obs_all, const float* __restrict__ w_all,
                                                            const uint8_t* __restrict__ stereo_all, int stride,
@@ -350,6 +358,29 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     double T[7];
     for (int k = 0; k < 7; k++) T[k] = s_T[k];
     double chi = 0;
+    if constexpr (kTree) {
+      double mine = 0;
+      for (int e = tid; e < n; e += kPoseThreads) {
+        with_edge(e, [&](EdgeReg& R) {
+          if (!R.level) {
+            double r[3];
+            pose_edge_error(F, R, T, T + 4, r);
+            const double c = pose_edge_chi2(R, r);
+            R.err[0] = r[0];
+            R.err[1] = r[1];
+            R.err[2] = r[2];
+            R.chi2 = c;
+            double term = c;
+            if (robust) {
+              double r1;
+              huber(c, R.stereo ? dStereo : dMono, &term, &r1);
+            }
+            mine += term;
+          }
+        });
+      }
+      return block_sum256(mine, s4);
+    }
     for (int base = 0; base < n; base += kSlabDoubles) {
       const int cnt = min(kSlabDoubles, n - base);
       for (int e = base + tid; e < base + cnt; e += kPoseThreads) {
@@ -402,6 +433,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
         double T[7];
         for (int k = 0; k < 7; k++) T[k] = s_T[k];
         double run = 0;  // threads 0 .. 26: quantity tid, added up edge by edge
+        double tsum[kSys];  // kTree: the thread's own sums over its edges
+#pragma unroll
+        for (int k = 0; k < kSys; k++) tsum[k] = 0;
         for (int base = 0; base < n; base += kChunk) {
           const int e = base + tid;
           double acc[kSys];
@@ -473,12 +507,18 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
               }
             }
           });
+          if constexpr (kTree) {
 #pragma unroll
-          for (int k = 0; k < kSys; k++) s_slab[k * kSlabStride + tid] = acc[k];
-          __syncthreads();
-          if (tid < kSys) run = ordered_sum(s_slab + tid * kSlabStride, min(kChunk, n - base), run);
-          __syncthreads();
+            for (int k = 0; k < kSys; k++) tsum[k] += acc[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < kSys; k++) s_slab[k * kSlabStride + tid] = acc[k];
+            __syncthreads();
+            if (tid < kSys) run = ordered_sum(s_slab + tid * kSlabStride, min(kChunk, n - base), run);
+            __syncthreads();
+          }
         }
+        if constexpr (kTree) run = gfs_red::block_sum_many<kSys, kPoseThreads / 64>(tsum, s_slab);  // valid in threads 0 .. 26
         if (tid < kSys) s_sys[tid] = run;
         __syncthreads();
       }
@@ -583,6 +623,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       constexpr int kTerms = 2 * kSlabDoubles;
       int bad_local = 0, good_local = 0;
       float avg = 0.0f;  // thread 0
+      float mine_avg = 0.0f;  // kTree: the thread's inlier terms, mono list first, then the stereo list
       for (int pass = 0; pass < 2; pass++)
         for (int base = 0; base < n; base += kTerms) {
           const int cnt = min(kTerms, n - base);
@@ -599,12 +640,18 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
                 if (!out) term = c;
               }
             });
-            s_term[e - base] = term;
+            if constexpr (kTree) mine_avg += term;
+            else s_term[e - base] = term;
           }
-          __syncthreads();
-          if (tid == 0) avg = ordered_sum(s_term, cnt, avg);
-          __syncthreads();
+          if constexpr (!kTree) {
+            __syncthreads();
+            if (tid == 0) avg = ordered_sum(s_term, cnt, avg);
+            __syncthreads();
+          }
         }
+      if constexpr (kTree) {  // (float terms, exactly representable in double: summed in double and rounded once)
+        avg = (float)block_sum256((double)mine_avg, s4);
+      }
       nBad = (int)block_sum256((double)bad_local, s4);
       nGood += (int)block_sum256((double)good_local, s4);  // nGood is never reset between the rounds
       if (tid == 0) {
@@ -665,6 +712,7 @@ struct gfs_pose {
   }
   gfs::DevBuf<double> d_err;
   gfs::DevBuf<uint8_t> d_level;
+  int sum_order = GFS_POSE_SUMS_TREE;
 };
 
 extern "C" {
@@ -703,6 +751,14 @@ void gfs_pose_destroy(gfs_pose* h) {
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+int gfs_pose_set_sum_order(gfs_pose* h, int order) {
+  GFS_REQUIRE(h && (order == GFS_POSE_SUMS_TREE || order == GFS_POSE_SUMS_EDGE_ORDER), GFS_ERR_INVALID_ARG,
+              "gfs_pose_set_sum_order: invalid argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->sum_order = order;
+  return GFS_OK;
 }
 
 int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_pose_solution* solutions) {
@@ -753,10 +809,15 @@ int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_
   }
   hipStream_t s = h->stream;
   GFS_HIP(hipMemcpyAsync(h->d_in.p, h->h_in.p, L.in_bytes, hipMemcpyHostToDevice, s));
-  GFS_LAUNCH("k_pose_opt", k_pose_opt, dim3(B), dim3(kPoseThreads), 0, s, reinterpret_cast<const PoseFrame*>(h->d_in.p),
-             reinterpret_cast<const double*>(h->d_in.p + L.o_xw), reinterpret_cast<const double*>(h->d_in.p + L.o_obs),
-             reinterpret_cast<const float*>(h->d_in.p + L.o_w), (const uint8_t*)(h->d_in.p + L.o_st), S, h->d_res.p + L.r_outl,
-             reinterpret_cast<double*>(h->d_res.p + L.r_chi), h->d_err.p, h->d_level.p, reinterpret_cast<PoseOut*>(h->d_res.p));
+  auto launch = [&](auto kernel) -> int {
+    GFS_LAUNCH("k_pose_opt", kernel, dim3(B), dim3(kPoseThreads), 0, s, reinterpret_cast<const PoseFrame*>(h->d_in.p),
+               reinterpret_cast<const double*>(h->d_in.p + L.o_xw), reinterpret_cast<const double*>(h->d_in.p + L.o_obs),
+               reinterpret_cast<const float*>(h->d_in.p + L.o_w), (const uint8_t*)(h->d_in.p + L.o_st), S, h->d_res.p + L.r_outl,
+               reinterpret_cast<double*>(h->d_res.p + L.r_chi), h->d_err.p, h->d_level.p, reinterpret_cast<PoseOut*>(h->d_res.p));
+    return GFS_OK;
+  };
+  const int rc_launch = h->sum_order == GFS_POSE_SUMS_EDGE_ORDER ? launch(k_pose_opt<false>) : launch(k_pose_opt<true>);
+  if (rc_launch) return rc_launch;
   GFS_HIP(hipMemcpyAsync(h->h_res.p, h->d_res.p, L.res_bytes, hipMemcpyDeviceToHost, s));
   GFS_HIP(hipStreamSynchronize(s));
   for (int f = 0; f < B; f++) {

@@ -370,6 +370,15 @@ int gfs_pose_create(int device, int max_obs, int max_batch, gfs_pose** out);
 void gfs_pose_destroy(gfs_pose* h);
 /* B independent frames (host pointers), one workgroup per frame. */
 int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_pose_solution* solutions);
+/* How the sums over a frame's edges (activeRobustChi2, the 6x6 normal equations, the inliers' mean chi2) are added up.
+ *   GFS_POSE_SUMS_TREE (default): a tree of fixed shape -- deterministic, the same bits for a frame alone or inside any batch; against
+ *     g2o's edge-by-edge sums the last bits differ (the bar on the pose is 1e-5; an outlier flag can differ only for an edge whose chi2
+ *     sits within rounding of 5.991 / 7.815).
+ *   GFS_POSE_SUMS_EDGE_ORDER: g2o's order, edge after edge on one lane (core/sparse_optimizer.cpp:104-122, core/base_unary_edge.hpp:43-72):
+ *     every double as the sequential code computes it, ~2x the latency of a single frame. */
+#define GFS_POSE_SUMS_TREE 0
+#define GFS_POSE_SUMS_EDGE_ORDER 1
+int gfs_pose_set_sum_order(gfs_pose* h, int order);
 
 /* ============================================================================================
  * 7. ORBmatcher::SearchByProjection, frame to frame — the windowed matcher of TrackWithMotionModel

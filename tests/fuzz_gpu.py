@@ -160,7 +160,7 @@ T1 = time.time()
 extra = budget * 0.25
 nx = dict(sbp=0, pose=0, match=0, klt=0, fmat=0)
 pm = api.ProjectionMatcher(max_last=2048, max_cur=2560, max_batch=1)
-po = api.PoseOptimizer(max_obs=2048, max_batch=1)
+po = api.PoseOptimizer(max_obs=2048, max_batch=1, sums="edge_order")  # (the bit-for-bit comparison below is a statement about g2o's sum order)
 mt = api.ORBmatcher()
 fm = api.FundamentalMatcher(max_points=2048, max_batch=1)
 ext = api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=480, max_cols=640)

@@ -14,10 +14,29 @@ def _rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
 
 
-def _same(r, ro):
-    assert np.array_equal(r["outlier"], ro["outlier"])
-    assert r["n_inliers"] == ro["n_inliers"] and r["rounds_run"] == ro["rounds_run"]
-    assert r["iterations_run"] == ro["iterations_run"]
+SUMS = ["tree", "edge_order"]  # the handle's default (fixed-shape tree sums) and g2o's edge order (the restatement's bits)
+
+
+def _flips_are_proved_ties(r, ro):
+    """Tree sums differ from the edge-ordered ones in their last bits: an outlier flag may differ only for an edge whose chi2 sits
+    within rounding of its threshold.  Returns the number of flipped flags, every one of them proved to be such a tie."""
+    flip = np.flatnonzero(r["outlier"] != ro["outlier"])
+    for e in flip:
+        c = float(ro["chi2"][e])
+        assert min(abs(c - 5.991), abs(c - 7.815)) <= 1e-6 * 7.815, (int(e), c, float(r["chi2"][e]))
+    return len(flip)
+
+
+def _same(r, ro, sums="edge_order"):
+    if sums == "tree":
+        nflip = _flips_are_proved_ties(r, ro)
+        assert abs(r["n_inliers"] - ro["n_inliers"]) <= nflip and r["rounds_run"] == ro["rounds_run"]
+        # (the number of LM iterations is decided, at a converged state, by the sign of a gain ratio that is rounding noise)
+        assert abs(r["iterations_run"] - ro["iterations_run"]) <= 2
+    else:
+        assert np.array_equal(r["outlier"], ro["outlier"])
+        assert r["n_inliers"] == ro["n_inliers"] and r["rounds_run"] == ro["rounds_run"]
+        assert r["iterations_run"] == ro["iterations_run"]
     assert _rel(r["q"], ro["q"]) < 1e-5 and _rel(r["t"], ro["t"]) < 1e-5
     if len(ro["chi2"]):
         assert _rel(r["chi2"], ro["chi2"]) < 1e-6
@@ -30,20 +49,28 @@ def _same(r, ro):
 @pytest.mark.parametrize("cfg", [dict(seed=11, n_obs=300), dict(seed=12, n_obs=1000, outlier_frac=0.2),
                                  dict(seed=13, n_obs=120, mono_frac=1.0), dict(seed=14, n_obs=150, mono_frac=0.0),
                                  dict(seed=15, n_obs=40, rot_deg=3.0, trans=0.1)])
-def test_single_frame_matches_oracle(gpu_api, oracle, cfg):
+@pytest.mark.parametrize("sums", SUMS)
+def test_single_frame_matches_oracle(gpu_api, oracle, cfg, sums):
     p = synth.pose_frame(**cfg)
-    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=4)
-    _same(po.PoseOptimization(p), oracle.pose_optimization(p))
+    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=4, sums=sums)
+    _same(po.PoseOptimization(p), oracle.pose_optimization(p), sums)
 
 
-def test_ragged_batch_matches_oracle(gpu_api, oracle):
+@pytest.mark.parametrize("sums", SUMS)
+def test_ragged_batch_matches_oracle(gpu_api, oracle, sums):
     frames = [synth.pose_frame(100 + i, n_obs=n) for i, n in enumerate([300, 2, 8, 0, 777, 64, 10, 9])]
     frames[3] = dict(frames[3], xw=np.zeros((0, 3)), obs=np.zeros((0, 3)), inv_sigma2=np.zeros(0, np.float32),
                      stereo=np.zeros(0, np.uint8), n_obs=0)
-    po = gpu_api.PoseOptimizer(max_obs=1024, max_batch=8)
+    po = gpu_api.PoseOptimizer(max_obs=1024, max_batch=8, sums=sums)
     res = po.PoseOptimization(frames)
     for p, r in zip(frames, res):
-        _same(r, oracle.pose_optimization(p))
+        _same(r, oracle.pose_optimization(p), sums)
+    # a frame gives the same bits alone as inside the batch, whichever way its sums are folded
+    solo = gpu_api.PoseOptimizer(max_obs=1024, max_batch=1, sums=sums)
+    for p, r in zip(frames, res):
+        a = solo.PoseOptimization(p)
+        assert np.array_equal(a["outlier"], r["outlier"]) and np.array_equal(a["chi2"], r["chi2"]) and np.array_equal(a["q"], r["q"]) \
+            and np.array_equal(a["t"], r["t"]) and a["iterations_run"] == r["iterations_run"]
     assert res[1]["n_inliers"] == 0 and res[1]["rounds_run"] == 0  # < 3 correspondences
     assert res[2]["rounds_run"] == 1 and res[7]["rounds_run"] == 1  # < 10 edges: one round
     assert res[6]["rounds_run"] == 4
@@ -53,7 +80,7 @@ def test_all_outliers_and_capacity_errors(gpu_api, oracle):
     p = synth.pose_frame(9, n_obs=50, outlier_frac=1.0, outlier_px=200.0)
     po = gpu_api.PoseOptimizer(max_obs=64, max_batch=2)
     r = po.PoseOptimization(p)
-    _same(r, oracle.pose_optimization(p))
+    _same(r, oracle.pose_optimization(p), "tree")
     assert r["outlier"].all() and r["n_inliers"] == 0
     with pytest.raises(gpu_api.GfsError):
         po.PoseOptimization(synth.pose_frame(1, n_obs=65))
@@ -78,7 +105,7 @@ def test_random_frames_follow_the_oracle_bit_for_bit(gpu_api, oracle):
     (core/sparse_optimizer.cpp:104-122, core/base_unary_edge.hpp:43-72) and sin / cos / pow carry glibc's bits, so the LM
     iteration counts -- decided at a converged state by the sign of a gain ratio that is rounding noise -- the poses and the
     per-edge chi2 are the CPU restatement's, bit for bit."""
-    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1)
+    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1, sums="edge_order")
     differ = []
     for i in range(1200):
         rng = np.random.default_rng([77, i])
@@ -93,3 +120,27 @@ def test_random_frames_follow_the_oracle_bit_for_bit(gpu_api, oracle):
         if not same:
             differ.append((i, p["n_obs"], r["iterations_run"], ro["iterations_run"], _rel(r["q"], ro["q"]), _rel(r["t"], ro["t"])))
     assert not differ, differ[:10]
+
+
+def test_random_frames_with_tree_sums_meet_the_bar_or_have_a_proved_tie(gpu_api, oracle):
+    """The same 1 200 frames through the handle's default, fixed-shape tree sums: pose within 1e-5 (north_star's bar for BA poses; the
+    observed differences are ~1e-12), chi2 within 1e-6, and the integer outputs -- outlier flags, n_inliers -- equal to the
+    restatement's in at least 99.9 % of the frames, every flipped flag proved to belong to an edge whose chi2 sits within rounding of
+    its threshold (the same kind of rule as the k-th-distance ties of the GICP test)."""
+    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1)
+    frames_with_flips, worst = 0, 0.0
+    for i in range(1200):
+        rng = np.random.default_rng([77, i])
+        p = synth.pose_frame(int(rng.integers(0, 1 << 30)), n_obs=int(rng.integers(0, 1500)), mono_frac=float(rng.choice([0.0, 0.15, 1.0])),
+                             outlier_frac=float(rng.uniform(0, 0.4)), rot_deg=float(rng.uniform(0, 3)), trans=float(rng.uniform(0, 0.1)))
+        r, ro = po.PoseOptimization(p), oracle.pose_optimization(p)
+        nflip = _flips_are_proved_ties(r, ro)
+        frames_with_flips += nflip > 0
+        assert abs(r["n_inliers"] - ro["n_inliers"]) <= nflip and r["rounds_run"] == ro["rounds_run"], i
+        if p["n_obs"] >= 3:
+            worst = max(worst, _rel(r["q"], ro["q"]), _rel(r["t"], ro["t"]))
+            assert _rel(r["q"], ro["q"]) < 1e-5 and _rel(r["t"], ro["t"]) < 1e-5, (i, _rel(r["q"], ro["q"]), _rel(r["t"], ro["t"]))
+            if len(ro["chi2"]):
+                assert _rel(r["chi2"], ro["chi2"]) < 1e-6, i
+    assert frames_with_flips <= 1, frames_with_flips  # >= 99.9 % of 1 200 frames
+    assert worst < 1e-7, worst
