@@ -3164,11 +3164,11 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   const int far2_chunks = std::max(1, std::min(32, knn_chunks));  // a handful of queries per cloud (a few dozen in the worst scenes), a workgroup each
   static const bool far2_groups = getenv("GFS_GICP_FAR2") && strcmp(getenv("GFS_GICP_FAR2"), "groups") == 0;  // the lane-group form
   if (far2_groups)
-    GFS_LAUNCH("k_knn_cov_far2", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(4, B, 2)), dim3(256), 0, s, h->d_pts.p,
+    GFS_LAUNCH("k_knn_cov_far_groups", (k_knn_cov_far<64, 4, false>), dim3(xcd_grid(4, B, 2)), dim3(256), 0, s, h->d_pts.p,
                h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p,
                h->d_hard_d.p, h->d_far2.p, 4, B, P, prm, h->d_cov6.p);
   else
-    GFS_LAUNCH("k_knn_cov_far2", k_knn_cov_far_wg, dim3(xcd_grid(far2_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p, h->d_ucell.p,
+    GFS_LAUNCH("k_knn_cov_far_wg", k_knn_cov_far_wg, dim3(xcd_grid(far2_chunks, B, 2)), dim3(256), 0, s, h->d_pts.p, h->d_ucell.p,
                h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p, h->d_hard_d.p,
                h->d_far2.p, far2_chunks, B, P, prm, h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter

@@ -24,7 +24,7 @@ def kname(full):
     k = m.group(1)
     t = re.search(r"k_knn_cov_far<(\d+)", full)
     if t:
-        k = "k_knn_cov_far" if t.group(1) == "16" else "k_knn_cov_far2"
+        k = "k_knn_cov_far" if t.group(1) == "16" else "k_knn_cov_far_groups"
     return k
 
 
