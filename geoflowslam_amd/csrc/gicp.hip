@@ -1849,6 +1849,18 @@ __device__ __forceinline__ void wave_reduce_store(double (&vals)[N], double* __r
   const int lane = threadIdx.x & 63;
   if (lane < N) dst_block[wave * N + lane] = tot;
 }
+// ... a batch of N <= 16 values whose places in the block's kRed-vector are given by `map`
+template <int N>
+__device__ __forceinline__ void wave_reduce_store_map(double (&vals)[N], const int (&map)[N], double* __restrict__ dst_block, int wave) {
+  const double tot = gfs_red::wave_sum_many<N>(vals);
+  const int lane = threadIdx.x & 63;
+  if (lane < N) {
+    int at = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) at = lane == k ? map[k] : at;
+    dst_block[wave * kRed + at] = tot;
+  }
+}
 // A 256-point chunk of a cloud is one workgroup of four waves, or -- the search kernels that need no LDS -- four workgroups of one
 // wave (a CU takes a new workgroup only when all its waves fit: one-wave workgroups fill the slots that finished waves leave).
 // `chunk` comes in as the launch block's index within the pair; returns the lane's point and its wave's slot of the chunk.
@@ -2170,6 +2182,125 @@ __device__ __forceinline__ int lin_stage_tile(LinTile& T, bool inrange, int cx, 
   return 0;
 }
 
+// ---- the factor of one correspondence (factors/gicp_factor.hpp:52-73), round 5.
+// With J = [R skew(p) | -R] = R [S | -I] (S = skew(p), twist order rotation, translation) the quadratic form is
+//   J' M J = [S | -I]' N [S | -I],  N = R' M R,  J' M r = [S | -I]' u,  u = N w,  w = R' r,  r' M r = w' u
+// so only N (6), Q = N S (9: each column two products, S has two non-zeros a column), the cross products Q(:,c) x p and u x p are
+// formed -- ~100 fused multiply-adds behind the Mahalanobis matrix instead of the ~175 of the dense J, M J, J' (M J) -- and, what
+// matters more, the state that has to stay in registers between the search and the reduction is N, Q, p, u, w (48 VGPRs) instead of
+// J, M J and 29 accumulators: the kernel fits 80 VGPRs = 6 waves a SIMD (112 = 4 before), and the search, a chain of dependent
+// look-ups, is paid in occupancy.  The wave reduction runs in two batches for the same reason (B first: it needs p, u, w; A is N
+// and Q themselves).  M = (Ct + R Cs R')^-1 is formed exactly as before (k_gicp_error reads it).  Same sums of the same kind of
+// terms: the results differ from round 4's in their last bits (the bar on the pose is 1e-5, batched = single stays bit for bit).
+struct LinFactor {
+  double N[6];  // xx xy xz yy yz zz
+  double Q[9];  // column-major N S
+  double px, py, pz, u[3], w[3];
+  bool on;
+};
+// index of each batch value in the 29-vector (upper H row-major over (r, c >= r), then b, e, count)
+__device__ constexpr int kLinMapA[15] = {3, 8, 12, 4, 9, 13, 5, 10, 14, 15, 16, 17, 18, 19, 20};  // H_rt (column-major of -Q'), H_tt
+__device__ constexpr int kLinMapB[14] = {0, 1, 2, 6, 7, 11, 21, 22, 23, 24, 25, 26, 27, 28};       // H_rr, b, e, count
+__device__ __forceinline__ void lin_factor_prepare(int i, const double4 p, double tx, double ty, double tz, int ti, const double* __restrict__ T12,
+                                                   int pair, int cs, int ct, int P, const double4* __restrict__ pts,
+                                                   const double* __restrict__ cov6, double* __restrict__ maha6, LinFactor& F) {
+  // The bar for GICP is 1e-5 on the pose (the sums are re-associated by the reduction tree anyway): fused multiply-adds here; the
+  // search stays un-contracted so that the correspondences are decided on the same distances as in the oracle.
+#pragma clang fp contract(fast)
+  F.on = ti >= 0;
+  if (!F.on) return;
+  const double* R = T12;
+  const double4* tp = pts + (size_t)ct * P;
+  const double* Cs = cov6 + ((size_t)cs * P + i) * 6;
+  const double* Ct = cov6 + ((size_t)ct * P + ti) * 6;
+  const double cs9[9] = {Cs[0], Cs[1], Cs[2], Cs[1], Cs[3], Cs[4], Cs[2], Cs[4], Cs[5]};
+  double RC[9];
+  for (int cc = 0; cc < 3; cc++)
+    for (int r = 0; r < 3; r++) RC[r + 3 * cc] = R[r] * cs9[3 * cc] + R[r + 3] * cs9[3 * cc + 1] + R[r + 6] * cs9[3 * cc + 2];
+  const double ct9[9] = {Ct[0], Ct[1], Ct[2], Ct[1], Ct[3], Ct[4], Ct[2], Ct[4], Ct[5]};
+  double A[9];
+  for (int cc = 0; cc < 3; cc++)
+    for (int r = 0; r < 3; r++) A[r + 3 * cc] = ct9[r + 3 * cc] + (RC[r] * R[cc] + RC[r + 3] * R[cc + 3] + RC[r + 6] * R[cc + 6]);
+  double M[9];
+  inv3(A, M);
+  double* mo = maha6 + ((size_t)pair * P + i) * 6;
+  mo[0] = M[0];
+  mo[1] = M[3];
+  mo[2] = M[6];
+  mo[3] = M[4];
+  mo[4] = M[7];
+  mo[5] = M[8];
+  const double4 q = tp[ti];
+  const double res[3] = {q.x - tx, q.y - ty, q.z - tz};
+  double MR[9];  // M R
+  for (int cc = 0; cc < 3; cc++)
+    for (int r = 0; r < 3; r++) MR[r + 3 * cc] = M[r] * R[3 * cc] + M[r + 3] * R[3 * cc + 1] + M[r + 6] * R[3 * cc + 2];
+  // N = R' (M R), upper triangle
+  auto rtm = [&](int a, int b) { return R[3 * a] * MR[3 * b] + R[3 * a + 1] * MR[3 * b + 1] + R[3 * a + 2] * MR[3 * b + 2]; };
+  F.N[0] = rtm(0, 0);
+  F.N[1] = rtm(0, 1);
+  F.N[2] = rtm(0, 2);
+  F.N[3] = rtm(1, 1);
+  F.N[4] = rtm(1, 2);
+  F.N[5] = rtm(2, 2);
+  const double n9[9] = {F.N[0], F.N[1], F.N[2], F.N[1], F.N[3], F.N[4], F.N[2], F.N[4], F.N[5]};  // (symmetric: rows = columns)
+  for (int k = 0; k < 3; k++) F.w[k] = R[3 * k] * res[0] + R[3 * k + 1] * res[1] + R[3 * k + 2] * res[2];
+  for (int r = 0; r < 3; r++) F.u[r] = n9[r] * F.w[0] + n9[r + 3] * F.w[1] + n9[r + 6] * F.w[2];
+  F.px = p.x;
+  F.py = p.y;
+  F.pz = p.z;
+  // Q = N S, S = skew(p): S e0 = (0, pz, -py), S e1 = (-pz, 0, px), S e2 = (py, -px, 0)
+  for (int r = 0; r < 3; r++) {
+    F.Q[r] = p.z * n9[r + 3] - p.y * n9[r + 6];
+    F.Q[r + 3] = p.x * n9[r + 6] - p.z * n9[r];
+    F.Q[r + 6] = p.y * n9[r] - p.x * n9[r + 3];
+  }
+}
+// batch B: H_rr = S' N S = Q(:,c) x p (upper triangle), b = (u x p, -u), e = w' u / 2, inlier count
+__device__ __forceinline__ void lin_factor_batch_b(const LinFactor& F, double (&v)[14]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+  for (int k = 0; k < 14; k++) v[k] = 0;
+  if (!F.on) return;
+  // (a x p)_0 = a1 pz - a2 py, _1 = a2 px - a0 pz, _2 = a0 py - a1 px
+  v[0] = F.Q[1] * F.pz - F.Q[2] * F.py;  // H(0,0): (Q(:,0) x p)_0
+  v[1] = F.Q[4] * F.pz - F.Q[5] * F.py;  // H(0,1): (Q(:,1) x p)_0
+  v[2] = F.Q[7] * F.pz - F.Q[8] * F.py;  // H(0,2)
+  v[3] = F.Q[5] * F.px - F.Q[3] * F.pz;  // H(1,1): (Q(:,1) x p)_1
+  v[4] = F.Q[8] * F.px - F.Q[6] * F.pz;  // H(1,2)
+  v[5] = F.Q[6] * F.py - F.Q[7] * F.px;  // H(2,2): (Q(:,2) x p)_2
+  v[6] = F.u[1] * F.pz - F.u[2] * F.py;
+  v[7] = F.u[2] * F.px - F.u[0] * F.pz;
+  v[8] = F.u[0] * F.py - F.u[1] * F.px;
+  v[9] = -F.u[0];
+  v[10] = -F.u[1];
+  v[11] = -F.u[2];
+  v[12] = 0.5 * (F.w[0] * F.u[0] + F.w[1] * F.u[1] + F.w[2] * F.u[2]);
+  v[13] = 1.0;
+}
+// batch A: H_rt = -S' N = -Q' as its entries (r, 3 + c) = -Q(c, r), and H_tt = N
+__device__ __forceinline__ void lin_factor_batch_a(const LinFactor& F, double (&v)[15]) {
+#pragma unroll
+  for (int k = 0; k < 15; k++) v[k] = 0;
+  if (!F.on) return;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) v[3 * c + r] = -F.Q[c + 3 * r];  // value 3 c + r -> H(r, 3 + c), kLinMapA
+#pragma unroll
+  for (int k = 0; k < 6; k++) v[9 + k] = F.N[k];
+}
+// the 29-vector of a point (callers that reduce all of it at once)
+__device__ __forceinline__ void lin_factor_accumulate(const LinFactor& F, double (&acc)[kRed]) {
+  double a[15], b[14];
+  lin_factor_batch_a(F, a);
+  lin_factor_batch_b(F, b);
+#pragma unroll
+  for (int k = 0; k < 15; k++) acc[kLinMapA[k]] += a[k];
+#pragma unroll
+  for (int k = 0; k < 14; k++) acc[kLinMapB[k]] += b[k];
+}
+
 // GICPFactor::linearize (factors/gicp_factor.hpp:35-73) of source point i of a pair under the pose T12 (R col-major | t): exact
 // 1-NN in the target cloud (through `src`), rejection beyond max_dist, the Mahalanobis matrix, and this point's terms ADDED to
 // acc (H upper triangle 21, b 6, e, inlier count).  Records the correspondence and the matrix for the error evaluations that follow.
@@ -2181,9 +2312,8 @@ __device__ __forceinline__ void gicp_lin_point(const Src& src, int i, const doub
                                                const u64* __restrict__ ucell, const unsigned* __restrict__ ubegin,
                                                const int* __restrict__ n_ucell, const unsigned* __restrict__ G,
                                                const int* __restrict__ gi, const GicpParams& prm, int* __restrict__ tgt_index,
-                                               double* __restrict__ maha6, double (&acc)[kRed]) {
+                                               double* __restrict__ maha6, LinFactor& F) {
   {
-    const double* R = T12;
     const double4* tp = pts + (size_t)ct * P;
     const u64* uc = ucell + (size_t)ct * (P + 1);
     const unsigned* ub = ubegin + (size_t)ct * (P + 1);
@@ -2248,57 +2378,12 @@ __device__ __forceinline__ void gicp_lin_point(const Src& src, int i, const doub
       }
       }
     }
-    int ti = -1;
-    if (bj >= 0 && !(best > prm.max_dist_sq)) {  // DistanceRejector: reject iff sq_dist > max_dist_sq
-      // The factor is ~900 double-precision multiplies and adds per point, and FP64 issues at half rate: fused multiply-adds
-      // halve them.  The bar for GICP is 1e-5 on the pose (the sums are re-associated by the reduction tree anyway); the
-      // search above stays un-contracted so that the correspondences are decided on the same distances as in the oracle.
-#pragma clang fp contract(fast)
-      ti = bj;
-      const double* Cs = cov6 + ((size_t)cs * P + i) * 6;
-      const double* Ct = cov6 + ((size_t)ct * P + bj) * 6;
-      const double cs9[9] = {Cs[0], Cs[1], Cs[2], Cs[1], Cs[3], Cs[4], Cs[2], Cs[4], Cs[5]};
-      double RC[9];
-      for (int cc = 0; cc < 3; cc++)
-        for (int r = 0; r < 3; r++) RC[r + 3 * cc] = R[r] * cs9[3 * cc] + R[r + 3] * cs9[3 * cc + 1] + R[r + 6] * cs9[3 * cc + 2];
-      const double ct9[9] = {Ct[0], Ct[1], Ct[2], Ct[1], Ct[3], Ct[4], Ct[2], Ct[4], Ct[5]};
-      double A[9];
-      for (int cc = 0; cc < 3; cc++)
-        for (int r = 0; r < 3; r++) A[r + 3 * cc] = ct9[r + 3 * cc] + (RC[r] * R[cc] + RC[r + 3] * R[cc + 3] + RC[r + 6] * R[cc + 6]);
-      double M[9];
-      inv3(A, M);
-      double* mo = maha6 + ((size_t)pair * P + i) * 6;
-      mo[0] = M[0];
-      mo[1] = M[3];
-      mo[2] = M[6];
-      mo[3] = M[4];
-      mo[4] = M[7];
-      mo[5] = M[8];
-      const double4 q = tp[bj];
-      const double res[3] = {q.x - tx, q.y - ty, q.z - tz};
-      // J = [R * skew(p) | -R]
-      const double Sk[9] = {0, p.z, -p.y, -p.z, 0, p.x, p.y, -p.x, 0};
-      double J[18];
-      for (int cc = 0; cc < 3; cc++)
-        for (int r = 0; r < 3; r++) {
-          J[r + 3 * cc] = R[r] * Sk[3 * cc] + R[r + 3] * Sk[3 * cc + 1] + R[r + 6] * Sk[3 * cc + 2];
-          J[r + 3 * (cc + 3)] = -R[r + 3 * cc];
-        }
-      double MJ[18];
-      for (int cc = 0; cc < 6; cc++)
-        for (int r = 0; r < 3; r++) MJ[r + 3 * cc] = M[r] * J[3 * cc] + M[r + 3] * J[3 * cc + 1] + M[r + 6] * J[3 * cc + 2];
-      int o = 0;
-      for (int r = 0; r < 6; r++)
-        for (int cc = r; cc < 6; cc++) acc[o++] += J[3 * r] * MJ[3 * cc] + J[3 * r + 1] * MJ[3 * cc + 1] + J[3 * r + 2] * MJ[3 * cc + 2];
-      double Mr[3];
-      for (int r = 0; r < 3; r++) Mr[r] = M[r] * res[0] + M[r + 3] * res[1] + M[r + 6] * res[2];
-      for (int r = 0; r < 6; r++) acc[21 + r] += J[3 * r] * Mr[0] + J[3 * r + 1] * Mr[1] + J[3 * r + 2] * Mr[2];
-      acc[27] += 0.5 * (res[0] * Mr[0] + res[1] * Mr[1] + res[2] * Mr[2]);
-      acc[28] += 1.0;
-    }
+    const int ti = (bj >= 0 && !(best > prm.max_dist_sq)) ? bj : -1;  // DistanceRejector: reject iff sq_dist > max_dist_sq
+    lin_factor_prepare(i, p, tx, ty, tz, ti, T12, pair, cs, ct, P, pts, cov6, maha6, F);
     tgt_index[(size_t)pair * P + i] = ti;
   }
 }
+
 
 // a source point, its image under the pose and the image's cell
 __device__ __forceinline__ void lin_image(const double4& p, const double* __restrict__ T12, const GicpParams& prm, double& tx, double& ty,
@@ -2316,8 +2401,13 @@ __device__ __forceinline__ void lin_image(const double4& p, const double* __rest
 
 // GICPFactor::linearize (factors/gicp_factor.hpp:35-73) for every source point of every pair whose state
 // machine is in the "linearise" phase; per-block partial sums of H (upper), b, e and the inlier count.
+#ifdef GFS_LIN_WAVES
+#define GFS_LIN_OCC __attribute__((amdgpu_waves_per_eu(GFS_LIN_WAVES, 8)))
+#else
+#define GFS_LIN_OCC
+#endif
 template <bool kTiled>
-__global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* __restrict__ st,
+__global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(const PairState* __restrict__ st,
                                                               const double4* __restrict__ pts,
                                                               const double* __restrict__ cov6, const u64* __restrict__ ucell,
                                                               const unsigned* __restrict__ ubegin,
@@ -2358,9 +2448,8 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
   const bool has_prev = n_lin > 0;
   double4 prev_q = make_double4(0, 0, 0, 0);
   if (has_prev && i < ms && prev_j >= 0) prev_q = tp[prev_j];
-  double acc[kRed];
-#pragma unroll
-  for (int k = 0; k < kRed; k++) acc[k] = 0;
+  LinFactor F;
+  F.on = false;
   double tx = 0, ty = 0, tz = 0;
   int cx = 0, cy = 0, cz = 0;
   bool in_range = false;
@@ -2377,17 +2466,27 @@ __global__ __launch_bounds__(kLinBlock) void k_gicp_linearize(const PairState* _
       if (tiled) {
         const NnTile src{&tile, tile.box[0] - 1, tile.box[2] - 1, tile.box[1] - tile.box[0] + 3};
         gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell,
-                       G, gi, prm, tgt_index, maha6, acc);
+                       G, gi, prm, tgt_index, maha6, F);
         done = true;
       }
     }
     if (!done) {
       const NnGlobal src{tp, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
       gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G,
-                     gi, prm, tgt_index, maha6, acc);
+                     gi, prm, tgt_index, maha6, F);
     }
   }
-  wave_reduce_store<kRed>(acc, partial + ((size_t)pair * nblk + chunk) * kLinWaves * kRed, wave_slot);
+  double* dst = partial + ((size_t)pair * nblk + chunk) * kLinWaves * kRed;
+  {
+    double vb[14];
+    lin_factor_batch_b(F, vb);
+    wave_reduce_store_map<14>(vb, kLinMapB, dst, wave_slot);
+  }
+  {
+    double va[15];
+    lin_factor_batch_a(F, va);
+    wave_reduce_store_map<15>(va, kLinMapA, dst, wave_slot);
+  }
 }
 
 // GICPFactor::error (factors/gicp_factor.hpp:76-86) with the frozen correspondences / Mahalanobis matrices.
@@ -2717,8 +2816,10 @@ __global__ __launch_bounds__(kLmBlock) __attribute__((amdgpu_waves_per_eu(4, 8))
         lin_image(p, S.T, prm, tx, ty, tz, cx, cy, cz, in_range);
         const int prev_j = has_prev ? tgt_index[(size_t)pair * P + i] : -1;
         const double4 prev_q = prev_j >= 0 ? pts[(size_t)ct * P + prev_j] : make_double4(0, 0, 0, 0);
+        LinFactor F;
         gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, S.T, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G, gi,
-                       prm, tgt_index, maha6, acc);
+                       prm, tgt_index, maha6, F);
+        lin_factor_accumulate(F, acc);
       }
       const double r = gfs_red::block_sum_many<kRed, kLmBlock / 64>(acc, s_red);
       if (tid < kRed) s_sum[tid] = r;
