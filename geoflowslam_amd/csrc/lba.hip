@@ -703,15 +703,18 @@ __global__ __launch_bounds__(kMk) void k_lba_build_landmarks(LbaDev D) { b_build
 
 
 // buildSystem, pose side: one workgroup per free pose, threads over its edges, fixed-order reduction
+// (kPoseWg threads a pose: a free pose of the configs[4] window has ~2 500 edges, and an edge is a chain of dependent loads --
+// index, then its data -- so the kernel's time is edges per THREAD: 10 at 256 threads, 27 us a launch; 2.5 at 1 024, round 5)
+constexpr int kPoseWg = 1024;
 __device__ __forceinline__ void b_build_poses(const LbaDev& D, const int bx, const int gdx) {
-  __shared__ double s_buf[(kMk / 64) * 32];
+  __shared__ double s_buf[(kPoseWg / 64) * 32];
   const LbaState& S = *D.S;
   const double *q = sel(D.q, D.q_try, S.cur), *t = sel(D.t, D.t_try, S.cur), *X = sel(D.X, D.X_try, S.cur);
   const int f = bx;
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0;
-  for (int i = D.pose_begin[f] + threadIdx.x; i < D.pose_begin[f + 1]; i += kMk) {
+  for (int i = D.pose_begin[f] + threadIdx.x; i < D.pose_begin[f + 1]; i += kPoseWg) {
     const int e = D.pose_edges[i];
     double xc[3], r[3], Ji[9], Jj[18];
     edge_residual(D, e, q, t, X, xc, r);
@@ -729,13 +732,13 @@ __device__ __forceinline__ void b_build_poses(const LbaDev& D, const int bx, con
 #pragma unroll
     for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * omr[0] + Jj[6 + a] * omr[1] + Jj[12 + a] * omr[2];
   }
-  const double v = gfs_red::block_sum_many<27, kMk / 64>(acc, s_buf);
+  const double v = gfs_red::block_sum_many<27, kPoseWg / 64>(acc, s_buf);
   if (threadIdx.x < 21)
     D.Hpp[21 * f + threadIdx.x] = v;
   else if (threadIdx.x < 27)
     D.bp[6 * f + (threadIdx.x - 21)] = v;
 }
-__global__ __launch_bounds__(kMk) void k_lba_build_poses(LbaDev D) { b_build_poses(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kPoseWg) void k_lba_build_poses(LbaDev D) { b_build_poses(D, blockIdx.x, gridDim.x); }
 
 
 // start of an LM iteration: currentChi, and at iteration 0 computeLambdaInit (tau * max |diag H|)
@@ -1474,12 +1477,36 @@ __device__ __forceinline__ void b_update(const LbaDev& D, const int bx, const in
     const int l = bx * kMk + threadIdx.x;
     if (l < D.n_points) {
       double cl[3] = {D.bl[3 * (size_t)l], D.bl[3 * (size_t)l + 1], D.bl[3 * (size_t)l + 2]};
-      for (int e = D.pt_begin[l]; e < D.pt_begin[l + 1]; e++) {
-        const int f = D.free_index[D.e_pose[e]];
-        if (f < 0) continue;
-        const double* B = D.Hpl + 18 * (size_t)e;
-        for (int c = 0; c < 3; c++)
-          for (int a = 0; a < 6; a++) cl[c] -= B[3 * a + c] * D.xp[6 * f + a];
+      // (edges in order, the same subtractions as a plain loop; but a plain loop is one chain of three dependent round trips an
+      //  edge -- pose index, free index, block -- for ~16 edges a landmark: four edges' indices and two edges' blocks are asked for
+      //  together, round 5)
+      const int e_end = D.pt_begin[l + 1];
+      for (int eb = D.pt_begin[l]; eb < e_end; eb += 4) {
+        int ep[4], f[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ep[u] = D.e_pose[min(eb + u, e_end - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) f[u] = eb + u < e_end ? D.free_index[ep[u]] : -1;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+          double Bv[2][18], xv[2][6];
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int e = min(eb + 2 * h2 + u, e_end - 1), ff = max(f[2 * h2 + u], 0);
+#pragma unroll
+            for (int k = 0; k < 18; k++) Bv[u][k] = D.Hpl[18 * (size_t)e + k];
+#pragma unroll
+            for (int a = 0; a < 6; a++) xv[u][a] = D.xp[6 * ff + a];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            if (f[2 * h2 + u] < 0) continue;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+              for (int a = 0; a < 6; a++) cl[c] -= Bv[u][3 * a + c] * xv[u][a];
+          }
+        }
       }
       const double* Di = D.Dinv + 6 * (size_t)l;
       const double xl[3] = {Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2], Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2],
@@ -1618,7 +1645,7 @@ __global__ __launch_bounds__(kMk) void kb_lba_build_landmarks(const LbaDev* __re
   GFS_LBAB_PROLOGUE(0, D.n_lm_wg)
   b_build_landmarks(D, blockIdx.x, need);
 }
-__global__ __launch_bounds__(kMk) void kb_lba_build_poses(const LbaDev* __restrict__ DD) {
+__global__ __launch_bounds__(kPoseWg) void kb_lba_build_poses(const LbaDev* __restrict__ DD) {
   GFS_LBAB_PROLOGUE(0, D.n_free)
   b_build_poses(D, blockIdx.x, need);
 }
@@ -2045,7 +2072,7 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, StopF
     GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
     if (mode == 1) {
       if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D);
-      if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kMk), 0, s, D);
+      if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kPoseWg), 0, s, D);
     }
     GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, 1);
     LbaDev Df = D;
@@ -2059,7 +2086,7 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, StopF
     if (stop && *stop) break;  // SparseOptimizer::terminate() at the top of the iteration
     GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
     if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D);
-    if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kMk), 0, s, D);
+    if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kPoseWg), 0, s, D);
     GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, iteration);
     bool terminate = false;
     for (;;) {
@@ -2416,7 +2443,7 @@ static int lba_solve_batch_impl(gfs_lba_batch* b, const gfs_lba_problem* problem
   for (int round = 0; round < max_rounds; round++) {
     GFS_LAUNCH("kb_lba_errors", kb_lba_errors, dim3(max_err, n), dim3(kMk), 0, s, DD, 0);
     GFS_LAUNCH("kb_lba_build_landmarks", kb_lba_build_landmarks, dim3(max_lm, n), dim3(kMk), 0, s, DD);
-    if (max_free > 0) GFS_LAUNCH("kb_lba_build_poses", kb_lba_build_poses, dim3(max_free, n), dim3(kMk), 0, s, DD);
+    if (max_free > 0) GFS_LAUNCH("kb_lba_build_poses", kb_lba_build_poses, dim3(max_free, n), dim3(kPoseWg), 0, s, DD);
     GFS_LAUNCH("kb_lba_begin", kb_lba_begin, dim3(1, n), dim3(kThreads), 0, s, DD, b->d_done.p);
     GFS_LAUNCH("kb_lba_dinv", kb_lba_dinv, dim3(max_upd, n), dim3(kMk), 0, s, DD);
     if (max_mfma_blocks > 0) {
