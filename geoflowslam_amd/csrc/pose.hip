@@ -268,6 +268,15 @@ __device__ __forceinline__ bool ldlt6_solve_positive(const double* H21, double l
 //   shape depends on nothing but the number of edges, so a frame gives the same bits alone or inside any batch; against the
 //   restatement the sums differ in their last bits (relative 1e-16), the bar on the pose is 1e-5, and an outlier flag can only
 //   differ where an edge's chi2 sits within rounding of its threshold (tests/test_gpu_pose.py proves that for every flip).
+#ifdef GFS_POSE_TIMING
+#define PT_INIT long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = clock64();
+#define PT(k) { const long long _n = clock64(); pt_acc[k] += _n - pt_last; pt_last = _n; }
+#define PT_END if (tid == 0 && f == 0) printf("POSET setup=%lld active=%lld build=%lld solve=%lld trial=%lld decide=%lld classify=%lld its=%d\n", pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], O.iterations_run);
+#else
+#define PT_INIT
+#define PT(k)
+#define PT_END
+#endif
 template <bool kTree>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __restrict__ frames, const double* __restrict__ xw_all,
                                                            const double* __restrict__ obs_all, const float* __restrict__ w_all,
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
   __shared__ double s_x[6];
   __shared__ int s_flag[3];
   const int f = blockIdx.x, tid = threadIdx.x;
+  PT_INIT
   const PoseFrame F = frames[f];
   const int n = F.n_obs;
   EdgeView E{xw_all + (size_t)f * stride * 3, obs_all + (size_t)f * stride * 3, w_all + (size_t)f * stride,
@@ -410,6 +420,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     return chi;
   };
   int nBad = 0, nGood = 0;
+  PT(0)
   for (int it = 0; it < F.n_rounds; it++) {
     const bool robust = it <= 2;  // setRobustKernel(0) at the end of round 2
     if (tid < 4) s_T[tid] = q0[tid];  // setEstimate(pFrame->GetPose()): the frame pose never changes
@@ -426,8 +437,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     bool fresh = false;       // uniform
     double currentChi = 0;    // thread 0
     for (int iteration = 0; iteration < F.its && n_active > 0; iteration++) {
+      PT(5)
       if (!fresh) currentChi = compute_active(robust);
       const double iniChi = currentChi;
+      PT(1)
       // ---- buildSystem: linearizeOplus + constructQuadraticForm, summed over the threads' edges
       {
         double T[7];
@@ -522,6 +535,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
         if (tid < kSys) s_sys[tid] = run;
         __syncthreads();
       }
+      PT(2)
       if (tid == 0 && iteration == 0) {  // computeLambdaInit: tau * max |diag(H)|
         double maxDiagonal = 0;
         for (int a = 0; a < 6; a++) maxDiagonal = fmax(fabs(s_sys[a * (a + 1) / 2 + a]), maxDiagonal);
@@ -551,7 +565,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           s_flag[0] = ok2 ? 1 : 0;
         }
         __syncthreads();
+        PT(3)
         double tempChi = compute_active(robust);
+        PT(4)
         if (tid == 0) {
           const bool ok2 = s_flag[0] != 0;
           if (!ok2) tempChi = 1.79769313486231570e308;
@@ -598,6 +614,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       __syncthreads();
       if (stop) break;
     }
+    PT(5)
     // ---- classification (:972-1060).  Outlier edges of the previous round are re-evaluated at the final estimate
     //      (parallel); the float accumulation runs on thread 0 in the reference's order (mono list, then stereo list).
     {
@@ -661,6 +678,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       }
     }
     __syncthreads();
+    PT(6)
     if (n < 10) break;  // optimizer.edges().size() < 10 (:1073)
   }
   if (tid < n) store_edge(tid, R0);  // what the host reads back: mvbOutlier and the per-edge chi2
@@ -671,6 +689,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
     O.n_inliers = n - nBad;
     outs[f] = O;
   }
+  PT_END
 }
 
 __global__ void k_test_glibc_math(const double* __restrict__ x, int n, double* __restrict__ out) {
