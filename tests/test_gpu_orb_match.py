@@ -95,6 +95,23 @@ def test_orb_batch_matches_single(gpu_api, oracle):
         assert m == mo and (k == ko).all() and (d == do).all()
 
 
+def test_orb_every_batch_size_maps_every_cell_once(gpu_api, oracle):
+    """k_fast_cells maps workgroup ids to (frame, cell) so that a frame's cells share an XCD (fast_map in csrc/orb.hip): with fewer
+    than 8 frames a frame's cells are cut into 8 / B' parts, with more the frames go round-robin over the XCDs and the last group of 8
+    is ragged.  Every batch size 1 .. 17 (and 24, 33) must give every frame the oracle's key points -- a cell mapped twice or not at
+    all changes the candidates."""
+    W, H = 320, 240
+    pool = [synth.noise_image(300 + i, W, H) for i in range(6)]
+    orc = oracle.OrbOracle(500, 1.2, 6, 20, 7)
+    want = [orc.extract(im) for im in pool]
+    ext = gpu_api.ORBextractor(500, 1.2, 6, 20, 7, max_rows=H, max_cols=W, max_batch=33)
+    for B in list(range(1, 18)) + [24, 33]:
+        imgs = [pool[(3 * b + B) % len(pool)] for b in range(B)]
+        for b, (m, k, d) in enumerate(ext.extract_batch(imgs)):
+            mo, ko, do = want[(3 * b + B) % len(pool)]
+            assert m == mo and (k == ko).all() and (d == do).all(), (B, b)
+
+
 def test_bf_match_random_and_ties(gpu_api, oracle):
     rng = np.random.default_rng(0)
     mt = gpu_api.ORBmatcher(max_query=5000, max_train=5000)
