@@ -129,145 +129,61 @@ __device__ __forceinline__ T ordered_sum(const T* __restrict__ v, int cnt, T s) 
 // kernel): here every index is a compile-time constant -- the loops over k, i, j are unrolled and the run-time pivot p is matched
 // against its (at most five) possible values, each with its own statically indexed swaps -- so the 21 entries of the lower
 // triangle, y and the transpositions stay in registers.  The arithmetic, operation for operation, is the restatement's.
-template <int K, int PC>
-__device__ __forceinline__ void ldlt6_transpose(double (&A)[6][6]) {  // symmetric transposition k <-> p restricted to the lower triangle
-#pragma unroll
-  for (int j = 0; j < K; j++) {
-    const double tmp = A[K][j];
-    A[K][j] = A[PC][j];
-    A[PC][j] = tmp;
-  }
-#pragma unroll
-  for (int i = PC + 1; i < 6; i++) {
-    const double tmp = A[i][K];
-    A[i][K] = A[i][PC];
-    A[i][PC] = tmp;
-  }
-  {
-    const double tmp = A[K][K];
-    A[K][K] = A[PC][PC];
-    A[PC][PC] = tmp;
-  }
-#pragma unroll
-  for (int i = K + 1; i < PC; i++) {
-    const double tmp = A[i][K];
-    A[i][K] = A[PC][i];
-    A[PC][i] = tmp;
-  }
-}
-template <int K>
-__device__ __forceinline__ void ldlt6_step(double (&A)[6][6], int (&tr)[6], int& sign) {
-  int p = K;
-  double best = fabs(A[K][K]);
-#pragma unroll
-  for (int i = K + 1; i < 6; i++)
-    if (fabs(A[i][i]) > best) {
-      best = fabs(A[i][i]);
-      p = i;
+#define GFS_LDLT_NAME(n) n
+#define GFS_LDLT_FP
+#include "pose_ldlt6.inc"
+#undef GFS_LDLT_NAME
+#undef GFS_LDLT_FP
+#define GFS_LDLT_NAME(n) n##_fast
+#define GFS_LDLT_FP _Pragma("clang fp contract(fast)")
+#include "pose_ldlt6.inc"
+#undef GFS_LDLT_NAME
+#undef GFS_LDLT_FP
+
+// VertexSE3Expmap::oplusImpl as pose_oplus (g2o_se3_dev.hpp), for the tree-sum default: the device library's sin / cos and a plain
+// cube instead of the bit-for-bit restatement of glibc's (a few hundred instructions on the one lane everybody waits for), fused
+// multiply-adds.  Same formulas, results within rounding.
+__device__ __forceinline__ void pose_oplus_fast(const double* q_in, const double* t_in, const double* u, double* q_out, double* t_out) {
+#pragma clang fp contract(fast)
+  const double om[3] = {u[0], u[1], u[2]}, ups[3] = {u[3], u[4], u[5]};
+  const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+  double O2[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) O2[3 * r + c] = O[3 * r] * O[c] + O[3 * r + 1] * O[3 + c] + O[3 * r + 2] * O[6 + c];
+  double R[9], V[9];
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; i++) {
+      R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i];
+      V[i] = R[i];
     }
-  tr[K] = p;
-  if constexpr (K + 1 < 6) { if (p == K + 1) ldlt6_transpose<K, K + 1 < 6 ? K + 1 : 5>(A); }
-  if constexpr (K + 2 < 6) { if (p == K + 2) ldlt6_transpose<K, K + 2 < 6 ? K + 2 : 5>(A); }
-  if constexpr (K + 3 < 6) { if (p == K + 3) ldlt6_transpose<K, K + 3 < 6 ? K + 3 : 5>(A); }
-  if constexpr (K + 4 < 6) { if (p == K + 4) ldlt6_transpose<K, K + 4 < 6 ? K + 4 : 5>(A); }
-  if constexpr (K + 5 < 6) { if (p == K + 5) ldlt6_transpose<K, K + 5 < 6 ? K + 5 : 5>(A); }
-  if constexpr (K > 0) {
-    double temp[K];
-#pragma unroll
-    for (int j = 0; j < K; j++) temp[j] = A[j][j] * A[K][j];
-    double acc = 0;
-#pragma unroll
-    for (int j = 0; j < K; j++) acc += A[K][j] * temp[j];
-    A[K][K] -= acc;
-#pragma unroll
-    for (int i = K + 1; i < 6; i++) {
-      double a2 = 0;
-#pragma unroll
-      for (int j = 0; j < K; j++) a2 += A[i][j] * temp[j];
-      A[i][K] -= a2;
+  } else {
+    double sn, cn;
+    sincos(theta, &sn, &cn);
+    const double a = sn / theta, b = (1 - cn) / (theta * theta), c = (theta - sn) / (theta * theta * theta);
+    for (int i = 0; i < 9; i++) {
+      R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+      V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i];
     }
   }
-  const double akk = A[K][K];
-  if (fabs(akk) > 0) {
-#pragma unroll
-    for (int i = K + 1; i < 6; i++) A[i][K] /= akk;
-  }
-  if (sign == 1) {
-    if (akk < 0) sign = 2;
-  } else if (sign == -1) {
-    if (akk > 0) sign = 2;
-  } else if (sign == 0) {
-    if (akk > 0) sign = 1;
-    else if (akk < 0) sign = -1;
-  }
-}
-template <int K>
-__device__ __forceinline__ void ldlt6_swap_y(double (&y)[6], int p) {  // y[K] <-> y[p], p >= K
-  if constexpr (K + 1 < 6) { if (p == K + 1) { const double t = y[K]; y[K] = y[K + 1 < 6 ? K + 1 : 5]; y[K + 1 < 6 ? K + 1 : 5] = t; } }
-  if constexpr (K + 2 < 6) { if (p == K + 2) { const double t = y[K]; y[K] = y[K + 2 < 6 ? K + 2 : 5]; y[K + 2 < 6 ? K + 2 : 5] = t; } }
-  if constexpr (K + 3 < 6) { if (p == K + 3) { const double t = y[K]; y[K] = y[K + 3 < 6 ? K + 3 : 5]; y[K + 3 < 6 ? K + 3 : 5] = t; } }
-  if constexpr (K + 4 < 6) { if (p == K + 4) { const double t = y[K]; y[K] = y[K + 4 < 6 ? K + 4 : 5]; y[K + 4 < 6 ? K + 4 : 5] = t; } }
-  if constexpr (K + 5 < 6) { if (p == K + 5) { const double t = y[K]; y[K] = y[K + 5 < 6 ? K + 5 : 5]; y[K + 5 < 6 ? K + 5 : 5] = t; } }
-}
-// H: the 21 entries of the lower triangle, packed a (a + 1) / 2 + c; lambda is added to the diagonal
-__device__ __forceinline__ bool ldlt6_solve_positive(const double* H21, double lambda, const double* b, double* x) {
-  double A[6][6];
-  {
-    int o = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int c = 0; c <= a; c++) {
-        A[a][c] = H21[o];
-        A[c][a] = H21[o];
-        o++;
-      }
-  }
-#pragma unroll
-  for (int a = 0; a < 6; a++) A[a][a] += lambda;
-  int tr[6], sign = 0;
-  ldlt6_step<0>(A, tr, sign);
-  ldlt6_step<1>(A, tr, sign);
-  ldlt6_step<2>(A, tr, sign);
-  ldlt6_step<3>(A, tr, sign);
-  ldlt6_step<4>(A, tr, sign);
-  ldlt6_step<5>(A, tr, sign);
-  if (sign != 1) return false;
-  double y[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) y[i] = b[i];
-  ldlt6_swap_y<0>(y, tr[0]);
-  ldlt6_swap_y<1>(y, tr[1]);
-  ldlt6_swap_y<2>(y, tr[2]);
-  ldlt6_swap_y<3>(y, tr[3]);
-  ldlt6_swap_y<4>(y, tr[4]);
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
-#pragma unroll
-  for (int i = 0; i < 6; i++) y[i] = fabs(A[i][i]) > 2.2250738585072014e-308 ? y[i] / A[i][i] : 0.0;
-#pragma unroll
-  for (int i = 5; i >= 0; i--)
-#pragma unroll
-    for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
-  ldlt6_swap_y<4>(y, tr[4]);
-  ldlt6_swap_y<3>(y, tr[3]);
-  ldlt6_swap_y<2>(y, tr[2]);
-  ldlt6_swap_y<1>(y, tr[1]);
-  ldlt6_swap_y<0>(y, tr[0]);
-#pragma unroll
-  for (int i = 0; i < 6; i++) x[i] = y[i];
-  return true;
+  double eq[4], et[3];
+  R_to_quat(R, eq);
+  for (int r = 0; r < 3; r++) et[r] = V[3 * r] * ups[0] + V[3 * r + 1] * ups[1] + V[3 * r + 2] * ups[2];
+  normalize_rotation(eq);
+  double rt[3];
+  quat_rotate(eq, t_in, rt);
+  const double* a = eq;
+  const double* b = q_in;
+  double q[4];
+  q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  normalize_rotation(q);
+  for (int i = 0; i < 3; i++) t_out[i] = et[i] + rt[i];
+  for (int i = 0; i < 4; i++) q_out[i] = q[i];
 }
 
-// kTree = false: every sum over the edges in edge order on one lane (the bits of the sequential restatement; a chain of n dependent
-//   additions, 21 cycles each, three times an LM iteration).
-// kTree = true (the default of the handle): the same terms added by a tree of FIXED shape -- a thread adds its own edges (e = tid,
-//   tid + 256, ...) in index order, then the 256 partial sums are folded by the wave shuffle tree and the four waves in order.  The
-//   shape depends on nothing but the number of edges, so a frame gives the same bits alone or inside any batch; against the
-//   restatement the sums differ in their last bits (relative 1e-16), the bar on the pose is 1e-5, and an outlier flag can only
-//   differ where an edge's chi2 sits within rounding of its threshold (tests/test_gpu_pose.py proves that for every flip).
 #ifdef GFS_POSE_TIMING
 #define PT_INIT long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = clock64();
 #define PT(k) { const long long _n = clock64(); pt_acc[k] += _n - pt_last; pt_last = _n; }
@@ -554,10 +470,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           for (int k = 0; k < 21; k++) H21[k] = s_sys[k];
 #pragma unroll
           for (int k = 0; k < 6; k++) b6[k] = s_sys[21 + k];
-          const bool ok2 = ldlt6_solve_positive(H21, currentLambda, b6, x);
+          const bool ok2 = kTree ? ldlt6_solve_positive_fast(H21, currentLambda, b6, x) : ldlt6_solve_positive(H21, currentLambda, b6, x);
           if (ok2) {
             double qn[4], tn[3];
-            pose_oplus(s_T, s_T + 4, x, qn, tn);
+            if constexpr (kTree) pose_oplus_fast(s_T, s_T + 4, x, qn, tn);
+            else pose_oplus(s_T, s_T + 4, x, qn, tn);
             for (int k = 0; k < 4; k++) s_T[k] = qn[k];
             for (int k = 0; k < 3; k++) s_T[4 + k] = tn[k];
           }
@@ -578,7 +495,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           scale += 1e-3;
           rho /= scale;
           if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - gfs_glibc::pow3(2 * rho - 1);
+            const double g3 = 2 * rho - 1;
+            double alpha = 1. - (kTree ? g3 * g3 * g3 : gfs_glibc::pow3(g3));
             alpha = fmin(alpha, 2. / 3.);
             const double scaleFactor = fmax(1. / 3., alpha);
             currentLambda *= scaleFactor;
