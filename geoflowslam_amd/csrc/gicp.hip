@@ -2487,12 +2487,6 @@ __global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(const 
     lin_factor_batch_a(F, va);
     wave_reduce_store_map<15>(va, kLinMapA, dst, wave_slot);
   }
-#ifdef GFS_LIN_FENCE_PROBE  // what would a last-workgroup-does-the-solve tail cost?  release fence + one ticket per wave and pair
-  __threadfence();
-#if GFS_LIN_FENCE_PROBE > 1
-  if ((threadIdx.x & 63) == 0) atomicAdd(&tgt_index[(size_t)pair * P + P - 1], 0);
-#endif
-#endif
 }
 
 // GICPFactor::error (factors/gicp_factor.hpp:76-86) with the frozen correspondences / Mahalanobis matrices.
