@@ -688,8 +688,14 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
     const int th = pass == 0 ? th_hi : th_lo;
     const int T = max(th, 1);
     const unsigned t2 = (unsigned)th * 0x00010001u;
-    // ---- phase 0 + compaction, 8 row steps (32 pass bits a lane) at a time
+    // ---- phase 0 + compaction, 8 row steps (32 pass bits a lane) at a time.  A list entry = offset in the tile | polarity to
+    //      test << 15 (0 dark, 1 bright) | 'if that is no corner, try the other polarity too' << 14.  A pixel that passed both (top darker, bottom brighter, left darker, right
+    //      brighter) gets one entry per polarity, so that phase 1 tests every entry once -- unless the list (one slot per detection
+    //      pixel, and every later chunk of rows must still fit one entry a pixel) would not hold them: that chunk then writes ONE
+    //      entry a pixel carrying both bits, and phase 1 tries the second polarity where the first is no corner (`merged`;
+    //      adversarial images only, the tests have three)
     int nq = 0;
+    bool merged = false;
     for (int row0 = 0; row0 < dh; row0 += 8 * rstep) {
       const int nit = min(8, (dh - row0 + rstep - 1) / rstep);
       unsigned flags = 0, flagsb = 0;  // pass bits of the dark / bright pre-test, a nibble a row step
@@ -710,20 +716,38 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
         flagsb |= (fc_nibble(be, bod) & vm) << (4 * it);
       }
       FC_T(1)
-      const int cnt = __builtin_popcount(flags) + __builtin_popcount(flagsb);
-      const int incl = fc_wave_scan(cnt);
+      const unsigned both = flags | flagsb;
+      int cnt = __builtin_popcount(flags) + __builtin_popcount(flagsb);
+      int incl = fc_wave_scan(cnt);
+      const int later_px = dw * max(dh - row0 - 8 * rstep, 0);  // detection pixels of the chunks still to come
+      const bool merged_here = nq + __builtin_amdgcn_readlane(incl, 63) > dw * dh - later_px;  // (uniform)
+      if (merged_here) {
+        merged = true;
+        cnt = __builtin_popcount(both);
+        incl = fc_wave_scan(cnt);
+      }
       int pos = nq + incl - cnt;
       nq += __builtin_amdgcn_readlane(incl, 63);
       const int obase = (3 + row0 + rl) * wp + u0, ostep = rstep * wp;
-      while (flags) {  // an entry: offset of the pixel in the tile | polarity << 15
-        const int j = __builtin_ctz(flags);
-        flags &= flags - 1;
-        list[pos++] = (unsigned short)(obase + (j >> 2) * ostep + (j & 3));
-      }
-      while (flagsb) {
-        const int j = __builtin_ctz(flagsb);
-        flagsb &= flagsb - 1;
-        list[pos++] = (unsigned short)((obase + (j >> 2) * ostep + (j & 3)) | 0x8000);
+      if (merged_here) {
+        unsigned rest = both;
+        while (rest) {
+          const int j = __builtin_ctz(rest);
+          rest &= rest - 1;
+          const unsigned dk = (flags >> j) & 1u, br = (flagsb >> j) & 1u;  // dark only: 0, bright only: 0x8000, both: 0x4000 (dark first)
+          list[pos++] = (unsigned short)((obase + (j >> 2) * ostep + (j & 3)) | ((dk & br) << 14) | ((br & ~dk & 1u) << 15));
+        }
+      } else {
+        while (flags) {
+          const int j = __builtin_ctz(flags);
+          flags &= flags - 1;
+          list[pos++] = (unsigned short)(obase + (j >> 2) * ostep + (j & 3));
+        }
+        while (flagsb) {
+          const int j = __builtin_ctz(flagsb);
+          flagsb &= flagsb - 1;
+          list[pos++] = (unsigned short)((obase + (j >> 2) * ostep + (j & 3)) | 0x8000);
+        }
       }
       FC_T(2)
     }
@@ -733,13 +757,26 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
     for (int k0 = 0; k0 < nq; k0 += 128) {
       const int ka = k0 + lane, kb = k0 + 64 + lane;
       const bool ona = ka < nq, onb = kb < nq;
-      const int oa = ona ? list[ka] : 3 * wp + ua, ob = onb ? list[kb] : 3 * wp + ua;
-      const bool ca = arc_is_corner_pol(tile + (oa & 0x7fff), wp, th, oa >> 15) && ona;
-      const bool cb = arc_is_corner_pol(tile + (ob & 0x7fff), wp, th, ob >> 15) && onb;
+      int ea = ona ? list[ka] : 3 * wp + ua, eb = onb ? list[kb] : 3 * wp + ua;
+      const int oa = ea & 0x3fff, ob = eb & 0x3fff;
+      bool ca = arc_is_corner_pol(tile + oa, wp, th, ea >> 15) && ona;
+      bool cb = arc_is_corner_pol(tile + ob, wp, th, eb >> 15) && onb;
+      if (merged) {  // (an entry may ask for both polarities: a pixel that passed both pre-tests and is no dark corner is tried as a bright one)
+        const bool seca = ona && !ca && (ea & 0x4000), secb = onb && !cb && (eb & 0x4000);
+        if (__any(seca || secb)) {
+          const bool c2a = arc_is_corner_pol(tile + oa, wp, th, 1), c2b = arc_is_corner_pol(tile + ob, wp, th, 1);
+          ca = ca || (seca && c2a);
+          cb = cb || (secb && c2b);
+          if (seca && c2a) ea |= 0x8000;
+          if (secb && c2b) eb |= 0x8000;
+        }
+        ea &= 0xbfff;  // a corner: offset | its polarity << 15
+        eb &= 0xbfff;
+      }
       const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
-      if (ca) list[nc + fc_mbcnt(ma)] = (unsigned short)oa;
+      if (ca) list[nc + fc_mbcnt(ma)] = (unsigned short)ea;
       nc += (int)__popcll(ma);
-      if (cb) list[nc + fc_mbcnt(mb)] = (unsigned short)ob;
+      if (cb) list[nc + fc_mbcnt(mb)] = (unsigned short)eb;
       nc += (int)__popcll(mb);
     }
     fc_wave_sync();
@@ -748,7 +785,7 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
     FC_T(3)
     // ---- phase 2: exact scores of the corners
     for (int k = lane; k < nc; k += 64) {
-      const int e = list[k], o = e & 0x7fff;
+      const int e = list[k], o = e & 0x3fff;
       sc[o] = (uint8_t)(arc_score_pol(tile + o, wp, e >> 15) - 1);  // corner at th => S > th >= 0
     }
     fc_wave_sync();
@@ -761,7 +798,7 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
       bool keep = false;
       int o = 0;
       if (k < nc) {
-        o = list[k] & 0x7fff;
+        o = list[k] & 0x3fff;
         const uint8_t* q = sc + o;
         const int s = q[0];
         // a neighbour below the threshold counts as 0, and s >= T is above every such neighbour: "s > max of the eight" says the same
@@ -2063,7 +2100,7 @@ int ensure_geometry(gfs_orb* h, int rows, int cols) {
   gfs::OrbGeometry G;
   G.build(h->P, rows, cols);
   GFS_REQUIRE(G.supported, GFS_ERR_UNSUPPORTED, "ORB geometry for %dx%d unsupported: %s", cols, rows, G.why);
-  GFS_REQUIRE(kFcWaves * G.fast_lds_wave <= 160 * 1024 && G.max_tile_w + 6 <= 256 && (G.max_tile_w + 6) * G.max_tile_h < 32768,
+  GFS_REQUIRE(kFcWaves * G.fast_lds_wave <= 160 * 1024 && G.max_tile_w + 6 <= 256 && (G.max_tile_w + 6) * G.max_tile_h < 16384,
               GFS_ERR_UNSUPPORTED, "FAST cell tile of %dx%d too large for LDS", cols, rows);
   GFS_REQUIRE(G.pyr_bytes <= h->cap_pyr && G.blur_bytes <= h->cap_blur && G.slab_entries <= h->cap_slab &&
                   G.cells.size() <= h->cap_cells && G.kp_cap <= h->cap_kp,
@@ -2288,7 +2325,7 @@ int gfs_orb_create(const gfs_orb_config* cfg, gfs_orb** out) {
   G.build(h->P, cfg->max_rows, cfg->max_cols);
   GFS_REQUIRE(G.supported, GFS_ERR_UNSUPPORTED, "ORB geometry for max size %dx%d unsupported: %s", cfg->max_cols,
               cfg->max_rows, G.why);
-  GFS_REQUIRE(kFcWaves * G.fast_lds_wave <= 160 * 1024 && G.max_tile_w + 6 <= 256 && (G.max_tile_w + 6) * G.max_tile_h < 32768, GFS_ERR_UNSUPPORTED,
+  GFS_REQUIRE(kFcWaves * G.fast_lds_wave <= 160 * 1024 && G.max_tile_w + 6 <= 256 && (G.max_tile_w + 6) * G.max_tile_h < 16384, GFS_ERR_UNSUPPORTED,
               "FAST cell tile too large for LDS");
   const size_t B = cfg->max_batch;
   h->cap_pyr = G.pyr_bytes + 4096;

@@ -95,6 +95,25 @@ def test_orb_batch_matches_single(gpu_api, oracle):
         assert m == mo and (k == ko).all() and (d == do).all()
 
 
+@pytest.mark.parametrize("kind", ["binary_noise", "checker3", "ternary_noise"])
+def test_orb_images_where_every_pixel_passes_the_pretests(gpu_api, oracle, kind):
+    """k_fast_cells keeps ONE list entry a pixel with the polarities its antipodal-pair pre-test allows.  On these images most pixels
+    pass the pre-test, many of them for BOTH polarities (top darker, bottom brighter, left darker, right brighter): the list is as
+    full as it can get, and a pixel that is no dark corner must still be tried as a bright one."""
+    rng = np.random.default_rng(5)
+    W, H = 640, 480
+    if kind == "binary_noise":
+        img = (rng.integers(0, 2, (H, W)) * 255).astype(np.uint8)
+    elif kind == "ternary_noise":
+        img = rng.choice(np.array([0, 128, 255], np.uint8), size=(H, W))
+    else:  # period-6 checkerboard in x and y, jittered: the four compass pixels of the ring (distance 3) alternate around the centre
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = ((((xx // 3) + (yy // 3)) % 2) * 200 + 20 + rng.integers(0, 30, (H, W))).astype(np.uint8)
+    ext = gpu_api.ORBextractor(1000, 1.2, 8, 20, 7)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    _compare_full(ext, orc, img)
+
+
 def test_orb_every_batch_size_maps_every_cell_once(gpu_api, oracle):
     """k_fast_cells maps workgroup ids to (frame, cell) so that a frame's cells share an XCD (fast_map in csrc/orb.hip): with fewer
     than 8 frames a frame's cells are cut into 8 / B' parts, with more the frames go round-robin over the XCDs and the last group of 8
