@@ -108,6 +108,14 @@ def supervise(argv, deadline_s):
     p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
     last = [None]
 
+    def forward(signum, frame):  # the driver stopping the parent must not leave the child running on the GPU
+        p.kill()
+        sys.exit(128 + signum)
+
+    import signal
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, forward)
+
     def reader():
         for ln in p.stdout:
             ln = ln.strip()
