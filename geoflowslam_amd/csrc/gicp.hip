@@ -1181,6 +1181,11 @@ struct TopKey11 {
   }
 };
 
+// point j of a cloud through a 32-bit byte offset (clouds hold < 2^20 points of 32 bytes): the address is a scalar base + a zero-extended
+// VGPR offset (global_load ... v, s[base]) instead of a sign extension and a 64-bit shift-add per load
+__device__ __forceinline__ double4 ld_pt(const double4* __restrict__ base, int j) {
+  return *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(base) + (unsigned)((unsigned)j << 5));
+}
 // (no arrays of double4 below: they end up in scratch memory behind FLAT instructions)
 __device__ __forceinline__ double knn_key(const double4& t, const double4& q, int j, bool on) {
   const double ddx = t.x - q.x, ddy = t.y - q.y, ddz = t.z - q.z;
@@ -1189,7 +1194,7 @@ __device__ __forceinline__ double knn_key(const double4& t, const double4& q, in
 // the run [j0, j1) of candidate points into the key list, four loads in flight
 __device__ __forceinline__ void knn_scan_run_keys(const double4* __restrict__ p, const double4& q, int j0, int j1, TopKey11& loc) {
   for (int j = j0; j < j1; j += 4) {
-    const double4 t0 = p[j], t1 = p[min(j + 1, j1 - 1)], t2 = p[min(j + 2, j1 - 1)], t3 = p[min(j + 3, j1 - 1)];
+    const double4 t0 = ld_pt(p, j), t1 = ld_pt(p, min(j + 1, j1 - 1)), t2 = ld_pt(p, min(j + 2, j1 - 1)), t3 = ld_pt(p, min(j + 3, j1 - 1));
     loc.push4(knn_key(t0, q, j, true), knn_key(t1, q, j + 1, j + 1 < j1), knn_key(t2, q, j + 2, j + 2 < j1),
               knn_key(t3, q, j + 3, j + 3 < j1));
   }
@@ -1207,7 +1212,7 @@ __device__ __forceinline__ void knn_scan_runs4_keys(const double4* __restrict__ 
       j[u] = vv + (vv < c1 ? o0 : vv < c2 ? o1 : vv < c3 ? o2 : o3);
     }
     const int j0 = j[0], j1 = j[1], j2 = j[2], j3 = j[3];
-    const double4 t0 = p[j0], t1 = p[j1], t2 = p[j2], t3 = p[j3];
+    const double4 t0 = ld_pt(p, j0), t1 = ld_pt(p, j1), t2 = ld_pt(p, j2), t3 = ld_pt(p, j3);
     loc.push4(knn_key(t0, q, j0, true), knn_key(t1, q, j1, v + 1 < total), knn_key(t2, q, j2, v + 2 < total),
               knn_key(t3, q, j3, v + 3 < total));
   }
@@ -1887,7 +1892,7 @@ struct NnGlobal {
     return 0;
   }
   __device__ __forceinline__ void load(int idx, double& x, double& y, double& z) const {
-    const double4 q = tp[idx];
+    const double4 q = ld_pt(tp, idx);
     x = q.x;
     y = q.y;
     z = q.z;
