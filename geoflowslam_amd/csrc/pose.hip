@@ -129,16 +129,198 @@ __device__ __forceinline__ T ordered_sum(const T* __restrict__ v, int cnt, T s) 
 // kernel): here every index is a compile-time constant -- the loops over k, i, j are unrolled and the run-time pivot p is matched
 // against its (at most five) possible values, each with its own statically indexed swaps -- so the 21 entries of the lower
 // triangle, y and the transpositions stay in registers.  The arithmetic, operation for operation, is the restatement's.
-#define GFS_LDLT_NAME(n) n
-#define GFS_LDLT_FP
-#include "pose_ldlt6.inc"
-#undef GFS_LDLT_NAME
-#undef GFS_LDLT_FP
-#define GFS_LDLT_NAME(n) n##_fast
-#define GFS_LDLT_FP _Pragma("clang fp contract(fast)")
-#include "pose_ldlt6.inc"
-#undef GFS_LDLT_NAME
-#undef GFS_LDLT_FP
+template <int K, int PC>
+__device__ __forceinline__ void ldlt6_transpose(double (&A)[6][6]) {  // symmetric transposition k <-> p restricted to the lower triangle
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    const double tmp = A[K][j];
+    A[K][j] = A[PC][j];
+    A[PC][j] = tmp;
+  }
+#pragma unroll
+  for (int i = PC + 1; i < 6; i++) {
+    const double tmp = A[i][K];
+    A[i][K] = A[i][PC];
+    A[i][PC] = tmp;
+  }
+  {
+    const double tmp = A[K][K];
+    A[K][K] = A[PC][PC];
+    A[PC][PC] = tmp;
+  }
+#pragma unroll
+  for (int i = K + 1; i < PC; i++) {
+    const double tmp = A[i][K];
+    A[i][K] = A[PC][i];
+    A[PC][i] = tmp;
+  }
+}
+template <int K>
+__device__ __forceinline__ void ldlt6_step(double (&A)[6][6], int (&tr)[6], int& sign) {
+  int p = K;
+  double best = fabs(A[K][K]);
+#pragma unroll
+  for (int i = K + 1; i < 6; i++)
+    if (fabs(A[i][i]) > best) {
+      best = fabs(A[i][i]);
+      p = i;
+    }
+  tr[K] = p;
+  if constexpr (K + 1 < 6) { if (p == K + 1) ldlt6_transpose<K, K + 1 < 6 ? K + 1 : 5>(A); }
+  if constexpr (K + 2 < 6) { if (p == K + 2) ldlt6_transpose<K, K + 2 < 6 ? K + 2 : 5>(A); }
+  if constexpr (K + 3 < 6) { if (p == K + 3) ldlt6_transpose<K, K + 3 < 6 ? K + 3 : 5>(A); }
+  if constexpr (K + 4 < 6) { if (p == K + 4) ldlt6_transpose<K, K + 4 < 6 ? K + 4 : 5>(A); }
+  if constexpr (K + 5 < 6) { if (p == K + 5) ldlt6_transpose<K, K + 5 < 6 ? K + 5 : 5>(A); }
+  if constexpr (K > 0) {
+    double temp[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) temp[j] = A[j][j] * A[K][j];
+    double acc = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) acc += A[K][j] * temp[j];
+    A[K][K] -= acc;
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) {
+      double a2 = 0;
+#pragma unroll
+      for (int j = 0; j < K; j++) a2 += A[i][j] * temp[j];
+      A[i][K] -= a2;
+    }
+  }
+  const double akk = A[K][K];
+  if (fabs(akk) > 0) {
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) A[i][K] /= akk;
+  }
+  if (sign == 1) {
+    if (akk < 0) sign = 2;
+  } else if (sign == -1) {
+    if (akk > 0) sign = 2;
+  } else if (sign == 0) {
+    if (akk > 0) sign = 1;
+    else if (akk < 0) sign = -1;
+  }
+}
+template <int K>
+__device__ __forceinline__ void ldlt6_swap_y(double (&y)[6], int p) {  // y[K] <-> y[p], p >= K
+  if constexpr (K + 1 < 6) { if (p == K + 1) { const double t = y[K]; y[K] = y[K + 1 < 6 ? K + 1 : 5]; y[K + 1 < 6 ? K + 1 : 5] = t; } }
+  if constexpr (K + 2 < 6) { if (p == K + 2) { const double t = y[K]; y[K] = y[K + 2 < 6 ? K + 2 : 5]; y[K + 2 < 6 ? K + 2 : 5] = t; } }
+  if constexpr (K + 3 < 6) { if (p == K + 3) { const double t = y[K]; y[K] = y[K + 3 < 6 ? K + 3 : 5]; y[K + 3 < 6 ? K + 3 : 5] = t; } }
+  if constexpr (K + 4 < 6) { if (p == K + 4) { const double t = y[K]; y[K] = y[K + 4 < 6 ? K + 4 : 5]; y[K + 4 < 6 ? K + 4 : 5] = t; } }
+  if constexpr (K + 5 < 6) { if (p == K + 5) { const double t = y[K]; y[K] = y[K + 5 < 6 ? K + 5 : 5]; y[K + 5 < 6 ? K + 5 : 5] = t; } }
+}
+// H: the 21 entries of the lower triangle, packed a (a + 1) / 2 + c; lambda is added to the diagonal
+__device__ __forceinline__ bool ldlt6_solve_positive(const double* H21, double lambda, const double* b, double* x) {
+  double A[6][6];
+  {
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c <= a; c++) {
+        A[a][c] = H21[o];
+        A[c][a] = H21[o];
+        o++;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; a++) A[a][a] += lambda;
+  int tr[6], sign = 0;
+  ldlt6_step<0>(A, tr, sign);
+  ldlt6_step<1>(A, tr, sign);
+  ldlt6_step<2>(A, tr, sign);
+  ldlt6_step<3>(A, tr, sign);
+  ldlt6_step<4>(A, tr, sign);
+  ldlt6_step<5>(A, tr, sign);
+  if (sign != 1) return false;
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = b[i];
+  ldlt6_swap_y<0>(y, tr[0]);
+  ldlt6_swap_y<1>(y, tr[1]);
+  ldlt6_swap_y<2>(y, tr[2]);
+  ldlt6_swap_y<3>(y, tr[3]);
+  ldlt6_swap_y<4>(y, tr[4]);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = fabs(A[i][i]) > 2.2250738585072014e-308 ? y[i] / A[i][i] : 0.0;
+#pragma unroll
+  for (int i = 5; i >= 0; i--)
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
+  ldlt6_swap_y<4>(y, tr[4]);
+  ldlt6_swap_y<3>(y, tr[3]);
+  ldlt6_swap_y<2>(y, tr[2]);
+  ldlt6_swap_y<1>(y, tr[1]);
+  ldlt6_swap_y<0>(y, tr[0]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = y[i];
+  return true;
+}
+
+// kTree = false: every sum over the edges in edge order on one lane (the bits of the sequential restatement; a chain of n dependent
+//   additions, 21 cycles each, three times an LM iteration).
+// kTree = true (the default of the handle): the same terms added by a tree of FIXED shape -- a thread adds its own edges (e = tid,
+//   tid + 256, ...) in index order, then the 256 partial sums are folded by the wave shuffle tree and the four waves in order.  The
+//   shape depends on nothing but the number of edges, so a frame gives the same bits alone or inside any batch; against the
+//   restatement the sums differ in their last bits (relative 1e-16), the bar on the pose is 1e-5, and an outlier flag can only
+//   differ where an edge's chi2 sits within rounding of its threshold (tests/test_gpu_pose.py proves that for every flip).
+
+// The 6x6 solve of the tree-sum default.  H + lambda I of an LM trial is symmetric positive definite unless the trial is hopeless, and
+// for such a matrix Eigen's diagonal pivoting only re-orders the rounding: an UN-pivoted LDL^T (as k_gicp_solve uses for the same
+// reason) gives the solution to rounding with ~150 instead of ~1 000 instructions on the one lane everybody waits for (no pivot
+// search, no transpositions, six reciprocals instead of 21 divisions).  "Not positive" (LinearSolverDense: the trial is rejected) =
+// a pivot that is not > 0 -- the same matrices, up to those within rounding of singular.
+__device__ __forceinline__ bool ldlt6_solve_spd_fast(const double* H21, double lambda, const double* b, double* x) {
+#pragma clang fp contract(fast)
+  double L[6][6], W[6][6], rd[6];  // L unit lower, W = L D, rd = 1 / d
+  {
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c <= a; c++) L[a][c] = H21[o++];
+  }
+#pragma unroll
+  for (int a = 0; a < 6; a++) L[a][a] += lambda;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) dj -= L[j][k] * W[j][k];
+    ok = ok && dj > 0.0;
+    rd[j] = 1.0 / dj;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double v = L[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= L[i][k] * W[j][k];
+      W[i][j] = v;
+      L[i][j] = v * rd[j];
+    }
+  }
+  if (!ok) return false;
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    y[i] = b[i];
+#pragma unroll
+    for (int j = 0; j < i; j++) y[i] -= L[i][j] * y[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] *= rd[i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) y[i] -= L[j][i] * y[j];
+    x[i] = y[i];
+  }
+  return true;
+}
 
 // VertexSE3Expmap::oplusImpl as pose_oplus (g2o_se3_dev.hpp), for the tree-sum default: the device library's sin / cos and a plain
 // cube instead of the bit-for-bit restatement of glibc's (a few hundred instructions on the one lane everybody waits for), fused
@@ -470,7 +652,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
           for (int k = 0; k < 21; k++) H21[k] = s_sys[k];
 #pragma unroll
           for (int k = 0; k < 6; k++) b6[k] = s_sys[21 + k];
-          const bool ok2 = kTree ? ldlt6_solve_positive_fast(H21, currentLambda, b6, x) : ldlt6_solve_positive(H21, currentLambda, b6, x);
+          const bool ok2 = kTree ? ldlt6_solve_spd_fast(H21, currentLambda, b6, x) : ldlt6_solve_positive(H21, currentLambda, b6, x);
           if (ok2) {
             double qn[4], tn[3];
             if constexpr (kTree) pose_oplus_fast(s_T, s_T + 4, x, qn, tn);
