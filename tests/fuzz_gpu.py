@@ -161,6 +161,7 @@ extra = budget * 0.25
 nx = dict(sbp=0, pose=0, match=0, klt=0, fmat=0)
 pm = api.ProjectionMatcher(max_last=2048, max_cur=2560, max_batch=1)
 po = api.PoseOptimizer(max_obs=2048, max_batch=1, sums="edge_order")  # (the bit-for-bit comparison below is a statement about g2o's sum order)
+po_tree = api.PoseOptimizer(max_obs=2048, max_batch=1)
 mt = api.ORBmatcher()
 fm = api.FundamentalMatcher(max_points=2048, max_batch=1)
 ext = api.ORBextractor(1000, 1.2, 8, 20, 7, max_rows=480, max_cols=640)
@@ -192,6 +193,15 @@ while time.time() - T1 < extra and ONLY is None and 5 in SECTIONS:
             if not (np.array_equal(r["outlier"], ro["outlier"]) and r["n_inliers"] == ro["n_inliers"] and r["rounds_run"] == ro["rounds_run"]
                     and r["iterations_run"] == ro["iterations_run"] and rel(r["q"], ro["q"]) < 1e-5 and rel(r["t"], ro["t"]) < 1e-5):
                 fails.append(("pose", "case 5:%d" % (i5 - 1), s, q["n_obs"], r["n_inliers"], ro["n_inliers"], r["iterations_run"], ro["iterations_run"]))
+            # ... and the handle's default: fixed-shape tree sums, un-pivoted solve -- pose within the bar, every flipped flag a proved
+            # chi2-threshold tie (tests/test_gpu_pose.py has the rule)
+            rt = po_tree.PoseOptimization(q)
+            flip = np.flatnonzero(rt["outlier"] != ro["outlier"])
+            tie = all(min(abs(float(ro["chi2"][e]) - 5.991), abs(float(ro["chi2"][e]) - 7.815)) <= 1e-6 * 7.815 for e in flip)
+            nx["pose_tree_frames_with_flips"] = nx.get("pose_tree_frames_with_flips", 0) + (len(flip) > 0)
+            if not (tie and abs(rt["n_inliers"] - ro["n_inliers"]) <= len(flip) and rt["rounds_run"] == ro["rounds_run"]
+                    and (q["n_obs"] < 3 or (rel(rt["q"], ro["q"]) < 1e-5 and rel(rt["t"], ro["t"]) < 1e-5))):
+                fails.append(("pose-tree", "case 5:%d" % (i5 - 1), s, q["n_obs"], rt["n_inliers"], ro["n_inliers"], len(flip)))
         elif which == 2:
             nq, nt = int(rng.integers(0, 3000)), int(rng.integers(0, 3000))
             dq = rng.integers(0, 256, (nq, 32), dtype=np.uint8); dt = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
