@@ -48,3 +48,20 @@ def test_bench_survives_a_side_leg_that_raises(gpu_api, tmp_path):
     assert cp.returncode == 0, cp.stderr[-3000:]
     d = json.loads(lines[-1])
     assert len(lines) == 1 and d["roofline"]["frac"] > 0 and d["roofline"]["traffic"] is None
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(gpu_api):
+    """The N > 1 path of bench.py (what the driver's SCALE run launches, there one rank per GPU over RCCL): here two ranks share GPU 0
+    over gloo -- rendezvous, per-rank scenes, barrier + max-over-ranks timing, the `strong` object (configs[3]: one batch cut over the
+    ranks) and ONE JSON line from rank 0 with rc 0."""
+    cp, lines = _run(["--gpus", "2", "--dist-backend", "gloo", "--all-ranks-device0", "--batch", "32", "--lanes", "2", "--steps", "3", "--warmup", "1",
+                      "--prime", "1", "--gen-procs", "8", "--verify", "0"], 900)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    assert len(lines) == 1, cp.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["global_batch_pairs"] == 64
+    assert d["roofline"] and "error" not in d["roofline"] and d["roofline"]["frac"] > 0
+    s = d["strong"]
+    assert s["scaling"] == "strong" and s["value"] > 0 and s["global_batch_pairs"] == 32 and s["pairs_per_gpu"] == 16
+    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
