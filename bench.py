@@ -108,9 +108,21 @@ def supervise(argv, deadline_s):
     p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
     last = [None]
 
-    def forward(signum, frame):  # the driver stopping the parent must not leave the child running on the GPU
+    def forward(signum, frame):
+        # The driver (or an outer `timeout`) stopping the parent must not leave the child running on the GPU -- and must not cost the
+        # headline either: the newest line the child produced is printed before leaving, rc 0 when there is one.
         p.kill()
-        sys.exit(128 + signum)
+        if last[0] is None:
+            sys.exit(128 + signum)
+        try:
+            o = json.loads(last[0])
+            o["side_legs_incomplete"] = f"stopped by signal {signum} after the last completed leg"
+            if o.get("verify_requested") and "verify" not in o:
+                o["verified"] = False
+            print(json.dumps(o), flush=True)
+        except Exception:
+            print(last[0], flush=True)
+        os._exit(0)
 
     import signal
     for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
@@ -142,6 +154,8 @@ def supervise(argv, deadline_s):
         try:
             o = json.loads(last[0])
             o["side_legs_incomplete"] = died
+            if o.get("verify_requested") and "verify" not in o:
+                o["verified"] = False  # a consumer that keys on `value` alone can see that the oracle check did not finish
             last[0] = json.dumps(o)
         except Exception:
             pass
@@ -476,9 +490,15 @@ def main():
         }
         if args.gicp_stream:
             out["config"]["workload"] += " [EXPERIMENT --gicp-stream: target preprocessing reused from the previous call]"
+        verify_wanted = rank == 0 and args.verify > 0 and not args.no_cpu_baseline and not args.gicp_stream
+        if verify_wanted:
+            out["verify_requested"] = int(args.verify)
         if verify:
             out["verified_pairs"] = verify.get("verified_pairs")
             out["verify"] = verify
+            out["verified"] = bool(verify.get("checked_pairs")) and verify.get("verified_pairs") == verify.get("checked_pairs")
+        elif verify_wanted and final_line[0]:
+            out["verified"] = False  # the check against the oracle was asked for and did not produce a result
         if strong:
             out["strong"] = strong
         if h2d:
@@ -486,6 +506,16 @@ def main():
         if klt:
             out["optical_flow"] = klt
         out.update(extras)
+        # the three side figures a reader looks for first, at the top level (the full objects stay where they are)
+        try:
+            if isinstance(extras.get("c4_shard"), dict) and "efficiency_vs_batch_512" in extras["c4_shard"]:
+                out["c4_shard_efficiency_vs_batch_512"] = extras["c4_shard"]["efficiency_vs_batch_512"]
+            if isinstance(extras.get("single_stream"), dict) and "median_ms" in extras["single_stream"]:
+                out["single_stream_median_ms"] = extras["single_stream"]["median_ms"]
+            if isinstance(extras.get("lba"), dict) and "ms_per_window" in extras["lba"]:
+                out["lba_ms_per_window"] = extras["lba"]["ms_per_window"]
+        except Exception:
+            pass
         if skipped_legs:
             out["skipped_legs"] = dict(legs=list(skipped_legs), reason=f"run older than --leg-budget-s {args.leg_budget_s:.0f} s")
         if cpu and "value" in cpu:
@@ -506,9 +536,12 @@ def main():
             return True
         return False
 
+    final_line = [False]
+
     def emit(final=False):
         if rank != 0 or not (final or "GFS_BENCH_CHILD" in os.environ):
             return
+        final_line[0] = final
         try:
             line = json.dumps(assemble(), default=str)
         except Exception as e:  # even a bug in the assembly must not cost the measured headline
@@ -580,6 +613,54 @@ def main():
     if rank == 0:
         roofline = guarded(roofline_leg)
         emit()
+
+    # ---- verification of the TIMED batch's outputs against the CPU oracle (a sample; after the timed region)
+    def verify_leg():
+        from oracle import oracle as O
+        O.lib()
+        step_overlapped()  # the same pass as the timed ones, outputs left in HBM
+        torch.cuda.synchronize()
+        picks = sorted(set(int(round(x)) for x in np.linspace(0, B - 1, min(args.verify, B))))
+        lane_of = {}
+        for li, ln in enumerate(lanes):
+            for k in range(ln.n):
+                lane_of[ln.b0 + k] = (ln, k)
+
+        def check(b):
+            ln, k = lane_of[b]
+            p = pairs[sel[b]]
+            orc = O.OrbOracle(NF, 1.2, NL, 20, 7)
+            _, k0, d0 = orc.extract(p["gray0"])
+            _, k1, d1 = orc.extract(p["gray1"])
+            _, gk1, gd1 = ln.ext.fetch(k)
+            ok_orb = len(gk1) == len(k1) and bool((gk1 == k1).all()) and bool((gd1 == d1).all())
+            ti, di = O.bf_match(d0, d1)
+            nq = len(ti)
+            gi = ln.m_idx.view(ln.n, ln.cap)[k, :nq].cpu().numpy()
+            gd = ln.m_dist.view(ln.n, ln.cap)[k, :nq].cpu().numpy()
+            ok_match = bool(np.array_equal(gi, ti) and np.array_equal(gd, di))
+            mo, no = O.gms_inlier_mask(k0, (W, H), k1, (W, H), np.arange(nq, dtype=np.int32), ti) if nq else (np.zeros(0, bool), 0)
+            gm = ln.m_mask.view(ln.n, ln.cap)[k, :nq].cpu().numpy().astype(bool)
+            ok_gms = bool(np.array_equal(gm, mo)) and int(ln.m_inl[k].item()) == int(no)
+            ro = O.gicp_align(p["cloud0"], p["cloud1"])
+            r = ln.gicp_out[k]
+            T = np.array(r.T).reshape(4, 4).T
+            e = float(np.linalg.norm(T - ro["T"]) / np.linalg.norm(ro["T"]))
+            ok_gicp = e <= 1e-5 and int(r.iterations) == ro["iterations"] and bool(r.converged) == ro["converged"]
+            return b, ok_orb, ok_match, ok_gms, ok_gicp, e
+
+        with ThreadPoolExecutor(max_workers=min(len(picks), 16)) as ex:
+            res = list(ex.map(check, picks))
+        bad = [dict(pair=b, orb=o, match=m, gms=gm_, gicp=gi_, gicp_rel_err=e) for b, o, m, gm_, gi_, e in res if not (o and m and gm_ and gi_)]
+        return dict(verified_pairs=len(res) - len(bad), checked_pairs=len(res),
+                      checks="ORB key points + descriptors, BF matches, GMS mask bit-exact; GICP pose <= 1e-5 rel. Frobenius, iterations and converged equal",
+                      max_gicp_rel_err=max(e for *_, e in res), failures=bad)
+
+    # (run right behind the roofline leg and outside the leg budget: a headline without its oracle check is worth less than any extra)
+    if rank == 0 and args.verify > 0 and not args.no_cpu_baseline and not args.gicp_stream:
+        verify = guarded(verify_leg)
+        emit()
+
 
     # ---- CPU baseline: the oracle (CPU restatement; the reference itself cannot be built: OpenCV/Eigen absent)
     def cpu_leg():
@@ -913,6 +994,18 @@ def main():
             ov["same_results_as_sequential"] = bool(all(a_["matches"] == b_["matches"] and a_["inliers"] == b_["inliers"] and np.array_equal(a_["T"], b_["T"])
                                                         and np.array_equal(a_["match"], b_["match"]) for a_, b_ in zip(states_g[-40:], states_v[-40:])))
             ss["orb_beside_registration"] = ov
+            # PoseOptimization runs in the library's default above: g2o's edge order, the reference's outlier flags bit for bit.  The opt-in
+            # fixed-shape tree sums (gfs_pose_set_sum_order(GFS_POSE_SUMS_TREE)) are timed beside it and labelled as what they are.
+            ss["pose_sum_order"] = "edge_order (library default: bit-identical to the oracle's g2o restatement)"
+            try:
+                gbe.set_pose_sums("tree")
+                gbe.have_target = False
+                lat_t, st_t, _ = bs.run_stream(gbe, frames_s, Kc, W, H, STRIDE, 60, warm=6)
+                tsum = bs.summarize(lat_t, st_t)
+                ss["with_tree_sums_opt_in"] = dict(median_ms=tsum["median_ms"], pose_optimization_ms=tsum["stages_median_ms"].get("pose_optimization"),
+                                                   note="GFS_POSE_SUMS_TREE: pose within 1e-7, outlier flags equal up to chi2-threshold ties; not the default")
+            finally:
+                gbe.set_pose_sums(None)
             ss.update(metric="single-stream front-end latency per frame (B = 1, sequential): ORB + the RGB-D tail of the Frame constructor (stereo-from-RGBD + depth->cloud: "
                              "gfs_frame_rgbd, the cloud stays on the device) + GICP (streaming entry) + SearchByProjection + PoseOptimization, host pointers in, "
                              "results out, every copy and sync included",
@@ -938,52 +1031,6 @@ def main():
             extras["single_stream"] = ss
         except Exception as e:
             extras["single_stream"] = dict(error=f"{type(e).__name__}: {e}")
-
-    # ---- verification of the TIMED batch's outputs against the CPU oracle (a sample; after the timed region)
-    def verify_leg():
-        from oracle import oracle as O
-        O.lib()
-        step_overlapped()  # the same pass as the timed ones, outputs left in HBM
-        torch.cuda.synchronize()
-        picks = sorted(set(int(round(x)) for x in np.linspace(0, B - 1, min(args.verify, B))))
-        lane_of = {}
-        for li, ln in enumerate(lanes):
-            for k in range(ln.n):
-                lane_of[ln.b0 + k] = (ln, k)
-
-        def check(b):
-            ln, k = lane_of[b]
-            p = pairs[sel[b]]
-            orc = O.OrbOracle(NF, 1.2, NL, 20, 7)
-            _, k0, d0 = orc.extract(p["gray0"])
-            _, k1, d1 = orc.extract(p["gray1"])
-            _, gk1, gd1 = ln.ext.fetch(k)
-            ok_orb = len(gk1) == len(k1) and bool((gk1 == k1).all()) and bool((gd1 == d1).all())
-            ti, di = O.bf_match(d0, d1)
-            nq = len(ti)
-            gi = ln.m_idx.view(ln.n, ln.cap)[k, :nq].cpu().numpy()
-            gd = ln.m_dist.view(ln.n, ln.cap)[k, :nq].cpu().numpy()
-            ok_match = bool(np.array_equal(gi, ti) and np.array_equal(gd, di))
-            mo, no = O.gms_inlier_mask(k0, (W, H), k1, (W, H), np.arange(nq, dtype=np.int32), ti) if nq else (np.zeros(0, bool), 0)
-            gm = ln.m_mask.view(ln.n, ln.cap)[k, :nq].cpu().numpy().astype(bool)
-            ok_gms = bool(np.array_equal(gm, mo)) and int(ln.m_inl[k].item()) == int(no)
-            ro = O.gicp_align(p["cloud0"], p["cloud1"])
-            r = ln.gicp_out[k]
-            T = np.array(r.T).reshape(4, 4).T
-            e = float(np.linalg.norm(T - ro["T"]) / np.linalg.norm(ro["T"]))
-            ok_gicp = e <= 1e-5 and int(r.iterations) == ro["iterations"] and bool(r.converged) == ro["converged"]
-            return b, ok_orb, ok_match, ok_gms, ok_gicp, e
-
-        with ThreadPoolExecutor(max_workers=min(len(picks), 16)) as ex:
-            res = list(ex.map(check, picks))
-        bad = [dict(pair=b, orb=o, match=m, gms=gm_, gicp=gi_, gicp_rel_err=e) for b, o, m, gm_, gi_, e in res if not (o and m and gm_ and gi_)]
-        return dict(verified_pairs=len(res) - len(bad), checked_pairs=len(res),
-                      checks="ORB key points + descriptors, BF matches, GMS mask bit-exact; GICP pose <= 1e-5 rel. Frobenius, iterations and converged equal",
-                      max_gicp_rel_err=max(e for *_, e in res), failures=bad)
-
-    if rank == 0 and args.verify > 0 and not args.no_cpu_baseline and not args.gicp_stream and not over_budget("verify"):
-        verify = guarded(verify_leg)
-        emit()
 
     # ---- PCIe-inclusive figure (N = 1): images and depth maps start in pinned HOST memory every pass, the clouds are built on the
     #      device (Frame::ConvertDepthToPointCloud), the per-pair results come back to pinned host memory

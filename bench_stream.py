@@ -40,18 +40,26 @@ def _quat_from_R(R):
 
 
 class GpuBackend:
-    def __init__(self, api, W, H, nfeatures, nlevels, max_points, device=0):
+    def __init__(self, api, W, H, nfeatures, nlevels, max_points, device=0, pose_sums=None):
+        """pose_sums: None = the library's default (g2o's edge order: the reference's outlier flags bit for bit), "tree" = the opt-in
+        fixed-shape tree sums (gfs_pose_set_sum_order)."""
+        self.api, self.device = api, device
         self.ext = api.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, max_rows=H, max_cols=W, max_batch=1, device=device)
         self.frm = api.Frame(max_rows=H, max_cols=W, max_keypoints=self.ext.cap, device=device)
         self.reg = api.RegistrationGICP(max_points=max_points, max_batch=1, device=device)
         self.pm = api.ProjectionMatcher(max_last=self.ext.cap, max_cur=self.ext.cap, max_batch=1, device=device)
-        self.po = api.PoseOptimizer(max_obs=self.ext.cap, max_batch=1, device=device)
+        self.po = api.PoseOptimizer(max_obs=self.ext.cap, max_batch=1, device=device, sums=pose_sums)
         t = self.ext.tables()
         self.scale, self.inv_sigma2 = np.asarray(t["scale"], np.float32), np.asarray(t["inv_sigma2"], np.float32)
         self.have_target = False
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(1)
         self.no_kps = np.zeros(0, self.ext(np.zeros((H, W), np.uint8))[1].dtype)
+
+    def set_pose_sums(self, sums):
+        """Replace the PoseOptimization handle by one with the given sum order (None = the library's default)."""
+        self.po.close()
+        self.po = self.api.PoseOptimizer(max_obs=self.ext.cap, max_batch=1, device=self.device, sums=sums)
 
     def orb(self, gray):
         _, k, d = self.ext(gray)

@@ -1005,12 +1005,14 @@ class PoseOptimizer:
 
     SUMS_TREE, SUMS_EDGE_ORDER = 0, 1  # GFS_POSE_SUMS_* (include/gfs_abi.h)
 
-    def __init__(self, max_obs=4096, max_batch=64, device=0, sums="tree"):
-        """sums: "tree" (the library's default: sums over the edges by a fixed-shape tree) or "edge_order" (g2o's order on one lane: the
-        bits of the sequential code, about twice the latency of a single frame)."""
+    def __init__(self, max_obs=4096, max_batch=64, device=0, sums=None):
+        """sums: None = the library's default (g2o's edge order on one lane: the bits of the sequential code, the reference's outlier
+        flags), "edge_order" = the same, said explicitly, or "tree" (opt-in: sums over the edges by a fixed-shape tree, about half the
+        latency of a single frame, flags equal up to chi2-threshold ties)."""
         self.h = C.c_void_p()
         _check(lib().gfs_pose_create(device, max_obs, max_batch, C.byref(self.h)), "gfs_pose_create")
-        _check(lib().gfs_pose_set_sum_order(self.h, {"tree": 0, "edge_order": 1}[sums]), "gfs_pose_set_sum_order")
+        if sums is not None:
+            _check(lib().gfs_pose_set_sum_order(self.h, {"tree": 0, "edge_order": 1}[sums]), "gfs_pose_set_sum_order")
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

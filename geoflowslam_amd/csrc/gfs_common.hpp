@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/gfs_abi.h"
+#include "../../include/gfs_abi_test.h"  // the test hooks are compiled into the library; their prototypes are not part of the boundary
 
 namespace gfs {
 

@@ -679,7 +679,10 @@ __global__ __launch_bounds__(64 * kFcWaves) void k_fast_cells(const CellDev* __r
 #pragma unroll
   for (int j = 0; j < 4; j++) vmask |= (u0 + j >= ua && u0 + j <= ub) ? (1u << j) : 0u;
   if (!lane_on) vmask = 0;
-  const int th_hi = min(max(ini_th, 0), 255), th_lo = min(max(min_th, 0), 255);
+  // (th_lo <= th_hi: the fallback pass runs only for a cell whose first pass kept nothing, and a threshold above the first one
+  //  cannot find a corner the first one missed -- the reference's second cv::FAST call then returns nothing as well, src/ORBextractor.cc:825-827.
+  //  Clamping keeps that result and the NMS's assumption that stale scores of pass 0 lie below pass 1's threshold.)
+  const int th_hi = min(max(ini_th, 0), 255), th_lo = min(min(max(min_th, 0), 255), th_hi);
   const float inv_wp = 1.0f / (float)wp;
   int nk = 0;
   [[maybe_unused]] int fc_nq = 0, fc_nc = 0;

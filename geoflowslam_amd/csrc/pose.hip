@@ -740,7 +740,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
       constexpr int kTerms = 2 * kSlabDoubles;
       int bad_local = 0, good_local = 0;
       float avg = 0.0f;  // thread 0
-      float mine_avg = 0.0f;  // kTree: the thread's inlier terms, mono list first, then the stereo list
+      double mine_avg = 0.0;  // kTree: the thread's inlier terms (floats, added exactly in double), mono list first, then the stereo list
       for (int pass = 0; pass < 2; pass++)
         for (int base = 0; base < n; base += kTerms) {
           const int cnt = min(kTerms, n - base);
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
                 if (!out) term = c;
               }
             });
-            if constexpr (kTree) mine_avg += term;
+            if constexpr (kTree) mine_avg += (double)term;
             else s_term[e - base] = term;
           }
           if constexpr (!kTree) {
@@ -766,8 +766,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(const PoseFrame* __re
             __syncthreads();
           }
         }
-      if constexpr (kTree) {  // (float terms, exactly representable in double: summed in double and rounded once)
-        avg = (float)block_sum256((double)mine_avg, s4);
+      if constexpr (kTree) {  // (float terms, exactly representable in double: every partial sum in double, rounded once)
+        avg = (float)block_sum256(mine_avg, s4);
       }
       nBad = (int)block_sum256((double)bad_local, s4);
       nGood += (int)block_sum256((double)good_local, s4);  // nGood is never reset between the rounds
@@ -831,7 +831,7 @@ struct gfs_pose {
   }
   gfs::DevBuf<double> d_err;
   gfs::DevBuf<uint8_t> d_level;
-  int sum_order = GFS_POSE_SUMS_TREE;
+  int sum_order = GFS_POSE_SUMS_EDGE_ORDER;  // the ABI default reproduces g2o's integer outputs; the tree is opt-in (gfs_abi.h)
 };
 
 extern "C" {

@@ -122,18 +122,7 @@ int gfs_orb_octree_host(const int32_t* x, const int32_t* y, const int32_t* score
  * candidates (x, y, score) in list order; returns their number. */
 int gfs_orb_octree_device(int device, const int32_t* x, const int32_t* y, const int32_t* score, int n, int min_x, int max_x,
                           int min_y, int max_y, int n_features, int32_t* out_x, int32_t* out_y, int32_t* out_score, int cap);
-/* Host test hooks for the libstdc++ std::sort replica used by the device quadtree (sorts (size, x) pairs in place). */
-int gfs_test_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
-int gfs_test_heap_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
-
-/* GPU test hook: sin(x), cos(x), pow(x, 3.0) of n doubles evaluated on the device with the restated glibc 2.35 arithmetic
- * (csrc/glibc_math.hpp) that the pose / window / registration optimizers use for SE3Quat::exp
- * (Thirdparty/g2o/g2o/types/se3quat.h:223-257) and the Levenberg step control (core/optimization_algorithm_levenberg.cpp:127). */
-int gfs_test_glibc_math(int device, const double* x, int n, double* sin_out, double* cos_out, double* pow3_out);
-/* GPU test hook for calibrating the HBM counters (profiles/calibrate.sh): a kernel with a KNOWN byte count -- mode 0 streaming read,
- * 1 per-lane gathers of 32-byte records out of a table of `table` records, 2 streaming write; n records (mode 1: n threads x per_thread
- * gathers).  *bytes_out = the bytes the kernel asked for. */
-int gfs_test_traffic(int device, int mode, long long n, long long table, int per_thread, long long* bytes_out);
+/* (the gfs_test_* hooks of the library's internal replicas -- sort, glibc math, traffic calibration -- are in gfs_abi_test.h) */
 
 /* ============================================================================================
  * 2. Brute-force Hamming matching — replaces
@@ -229,15 +218,6 @@ int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset);
 /* Diagnostics (tools/knn_probe.py): out = {down-sampled points, queries deferred to the r = 2 pass, queries deferred to the
  * isolated-point pass} of cloud (b, which) of the last call; dk (may be NULL): the squared-distance bounds of the latter. */
 int gfs_gicp_knn_stats(gfs_gicp* h, int b, int which, int out[3], double* dk, int cap);
-/* GPU test hook: the voxel sort of the preprocessing — the device replica of small_gicp's quick_sort_omp
- * (util/sort_omp.hpp:58-85: 3-way quicksort above 1024 elements, libstdc++ std::sort below), whose permutation of
- * equal keys decides the 1024-block splits of voxelgrid_sampling_omp (util/downsampling_omp.hpp:57-90) — on n <=
- * max_points caller keys (3 x 21-bit voxel fields, or all ones = invalid).  perm_out[i] = input index of the i-th
- * element of the sorted sequence. */
-int gfs_test_voxel_sort(gfs_gicp* h, const unsigned long long* keys, int n, unsigned* perm_out);
-/* GPU test hook: the one-wave std::sort replica (csrc/wave_std_sort.hpp: the voxel sort's leaves, sort_omp.hpp:61, and the quadtree's
- * (size, x) list, ORBextractor.cc:697-698) on n <= 1024 caller keys; perm_out[i] = original index of the element left at position i. */
-int gfs_test_wave_std_sort(int device, const unsigned* keys, int n, unsigned short* perm_out);
 
 /* ============================================================================================
  * 4. Local bundle adjustment — replaces the numeric core of Optimizer::LocalBundleAdjustment
@@ -371,11 +351,13 @@ void gfs_pose_destroy(gfs_pose* h);
 /* B independent frames (host pointers), one workgroup per frame. */
 int gfs_pose_optimize(gfs_pose* h, const gfs_pose_problem* problems, int B, gfs_pose_solution* solutions);
 /* How the sums over a frame's edges (activeRobustChi2, the 6x6 normal equations, the inliers' mean chi2) are added up.
- *   GFS_POSE_SUMS_TREE (default): a tree of fixed shape -- deterministic, the same bits for a frame alone or inside any batch; against
- *     g2o's edge-by-edge sums the last bits differ (the bar on the pose is 1e-5; an outlier flag can differ only for an edge whose chi2
- *     sits within rounding of 5.991 / 7.815).
- *   GFS_POSE_SUMS_EDGE_ORDER: g2o's order, edge after edge on one lane (core/sparse_optimizer.cpp:104-122, core/base_unary_edge.hpp:43-72):
- *     every double as the sequential code computes it, ~2x the latency of a single frame. */
+ *   GFS_POSE_SUMS_EDGE_ORDER (default since round 6): g2o's order, edge after edge on one lane (core/sparse_optimizer.cpp:104-122,
+ *     core/base_unary_edge.hpp:43-72): every double as the sequential code computes it -- mvbOutlier, the return value, the LM
+ *     iteration counts and the pose are those of the reference's single-threaded solve, bit for bit against the oracle restatement.
+ *   GFS_POSE_SUMS_TREE (opt-in): a tree of fixed shape -- deterministic, the same bits for a frame alone or inside any batch, about
+ *     half the latency of a single frame; against g2o's edge-by-edge sums the last bits differ.  GUARANTEED (tests/test_gpu_pose.py):
+ *     pose within 1e-7 relative; an outlier flag can differ only for an edge whose chi2 sits within 7.8e-6 of 5.991 / 7.815, the LM
+ *     iteration count by at most 2.  A caller that needs the reference's flags exactly keeps the default. */
 #define GFS_POSE_SUMS_TREE 0
 #define GFS_POSE_SUMS_EDGE_ORDER 1
 int gfs_pose_set_sum_order(gfs_pose* h, int order);

@@ -13,9 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_header_symbols_exported(api):
-    hdr = open(os.path.join(ROOT, "include", "gfs_abi.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(gfs_[a-z0-9_]+)\s*\(", hdr)))
+    declared = []
+    for name in ("gfs_abi.h", "gfs_abi_test.h"):  # the boundary, and the test hooks kept apart from it
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        syms = set(re.findall(r"\b(gfs_[a-z0-9_]+)\s*\(", hdr))
+        assert all(s.startswith("gfs_test_") for s in syms) == (name == "gfs_abi_test.h"), name
+        assert not any(s.startswith("gfs_test_") for s in syms) or name == "gfs_abi_test.h", "test hook in the product header"
+        declared += sorted(syms)
+    declared = sorted(set(declared))
     assert len(declared) >= 35
     L = api.lib()
     missing = [s for s in declared if not hasattr(L, s)]

@@ -124,6 +124,43 @@ def test_supervisor_prints_exactly_one_line_whatever_the_child_does(tmp_path, mo
     assert "some library chatter" in cp.stderr
 
 
+def test_supervisor_prints_the_headline_when_it_is_stopped_by_a_signal(tmp_path):
+    """the most likely way a slow run ends is an outer `timeout` / the driver sending SIGTERM to the PARENT while the child
+    is inside a side leg.  The newest line must still reach stdout (rc 0), marked incomplete and -- the oracle check having been asked
+    for and not done -- `verified: false`."""
+    import signal
+    import time
+    fake = tmp_path / "fake_bench.py"
+    fake.write_text(textwrap.dedent('''
+        import json, os, sys, time
+        print(json.dumps({"value": 1.0, "roofline": {"frac": 0.3}, "verify_requested": 16}), flush=True)
+        open(sys.argv[1], "w").write("in a side leg")
+        time.sleep(120)
+    '''))
+    flag = tmp_path / "flag"
+    drv = tmp_path / "drv.py"
+    drv.write_text(textwrap.dedent(f'''
+        import importlib.util, sys
+        spec = importlib.util.spec_from_file_location("bench_mod", {os.path.join(ROOT, "bench.py")!r})
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+        m.__file__ = {str(fake)!r}
+        m.supervise([{str(flag)!r}], 100.0)
+    '''))
+    p = subprocess.Popen([sys.executable, str(drv)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not flag.exists() and time.time() - t0 < 60:
+        time.sleep(0.05)
+    assert flag.exists()
+    time.sleep(0.3)  # the reader thread has the line by now
+    p.send_signal(signal.SIGTERM)  # the exact PID this test started
+    out, err = p.communicate(timeout=30)
+    assert p.returncode == 0, (p.returncode, err)
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and "signal" in d["side_legs_incomplete"] and d["verified"] is False
+
+
 def test_every_side_leg_of_bench_is_guarded():
     """Static: in main(), after the timed region, every statement that can raise sits in a try / guarded() leg, and the line is
     assembled from .get()-style accesses of the legs' objects."""

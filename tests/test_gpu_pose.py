@@ -14,7 +14,7 @@ def _rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
 
 
-SUMS = ["tree", "edge_order"]  # the handle's default (fixed-shape tree sums) and g2o's edge order (the restatement's bits)
+SUMS = [None, "edge_order", "tree"]  # the handle's default (= g2o's edge order: the restatement's bits), the same said explicitly, the opt-in tree sums
 
 
 def _flips_are_proved_ties(r, ro):
@@ -27,7 +27,7 @@ def _flips_are_proved_ties(r, ro):
     return len(flip)
 
 
-def _same(r, ro, sums="edge_order"):
+def _same(r, ro, sums=None):
     if sums == "tree":
         nflip = _flips_are_proved_ties(r, ro)
         assert abs(r["n_inliers"] - ro["n_inliers"]) <= nflip and r["rounds_run"] == ro["rounds_run"]
@@ -105,7 +105,7 @@ def test_random_frames_follow_the_oracle_bit_for_bit(gpu_api, oracle):
     (core/sparse_optimizer.cpp:104-122, core/base_unary_edge.hpp:43-72) and sin / cos / pow carry glibc's bits, so the LM
     iteration counts -- decided at a converged state by the sign of a gain ratio that is rounding noise -- the poses and the
     per-edge chi2 are the CPU restatement's, bit for bit."""
-    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1, sums="edge_order")
+    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1)  # the ABI default: what a drop-in caller gets
     differ = []
     for i in range(1200):
         rng = np.random.default_rng([77, i])
@@ -123,11 +123,11 @@ def test_random_frames_follow_the_oracle_bit_for_bit(gpu_api, oracle):
 
 
 def test_random_frames_with_tree_sums_meet_the_bar_or_have_a_proved_tie(gpu_api, oracle):
-    """The same 1 200 frames through the handle's default, fixed-shape tree sums: pose within 1e-5 (north_star's bar for BA poses; the
+    """The same 1 200 frames through the opt-in fixed-shape tree sums (GFS_POSE_SUMS_TREE): pose within 1e-5 (north_star's bar for BA poses; the
     observed differences are ~1e-12), chi2 within 1e-6, and the integer outputs -- outlier flags, n_inliers -- equal to the
     restatement's in at least 99.9 % of the frames, every flipped flag proved to belong to an edge whose chi2 sits within rounding of
     its threshold (the same kind of rule as the k-th-distance ties of the GICP test)."""
-    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1)
+    po = gpu_api.PoseOptimizer(max_obs=2048, max_batch=1, sums="tree")
     frames_with_flips, worst = 0, 0.0
     for i in range(1200):
         rng = np.random.default_rng([77, i])
