@@ -184,7 +184,7 @@ ABI_SYMBOLS = [
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",
-    "gfs_gicp_fetch_preprocessed", "gfs_gicp_tile_stats", "gfs_gicp_knn_stats", "gfs_frame_rgbd", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort", "gfs_test_wave_std_sort",
+    "gfs_gicp_fetch_preprocessed", "gfs_gicp_tile_stats", "gfs_gicp_knn_stats", "gfs_gicp_coop_stats", "gfs_frame_rgbd", "gfs_gicp_align_next", "gfs_gicp_align_next_batch_device", "gfs_test_voxel_sort", "gfs_test_wave_std_sort",
     "gfs_lba_create", "gfs_lba_destroy", "gfs_lba_solve", "gfs_lba_solve_bool", "gfs_lba_linearize", "gfs_lba_batch_create", "gfs_lba_batch_destroy",
     "gfs_lba_solve_batch",
     "gfs_frame_create", "gfs_frame_destroy", "gfs_depth_to_cloud", "gfs_depth_to_cloud_batch_device", "gfs_depth_convert_u16_batch_device", "gfs_stereo_from_rgbd",
@@ -243,6 +243,7 @@ def lib():
             L.gfs_gicp_fetch_preprocessed.argtypes = [vp, i, i, vp, vp, i, ip]
             L.gfs_gicp_tile_stats.argtypes = [vp, vp, i]
             L.gfs_gicp_knn_stats.argtypes = [vp, i, i, vp, vp, i]
+            L.gfs_gicp_coop_stats.argtypes = [vp, vp]
             L.gfs_test_voxel_sort.argtypes = [vp, vp, i, vp]
             L.gfs_test_wave_std_sort.argtypes = [i, vp, i, vp]
             L.gfs_gicp_align_next.argtypes = [vp, vp, i, vp, C.POINTER(GicpConfig), C.POINTER(GicpResult)]
@@ -580,6 +581,12 @@ class RegistrationGICP:
         out = np.zeros(8, np.uint64)
         _check(lib().gfs_gicp_tile_stats(self.h, _p(out), int(reset)), "gfs_gicp_tile_stats")
         return out
+
+    def coop_stats(self):
+        """dict(launches, last_workgroups, failed, budget) of the cooperative LM kernel on this handle: gfs_gicp_coop_stats."""
+        out = np.zeros(4, np.int32)
+        _check(lib().gfs_gicp_coop_stats(self.h, _p(out)), "gfs_gicp_coop_stats")
+        return dict(launches=int(out[0]), last_workgroups=int(out[1]), failed=bool(out[2]), budget=int(out[3]))
 
     def knn_stats(self, b, which, cap=256):
         """(points, deferred to the r = 2 pass, deferred to the isolated-point pass), bounds of the latter: gfs_gicp_knn_stats."""

@@ -13,6 +13,7 @@
 // fixed stride of P entries.  Down-sampled points are stored sorted by (cell z, cell y, cell x) so that one cell
 // and its two x-neighbours form a contiguous run: a 27-cell probe is 9 binary searches + 9 linear runs.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -1848,14 +1849,28 @@ __device__ __forceinline__ void inv3(const double* A, double* M) {
 // leaves instead of waiting at two barriers for the slowest of its block (clock64 per section, -DGFS_LIN_TIMING in round 4: a
 // wave of k_gicp_linearize lived 55 - 74 k cycles, 7 - 23 k of them in the reduction, nearly all of that waiting).
 constexpr int kLinWaves = kLinBlock / 64;
-template <int N>
+// Words that cross WORKGROUPS inside one launch (k_gicp_lm_coop): 8-byte relaxed agent-scope accesses = `global_load / global_store
+// ... sc1` on gfx950 -- write-through stores and L1-bypassing loads, so that no release / acquire fence (an L2 write-back, an L1
+// invalidate) is needed around them; the publishing wave drains its stores (s_waitcnt vmcnt(0)) before the arrival is counted.
+template <class T>
+__device__ __forceinline__ T ld_ag(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_ag(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int N, bool kAgent = false>
 __device__ __forceinline__ void wave_reduce_store(double (&vals)[N], double* __restrict__ dst_block, int wave) {
   const double tot = gfs_red::wave_sum_many<N>(vals);
   const int lane = threadIdx.x & 63;
-  if (lane < N) dst_block[wave * N + lane] = tot;
+  if (lane < N) {
+    if constexpr (kAgent) st_ag(dst_block + wave * N + lane, tot);
+    else dst_block[wave * N + lane] = tot;
+  }
 }
 // ... a batch of N <= 16 values whose places in the block's kRed-vector are given by `map`
-template <int N>
+template <int N, bool kAgent = false>
 __device__ __forceinline__ void wave_reduce_store_map(double (&vals)[N], const int (&map)[N], double* __restrict__ dst_block, int wave) {
   const double tot = gfs_red::wave_sum_many<N>(vals);
   const int lane = threadIdx.x & 63;
@@ -1863,7 +1878,8 @@ __device__ __forceinline__ void wave_reduce_store_map(double (&vals)[N], const i
     int at = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) at = lane == k ? map[k] : at;
-    dst_block[wave * kRed + at] = tot;
+    if constexpr (kAgent) st_ag(dst_block + wave * kRed + at, tot);
+    else dst_block[wave * kRed + at] = tot;
   }
 }
 // A 256-point chunk of a cloud is one workgroup of four waves, or -- the search kernels that need no LDS -- four workgroups of one
@@ -2206,12 +2222,23 @@ struct LinFactor {
 // index of each batch value in the 29-vector (upper H row-major over (r, c >= r), then b, e, count)
 __device__ constexpr int kLinMapA[15] = {3, 8, 12, 4, 9, 13, 5, 10, 14, 15, 16, 17, 18, 19, 20};  // H_rt (column-major of -Q'), H_tt
 __device__ constexpr int kLinMapB[14] = {0, 1, 2, 6, 7, 11, 21, 22, 23, 24, 25, 26, 27, 28};       // H_rr, b, e, count
+// (a0 b0 + a1 b1 + a2 b2) and c + (...) as chains of explicit fused multiply-adds.  The bar for GICP is 1e-5 on the pose (the sums
+// are re-associated by the reduction tree anyway), so the factor uses FMAs -- written out, NOT left to `fp contract(fast)`: which
+// products the compiler fuses may differ between two instantiations of the same source (k_gicp_linearize, coop_lin_chunk,
+// k_gicp_lm), and the three must give the same bits (round 6: one pair in ~60 differed in the last bit of e).  The search stays
+// un-contracted so that the correspondences are decided on the same distances as in the oracle.
+__device__ __forceinline__ double fma3(double a0, double b0, double a1, double b1, double a2, double b2) {
+  return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+}
+__device__ __forceinline__ double fma3p(double c, double a0, double b0, double a1, double b1, double a2, double b2) {
+  return __builtin_fma(a2, b2, __builtin_fma(a1, b1, __builtin_fma(a0, b0, c)));
+}
+__device__ __forceinline__ double fmsub2(double a0, double b0, double a1, double b1) {  // a0 b0 - a1 b1
+  return __builtin_fma(a0, b0, -(a1 * b1));
+}
 __device__ __forceinline__ void lin_factor_prepare(int i, const double4 p, double tx, double ty, double tz, int ti, const double* __restrict__ T12,
                                                    int pair, int cs, int ct, int P, const double4* __restrict__ pts,
                                                    const double* __restrict__ cov6, double* __restrict__ maha6, LinFactor& F) {
-  // The bar for GICP is 1e-5 on the pose (the sums are re-associated by the reduction tree anyway): fused multiply-adds here; the
-  // search stays un-contracted so that the correspondences are decided on the same distances as in the oracle.
-#pragma clang fp contract(fast)
   F.on = ti >= 0;
   if (!F.on) return;
   const double* R = T12;
@@ -2221,11 +2248,11 @@ __device__ __forceinline__ void lin_factor_prepare(int i, const double4 p, doubl
   const double cs9[9] = {Cs[0], Cs[1], Cs[2], Cs[1], Cs[3], Cs[4], Cs[2], Cs[4], Cs[5]};
   double RC[9];
   for (int cc = 0; cc < 3; cc++)
-    for (int r = 0; r < 3; r++) RC[r + 3 * cc] = R[r] * cs9[3 * cc] + R[r + 3] * cs9[3 * cc + 1] + R[r + 6] * cs9[3 * cc + 2];
+    for (int r = 0; r < 3; r++) RC[r + 3 * cc] = fma3(R[r], cs9[3 * cc], R[r + 3], cs9[3 * cc + 1], R[r + 6], cs9[3 * cc + 2]);
   const double ct9[9] = {Ct[0], Ct[1], Ct[2], Ct[1], Ct[3], Ct[4], Ct[2], Ct[4], Ct[5]};
   double A[9];
   for (int cc = 0; cc < 3; cc++)
-    for (int r = 0; r < 3; r++) A[r + 3 * cc] = ct9[r + 3 * cc] + (RC[r] * R[cc] + RC[r + 3] * R[cc + 3] + RC[r + 6] * R[cc + 6]);
+    for (int r = 0; r < 3; r++) A[r + 3 * cc] = fma3p(ct9[r + 3 * cc], RC[r], R[cc], RC[r + 3], R[cc + 3], RC[r + 6], R[cc + 6]);
   double M[9];
   inv3(A, M);
   double* mo = maha6 + ((size_t)pair * P + i) * 6;
@@ -2239,9 +2266,9 @@ __device__ __forceinline__ void lin_factor_prepare(int i, const double4 p, doubl
   const double res[3] = {q.x - tx, q.y - ty, q.z - tz};
   double MR[9];  // M R
   for (int cc = 0; cc < 3; cc++)
-    for (int r = 0; r < 3; r++) MR[r + 3 * cc] = M[r] * R[3 * cc] + M[r + 3] * R[3 * cc + 1] + M[r + 6] * R[3 * cc + 2];
+    for (int r = 0; r < 3; r++) MR[r + 3 * cc] = fma3(M[r], R[3 * cc], M[r + 3], R[3 * cc + 1], M[r + 6], R[3 * cc + 2]);
   // N = R' (M R), upper triangle
-  auto rtm = [&](int a, int b) { return R[3 * a] * MR[3 * b] + R[3 * a + 1] * MR[3 * b + 1] + R[3 * a + 2] * MR[3 * b + 2]; };
+  auto rtm = [&](int a, int b) { return fma3(R[3 * a], MR[3 * b], R[3 * a + 1], MR[3 * b + 1], R[3 * a + 2], MR[3 * b + 2]); };
   F.N[0] = rtm(0, 0);
   F.N[1] = rtm(0, 1);
   F.N[2] = rtm(0, 2);
@@ -2249,38 +2276,37 @@ __device__ __forceinline__ void lin_factor_prepare(int i, const double4 p, doubl
   F.N[4] = rtm(1, 2);
   F.N[5] = rtm(2, 2);
   const double n9[9] = {F.N[0], F.N[1], F.N[2], F.N[1], F.N[3], F.N[4], F.N[2], F.N[4], F.N[5]};  // (symmetric: rows = columns)
-  for (int k = 0; k < 3; k++) F.w[k] = R[3 * k] * res[0] + R[3 * k + 1] * res[1] + R[3 * k + 2] * res[2];
-  for (int r = 0; r < 3; r++) F.u[r] = n9[r] * F.w[0] + n9[r + 3] * F.w[1] + n9[r + 6] * F.w[2];
+  for (int k = 0; k < 3; k++) F.w[k] = fma3(R[3 * k], res[0], R[3 * k + 1], res[1], R[3 * k + 2], res[2]);
+  for (int r = 0; r < 3; r++) F.u[r] = fma3(n9[r], F.w[0], n9[r + 3], F.w[1], n9[r + 6], F.w[2]);
   F.px = p.x;
   F.py = p.y;
   F.pz = p.z;
   // Q = N S, S = skew(p): S e0 = (0, pz, -py), S e1 = (-pz, 0, px), S e2 = (py, -px, 0)
   for (int r = 0; r < 3; r++) {
-    F.Q[r] = p.z * n9[r + 3] - p.y * n9[r + 6];
-    F.Q[r + 3] = p.x * n9[r + 6] - p.z * n9[r];
-    F.Q[r + 6] = p.y * n9[r] - p.x * n9[r + 3];
+    F.Q[r] = fmsub2(p.z, n9[r + 3], p.y, n9[r + 6]);
+    F.Q[r + 3] = fmsub2(p.x, n9[r + 6], p.z, n9[r]);
+    F.Q[r + 6] = fmsub2(p.y, n9[r], p.x, n9[r + 3]);
   }
 }
 // batch B: H_rr = S' N S = Q(:,c) x p (upper triangle), b = (u x p, -u), e = w' u / 2, inlier count
 __device__ __forceinline__ void lin_factor_batch_b(const LinFactor& F, double (&v)[14]) {
-#pragma clang fp contract(fast)
 #pragma unroll
   for (int k = 0; k < 14; k++) v[k] = 0;
   if (!F.on) return;
   // (a x p)_0 = a1 pz - a2 py, _1 = a2 px - a0 pz, _2 = a0 py - a1 px
-  v[0] = F.Q[1] * F.pz - F.Q[2] * F.py;  // H(0,0): (Q(:,0) x p)_0
-  v[1] = F.Q[4] * F.pz - F.Q[5] * F.py;  // H(0,1): (Q(:,1) x p)_0
-  v[2] = F.Q[7] * F.pz - F.Q[8] * F.py;  // H(0,2)
-  v[3] = F.Q[5] * F.px - F.Q[3] * F.pz;  // H(1,1): (Q(:,1) x p)_1
-  v[4] = F.Q[8] * F.px - F.Q[6] * F.pz;  // H(1,2)
-  v[5] = F.Q[6] * F.py - F.Q[7] * F.px;  // H(2,2): (Q(:,2) x p)_2
-  v[6] = F.u[1] * F.pz - F.u[2] * F.py;
-  v[7] = F.u[2] * F.px - F.u[0] * F.pz;
-  v[8] = F.u[0] * F.py - F.u[1] * F.px;
+  v[0] = fmsub2(F.Q[1], F.pz, F.Q[2], F.py);  // H(0,0): (Q(:,0) x p)_0
+  v[1] = fmsub2(F.Q[4], F.pz, F.Q[5], F.py);  // H(0,1): (Q(:,1) x p)_0
+  v[2] = fmsub2(F.Q[7], F.pz, F.Q[8], F.py);  // H(0,2)
+  v[3] = fmsub2(F.Q[5], F.px, F.Q[3], F.pz);  // H(1,1): (Q(:,1) x p)_1
+  v[4] = fmsub2(F.Q[8], F.px, F.Q[6], F.pz);  // H(1,2)
+  v[5] = fmsub2(F.Q[6], F.py, F.Q[7], F.px);  // H(2,2): (Q(:,2) x p)_2
+  v[6] = fmsub2(F.u[1], F.pz, F.u[2], F.py);
+  v[7] = fmsub2(F.u[2], F.px, F.u[0], F.pz);
+  v[8] = fmsub2(F.u[0], F.py, F.u[1], F.px);
   v[9] = -F.u[0];
   v[10] = -F.u[1];
   v[11] = -F.u[2];
-  v[12] = 0.5 * (F.w[0] * F.u[0] + F.w[1] * F.u[1] + F.w[2] * F.u[2]);
+  v[12] = 0.5 * fma3(F.w[0], F.u[0], F.w[1], F.u[1], F.w[2], F.u[2]);
   v[13] = 1.0;
 }
 // batch A: H_rt = -S' N = -Q' as its entries (r, 3 + c) = -Q(c, r), and H_tt = N
@@ -2651,9 +2677,72 @@ __device__ void solve_and_propose(const double* H21, const double* b6, double la
   for (int i = 0; i < 3; i++) newT12[9 + i] = T12[i] * E[9] + T12[i + 3] * E[10] + T12[i + 6] * E[11] + T12[9 + i];
 }
 
+// The two scalar steps of LevenbergMarquardtOptimizer::optimize (registration/optimizer.hpp:83-147) on a pair's state, shared by the
+// launch-per-step kernels (k_gicp_solve / k_gicp_decide: S in global memory) and the cooperative kernel (k_gicp_lm_coop: S is a copy
+// in LDS) -- one body, so that the two forms cannot drift apart by a bit.
+// (split so that a caller has ONE call site of the damped solve: its 6x6 LDL^T holds ~120 registers)
+// the damped solve of the state's last linearisation: delta and the trial pose
+__device__ __forceinline__ void lm_solve(PairState& S) {
+  double H[21], b[6], T[12], delta[6], newT[12];
+#pragma unroll
+  for (int k = 0; k < 21; k++) H[k] = S.H[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) b[k] = S.b[k];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = S.T[k];
+  solve_and_propose(H, b, S.lambda, T, delta, newT);
+#pragma unroll
+  for (int k = 0; k < 6; k++) S.delta[k] = delta[k];
+#pragma unroll
+  for (int k = 0; k < 12; k++) S.newT[k] = newT[k];
+}
+// after a linearisation: sums = the folded 29-vector (H upper 21 | b 6 | e | inlier count); lm_solve follows
+__device__ __forceinline__ void lm_after_linearize(PairState& S, const double* sums) {
+#pragma unroll
+  for (int k = 0; k < 21; k++) S.H[k] = sums[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) S.b[k] = sums[21 + k];
+  S.e = sums[27];
+  S.inliers = (int)(sums[28] + 0.5);
+  S.n_lin++;
+  S.inner = 0;
+  S.phase = 1;
+}
+// after an error pass over the trial pose: accept / reject (optimizer.hpp:115-141).  *done: the pair has finished (phase 2);
+// returns true when the trial was rejected and another damped solve (lm_solve, with the raised lambda) follows.
+__device__ __forceinline__ bool lm_after_error(PairState& S, double new_e, const GicpParams& prm, bool* done) {
+  S.n_err++;
+  *done = false;
+  if (new_e <= S.e) {
+    const double dr = sqrt(S.delta[0] * S.delta[0] + S.delta[1] * S.delta[1] + S.delta[2] * S.delta[2]);
+    const double dt = sqrt(S.delta[3] * S.delta[3] + S.delta[4] * S.delta[4] + S.delta[5] * S.delta[5]);
+    S.converged = (dr <= prm.rot_eps && dt <= prm.trans_eps) ? 1 : 0;
+    for (int k = 0; k < 12; k++) S.T[k] = S.newT[k];
+    S.lambda /= 10.0;
+    S.iterations = S.outer;
+    S.outer++;
+    if (S.converged || S.outer >= prm.max_iterations) {
+      S.phase = 2;
+      *done = true;
+    } else {
+      S.phase = 0;
+    }
+    return false;
+  }
+  S.lambda *= 10.0;
+  S.inner++;
+  if (S.inner >= 10) {  // max_inner_iterations: !success -> break
+    S.iterations = S.outer;
+    S.phase = 2;
+    *done = true;
+    return false;
+  }
+  return true;
+}
+
 // fixed-order sum of `n` blocks' partial vectors (kLinWaves wave vectors of `stride` doubles each, wave_reduce_store): the waves of
 // a block first, then 8 strided sub-sums per component over the blocks, then 8 -> 1
-template <int NCOMP>
+template <int NCOMP, bool kAgent = false>
 __device__ __forceinline__ void fold_partials(const double* __restrict__ part, int n, int stride, double* s_part /*[8][32]*/,
                                               double* s_out /*[32]*/) {
   const int comp = threadIdx.x & 31, sub = threadIdx.x >> 5;  // 256 threads = 32 components x 8 sub-sums
@@ -2661,8 +2750,16 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
   if (comp < NCOMP)
     for (int k = sub; k < n; k += 8) {
       double blk = 0;  // the block's sum: its waves in order
+      if constexpr (kAgent) {  // (written by other workgroups of this launch: L1-bypassing loads, all four in flight)
+        double v[kLinWaves];
 #pragma unroll
-      for (int w = 0; w < kLinWaves; w++) blk += part[((size_t)k * kLinWaves + w) * stride + comp];
+        for (int w = 0; w < kLinWaves; w++) v[w] = ld_ag(part + ((size_t)k * kLinWaves + w) * stride + comp);
+#pragma unroll
+        for (int w = 0; w < kLinWaves; w++) blk += v[w];
+      } else {
+#pragma unroll
+        for (int w = 0; w < kLinWaves; w++) blk += part[((size_t)k * kLinWaves + w) * stride + comp];
+      }
       a += blk;
     }
   s_part[sub * 32 + comp] = a;
@@ -2688,28 +2785,8 @@ __global__ __launch_bounds__(256) void k_gicp_solve(PairState* __restrict__ st, 
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
   fold_partials<kRed>(partial + (size_t)pair * nblk_max * kLinWaves * kRed, nblk, kRed, s_part, s_sum);
   if (threadIdx.x == 0) {
-    PairState& S = st[pair];
-    double H[21], b[6], T[12], delta[6], newT[12];
-#pragma unroll
-    for (int k = 0; k < 21; k++) H[k] = s_sum[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) b[k] = s_sum[21 + k];
-#pragma unroll
-    for (int k = 0; k < 12; k++) T[k] = S.T[k];
-    solve_and_propose(H, b, S.lambda, T, delta, newT);
-#pragma unroll
-    for (int k = 0; k < 21; k++) S.H[k] = H[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) S.b[k] = b[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) S.delta[k] = delta[k];
-#pragma unroll
-    for (int k = 0; k < 12; k++) S.newT[k] = newT[k];
-    S.e = s_sum[27];
-    S.inliers = (int)(s_sum[28] + 0.5);
-    S.n_lin++;
-    S.inner = 0;
-    S.phase = 1;
+    lm_after_linearize(st[pair], s_sum);
+    lm_solve(st[pair]);
   }
 }
 
@@ -2736,44 +2813,230 @@ __global__ __launch_bounds__(256) void k_gicp_decide(PairState* __restrict__ st,
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
   fold_partials<1>(epartial + (size_t)pair * nblk_max * kLinWaves, nblk, 1, s_part, s_sum);
   if (threadIdx.x != 0) return;
-  PairState& S = st[pair];
-  const double new_e = s_sum[0];
-  S.n_err++;
-  if (new_e <= S.e) {
-    const double dr = sqrt(S.delta[0] * S.delta[0] + S.delta[1] * S.delta[1] + S.delta[2] * S.delta[2]);
-    const double dt = sqrt(S.delta[3] * S.delta[3] + S.delta[4] * S.delta[4] + S.delta[5] * S.delta[5]);
-    S.converged = (dr <= prm.rot_eps && dt <= prm.trans_eps) ? 1 : 0;
-    for (int k = 0; k < 12; k++) S.T[k] = S.newT[k];
-    S.lambda /= 10.0;
-    S.iterations = S.outer;
-    S.outer++;
-    if (S.converged || S.outer >= prm.max_iterations) {
-      S.phase = 2;
-      atomicAdd(n_done, 1);
-    } else {
-      S.phase = 0;
+  bool done;
+  if (lm_after_error(st[pair], s_sum[0], prm, &done)) lm_solve(st[pair]);
+  if (done) atomicAdd(n_done, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gicp_lm_coop: the Levenberg-Marquardt loop of a FEW pairs without the host and without a launch per step -- G workgroups a
+// pair walk the pair's 256-point chunks (workgroup g takes chunks g, g + G, ...), write the SAME per-wave partial sums into the
+// SAME slots as k_gicp_linearize / k_gicp_error, meet at a per-pair barrier, and the workgroup that arrives last folds them with
+// the SAME fold_partials and takes the scalar step (lm_after_linearize / lm_after_error): the results are those of the
+// launch-per-step form bit for bit, whatever G is and whichever workgroup folds.
+//   Used (gicp_run) where four launches + a host poll per step are most of the time: a single pair (one live stream: ~5 steps of
+// 75 workgroups each), and the tail of a batch whose last few pairs iterate on an otherwise idle chip.
+//   What crosses workgroups -- the partial sums, the pair's state, the barrier words -- moves through 8-byte agent-scope accesses
+// (ld_ag / st_ag: write-through stores, L1-bypassing loads; every storing wave drains before its workgroup's arrival is counted,
+// MI355X guide: inter-workgroup communication).  tgt_index / maha6 of a point are written and re-read by the same thread (a chunk
+// belongs to one workgroup for the whole launch): plain accesses.
+//   The grid must be co-resident (waiting workgroups spin): gicp_run sizes it from the occupancy query, with a process-wide
+// budget.  Spins are bounded: a workgroup that waits too long sets the error word and leaves, gicp_run then repeats the call
+// with launches.
+// ------------------------------------------------------------------------------------------------
+// a wave-uniform double (read out of LDS) moved to scalar registers: what a scalar load of the launch-per-step kernels' state gives
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+struct CoopSync {
+  unsigned arrive;  // arrivals at this pair's barriers (monotonic within a launch; k_gicp_init zeroes it)
+  unsigned gen;     // barriers completed
+};
+constexpr int kStateWords = (int)(sizeof(PairState) / 8);
+static_assert(sizeof(PairState) % 8 == 0 && kStateWords <= 64, "PairState is moved as 8-byte words by one wave");
+constexpr unsigned kCoopSpinLimit = 4u << 20;  // polls of ~1 us: seconds, far beyond any legitimate wait
+
+// What the two per-chunk bodies need, uniform per launch.  It sits in LDS and the bodies are separate (noinline) functions that
+// read it back into scalar registers: inlined into the kernel's loops the linearisation took 200 - 240 VGPRs instead of the 94 it
+// takes in k_gicp_linearize (1 - 2 workgroups a CU: no budget for a tail of several pairs); as a function of its own it keeps its
+// registers, and the kernel around it is small.
+struct CoopCtx {
+  const double4* pts;
+  const double* cov6;
+  const u64* ucell;
+  const unsigned* ubegin;
+  const int* n_ucell;
+  const unsigned* grid;
+  const int* ginfo;
+  int* tgt_index;
+  double* maha6;
+  double* partial;
+  double* epartial;
+  int P, nblk;
+  GicpParams prm;
+};
+typedef __attribute__((address_space(3))) const unsigned* lds_words;
+// a struct of wave-uniform values out of LDS into scalar registers, word by word
+template <class T>
+__device__ __forceinline__ void uniform_load(T& dst, const void* lds_generic) {
+  static_assert(sizeof(T) % 4 == 0, "whole words");
+  const lds_words w = (lds_words)lds_generic;
+  unsigned tmp[sizeof(T) / 4];
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 4; k++) tmp[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)w[k]);
+  __builtin_memcpy(&dst, tmp, sizeof(T));
+}
+
+// GICPFactor::linearize of chunk `chunk` (256 source points, this workgroup's threads) of a pair under the pose in the LDS copy of
+// its state: the body of k_gicp_linearize<false>, partial sums stored write-through
+__device__ __attribute__((noinline)) void coop_lin_chunk(const void* ctx_lds, const void* state_lds, int pair_v, int chunk_v, int ms_v) {
+  CoopCtx C;
+  uniform_load(C, ctx_lds);
+  struct Head {
+    double T[12];
+  } Hd;
+  uniform_load(Hd, state_lds);  // PairState begins with T[12]
+  const int pair = __builtin_amdgcn_readfirstlane(pair_v), chunk = __builtin_amdgcn_readfirstlane(chunk_v),
+            ms = __builtin_amdgcn_readfirstlane(ms_v);
+  const bool has_prev = __builtin_amdgcn_readfirstlane(reinterpret_cast<const PairState*>(state_lds)->n_lin) > 0;
+  const int tid = threadIdx.x, P = C.P;
+  const int cs = 2 * pair + C.prm.src_slot, ct = 2 * pair + 1 - C.prm.src_slot;
+  const unsigned* G0 = C.grid + (size_t)ct * (kGridCap + 1);
+  const int* gi = C.ginfo + 8 * ct;
+  const double4* tp = C.pts + (size_t)ct * P;
+  const int i = chunk * kLinBlock + tid;
+  LinFactor F;
+  F.on = false;
+  if (i < ms) {
+    const double4 p = C.pts[(size_t)cs * P + i];
+    const int prev_j = has_prev ? C.tgt_index[(size_t)pair * P + i] : -1;
+    double4 prev_q = make_double4(0, 0, 0, 0);
+    if (prev_j >= 0) prev_q = tp[prev_j];
+    double tx = 0, ty = 0, tz = 0;
+    int cx = 0, cy = 0, cz = 0;
+    bool in_range = false;
+    lin_image(p, Hd.T, C.prm, tx, ty, tz, cx, cy, cz, in_range);
+    const NnGlobal src{tp, gi, G0, C.ucell + (size_t)ct * (P + 1), C.ubegin + (size_t)ct * (P + 1), C.n_ucell[ct]};
+    gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, Hd.T, has_prev, prev_j, prev_q, pair, cs, ct, P, C.pts, C.cov6, C.ucell, C.ubegin,
+                   C.n_ucell, G0, gi, C.prm, C.tgt_index, C.maha6, F);
+  }
+  double* dst = C.partial + ((size_t)pair * C.nblk + chunk) * kLinWaves * kRed;
+  const int wave_slot = tid >> 6;
+  {
+    double vb[14];
+    lin_factor_batch_b(F, vb);
+    wave_reduce_store_map<14, true>(vb, kLinMapB, dst, wave_slot);
+  }
+  {
+    double va[15];
+    lin_factor_batch_a(F, va);
+    wave_reduce_store_map<15, true>(va, kLinMapA, dst, wave_slot);
+  }
+}
+
+// GICPFactor::error of a chunk under the trial pose (the body of k_gicp_error)
+__device__ __attribute__((noinline)) void coop_err_chunk(const void* ctx_lds, const void* state_lds, int pair_v, int chunk_v, int ms_v) {
+  CoopCtx C;
+  uniform_load(C, ctx_lds);
+  struct Head {
+    double T[12], newT[12];
+  } Hd;
+  uniform_load(Hd, state_lds);  // PairState: T[12] | newT[12] | ...
+  const int pair = __builtin_amdgcn_readfirstlane(pair_v), chunk = __builtin_amdgcn_readfirstlane(chunk_v),
+            ms = __builtin_amdgcn_readfirstlane(ms_v);
+  const int tid = threadIdx.x, P = C.P;
+  const int cs = 2 * pair + C.prm.src_slot, ct = 2 * pair + 1 - C.prm.src_slot;
+  const int i = chunk * kLinBlock + tid;
+  double e[1] = {0.0};
+  if (i < ms) {
+    const int ti = C.tgt_index[(size_t)pair * P + i];
+    if (ti >= 0) {
+      const double4 p = C.pts[(size_t)cs * P + i];
+      const double* R = Hd.newT;
+      const double* t = Hd.newT + 9;
+      const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
+      const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
+      const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
+      const double4 q = C.pts[(size_t)ct * P + ti];
+      const double r0 = q.x - tx, r1 = q.y - ty, r2 = q.z - tz;
+      const double* M = C.maha6 + ((size_t)pair * P + i) * 6;
+      const double m0 = M[0] * r0 + M[1] * r1 + M[2] * r2, m1 = M[1] * r0 + M[3] * r1 + M[4] * r2,
+                   m2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
+      e[0] = 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
     }
-  } else {
-    S.lambda *= 10.0;
-    S.inner++;
-    if (S.inner >= 10) {  // max_inner_iterations: !success -> break
-      S.iterations = S.outer;
-      S.phase = 2;
-      atomicAdd(n_done, 1);
+  }
+  wave_reduce_store<1, true>(e, C.epartial + ((size_t)pair * C.nblk + chunk) * kLinWaves, tid >> 6);
+}
+static_assert(offsetof(PairState, T) == 0 && offsetof(PairState, newT) == 12 * sizeof(double), "coop_*_chunk read the head of PairState");
+
+__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gicp_lm_coop(
+    PairState* __restrict__ st, const double4* __restrict__ pts, const double* __restrict__ cov6, const u64* __restrict__ ucell,
+    const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
+    const unsigned* __restrict__ grid, const int* __restrict__ ginfo, int nchunks, int P, GicpParams prm, int* __restrict__ tgt_index,
+    double* __restrict__ maha6, double* __restrict__ partial, double* __restrict__ epartial, int nblk, const int* __restrict__ act,
+    const int* __restrict__ n_act, int n_fixed, CoopSync* __restrict__ sync, int* __restrict__ n_done, int* __restrict__ n_err) {
+  __shared__ double s_part[8 * 32], s_sum[32];
+  __shared__ u64 s_state[64];
+  __shared__ CoopCtx s_ctx;
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  // pairs of this launch: the list the previous round's k_gicp_decide wrote (act), or pairs 0 .. n_fixed - 1; every workgroup
+  // derives the same G from the same count
+  const int n = act ? *n_act : n_fixed;
+  if (n <= 0) return;
+  const int G = max(1, min(nchunks, (int)gridDim.x / n));
+  const int slot = blockIdx.x / G, g = blockIdx.x - slot * G;
+  if (slot >= n) return;
+  const int pair = act ? act[slot] : slot;
+  const int ms = m_counts[2 * pair + prm.src_slot];
+  const int nblk_pair = (ms + kLinBlock - 1) / kLinBlock;
+  const int Gp = max(1, min(G, nblk_pair));  // workgroups that have a chunk (at least one: the scalar steps must run)
+  if (g >= Gp) return;
+  if (tid == 0) s_ctx = CoopCtx{pts, cov6, ucell, ubegin, n_ucell, grid, ginfo, tgt_index, maha6, partial, epartial, P, nblk, prm};
+  u64* Sw = reinterpret_cast<u64*>(st + pair);
+  PairState& S = *reinterpret_cast<PairState*>(s_state);
+  CoopSync* sy = sync + pair;
+  unsigned episode = 0;
+  while (true) {
+    if (tid < kStateWords) s_state[tid] = ld_ag(Sw + tid);
+    __syncthreads();
+    const int phase = __builtin_amdgcn_readfirstlane(S.phase);
+    if (phase == 2) break;
+    if (phase == 0) {
+      for (int chunk = g; chunk < nblk_pair; chunk += Gp) coop_lin_chunk(&s_ctx, s_state, pair, chunk, ms);
     } else {
-      double H[21], b[6], T[12], delta[6], newT[12];
-#pragma unroll
-      for (int k = 0; k < 21; k++) H[k] = S.H[k];
-#pragma unroll
-      for (int k = 0; k < 6; k++) b[k] = S.b[k];
-#pragma unroll
-      for (int k = 0; k < 12; k++) T[k] = S.T[k];
-      solve_and_propose(H, b, S.lambda, T, delta, newT);
-#pragma unroll
-      for (int k = 0; k < 6; k++) S.delta[k] = delta[k];
-#pragma unroll
-      for (int k = 0; k < 12; k++) S.newT[k] = newT[k];
+      for (int chunk = g; chunk < nblk_pair; chunk += Gp) coop_err_chunk(&s_ctx, s_state, pair, chunk, ms);
     }
+    // ---- the pair's barrier: every storing wave drains, the workgroup's arrival is counted once, the last one takes the step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&sy->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == (episode + 1) * (unsigned)Gp - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last) {
+      bool done = false;
+      if (phase == 0) fold_partials<kRed, true>(partial + (size_t)pair * nblk * kLinWaves * kRed, nblk_pair, kRed, s_part, s_sum);
+      else fold_partials<1, true>(epartial + (size_t)pair * nblk * kLinWaves, nblk_pair, 1, s_part, s_sum);
+      if (tid == 0) {
+        bool solve = true;
+        if (phase == 0) lm_after_linearize(S, s_sum);
+        else solve = lm_after_error(S, s_sum[0], prm, &done);
+        if (solve) lm_solve(S);
+      }
+      __syncthreads();
+      if (tid < kStateWords) st_ag(Sw + tid, s_state[tid]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the state words are stored by wave 0, which also stores the flag)
+      if (tid == 0) {
+        if (done) atomicAdd(n_done, 1);
+        st_ag(&sy->gen, episode + 1);
+      }
+    } else if (tid == 0) {
+      unsigned spins = 0;
+      while (ld_ag(&sy->gen) < episode + 1) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kCoopSpinLimit) {  // never in a sized launch; leave a mark instead of a hung GPU
+          atomicAdd(n_err, 1);
+          s_last = -1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_last < 0) return;  // (the other workgroups of the pair run into the same limit; gicp_run repeats the call with launches)
+    episode++;
   }
 }
 
@@ -2915,9 +3178,11 @@ __global__ __launch_bounds__(kLmBlock) __attribute__((amdgpu_waves_per_eu(4, 8))
 }
 
 __global__ void k_gicp_init(PairState* __restrict__ st, const double* __restrict__ init_T, int B, int max_iterations,
-                            int* __restrict__ n_done) {
+                            int* __restrict__ n_done, CoopSync* __restrict__ sync) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= B) return;
+  sync[pair].arrive = 0;
+  sync[pair].gen = 0;
   PairState& S = st[pair];
   const double* T = init_T + 16 * (size_t)pair;
   for (int c = 0; c < 3; c++)
@@ -2960,6 +3225,17 @@ struct gfs_gicp {
   // 128 pairs per batch (25 vs 6 ms per 512 pairs), it pays only for batches of many thousand small pairs.
   gfs::DevBuf<int> d_active, d_nactive;  // [2][B] pairs still iterating (written by k_gicp_decide for the next round), [2] their number
   bool lm_rounds = true;
+  // k_gicp_lm_coop (the loop of a few pairs in one launch): GFS_GICP_COOP=0 switches it off; coop_cap = workgroups of it the device
+  // holds at once (occupancy query, one fewer per CU than the API says: the hardware may admit fewer); a launch takes its
+  // workgroups from a process-wide budget of half of that (CoopBudget) and gives them back when the call has been waited for
+  bool coop = true, coop_failed = false;
+  int coop_cap = 0, coop_reserved = 0, coop_launches = 0, coop_last_wgs = 0;
+  // GFS_GICP_COOP_TAIL = f > 0: the TAIL of a larger batch also goes to the kernel once (pairs left) x (chunks a pair) <= f x budget.
+  // Off by default -- measured (round 6, 64-pair block in 2 lanes): 2.07 ms a step without, 2.09 / 2.11 / 2.17 / 2.29 ms with f = 1 / 2 /
+  // 4 / 8: on a chip that other lanes keep busy a barrier episode (drain, arrival, fold by the last workgroup, publish, poll) costs
+  // what the two launch boundaries it replaces cost, and the resident workgroups are in the other lanes' way.
+  double coop_tail = 0.0;
+  gfs::DevBuf<CoopSync> d_sync;
   bool tile_stats_on = false;  // GFS_GICP_TILE_STATS=1
   gfs::DevBuf<unsigned> d_tile_stats;  // [8] outcome counters of k_gicp_linearize's tile staging (gfs_gicp_tile_stats)
   bool vqs_lds = true;  // GFS_GICP_VQS_LDS=0: without k_voxel_qsort_top_lds
@@ -2979,6 +3255,28 @@ struct gfs_gicp {
   double last_leaf = 0, last_cell = 0;
   int last_k = 0;
   gfs::DevBuf<int> d_zero;  // [Bmax] zeros: the point counts of the slot that is not re-read in a streaming call
+};
+
+// Workgroups of k_gicp_lm_coop in flight in this process, per device: the kernel's workgroups wait for each other, so all of them
+// -- of every handle's launch -- must be resident together.  A launch reserves before it is enqueued and releases after its call's
+// final synchronisation; a launch that cannot get enough falls back to the launch-per-step rounds.
+struct CoopBudget {
+  static std::atomic<int>& in_use(int device) {
+    static std::atomic<int> a[64];
+    return a[device & 63];
+  }
+  static int reserve(int device, int want, int least, int total) {
+    std::atomic<int>& u = in_use(device);
+    int cur = u.load();
+    while (true) {
+      const int get = std::min(want, total - cur);
+      if (get < least) return 0;
+      if (u.compare_exchange_weak(cur, cur + get)) return get;
+    }
+  }
+  static void release(int device, int n) {
+    if (n > 0) in_use(device).fetch_sub(n);
+  }
 };
 
 // The n >= 1024 levels of the voxel sort: the LDS-resident kernel for clouds of at most kVqsLdsE * 1024 points whose keys compact to
@@ -3085,6 +3383,18 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   GFS_HIP(hipFuncSetAttribute((const void*)k_cell_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kCsLdsBytes));
   if (const char* e = getenv("GFS_GICP_LM")) h->lm_rounds = strcmp(e, "persistent") != 0;
   if (const char* e = getenv("GFS_GICP_TILE_STATS")) h->tile_stats_on = atoi(e) != 0;
+  if (const char* e = getenv("GFS_GICP_COOP")) h->coop = atoi(e) != 0;
+  if (const char* e = getenv("GFS_GICP_COOP_TAIL")) h->coop_tail = atof(e);
+  {
+    int per_cu = 0, cus = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_gicp_lm_coop, kLinBlock, 0) == hipSuccess &&
+        hipGetDeviceProperties(&prop, device) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    h->coop_cap = std::max(0, std::min(per_cu, 8) - 1) * cus;
+    if (const char* e = getenv("GFS_GICP_COOP_WGS")) h->coop_cap = std::min(h->coop_cap, 2 * std::max(0, atoi(e)));  // (budget = cap / 2)
+    (void)hipGetLastError();
+  }
   const size_t P = h->P, B = max_batch, C2 = 2 * B;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
@@ -3105,7 +3415,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_kinfo1.alloc(C2 * 8));
   A(h->d_kinfo2.alloc(C2 * 8));
   A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
-  A(h->d_ndone.alloc(2));  // [0] pairs done, [1] clouds the LDS sort kernel left to the kernels that were not launched
+  A(h->d_ndone.alloc(4));  // [0] pairs done, [1] clouds the LDS sort kernel left to the kernels that were not launched, [2] k_gicp_lm_coop's timeouts
+  A(h->d_sync.alloc(B));
   A(h->d_active.alloc(2 * (size_t)B));
   A(h->d_nactive.alloc(2));
   A(h->d_tile_stats.alloc(8));
@@ -3134,7 +3445,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_initT.alloc(B * 16));
   A(h->d_state.alloc(B));
   A(h->h_state.alloc(B));
-  A(h->h_ndone.alloc(4));
+  A(h->h_ndone.alloc(8));  // [0..3] the two rounds in flight, [4..6] the call's last look
   for (int k = 0; k < 2; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_round[k], hipEventDisableTiming));
   A(h->h_m.alloc(C2));
   A(h->h_initT.alloc(B * 16));
@@ -3214,7 +3525,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   for (int b = 0; b < B; b++)
     for (int k = 0; k < 16; k++) h->h_initT.p[16 * b + k] = init_T ? init_T[16 * b + k] : (k % 5 == 0 ? 1.0 : 0.0);
   GFS_HIP(hipMemcpyAsync(h->d_initT.p, h->h_initT.p, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, 2 * sizeof(int), s));
+  GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, 4 * sizeof(int), s));
   const int npts = std::min(stride_pts, P);
   // The cell sort key gives the cell z 19 bits, y 20 and x (in sixteenths) 25: every coordinate of a voxel mean fits while
   // |coordinate| < 2^18 cells.  The voxel fields admit 10^6 leaves, which is less whenever cell >= 4 leaves (the reference's
@@ -3279,7 +3590,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
                h->d_far2.p, far2_chunks, B, P, prm, h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
   GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
-             prm.max_iterations, h->d_ndone.p);
+             prm.max_iterations, h->d_ndone.p, h->d_sync.p);
   if (!h->lm_rounds) {
     // the whole Levenberg-Marquardt loop of a pair in one workgroup (k_gicp_lm): one launch, no host poll
     GFS_LAUNCH("k_gicp_lm", k_gicp_lm, dim3(B), dim3(kLmBlock), 0, s, h->d_state.p, h->d_pts.p, h->d_cov6.p, h->d_ucell.p,
@@ -3288,11 +3599,37 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     const int nblk_run = gfs::div_up(npts, kLinBlock);
     const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
     int known_done = 0;  // pairs known to be done: the count polled one round behind
-    for (int round = 0; round < max_rounds; round++) {
+    // k_gicp_lm_coop takes the loop of `n_ub` pairs (an upper bound of those still iterating; the exact list, if any, is on the
+    // device) off the host: the rest of the loop is ONE launch.  Its workgroups wait for each other, so they come out of the
+    // process-wide budget; with too few left the rounds below carry on.
+    static const bool lin_wg_default = !getenv("GFS_GICP_LIN_WG") || atoi(getenv("GFS_GICP_LIN_WG")) / 64 * 64 >= 256;
+    const bool coop_ok = h->coop && !h->coop_failed && !prm.lin_tile && lin_wg_default && h->coop_cap > 0 && prm.max_iterations > 0;
+    const int coop_budget = h->coop_cap / 2;
+    auto launch_coop = [&](int n_ub, const int* act_list, const int* n_act_list) -> bool {
+      const int want = std::min(n_ub * nblk_run, coop_budget);
+      const int got = CoopBudget::reserve(h->device, want, std::max(n_ub, want / 2), coop_budget);
+      if (got <= 0) return false;
+      h->coop_reserved += got;
+      h->coop_launches++;
+      h->coop_last_wgs = got;
+      GFS_LAUNCH("k_gicp_lm_coop", k_gicp_lm_coop, dim3(got), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p, h->d_cov6.p, h->d_ucell.p,
+                 h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p, nblk_run, P, prm, h->d_tgt_index.p, h->d_maha6.p,
+                 h->d_partial.p, h->d_epartial.p, h->nblk, act_list, n_act_list, n_ub, h->d_sync.p, h->d_ndone.p, h->d_ndone.p + 2);
+      return true;
+    };
+    // a batch small enough for a workgroup per chunk of every pair (one live stream: B = 1) runs its whole loop there
+    bool in_coop = coop_ok && (long long)B * nblk_run <= coop_budget && launch_coop(B, nullptr, nullptr);
+    for (int round = 0; round < max_rounds && !in_coop; round++) {
       // Late rounds run for a handful of pairs: their grids are cut to the pairs still iterating.  The host knows an upper bound
       // (the done counter it polled for round - 2); the list itself is written on the device by the previous round's
       // k_gicp_decide.  While most pairs are active the full grid with its XCD-aware pair -> block map is kept.
       const int ub = B - known_done;
+      // ... and once the pairs left would each get at least 1 / coop_tail of a workgroup per chunk, the tail goes to the cooperative kernel
+      if (coop_ok && round >= 2 && ub < B && (double)ub * nblk_run <= h->coop_tail * coop_budget &&
+          launch_coop(ub, h->d_active.p + (size_t)(round & 1) * B, h->d_nactive.p + (round & 1))) {
+        in_coop = true;
+        break;
+      }
       const bool listed = round >= 2 && 4 * ub <= B;
       const int* act = listed ? h->d_active.p + (size_t)(round & 1) * B : nullptr;
       const int* n_act = h->d_nactive.p + (round & 1);
@@ -3342,9 +3679,19 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   }
   GFS_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, (size_t)B * sizeof(PairState), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_m.p, h->d_m.p, (size_t)C2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  if (optimistic_sort) GFS_HIP(hipMemcpyAsync(h->h_ndone.p, h->d_ndone.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipStreamSynchronize(s));
-  if (optimistic_sort && h->h_ndone.p[1] > 0) {  // (the polls inside the loop normally catch this after round 0; never return such a result)
+  h->h_ndone.p[4] = h->h_ndone.p[5] = h->h_ndone.p[6] = 0;
+  GFS_HIP(hipMemcpyAsync(h->h_ndone.p + 4, h->d_ndone.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+  const hipError_t rc_sync = hipStreamSynchronize(s);
+  CoopBudget::release(h->device, h->coop_reserved);  // (whatever happened: the kernel is not running any more)
+  h->coop_reserved = 0;
+  GFS_HIP(rc_sync);
+  if (h->h_ndone.p[6] > 0 && !h->coop_failed) {
+    // a workgroup of k_gicp_lm_coop gave up waiting (its grid was not resident together: another process on this device?): never
+    // return such a result -- the call again with a launch per step, and this handle stays with that
+    h->coop_failed = true;
+    return gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
+  }
+  if (optimistic_sort && h->h_ndone.p[5] > 0) {  // (the polls inside the loop normally catch this after round 0; never return such a result)
     h->sort_all_kernels = true;
     const int rc_again = gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
     h->sort_all_kernels = false;
@@ -3493,6 +3840,16 @@ int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset) {
 
 // Diagnostics: how many queries of cloud (b, which) of the last call went to the deferred k-NN passes, and the far ones' bounds.
 // out = {points, deferred to the r = 2 pass, deferred to the isolated-point pass}; dk (may be null): the latter's bounds (cap entries)
+int gfs_gicp_coop_stats(gfs_gicp* h, int out[4]) {
+  GFS_REQUIRE(h && out, GFS_ERR_INVALID_ARG, "gfs_gicp_coop_stats: invalid argument");
+  std::lock_guard<std::recursive_mutex> lk(h->mu);
+  out[0] = h->coop_launches;
+  out[1] = h->coop_last_wgs;
+  out[2] = h->coop_failed ? 1 : 0;
+  out[3] = h->coop && h->lm_rounds ? h->coop_cap / 2 : 0;
+  return GFS_OK;
+}
+
 int gfs_gicp_knn_stats(gfs_gicp* h, int b, int which, int out[3], double* dk, int cap) {
   GFS_REQUIRE(h && b >= 0 && b < h->last_B && (which == 0 || which == 1) && out, GFS_ERR_INVALID_ARG, "gfs_gicp_knn_stats: invalid argument");
   std::lock_guard<std::recursive_mutex> lk(h->mu);

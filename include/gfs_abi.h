@@ -218,6 +218,10 @@ int gfs_gicp_tile_stats(gfs_gicp* h, unsigned long long* out8, int reset);
 /* Diagnostics (tools/knn_probe.py): out = {down-sampled points, queries deferred to the r = 2 pass, queries deferred to the
  * isolated-point pass} of cloud (b, which) of the last call; dk (may be NULL): the squared-distance bounds of the latter. */
 int gfs_gicp_knn_stats(gfs_gicp* h, int b, int which, int out[3], double* dk, int cap);
+/* Diagnostics: how the Levenberg-Marquardt loops of this handle's calls were driven.  out = {launches of the cooperative kernel
+ * (the loop of a few pairs in ONE launch: a single live stream, the tail of a batch) so far, workgroups of the last such launch,
+ * 1 if a launch ever failed to become resident and the handle fell back to a launch per step for good, the workgroup budget}. */
+int gfs_gicp_coop_stats(gfs_gicp* h, int out[4]);
 
 /* ============================================================================================
  * 4. Local bundle adjustment — replaces the numeric core of Optimizer::LocalBundleAdjustment

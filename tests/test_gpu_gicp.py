@@ -344,6 +344,71 @@ def test_streaming_batch_device(gpu_api):
     hip.free()
 
 
+def test_cooperative_lm_kernel_gives_the_bits_of_the_launch_per_step_rounds(gpu_api, monkeypatch):
+    """k_gicp_lm_coop (the LM loop of a few pairs in ONE launch: several workgroups a pair, a per-pair barrier, the last arriver
+    folds) against the launch-per-step rounds (k_gicp_linearize / solve / error / decide + host polls): every output bit for
+    bit -- single pairs (the whole loop runs there), a small batch (the same), a batch of 24 whose tail goes there after the
+    full rounds; ragged iteration counts, an initial guess far off (many rejected trials), an empty and a tiny cloud."""
+    from test_gpu_gms import _Hip
+    rng = np.random.default_rng(5)
+    pairs = []
+    for k in range(24):
+        fp = synth.frame_pair(300 + k, 160, 120, stride=1 + (k % 2))
+        pairs.append((fp["cloud0"], fp["cloud1"]))
+    pairs[3] = (pairs[3][0], pairs[3][1][:7])          # a tiny source cloud
+    pairs[5] = (pairs[5][0], pairs[5][1][:0])          # an empty one
+    inits = [None] * 24
+    inits[2] = np.linalg.inv(synth.random_motion(rng)) @ np.linalg.inv(synth.random_motion(rng))
+    far = np.eye(4)
+    far[:3, 3] = [0.08, -0.05, 0.06]
+    inits[7] = far
+    SP = 20480
+    monkeypatch.setenv("GFS_GICP_COOP", "0")
+    rounds1 = gpu_api.RegistrationGICP(max_points=SP)
+    roundsB = gpu_api.RegistrationGICP(max_points=SP, max_batch=24)
+    monkeypatch.delenv("GFS_GICP_COOP")
+    monkeypatch.setenv("GFS_GICP_COOP_TAIL", "2")  # (the tail of a larger batch: off by default, measured slower next to busy lanes)
+    coop1 = gpu_api.RegistrationGICP(max_points=SP)
+    coopB = gpu_api.RegistrationGICP(max_points=SP, max_batch=24)
+    assert rounds1.coop_stats()["budget"] == 0 and coop1.coop_stats()["budget"] >= 75
+    # one pair at a time, and the streaming entry
+    its = []
+    for k in range(12):
+        a, b = coop1.RegisterPointClouds(*pairs[k], inits[k]), rounds1.RegisterPointClouds(*pairs[k], inits[k])
+        assert _same(a, b) and a["n_linearize"] == b["n_linearize"] and a["n_error_evals"] == b["n_error_evals"], k
+        its.append(a["n_error_evals"])
+    assert coop1.coop_stats()["launches"] == 12 and not coop1.coop_stats()["failed"] and rounds1.coop_stats()["launches"] == 0
+    assert len(set(its)) >= 3 and max(its) >= 6, its  # ragged: short and long loops, rejected trials
+    a, b = coop1.RegisterNext(pairs[13][1]), rounds1.RegisterNext(pairs[13][1])
+    assert _same(a, b)
+    # batches through the device entry: 4 pairs (whole loop in the kernel), 24 pairs (rounds, then the tail)
+    hip = _Hip()
+
+    def dev(which, idx):
+        c = np.zeros((len(idx), SP, 4), np.float32)
+        n = np.zeros(len(idx), np.int32)
+        for j, k in enumerate(idx):
+            c[j, :len(pairs[k][which])] = pairs[k][which]
+            n[j] = len(pairs[k][which])
+        return hip.to_device(c), hip.to_device(n)
+
+    for idx in ([0, 2, 5, 7], list(range(24))):
+        t, s_ = dev(0, idx), dev(1, idx)
+        T0 = np.stack([np.eye(4) if inits[k] is None else inits[k] for k in idx])
+        before = coopB.coop_stats()["launches"]
+        got = coopB.align_batch_device(t[0], t[1], s_[0], s_[1], len(idx), SP, init_T=T0)
+        want = roundsB.align_batch_device(t[0], t[1], s_[0], s_[1], len(idx), SP, init_T=T0)
+        for j in range(len(idx)):
+            assert _same(got[j], want[j]) and got[j]["n_error_evals"] == want[j]["n_error_evals"], (len(idx), j)
+        if len(idx) * 80 <= coopB.coop_stats()["budget"] or len(idx) > 8:  # the whole loop / the tail behind the full rounds
+            assert coopB.coop_stats()["launches"] == before + 1, (len(idx), coopB.coop_stats())
+        # ... and a pair inside a batch = the pair alone
+        for j, k in enumerate(idx[:4]):
+            assert _same(got[j], coop1.RegisterPointClouds(*pairs[k], inits[k])), (len(idx), j)
+    assert not coopB.coop_stats()["failed"]
+    hip.free()
+
+
 def _gicp_same(r, ro, bar=1e-5):
     return (r["converged"] == ro["converged"] and r["iterations"] == ro["iterations"] and r["num_inliers"] == ro["num_inliers"]
             and r["n_target_ds"] == ro["n_target_ds"] and r["n_source_ds"] == ro["n_source_ds"] and _rel(r["T"], ro["T"]) < bar)
