@@ -38,8 +38,10 @@ def algorithmic_bytes_per_step(kernel, ctx):
         "k_orient_brief": B * K * (31 * 31 + 37 * 37 + 60),         # K x (31x31 + 37x37) read + 60 B out
         "k_bf_hamming": B * (32 * 2 * K + 8 * K),
         "k_gms": B * (2 * 28 * K + 5 * K),                          # both key-point sets + match indices in, mask out
-        "k_gicp_linearize": 320.0 * ctx["lin_points"],              # 320 B per source point per linearisation
-        "k_gicp_error": 136.0 * ctx["err_points"],
+        # 320 B per source point per linearisation.  Since round 6 a pending trial's error is evaluated in the same pass (it needs the
+        # point under the trial pose and the previous correspondence, which the linearisation loads anyway): only the error-ONLY passes
+        # -- a pair's last trial, one per pair -- are counted on top (136 B a point); the errors that ride along are not
+        "k_gicp_linearize": 320.0 * ctx["lin_points"] + 136.0 * ctx.get("last_err_points", 0),
         "k_knn_cov": (10 * 32 + 160) * ctx["ds_points"],            # 10-NN gather + covariance write, both clouds
         "k_radix_sort": 2 * 12 * ctx["ds_points"],                    # the cell sort: (8 B key + 4 B index) read + written
         "k_cell_sort_lds": 2 * 12 * ctx["ds_points"],
@@ -590,8 +592,8 @@ def main():
         P = sum(r * c for r, c in lv)
         ctx = dict(B=B, P0=W * H, P=P, p_last=lv[-1][0] * lv[-1][1], K=float(counts.float().mean()),
                    cands=float(np.mean([sum(len(ext.candidates(l, b)[0]) for l in range(NL)) for b in range(min(lanes[0].n, 4))])),
-                   lin_points=lin_pts, err_points=err_pts, ds_points=sum(r["n_source_ds"] + r["n_target_ds"] for r in g),
-                   in_points=int(n0.sum() + n1.sum()))
+                   lin_points=lin_pts, err_points=err_pts, last_err_points=sum(r["n_source_ds"] for r in g if r["n_error_evals"] > 0),
+                   ds_points=sum(r["n_source_ds"] + r["n_target_ds"] for r in g), in_points=int(n0.sum() + n1.sum()))
         tot = sum(v[0] for v in kern.values())
         name = max(kern, key=lambda k: kern[k][0])
         ms, launches = kern[name]

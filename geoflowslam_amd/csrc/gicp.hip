@@ -3,9 +3,11 @@
 //   voxel-grid downsampling (util/downsampling_omp.hpp:26-95)  -> k_voxel_keys, k_radix_sort, k_voxel_reduce
 //   exact k-NN (ann/kdtree.hpp) + covariances (util/normal_estimation.hpp:66-92) -> cell grid + k_knn_cov
 //   GICPFactor::linearize / error (factors/gicp_factor.hpp:35-89) + ParallelReductionOMP
-//   (registration/reduction_omp.hpp:21-69)                   -> k_gicp_linearize / k_gicp_error (+ fixed-order sums)
+//   (registration/reduction_omp.hpp:21-69)                   -> k_gicp_linearize (a trial's error and the linearisation at the
+//                                                              trial pose in ONE pass since round 6; + fixed-order sums)
 //   LevenbergMarquardtOptimizer::optimize (registration/optimizer.hpp:83-147) -> device-side state machine
-//                                                              (k_gicp_solve / k_gicp_decide); the host only polls "all done".
+//                                                              (k_gicp_step); the host only polls "all done"; a small batch runs its
+//                                                              whole loop in one launch (k_gicp_lm_coop).
 // Everything is double precision like the reference.  The KdTree is replaced by a uniform cell grid (cell edge =
 // max correspondence distance): nearest-neighbour results are exact (certified ring by ring), hence structure independent (ties aside).
 //
@@ -46,11 +48,17 @@ struct PairState {
   double H[21], b[6], e;  // last linearisation (upper triangle, (i,j) i<=j in row-major order)
   double lambda;
   int outer, inner;
-  int phase;  // 0 = linearise next, 1 = error evaluation next, 2 = done
+  // 0 = first linearisation (at T) next; 1 = a trial pose (newT) is pending: the next pass evaluates its error with the frozen
+  // correspondences AND linearises at newT into the other correspondence buffer -- if the trial is accepted that IS the next
+  // linearisation (round 6: one pass and one scalar step per LM trial instead of two each); 3 = a trial is pending whose acceptance
+  // ends the loop (converged step, or the last iteration): error only; 2 = done
+  int phase;
   int converged;
   int iterations;  // RegistrationResult::iterations (index of the last outer iteration)
   int inliers;
   int n_lin, n_err;
+  int buf;  // which of the two (tgt_index, maha6) buffers holds the correspondences of the last accepted linearisation
+  int pad_;
 };
 
 struct GicpParams {
@@ -1845,7 +1853,7 @@ __device__ __forceinline__ void inv3(const double* A, double* M) {
 // per-wave shuffle reduction, then the 4 waves of the block are folded in fixed order: deterministic sums
 // per-WAVE partial sums (wave totals by recursive halving, wave_reduce.hpp), stored side by side per block: slot `wave` of the
 // block's kLinWaves slots.  The four waves of a block are added up, in the fixed order 0 + w0 + w1 + w2 + w3, by the kernel that
-// folds the partials (fold_partials): the same numbers as a block-wide sum in LDS, but a wave that has finished its points
+// folds the partials (fold_round): the same numbers as a block-wide sum in LDS, but a wave that has finished its points
 // leaves instead of waiting at two barriers for the slowest of its block (clock64 per section, -DGFS_LIN_TIMING in round 4: a
 // wave of k_gicp_linearize lived 55 - 74 k cycles, 7 - 23 k of them in the reduction, nearly all of that waiting).
 constexpr int kLinWaves = kLinBlock / 64;
@@ -2435,20 +2443,58 @@ __device__ __forceinline__ void lin_image(const double4& p, const double* __rest
 #ifdef GFS_LIN_WAVES
 #define GFS_LIN_OCC __attribute__((amdgpu_waves_per_eu(GFS_LIN_WAVES, 8)))
 #else
-#define GFS_LIN_OCC
+// 5 waves a SIMD is what the pass takes by itself (91 - 94 VGPRs); said explicitly because the scalar step it calls in its last
+// workgroup (pair_step_last, not inlined) is otherwise scheduled without an occupancy target, takes 180 and drags the kernel to 2
+#define GFS_LIN_OCC __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
-template <bool kTiled>
-__global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(const PairState* __restrict__ st,
+struct CoopSync {
+  unsigned arrive;  // k_gicp_linearize: workgroups of the pair that have finished this pass (the last one resets it);
+                    // k_gicp_lm_coop: arrivals at the pair's barriers (monotonic within the launch); k_gicp_init zeroes it
+  unsigned gen;     // k_gicp_lm_coop: barriers completed
+};
+// (defined behind the scalar steps below) the pair's fold + scalar step, run by the workgroup of a pass that finishes last
+__device__ void pair_step_last(PairState* S, const double* part, const double* epart, int nblk_pair, int phase, double rot_eps,
+                               double trans_eps, int max_iterations, int pair, int* n_done, int* act_next, int* n_act_next, double* s_part,
+                               double* s_sum);
+
+// GICPFactor::error of a pending trial for source point i: 0.5 r' M r with the frozen correspondence q and matrix M (factors/gicp_factor.hpp:76-86);
+// (tx, ty, tz) = the point under the trial pose as lin_image computes it (the same expression, un-contracted)
+__device__ __forceinline__ double gicp_trial_error(const double4 q, double tx, double ty, double tz, const double* __restrict__ M) {
+  const double r0 = q.x - tx, r1 = q.y - ty, r2 = q.z - tz;
+  const double m0 = M[0] * r0 + M[1] * r1 + M[2] * r2, m1 = M[1] * r0 + M[3] * r1 + M[4] * r2, m2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
+  return 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
+}
+
+// One pass over the source points of every pair that is not done (PairState::phase):
+//   phase 0: GICPFactor::linearize at T;
+//   phase 1: the error of the pending trial newT with the frozen correspondences AND the linearisation at newT, written to the pair's
+//            OTHER correspondence buffer -- both need the point under newT and the previous correspondence (the search's first bound is
+//            the error's residual), so the error costs six more loads;
+//   phase 3: the trial's error only.
+// Per-block partial sums of H (upper), b, e, the inlier count (partial) and of the trial's error (epartial).
+// kFuse (256-thread workgroups): the pair's scalar step (k_gicp_step) is taken by the workgroup of the pair that finishes LAST, inside
+// this launch -- a round of the LM loop is ONE launch.  The partial sums then cross workgroups within the launch: they are stored
+// write-through (st_ag), every wave drains its stores before the workgroup's arrival is counted (one agent-scope atomic a
+// workgroup), and the last arriver folds them with L1-bypassing loads -- no release / acquire fence (round 5 had measured the
+// fence form of this pattern: 2.97 -> 23.8 ms a step).  Nobody waits for anybody: no residency requirement.
+template <bool kTiled, bool kFuse>
+__global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(PairState* __restrict__ st,
                                                               const double4* __restrict__ pts,
                                                               const double* __restrict__ cov6, const u64* __restrict__ ucell,
                                                               const unsigned* __restrict__ ubegin,
                                                               const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
                                                               const unsigned* __restrict__ grid, const int* __restrict__ ginfo,
                                                               int nchunks, int npairs, int P, GicpParams prm,
-                                                              int* __restrict__ tgt_index, double* __restrict__ maha6,
-                                                              double* __restrict__ partial, int nblk, const int* __restrict__ act,
-                                                              const int* __restrict__ n_act) {
+                                                              int* __restrict__ tgt_index, double* __restrict__ maha6, size_t buf_stride,
+                                                              double* __restrict__ partial, double* __restrict__ epartial, int nblk,
+                                                              const int* __restrict__ act, const int* __restrict__ n_act,
+                                                              CoopSync* __restrict__ sync, int* __restrict__ n_done,
+                                                              int* __restrict__ act_next, int* __restrict__ n_act_next,
+                                                              int* __restrict__ n_act_clear) {
   __shared__ typename std::conditional<kTiled, LinTile, int>::type tile;  // the untiled instance keeps its LDS (and its occupancy)
+  if constexpr (kFuse) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_act_clear = 0;  // the counter the NEXT round's last arrivers fill
+  }
   int pair, sub, chunk;
   if (act) {  // a late round: only the pairs on the list (the grid covers an upper bound of their number)
     const int slot = blockIdx.x / nchunks;
@@ -2463,10 +2509,11 @@ __global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(const 
   // remain are: state -> (tile rows) -> (tile points) -> search in LDS -> target covariance.
   const int cs = 2 * pair + prm.src_slot, ct = 2 * pair + 1 - prm.src_slot;
   const PairState* Sp = st + pair;
-  const int phase = Sp->phase, n_lin = Sp->n_lin;
+  const int phase = Sp->phase, n_lin = Sp->n_lin, cur = Sp->buf;
+  const double* Tp = phase == 0 ? Sp->T : Sp->newT;
   double T12[12];
 #pragma unroll
-  for (int k = 0; k < 12; k++) T12[k] = Sp->T[k];
+  for (int k = 0; k < 12; k++) T12[k] = Tp[k];
   const int ms = m_counts[cs];
   const unsigned* G = grid + (size_t)ct * (kGridCap + 1);
   const int* gi = ginfo + 8 * ct;
@@ -2474,8 +2521,12 @@ __global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(const 
   const int i = lin_point_of(chunk, &wave_slot);  // < P: the grid covers at most the clouds' capacity
   const double4 p = pts[(size_t)cs * P + i];
   const double4* tp = pts + (size_t)ct * P;
-  const int prev_j = tgt_index[(size_t)pair * P + i];
-  if (phase != 0 || chunk * kLinBlock >= ms) return;
+  const int* ti_cur = tgt_index + (size_t)cur * buf_stride;
+  const double* maha_cur = maha6 + (size_t)cur * buf_stride * 6;
+  const int prev_j = ti_cur[(size_t)pair * P + i];
+  const int nblk_pair = (ms + kLinBlock - 1) / kLinBlock;
+  // (kFuse: a pair without source points still takes its scalar steps -- chunk 0's workgroup stays for that)
+  if (phase == 2 || chunk >= (kFuse ? max(nblk_pair, 1) : nblk_pair)) return;
   const bool has_prev = n_lin > 0;
   double4 prev_q = make_double4(0, 0, 0, 0);
   if (has_prev && i < ms && prev_j >= 0) prev_q = tp[prev_j];
@@ -2485,82 +2536,65 @@ __global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(const 
   int cx = 0, cy = 0, cz = 0;
   bool in_range = false;
   if (i < ms) lin_image(p, T12, prm, tx, ty, tz, cx, cy, cz, in_range);
-  bool tiled = false;
-  if constexpr (kTiled) {
-    const int why = prm.nn_rings <= 1 ? lin_stage_tile(tile, i < ms && in_range, cx, cy, cz, tp, gi, G) : 6;
-    tiled = why == 0;
-    if (prm.tile_stats && threadIdx.x == 0) atomicAdd(prm.tile_stats + why, 1u);
+  if (phase != 0) {  // the pending trial's error (the separate k_gicp_error pass of rounds 1 - 5)
+    double e[1] = {0.0};
+    if (i < ms && prev_j >= 0) e[0] = gicp_trial_error(prev_q, tx, ty, tz, maha_cur + ((size_t)pair * P + i) * 6);
+    wave_reduce_store<1, kFuse>(e, epartial + ((size_t)pair * nblk + chunk) * kLinWaves, wave_slot);
   }
-  if (i < ms) {
-    bool done = false;
+  if (phase != 3) {
+    const int wr = phase == 0 ? cur : cur ^ 1;
+    int* ti_wr = tgt_index + (size_t)wr * buf_stride;
+    double* maha_wr = maha6 + (size_t)wr * buf_stride * 6;
+    bool tiled = false;
     if constexpr (kTiled) {
-      if (tiled) {
-        const NnTile src{&tile, tile.box[0] - 1, tile.box[2] - 1, tile.box[1] - tile.box[0] + 3};
+      const int why = prm.nn_rings <= 1 ? lin_stage_tile(tile, i < ms && in_range, cx, cy, cz, tp, gi, G) : 6;
+      tiled = why == 0;
+      if (prm.tile_stats && threadIdx.x == 0) atomicAdd(prm.tile_stats + why, 1u);
+    }
+    if (i < ms) {
+      bool done = false;
+      if constexpr (kTiled) {
+        if (tiled) {
+          const NnTile src{&tile, tile.box[0] - 1, tile.box[2] - 1, tile.box[1] - tile.box[0] + 3};
+          gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin,
+                         n_ucell, G, gi, prm, ti_wr, maha_wr, F);
+          done = true;
+        }
+      }
+      if (!done) {
+        const NnGlobal src{tp, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
         gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell,
-                       G, gi, prm, tgt_index, maha6, F);
-        done = true;
+                       G, gi, prm, ti_wr, maha_wr, F);
       }
     }
-    if (!done) {
-      const NnGlobal src{tp, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
-      gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell, G,
-                     gi, prm, tgt_index, maha6, F);
+    double* dst = partial + ((size_t)pair * nblk + chunk) * kLinWaves * kRed;
+    {
+      double vb[14];
+      lin_factor_batch_b(F, vb);
+      wave_reduce_store_map<14, kFuse>(vb, kLinMapB, dst, wave_slot);
+    }
+    {
+      double va[15];
+      lin_factor_batch_a(F, va);
+      wave_reduce_store_map<15, kFuse>(va, kLinMapA, dst, wave_slot);
     }
   }
-  double* dst = partial + ((size_t)pair * nblk + chunk) * kLinWaves * kRed;
-  {
-    double vb[14];
-    lin_factor_batch_b(F, vb);
-    wave_reduce_store_map<14>(vb, kLinMapB, dst, wave_slot);
-  }
-  {
-    double va[15];
-    lin_factor_batch_a(F, va);
-    wave_reduce_store_map<15>(va, kLinMapA, dst, wave_slot);
-  }
-}
-
-// GICPFactor::error (factors/gicp_factor.hpp:76-86) with the frozen correspondences / Mahalanobis matrices.
-__global__ __launch_bounds__(kLinBlock) void k_gicp_error(const PairState* __restrict__ st, const double4* __restrict__ pts,
-                                                           const int* __restrict__ m_counts, int P,
-                                                           const int* __restrict__ tgt_index, const double* __restrict__ maha6,
-                                                           double* __restrict__ epartial, int nblk, int nchunks, int npairs, int src_slot,
-                                                           const int* __restrict__ act, const int* __restrict__ n_act) {
-  int pair, sub, chunk;
-  if (act) {  // a late round: only the pairs on the list
-    const int slot = blockIdx.x / nchunks;
-    if (slot >= *n_act) return;
-    pair = act[slot];
-    chunk = blockIdx.x - slot * nchunks;
-  } else if (!xcd_pair_map(nchunks, npairs, 1, &pair, &sub, &chunk)) {
-    return;
-  }
-  const PairState& S = st[pair];
-  if (S.phase != 1) return;
-  const int cs = 2 * pair + src_slot, ct = 2 * pair + 1 - src_slot;
-  const int ms = m_counts[cs];
-  int wave_slot;
-  const int i = lin_point_of(chunk, &wave_slot);
-  if (chunk * kLinBlock >= ms) return;
-  double e[1] = {0.0};
-  if (i < ms) {
-    const int ti = tgt_index[(size_t)pair * P + i];
-    if (ti >= 0) {
-      const double4 p = pts[(size_t)cs * P + i];
-      const double* R = S.newT;
-      const double* t = S.newT + 9;
-      const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
-      const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
-      const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
-      const double4 q = pts[(size_t)ct * P + ti];
-      const double r0 = q.x - tx, r1 = q.y - ty, r2 = q.z - tz;
-      const double* M = maha6 + ((size_t)pair * P + i) * 6;
-      const double m0 = M[0] * r0 + M[1] * r1 + M[2] * r2, m1 = M[1] * r0 + M[3] * r1 + M[4] * r2,
-                   m2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
-      e[0] = 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
+  if constexpr (kFuse) {
+    __shared__ double s_part[8 * 32], s_sum[32];
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its partial sums have left before the arrival is counted
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&sync[pair].arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old + 1 == (unsigned)max(nblk_pair, 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last) {
+      pair_step_last(st + pair, partial + (size_t)pair * nblk * kLinWaves * kRed, epartial + (size_t)pair * nblk * kLinWaves, nblk_pair, phase,
+                     prm.rot_eps, prm.trans_eps, prm.max_iterations, pair, n_done, act_next, n_act_next, s_part, s_sum);
+      if (threadIdx.x == 0) st_ag(&sync[pair].arrive, 0u);  // (everybody of this pair has arrived; the next pass is another launch)
     }
   }
-  wave_reduce_store<1>(e, epartial + ((size_t)pair * nblk + chunk) * kLinWaves, wave_slot);
 }
 
 // (H + lambda I) delta = -b, then new_T = T * se3_exp(delta) (registration/optimizer.hpp:109-112, util/lie.hpp:54-103).
@@ -2678,7 +2712,7 @@ __device__ void solve_and_propose(const double* H21, const double* b6, double la
 }
 
 // The two scalar steps of LevenbergMarquardtOptimizer::optimize (registration/optimizer.hpp:83-147) on a pair's state, shared by the
-// launch-per-step kernels (k_gicp_solve / k_gicp_decide: S in global memory) and the cooperative kernel (k_gicp_lm_coop: S is a copy
+// launch-per-step kernel (k_gicp_step: S in global memory) and the cooperative kernel (k_gicp_lm_coop: S is a copy
 // in LDS) -- one body, so that the two forms cannot drift apart by a bit.
 // (split so that a caller has ONE call site of the damped solve: its 6x6 LDL^T holds ~120 registers)
 // the damped solve of the state's last linearisation: delta and the trial pose
@@ -2740,31 +2774,67 @@ __device__ __forceinline__ bool lm_after_error(PairState& S, double new_e, const
   return true;
 }
 
+// would accepting the pending trial end the loop?  (optimizer.hpp:119-121 decides with the same delta; 138: the iteration cap)
+__device__ __forceinline__ bool lm_trial_is_last(const PairState& S, const GicpParams& prm) {
+  const double dr = sqrt(S.delta[0] * S.delta[0] + S.delta[1] * S.delta[1] + S.delta[2] * S.delta[2]);
+  const double dt = sqrt(S.delta[3] * S.delta[3] + S.delta[4] * S.delta[4] + S.delta[5] * S.delta[5]);
+  return (dr <= prm.rot_eps && dt <= prm.trans_eps) || S.outer + 1 >= prm.max_iterations;
+}
+// One scalar step of a pair after a pass: sums[0 .. 28] = the folded linearisation (valid in phases 0 and 1), sums[29] = the folded
+// error of the trial (phases 1 and 3).  The sequence of states is LevenbergMarquardtOptimizer::optimize's: the linearisation at an
+// accepted pose is the one the reference computes next -- here it was computed in the same pass as the trial's error.
+__device__ __forceinline__ void lm_round_step(PairState& S, const double* sums, const GicpParams& prm, bool* done) {
+  *done = false;
+  bool solve = true;
+  if (S.phase == 0) {
+    lm_after_linearize(S, sums);
+  } else {
+    const int was = S.phase;
+    solve = lm_after_error(S, sums[29], prm, done);  // true: rejected, another damped solve of the same linearisation
+    if (!solve && !*done) {  // accepted, the loop goes on
+      if (was == 1) {  // the speculative linearisation at the accepted pose is the next one: its correspondences become the frozen ones
+        S.buf ^= 1;
+        lm_after_linearize(S, sums);
+        solve = true;
+      }  // (was == 3 cannot get here -- the same delta decided both; if it ever did, phase 0 linearises at T in the next pass)
+    }
+  }
+  if (solve) {
+    lm_solve(S);
+    S.phase = lm_trial_is_last(S, prm) ? 3 : 1;
+  }
+}
+
 // fixed-order sum of `n` blocks' partial vectors (kLinWaves wave vectors of `stride` doubles each, wave_reduce_store): the waves of
-// a block first, then 8 strided sub-sums per component over the blocks, then 8 -> 1
-template <int NCOMP, bool kAgent = false>
-__device__ __forceinline__ void fold_partials(const double* __restrict__ part, int n, int stride, double* s_part /*[8][32]*/,
-                                              double* s_out /*[32]*/) {
+// a block first, then 8 strided sub-sums per component over the blocks, then 8 -> 1.  Components 0 .. 28 come from `part` (the
+// linearisation, if `lin`), component 29 from `epart` (the trial's error, if `err`): one pass for both, the order of the
+// additions of every component is that of a fold of its own.
+template <bool kAgent = false>
+__device__ __forceinline__ void fold_round(const double* __restrict__ part, const double* __restrict__ epart, bool lin, bool err, int n,
+                                           double* s_part /*[8][32]*/, double* s_out /*[32]*/) {
   const int comp = threadIdx.x & 31, sub = threadIdx.x >> 5;  // 256 threads = 32 components x 8 sub-sums
   double a = 0;
-  if (comp < NCOMP)
+  const bool mine = (comp < kRed && lin) || (comp == kRed && err);
+  const double* src = comp < kRed ? part + comp : epart;
+  const int stride = comp < kRed ? kRed : 1;
+  if (mine)
     for (int k = sub; k < n; k += 8) {
       double blk = 0;  // the block's sum: its waves in order
       if constexpr (kAgent) {  // (written by other workgroups of this launch: L1-bypassing loads, all four in flight)
         double v[kLinWaves];
 #pragma unroll
-        for (int w = 0; w < kLinWaves; w++) v[w] = ld_ag(part + ((size_t)k * kLinWaves + w) * stride + comp);
+        for (int w = 0; w < kLinWaves; w++) v[w] = ld_ag(src + ((size_t)k * kLinWaves + w) * stride);
 #pragma unroll
         for (int w = 0; w < kLinWaves; w++) blk += v[w];
       } else {
 #pragma unroll
-        for (int w = 0; w < kLinWaves; w++) blk += part[((size_t)k * kLinWaves + w) * stride + comp];
+        for (int w = 0; w < kLinWaves; w++) blk += src[((size_t)k * kLinWaves + w) * stride];
       }
       a += blk;
     }
   s_part[sub * 32 + comp] = a;
   __syncthreads();
-  if (threadIdx.x < NCOMP) {
+  if (threadIdx.x < 32) {
     double v = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) v += s_part[q * 32 + threadIdx.x];
@@ -2773,56 +2843,50 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
   __syncthreads();
 }
 
-// after a linearise pass: fold the per-block partial sums (fixed order), first damped solve
-__global__ __launch_bounds__(256) void k_gicp_solve(PairState* __restrict__ st, const double* __restrict__ partial,
-                                                    const int* __restrict__ m_counts, int nblk_max, int src_slot,
-                                                    int* __restrict__ n_act_next) {
+// after a pass: fold the pair's partial sums (fixed order) and take the scalar step; the pairs that are not done after it go on
+// the list of the next round (the order is whatever the atomics give -- pairs are independent)
+__global__ __launch_bounds__(256) void k_gicp_step(PairState* __restrict__ st, const double* __restrict__ partial,
+                                                   const double* __restrict__ epartial, const int* __restrict__ m_counts, int nblk_max,
+                                                   GicpParams prm, int* __restrict__ n_done, int* __restrict__ act_next,
+                                                   int* __restrict__ n_act_next, int* __restrict__ n_act_clear) {
   __shared__ double s_part[8 * 32], s_sum[32];
   const int pair = blockIdx.x;
-  if (pair == 0 && threadIdx.x == 0) *n_act_next = 0;  // k_gicp_decide of this round fills the list of the next one
-  if (st[pair].phase != 0) return;
-  const int ms = m_counts[2 * pair + src_slot];
-  const int nblk = (ms + kLinBlock - 1) / kLinBlock;
-  fold_partials<kRed>(partial + (size_t)pair * nblk_max * kLinWaves * kRed, nblk, kRed, s_part, s_sum);
-  if (threadIdx.x == 0) {
-    lm_after_linearize(st[pair], s_sum);
-    lm_solve(st[pair]);
-  }
-}
-
-// after an error pass: accept / reject the trial (registration/optimizer.hpp:115-141)
-__global__ __launch_bounds__(256) void k_gicp_decide(PairState* __restrict__ st, const double* __restrict__ epartial,
-                                                     const int* __restrict__ m_counts, int nblk_max, GicpParams prm,
-                                                     int* __restrict__ n_done, int* __restrict__ act_next, int* __restrict__ n_act_next) {
-  // act_next / n_act_next: the pairs that are not done after this round, for the grids of the next one (filled by GicpActive's
-  // destructor on every path out of the bookkeeping below; the order is whatever the atomics give -- pairs are independent)
-  __shared__ double s_part[8 * 32], s_sum[32];
-  const int pair = blockIdx.x;
-  struct GicpActive {
-    const PairState* st;
-    int pair;
-    int* list;
-    int* n;
-    bool lead;
-    __device__ ~GicpActive() {
-      if (lead && st[pair].phase != 2) list[atomicAdd(n, 1)] = pair;
-    }
-  } note{st, pair, act_next, n_act_next, threadIdx.x == 0};
-  if (st[pair].phase != 1) return;
+  if (pair == 0 && threadIdx.x == 0) *n_act_clear = 0;  // the counter the NEXT round's step fills
+  const int phase = st[pair].phase;
+  if (phase == 2) return;
   const int ms = m_counts[2 * pair + prm.src_slot];
   const int nblk = (ms + kLinBlock - 1) / kLinBlock;
-  fold_partials<1>(epartial + (size_t)pair * nblk_max * kLinWaves, nblk, 1, s_part, s_sum);
+  fold_round(partial + (size_t)pair * nblk_max * kLinWaves * kRed, epartial + (size_t)pair * nblk_max * kLinWaves, phase != 3, phase != 0, nblk,
+             s_part, s_sum);
   if (threadIdx.x != 0) return;
   bool done;
-  if (lm_after_error(st[pair], s_sum[0], prm, &done)) lm_solve(st[pair]);
+  lm_round_step(st[pair], s_sum, prm, &done);
   if (done) atomicAdd(n_done, 1);
+  else act_next[atomicAdd(n_act_next, 1)] = pair;
+}
+
+// the same fold + step for the workgroup of a fused pass (k_gicp_linearize<.., true>) that arrives last: the partial sums come from
+// other workgroups of the running launch (L1-bypassing loads), the state is this pair's alone until the next launch
+__device__ __attribute__((noinline)) void pair_step_last(PairState* S, const double* part, const double* epart, int nblk_pair, int phase,
+                                                         double rot_eps, double trans_eps, int max_iterations, int pair, int* n_done,
+                                                         int* act_next, int* n_act_next, double* s_part, double* s_sum) {
+  fold_round<true>(part, epart, phase != 3, phase != 0, nblk_pair, s_part, s_sum);
+  if (threadIdx.x != 0) return;
+  GicpParams q{};
+  q.rot_eps = rot_eps;
+  q.trans_eps = trans_eps;
+  q.max_iterations = max_iterations;
+  bool done;
+  lm_round_step(*S, s_sum, q, &done);
+  if (done) atomicAdd(n_done, 1);
+  else act_next[atomicAdd(n_act_next, 1)] = pair;
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_gicp_lm_coop: the Levenberg-Marquardt loop of a FEW pairs without the host and without a launch per step -- G workgroups a
 // pair walk the pair's 256-point chunks (workgroup g takes chunks g, g + G, ...), write the SAME per-wave partial sums into the
-// SAME slots as k_gicp_linearize / k_gicp_error, meet at a per-pair barrier, and the workgroup that arrives last folds them with
-// the SAME fold_partials and takes the scalar step (lm_after_linearize / lm_after_error): the results are those of the
+// SAME slots as k_gicp_linearize, meet at a per-pair barrier, and the workgroup that arrives last folds them with
+// the SAME fold_round and takes the SAME scalar step (lm_round_step) as k_gicp_step: the results are those of the
 // launch-per-step form bit for bit, whatever G is and whichever workgroup folds.
 //   Used (gicp_run) where four launches + a host poll per step are most of the time: a single pair (one live stream: ~5 steps of
 // 75 workgroups each), and the tail of a batch whose last few pairs iterate on an otherwise idle chip.
@@ -2839,10 +2903,6 @@ __device__ __forceinline__ double uniform_d(double v) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
-struct CoopSync {
-  unsigned arrive;  // arrivals at this pair's barriers (monotonic within a launch; k_gicp_init zeroes it)
-  unsigned gen;     // barriers completed
-};
 constexpr int kStateWords = (int)(sizeof(PairState) / 8);
 static_assert(sizeof(PairState) % 8 == 0 && kStateWords <= 64, "PairState is moved as 8-byte words by one wave");
 constexpr unsigned kCoopSpinLimit = 4u << 20;  // polls of ~1 us: seconds, far beyond any legitimate wait
@@ -2863,6 +2923,7 @@ struct CoopCtx {
   double* maha6;
   double* partial;
   double* epartial;
+  size_t buf_stride;
   int P, nblk;
   GicpParams prm;
 };
@@ -2878,41 +2939,59 @@ __device__ __forceinline__ void uniform_load(T& dst, const void* lds_generic) {
   __builtin_memcpy(&dst, tmp, sizeof(T));
 }
 
-// GICPFactor::linearize of chunk `chunk` (256 source points, this workgroup's threads) of a pair under the pose in the LDS copy of
-// its state: the body of k_gicp_linearize<false>, partial sums stored write-through
-__device__ __attribute__((noinline)) void coop_lin_chunk(const void* ctx_lds, const void* state_lds, int pair_v, int chunk_v, int ms_v) {
+// One chunk (256 source points, this workgroup's threads) of a pair's pass under the state in LDS: the untiled body of
+// k_gicp_linearize -- the pending trial's error and / or the linearisation, by phase -- with the partial sums stored write-through
+__device__ __attribute__((noinline)) void coop_pass_chunk(const void* ctx_lds, const void* state_lds, int pair_v, int chunk_v, int ms_v) {
   CoopCtx C;
   uniform_load(C, ctx_lds);
   struct Head {
-    double T[12];
+    double T[12], newT[12];
   } Hd;
-  uniform_load(Hd, state_lds);  // PairState begins with T[12]
+  uniform_load(Hd, state_lds);  // PairState: T[12] | newT[12] | ...
+  const PairState* Sl = reinterpret_cast<const PairState*>(state_lds);
   const int pair = __builtin_amdgcn_readfirstlane(pair_v), chunk = __builtin_amdgcn_readfirstlane(chunk_v),
-            ms = __builtin_amdgcn_readfirstlane(ms_v);
-  const bool has_prev = __builtin_amdgcn_readfirstlane(reinterpret_cast<const PairState*>(state_lds)->n_lin) > 0;
-  const int tid = threadIdx.x, P = C.P;
+            ms = __builtin_amdgcn_readfirstlane(ms_v), phase = __builtin_amdgcn_readfirstlane(Sl->phase),
+            cur = __builtin_amdgcn_readfirstlane(Sl->buf);
+  const bool has_prev = __builtin_amdgcn_readfirstlane(Sl->n_lin) > 0;
+  // (element by element: `const double* T12 = phase == 0 ? Hd.T : Hd.newT` -- a run-time choice between two register-resident
+  //  arrays -- gave the pose of the wrong branch in this non-inlined function with ROCm 7.2's compiler; found by the parity tests)
+  double T12[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T12[k] = phase == 0 ? Hd.T[k] : Hd.newT[k];
+  const int tid = threadIdx.x, P = C.P, wave_slot = tid >> 6;
   const int cs = 2 * pair + C.prm.src_slot, ct = 2 * pair + 1 - C.prm.src_slot;
   const unsigned* G0 = C.grid + (size_t)ct * (kGridCap + 1);
   const int* gi = C.ginfo + 8 * ct;
   const double4* tp = C.pts + (size_t)ct * P;
+  const int* ti_cur = C.tgt_index + (size_t)cur * C.buf_stride;
+  const double* maha_cur = C.maha6 + (size_t)cur * C.buf_stride * 6;
   const int i = chunk * kLinBlock + tid;
+  double4 p = make_double4(0, 0, 0, 0), prev_q = make_double4(0, 0, 0, 0);
+  int prev_j = -1;
+  double tx = 0, ty = 0, tz = 0;
+  int cx = 0, cy = 0, cz = 0;
+  bool in_range = false;
+  if (i < ms) {
+    p = C.pts[(size_t)cs * P + i];
+    if (has_prev) prev_j = ti_cur[(size_t)pair * P + i];
+    if (prev_j >= 0) prev_q = tp[prev_j];
+    lin_image(p, T12, C.prm, tx, ty, tz, cx, cy, cz, in_range);
+  }
+  if (phase != 0) {
+    double e[1] = {0.0};
+    if (i < ms && prev_j >= 0) e[0] = gicp_trial_error(prev_q, tx, ty, tz, maha_cur + ((size_t)pair * P + i) * 6);
+    wave_reduce_store<1, true>(e, C.epartial + ((size_t)pair * C.nblk + chunk) * kLinWaves, wave_slot);
+    if (phase == 3) return;
+  }
+  const int wr = phase == 0 ? cur : cur ^ 1;
   LinFactor F;
   F.on = false;
   if (i < ms) {
-    const double4 p = C.pts[(size_t)cs * P + i];
-    const int prev_j = has_prev ? C.tgt_index[(size_t)pair * P + i] : -1;
-    double4 prev_q = make_double4(0, 0, 0, 0);
-    if (prev_j >= 0) prev_q = tp[prev_j];
-    double tx = 0, ty = 0, tz = 0;
-    int cx = 0, cy = 0, cz = 0;
-    bool in_range = false;
-    lin_image(p, Hd.T, C.prm, tx, ty, tz, cx, cy, cz, in_range);
     const NnGlobal src{tp, gi, G0, C.ucell + (size_t)ct * (P + 1), C.ubegin + (size_t)ct * (P + 1), C.n_ucell[ct]};
-    gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, Hd.T, has_prev, prev_j, prev_q, pair, cs, ct, P, C.pts, C.cov6, C.ucell, C.ubegin,
-                   C.n_ucell, G0, gi, C.prm, C.tgt_index, C.maha6, F);
+    gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, C.pts, C.cov6, C.ucell, C.ubegin,
+                   C.n_ucell, G0, gi, C.prm, C.tgt_index + (size_t)wr * C.buf_stride, C.maha6 + (size_t)wr * C.buf_stride * 6, F);
   }
   double* dst = C.partial + ((size_t)pair * C.nblk + chunk) * kLinWaves * kRed;
-  const int wave_slot = tid >> 6;
   {
     double vb[14];
     lin_factor_batch_b(F, vb);
@@ -2924,54 +3003,21 @@ __device__ __attribute__((noinline)) void coop_lin_chunk(const void* ctx_lds, co
     wave_reduce_store_map<15, true>(va, kLinMapA, dst, wave_slot);
   }
 }
-
-// GICPFactor::error of a chunk under the trial pose (the body of k_gicp_error)
-__device__ __attribute__((noinline)) void coop_err_chunk(const void* ctx_lds, const void* state_lds, int pair_v, int chunk_v, int ms_v) {
-  CoopCtx C;
-  uniform_load(C, ctx_lds);
-  struct Head {
-    double T[12], newT[12];
-  } Hd;
-  uniform_load(Hd, state_lds);  // PairState: T[12] | newT[12] | ...
-  const int pair = __builtin_amdgcn_readfirstlane(pair_v), chunk = __builtin_amdgcn_readfirstlane(chunk_v),
-            ms = __builtin_amdgcn_readfirstlane(ms_v);
-  const int tid = threadIdx.x, P = C.P;
-  const int cs = 2 * pair + C.prm.src_slot, ct = 2 * pair + 1 - C.prm.src_slot;
-  const int i = chunk * kLinBlock + tid;
-  double e[1] = {0.0};
-  if (i < ms) {
-    const int ti = C.tgt_index[(size_t)pair * P + i];
-    if (ti >= 0) {
-      const double4 p = C.pts[(size_t)cs * P + i];
-      const double* R = Hd.newT;
-      const double* t = Hd.newT + 9;
-      const double tx = R[0] * p.x + R[3] * p.y + R[6] * p.z + t[0];
-      const double ty = R[1] * p.x + R[4] * p.y + R[7] * p.z + t[1];
-      const double tz = R[2] * p.x + R[5] * p.y + R[8] * p.z + t[2];
-      const double4 q = C.pts[(size_t)ct * P + ti];
-      const double r0 = q.x - tx, r1 = q.y - ty, r2 = q.z - tz;
-      const double* M = C.maha6 + ((size_t)pair * P + i) * 6;
-      const double m0 = M[0] * r0 + M[1] * r1 + M[2] * r2, m1 = M[1] * r0 + M[3] * r1 + M[4] * r2,
-                   m2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
-      e[0] = 0.5 * (r0 * m0 + r1 * m1 + r2 * m2);
-    }
-  }
-  wave_reduce_store<1, true>(e, C.epartial + ((size_t)pair * C.nblk + chunk) * kLinWaves, tid >> 6);
-}
-static_assert(offsetof(PairState, T) == 0 && offsetof(PairState, newT) == 12 * sizeof(double), "coop_*_chunk read the head of PairState");
+static_assert(offsetof(PairState, T) == 0 && offsetof(PairState, newT) == 12 * sizeof(double), "coop_pass_chunk reads the head of PairState");
 
 __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gicp_lm_coop(
     PairState* __restrict__ st, const double4* __restrict__ pts, const double* __restrict__ cov6, const u64* __restrict__ ucell,
     const unsigned* __restrict__ ubegin, const int* __restrict__ n_ucell, const int* __restrict__ m_counts,
     const unsigned* __restrict__ grid, const int* __restrict__ ginfo, int nchunks, int P, GicpParams prm, int* __restrict__ tgt_index,
-    double* __restrict__ maha6, double* __restrict__ partial, double* __restrict__ epartial, int nblk, const int* __restrict__ act,
-    const int* __restrict__ n_act, int n_fixed, CoopSync* __restrict__ sync, int* __restrict__ n_done, int* __restrict__ n_err) {
+    double* __restrict__ maha6, size_t buf_stride, double* __restrict__ partial, double* __restrict__ epartial, int nblk,
+    const int* __restrict__ act, const int* __restrict__ n_act, int n_fixed, CoopSync* __restrict__ sync, int* __restrict__ n_done,
+    int* __restrict__ n_err) {
   __shared__ double s_part[8 * 32], s_sum[32];
   __shared__ u64 s_state[64];
   __shared__ CoopCtx s_ctx;
   __shared__ int s_last;
   const int tid = threadIdx.x;
-  // pairs of this launch: the list the previous round's k_gicp_decide wrote (act), or pairs 0 .. n_fixed - 1; every workgroup
+  // pairs of this launch: the list the previous round's k_gicp_step wrote (act), or pairs 0 .. n_fixed - 1; every workgroup
   // derives the same G from the same count
   const int n = act ? *n_act : n_fixed;
   if (n <= 0) return;
@@ -2983,7 +3029,7 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
   const int nblk_pair = (ms + kLinBlock - 1) / kLinBlock;
   const int Gp = max(1, min(G, nblk_pair));  // workgroups that have a chunk (at least one: the scalar steps must run)
   if (g >= Gp) return;
-  if (tid == 0) s_ctx = CoopCtx{pts, cov6, ucell, ubegin, n_ucell, grid, ginfo, tgt_index, maha6, partial, epartial, P, nblk, prm};
+  if (tid == 0) s_ctx = CoopCtx{pts, cov6, ucell, ubegin, n_ucell, grid, ginfo, tgt_index, maha6, partial, epartial, buf_stride, P, nblk, prm};
   u64* Sw = reinterpret_cast<u64*>(st + pair);
   PairState& S = *reinterpret_cast<PairState*>(s_state);
   CoopSync* sy = sync + pair;
@@ -2993,11 +3039,7 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
     __syncthreads();
     const int phase = __builtin_amdgcn_readfirstlane(S.phase);
     if (phase == 2) break;
-    if (phase == 0) {
-      for (int chunk = g; chunk < nblk_pair; chunk += Gp) coop_lin_chunk(&s_ctx, s_state, pair, chunk, ms);
-    } else {
-      for (int chunk = g; chunk < nblk_pair; chunk += Gp) coop_err_chunk(&s_ctx, s_state, pair, chunk, ms);
-    }
+    for (int chunk = g; chunk < nblk_pair; chunk += Gp) coop_pass_chunk(&s_ctx, s_state, pair, chunk, ms);
     // ---- the pair's barrier: every storing wave drains, the workgroup's arrival is counted once, the last one takes the step
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -3008,14 +3050,9 @@ __global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(5, 8)
     __syncthreads();
     if (s_last) {
       bool done = false;
-      if (phase == 0) fold_partials<kRed, true>(partial + (size_t)pair * nblk * kLinWaves * kRed, nblk_pair, kRed, s_part, s_sum);
-      else fold_partials<1, true>(epartial + (size_t)pair * nblk * kLinWaves, nblk_pair, 1, s_part, s_sum);
-      if (tid == 0) {
-        bool solve = true;
-        if (phase == 0) lm_after_linearize(S, s_sum);
-        else solve = lm_after_error(S, s_sum[0], prm, &done);
-        if (solve) lm_solve(S);
-      }
+      fold_round<true>(partial + (size_t)pair * nblk * kLinWaves * kRed, epartial + (size_t)pair * nblk * kLinWaves, phase != 3, phase != 0,
+                       nblk_pair, s_part, s_sum);
+      if (tid == 0) lm_round_step(S, s_sum, prm, &done);
       __syncthreads();
       if (tid < kStateWords) st_ag(Sw + tid, s_state[tid]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the state words are stored by wave 0, which also stores the flag)
@@ -3199,6 +3236,7 @@ __global__ void k_gicp_init(PairState* __restrict__ st, const double* __restrict
   S.iterations = 0;
   S.inliers = 0;
   S.n_lin = S.n_err = 0;
+  S.buf = S.pad_ = 0;
   S.phase = max_iterations > 0 ? 0 : 2;
   if (max_iterations <= 0) atomicAdd(n_done, 1);
 }
@@ -3223,12 +3261,13 @@ struct gfs_gicp {
   // one launch per step of the LM state machine (default).  GFS_GICP_LM=persistent: the whole loop of a pair in one workgroup
   // (k_gicp_lm) — no launches / host polls inside the loop, but only one workgroup of parallelism per pair: measured 4x slower at
   // 128 pairs per batch (25 vs 6 ms per 512 pairs), it pays only for batches of many thousand small pairs.
-  gfs::DevBuf<int> d_active, d_nactive;  // [2][B] pairs still iterating (written by k_gicp_decide for the next round), [2] their number
+  gfs::DevBuf<int> d_active, d_nactive;  // [3][B] pairs still iterating (written by k_gicp_step for the next round), [3] their number (round r: r % 3)
   bool lm_rounds = true;
   // k_gicp_lm_coop (the loop of a few pairs in one launch): GFS_GICP_COOP=0 switches it off; coop_cap = workgroups of it the device
   // holds at once (occupancy query, one fewer per CU than the API says: the hardware may admit fewer); a launch takes its
   // workgroups from a process-wide budget of half of that (CoopBudget) and gives them back when the call has been waited for
   bool coop = true, coop_failed = false;
+  bool fuse_step = false;  // GFS_GICP_FUSE_STEP=1 (read at creation): see the round loop of gicp_run
   int coop_cap = 0, coop_reserved = 0, coop_launches = 0, coop_last_wgs = 0;
   // GFS_GICP_COOP_TAIL = f > 0: the TAIL of a larger batch also goes to the kernel once (pairs left) x (chunks a pair) <= f x budget.
   // Off by default -- measured (round 6, 64-pair block in 2 lanes): 2.07 ms a step without, 2.09 / 2.11 / 2.17 / 2.29 ms with f = 1 / 2 /
@@ -3384,6 +3423,7 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   if (const char* e = getenv("GFS_GICP_LM")) h->lm_rounds = strcmp(e, "persistent") != 0;
   if (const char* e = getenv("GFS_GICP_TILE_STATS")) h->tile_stats_on = atoi(e) != 0;
   if (const char* e = getenv("GFS_GICP_COOP")) h->coop = atoi(e) != 0;
+  if (const char* e = getenv("GFS_GICP_FUSE_STEP")) h->fuse_step = atoi(e) != 0;
   if (const char* e = getenv("GFS_GICP_COOP_TAIL")) h->coop_tail = atof(e);
   {
     int per_cu = 0, cus = 0;
@@ -3417,8 +3457,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_grid.alloc(C2 * ((size_t)kGridCap + 1)));
   A(h->d_ndone.alloc(4));  // [0] pairs done, [1] clouds the LDS sort kernel left to the kernels that were not launched, [2] k_gicp_lm_coop's timeouts
   A(h->d_sync.alloc(B));
-  A(h->d_active.alloc(2 * (size_t)B));
-  A(h->d_nactive.alloc(2));
+  A(h->d_active.alloc(3 * (size_t)B));
+  A(h->d_nactive.alloc(4));
   A(h->d_tile_stats.alloc(8));
   A(h->d_keys0.alloc(C2 * P));
   A(h->d_keys1.alloc(C2 * P));
@@ -3438,8 +3478,8 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_tmp.alloc(C2 * P));
   A(h->d_pts.alloc(C2 * P));
   A(h->d_cov6.alloc(C2 * P * 6));
-  A(h->d_maha6.alloc(B * P * 6));
-  A(h->d_tgt_index.alloc(B * P));
+  A(h->d_maha6.alloc(2 * B * P * 6));  // two buffers a pair: the frozen correspondences and those of the speculative linearisation
+  A(h->d_tgt_index.alloc(2 * B * P));
   A(h->d_partial.alloc(B * h->nblk * kLinWaves * kRed));
   A(h->d_epartial.alloc(B * h->nblk * kLinWaves));
   A(h->d_initT.alloc(B * 16));
@@ -3598,6 +3638,8 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   } else {
     const int nblk_run = gfs::div_up(npts, kLinBlock);
     const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
+    const size_t buf_stride = (size_t)h->Bmax * P;  // elements between a pair's two (tgt_index, maha6 / 6) buffers
+    GFS_HIP(hipMemsetAsync(h->d_nactive.p, 0, 4 * sizeof(int), s));
     int known_done = 0;  // pairs known to be done: the count polled one round behind
     // k_gicp_lm_coop takes the loop of `n_ub` pairs (an upper bound of those still iterating; the exact list, if any, is on the
     // device) off the host: the rest of the loop is ONE launch.  Its workgroups wait for each other, so they come out of the
@@ -3606,7 +3648,8 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     const bool coop_ok = h->coop && !h->coop_failed && !prm.lin_tile && lin_wg_default && h->coop_cap > 0 && prm.max_iterations > 0;
     const int coop_budget = h->coop_cap / 2;
     auto launch_coop = [&](int n_ub, const int* act_list, const int* n_act_list) -> bool {
-      const int want = std::min(n_ub * nblk_run, coop_budget);
+      static const int max_wg = getenv("GFS_GICP_COOP_MAXWG") ? std::max(1, atoi(getenv("GFS_GICP_COOP_MAXWG"))) : (1 << 30);  // debugging: fewer workgroups a pair
+      const int want = std::min(std::min(n_ub * nblk_run, coop_budget), std::max(n_ub, max_wg));
       const int got = CoopBudget::reserve(h->device, want, std::max(n_ub, want / 2), coop_budget);
       if (got <= 0) return false;
       h->coop_reserved += got;
@@ -3614,7 +3657,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
       h->coop_last_wgs = got;
       GFS_LAUNCH("k_gicp_lm_coop", k_gicp_lm_coop, dim3(got), dim3(kLinBlock), 0, s, h->d_state.p, h->d_pts.p, h->d_cov6.p, h->d_ucell.p,
                  h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p, nblk_run, P, prm, h->d_tgt_index.p, h->d_maha6.p,
-                 h->d_partial.p, h->d_epartial.p, h->nblk, act_list, n_act_list, n_ub, h->d_sync.p, h->d_ndone.p, h->d_ndone.p + 2);
+                 buf_stride, h->d_partial.p, h->d_epartial.p, h->nblk, act_list, n_act_list, n_ub, h->d_sync.p, h->d_ndone.p, h->d_ndone.p + 2);
       return true;
     };
     // a batch small enough for a workgroup per chunk of every pair (one live stream: B = 1) runs its whole loop there
@@ -3626,15 +3669,16 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
       const int ub = B - known_done;
       // ... and once the pairs left would each get at least 1 / coop_tail of a workgroup per chunk, the tail goes to the cooperative kernel
       if (coop_ok && round >= 2 && ub < B && (double)ub * nblk_run <= h->coop_tail * coop_budget &&
-          launch_coop(ub, h->d_active.p + (size_t)(round & 1) * B, h->d_nactive.p + (round & 1))) {
+          launch_coop(ub, h->d_active.p + (size_t)(round % 3) * B, h->d_nactive.p + (round % 3))) {
         in_coop = true;
         break;
       }
       const bool listed = round >= 2 && 4 * ub <= B;
-      const int* act = listed ? h->d_active.p + (size_t)(round & 1) * B : nullptr;
-      const int* n_act = h->d_nactive.p + (round & 1);
-      int* act_next = h->d_active.p + (size_t)((round + 1) & 1) * B;
-      int* n_act_next = h->d_nactive.p + ((round + 1) & 1);
+      const int* act = listed ? h->d_active.p + (size_t)(round % 3) * B : nullptr;
+      const int* n_act = h->d_nactive.p + (round % 3);
+      int* act_next = h->d_active.p + (size_t)((round + 1) % 3) * B;
+      int* n_act_next = h->d_nactive.p + ((round + 1) % 3);
+      int* n_act_clear = h->d_nactive.p + ((round + 2) % 3);
       const dim3 grid_pts(listed ? std::max(ub, 1) * nblk_run : xcd_grid(nblk_run, B, 1));
       // GFS_GICP_LIN_WG=64 / 128: the kernels without LDS as one- or two-wave workgroups, four or two to a chunk (lin_point_of).
       // Measured in round 4: k_gicp_linearize alone 150 -> 137 us per launch of 512 pairs with one-wave workgroups (finished waves
@@ -3643,21 +3687,32 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
       static const int lin_wg = getenv("GFS_GICP_LIN_WG") ? std::max(64, std::min(256, atoi(getenv("GFS_GICP_LIN_WG")) / 64 * 64)) : 256;
       const int per = kLinBlock / (lin_wg == 128 ? 128 : lin_wg == 256 ? 256 : 64), wg = kLinBlock / per;
       const dim3 grid_w(listed ? std::max(ub, 1) * nblk_run * per : xcd_grid(nblk_run * per, B, 1));
+      // one pass per round: the pending trials' errors + the linearisations, and -- in the pair's last workgroup -- its scalar step
+      // (GFS_GICP_LIN_WG = 64 / 128, workgroups smaller than the fold needs: the step as a launch of its own, k_gicp_step)
+      // GFS_GICP_FUSE_STEP=1 (256-thread workgroups): the step inside the pass, taken by the pair's last workgroup -- a round is ONE
+      // launch.  Measured (round 6): SLOWER -- a lane of 32 pairs 8 x (45 + 11) -> 8 x 60 us of kernels a call, the 64-pair block 2.03 ->
+      // 2.07 ms, the headline 42.8 -> 41.3 k frames/s: the last workgroup's fold through L1-bypassing loads and its one-lane solve
+      // lengthen every pass by more than the launch boundary they save.  Kept behind the knob with its parity test.
+      const bool fuse = h->fuse_step && wg == kLinBlock;
       if (prm.lin_tile) {
-        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<true>, grid_pts, dim3(kLinBlock), 0, s, h->d_state.p,
+        GFS_LAUNCH("k_gicp_linearize", (k_gicp_linearize<true, false>), grid_pts, dim3(kLinBlock), 0, s, h->d_state.p,
                    h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
-                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk, act, n_act);
+                   nblk_run, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, buf_stride, h->d_partial.p, h->d_epartial.p, h->nblk, act, n_act,
+                   nullptr, nullptr, nullptr, nullptr, nullptr);
+      } else if (fuse) {
+        GFS_LAUNCH("k_gicp_linearize", (k_gicp_linearize<false, true>), grid_w, dim3(wg), 0, s, h->d_state.p,
+                   h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
+                   nblk_run * per, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, buf_stride, h->d_partial.p, h->d_epartial.p, h->nblk, act, n_act,
+                   h->d_sync.p, h->d_ndone.p, act_next, n_act_next, n_act_clear);
       } else {
-        GFS_LAUNCH("k_gicp_linearize", k_gicp_linearize<false>, grid_w, dim3(wg), 0, s, h->d_state.p,
+        GFS_LAUNCH("k_gicp_linearize", (k_gicp_linearize<false, false>), grid_w, dim3(wg), 0, s, h->d_state.p,
                    h->d_pts.p, h->d_cov6.p, h->d_ucell.p, h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_grid.p, h->d_ginfo.p,
-                   nblk_run * per, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, h->d_partial.p, h->nblk, act, n_act);
+                   nblk_run * per, B, P, prm, h->d_tgt_index.p, h->d_maha6.p, buf_stride, h->d_partial.p, h->d_epartial.p, h->nblk, act, n_act,
+                   nullptr, nullptr, nullptr, nullptr, nullptr);
       }
-      GFS_LAUNCH("k_gicp_solve", k_gicp_solve, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_m.p, h->nblk, prm.src_slot,
-                 n_act_next);
-      GFS_LAUNCH("k_gicp_error", k_gicp_error, grid_w, dim3(wg), 0, s, h->d_state.p, h->d_pts.p,
-                 h->d_m.p, P, h->d_tgt_index.p, h->d_maha6.p, h->d_epartial.p, h->nblk, nblk_run * per, B, prm.src_slot, act, n_act);
-      GFS_LAUNCH("k_gicp_decide", k_gicp_decide, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
-                 h->d_ndone.p, act_next, n_act_next);
+      if (!fuse || prm.lin_tile)
+        GFS_LAUNCH("k_gicp_step", k_gicp_step, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
+                   h->d_ndone.p, act_next, n_act_next, n_act_clear);
       // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
       // speculative round after convergence finds every pair in phase 2 and its blocks exit at once.
       GFS_HIP(hipMemcpyAsync(h->h_ndone.p + 2 * (round & 1), h->d_ndone.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));

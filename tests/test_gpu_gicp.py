@@ -409,6 +409,31 @@ def test_cooperative_lm_kernel_gives_the_bits_of_the_launch_per_step_rounds(gpu_
     hip.free()
 
 
+def test_step_in_the_last_workgroup_knob_gives_the_same_bits(gpu_api, monkeypatch):
+    """GFS_GICP_FUSE_STEP=1: a pair's scalar step taken by the workgroup of the pass that finishes last (one launch a round; measured
+    slower, not the default) -- the same bits as the step kernel, for a ragged batch with an empty and a tiny cloud."""
+    from test_gpu_gms import _Hip
+    pairs = []
+    for k in range(12):
+        fp = synth.frame_pair(500 + k, 160, 120, stride=1 + (k % 2))
+        pairs.append((fp["cloud0"], fp["cloud1"]))
+    pairs[3] = (pairs[3][0], pairs[3][1][:7])
+    pairs[5] = (pairs[5][0], pairs[5][1][:0])
+    SP, B = 20480, 12
+    c0 = np.zeros((B, SP, 4), np.float32); c1 = np.zeros((B, SP, 4), np.float32); n0 = np.zeros(B, np.int32); n1 = np.zeros(B, np.int32)
+    for b, (a, s_) in enumerate(pairs):
+        c0[b, :len(a)], c1[b, :len(s_)], n0[b], n1[b] = a, s_, len(a), len(s_)
+    hip = _Hip()
+    d = [hip.to_device(x) for x in (c0, n0, c1, n1)]
+    monkeypatch.setenv("GFS_GICP_COOP", "0")
+    want = gpu_api.RegistrationGICP(max_points=SP, max_batch=B).align_batch_device(d[0], d[1], d[2], d[3], B, SP)
+    monkeypatch.setenv("GFS_GICP_FUSE_STEP", "1")
+    got = gpu_api.RegistrationGICP(max_points=SP, max_batch=B).align_batch_device(d[0], d[1], d[2], d[3], B, SP)
+    for b in range(B):
+        assert _same(got[b], want[b]) and got[b]["n_error_evals"] == want[b]["n_error_evals"], b
+    hip.free()
+
+
 def _gicp_same(r, ro, bar=1e-5):
     return (r["converged"] == ro["converged"] and r["iterations"] == ro["iterations"] and r["num_inliers"] == ro["num_inliers"]
             and r["n_target_ds"] == ro["n_target_ds"] and r["n_source_ds"] == ro["n_source_ds"] and _rel(r["T"], ro["T"]) < bar)
