@@ -446,9 +446,11 @@ def test_random_pairs_meet_the_bar_or_have_a_proved_kth_distance_tie(gpu_api, or
     bit-identical, some point has an EXACT distance tie between its 10th and 11th neighbour (ann/knn_result.hpp:80-101 keeps the first
     one pushed, i.e. the KdTree's visiting order, which the reference itself does not reproduce between runs: DESIGN.md section 2),
     and after moving the raw points behind every tied 11th neighbour by 20 micrometres the same pair agrees."""
+    import concurrent.futures as cf
     reg = gpu_api.RegistrationGICP(max_points=65536)
     ties, worst = [], 0.0
-    for ci in range(2000):
+
+    def draw(ci):  # the pair and the oracle's answer: on worker threads (the oracle is a C library, the GIL is released), ahead of the GPU
         rng = np.random.default_rng([4321, 2, ci])
         s = int(rng.integers(0, 1 << 30))
         w, h = int(rng.choice([96, 128, 160, 200])), int(rng.choice([72, 96, 120, 150]))
@@ -457,7 +459,16 @@ def test_random_pairs_meet_the_bar_or_have_a_proved_kth_distance_tie(gpu_api, or
             c0 = c0[:int(len(c0) * rng.uniform(0.2, 1.0))]
         if rng.integers(0, 4) == 0:
             c1 = c1[::int(rng.integers(1, 4))]
-        r, ro = reg.RegisterPointClouds(c0, c1), oracle.gicp_align(c0, c1)
+        return c0, c1, oracle.gicp_align(c0, c1)
+
+    pool = cf.ThreadPoolExecutor(max_workers=24)
+    drawn = {}
+    for ci in range(2000):
+        for k in range(ci, min(ci + 96, 2000)):  # a bounded window of pairs in flight
+            if k not in drawn:
+                drawn[k] = pool.submit(draw, k)
+        c0, c1, ro = drawn.pop(ci).result()
+        r = reg.RegisterPointClouds(c0, c1)
         if _gicp_same(r, ro):
             worst = max(worst, _rel(r["T"], ro["T"]))
             continue
@@ -483,6 +494,7 @@ def test_random_pairs_meet_the_bar_or_have_a_proved_kth_distance_tie(gpu_api, or
         else:
             raise AssertionError(("still over the bar with every tie broken", ci))
         ties.append((ci, _rel(r["T"], ro["T"]), n_ties))
+    pool.shutdown()
     assert len(ties) <= 40, ties  # round 2 measured 7 of 13 000
     assert worst < 1e-5
 

@@ -18,3 +18,10 @@ if hasattr(api, "BatchOptimizer"):
     for _ in range(6):
         t = time.perf_counter(); bat.LocalBundleAdjustment(wins); ts.append(time.perf_counter() - t)
     print("64 windows batched: median %.2f ms = %.0f windows/s" % (np.median(ts) * 1e3, 64 / np.median(ts)))
+    one = api.BatchOptimizer(1, max_poses=32, max_points=4096, max_edges=65536)
+    for _ in range(5): rb = one.LocalBundleAdjustment([w])
+    ts = []
+    for _ in range(40):
+        t = time.perf_counter(); rb = one.LocalBundleAdjustment([w]); ts.append(time.perf_counter() - t)
+    same = np.array_equal(rb[0]["poses"], r["poses"]) and np.array_equal(rb[0]["points"], r["points"]) if "poses" in r else None
+    print("one window through the batched entry: median %.3f ms, min %.3f ms, same bits as gfs_lba_solve: %s" % (np.median(ts) * 1e3, np.min(ts) * 1e3, same))
