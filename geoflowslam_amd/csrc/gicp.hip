@@ -34,8 +34,15 @@ constexpr int kCoordBits = 21;
 constexpr int kCoordOffset = 1 << (kCoordBits - 1);
 constexpr int kCoordMask = (1 << kCoordBits) - 1;
 // The CELL sort key (k_voxel_reduce -> k_radix_sort -> k_cell_build) orders the points of a cell by x as well: its x field counts
-// sixteenths of a cell.  Fields: x fine 25 bits | y 20 bits | z 19 bits (|cell coordinate| < 2^18: k_voxel_keys' max_vox sees to it).
-constexpr int kFineBits = 4, kFine = 1 << kFineBits;
+// 1 / kFine of a cell (sixty-fourths since round 6).  Fields: x fine 25 bits | y 20 bits | z 19 bits (|cell coordinate| < 2^18: k_voxel_keys' max_vox sees to it).
+// Sub-cell bits of a cell sort key's x field: the points of a row of cells are ordered by 1 / 2^bits of a cell along x, and the walk of
+// the linearisation's 1-NN search (nn_sweep) stops one such slice beyond its bound.  Measured (round 6, k_gicp_linearize per 512-pair
+// step, serial): 3 bits 3.37 ms, 4 (rounds 3 - 5) 3.25, 5: 3.18, 6: 3.14 -- 6 is what the 25-bit field holds beside 19 bits of cell.
+#ifndef GFS_FINE_BITS
+#define GFS_FINE_BITS 6
+#endif
+constexpr int kFineBits = GFS_FINE_BITS, kFine = 1 << kFineBits;
+static_assert(kFineBits >= 1 && kFineBits <= 6, "the x field of a cell sort key: 19 bits of cell + the sub-cell bits in 25");
 constexpr int kCkSy = 25, kCkSz = 45;  // bit positions of the y and z fields of a cell sort key
 constexpr int kCkOffX = 1 << 24, kCkOffY = 1 << 19, kCkOffZ = 1 << 18;
 constexpr int kRed = 29;  // 21 (upper H) + 6 (b) + 1 (e) + 1 (inlier count)
@@ -620,7 +627,7 @@ __global__ __launch_bounds__(1024) void k_voxel_reduce(const float4* __restrict_
       } while (j < 1024 && !s_stop[j]);
       const double mx = sx / sw, my = sy / sw, mz = sz / sw;
       out[pos] = make_double4(mx, my, mz, sw / sw);
-      {  // cell sort key: the cell (as every search computes it: floor(v * inv_cell)) and, below it, the sixteenth of the cell along x
+      {  // cell sort key: the cell (as every search computes it: floor(v * inv_cell)) and, below it, the slice (1 / kFine) of the cell along x
         const double ux = mx * inv_cell;
         const int cxm = fast_floor_d(ux), cym = fast_floor_d(my * inv_cell), czm = fast_floor_d(mz * inv_cell);
         const int sub = min(max((int)((ux - (double)cxm) * (double)kFine), 0), kFine - 1);
@@ -1208,6 +1215,36 @@ __device__ __forceinline__ void knn_scan_run_keys(const double4* __restrict__ p,
               knn_key(t3, q, j + 3, j + 3 < j1));
   }
 }
+// The query's OWN row of cells [lo, hi) -- it holds the query itself, at index i -- walked from the query outwards, two candidates a
+// side per step (round 6).  The row is ordered by slices of 1 / kFine of a cell along x (the cell sort key), so everything beyond
+// the outermost point seen on a side has an x of at least that point's minus one slice: the side stops once that gap alone exceeds
+// the k-th distance so far.  A depth-camera cloud puts 25 points into a cell its surface crosses, the k-th neighbour is ~4 cm away
+// and the row 30 cm long: the walk takes a third of the row.  The keys are (distance | index), so the list does not depend on the
+// order of the visits, and what is left out is farther than the k-th candidate at that time (as with the neighbouring rows below).
+__device__ __forceinline__ void knn_walk_own_row(const double4* __restrict__ p, const double4& q, int i, int lo, int hi, double slack,
+                                                 int want, TopKey11& loc) {
+  int r = i, l = i - 1;
+  bool ra = r < hi, la = l >= lo;
+  const int kw_at = max(want - 1, 0);
+  while (ra || la) {
+    const int j0 = min(r, hi - 1), j1 = max(l, lo), j2 = min(r + 1, hi - 1), j3 = max(l - 1, lo);
+    const bool on2 = ra && r + 1 < hi, on3 = la && l - 1 >= lo;
+    const double4 t0 = ld_pt(p, j0), t1 = ld_pt(p, j1), t2 = ld_pt(p, j2), t3 = ld_pt(p, j3);
+    loc.push4(knn_key(t0, q, j0, ra), knn_key(t1, q, j1, la), knn_key(t2, q, j2, on2), knn_key(t3, q, j3, on3));
+    const double kw = loc.at(kw_at);
+    const double B = kw < TopKey11::kNone ? TopKey11::upper(kw) : TopKey11::kNone;
+    if (ra) {
+      r += 2;
+      const double g = t2.x - slack - q.x;  // (t2 = t0 when the row ends at r: nothing is ahead then anyway)
+      ra = r < hi && !(g > 0.0 && g * g > B);
+    }
+    if (la) {
+      l -= 2;
+      const double g = q.x - t3.x - slack;
+      la = l >= lo && !(g > 0.0 && g * g > B);
+    }
+  }
+}
 // the same over up to four runs (begin, length) concatenated into one lane-private sequence
 __device__ __forceinline__ void knn_scan_runs4_keys(const double4* __restrict__ p, const double4& q, int b0, int l0, int b1, int l1,
                                                     int b2, int l2, int b3, int l3, TopKey11& loc) {
@@ -1379,7 +1416,14 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
     {
       int j0, j1;
       row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy, cz, &j0, &j1);
-      knn_scan_run_keys(p, q, j0, j1, best);
+#ifdef GFS_KNN_OWN_ROW_SCAN
+      knn_scan_run_keys(p, q, j0, j1, best);  // (rounds 3 - 5: the whole row)
+#else
+      if (i >= j0 && i < j1)  // (always: the query is a point of its own cell)
+        knn_walk_own_row(p, q, i, j0, j1, prm.cell * (1.0 / kFine + 1e-9), want, best);
+      else
+        knn_scan_run_keys(p, q, j0, j1, best);
+#endif
     }
     // k-th distance so far (its upper end), or "none yet"
     auto kth_bound = [&]() {
@@ -1909,6 +1953,9 @@ struct NnGlobal {
   const u64* uc;
   const unsigned* ub;
   int nu;
+#ifdef GFS_LIN_UTIL
+  unsigned* util;
+#endif
   // boundaries (global point indices) of cells cx-1, cx, cx+1 of row (y, z); returns the offset that turns a global point index
   // into this source's index (0 here)
   __device__ __forceinline__ int cells3(int cx, int y, int z, int* e) const {
@@ -1954,6 +2001,9 @@ struct LinTile {
 struct NnTile {
   const LinTile* t;
   int y0, z0, ny;  // the box's first row (cymin - 1, czmin - 1) and its row count along y
+#ifdef GFS_LIN_UTIL
+  unsigned* util;
+#endif
   __device__ __forceinline__ int cells3(int cx, int y, int z, int* e) const {
     const int r = (y - y0) + ny * (z - z0);
     const int coff = t->row_coff[r];
@@ -1972,9 +2022,9 @@ struct NnTile {
 };
 
 // The candidates of one row of cells (y, z): the strip [lo, hi) of points (global indices; index in the source = global + d) is
-// ordered by sixteenths of a cell along x (the cell sort key, k_voxel_reduce).  Walk outwards from `start` in both directions, two
+// ordered by slices of 1 / kFine of a cell along x (the cell sort key, k_voxel_reduce).  Walk outwards from `start` in both directions, two
 // candidates a side per step; a side stops when everything still ahead of it is farther than the bound: a point ahead has an x of
-// at least (x of the outermost point seen on that side) - slack, slack = one sixteenth of a cell (+ rounding).  row2 = squared
+// at least (x of the outermost point seen on that side) - slack, slack = one such slice (+ rounding).  row2 = squared
 // lower bound of the distance in y and z.  Any walk order gives the exact nearest neighbour; the order only breaks exact ties.
 template <class Src>
 __device__ __forceinline__ void nn_sweep(const Src& src, double tx, double ty, double tz, int lo, int hi, int d, int start, double row2,
@@ -1982,6 +2032,15 @@ __device__ __forceinline__ void nn_sweep(const Src& src, double tx, double ty, d
   int r = start, l = start - 1;
   bool ra = r < hi, la = l >= lo;
   while (ra || la) {
+#ifdef GFS_LIN_UTIL
+    if (src.util) {  // lanes at work in this step of the walk / steps of the wave (variant builds only)
+      const unsigned long long m = __ballot(1);
+      if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+        atomicAdd(src.util + 4, (unsigned)__popcll(m));
+        atomicAdd(src.util + 5, 1u);
+      }
+    }
+#endif
     // clamped into the strip: a clamped index is just another (or the same) candidate of the strip
     const int j[4] = {min(r, hi - 1), max(l, lo), min(r + 1, hi - 1), max(l - 1, lo)};
     double qx[4], dd[4];
@@ -2035,6 +2094,15 @@ __device__ __forceinline__ void nn_search27(const Src& src, const GicpParams& pr
       nn_sweep(src, tx, ty, tz, e[0], e[3], d, start, row2, slack, prm.max_dist_sq, B, best, bj);
     }
   };
+#ifdef GFS_LIN_UTIL
+  if (src.util) {  // searches (lanes) and waves that search
+    const unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+      atomicAdd(src.util + 6, (unsigned)__popcll(m));
+      atomicAdd(src.util + 7, 1u);
+    }
+  }
+#endif
   row(cy, cz, 0.0);
   unsigned need = 0;
 #pragma unroll
@@ -2044,6 +2112,15 @@ __device__ __forceinline__ void nn_search27(const Src& src, const GicpParams& pr
     if (a * a + c * c <= B) need |= 1u << t8;
   }
   while (__any(need != 0)) {
+#ifdef GFS_LIN_UTIL
+    if (src.util) {  // rounds of neighbouring rows per wave, and the lanes that have one
+      const unsigned long long m = __ballot(need != 0);
+      if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) {
+        atomicAdd(src.util + 2, (unsigned)__popcll(m));
+        atomicAdd(src.util + 3, 1u);
+      }
+    }
+#endif
     if (need != 0) {
       const int t8 = __ffs(need) - 1;
       need &= need - 1;
@@ -2562,7 +2639,11 @@ __global__ __launch_bounds__(kLinBlock) GFS_LIN_OCC void k_gicp_linearize(PairSt
         }
       }
       if (!done) {
+#ifdef GFS_LIN_UTIL
+        const NnGlobal src{tp, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct], prm.tile_stats};
+#else
         const NnGlobal src{tp, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
+#endif
         gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, pts, cov6, ucell, ubegin, n_ucell,
                        G, gi, prm, ti_wr, maha_wr, F);
       }
@@ -2987,7 +3068,11 @@ __device__ __attribute__((noinline)) void coop_pass_chunk(const void* ctx_lds, c
   LinFactor F;
   F.on = false;
   if (i < ms) {
+#ifdef GFS_LIN_UTIL
+    const NnGlobal src{tp, gi, G0, C.ucell + (size_t)ct * (P + 1), C.ubegin + (size_t)ct * (P + 1), C.n_ucell[ct], nullptr};
+#else
     const NnGlobal src{tp, gi, G0, C.ucell + (size_t)ct * (P + 1), C.ubegin + (size_t)ct * (P + 1), C.n_ucell[ct]};
+#endif
     gicp_lin_point(src, i, p, tx, ty, tz, cx, cy, cz, in_range, T12, has_prev, prev_j, prev_q, pair, cs, ct, P, C.pts, C.cov6, C.ucell, C.ubegin,
                    C.n_ucell, G0, gi, C.prm, C.tgt_index + (size_t)wr * C.buf_stride, C.maha6 + (size_t)wr * C.buf_stride * 6, F);
   }
@@ -3113,7 +3198,11 @@ __global__ __launch_bounds__(kLmBlock) __attribute__((amdgpu_waves_per_eu(4, 8))
       for (int k = 0; k < kRed; k++) acc[k] = 0;
       const bool has_prev = S.n_lin > 0;
       for (int i = tid; i < ms; i += kLmBlock) {
+#ifdef GFS_LIN_UTIL
+        const NnGlobal src{pts + (size_t)ct * P, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct], nullptr};
+#else
         const NnGlobal src{pts + (size_t)ct * P, gi, G, ucell + (size_t)ct * (P + 1), ubegin + (size_t)ct * (P + 1), n_ucell[ct]};
+#endif
         const double4 p = pts[(size_t)cs * P + i];
         double tx, ty, tz;
         int cx, cy, cz;
@@ -3285,7 +3374,9 @@ struct gfs_gicp {
   gfs::DevBuf<PairState> d_state;
   gfs::PinBuf<PairState> h_state;
   gfs::PinBuf<int> h_ndone, h_m;
-  hipEvent_t ev_round[2] = {nullptr, nullptr};  // completion of the two LM rounds in flight
+  static constexpr int kAheadMax = 8;
+  hipEvent_t ev_round[kAheadMax + 1] = {};  // completion of the LM rounds in flight
+  int ahead = 1;  // LM rounds queued beyond the one whose done counter the host waits for (GFS_GICP_AHEAD, measured in round 6: see gicp_run)
   gfs::PinBuf<double> h_initT;
   int last_B = 0;
   // streaming (gfs_gicp_align_next*): slot parity that holds the preprocessed SOURCE clouds of the last call, and what they
@@ -3485,8 +3576,9 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_initT.alloc(B * 16));
   A(h->d_state.alloc(B));
   A(h->h_state.alloc(B));
-  A(h->h_ndone.alloc(8));  // [0..3] the two rounds in flight, [4..6] the call's last look
-  for (int k = 0; k < 2; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_round[k], hipEventDisableTiming));
+  A(h->h_ndone.alloc(2 * (gfs_gicp::kAheadMax + 1) + 4));  // [2 slot ..] the rounds in flight, the last three: the call's last look
+  for (int k = 0; k <= gfs_gicp::kAheadMax; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_round[k], hipEventDisableTiming));
+  if (const char* e = getenv("GFS_GICP_AHEAD")) h->ahead = std::max(1, std::min(gfs_gicp::kAheadMax, atoi(e)));
   A(h->h_m.alloc(C2));
   A(h->h_initT.alloc(B * 16));
   A(h->d_zero.alloc(B));
@@ -3503,7 +3595,7 @@ void gfs_gicp_destroy(gfs_gicp* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   (void)hipStreamDestroy(h->stream);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k <= gfs_gicp::kAheadMax; k++)
     if (h->ev_round[k]) (void)hipEventDestroy(h->ev_round[k]);
   delete h;
 }
@@ -3567,7 +3659,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   GFS_HIP(hipMemcpyAsync(h->d_initT.p, h->h_initT.p, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, s));
   GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, 4 * sizeof(int), s));
   const int npts = std::min(stride_pts, P);
-  // The cell sort key gives the cell z 19 bits, y 20 and x (in sixteenths) 25: every coordinate of a voxel mean fits while
+  // The cell sort key gives the cell z 19 bits, y 20 and x (in 1 / kFine of a cell) 25: every coordinate of a voxel mean fits while
   // |coordinate| < 2^18 cells.  The voxel fields admit 10^6 leaves, which is less whenever cell >= 4 leaves (the reference's
   // 0.1 / 0.02 m); for a smaller ratio the admitted range shrinks to what the cell key can hold (>= 13 km at 0.05 m).
   const double max_vox = std::min(1.0e6, (double)((1 << 18) - 2) * prm.cell * prm.inv_leaf);
@@ -3713,13 +3805,20 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
       if (!fuse || prm.lin_tile)
         GFS_LAUNCH("k_gicp_step", k_gicp_step, dim3(B), dim3(256), 0, s, h->d_state.p, h->d_partial.p, h->d_epartial.p, h->d_m.p, h->nblk, prm,
                    h->d_ndone.p, act_next, n_act_next, n_act_clear);
-      // One round is always queued ahead of the one being polled (the GPU never idles on the host round trip); the
-      // speculative round after convergence finds every pair in phase 2 and its blocks exit at once.
-      GFS_HIP(hipMemcpyAsync(h->h_ndone.p + 2 * (round & 1), h->d_ndone.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-      GFS_HIP(hipEventRecord(h->ev_round[round & 1], s));
-      if (round >= 1) {
-        GFS_HIP(hipEventSynchronize(h->ev_round[(round - 1) & 1]));
-        if (optimistic_sort && h->h_ndone.p[2 * ((round - 1) & 1) + 1] > 0) {
+      // One round (`ahead`, GFS_GICP_AHEAD) is queued beyond the one being polled: the GPU does not idle on the host's round trip; the
+      // speculative round behind convergence finds every pair in phase 2 and its blocks exit at once.  The state machine lives on the
+      // device, so how far ahead the host runs changes no result.  Round 6 measured deeper queues, because a kernel trace of the
+      // 64-pair block under rocprofv3 shows the GICP stream idle for ~50 us behind every round's counter copy (tools/probes/
+      // chain_timeline.py): ahead = 1 / 2 / 3 / 4 / 6 -> 2.000 / 2.014 / 2.019 / 2.041 / 2.054 ms per 64 pairs (2 lanes), 11.92 / 11.93 /
+      // 11.98 / 12.05 / 12.09 ms per 512 -- the gaps are the profiler's, without it the host keeps up, and every extra round in flight
+      // is two empty launches and a copy at the end of the call.
+      const int nslot = h->ahead + 1, slot = round % nslot;
+      GFS_HIP(hipMemcpyAsync(h->h_ndone.p + 2 * slot, h->d_ndone.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+      GFS_HIP(hipEventRecord(h->ev_round[slot], s));
+      if (round >= h->ahead) {
+        const int pslot = (round - h->ahead) % nslot;
+        GFS_HIP(hipEventSynchronize(h->ev_round[pslot]));
+        if (optimistic_sort && h->h_ndone.p[2 * pslot + 1] > 0) {
           // a cloud needed the voxel-sort kernels that were not launched (keys wider than 31 bits): everything again, with them
           GFS_HIP(hipStreamSynchronize(s));
           h->sort_all_kernels = true;
@@ -3727,26 +3826,27 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
           h->sort_all_kernels = false;
           return rc_again;
         }
-        known_done = h->h_ndone.p[2 * ((round - 1) & 1)];
+        known_done = h->h_ndone.p[2 * pslot];
         if (known_done >= B) break;
       }
     }
   }
   GFS_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, (size_t)B * sizeof(PairState), hipMemcpyDeviceToHost, s));
   GFS_HIP(hipMemcpyAsync(h->h_m.p, h->d_m.p, (size_t)C2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  h->h_ndone.p[4] = h->h_ndone.p[5] = h->h_ndone.p[6] = 0;
-  GFS_HIP(hipMemcpyAsync(h->h_ndone.p + 4, h->d_ndone.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+  int* const last_look = h->h_ndone.p + 2 * (gfs_gicp::kAheadMax + 1);  // {pairs done, clouds the LDS sorts left, workgroups that gave up waiting}
+  last_look[0] = last_look[1] = last_look[2] = 0;
+  GFS_HIP(hipMemcpyAsync(last_look, h->d_ndone.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   const hipError_t rc_sync = hipStreamSynchronize(s);
   CoopBudget::release(h->device, h->coop_reserved);  // (whatever happened: the kernel is not running any more)
   h->coop_reserved = 0;
   GFS_HIP(rc_sync);
-  if (h->h_ndone.p[6] > 0 && !h->coop_failed) {
+  if (last_look[2] > 0 && !h->coop_failed) {
     // a workgroup of k_gicp_lm_coop gave up waiting (its grid was not resident together: another process on this device?): never
     // return such a result -- the call again with a launch per step, and this handle stays with that
     h->coop_failed = true;
     return gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
   }
-  if (optimistic_sort && h->h_ndone.p[5] > 0) {  // (the polls inside the loop normally catch this after round 0; never return such a result)
+  if (optimistic_sort && last_look[1] > 0) {  // (the polls inside the loop normally catch this after round 0; never return such a result)
     h->sort_all_kernels = true;
     const int rc_again = gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
     h->sort_all_kernels = false;
