@@ -95,8 +95,18 @@ __device__ __forceinline__ u64 pack_key(int cx, int cy, int cz) {
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ tgt, const float4* __restrict__ src,
                                                     const int* __restrict__ nt, const int* __restrict__ ns,
                                                     int stride_pts, int P, double inv_leaf, double max_vox, u64* __restrict__ keys,
-                                                    unsigned* __restrict__ idx, int* __restrict__ counts, int only) {
+                                                    unsigned* __restrict__ idx, int* __restrict__ counts, int only,
+                                                    int* __restrict__ n_done4, int* __restrict__ n_heap, int* __restrict__ n_active4) {
   const int c = blockIdx.y, pair = c >> 1, which = c & 1;
+  // the first kernel of a call also zeroes the call's counters (round 6: three memset launches in front of it before): the done /
+  // left-over / gave-up counters, the per-cloud heap-range counts of the voxel sort, the active-pair counts of the LM rounds
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    if (threadIdx.x == 0) n_heap[c] = 0;
+    if (c == 0) {
+      n_done4[threadIdx.x] = 0;
+      n_active4[threadIdx.x] = 0;
+    }
+  }
   if (only >= 0 && which != only) return;
   const int n = min(which ? ns[pair] : nt[pair], P);
   const float4* in = (which ? src : tgt) + (size_t)pair * stride_pts;
@@ -1215,6 +1225,20 @@ __device__ __forceinline__ void knn_scan_run_keys(const double4* __restrict__ p,
               knn_key(t3, q, j + 3, j + 3 < j1));
   }
 }
+#ifdef GFS_KNN_UTIL
+// variant builds (tools/probes/knn_util_probe.py): lanes at work summed over the steps of a scan, and the steps (per wave)
+__device__ __forceinline__ void knn_util_step(unsigned* util, int slot) {
+  if (!util) return;
+  const unsigned long long m = __ballot(1);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+    atomicAdd(util + slot, (unsigned)__popcll(m));
+    atomicAdd(util + slot + 1, 1u);
+  }
+}
+#define GFS_KNN_UTIL_STEP(util, slot) knn_util_step(util, slot)
+#else
+#define GFS_KNN_UTIL_STEP(util, slot)
+#endif
 // The query's OWN row of cells [lo, hi) -- it holds the query itself, at index i -- walked from the query outwards, two candidates a
 // side per step (round 6).  The row is ordered by slices of 1 / kFine of a cell along x (the cell sort key), so everything beyond
 // the outermost point seen on a side has an x of at least that point's minus one slice: the side stops once that gap alone exceeds
@@ -1222,11 +1246,12 @@ __device__ __forceinline__ void knn_scan_run_keys(const double4* __restrict__ p,
 // and the row 30 cm long: the walk takes a third of the row.  The keys are (distance | index), so the list does not depend on the
 // order of the visits, and what is left out is farther than the k-th candidate at that time (as with the neighbouring rows below).
 __device__ __forceinline__ void knn_walk_own_row(const double4* __restrict__ p, const double4& q, int i, int lo, int hi, double slack,
-                                                 int want, TopKey11& loc) {
+                                                 int want, TopKey11& loc, unsigned* util = nullptr) {
   int r = i, l = i - 1;
   bool ra = r < hi, la = l >= lo;
   const int kw_at = max(want - 1, 0);
   while (ra || la) {
+    GFS_KNN_UTIL_STEP(util, 0);
     const int j0 = min(r, hi - 1), j1 = max(l, lo), j2 = min(r + 1, hi - 1), j3 = max(l - 1, lo);
     const bool on2 = ra && r + 1 < hi, on3 = la && l - 1 >= lo;
     const double4 t0 = ld_pt(p, j0), t1 = ld_pt(p, j1), t2 = ld_pt(p, j2), t3 = ld_pt(p, j3);
@@ -1247,10 +1272,11 @@ __device__ __forceinline__ void knn_walk_own_row(const double4* __restrict__ p, 
 }
 // the same over up to four runs (begin, length) concatenated into one lane-private sequence
 __device__ __forceinline__ void knn_scan_runs4_keys(const double4* __restrict__ p, const double4& q, int b0, int l0, int b1, int l1,
-                                                    int b2, int l2, int b3, int l3, TopKey11& loc) {
+                                                    int b2, int l2, int b3, int l3, TopKey11& loc, unsigned* util = nullptr) {
   const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
   const int o0 = b0, o1 = b1 - c1, o2 = b2 - c2, o3 = b3 - c3;
   for (int v = 0; v < total; v += 4) {
+    GFS_KNN_UTIL_STEP(util, 2);
     int j[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -1420,7 +1446,7 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
       knn_scan_run_keys(p, q, j0, j1, best);  // (rounds 3 - 5: the whole row)
 #else
       if (i >= j0 && i < j1)  // (always: the query is a point of its own cell)
-        knn_walk_own_row(p, q, i, j0, j1, prm.cell * (1.0 / kFine + 1e-9), want, best);
+        knn_walk_own_row(p, q, i, j0, j1, prm.cell * (1.0 / kFine + 1e-9), want, best, prm.tile_stats);
       else
         knn_scan_run_keys(p, q, j0, j1, best);
 #endif
@@ -1449,8 +1475,16 @@ __global__ __launch_bounds__(128) void k_knn_cov(const double4* __restrict__ pts
           rl[u] = e0 - b0;
         }
       }
-      knn_scan_runs4_keys(p, q, rb[0], rl[0], rb[1], rl[1], rb[2], rl[2], rb[3], rl[3], best);
+      knn_scan_runs4_keys(p, q, rb[0], rl[0], rb[1], rl[1], rb[2], rl[2], rb[3], rl[3], best, prm.tile_stats);
     }
+#ifdef GFS_KNN_UTIL
+    if (prm.tile_stats) {  // queries (lanes) and waves; the candidates of the own row as a whole
+      GFS_KNN_UTIL_STEP(prm.tile_stats, 4);
+      int j0, j1;
+      row_range(gi, G, uc, ub, nu, cx - 1, cx + 1, cy, cz, &j0, &j1);
+      atomicAdd(prm.tile_stats + 6, (unsigned)(j1 - j0));
+    }
+#endif
     // certified: nothing outside the 27-cell cube can be nearer than the k-th candidate.  The cube's faces are 1 + u and 2 - u
     // cells away from the query along each axis (u = its position inside its own cell): at least one cell, up to 1.5
     const double fx = fmin(ux + 1.0, 2.0 - ux), fy = fmin(uy + 1.0, 2.0 - uy), fz = fmin(uz + 1.0, 2.0 - uz);
@@ -3330,6 +3364,18 @@ __global__ void k_gicp_init(PairState* __restrict__ st, const double* __restrict
   if (max_iterations <= 0) atomicAdd(n_done, 1);
 }
 
+// the call's results into pinned host memory (the device's view of it): the pairs' final states, the down-sampled sizes, the counters'
+// last look -- one launch in the place of three device-to-host copies (each a blit kernel of its own on the stream)
+__global__ __launch_bounds__(256) void k_gicp_publish(const PairState* __restrict__ st, const int* __restrict__ m_counts,
+                                                      const int* __restrict__ n_done, int B, u64* __restrict__ host_state,
+                                                      int* __restrict__ host_m, int* __restrict__ host_last) {
+  const int t = blockIdx.x * 256 + threadIdx.x, nw = B * kStateWords;
+  const u64* src = reinterpret_cast<const u64*>(st);
+  for (int k = t; k < nw; k += gridDim.x * 256) host_state[k] = src[k];
+  for (int k = t; k < 2 * B; k += gridDim.x * 256) host_m[k] = m_counts[k];
+  if (t < 3) host_last[t] = n_done[t];
+}
+
 }  // namespace
 
 struct gfs_gicp {
@@ -3370,7 +3416,7 @@ struct gfs_gicp {
   bool sort_all_kernels = false;  // set for the second run of a call whose first run found a cloud the LDS sort kernel could not take
   bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
-  gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial, d_initT;
+  gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial;
   gfs::DevBuf<PairState> d_state;
   gfs::PinBuf<PairState> h_state;
   gfs::PinBuf<int> h_ndone, h_m;
@@ -3378,6 +3424,9 @@ struct gfs_gicp {
   hipEvent_t ev_round[kAheadMax + 1] = {};  // completion of the LM rounds in flight
   int ahead = 1;  // LM rounds queued beyond the one whose done counter the host waits for (GFS_GICP_AHEAD, measured in round 6: see gicp_run)
   gfs::PinBuf<double> h_initT;
+  const double* hd_initT = nullptr;  // h_initT as the device sees it (k_gicp_init reads the initial poses over the bus)
+  PairState* hd_state = nullptr;     // h_state, h_m, the call's last look at the counters (h_ndone's tail) as the device sees them:
+  int *hd_m = nullptr, *hd_last = nullptr;  // k_gicp_publish writes the call's results there (one launch instead of three copies)
   int last_B = 0;
   // streaming (gfs_gicp_align_next*): slot parity that holds the preprocessed SOURCE clouds of the last call, and what they
   // were preprocessed with
@@ -3573,14 +3622,17 @@ int gfs_gicp_create(int device, int max_points, int max_batch, gfs_gicp** out) {
   A(h->d_tgt_index.alloc(2 * B * P));
   A(h->d_partial.alloc(B * h->nblk * kLinWaves * kRed));
   A(h->d_epartial.alloc(B * h->nblk * kLinWaves));
-  A(h->d_initT.alloc(B * 16));
   A(h->d_state.alloc(B));
   A(h->h_state.alloc(B));
   A(h->h_ndone.alloc(2 * (gfs_gicp::kAheadMax + 1) + 4));  // [2 slot ..] the rounds in flight, the last three: the call's last look
   for (int k = 0; k <= gfs_gicp::kAheadMax; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_round[k], hipEventDisableTiming));
   if (const char* e = getenv("GFS_GICP_AHEAD")) h->ahead = std::max(1, std::min(gfs_gicp::kAheadMax, atoi(e)));
+  GFS_HIP(hipHostGetDevicePointer((void**)&h->hd_last, h->h_ndone.p + 2 * (gfs_gicp::kAheadMax + 1), 0));
   A(h->h_m.alloc(C2));
   A(h->h_initT.alloc(B * 16));
+  GFS_HIP(hipHostGetDevicePointer((void**)&h->hd_initT, h->h_initT.p, 0));
+  GFS_HIP(hipHostGetDevicePointer((void**)&h->hd_state, h->h_state.p, 0));
+  GFS_HIP(hipHostGetDevicePointer((void**)&h->hd_m, h->h_m.p, 0));
   A(h->d_zero.alloc(B));
 #undef A
   if (!rc) (void)hipMemset(h->d_tile_stats.p, 0, 8 * sizeof(unsigned));
@@ -3656,8 +3708,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   const int* n_odd = (const int*)(streaming ? (prm.src_slot == 1 ? dev_ns : (const void*)h->d_zero.p) : dev_ns);
   for (int b = 0; b < B; b++)
     for (int k = 0; k < 16; k++) h->h_initT.p[16 * b + k] = init_T ? init_T[16 * b + k] : (k % 5 == 0 ? 1.0 : 0.0);
-  GFS_HIP(hipMemcpyAsync(h->d_initT.p, h->h_initT.p, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, s));
-  GFS_HIP(hipMemsetAsync(h->d_ndone.p, 0, 4 * sizeof(int), s));
+  // (no upload: k_gicp_init reads the poses out of the pinned buffer -- 128 bytes a pair -- and k_voxel_keys zeroes the counters)
   const int npts = std::min(stride_pts, P);
   // The cell sort key gives the cell z 19 bits, y 20 and x (in 1 / kFine of a cell) 25: every coordinate of a voxel mean fits while
   // |coordinate| < 2^18 cells.  The voxel fields admit 10^6 leaves, which is less whenever cell >= 4 leaves (the reference's
@@ -3665,7 +3716,8 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   const double max_vox = std::min(1.0e6, (double)((1 << 18) - 2) * prm.cell * prm.inv_leaf);
   // ---- preprocess_points x 2B (registration_helper.cpp:22-34)
   GFS_LAUNCH("k_voxel_keys", k_voxel_keys, dim3(gfs::div_up(npts, 256), C2), dim3(256), 0, s, in_even, in_odd, n_even, n_odd,
-             stride_pts, P, prm.inv_leaf, max_vox, h->d_keys0.p, h->d_val0.p, h->d_counts.p, prm.only);
+             stride_pts, P, prm.inv_leaf, max_vox, h->d_keys0.p, h->d_val0.p, h->d_counts.p, prm.only, h->d_ndone.p, h->d_nheap.p,
+             h->d_nactive.p);
   if (h->stable_voxel_order) {
     GFS_LAUNCH("k_radix_sort", k_radix_sort, dim3(C2), dim3(1024), 0, s, h->d_keys0.p, h->d_keys1.p, h->d_val0.p, h->d_val1.p,
                h->d_counts.p, P, h->d_which.p, h->d_kinfo1.p, prm.only, kCoordBits, 2 * kCoordBits);
@@ -3673,7 +3725,6 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     // the reference's (unstable) quick_sort_omp permutation, reproduced exactly: util/sort_omp.hpp:58-85
     const int leaf_parts = std::max(1, std::min(64, P / 1024));  // x 4 waves: a wave per leaf for nearly every cloud (the longest leaf sets the time)
     int rc_leaf = 0;
-    GFS_HIP(hipMemsetAsync(h->d_nheap.p, 0, (size_t)C2 * sizeof(int), s));
     GFS_HIP(voxel_qsort_top(h, C2, s, prm.only, optimistic_sort ? h->d_ndone.p + 1 : nullptr));
     // (GFS_GICP_VOXEL_TIES=exact: the reference's permutation even where it cannot change a voxel mean)
     static const bool exact_ties = getenv("GFS_GICP_VOXEL_TIES") && strcmp(getenv("GFS_GICP_VOXEL_TIES"), "exact") == 0;
@@ -3721,7 +3772,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
                h->d_ubegin.p, h->d_nucell.p, h->d_m.p, h->d_bbox.p, h->d_grid.p, h->d_ginfo.p, h->d_hard.p, h->d_hard_d.p,
                h->d_far2.p, far2_chunks, B, P, prm, h->d_cov6.p);
   // ---- LevenbergMarquardtOptimizer::optimize: device state machine, host polls the done counter
-  GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->d_initT.p, B,
+  GFS_LAUNCH("k_gicp_init", k_gicp_init, dim3(gfs::div_up(B, 64)), dim3(64), 0, s, h->d_state.p, h->hd_initT, B,
              prm.max_iterations, h->d_ndone.p, h->d_sync.p);
   if (!h->lm_rounds) {
     // the whole Levenberg-Marquardt loop of a pair in one workgroup (k_gicp_lm): one launch, no host poll
@@ -3731,7 +3782,6 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     const int nblk_run = gfs::div_up(npts, kLinBlock);
     const int max_rounds = std::max(1, prm.max_iterations) * 11 + 2;
     const size_t buf_stride = (size_t)h->Bmax * P;  // elements between a pair's two (tgt_index, maha6 / 6) buffers
-    GFS_HIP(hipMemsetAsync(h->d_nactive.p, 0, 4 * sizeof(int), s));
     int known_done = 0;  // pairs known to be done: the count polled one round behind
     // k_gicp_lm_coop takes the loop of `n_ub` pairs (an upper bound of those still iterating; the exact list, if any, is on the
     // device) off the host: the rest of the loop is ONE launch.  Its workgroups wait for each other, so they come out of the
@@ -3831,11 +3881,10 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
       }
     }
   }
-  GFS_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, (size_t)B * sizeof(PairState), hipMemcpyDeviceToHost, s));
-  GFS_HIP(hipMemcpyAsync(h->h_m.p, h->d_m.p, (size_t)C2 * sizeof(int), hipMemcpyDeviceToHost, s));
   int* const last_look = h->h_ndone.p + 2 * (gfs_gicp::kAheadMax + 1);  // {pairs done, clouds the LDS sorts left, workgroups that gave up waiting}
   last_look[0] = last_look[1] = last_look[2] = 0;
-  GFS_HIP(hipMemcpyAsync(last_look, h->d_ndone.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GFS_LAUNCH("k_gicp_publish", k_gicp_publish, dim3(std::max(1, std::min(16, gfs::div_up(B * kStateWords, 256)))), dim3(256), 0, s, h->d_state.p,
+             h->d_m.p, h->d_ndone.p, B, reinterpret_cast<u64*>(h->hd_state), h->hd_m, h->hd_last);
   const hipError_t rc_sync = hipStreamSynchronize(s);
   CoopBudget::release(h->device, h->coop_reserved);  // (whatever happened: the kernel is not running any more)
   h->coop_reserved = 0;
