@@ -2,6 +2,7 @@
 #include "orb_host.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -118,7 +119,7 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
     // ComputePyramid, src/ORBextractor.cc:1228-1231
     L.cols = cv_round_f((float)cols * p.inv_scale[l]);
     L.rows = cv_round_f((float)rows * p.inv_scale[l]);
-    L.pitch = (int)((L.cols + 63) / 64 * 64);
+    L.pitch = (int)((L.cols + 127) / 128 * 128);  // whole 128-byte lines a row (round 6: two 64-pixel blur tiles share a line exactly)
     L.plane_off = (unsigned)pyr;
     if (l > 0) pyr += (size_t)L.pitch * L.rows;
     L.blur_off = (unsigned)blur;
@@ -202,6 +203,57 @@ void OrbGeometry::build(const OrbParams& p, int rows_, int cols_) {
     kp_cap += L.kp_cap;
     for (int ty = 0; ty < (L.rows + 31) / 32; ty++)  // 64 x 32 tiles (k_blur7)
       for (int tx = 0; tx < (L.cols + 63) / 64; tx++) blur_tiles.push_back(BlurTileDev{(short)l, (short)tx, (short)ty, 0, L.rows, L.cols, L.pitch, L.plane_off, L.blur_off, 0u});
+  }
+  {
+    // Order of k_blur7's workgroups (round 6).  MI355X hands workgroup i to XCD i % 8, and every XCD has its own L2.  The two 64-pixel
+    // tiles over one 128-byte line of every row (tx = 2 k, 2 k + 1) and the two tile rows that share a 6-row halo (ty = 2 m, 2 m + 1)
+    // form a block of four that goes to positions p, p + 8, p + 16, p + 24 of the list: ONE XCD's L2 serves all four -- in the natural
+    // order every line crossed the fabric twice and the halo rows once more, FETCH_SIZE 2.4 x the pixels (profiles r05e).  A whole
+    // frame's list shifts by the same amount from frame to frame, so the grouping holds for every frame of a batch.
+    auto at = [&](int l, int tx, int ty) -> const BlurTileDev* {
+      for (const BlurTileDev& t : blur_tiles)
+        if (t.level == l && t.tx == tx && t.ty == ty) return &t;
+      return nullptr;
+    };
+    std::vector<std::array<BlurTileDev, 4>> quads;
+    std::vector<std::array<BlurTileDev, 2>> pairs;
+    std::vector<BlurTileDev> single;
+    for (const BlurTileDev& t : blur_tiles) {
+      if ((t.tx & 1) || (t.ty & 1)) {
+        // an odd tile belongs to the even tile left of / above it when that one exists (it always does), else it is on its own
+        continue;
+      }
+      const BlurTileDev *r = at(t.level, t.tx + 1, t.ty), *d = at(t.level, t.tx, t.ty + 1), *rd = at(t.level, t.tx + 1, t.ty + 1);
+      if (r && d && rd) {
+        quads.push_back({t, *r, *d, *rd});
+      } else if (r) {
+        pairs.push_back({t, *r});
+        if (d) single.push_back(*d);
+      } else if (d) {
+        pairs.push_back({t, *d});
+      } else {
+        single.push_back(t);
+      }
+    }
+    std::vector<BlurTileDev> out;
+    out.reserve(blur_tiles.size());
+    size_t g = 0;
+    for (; g + 8 <= quads.size(); g += 8)
+      for (int k = 0; k < 4; k++)
+        for (size_t i = 0; i < 8; i++) out.push_back(quads[g + i][k]);
+    for (; g < quads.size(); g++) {  // (fewer than eight blocks left: as two pairs)
+      pairs.push_back({quads[g][0], quads[g][1]});
+      pairs.push_back({quads[g][2], quads[g][3]});
+    }
+    for (g = 0; g + 8 <= pairs.size(); g += 8)
+      for (int k = 0; k < 2; k++)
+        for (size_t i = 0; i < 8; i++) out.push_back(pairs[g + i][k]);
+    for (; g < pairs.size(); g++) {
+      out.push_back(pairs[g][0]);
+      out.push_back(pairs[g][1]);
+    }
+    out.insert(out.end(), single.begin(), single.end());
+    if (out.size() == blur_tiles.size()) blur_tiles.swap(out);  // (every tile exactly once; else keep the natural order)
   }
   if (cols >= 4096 || rows >= 4096) {
     supported = false;
