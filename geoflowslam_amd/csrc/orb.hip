@@ -1853,7 +1853,17 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
                                                       const KpIn* __restrict__ kpin, const int* __restrict__ kp_count,
                                                       int kp_cap, const int* __restrict__ umax,
                                                       const int8_t* __restrict__ pattern, gfs_keypoint* __restrict__ kps,
-                                                      uint8_t* __restrict__ desc) {
+                                                      uint8_t* __restrict__ desc, int xcd_frames, int nchunks) {
+  // (chunk of key points, frame) of this workgroup.  xcd_frames > 0 (a batch of at least eight frames, 1-D grid): all workgroups
+  // of a frame run on ONE XCD -- MI355X hands workgroup i to XCD i % 8 -- so that the frame's two pyramids are read into one L2
+  // instead of into all eight (round 6: FETCH_SIZE 2.4 x what the key points' windows cover before)
+  int wg_chunk = blockIdx.x, wg_frame = blockIdx.y;
+  if (xcd_frames > 0) {
+    const int id = blockIdx.x, slot = id >> 3;
+    wg_frame = (slot / nchunks) * 8 + (id & 7);
+    wg_chunk = slot % nchunks;
+    if (wg_frame >= xcd_frames) return;
+  }
   __shared__ uint2 s_w[31 * 8];  // (W, M) of word j of disc row r
   __shared__ uint32_t s_patch[kObPerWg][kObRows * kObRowWords];
   if (threadIdx.x < 31 * 8) {
@@ -1873,9 +1883,9 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
   // Sixteen lanes per key point, four key points per wave: the per-key-point scalar work (fastAtan2, glibc's sincosf) is done for four
   // of them at once instead of on 64 lanes for one; the pixel sums and the 256 tests are the same work either way.
   const int sl = threadIdx.x & (kObGroup - 1);
-  const int b = blockIdx.y, n_kp = kp_count[b];
-  const int k_raw = blockIdx.x * kObPerWg + (threadIdx.x / kObGroup);
-  if ((int)(blockIdx.x * kObPerWg + (threadIdx.x >> 6) * (64 / kObGroup)) >= n_kp) return;  // the wave's first key point: wave-uniform
+  const int b = wg_frame, n_kp = kp_count[b];
+  const int k_raw = wg_chunk * kObPerWg + (threadIdx.x / kObGroup);
+  if ((int)(wg_chunk * kObPerWg + (threadIdx.x >> 6) * (64 / kObGroup)) >= n_kp) return;  // the wave's first key point: wave-uniform
   const bool live = k_raw < n_kp;
   const int k = live ? k_raw : n_kp - 1;  // a group past the end repeats the last key point and stores nothing
   const KpIn in = kpin[(size_t)b * kp_cap + k];
@@ -2188,9 +2198,14 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
                h->d_kept_off.p, h->cap_kp, lap0, lap1, h->d_kpin.p, h->d_kp_count.p, h->d_mono.p);
     GFS_LAUNCH("k_blur7", k_blur7, dim3((unsigned)G.blur_tiles.size(), B), dim3(256), 0, s, h->d_levels.p, h->d_tiles.p, l0,
                h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, tp[0], tp[1], tp[2], tp[3]);
-    GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(h->cap_kp, kObPerWg), B), dim3(256), 0, s, h->d_levels.p, l0,
-               h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_umax.p,
-               h->d_pattern.p, h->d_kps.p, h->d_desc.p);
+    {
+      static const bool ob_xcd = !(getenv("GFS_ORB_OB_XCD") && atoi(getenv("GFS_ORB_OB_XCD")) == 0);
+      const int nch = gfs::div_up(h->cap_kp, kObPerWg);
+      const bool by_xcd = ob_xcd && B >= 8;  // (fewer frames than XCDs: a frame's key points over the whole chip)
+      GFS_LAUNCH("k_orient_brief", k_orient_brief, by_xcd ? dim3((unsigned)(gfs::div_up(B, 8) * 8 * nch)) : dim3(nch, B), dim3(256), 0, s,
+                 h->d_levels.p, l0, h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_umax.p,
+                 h->d_pattern.p, h->d_kps.p, h->d_desc.p, by_xcd ? B : 0, nch);
+    }
     h->last_B = B;
     h->last_l0 = l0;
     h->host_counts_valid = false;
@@ -2263,7 +2278,7 @@ int run_batch(gfs_orb* h, Lvl0 l0, int B, int rows, int cols, int lap0, int lap1
     // 6. orientation + descriptors
     GFS_LAUNCH("k_orient_brief", k_orient_brief, dim3(gfs::div_up(max_n, kObPerWg), B), dim3(256), 0, s, h->d_levels.p, l0,
                h->d_pyr.p, cap_pyr, h->d_blur.p, cap_blur, h->d_kpin.p, h->d_kp_count.p, h->cap_kp, h->d_umax.p,
-               h->d_pattern.p, h->d_kps.p, h->d_desc.p);
+               h->d_pattern.p, h->d_kps.p, h->d_desc.p, 0, 0);
   }
   h->last_B = B;
   h->last_l0 = l0;
