@@ -3414,6 +3414,8 @@ struct gfs_gicp {
   gfs::DevBuf<unsigned> d_tile_stats;  // [8] outcome counters of k_gicp_linearize's tile staging (gfs_gicp_tile_stats)
   bool vqs_lds = true;  // GFS_GICP_VQS_LDS=0: without k_voxel_qsort_top_lds
   bool sort_all_kernels = false;  // set for the second run of a call whose first run found a cloud the LDS sort kernel could not take
+  int sort_all_hold = 0;  // ... and the next calls launch every sort kernel at once instead of finding out again (a stream of wide scenes
+                          // would pay every call twice); counted down, then the optimistic launch is tried again
   bool stable_voxel_order = false;  // GFS_GICP_VOXEL_ORDER=stable: the round-1 stable radix order instead of the reference's
   gfs::DevBuf<double4> d_tmp, d_pts;
   gfs::DevBuf<double> d_cov6, d_maha6, d_partial, d_epartial;
@@ -3669,7 +3671,8 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const int P = h->P, C2 = 2 * B;
   // (the round loop below looks at the count the LDS sort kernel leaves; the persistent LM kernel has no such look)
-  const bool optimistic_sort = h->lm_rounds && !h->sort_all_kernels;
+  const bool optimistic_sort = h->lm_rounds && !h->sort_all_kernels && h->sort_all_hold == 0;
+  if (h->sort_all_hold > 0 && !h->sort_all_kernels) h->sort_all_hold--;
   GicpParams prm;
   prm.inv_leaf = 1.0 / cfg->downsampling_resolution;
   // cell edge = max correspondence distance: one ring of cells certifies every 1-NN probe and (for voxel-sized
@@ -3874,6 +3877,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
           h->sort_all_kernels = true;
           const int rc_again = gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
           h->sort_all_kernels = false;
+          h->sort_all_hold = 64;
           return rc_again;
         }
         known_done = h->h_ndone.p[2 * pslot];
@@ -3899,6 +3903,7 @@ static int gicp_run(gfs_gicp* h, const void* dev_target, const void* dev_nt, con
     h->sort_all_kernels = true;
     const int rc_again = gicp_run(h, dev_target, dev_nt, dev_source, dev_ns, B, stride_pts, init_T, cfg, out, stream, streaming);
     h->sort_all_kernels = false;
+    h->sort_all_hold = 64;
     return rc_again;
   }
   for (int b = 0; b < B; b++) {
