@@ -181,6 +181,7 @@ ABI_SYMBOLS = [
     "gfs_orb_extract", "gfs_orb_extract_batch", "gfs_orb_extract_batch_device", "gfs_orb_device_results",
     "gfs_orb_fetch", "gfs_orb_level_size", "gfs_orb_fetch_level", "gfs_orb_fetch_candidates", "gfs_orb_octree_host",
     "gfs_orb_octree_device", "gfs_test_sort_replica", "gfs_test_heap_sort_replica", "gfs_test_glibc_math", "gfs_test_traffic",
+    "gfs_test_orb_blur_tiles",
     "gfs_hamming256", "gfs_matcher_create", "gfs_matcher_destroy", "gfs_bf_match_hamming",
     "gfs_bf_match_hamming_batch_device",
     "gfs_gicp_default_config", "gfs_gicp_create", "gfs_gicp_destroy", "gfs_gicp_align", "gfs_gicp_align_batch_device",

@@ -571,6 +571,22 @@ void distribute_octree(const uint32_t* c, int n, int min_x, int max_x, int min_y
 
 }  // namespace gfs
 
+// ---- test hook: the launch order of k_blur7's tiles (OrbGeometry::build), host only ----
+extern "C" int gfs_test_orb_blur_tiles(int rows, int cols, int nlevels, float scale_factor, int32_t* level_tx_ty, int cap) {
+  gfs::OrbParams P;
+  P.init(1000, scale_factor, nlevels, 20, 7, 1);
+  gfs::OrbGeometry G;
+  G.build(P, rows, cols);
+  if (!G.supported) return -1;
+  const int n = (int)G.blur_tiles.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    level_tx_ty[3 * i] = G.blur_tiles[i].level;
+    level_tx_ty[3 * i + 1] = G.blur_tiles[i].tx;
+    level_tx_ty[3 * i + 2] = G.blur_tiles[i].ty;
+  }
+  return n;
+}
+
 // ---- test hook: the std::sort replica used by the device quadtree, run on the host against caller data ----
 #include "std_sort_replica.hpp"
 extern "C" int gfs_test_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n) {

@@ -15,6 +15,11 @@ extern "C" {
 int gfs_test_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
 int gfs_test_heap_sort_replica(int32_t* size_key, int32_t* x_key, int32_t* payload, int n);
 
+/* Host test hook: the order in which k_blur7 takes the 64 x 32 tiles of a frame's pyramid (rows x cols, nlevels levels at
+ * scale_factor): level_tx_ty[3 i ..] = (level, tile column, tile row) of list position i, at most cap entries; returns the number of
+ * tiles.  The 2 x 2 tiles over the same 128-byte lines sit at positions p, p + 8, p + 16, p + 24 (one XCD's L2 serves them). */
+int gfs_test_orb_blur_tiles(int rows, int cols, int nlevels, float scale_factor, int32_t* level_tx_ty, int cap);
+
 /* GPU test hook: sin(x), cos(x), pow(x, 3.0) of n doubles evaluated on the device with the restated glibc 2.35 arithmetic
  * (csrc/glibc_math.hpp) that the pose / window / registration optimizers use for SE3Quat::exp
  * (Thirdparty/g2o/g2o/types/se3quat.h:223-257) and the Levenberg step control (core/optimization_algorithm_levenberg.cpp:127). */

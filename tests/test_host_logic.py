@@ -71,6 +71,44 @@ def test_std_sort_replica_matches_libstdcxx(api, oracle):
         assert _sort_pair(P.gfs_test_heap_sort_replica, O.gfso_std_partial_sort_pairs, s, x)
 
 
+def test_blur_tile_order_groups_the_tiles_over_one_line_on_one_xcd(api):
+    """k_blur7's launch order (OrbGeometry::build, round 6): every 64 x 32 tile of every level exactly once; MI355X hands workgroup i
+    to XCD i % 8, so the 2 x 2 tiles over the same 128-byte lines and halo rows -- (2k, 2m), (2k + 1, 2m), (2k, 2m + 1), (2k + 1, 2m + 1) --
+    must sit at positions p, p + 8, p + 16, p + 24, pairs at p, p + 8; only a tail of fewer than eight groups may be left unaligned."""
+    import ctypes as C
+    L = api.lib()
+    L.gfs_test_orb_blur_tiles.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+    L.gfs_test_orb_blur_tiles.restype = C.c_int
+    for rows, cols, nl, sf in ((480, 640, 8, 1.2), (720, 1280, 8, 1.2), (240, 320, 6, 1.2), (203, 517, 3, 1.5), (128, 160, 2, 1.2)):
+        out = np.zeros((8192, 3), np.int32)
+        n = L.gfs_test_orb_blur_tiles(rows, cols, nl, sf, out.ctypes.data_as(C.c_void_p), len(out))
+        assert 0 < n <= len(out)
+        tiles = [tuple(int(v) for v in t) for t in out[:n]]
+        # exactly the tiles of every level (cvRound(size / scale) as ComputePyramid sizes the levels)
+        want = set()
+        for l in range(nl):
+            inv = np.float32(1.0) / np.float32(sf) ** l if l else np.float32(1.0)
+            lc, lr = int(np.rint(np.float32(cols) * np.float32(1.0 / float(np.float32(sf) ** l)))), int(np.rint(np.float32(rows) * np.float32(1.0 / float(np.float32(sf) ** l))))
+            want |= {(l, tx, ty) for ty in range((lr + 31) // 32) for tx in range((lc + 63) // 64)}
+        assert len(tiles) == len(set(tiles)) == n and len(set(t[0] for t in tiles)) == nl
+        assert abs(len(want) - n) <= 2 * nl, (len(want), n)  # (level sizes: this test's rounding may differ from cvRound by a pixel)
+        pos = {t: i for i, t in enumerate(tiles)}
+        grouped = loose = 0
+        for (l, tx, ty), p in pos.items():
+            if tx % 2 or ty % 2:
+                continue
+            block = [t for t in ((l, tx + 1, ty), (l, tx, ty + 1), (l, tx + 1, ty + 1)) if t in pos]
+            same_xcd = all(pos[t] % 8 == p % 8 for t in block)
+            tight = all(0 < pos[t] - p <= 24 and (pos[t] - p) % 8 == 0 for t in block)
+            if block:
+                grouped += int(same_xcd and tight)
+                loose += int(not (same_xcd and tight))
+        assert loose <= 14, (rows, cols, loose)  # the tails: fewer than eight blocks, then fewer than eight pairs
+        assert grouped >= 1 or n < 8, (rows, cols, grouped)
+        if n >= 64:
+            assert grouped >= 0.8 * (grouped + loose), (rows, cols, grouped, loose)
+
+
 def test_reference_dropins_compile():
     """geoflowslam_amd/host/gfs_reference_dropins.hpp -- the code INTEGRATION.md tells a maintainer to add to the reference tree --
     goes through a compiler: against the reference's real include/ORBextractor.h and small_gicp registration_result.hpp when
