@@ -102,6 +102,78 @@ def select_committed_traffic(profiles_dir, kernel, launches_per_step, batch_pair
         return dict(none, note=f"traffic unavailable: {type(e).__name__}: {e}")
 
 
+def measure_traffic_live(kernel, batch_pairs, nlanes, timeout_s, alg_bytes_per_launch=None):
+    """`roofline.traffic` measured by THIS run: FETCH_SIZE and WRITE_SIZE of `kernel`, per launch, from two child runs of this script
+    under rocprofv3 (one counter a pass: they do not fit one, and no trace domain beside them).  Same batch size and lane shape as the
+    timed run, one warm-up + one timed step + the two profiling steps, 64 distinct scenes tiled over the batch (a child renders its own).
+    (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024, as select_committed_traffic() forms it.  The child's scenes converge after other numbers of
+    iterations than the parent's 512 (fewer, larger launches), so the figure is carried over per ALGORITHMIC byte: the child's counter
+    bytes per step over the algorithmic bytes per step of ITS OWN roofline object, times the parent's algorithmic bytes per launch.
+    Never raises; a child is killed with its process group when it outlives its share of timeout_s."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    out = dict(traffic=None, traffic_raw_counters=None, source=None)
+    try:
+        rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+        if not rp:
+            return dict(out, note="rocprofv3 not found")
+        kb, launches, child_alg_step = {}, {}, None
+        child_steps = 1 + 1 + 2  # warm-up + timed + the roofline leg's two profiling steps: every one the same pass over the batch
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix=f"gfs_pmc_{counter}_", dir="/tmp")
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GFS_BENCH_CHILD")}
+            env.update(TMPDIR="/tmp", GFS_BENCH_NO_SUPERVISOR="1", GFS_BENCH_LIVE_TRAFFIC="0")
+            # (only the roofline's kernel is instrumented: every other dispatch runs at full speed)
+            cmd = [rp, "--pmc", counter, "--kernel-include-regex", kernel, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1",
+                   "--warmup", "1", "--batch", str(batch_pairs), "--lanes", str(nlanes), "--distinct", "64", "--no-cpu-baseline", "--no-extras",
+                   "--no-klt", "--verify", "0", "--prime", "0"]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True, text=True)
+            try:
+                child_out, _ = p.communicate(timeout=timeout_s / 2)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except Exception:
+                    p.kill()
+                p.wait()
+                shutil.rmtree(d, ignore_errors=True)
+                return dict(out, note=f"the {counter} pass did not finish in {timeout_s / 2:.0f} s (killed)")
+            try:  # the child's own line: algorithmic bytes of the kernel per step of ITS batch
+                cr = json.loads([ln_ for ln_ in child_out.splitlines() if ln_.startswith("{")][-1])["roofline"]
+                if cr["kernel"] == kernel:
+                    child_alg_step = float(cr["algorithmic_bytes_per_launch"]) * float(cr["launches_per_step"])
+            except Exception:
+                pass
+            tot, ids = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        tot += float(r["Counter_Value"])
+                        ids.add(r["Dispatch_Id"])
+            shutil.rmtree(d, ignore_errors=True)
+            if not ids:
+                return dict(out, note=f"the {counter} pass (rc {p.returncode}) left no rows for {kernel}")
+            kb[counter], launches[counter] = tot, len(ids)
+        f_l, w_l = kb["FETCH_SIZE"] / launches["FETCH_SIZE"], kb["WRITE_SIZE"] / launches["WRITE_SIZE"]
+        res = dict(fetch_kb_per_launch_child=round(f_l, 1), write_kb_per_launch_child=round(w_l, 1), launches_counted=launches["FETCH_SIZE"],
+                   child_launches_per_step=launches["FETCH_SIZE"] / child_steps)
+        if child_alg_step and alg_bytes_per_launch:
+            up_step = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024 / child_steps
+            raw_step = (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024 / child_steps
+            res.update(traffic=int(up_step / child_alg_step * alg_bytes_per_launch), traffic_raw_counters=int(raw_step / child_alg_step * alg_bytes_per_launch),
+                       traffic_per_algorithmic_byte=round(up_step / child_alg_step, 4), raw_counters_per_algorithmic_byte=round(raw_step / child_alg_step, 4),
+                       scaled="per algorithmic byte: the child's counter bytes per step / its algorithmic bytes per step x this run's algorithmic bytes per launch")
+        else:  # (no usable line of the child: its own launches as they are)
+            res.update(traffic=int((2.0 * f_l + w_l) * 1024), traffic_raw_counters=int((f_l + w_l) * 1024), scaled="per launch of the child run")
+        return dict(res,
+                    source=f"measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on {kernel} (two child runs of bench.py after the timed "
+                           f"region, batch {batch_pairs}, {nlanes} lanes, 64 distinct scenes tiled), 2 x FETCH_SIZE + WRITE_SIZE",
+                    note="the factor 2 is the measured under-count of streaming reads (profiles/r03_calibration.json) and over-counts the share of "
+                         "cache-missing gathers: an upper bound of the HBM-side bytes")
+    except Exception as e:
+        return dict(out, note=f"live traffic unavailable: {type(e).__name__}: {e}")
+
+
 def supervise(argv, deadline_s):
     """N = 1 only: run the bench in a CHILD process that prints the JSON line again after every side leg, keep the newest one and
     print exactly ONE line.  A side leg that crashes the process (GPU fault, segfault in a library) or hangs past the deadline then
@@ -247,6 +319,8 @@ def main():
     ap.add_argument("--leg-budget-s", type=float, default=420.0,
                     help="side legs (everything after roofline + cpu_baseline) are skipped once the run is this old: the line must reach the driver")
     ap.add_argument("--deadline-s", type=float, default=1500.0, help="N = 1: the supervising parent stops a hung child after this long and prints the newest line")
+    ap.add_argument("--live-traffic-timeout-s", type=float, default=300.0,
+                    help="both rocprofv3 --pmc child runs of the roofline.traffic leg together (GFS_BENCH_LIVE_TRAFFIC=0 skips the leg)")
     ap.add_argument("--no-supervisor", action="store_true", help="N = 1: run in this process (no child), side legs guarded by try/except only")
     args = ap.parse_args()
     t_start = time.perf_counter()
@@ -1196,6 +1270,22 @@ def main():
                 del ln.dd0, ln.dd1, ln.gg, ln.cc0, ln.cc1
         except Exception as e:
             h2d = dict(error=f"{type(e).__name__}: {e}")
+    # ---- HBM-side traffic of the roofline's kernel, MEASURED BY THIS RUN: two child runs of this script (one step of the same batch and
+    #      lane shape, 64 distinct scenes tiled) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- counters in their own passes,
+    #      no trace domains (MI355X_MICROARCH.md).  The last leg: whatever happens here costs nothing that was measured before.
+    if (rank == 0 and world == 1 and not args.no_extras and args.workload == "c2" and isinstance(roofline, dict) and roofline.get("kernel")
+            and os.environ.get("GFS_BENCH_LIVE_TRAFFIC", "1") != "0" and not over_budget("traffic_live")):
+        try:
+            live = measure_traffic_live(roofline["kernel"], B, nlanes, args.live_traffic_timeout_s, roofline.get("algorithmic_bytes_per_launch"))
+            roofline["traffic_live"] = live
+            if live.get("traffic") is not None:
+                roofline["traffic_committed"] = dict(traffic=roofline.get("traffic"), traffic_raw_counters=roofline.get("traffic_raw_counters"),
+                                                     source=roofline.get("traffic_source"))
+                roofline["traffic"], roofline["traffic_raw_counters"] = live["traffic"], live["traffic_raw_counters"]
+                roofline["traffic_source"] = live["source"]
+                roofline["traffic_is_upper_bound"] = True
+        except Exception as e:
+            roofline["traffic_live"] = dict(error=f"{type(e).__name__}: {e}")
     emit(final=True)
     if world > 1:
         dist.destroy_process_group()
