@@ -30,6 +30,7 @@
 namespace {
 
 constexpr int kThreads = 1024;
+constexpr int kFlagInts = 8;  // one slot of gfs_lba::h_flags: 4 ints + 2 doubles
 constexpr int kMaxFreeLds = 30;  // up to this many free poses the reduced system (180 x 180 packed) is factored in LDS
 
 // LM bookkeeping of the multi-kernel path, resident in HBM (the scalar logic of OptimizationAlgorithmLevenberg::solve)
@@ -41,6 +42,8 @@ struct LbaState {
   int again, terminate;          // outputs of k_lba_decide for the host loop
   int err_at_cur;                // chi2 / err / part_chi already hold the accepted estimate's values (the accepted trial computed them)
   int phase, it;                 // batched entry: 0 = build next, 1 = trial next, 2 = done; index of the running LM iteration
+  int spec_ok, pad_;             // k_lba_decide: the trial was accepted and the loop goes on -- the build group of the NEXT iteration, queued
+                                 // behind it speculatively by gfs_lba_solve's host loop (gate = 1), may run (round 6)
 };
 
 // The descriptor's pointers carry the GLOBAL address space in device code: the batched kernels read their descriptor from an array
@@ -591,6 +594,7 @@ __device__ __forceinline__ void b_init(const LbaDev& D, const int bx, const int 
     S.again = S.terminate = 0;
     S.phase = S.it = 0;
     S.err_at_cur = 0;
+    S.spec_ok = S.pad_ = 0;
   }
 }
 __global__ __launch_bounds__(kMk) void k_lba_init(LbaDev D) { b_init(D, blockIdx.x, gridDim.x); }
@@ -623,7 +627,12 @@ __device__ __forceinline__ void b_errors(const LbaDev& D, const int bx, const in
   const double tot = block_sum256(local, s4);
   if (threadIdx.x == 0) D.part_chi[bx] = tot;
 }
-__global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial) { b_errors(D, blockIdx.x, gridDim.x, trial); }
+// gate = 1 (k_lba_errors / build_landmarks / build_poses / begin): a launch queued speculatively behind k_lba_decide -- it runs only if that
+// trial was accepted and the loop goes on (LbaState::spec_ok); uniform per launch, in front of every barrier
+__global__ __launch_bounds__(kMk) void k_lba_errors(LbaDev D, int trial, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_errors(D, blockIdx.x, gridDim.x, trial);
+}
 
 
 // buildSystem, landmark side: Hll, bl and the per-edge pose-landmark blocks.  16 lanes per landmark (its edges over the
@@ -699,7 +708,10 @@ __device__ __forceinline__ void b_build_landmarks(const LbaDev& D, const int bx,
     }
   }
 }
-__global__ __launch_bounds__(kMk) void k_lba_build_landmarks(LbaDev D) { b_build_landmarks(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kMk) void k_lba_build_landmarks(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_build_landmarks(D, blockIdx.x, gridDim.x);
+}
 
 
 // buildSystem, pose side: one workgroup per free pose, threads over its edges, fixed-order reduction
@@ -738,7 +750,10 @@ __device__ __forceinline__ void b_build_poses(const LbaDev& D, const int bx, con
   else if (threadIdx.x < 27)
     D.bp[6 * f + (threadIdx.x - 21)] = v;
 }
-__global__ __launch_bounds__(kPoseWg) void k_lba_build_poses(LbaDev D) { b_build_poses(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kPoseWg) void k_lba_build_poses(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_build_poses(D, blockIdx.x, gridDim.x);
+}
 
 
 // start of an LM iteration: currentChi, and at iteration 0 computeLambdaInit (tau * max |diag H|)
@@ -772,14 +787,20 @@ __device__ __forceinline__ void b_begin(const LbaDev& D, const int bx, const int
     S.again = 0;
   }
 }
-__global__ __launch_bounds__(kThreads) void k_lba_begin(LbaDev D, int iteration) { b_begin(D, blockIdx.x, gridDim.x, iteration); }
+__global__ __launch_bounds__(kThreads) void k_lba_begin(LbaDev D, int iteration, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_begin(D, blockIdx.x, gridDim.x, iteration);
+}
 
 
 __device__ __forceinline__ void b_dinv(const LbaDev& D, const int bx, const int gdx) {
   const int l = bx * kMk + threadIdx.x;
   if (l < D.n_points) inv3_sym(D.Hll + 6 * (size_t)l, D.S->lambda, D.Dinv + 6 * (size_t)l);
 }
-__global__ __launch_bounds__(kMk) void k_lba_dinv(LbaDev D) { b_dinv(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kMk) void k_lba_dinv(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_dinv(D, blockIdx.x, gridDim.x);
+}
 
 
 // Schur complement, one workgroup per pose pair (i1 >= i2): Hs(i1,i2) = [i1==i2](Hpp + lambda I) - sum_l B_i1 Dinv_l B_i2^T
@@ -847,7 +868,10 @@ __device__ __forceinline__ void b_schur(const LbaDev& D, const int bx, const int
   if (tk < 4) store_h(32 + tk, v1);
   if (i1 == i2 && tk >= 4 && tk < 10) D.bs[6 * i1 + (tk - 4)] = D.bp[6 * i1 + (tk - 4)] - v1;
 }
-__global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D) { b_schur(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kMk) void k_lba_schur(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_schur(D, blockIdx.x, gridDim.x);
+}
 
 // The same products taken landmark by landmark.  b_schur gives a workgroup to a pose pair, and every pair re-reads the 6x3
 // blocks of its two poses for each common landmark: Hpl is read ~n_free times (L2 traffic, 0.8 MB per pair).  Here a workgroup
@@ -942,7 +966,10 @@ __device__ __forceinline__ void b_schur_chunks(const LbaDev& D, const int bx) {
     }
   }
 }
-__global__ __launch_bounds__(kMk) void k_lba_schur_chunks(LbaDev D) { b_schur_chunks(D, blockIdx.x); }
+__global__ __launch_bounds__(kMk) void k_lba_schur_chunks(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_schur_chunks(D, blockIdx.x);
+}
 
 // ---- the same sum on the matrix cores.  With W_l (6F x 3: the blocks B_f of landmark l stacked, zero where pose f does not see
 // it) the Schur sum over landmarks is  S = sum_l (W_l Dinv_l) W_l^T = [WD_1 WD_2 ...] [W_1 W_2 ...]^T : one (6F x 3L)(3L x 6F)
@@ -1119,7 +1146,8 @@ __device__ __forceinline__ void b_schur_mfma(const LbaDev& D, const int bx) {
   }
 }
 template <bool kOneBlock>
-__global__ __launch_bounds__(kMk, kOneBlock ? 2 : 1) void k_lba_schur_mfma(LbaDev D) {
+__global__ __launch_bounds__(kMk, kOneBlock ? 2 : 1) void k_lba_schur_mfma(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
   b_schur_mfma<kOneBlock>(D, blockIdx.x);
 }
 
@@ -1154,7 +1182,10 @@ __device__ __forceinline__ void b_schur_reduce_mfma(const LbaDev& D, const int b
     }
   }
 }
-__global__ __launch_bounds__(kMk) void k_lba_schur_reduce_mfma(LbaDev D) { b_schur_reduce_mfma(D, blockIdx.x); }
+__global__ __launch_bounds__(kMk) void k_lba_schur_reduce_mfma(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_schur_reduce_mfma(D, blockIdx.x);
+}
 
 // Hs = [diagonal block](Hpp + lambda I) - sum over chunks (in chunk order), bs = bp - sum: one thread per entry of the packed
 // lower triangle, then one per entry of the right-hand side
@@ -1183,7 +1214,10 @@ __device__ __forceinline__ void b_schur_reduce(const LbaDev& D, const int bx) {
     D.bs[j] = D.bp[j] - sum;
   }
 }
-__global__ __launch_bounds__(kMk) void k_lba_schur_reduce(LbaDev D) { b_schur_reduce(D, blockIdx.x); }
+__global__ __launch_bounds__(kMk) void k_lba_schur_reduce(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_schur_reduce(D, blockIdx.x);
+}
 
 
 
@@ -1456,7 +1490,8 @@ __device__ __forceinline__ void b_solve(const LbaDev& D) {
   if (threadIdx.x == 0) D.S->solve_ok = ok ? 1 : 0;
 }
 template <bool kLds>
-__global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D) {
+__global__ __launch_bounds__(kThreads) void k_lba_solve(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
   if (kLds)
     b_solve_lds(D);
   else
@@ -1528,11 +1563,15 @@ __device__ __forceinline__ void b_update(const LbaDev& D, const int bx, const in
   const double tot = block_sum256(loc, s4);
   if (threadIdx.x == 0) D.part_scale[bx] = tot;
 }
-__global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D) { b_update(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kMk) void k_lba_update(LbaDev D, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_update(D, blockIdx.x, gridDim.x);
+}
 
 
 // end of an LM trial (and, when the trial loop ends, of the iteration): rho test, lambda update, termination tests
-__device__ __forceinline__ void b_decide(const LbaDev& D, const int bx, int force_end, int* __restrict__ host_flags) {
+__device__ __forceinline__ void b_decide(const LbaDev& D, const int bx, int force_end, int* __restrict__ host_flags,
+                                         double* __restrict__ snap = nullptr) {
   if (threadIdx.x != 0 || bx != 0) return;
   LbaState& S = *D.S;
   if (!force_end) {
@@ -1578,12 +1617,33 @@ __device__ __forceinline__ void b_decide(const LbaDev& D, const int bx, int forc
       if (S.n_bad >= 3) S.terminate = 1;
     }
   }
+  S.spec_ok = (!S.again && !S.terminate && !force_end) ? 1 : 0;
   host_flags[0] = S.again;
   host_flags[1] = S.terminate;
   host_flags[2] = S.cur;
   host_flags[3] = S.iters;
+  if (snap) {  // what k_lba_finish reports if the loop ends HERE (gfs_lba_solve: an iteration running ahead of a stop flag is discarded)
+    snap[0] = S.lambda;
+    snap[1] = S.last_chi;
+  }
 }
-__global__ void k_lba_decide(LbaDev D, int force_end, int* __restrict__ host_flags) { b_decide(D, blockIdx.x, force_end, host_flags); }
+// host_out: one slot of gfs_lba::h_flags -- {again, terminate, cur, iters} and, 16 bytes on, {lambda, last_chi}
+__global__ void k_lba_decide(LbaDev D, int force_end, int* __restrict__ host_out, int gate) {
+  if (gate && !D.S->spec_ok) return;
+  b_decide(D, blockIdx.x, force_end, host_out, reinterpret_cast<double*>(host_out + 4));
+}
+// the state k_lba_decide left behind an earlier iteration, put back (an iteration that ran ahead of the caller's stop flag is discarded:
+// its trial only wrote the OTHER estimate buffer); the errors are evaluated again at that estimate by the caller
+__global__ void k_lba_restore(LbaDev D, int cur, int iters, double lambda, double last_chi) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  LbaState& S = *D.S;
+  S.cur = cur;
+  S.iters = iters;
+  S.lambda = lambda;
+  S.last_chi = last_chi;
+  S.err_at_cur = 0;
+  S.spec_ok = 0;
+}
 
 
 __device__ __forceinline__ void b_finish(const LbaDev& D, const int bx) {
@@ -1744,7 +1804,8 @@ struct gfs_lba {
   hipStream_t stream;
   std::mutex mu;
   int* h_stop = nullptr;  // host-mapped
-  int* h_flags = nullptr;  // host-mapped: {again, terminate, cur, iters} written by k_lba_decide
+  int* h_flags = nullptr;  // host-mapped, two slots of kFlagInts ints: {again, terminate, cur, iters | lambda, last_chi (doubles)} written by k_lba_decide
+  hipEvent_t ev_decide[2] = {nullptr, nullptr};  // behind decide i: event i & 1 -- the host waits for THIS, not for what is queued behind it
   LbaDev last_desc;        // the window of the last run()
   gfs::DevBuf<LbaState> d_state;
   gfs::PinBuf<unsigned char> h_stage;  // pinned staging arena for the problem upload (pageable copies cost ~2 ms each)
@@ -2069,12 +2130,12 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, StopF
   GFS_LAUNCH("k_lba_init", k_lba_init, dim3(64), dim3(kMk), 0, s, D);
   const bool lin_only = mode == 1 || p->iterations <= 0;
   if (lin_only) {
-    GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
+    GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0, 0);
     if (mode == 1) {
-      if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D);
-      if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kPoseWg), 0, s, D);
+      if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D, 0);
+      if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kPoseWg), 0, s, D, 0);
     }
-    GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, 1);
+    GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, 1, 0);
     LbaDev Df = D;
     Df.mode = 1;
     GFS_LAUNCH("k_lba_finish", k_lba_finish, dim3(1), dim3(64), 0, s, Df);
@@ -2082,46 +2143,107 @@ int run(gfs_lba* h, const gfs_lba_problem* p, const HostPrep& P, int mode, StopF
     return GFS_OK;
   }
   const int npairs = P.n_free * (P.n_free + 1) / 2;
-  for (int iteration = 0; iteration < p->iterations; iteration++) {
-    if (stop && *stop) break;  // SparseOptimizer::terminate() at the top of the iteration
-    GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0);
-    if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D);
-    if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kPoseWg), 0, s, D);
-    GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, iteration);
-    bool terminate = false;
-    for (;;) {
-      GFS_LAUNCH("k_lba_dinv", k_lba_dinv, g_upd, dim3(kMk), 0, s, D);
-      if (npairs > 0 && D.schur_mfma) {
-        if (D.n_pair_tiles == 1)
-          GFS_LAUNCH("k_lba_schur_mfma", k_lba_schur_mfma<true>, dim3(D.n_schur_chunks), dim3(kMk), schur_mfma_lds_bytes(D), s, D);
-        else
-          GFS_LAUNCH("k_lba_schur_mfma", k_lba_schur_mfma<false>, dim3(D.n_schur_chunks * D.n_pair_tiles), dim3(kMk), schur_mfma_lds_bytes(D), s, D);
-        GFS_LAUNCH("k_lba_schur_reduce", k_lba_schur_reduce_mfma, dim3(gfs::div_up(n * (n + 1) / 2 + n, kMk)), dim3(kMk), 0, s, D);
-      } else if (npairs > 0 && D.schur_sub) {
-        GFS_LAUNCH("k_lba_schur_chunks", k_lba_schur_chunks, dim3(D.n_schur_chunks * D.n_pair_tiles), dim3(kMk), schur_lds_bytes(D), s, D);
-        GFS_LAUNCH("k_lba_schur_reduce", k_lba_schur_reduce, dim3(gfs::div_up(n * (n + 1) / 2 + n, kMk)), dim3(kMk), 0, s, D);
-      } else if (npairs > 0) {
-        GFS_LAUNCH("k_lba_schur", k_lba_schur, dim3(npairs), dim3(kMk), 0, s, D);
-      }
-      if (in_lds)
-        GFS_LAUNCH("k_lba_solve", k_lba_solve<true>, dim3(1), dim3(kThreads), lds, s, D);
+  // ---- the LM loop.  Round 6: the host runs ONE ITERATION AHEAD of what it knows.  Behind the decide kernel of iteration k's trial it
+  // queues the whole of iteration k + 1 -- build group and first trial -- GATED on the device by what that kernel decides
+  // (LbaState::spec_ok: trial accepted, loop goes on; every kernel of a gated launch leaves at once otherwise), and only then waits
+  // for decide k's flags (an event behind it, the flags in host-mapped memory).  An accepted trial -- the rule -- finds the GPU already
+  // at work on the next iteration while the host wakes up and queues the one after: the ~24 us round trip and the ~40 us of launch
+  // calls per iteration are off the critical path.  A rejected trial costs the launches of one gated iteration (~35 us) and is retried
+  // ungated.  Same kernels in the same order per executed trial: bit-identical results.  The caller's stop flag is looked at where
+  // g2o looks (top of an iteration, end of a rejected trial); if it is up when an iteration is already running ahead, that iteration
+  // is DISCARDED: its trial wrote only the other estimate buffer, the scalar state decide k left is put back from its snapshot
+  // (k_lba_restore) and the errors are evaluated again at that estimate -- what the loop without the look-ahead would have left.
+  // GFS_LBA_SPECULATE=0: that loop (every launch once the flags are known).
+  static const bool speculate = !(getenv("GFS_LBA_SPECULATE") && atoi(getenv("GFS_LBA_SPECULATE")) == 0);
+  auto build_group = [&](int iteration, int gate) -> int {
+    GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0, gate);
+    if (D.n_lm_wg > 0) GFS_LAUNCH("k_lba_build_landmarks", k_lba_build_landmarks, g_lm, dim3(kMk), 0, s, D, gate);
+    if (P.n_free > 0) GFS_LAUNCH("k_lba_build_poses", k_lba_build_poses, dim3(P.n_free), dim3(kPoseWg), 0, s, D, gate);
+    GFS_LAUNCH("k_lba_begin", k_lba_begin, dim3(1), dim3(kThreads), 0, s, D, iteration, gate);
+    return GFS_OK;
+  };
+  int n_decides = 0;  // decide kernels queued so far: number i writes slot i & 1 of h_flags and is followed by event i & 1
+  auto trial_group = [&](int gate) -> int {
+    GFS_LAUNCH("k_lba_dinv", k_lba_dinv, g_upd, dim3(kMk), 0, s, D, gate);
+    if (npairs > 0 && D.schur_mfma) {
+      if (D.n_pair_tiles == 1)
+        GFS_LAUNCH("k_lba_schur_mfma", k_lba_schur_mfma<true>, dim3(D.n_schur_chunks), dim3(kMk), schur_mfma_lds_bytes(D), s, D, gate);
       else
-        GFS_LAUNCH("k_lba_solve", k_lba_solve<false>, dim3(1), dim3(kThreads), lds, s, D);
-      GFS_LAUNCH("k_lba_update", k_lba_update, g_upd, dim3(kMk), 0, s, D);
-      GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 1);
-      GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 0, d_flags);
-      GFS_HIP(hipStreamSynchronize(s));
-      const bool again = h->h_flags[0] != 0;
-      terminate = h->h_flags[1] != 0;
-      if (!again) break;
-      if (stop && *stop) {  // the stop flag ends the trial loop: close the iteration's bookkeeping on the device
-        GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 1, d_flags);
+        GFS_LAUNCH("k_lba_schur_mfma", k_lba_schur_mfma<false>, dim3(D.n_schur_chunks * D.n_pair_tiles), dim3(kMk), schur_mfma_lds_bytes(D), s, D, gate);
+      GFS_LAUNCH("k_lba_schur_reduce", k_lba_schur_reduce_mfma, dim3(gfs::div_up(n * (n + 1) / 2 + n, kMk)), dim3(kMk), 0, s, D, gate);
+    } else if (npairs > 0 && D.schur_sub) {
+      GFS_LAUNCH("k_lba_schur_chunks", k_lba_schur_chunks, dim3(D.n_schur_chunks * D.n_pair_tiles), dim3(kMk), schur_lds_bytes(D), s, D, gate);
+      GFS_LAUNCH("k_lba_schur_reduce", k_lba_schur_reduce, dim3(gfs::div_up(n * (n + 1) / 2 + n, kMk)), dim3(kMk), 0, s, D, gate);
+    } else if (npairs > 0) {
+      GFS_LAUNCH("k_lba_schur", k_lba_schur, dim3(npairs), dim3(kMk), 0, s, D, gate);
+    }
+    if (in_lds)
+      GFS_LAUNCH("k_lba_solve", k_lba_solve<true>, dim3(1), dim3(kThreads), lds, s, D, gate);
+    else
+      GFS_LAUNCH("k_lba_solve", k_lba_solve<false>, dim3(1), dim3(kThreads), lds, s, D, gate);
+    GFS_LAUNCH("k_lba_update", k_lba_update, g_upd, dim3(kMk), 0, s, D, gate);
+    GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 1, gate);
+    GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 0, d_flags + kFlagInts * (n_decides & 1), gate);
+    GFS_HIP(hipEventRecord(h->ev_decide[n_decides & 1], s));
+    n_decides++;
+    return GFS_OK;
+  };
+  auto flags_of = [&](int i) { return h->h_flags + kFlagInts * (i & 1); };
+  if (!speculate) {
+    for (int iteration = 0; iteration < p->iterations; iteration++) {
+      if (stop && *stop) break;  // SparseOptimizer::terminate() at the top of the iteration
+      if ((rc = build_group(iteration, 0))) return rc;
+      bool terminate = false;
+      for (;;) {
+        if ((rc = trial_group(0))) return rc;
         GFS_HIP(hipStreamSynchronize(s));
-        terminate = h->h_flags[1] != 0;
+        const int* f = flags_of(n_decides - 1);
+        const bool again = f[0] != 0;
+        terminate = f[1] != 0;
+        if (!again) break;
+        if (stop && *stop) {  // the stop flag ends the trial loop: close the iteration's bookkeeping on the device
+          GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 1, d_flags + kFlagInts * (n_decides & 1), 0);
+          n_decides++;
+          GFS_HIP(hipStreamSynchronize(s));
+          terminate = flags_of(n_decides - 1)[1] != 0;
+          break;
+        }
+      }
+      if (terminate) break;
+    }
+  } else if (!(stop && *stop)) {
+    int iteration = 0;
+    if ((rc = build_group(0, 0)) || (rc = trial_group(0))) return rc;
+    int waiting = n_decides - 1;  // the decide whose verdict the host waits for next
+    for (;;) {
+      const bool ahead = iteration + 1 < p->iterations;
+      if (ahead && ((rc = build_group(iteration + 1, 1)) || (rc = trial_group(1)))) return rc;  // gated on decide `waiting`
+      GFS_HIP(hipEventSynchronize(h->ev_decide[waiting & 1]));
+      const int* f = flags_of(waiting);
+      const bool again = f[0] != 0, terminate = f[1] != 0;
+      if (again) {  // rejected: what was queued ahead has left (or is leaving) untouched
+        if (stop && *stop) {
+          GFS_LAUNCH("k_lba_decide", k_lba_decide, dim3(1), dim3(64), 0, s, D, 1, d_flags + kFlagInts * (n_decides & 1), 0);
+          n_decides++;
+          break;
+        }
+        if ((rc = trial_group(0))) return rc;
+        waiting = n_decides - 1;
+        continue;
+      }
+      if (terminate || !ahead) break;
+      iteration++;  // accepted, the loop goes on: iteration `iteration` is already running (decide waiting + 1)
+      if (stop && *stop) {  // ... but g2o would not have started it: put decide `waiting`'s state back
+        const int cur = f[2], iters = f[3];
+        const double* snap = reinterpret_cast<const double*>(f + 4);
+        const double lambda = snap[0], last_chi = snap[1];
+        GFS_HIP(hipStreamSynchronize(s));  // (the iteration running ahead: let it finish, nothing reads the snapshot slot meanwhile)
+        GFS_LAUNCH("k_lba_restore", k_lba_restore, dim3(1), dim3(64), 0, s, D, cur, iters, lambda, last_chi);
+        GFS_LAUNCH("k_lba_errors", k_lba_errors, g_err, dim3(kMk), 0, s, D, 0, 0);
         break;
       }
+      waiting = waiting + 1;
     }
-    if (terminate) break;
   }
   GFS_LAUNCH("k_lba_finish", k_lba_finish, dim3(1), dim3(64), 0, s, D);
   if (timing) {
@@ -2147,7 +2269,8 @@ int gfs_lba_create(int device, int max_poses, int max_points, int max_edges, gfs
   GFS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   if (int rc0 = lba_raise_lds_limits(device)) return rc0;
   GFS_HIP(hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped));
-  GFS_HIP(hipHostMalloc((void**)&h->h_flags, 4 * sizeof(int), hipHostMallocMapped));
+  GFS_HIP(hipHostMalloc((void**)&h->h_flags, 2 * kFlagInts * sizeof(int), hipHostMallocMapped));
+  for (int k = 0; k < 2; k++) GFS_HIP(hipEventCreateWithFlags(&h->ev_decide[k], hipEventDisableTiming));
   const size_t NP = max_points, E = max_edges, NQ = max_poses, F = max_poses;
   int rc = 0;
 #define A(x) if (!rc) rc = (x)
@@ -2193,6 +2316,8 @@ void gfs_lba_destroy(gfs_lba* h) {
   (void)hipStreamDestroy(h->stream);
   if (h->h_stop) (void)hipHostFree(h->h_stop);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
+  for (int k = 0; k < 2; k++)
+    if (h->ev_decide[k]) (void)hipEventDestroy(h->ev_decide[k]);
   delete h;
 }
 

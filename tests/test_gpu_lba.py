@@ -96,6 +96,49 @@ def test_stop_flag_raised_while_solving(gpu_api, oracle):
         assert r["final_chi2"] <= chi0 * (1 + 1e-12)
 
 
+def test_stopped_solve_is_exactly_the_state_after_its_last_iteration(gpu_api):
+    """gfs_lba_solve's host loop runs one LM iteration ahead of the flags it has read (round 6).  When the caller's stop flag goes up while
+    an iteration is running ahead, that iteration is discarded: the result must be, bit for bit, what optimize(k) leaves for the k
+    iterations the stopped call reports -- estimates, per-edge chi2, final chi2, lambda.  The flag is raised at a sweep of delays so that
+    it lands in different iterations (and some calls see it only after they are done)."""
+    import threading
+    import time
+    w = synth.lba_window(0, n_free=20, n_fixed=5, n_points=3000)
+    opt = gpu_api.Optimizer()
+    full = opt.LocalBundleAdjustment(w)
+    by_iterations = {}
+    seen = set()
+    for delay_us in (400, 600, 800, 1000, 1200, 1400, 1600, 1800, 2000, 2300, 700, 1100, 1500, 1900):
+        flag = np.zeros(1, np.int32)
+
+        def raiser():
+            time.sleep(delay_us * 1e-6)
+            flag[0] = 1
+
+        t = threading.Thread(target=raiser)
+        t.start()
+        r = opt.LocalBundleAdjustment(w, stop_flag=flag)
+        t.join()
+        assert r is not None
+        k = r["iterations_run"]
+        seen.add(k)
+        if k not in by_iterations:
+            wk = dict(w)
+            wk["iterations"] = k
+            by_iterations[k] = opt.LocalBundleAdjustment(wk)  # no flag: the loop runs ahead, nothing is discarded
+        ref = by_iterations[k]
+        if k == full["iterations_run"] and ref["iterations_run"] != k:
+            continue  # (the full run ended by its own termination rule before `iterations`)
+        if k == 0:  # the flag was up before the first iteration: nothing was evaluated (g2o computes no errors either), the estimates stand
+            assert np.array_equal(r["points"], ref["points"]) and np.array_equal(r["pose_t"], ref["pose_t"]), delay_us
+            continue
+        for key in ("points", "pose_t", "pose_q", "edge_chi2"):
+            assert np.array_equal(r[key], ref[key]), (delay_us, k, key)
+        assert r["final_chi2"] == ref["final_chi2"] and r["final_lambda"] == ref["final_lambda"] and r["iterations_run"] == ref["iterations_run"], (delay_us, k)
+    # (every stop with 0 < k < the full count went through the discard: the next iteration is always running ahead when the flags are read)
+    assert any(0 < k < full["iterations_run"] for k in seen), seen
+
+
 def test_stop_flag_raised_while_a_batch_is_solving(gpu_api, oracle):
     """the same for gfs_lba_solve_batch: every window closes its running iteration and returns what it has"""
     import threading
