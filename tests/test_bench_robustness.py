@@ -191,3 +191,17 @@ def test_every_side_leg_of_bench_is_guarded():
             check(st.body)
         else:
             raise AssertionError(f"unexpected top-level statement after the headline at bench.py:{st.lineno}")
+
+
+def test_live_traffic_leg_never_raises_without_a_gpu():
+    """bench.py's last side leg measures roofline.traffic with two child runs under rocprofv3 --pmc.  Here (no GPU) the children leave
+    at their device check: the leg must come back with traffic = None and the reason, inside its time limit, and raise nothing."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t0 = time.time()
+    out = bench.measure_traffic_live("k_gicp_linearize", 16, 2, 240.0, 1000.0)
+    assert isinstance(out, dict) and out.get("traffic") is None and out.get("note"), out
+    assert time.time() - t0 < 200
