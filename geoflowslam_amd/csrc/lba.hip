@@ -982,7 +982,13 @@ __global__ __launch_bounds__(kMk) void k_lba_schur_chunks(LbaDev D, int gate) {
 // (landmark-major order), so the staging threads read e_pose / e_point / Hpl of edge e0 + tid directly, one sub-batch ahead of the
 // products.  Per-chunk partial blocks go to HBM ([chunk][row][col], leading dimension 128 NB) and b_schur_reduce adds them in
 // chunk order.  Operands are products of single roundings (fused multiply-add inside the matrix core), like b_schur_chunks.
-constexpr int kSchurMPts = 128;  // landmarks per workgroup
+// (round 6: 64 landmarks a workgroup instead of 128 -- a configs[4] window of 3 000 landmarks is 47 workgroups instead of 24 on the 256 CUs,
+//  one window 2.13 - 2.16 -> 2.00 ms; 32: 2.02 ms; the batched path, whose launches fill the chip either way, is unchanged.  The partial
+//  blocks are added in chunk order by the reduce kernel: the chunk size is part of the arithmetic, the same for one window and a batch)
+#ifndef GFS_SCHUR_MPTS
+#define GFS_SCHUR_MPTS 64
+#endif
+constexpr int kSchurMPts = GFS_SCHUR_MPTS;  // landmarks per workgroup
 constexpr int kSchurSub = 8;     // landmarks staged at a time
 constexpr int kSchurLd = 144;    // row stride (doubles) of a staged column
 typedef double d4_t __attribute__((ext_vector_type(4)));
