@@ -202,6 +202,6 @@ def test_live_traffic_leg_never_raises_without_a_gpu():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     t0 = time.time()
-    out = bench.measure_traffic_live("k_gicp_linearize", 16, 2, 240.0, 1000.0)
+    out = bench.measure_traffic_live("k_gicp_linearize", 2, 1, 240.0, 1000.0)
     assert isinstance(out, dict) and out.get("traffic") is None and out.get("note"), out
     assert time.time() - t0 < 200
